@@ -1,0 +1,210 @@
+"""ctypes binding of the C ABI in include/flm_gpu.h (test and bench plumbing; not the product).
+
+The product library is fast-llama_amd/lib/libflm_gpu.so (hand-written HIP, built by
+__graft_entry__.build()).  There is NO CPU fallback: if the library is missing or a call fails,
+FlmError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libflm_gpu.so")
+
+QT_NONE, QT_INT16, QT_INT8 = 0, 1, 2
+KCLASSES = ("embed", "qkv", "attn", "attn_o", "ffn13", "ffn2", "cls", "argmax", "allreduce")
+
+# every symbol include/flm_gpu.h declares (tests check the library exports all of them)
+SYMBOLS = (
+    "flm_comm_unique_id", "flm_ctx_create", "flm_ctx_destroy", "flm_last_error", "flm_upload_tensor",
+    "flm_forward", "flm_forward_argmax", "flm_decode_greedy", "flm_decode_timed", "flm_reset_kv", "flm_sync",
+    "flm_kernel_times", "flm_kernel_bytes", "flm_set_option",
+    "flm_op_quantize", "flm_op_matmul_q", "flm_op_rmsnorm", "flm_op_swiglu", "flm_op_rope", "flm_op_softmax",
+    "flm_op_attention", "flm_plan_shards",
+)
+
+
+class FlmError(RuntimeError):
+    pass
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dim", "hidden_dim", "n_layers", "n_heads", "n_kv_heads", "vocab_size",
+                                          "max_seq_len", "quant_type", "quant_group_size")]
+
+
+class ShardPlan(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("head_begin", "head_count", "hidden_begin", "hidden_count", "vocab_begin", "vocab_count")]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FlmError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
+        _lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        _lib.flm_last_error.restype = C.c_char_p
+        _lib.flm_last_error.argtypes = [C.c_void_p]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _check(rc, ctx=None):
+    if rc != 0:
+        msg = lib().flm_last_error(ctx)
+        raise FlmError(f"flm error {rc}: {msg.decode() if msg else ''}")
+
+
+def desc_from_config(cfg, max_seq_len=1024) -> ModelDesc:
+    return ModelDesc(cfg.dim, cfg.hidden_dim, cfg.n_layers, cfg.n_heads, cfg.n_kv_heads, cfg.vocab_size,
+                     max_seq_len, cfg.quant_type, cfg.quant_group_size)
+
+
+def plan_shards(desc: ModelDesc, rank: int, world: int) -> ShardPlan:
+    out = ShardPlan()
+    _check(lib().flm_plan_shards(C.byref(desc), rank, world, C.byref(out)))
+    return out
+
+
+def comm_unique_id() -> bytes:
+    buf = C.create_string_buffer(128)
+    _check(lib().flm_comm_unique_id(buf))
+    return buf.raw
+
+
+class Ctx:
+    """flm_ctx wrapper.  tensors: {(kind, layer): fp32 ndarray | (q, scales)} as produced by synth/flmfile."""
+
+    def __init__(self, desc: ModelDesc, device=0, rank=0, world=1, comm_id: bytes | None = None):
+        self.desc = desc
+        self._h = C.c_void_p()
+        _check(lib().flm_ctx_create(C.byref(desc), device, rank, world, comm_id, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().flm_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, kind, layer, value):
+        if isinstance(value, tuple):
+            q, s = value
+            q = np.ascontiguousarray(q); s = np.ascontiguousarray(s, dtype=np.float32)
+            qt = QT_INT8 if q.dtype == np.int8 else QT_INT16
+            _check(lib().flm_upload_tensor(self._h, kind, layer, qt, _p(q), _p(s), q.shape[0], q.shape[1]), self._h)
+        else:
+            v = np.ascontiguousarray(value, dtype=np.float32)
+            rows, cols = v.shape if v.ndim == 2 else (1, v.shape[0])
+            _check(lib().flm_upload_tensor(self._h, kind, layer, QT_NONE, _p(v), None, rows, cols), self._h)
+
+    def upload_all(self, tensors):
+        for (kind, layer), v in tensors.items():
+            self.upload(kind, layer, v)
+
+    def forward(self, tokens, pos) -> np.ndarray:
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        out = np.empty(self.desc.vocab_size, dtype=np.float32)
+        _check(lib().flm_forward(self._h, _p(t), len(t), int(pos), _p(out)), self._h)
+        return out
+
+    def forward_argmax(self, tokens, pos) -> int:
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        nxt = C.c_int32(-1)
+        _check(lib().flm_forward_argmax(self._h, _p(t), len(t), int(pos), C.byref(nxt)), self._h)
+        return nxt.value
+
+    def decode_greedy(self, first_token, pos, n_steps) -> np.ndarray:
+        out = np.empty(n_steps, dtype=np.int32)
+        _check(lib().flm_decode_greedy(self._h, int(first_token), int(pos), int(n_steps), _p(out)), self._h)
+        return out
+
+    def decode_timed(self, first_token, pos, n_steps) -> float:
+        ms = C.c_float(0)
+        _check(lib().flm_decode_timed(self._h, int(first_token), int(pos), int(n_steps), C.byref(ms)), self._h)
+        return ms.value
+
+    def reset_kv(self):
+        _check(lib().flm_reset_kv(self._h), self._h)
+
+    def sync(self):
+        _check(lib().flm_sync(self._h), self._h)
+
+    def set_option(self, key, value):
+        _check(lib().flm_set_option(self._h, key.encode(), int(value)), self._h)
+
+    def kernel_times(self, pos, iters=3):
+        avg = np.zeros(len(KCLASSES), dtype=np.float32); cnt = np.zeros(len(KCLASSES), dtype=np.int32)
+        _check(lib().flm_kernel_times(self._h, int(pos), int(iters), _p(avg), _p(cnt)), self._h)
+        return {k: (float(avg[i]), int(cnt[i])) for i, k in enumerate(KCLASSES)}
+
+    def kernel_bytes(self, kclass, pos) -> float:
+        b = C.c_double(0)
+        _check(lib().flm_kernel_bytes(self._h, KCLASSES.index(kclass), int(pos), C.byref(b)), self._h)
+        return b.value
+
+
+# ---- op level ---------------------------------------------------------------------------------
+def op_quantize(x, qt, gs=64):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    q = np.empty(x.size, dtype=np.int8 if qt == QT_INT8 else np.int16)
+    s = np.empty(x.size // gs, dtype=np.float32)
+    _check(lib().flm_op_quantize(qt, _p(q), _p(s), _p(x), C.c_size_t(x.size), gs))
+    return q, s
+
+
+def op_matmul_q(qt, W, sW, X, sX, gs=64):
+    W = np.ascontiguousarray(W); X = np.ascontiguousarray(X)
+    sW = np.ascontiguousarray(sW, dtype=np.float32); sX = np.ascontiguousarray(sX, dtype=np.float32)
+    m, n = W.shape; w = X.shape[0]
+    out = np.empty((w, m), dtype=np.float32)
+    _check(lib().flm_op_matmul_q(qt, _p(out), _p(W), _p(sW), _p(X), _p(sX), m, n, w, gs))
+    return out
+
+
+def op_rmsnorm(x, w):
+    x = np.ascontiguousarray(x, dtype=np.float32); w = np.ascontiguousarray(w, dtype=np.float32)
+    o = np.empty_like(x)
+    _check(lib().flm_op_rmsnorm(_p(o), _p(x), _p(w), C.c_size_t(x.size)))
+    return o
+
+
+def op_swiglu(xo, xr):
+    a = np.array(xo, dtype=np.float32, copy=True); b = np.ascontiguousarray(xr, dtype=np.float32)
+    _check(lib().flm_op_swiglu(_p(a), _p(b), C.c_size_t(a.size)))
+    return a
+
+
+def op_rope(x, pos):
+    x = np.ascontiguousarray(x, dtype=np.float32); o = np.empty_like(x)
+    _check(lib().flm_op_rope(_p(o), _p(x), x.size, int(pos)))
+    return o
+
+
+def op_softmax(x, n=None):
+    a = np.array(x, dtype=np.float32, copy=True)
+    _check(lib().flm_op_softmax(_p(a), int(a.size if n is None else n)))
+    return a
+
+
+def op_attention(kc, vc, q, k, v, n_heads, hs, max_seq, pos, n_splits=0):
+    """kc, vc [n_heads, max_seq, hs] are updated in place; returns out [n_heads*hs]."""
+    out = np.empty(n_heads * hs, dtype=np.float32)
+    for a in (kc, vc):
+        assert a.dtype == np.float32 and a.flags.c_contiguous
+    q = np.ascontiguousarray(q, dtype=np.float32); k = np.ascontiguousarray(k, dtype=np.float32); v = np.ascontiguousarray(v, dtype=np.float32)
+    _check(lib().flm_op_attention(_p(out), _p(kc), _p(vc), _p(q), _p(k), _p(v), n_heads, hs, max_seq, int(pos), int(n_splits)))
+    return out

@@ -1,0 +1,821 @@
+// flm_gpu.hip -- device context, weight upload, per-token forward and the C ABI (include/flm_gpu.h).
+//
+// Host-side orchestration of the kernels in flm_kernels.h.  What the reference does with 161
+// fork-joins over pinned CPU threads per token (src/transformer/transformer.cpp:105-161)
+// is here one stream of 5*L+3 kernel launches whose position/token operands live in device memory, so
+// the whole token can be replayed from a hipGraph with no host round trip.
+#include "flm_gpu.h"
+#include "flm_kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace flm;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct QMat { void* q = nullptr; float* s = nullptr; int rows = 0, cols = 0; };
+struct LayerW {
+    QMat qkv, o, w1, w3, w2;
+    float* att_norm = nullptr; float* ffn_norm = nullptr;
+    unsigned got = 0;     // bitmask of uploaded kinds
+};
+
+enum KClass { KC_EMBED = 0, KC_QKV, KC_ATTN, KC_ATTN_O, KC_FFN13, KC_FFN2, KC_CLS, KC_ARGMAX, KC_ALLREDUCE };
+
+struct TimedLaunch { int kclass; hipEvent_t e0, e1; };
+
+} // namespace
+
+struct flm_ctx {
+    flm_model_desc d{};
+    int device = 0, rank = 0, world = 1;
+    flm_shard_plan plan{};
+    int hs = 0, esz = 1, cu_count = 256;
+    int dim_local = 0, hidden_local = 0, heads_local = 0, vocab_slot = 0;
+    hipStream_t stream = nullptr;
+    ncclComm_t comm = nullptr;
+
+    std::vector<LayerW> layers;
+    void* emb = nullptr; float* emb_s = nullptr; int emb_qt = 0; bool got_emb = false;
+    float* out_norm = nullptr; bool got_out_norm = false;
+    QMat cls; bool got_cls = false;
+
+    float *kcache = nullptr, *vcache = nullptr;       // [L][heads_local][max_seq][hs]
+    float *x1 = nullptr, *qbuf = nullptr, *att_out = nullptr, *att_part = nullptr, *hd = nullptr;
+    float *partial = nullptr, *logits = nullptr;
+    float *rope_cos = nullptr, *rope_sin = nullptr;
+    DecodeState* state = nullptr; int* prompt_dev = nullptr; int* out_tokens_dev = nullptr;
+    int prompt_cap = 0, out_cap = 0;
+
+    // options
+    int wg_per_cu = 2; int use_graph = 1; int attn_splits = 0; int attn_wg = 0;
+    std::map<int, hipGraphExec_t> graphs;             // key = splits*4 + with_cls*2 + advance
+    std::vector<TimedLaunch>* timing = nullptr;
+    std::string err;
+};
+
+namespace {
+
+#define HIPC(ctx, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    char b_[512]; snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    if (ctx) (ctx)->err = b_; g_last_error = b_; return FLM_ERR_HIP; } } while (0)
+#define NCCLC(ctx, expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) { \
+    char b_[512]; snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__, __LINE__); \
+    if (ctx) (ctx)->err = b_; g_last_error = b_; return FLM_ERR_COMM; } } while (0)
+
+int fail(flm_ctx* c, int code, const char* msg) { if (c) c->err = msg; g_last_error = msg; return code; }
+
+int esz_of(int qt) { return qt == FLM_QT_INT8 ? 1 : qt == FLM_QT_INT16 ? 2 : 4; }
+
+// balanced contiguous split (split_rows, transformer.cpp:264-287)
+void split_even(int total, int parts, int idx, int* begin, int* count) {
+    const int itv = total / parts, rem = total % parts;
+    if (idx < rem) { *begin = (itv + 1) * idx; *count = itv + 1; }
+    else { *begin = (itv + 1) * rem + itv * (idx - rem); *count = itv; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GEMV dispatch
+// ---------------------------------------------------------------------------------------------
+template <int QT, int PRO, int EPI>
+int launch_gemv_xr(flm_ctx* c, hipStream_t st, const GemvArgs& a, int grid) {
+    const size_t lds = gemv_lds_bytes(a.n, QTraits<QT>::kEsz);
+    const int rounds = (a.n + kBlock * 4 - 1) / (kBlock * 4);
+    if (PRO == PRO_NONE || PRO == PRO_ATTN_COMBINE_QUANT) hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 0>), dim3(grid), dim3(kBlock), lds, st, a);
+    else if (rounds <= 4)  hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 4>),  dim3(grid), dim3(kBlock), lds, st, a);
+    else if (rounds <= 12) hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 12>), dim3(grid), dim3(kBlock), lds, st, a);
+    else                   hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 0>),  dim3(grid), dim3(kBlock), lds, st, a);
+    HIPC(c, hipGetLastError());
+    return FLM_OK;
+}
+template <int PRO, int EPI>
+int launch_gemv(flm_ctx* c, hipStream_t st, int qt, const GemvArgs& a, int grid) {
+    if (a.n % kGroup != 0 || a.n <= 0) return fail(c, FLM_ERR_INVALID, "gemv: n must be a positive multiple of 64");
+    if (gemv_lds_bytes(a.n, esz_of(qt)) > 160 * 1024) return fail(c, FLM_ERR_UNSUPPORTED, "gemv: activation vector does not fit LDS");
+    if (qt == FLM_QT_INT8)  return launch_gemv_xr<QT_INT8, PRO, EPI>(c, st, a, grid);
+    if (qt == FLM_QT_INT16) return launch_gemv_xr<QT_INT16, PRO, EPI>(c, st, a, grid);
+    return fail(c, FLM_ERR_UNSUPPORTED, "gemv: quant type must be INT8 or INT16");
+}
+// grid: wg_per_cu workgroups per CU, but never more waves than batches of work
+int gemv_grid(int cu_count, int wg_per_cu, int items, int rows_per_item) {
+    const int ipb = kRows / rows_per_item;
+    const int batches = (items + ipb - 1) / ipb;
+    int wgs = cu_count * wg_per_cu;
+    const int need = (batches + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (wgs > need) wgs = need;
+    return wgs < 1 ? 1 : wgs;
+}
+
+// quantize a flat fp32 array on the device with the fused path's quantizer (A13, load time):
+// one 16-lane group per 64-element group.
+template <int QT>
+__global__ void k_quantize_flat(void* q, float* s, const float* x, size_t n) {
+    using T = QTraits<QT>;
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+    const size_t nr = (n + stride - 1) / stride;
+    for (size_t it = 0; it < nr; ++it) {
+        const size_t e = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4 + it * stride;
+        const bool act = e < n;
+        float4 v = act ? *reinterpret_cast<const float4*>(x + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, kWave));
+        const float sc = __fdiv_rn(mx, T::kF);
+        if (act) {
+            const int q0 = quant_elem(v.x, sc), q1 = quant_elem(v.y, sc), q2 = quant_elem(v.z, sc), q3 = quant_elem(v.w, sc);
+            if constexpr (QT == QT_INT8) {
+                reinterpret_cast<uint32_t*>(q)[e / 4] = (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
+            } else {
+                uint2 pk; pk.x = (uint32_t)(q0 & 0xffff) | ((uint32_t)(q1 & 0xffff) << 16); pk.y = (uint32_t)(q2 & 0xffff) | ((uint32_t)(q3 & 0xffff) << 16);
+                reinterpret_cast<uint2*>(q)[e / 4] = pk;
+            }
+            if ((threadIdx.x & 15) == 0) s[e / kGroup] = sc;
+        }
+    }
+}
+int quantize_flat(flm_ctx* c, hipStream_t st, int qt, void* q, float* s, const float* x, size_t n) {
+    if (n % kGroup) return fail(c, FLM_ERR_INVALID, "quantize: n must be a multiple of 64");
+    size_t blocks = (n / 4 + kBlock - 1) / kBlock; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    if (qt == FLM_QT_INT8) hipLaunchKernelGGL(k_quantize_flat<QT_INT8>, dim3((unsigned)blocks), dim3(kBlock), 0, st, q, s, x, n);
+    else if (qt == FLM_QT_INT16) hipLaunchKernelGGL(k_quantize_flat<QT_INT16>, dim3((unsigned)blocks), dim3(kBlock), 0, st, q, s, x, n);
+    else return fail(c, FLM_ERR_UNSUPPORTED, "quantize: type");
+    HIPC(c, hipGetLastError());
+    return FLM_OK;
+}
+
+// RoPE table with the reference's fp32 recurrence (rope_v2, src/blas/tf_operators.cpp:362-396):
+// theta_0 = pos, theta_{i+1} = theta_i * powf(10000, -2/hs); cosf/sinf from the host libm, the same
+// library the reference calls, so the table is bit-identical to what rope_v2 computes per call.
+void build_rope_table(int hs, int max_seq, std::vector<float>& cs, std::vector<float>& sn) {
+    cs.resize((size_t)max_seq * (hs / 2)); sn.resize(cs.size());
+    const float theta_scale = powf(10000.0f, -2.0f / hs);
+    for (int p = 0; p < max_seq; ++p) {
+        float theta = (float)p;
+        for (int i = 0; i < hs / 2; ++i) {
+            cs[(size_t)p * (hs / 2) + i] = cosf(theta);
+            sn[(size_t)p * (hs / 2) + i] = sinf(theta);
+            theta *= theta_scale;
+        }
+    }
+}
+
+int alloc_qmat(flm_ctx* c, QMat& m, int rows, int cols, int qt) {
+    m.rows = rows; m.cols = cols;
+    HIPC(c, hipMalloc(&m.q, (size_t)rows * cols * esz_of(qt)));
+    HIPC(c, hipMalloc((void**)&m.s, (size_t)rows * (cols / kGroup) * sizeof(float)));
+    return FLM_OK;
+}
+
+// copy a (row range x column range) window of a host matrix into a device QMat at dst_row0.
+// fp32 sources are staged and quantized on the device (A13).
+int upload_window(flm_ctx* c, QMat& m, int dst_row0, int src_qt, const void* values, const float* scales,
+                  int src_cols, int row0, int nrows, int col0, int ncols) {
+    const int qt = c->d.quant_type, gs = kGroup;
+    if (ncols != m.cols) return fail(c, FLM_ERR_INVALID, "upload: column window does not match the device matrix");
+    if (src_qt == FLM_QT_NONE) {
+        float* stage = nullptr;
+        HIPC(c, hipMalloc((void**)&stage, (size_t)nrows * ncols * sizeof(float)));
+        HIPC(c, hipMemcpy2DAsync(stage, (size_t)ncols * 4, (const float*)values + (size_t)row0 * src_cols + col0, (size_t)src_cols * 4,
+                                 (size_t)ncols * 4, nrows, hipMemcpyHostToDevice, c->stream));
+        int r = quantize_flat(c, c->stream, qt, (char*)m.q + (size_t)dst_row0 * ncols * c->esz, m.s + (size_t)dst_row0 * (ncols / gs), stage, (size_t)nrows * ncols);
+        if (r) { hipFree(stage); return r; }
+        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, hipFree(stage));
+        return FLM_OK;
+    }
+    if (src_qt != qt) return fail(c, FLM_ERR_INVALID, "upload: tensor quant type differs from the model's");
+    const int e = c->esz;
+    HIPC(c, hipMemcpy2DAsync((char*)m.q + (size_t)dst_row0 * ncols * e, (size_t)ncols * e,
+                             (const char*)values + ((size_t)row0 * src_cols + col0) * e, (size_t)src_cols * e,
+                             (size_t)ncols * e, nrows, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemcpy2DAsync(m.s + (size_t)dst_row0 * (ncols / gs), (size_t)(ncols / gs) * 4,
+                             scales + (size_t)row0 * (src_cols / gs) + col0 / gs, (size_t)(src_cols / gs) * 4,
+                             (size_t)(ncols / gs) * 4, nrows, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return FLM_OK;
+}
+
+bool model_complete(const flm_ctx* c) {
+    if (!c->got_emb || !c->got_out_norm || !c->got_cls) return false;
+    const unsigned need = (1u << 0) | (1u << 1) | (1u << 2) | (1u << 3) | (1u << 4) | (1u << 5) | (1u << 6) | (1u << 7) | (1u << 8);
+    for (auto& l : c->layers) if ((l.got & need) != need) return false;
+    return true;
+}
+
+int attn_splits_for(const flm_ctx* c, int pos) {
+    if (c->attn_splits > 0) return c->attn_splits;
+    // keep >= ~32 positions per workgroup, at most 8 splits (heads*splits workgroups fill the chip)
+    const int T = pos + 1;
+    int s = 1;
+    while (s < 8 && T / (s * 2) >= 32) s *= 2;
+    return s;
+}
+
+struct Tick {
+    flm_ctx* c; hipStream_t st; int kclass; hipEvent_t e0 = nullptr, e1 = nullptr;
+    Tick(flm_ctx* c_, hipStream_t st_, int k) : c(c_), st(st_), kclass(k) {
+        if (c->timing) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, st); }
+    }
+    ~Tick() { if (c->timing) { hipEventRecord(e1, st); c->timing->push_back({kclass, e0, e1}); } }
+};
+
+// ---------------------------------------------------------------------------------------------
+// One token: ParallelTransformer::forward at bs == 1 (transformer.cpp:105-161).
+// Position and token are read from c->state on the device.
+//   with_cls  : run the final norm + classifier (+ argmax)
+//   advance   : 1 = greedy (tok <- argmax, pos++), 0 = leave state (caller copies logits), 2 = prompt feed
+// ---------------------------------------------------------------------------------------------
+int enqueue_token(flm_ctx* c, hipStream_t st, int n_splits, bool with_cls, int advance) {
+    const auto& d = c->d;
+    const int qt = d.quant_type, hs = c->hs, L = d.n_layers;
+    const bool tp = c->world > 1;
+    const int* pos_ptr = &c->state->pos;
+    {
+        Tick t(c, st, KC_EMBED);
+        hipLaunchKernelGGL(k_embed, dim3((d.dim + 255) / 256), dim3(256), 0, st, c->x1, (const void*)c->emb, (const float*)c->emb_s, c->emb_qt, d.dim, (const int*)&c->state->tok);
+        HIPC(c, hipGetLastError());
+    }
+    const size_t kv_layer = (size_t)c->heads_local * d.max_seq_len * hs;
+    for (int l = 0; l < L; ++l) {
+        LayerW& w = c->layers[l];
+        {   // QKV task + RoPE + KV append (transformer.cpp:132-135, execute_qkv :386-395, execute_attn :431-439)
+            GemvArgs a{};
+            a.W = w.qkv.q; a.sW = w.qkv.s; a.n = d.dim; a.items = w.qkv.rows / 2;
+            a.x = c->x1; a.norm_w = w.att_norm;
+            a.out = c->qbuf; a.kcache = c->kcache + (size_t)l * kv_layer; a.vcache = c->vcache + (size_t)l * kv_layer;
+            a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.pos_ptr = pos_ptr;
+            a.dim = c->dim_local; a.kv_dim = c->dim_local; a.max_seq = d.max_seq_len; a.hs = hs;
+            Tick t(c, st, KC_QKV);
+            int r = launch_gemv<PRO_RMSNORM_QUANT, EPI_ROPE_KV>(c, st, qt, a, gemv_grid(c->cu_count, c->wg_per_cu, a.items, 2));
+            if (r) return r;
+        }
+        {   // ATTN task (execute_attn :441-449)
+            AttnArgs a{};
+            a.q = c->qbuf; a.kcache = c->kcache + (size_t)l * kv_layer; a.vcache = c->vcache + (size_t)l * kv_layer;
+            a.out = n_splits == 1 ? c->att_out : c->att_part; a.pos_ptr = pos_ptr; a.hs = hs; a.max_seq = d.max_seq_len; a.n_splits = n_splits;
+            const int per_max = (d.max_seq_len + n_splits - 1) / n_splits;
+            Tick t(c, st, KC_ATTN);
+            hipLaunchKernelGGL(k_attn_decode, dim3(c->heads_local, n_splits), dim3(kBlock), attn_lds_bytes(per_max, hs), st, a);
+            HIPC(c, hipGetLastError());
+        }
+        {   // ATTN_O task + residual (transformer.cpp:138-139, execute_attn_o :457-466)
+            GemvArgs a{};
+            a.W = w.o.q; a.sW = w.o.s; a.n = c->dim_local; a.items = d.dim;
+            a.x = c->att_out; a.att_part = c->att_part; a.n_splits = n_splits; a.hs = hs;
+            a.out = tp ? c->partial : c->x1;
+            Tick t(c, st, KC_ATTN_O);
+            const int grid = gemv_grid(c->cu_count, c->wg_per_cu, a.items, 1);
+            int r;
+            if (n_splits == 1) r = tp ? launch_gemv<PRO_QUANT, EPI_STORE>(c, st, qt, a, grid) : launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, a, grid);
+            else r = tp ? launch_gemv<PRO_ATTN_COMBINE_QUANT, EPI_STORE>(c, st, qt, a, grid) : launch_gemv<PRO_ATTN_COMBINE_QUANT, EPI_RESIDUAL>(c, st, qt, a, grid);
+            if (r) return r;
+        }
+        if (tp) {
+            Tick t(c, st, KC_ALLREDUCE);
+            NCCLC(c, ncclAllReduce(c->partial, c->partial, d.dim, ncclFloat, ncclSum, c->comm, st));
+            hipLaunchKernelGGL(k_add_inplace, dim3((d.dim + 255) / 256), dim3(256), 0, st, c->x1, (const float*)c->partial, d.dim);
+            HIPC(c, hipGetLastError());
+        }
+        {   // FFN13 task + SwiGLU (transformer.cpp:144-147, execute_ffn13 :468-483)
+            GemvArgs a{};
+            a.W = w.w1.q; a.sW = w.w1.s; a.W2nd = w.w3.q; a.sW2nd = w.w3.s; a.n = d.dim; a.items = c->hidden_local;
+            a.x = c->x1; a.norm_w = w.ffn_norm; a.out = c->hd;
+            Tick t(c, st, KC_FFN13);
+            int r = launch_gemv<PRO_RMSNORM_QUANT, EPI_SWIGLU>(c, st, qt, a, gemv_grid(c->cu_count, c->wg_per_cu, a.items, 2));
+            if (r) return r;
+        }
+        {   // FFN2 task + residual (transformer.cpp:149-150, execute_ffn2 :485-494)
+            GemvArgs a{};
+            a.W = w.w2.q; a.sW = w.w2.s; a.n = c->hidden_local; a.items = d.dim;
+            a.x = c->hd; a.out = tp ? c->partial : c->x1;
+            Tick t(c, st, KC_FFN2);
+            const int grid = gemv_grid(c->cu_count, c->wg_per_cu, a.items, 1);
+            int r = tp ? launch_gemv<PRO_QUANT, EPI_STORE>(c, st, qt, a, grid) : launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, a, grid);
+            if (r) return r;
+        }
+        if (tp) {
+            Tick t(c, st, KC_ALLREDUCE);
+            NCCLC(c, ncclAllReduce(c->partial, c->partial, d.dim, ncclFloat, ncclSum, c->comm, st));
+            hipLaunchKernelGGL(k_add_inplace, dim3((d.dim + 255) / 256), dim3(256), 0, st, c->x1, (const float*)c->partial, d.dim);
+            HIPC(c, hipGetLastError());
+        }
+    }
+    if (with_cls) {
+        {   // final norm + CLS task (transformer.cpp:154-160, execute_cls :496-505)
+            GemvArgs a{};
+            a.W = c->cls.q; a.sW = c->cls.s; a.n = d.dim; a.items = c->cls.rows;
+            a.x = c->x1; a.norm_w = c->out_norm; a.out = c->logits + (tp ? (size_t)c->rank * c->vocab_slot : 0);
+            Tick t(c, st, KC_CLS);
+            int r = launch_gemv<PRO_RMSNORM_QUANT, EPI_STORE>(c, st, qt, a, gemv_grid(c->cu_count, c->wg_per_cu, a.items, 1));
+            if (r) return r;
+        }
+        if (tp) {
+            Tick t(c, st, KC_ALLREDUCE);
+            NCCLC(c, ncclAllGather(c->logits + (size_t)c->rank * c->vocab_slot, c->logits, c->vocab_slot, ncclFloat, c->comm, st));
+        }
+        if (advance != 0) {
+            Tick t(c, st, KC_ARGMAX);
+            hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, st, (const float*)c->logits, d.vocab_size, c->state, c->out_tokens_dev, 1);
+            HIPC(c, hipGetLastError());
+        }
+    } else if (advance == 2) {
+        hipLaunchKernelGGL(k_advance_prompt, dim3(1), dim3(64), 0, st, c->state, (const int*)c->prompt_dev);
+        HIPC(c, hipGetLastError());
+    }
+    return FLM_OK;
+}
+
+// run one token, through a cached hipGraph when enabled
+int run_token(flm_ctx* c, int pos_host, bool with_cls, int advance) {
+    const int S = attn_splits_for(c, pos_host);
+    if (!c->use_graph || c->timing || c->world > 1) return enqueue_token(c, c->stream, S, with_cls, advance);
+    const int key = S * 8 + (with_cls ? 4 : 0) + advance;
+    auto it = c->graphs.find(key);
+    if (it == c->graphs.end()) {
+        hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+        HIPC(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        int r = enqueue_token(c, c->stream, S, with_cls, advance);
+        hipError_t e = hipStreamEndCapture(c->stream, &g);
+        if (r) { if (g) hipGraphDestroy(g); return r; }
+        HIPC(c, e);
+        HIPC(c, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        HIPC(c, hipGraphDestroy(g));
+        it = c->graphs.emplace(key, ge).first;
+    }
+    HIPC(c, hipGraphLaunch(it->second, c->stream));
+    return FLM_OK;
+}
+
+int ensure_token_bufs(flm_ctx* c, int n_prompt, int n_out) {
+    if (n_prompt > c->prompt_cap) {
+        if (c->prompt_dev) hipFree(c->prompt_dev);
+        c->prompt_cap = n_prompt < 1024 ? 1024 : n_prompt;
+        HIPC(c, hipMalloc((void**)&c->prompt_dev, sizeof(int) * c->prompt_cap));
+        for (auto& g : c->graphs) hipGraphExecDestroy(g.second);     // graphs captured the old pointer
+        c->graphs.clear();
+    }
+    if (n_out > c->out_cap) {
+        if (c->out_tokens_dev) hipFree(c->out_tokens_dev);
+        c->out_cap = n_out < 4096 ? 4096 : n_out;
+        HIPC(c, hipMalloc((void**)&c->out_tokens_dev, sizeof(int) * c->out_cap));
+        for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
+        c->graphs.clear();
+    }
+    return FLM_OK;
+}
+
+int check_ready(flm_ctx* c, int n, int pos) {
+    if (!c) return FLM_ERR_INVALID;
+    if (!model_complete(c)) return fail(c, FLM_ERR_STATE, "forward before all tensors were uploaded");
+    if (n < 1 || pos < 0 || pos + n > c->d.max_seq_len) return fail(c, FLM_ERR_INVALID, "tokens/pos outside [0, max_seq_len]");
+    HIPC(c, hipSetDevice(c->device));
+    return FLM_OK;
+}
+
+// feed tokens[0..n) sequentially (row i of the reference's batched prefill depends only on rows
+// <= i through the KV cache, so token-by-token evaluation performs the same per-row arithmetic).
+int feed(flm_ctx* c, const int32_t* tokens, int n, int pos, int final_advance) {
+    int r = ensure_token_bufs(c, n, 1);
+    if (r) return r;
+    for (int i = 0; i < n; ++i) if (tokens[i] < 0 || tokens[i] >= c->d.vocab_size) return fail(c, FLM_ERR_INVALID, "token id out of range");
+    HIPC(c, hipMemcpyAsync(c->prompt_dev, tokens, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
+    DecodeState s{pos, tokens[0], 0, 0};
+    HIPC(c, hipMemcpyAsync(c->state, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
+    for (int i = 0; i + 1 < n; ++i) { r = run_token(c, pos + i, false, 2); if (r) return r; }
+    // last token: classifier; state.step is reset so out_tokens[0] receives the argmax
+    if (n > 1) {
+        // step was used as the prompt cursor; zero it for the argmax slot
+        hipLaunchKernelGGL(k_set_step, dim3(1), dim3(64), 0, c->stream, c->state, 0);
+        HIPC(c, hipGetLastError());
+    }
+    return run_token(c, pos + n - 1, true, final_advance);
+}
+
+} // namespace
+
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    int alloc(size_t n) { return hipMalloc(&p, n ? n : 4) == hipSuccess ? 0 : 1; }
+    template <class T> T* as() { return reinterpret_cast<T*>(p); }
+};
+#define OPC(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_last_error = std::string(#expr " failed: ") + hipGetErrorString(e_); return FLM_ERR_HIP; } } while (0)
+}
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+const char* flm_last_error(const flm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int flm_plan_shards(const flm_model_desc* d, int rank, int world, flm_shard_plan* out) {
+    if (!d || !out || world < 1 || rank < 0 || rank >= world) return FLM_ERR_INVALID;
+    if (d->n_heads < world) return FLM_ERR_UNSUPPORTED;
+    const int gs = d->quant_group_size > 0 ? d->quant_group_size : kGroup;
+    if (d->hidden_dim % gs) return FLM_ERR_INVALID;
+    int b, n;
+    split_even(d->n_heads, world, rank, &b, &n);           out->head_begin = b; out->head_count = n;
+    split_even(d->hidden_dim / gs, world, rank, &b, &n);   out->hidden_begin = b * gs; out->hidden_count = n * gs;
+    const int slot = (d->vocab_size + world - 1) / world;  // ceil split: slot layout == vocab layout
+    b = slot * rank; n = d->vocab_size - b; if (n > slot) n = slot; if (n < 0) n = 0;
+    out->vocab_begin = b; out->vocab_count = n;
+    return FLM_OK;
+}
+
+int flm_comm_unique_id(void* out128) {
+    if (!out128) return FLM_ERR_INVALID;
+    ncclUniqueId id;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) { g_last_error = ncclGetErrorString(r); return FLM_ERR_COMM; }
+    memcpy(out128, &id, 128);
+    return FLM_OK;
+}
+
+int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int world, const void* comm_id, flm_ctx** out) {
+    if (!desc || !out) return fail(nullptr, FLM_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const auto& d = *desc;
+    if (d.dim < 64 || d.hidden_dim < 64 || d.n_layers < 1 || d.n_heads < 1 || d.vocab_size < 1 || d.max_seq_len < 1)
+        return fail(nullptr, FLM_ERR_INVALID, "invalid model dimensions");
+    if (d.quant_group_size != kGroup) return fail(nullptr, FLM_ERR_UNSUPPORTED, "quant_group_size must be 64");
+    if (d.quant_type != FLM_QT_INT8 && d.quant_type != FLM_QT_INT16) return fail(nullptr, FLM_ERR_UNSUPPORTED, "quant_type must be INT8 or INT16");
+    if (d.n_kv_heads != d.n_heads) return fail(nullptr, FLM_ERR_UNSUPPORTED, "n_kv_heads != n_heads: the reference's grouped-query path is broken (transformer.cpp:449); not reproduced");
+    if (d.dim % d.n_heads || d.dim % kGroup || d.hidden_dim % kGroup) return fail(nullptr, FLM_ERR_INVALID, "dim/hidden_dim must be multiples of 64 and dim of n_heads");
+    const int hs = d.dim / d.n_heads;
+    if (hs % 4 || hs > 256 || hs < 8) return fail(nullptr, FLM_ERR_UNSUPPORTED, "head_size must be a multiple of 4 in [8,256]");
+    if (world < 1 || rank < 0 || rank >= world) return fail(nullptr, FLM_ERR_INVALID, "rank/world");
+    if (world > 1 && (hs % kGroup)) return fail(nullptr, FLM_ERR_UNSUPPORTED, "tensor parallelism needs head_size % 64 == 0 (quant groups may not straddle ranks)");
+    if (world > 1 && !comm_id) return fail(nullptr, FLM_ERR_INVALID, "comm_id required when world > 1");
+
+    flm_ctx* c = new flm_ctx();
+    c->d = d; c->device = device_id; c->rank = rank; c->world = world; c->hs = hs; c->esz = esz_of(d.quant_type);
+    int r = flm_plan_shards(desc, rank, world, &c->plan);
+    if (r) { delete c; return fail(nullptr, r, "cannot shard this model over the requested world size"); }
+    c->heads_local = c->plan.head_count; c->dim_local = c->heads_local * hs; c->hidden_local = c->plan.hidden_count;
+    c->vocab_slot = (d.vocab_size + world - 1) / world;
+    auto bail = [&](int code) { g_last_error = c->err; flm_ctx_destroy(c); return code; };
+#define HIPB(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { c->err = std::string(#expr " failed: ") + hipGetErrorString(e_); return bail(FLM_ERR_HIP); } } while (0)
+    HIPB(hipSetDevice(device_id));
+    hipDeviceProp_t prop; HIPB(hipGetDeviceProperties(&prop, device_id));
+    c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIPB(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (world > 1) {
+        ncclUniqueId id; memcpy(&id, comm_id, 128);
+        ncclResult_t nr = ncclCommInitRank(&c->comm, world, id, rank);
+        if (nr != ncclSuccess) { c->err = std::string("ncclCommInitRank failed: ") + ncclGetErrorString(nr); return bail(FLM_ERR_COMM); }
+    }
+    const int L = d.n_layers, qt = d.quant_type;
+    c->layers.resize(L);
+    for (int l = 0; l < L; ++l) {
+        LayerW& w = c->layers[l];
+        if (alloc_qmat(c, w.qkv, 3 * c->dim_local, d.dim, qt) || alloc_qmat(c, w.o, d.dim, c->dim_local, qt) ||
+            alloc_qmat(c, w.w1, c->hidden_local, d.dim, qt) || alloc_qmat(c, w.w3, c->hidden_local, d.dim, qt) ||
+            alloc_qmat(c, w.w2, d.dim, c->hidden_local, qt)) return bail(FLM_ERR_OOM);
+        HIPB(hipMalloc((void**)&w.att_norm, d.dim * 4)); HIPB(hipMalloc((void**)&w.ffn_norm, d.dim * 4));
+    }
+    if (alloc_qmat(c, c->cls, c->plan.vocab_count > 0 ? c->plan.vocab_count : 1, d.dim, qt)) return bail(FLM_ERR_OOM);
+    c->cls.rows = c->plan.vocab_count;
+    HIPB(hipMalloc((void**)&c->out_norm, d.dim * 4));
+    const size_t kvn = (size_t)L * c->heads_local * d.max_seq_len * hs;
+    HIPB(hipMalloc((void**)&c->kcache, kvn * 4)); HIPB(hipMalloc((void**)&c->vcache, kvn * 4));
+    HIPB(hipMemsetAsync(c->kcache, 0, kvn * 4, c->stream)); HIPB(hipMemsetAsync(c->vcache, 0, kvn * 4, c->stream));
+    HIPB(hipMalloc((void**)&c->x1, d.dim * 4)); HIPB(hipMalloc((void**)&c->qbuf, c->dim_local * 4));
+    HIPB(hipMalloc((void**)&c->att_out, c->dim_local * 4));
+    HIPB(hipMalloc((void**)&c->att_part, (size_t)c->heads_local * 8 * (hs + kAttnPartPad) * 4));
+    HIPB(hipMalloc((void**)&c->hd, c->hidden_local * 4)); HIPB(hipMalloc((void**)&c->partial, d.dim * 4));
+    HIPB(hipMalloc((void**)&c->logits, (size_t)c->vocab_slot * world * 4));
+    HIPB(hipMemsetAsync(c->logits, 0, (size_t)c->vocab_slot * world * 4, c->stream));
+    HIPB(hipMalloc((void**)&c->state, sizeof(DecodeState)));
+    HIPB(hipMemsetAsync(c->state, 0, sizeof(DecodeState), c->stream));
+    std::vector<float> cs, sn; build_rope_table(hs, d.max_seq_len, cs, sn);
+    HIPB(hipMalloc((void**)&c->rope_cos, cs.size() * 4)); HIPB(hipMalloc((void**)&c->rope_sin, sn.size() * 4));
+    HIPB(hipMemcpy(c->rope_cos, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
+    HIPB(hipMemcpy(c->rope_sin, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+    if (ensure_token_bufs(c, 1, 1)) return bail(FLM_ERR_OOM);
+    HIPB(hipStreamSynchronize(c->stream));
+#undef HIPB
+    *out = c;
+    return FLM_OK;
+}
+
+void flm_ctx_destroy(flm_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
+    auto fq = [](QMat& m) { if (m.q) hipFree(m.q); if (m.s) hipFree(m.s); };
+    for (auto& l : c->layers) { fq(l.qkv); fq(l.o); fq(l.w1); fq(l.w3); fq(l.w2); if (l.att_norm) hipFree(l.att_norm); if (l.ffn_norm) hipFree(l.ffn_norm); }
+    fq(c->cls);
+    void* ptrs[] = {c->emb, c->emb_s, c->out_norm, c->kcache, c->vcache, c->x1, c->qbuf, c->att_out, c->att_part, c->hd, c->partial,
+                    c->logits, c->rope_cos, c->rope_sin, c->state, c->prompt_dev, c->out_tokens_dev};
+    for (void* p : ptrs) if (p) hipFree(p);
+    if (c->comm) ncclCommDestroy(c->comm);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int flm_set_option(flm_ctx* c, const char* key, int value) {
+    if (!c || !key) return FLM_ERR_INVALID;
+    std::string k(key);
+    if (k == "wg_per_cu") c->wg_per_cu = value > 0 ? value : 2;
+    else if (k == "use_graph") c->use_graph = value;
+    else if (k == "attn_splits") c->attn_splits = value;
+    else return fail(c, FLM_ERR_INVALID, "unknown option");
+    for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
+    c->graphs.clear();
+    return FLM_OK;
+}
+
+int flm_upload_tensor(flm_ctx* c, int kind, int layer, int src_qt, const void* values, const float* scales, int rows, int cols) {
+    if (!c || !values) return FLM_ERR_INVALID;
+    HIPC(c, hipSetDevice(c->device));
+    const auto& d = c->d;
+    const int hs = c->hs;
+    if (src_qt != FLM_QT_NONE && !scales) return fail(c, FLM_ERR_INVALID, "quantized tensor without scales");
+    if (kind >= 16 && (layer < 0 || layer >= d.n_layers)) return fail(c, FLM_ERR_INVALID, "layer out of range");
+    auto vec = [&](float* dst, int n) -> int {
+        if (src_qt != FLM_QT_NONE || (size_t)rows * cols != (size_t)n) return fail(c, FLM_ERR_INVALID, "norm tensor must be fp32 [dim]");
+        HIPC(c, hipMemcpy(dst, values, (size_t)n * 4, hipMemcpyHostToDevice));
+        return FLM_OK;
+    };
+    const int hb = c->plan.head_begin * hs, hn = c->dim_local;
+    switch (kind) {
+    case FLM_T_TOKEN_EMBD: {
+        if (rows != d.vocab_size || cols != d.dim) return fail(c, FLM_ERR_INVALID, "embedding shape");
+        const size_t n = (size_t)rows * cols;
+        if (c->emb) { hipFree(c->emb); c->emb = nullptr; } if (c->emb_s) { hipFree(c->emb_s); c->emb_s = nullptr; }
+        HIPC(c, hipMalloc(&c->emb, n * esz_of(src_qt)));
+        HIPC(c, hipMemcpy(c->emb, values, n * esz_of(src_qt), hipMemcpyHostToDevice));
+        if (src_qt != FLM_QT_NONE) { HIPC(c, hipMalloc((void**)&c->emb_s, n / kGroup * 4)); HIPC(c, hipMemcpy(c->emb_s, scales, n / kGroup * 4, hipMemcpyHostToDevice)); }
+        c->emb_qt = src_qt; c->got_emb = true;
+        for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
+        c->graphs.clear();
+        return FLM_OK; }
+    case FLM_T_OUTPUT_NORM: { int r = vec(c->out_norm, d.dim); if (!r) c->got_out_norm = true; return r; }
+    case FLM_T_INPUT_NORM:  { int r = vec(c->layers[layer].att_norm, d.dim); if (!r) c->layers[layer].got |= 1u << 0; return r; }
+    case FLM_T_POST_NORM:   { int r = vec(c->layers[layer].ffn_norm, d.dim); if (!r) c->layers[layer].got |= 1u << 1; return r; }
+    case FLM_T_CLASSIFIER: {
+        if (rows != d.vocab_size || cols != d.dim) return fail(c, FLM_ERR_INVALID, "classifier shape");
+        if (c->plan.vocab_count > 0) { int r = upload_window(c, c->cls, 0, src_qt, values, scales, cols, c->plan.vocab_begin, c->plan.vocab_count, 0, cols); if (r) return r; }
+        c->got_cls = true; return FLM_OK; }
+    case FLM_T_ATTN_Q: case FLM_T_ATTN_K: case FLM_T_ATTN_V: {
+        if (rows != d.dim || cols != d.dim) return fail(c, FLM_ERR_INVALID, "q/k/v shape");
+        const int which = kind - FLM_T_ATTN_Q;
+        int r = upload_window(c, c->layers[layer].qkv, which * hn, src_qt, values, scales, cols, hb, hn, 0, cols);
+        if (!r) c->layers[layer].got |= 1u << (2 + which);
+        return r; }
+    case FLM_T_ATTN_O: {
+        if (rows != d.dim || cols != d.dim) return fail(c, FLM_ERR_INVALID, "o shape");
+        if (src_qt == FLM_QT_NONE && c->world > 1) {
+            // fp32 source under TP: groups are along the columns, so quantizing the column window equals windowing the quantized matrix
+        }
+        int r = upload_window(c, c->layers[layer].o, 0, src_qt, values, scales, cols, 0, rows, hb, hn);
+        if (!r) c->layers[layer].got |= 1u << 5;
+        return r; }
+    case FLM_T_MLP_GATE: case FLM_T_MLP_UP: {
+        if (rows != d.hidden_dim || cols != d.dim) return fail(c, FLM_ERR_INVALID, "ffn1/3 shape");
+        QMat& m = kind == FLM_T_MLP_GATE ? c->layers[layer].w1 : c->layers[layer].w3;
+        int r = upload_window(c, m, 0, src_qt, values, scales, cols, c->plan.hidden_begin, c->plan.hidden_count, 0, cols);
+        if (!r) c->layers[layer].got |= 1u << (kind == FLM_T_MLP_GATE ? 6 : 7);
+        return r; }
+    case FLM_T_MLP_DOWN: {
+        if (rows != d.dim || cols != d.hidden_dim) return fail(c, FLM_ERR_INVALID, "ffn2 shape");
+        int r = upload_window(c, c->layers[layer].w2, 0, src_qt, values, scales, cols, 0, rows, c->plan.hidden_begin, c->plan.hidden_count);
+        if (!r) c->layers[layer].got |= 1u << 8;
+        return r; }
+    default: return fail(c, FLM_ERR_INVALID, "unknown tensor kind");
+    }
+}
+
+int flm_reset_kv(flm_ctx* c) {
+    if (!c) return FLM_ERR_INVALID;
+    HIPC(c, hipSetDevice(c->device));
+    const size_t kvn = (size_t)c->d.n_layers * c->heads_local * c->d.max_seq_len * c->hs;
+    HIPC(c, hipMemsetAsync(c->kcache, 0, kvn * 4, c->stream)); HIPC(c, hipMemsetAsync(c->vcache, 0, kvn * 4, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return FLM_OK;
+}
+
+int flm_sync(flm_ctx* c) { if (!c) return FLM_ERR_INVALID; HIPC(c, hipSetDevice(c->device)); HIPC(c, hipStreamSynchronize(c->stream)); return FLM_OK; }
+
+int flm_forward(flm_ctx* c, const int32_t* tokens, int n, int pos, float* logits_host) {
+    if (!tokens || !logits_host) return FLM_ERR_INVALID;
+    int r = check_ready(c, n, pos); if (r) return r;
+    r = feed(c, tokens, n, pos, 0); if (r) return r;
+    HIPC(c, hipMemcpyAsync(logits_host, c->logits, (size_t)c->d.vocab_size * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return FLM_OK;
+}
+
+int flm_forward_argmax(flm_ctx* c, const int32_t* tokens, int n, int pos, int32_t* next_token) {
+    if (!tokens || !next_token) return FLM_ERR_INVALID;
+    int r = check_ready(c, n, pos); if (r) return r;
+    r = feed(c, tokens, n, pos, 1); if (r) return r;
+    HIPC(c, hipMemcpyAsync(next_token, c->out_tokens_dev, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return FLM_OK;
+}
+
+static int decode_loop(flm_ctx* c, int32_t first_token, int pos, int n_steps, hipEvent_t e0, hipEvent_t e1) {
+    int r = check_ready(c, n_steps, pos); if (r) return r;
+    if (first_token < 0 || first_token >= c->d.vocab_size) return fail(c, FLM_ERR_INVALID, "token id out of range");
+    r = ensure_token_bufs(c, 1, n_steps); if (r) return r;
+    DecodeState s{pos, first_token, 0, 0};
+    HIPC(c, hipMemcpyAsync(c->state, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
+    if (e0) HIPC(c, hipEventRecord(e0, c->stream));
+    for (int i = 0; i < n_steps; ++i) { r = run_token(c, pos + i, true, 1); if (r) return r; }
+    if (e1) HIPC(c, hipEventRecord(e1, c->stream));
+    return FLM_OK;
+}
+
+int flm_decode_greedy(flm_ctx* c, int32_t first_token, int pos, int n_steps, int32_t* out_tokens) {
+    if (!out_tokens) return FLM_ERR_INVALID;
+    int r = decode_loop(c, first_token, pos, n_steps, nullptr, nullptr); if (r) return r;
+    HIPC(c, hipMemcpyAsync(out_tokens, c->out_tokens_dev, sizeof(int) * n_steps, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return FLM_OK;
+}
+
+int flm_decode_timed(flm_ctx* c, int32_t first_token, int pos, int n_steps, float* ms) {
+    if (!ms || !c) return FLM_ERR_INVALID;
+    HIPC(c, hipSetDevice(c->device));
+    hipEvent_t e0, e1; HIPC(c, hipEventCreate(&e0)); HIPC(c, hipEventCreate(&e1));
+    int r = decode_loop(c, first_token, pos, n_steps, e0, e1);
+    if (!r) { hipError_t e = hipEventSynchronize(e1); if (e == hipSuccess) e = hipEventElapsedTime(ms, e0, e1); if (e != hipSuccess) { c->err = hipGetErrorString(e); r = FLM_ERR_HIP; } }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return r;
+}
+
+int flm_kernel_times(flm_ctx* c, int pos, int iters, float* avg_us, int32_t* count) {
+    if (!avg_us || !count || iters < 1) return FLM_ERR_INVALID;
+    int r = check_ready(c, 1, pos); if (r) return r;
+    double tot[FLM_KCLASSES] = {0}; long cnt[FLM_KCLASSES] = {0};
+    r = ensure_token_bufs(c, 1, 1); if (r) return r;
+    for (int it = 0; it < iters + 1; ++it) {
+        DecodeState s{pos, 1 % c->d.vocab_size, 0, 0};
+        HIPC(c, hipMemcpyAsync(c->state, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
+        std::vector<TimedLaunch> tl; c->timing = &tl;
+        r = enqueue_token(c, c->stream, attn_splits_for(c, pos), true, 1);
+        c->timing = nullptr;
+        hipStreamSynchronize(c->stream);
+        for (auto& t : tl) {
+            float ms = 0.f;
+            if (!r && it > 0 && hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) { tot[t.kclass] += ms * 1000.0; cnt[t.kclass] += 1; }
+            hipEventDestroy(t.e0); hipEventDestroy(t.e1);
+        }
+        if (r) return r;
+    }
+    for (int k = 0; k < FLM_KCLASSES; ++k) { avg_us[k] = cnt[k] ? (float)(tot[k] / cnt[k]) : 0.f; count[k] = (int32_t)(cnt[k] / iters); }
+    return FLM_OK;
+}
+
+int flm_kernel_bytes(flm_ctx* c, int kclass, int pos, double* bytes) {
+    if (!c || !bytes) return FLM_ERR_INVALID;
+    const auto& d = c->d; const double e = c->esz, sb = 4.0 / kGroup;
+    auto mat = [&](double rows, double cols) { return rows * cols * (e + sb); };
+    switch (kclass) {
+    case KC_EMBED:  *bytes = d.dim * 4.0; break;
+    case KC_QKV:    *bytes = mat(3.0 * c->dim_local, d.dim) + d.dim * 4.0; break;               // + rmsnorm weight
+    case KC_ATTN:   *bytes = 2.0 * c->heads_local * c->hs * 4.0 * (pos + 1); break;             // fp32 K and V rows
+    case KC_ATTN_O: *bytes = mat(d.dim, c->dim_local); break;
+    case KC_FFN13:  *bytes = 2.0 * mat(c->hidden_local, d.dim) + d.dim * 4.0; break;
+    case KC_FFN2:   *bytes = mat(d.dim, c->hidden_local); break;
+    case KC_CLS:    *bytes = mat(c->cls.rows, d.dim) + d.dim * 4.0; break;
+    default:        *bytes = 0; break;
+    }
+    return FLM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// op-level exports
+// ---------------------------------------------------------------------------------------------
+
+int flm_op_quantize(int qt, void* qx, float* qs, const float* x, size_t n, int gs) {
+    if (!qx || !qs || !x || gs != kGroup || n % kGroup) return FLM_ERR_INVALID;
+    if (qt != FLM_QT_INT8 && qt != FLM_QT_INT16) return FLM_ERR_UNSUPPORTED;
+    const int e = esz_of(qt);
+    DevBuf dx, dq, ds;
+    if (dx.alloc(n * 4) || dq.alloc(n * e) || ds.alloc(n / kGroup * 4)) return FLM_ERR_OOM;
+    OPC(hipMemcpy(dx.p, x, n * 4, hipMemcpyHostToDevice));
+    if (n <= 16384) {
+        // through the fused path's prologue (PRO_QUANT), tapped
+        GemvArgs a{}; a.n = (int)n; a.items = 0; a.x = dx.as<float>(); a.dbg_xq = dq.p; a.dbg_xs = ds.as<float>();
+        int r = launch_gemv<PRO_QUANT, EPI_STORE>(nullptr, 0, qt, a, 1); if (r) return r;
+    } else {
+        int r = quantize_flat(nullptr, 0, qt, dq.p, ds.as<float>(), dx.as<float>(), n); if (r) return r;
+    }
+    OPC(hipDeviceSynchronize());
+    OPC(hipMemcpy(qx, dq.p, n * e, hipMemcpyDeviceToHost));
+    OPC(hipMemcpy(qs, ds.p, n / kGroup * 4, hipMemcpyDeviceToHost));
+    return FLM_OK;
+}
+
+int flm_op_rmsnorm(float* o, const float* x, const float* w, size_t n) {
+    if (!o || !x || !w || n % kGroup || n > 16384 || n == 0) return FLM_ERR_INVALID;
+    DevBuf dx, dw, dn, dq, ds;
+    if (dx.alloc(n * 4) || dw.alloc(n * 4) || dn.alloc(n * 4) || dq.alloc(n) || ds.alloc(n / kGroup * 4)) return FLM_ERR_OOM;
+    OPC(hipMemcpy(dx.p, x, n * 4, hipMemcpyHostToDevice)); OPC(hipMemcpy(dw.p, w, n * 4, hipMemcpyHostToDevice));
+    GemvArgs a{}; a.n = (int)n; a.items = 0; a.x = dx.as<float>(); a.norm_w = dw.as<float>();
+    a.dbg_xn = dn.as<float>(); a.dbg_xq = dq.p; a.dbg_xs = ds.as<float>();
+    int r = launch_gemv<PRO_RMSNORM_QUANT, EPI_STORE>(nullptr, 0, FLM_QT_INT8, a, 1); if (r) return r;
+    OPC(hipDeviceSynchronize());
+    OPC(hipMemcpy(o, dn.p, n * 4, hipMemcpyDeviceToHost));
+    return FLM_OK;
+}
+
+int flm_op_matmul_q(int qt, float* out, const void* W, const float* sW, const void* X, const float* sX, int m, int n, int w, int gs) {
+    if (!out || !W || !sW || !X || !sX || m < 1 || n < 1 || w < 1 || gs != kGroup || n % kGroup) return FLM_ERR_INVALID;
+    if (qt != FLM_QT_INT8 && qt != FLM_QT_INT16) return FLM_ERR_UNSUPPORTED;
+    const size_t e = esz_of(qt), sn = n / kGroup;
+    DevBuf dW, dsW, dX, dsX, dO;
+    if (dW.alloc((size_t)m * n * e) || dsW.alloc((size_t)m * sn * 4) || dX.alloc((size_t)w * n * e) || dsX.alloc((size_t)w * sn * 4) || dO.alloc((size_t)w * m * 4)) return FLM_ERR_OOM;
+    OPC(hipMemcpy(dW.p, W, (size_t)m * n * e, hipMemcpyHostToDevice)); OPC(hipMemcpy(dsW.p, sW, (size_t)m * sn * 4, hipMemcpyHostToDevice));
+    OPC(hipMemcpy(dX.p, X, (size_t)w * n * e, hipMemcpyHostToDevice)); OPC(hipMemcpy(dsX.p, sX, (size_t)w * sn * 4, hipMemcpyHostToDevice));
+    int dev = 0, cus = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    for (int b = 0; b < w; ++b) {
+        GemvArgs a{}; a.W = dW.p; a.sW = dsW.as<float>(); a.n = n; a.items = m;
+        a.xq = (const char*)dX.p + (size_t)b * n * e; a.xs = dsX.as<float>() + (size_t)b * sn; a.out = dO.as<float>() + (size_t)b * m;
+        int r = launch_gemv<PRO_NONE, EPI_STORE>(nullptr, 0, qt, a, gemv_grid(cus, 2, m, 1)); if (r) return r;
+    }
+    OPC(hipDeviceSynchronize());
+    OPC(hipMemcpy(out, dO.p, (size_t)w * m * 4, hipMemcpyDeviceToHost));
+    return FLM_OK;
+}
+
+int flm_op_swiglu(float* xo, const float* xr, size_t n) {
+    if (!xo || !xr || n == 0) return FLM_ERR_INVALID;
+    DevBuf a, b; if (a.alloc(n * 4) || b.alloc(n * 4)) return FLM_ERR_OOM;
+    OPC(hipMemcpy(a.p, xo, n * 4, hipMemcpyHostToDevice)); OPC(hipMemcpy(b.p, xr, n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_op_swiglu, dim3(256), dim3(256), 0, 0, a.as<float>(), (const float*)b.as<float>(), n);
+    OPC(hipGetLastError()); OPC(hipDeviceSynchronize());
+    OPC(hipMemcpy(xo, a.p, n * 4, hipMemcpyDeviceToHost));
+    return FLM_OK;
+}
+
+int flm_op_rope(float* o, const float* x, int n_dims, int pos) {
+    if (!o || !x || n_dims < 2 || n_dims % 2 || pos < 0) return FLM_ERR_INVALID;
+    std::vector<float> cs, sn; build_rope_table(n_dims, pos + 1, cs, sn);
+    DevBuf dx, dout, dc, dsn; const size_t h = n_dims / 2;
+    if (dx.alloc(n_dims * 4) || dout.alloc(n_dims * 4) || dc.alloc(h * 4) || dsn.alloc(h * 4)) return FLM_ERR_OOM;
+    OPC(hipMemcpy(dx.p, x, n_dims * 4, hipMemcpyHostToDevice));
+    OPC(hipMemcpy(dc.p, cs.data() + (size_t)pos * h, h * 4, hipMemcpyHostToDevice)); OPC(hipMemcpy(dsn.p, sn.data() + (size_t)pos * h, h * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_op_rope, dim3((unsigned)((h + 63) / 64)), dim3(64), 0, 0, dout.as<float>(), (const float*)dx.as<float>(), n_dims, (const float*)dc.as<float>(), (const float*)dsn.as<float>());
+    OPC(hipGetLastError()); OPC(hipDeviceSynchronize());
+    OPC(hipMemcpy(o, dout.p, n_dims * 4, hipMemcpyDeviceToHost));
+    return FLM_OK;
+}
+
+int flm_op_softmax(float* x, int n) {
+    if (!x || n < 1) return FLM_ERR_INVALID;
+    DevBuf d; if (d.alloc((size_t)n * 4)) return FLM_ERR_OOM;
+    OPC(hipMemcpy(d.p, x, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_op_softmax, dim3(1), dim3(kBlock), 0, 0, d.as<float>(), n);
+    OPC(hipGetLastError()); OPC(hipDeviceSynchronize());
+    OPC(hipMemcpy(x, d.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return FLM_OK;
+}
+
+int flm_op_attention(float* out, float* kc, float* vc, const float* q, const float* k, const float* v,
+                     int n_heads, int hs, int max_seq, int pos, int n_splits) {
+    if (!out || !kc || !vc || !q || !k || !v || n_heads < 1 || hs < 8 || hs % 4 || hs > 256 || pos < 0 || pos >= max_seq) return FLM_ERR_INVALID;
+    if (n_splits < 0 || n_splits > 8) return FLM_ERR_INVALID;
+    const size_t nd = (size_t)n_heads * hs, nc = (size_t)n_heads * max_seq * hs, h2 = hs / 2;
+    std::vector<float> cs, sn; build_rope_table(hs, pos + 1, cs, sn);
+    DevBuf dq, dk, dv, dkc, dvc, dout, dpart, dc, dsn, dpos;
+    if (dq.alloc(nd * 4) || dk.alloc(nd * 4) || dv.alloc(nd * 4) || dkc.alloc(nc * 4) || dvc.alloc(nc * 4) || dout.alloc(nd * 4) ||
+        dpart.alloc((size_t)n_heads * 8 * (hs + kAttnPartPad) * 4) || dc.alloc(h2 * 4) || dsn.alloc(h2 * 4) || dpos.alloc(4)) return FLM_ERR_OOM;
+    OPC(hipMemcpy(dq.p, q, nd * 4, hipMemcpyHostToDevice)); OPC(hipMemcpy(dk.p, k, nd * 4, hipMemcpyHostToDevice)); OPC(hipMemcpy(dv.p, v, nd * 4, hipMemcpyHostToDevice));
+    OPC(hipMemcpy(dkc.p, kc, nc * 4, hipMemcpyHostToDevice)); OPC(hipMemcpy(dvc.p, vc, nc * 4, hipMemcpyHostToDevice));
+    OPC(hipMemcpy(dc.p, cs.data() + (size_t)pos * h2, h2 * 4, hipMemcpyHostToDevice)); OPC(hipMemcpy(dsn.p, sn.data() + (size_t)pos * h2, h2 * 4, hipMemcpyHostToDevice));
+    OPC(hipMemcpy(dpos.p, &pos, 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_op_kv_append, dim3((unsigned)((nd / 2 + 255) / 256)), dim3(256), 0, 0, dq.as<float>(), (const float*)dk.as<float>(), (const float*)dv.as<float>(),
+                       dkc.as<float>(), dvc.as<float>(), (const float*)dc.as<float>(), (const float*)dsn.as<float>(), n_heads, hs, max_seq, pos);
+    OPC(hipGetLastError());
+    int S = n_splits;
+    if (S == 0) { S = 1; while (S < 8 && (pos + 1) / (S * 2) >= 32) S *= 2; }
+    AttnArgs a{}; a.q = dq.as<float>(); a.kcache = dkc.as<float>(); a.vcache = dvc.as<float>(); a.pos_ptr = dpos.as<int>(); a.hs = hs; a.max_seq = max_seq; a.n_splits = S;
+    a.out = S == 1 ? dout.as<float>() : dpart.as<float>();
+    hipLaunchKernelGGL(k_attn_decode, dim3(n_heads, S), dim3(kBlock), attn_lds_bytes((max_seq + S - 1) / S, hs), 0, a);
+    OPC(hipGetLastError());
+    if (S > 1) { hipLaunchKernelGGL(k_op_attn_combine, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, 0, dout.as<float>(), (const float*)dpart.as<float>(), n_heads, hs, S); OPC(hipGetLastError()); }
+    OPC(hipDeviceSynchronize());
+    OPC(hipMemcpy(out, dout.p, nd * 4, hipMemcpyDeviceToHost));
+    OPC(hipMemcpy(kc, dkc.p, nc * 4, hipMemcpyDeviceToHost)); OPC(hipMemcpy(vc, dvc.p, nc * 4, hipMemcpyDeviceToHost));
+    return FLM_OK;
+}
+
+} // extern "C"

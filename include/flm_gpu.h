@@ -1,0 +1,151 @@
+/* flm_gpu.h -- C ABI of the MI355X (gfx950) implementation of fast-llama's per-token hot path.
+ *
+ * The reference (CoderLSF/fast-llama) has no plugin/FFI seam; its path sits behind the C++ class
+ * ParallelTransformer (src/transformer/transformer.h:76-99) and the raw-pointer operator set
+ * cpuft::quant::* (src/blas/quant_operators.h:37-82) / cpuft::simd::* (src/platforms/arch/simd.h:13-63).
+ * This header is the boundary a maintainer would bind instead: one device-resident forward per
+ * token (model level) plus 1:1 mirrors of the operator seam (op level, used by the parity tests).
+ * Plain pointers and sizes only; no C++/torch types; no exceptions cross it.  Every entry point
+ * cites the reference interface it replaces (paths relative to the reference repo root).
+ *
+ * Threading: one caller thread per ctx at a time (as ParallelTransformer::forward, single caller,
+ * transformer.h:101-110).  Independent ctxs (replicas / tensor-parallel ranks) are independent.
+ * Ownership: the caller owns every host pointer (copied during the call); the ctx owns all device
+ * memory, allocated at create/upload time -- nothing is allocated inside flm_forward*.
+ */
+#ifndef FLM_GPU_H
+#define FLM_GPU_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes (reference: bool + printf, src/utils/log.h; here: int + flm_last_error) */
+#define FLM_OK               0
+#define FLM_ERR_INVALID     -1   /* bad argument / shape */
+#define FLM_ERR_UNSUPPORTED -2   /* e.g. n_kv_heads != n_heads (reference GQA path is broken, transformer.cpp:449) */
+#define FLM_ERR_HIP         -3   /* HIP runtime error, see flm_last_error */
+#define FLM_ERR_OOM         -4
+#define FLM_ERR_STATE       -5   /* e.g. forward before all tensors were uploaded */
+#define FLM_ERR_COMM        -6   /* RCCL error */
+
+/* QuantType numbering == cpuft::quant::QuantType (src/blas/quant_operators.h:18-25) */
+#define FLM_QT_NONE  0
+#define FLM_QT_INT16 1
+#define FLM_QT_INT8  2
+
+/* tensor kinds == .flm TensorType (src/model_loaders/flm_loader.cpp:50-67) */
+#define FLM_T_TOKEN_EMBD  1
+#define FLM_T_OUTPUT_NORM 2
+#define FLM_T_CLASSIFIER  3
+#define FLM_T_INPUT_NORM 17
+#define FLM_T_ATTN_Q     18
+#define FLM_T_ATTN_K     19
+#define FLM_T_ATTN_V     20
+#define FLM_T_ATTN_O     21
+#define FLM_T_MLP_GATE   22   /* ffn_1 */
+#define FLM_T_MLP_UP     23   /* ffn_3 */
+#define FLM_T_MLP_DOWN   24   /* ffn_2 */
+#define FLM_T_POST_NORM  25
+
+typedef struct flm_ctx flm_ctx;
+
+/* == TransformerConfig (src/model_loaders/model_loader.h:46-68), the fields the path uses.
+ * rope_freq_base / rms_norm_eps are NOT here on purpose: the reference ops hard-code 10000 and
+ * 1e-5 (tf_operators.cpp:353, x86_simd.cpp:1755) and ignore the file's values. */
+typedef struct flm_model_desc {
+    int32_t dim;
+    int32_t hidden_dim;
+    int32_t n_layers;
+    int32_t n_heads;
+    int32_t n_kv_heads;       /* must equal n_heads (see FLM_ERR_UNSUPPORTED) */
+    int32_t vocab_size;
+    int32_t max_seq_len;      /* reference clamps to 1024 (transformer.cpp:32) */
+    int32_t quant_type;       /* FLM_QT_INT8 | FLM_QT_INT16: type of the linear layers and activations */
+    int32_t quant_group_size; /* 64 */
+} flm_model_desc;
+
+/* ---- lifecycle: replaces ParallelTransformer::load (transformer.cpp:23-42) + parallel_*_init
+ *      (transformer.cpp:209-384).  device_id = HIP ordinal.  rank/world/comm_id: tensor-parallel
+ *      group (world == 1: comm_id may be NULL).  comm_id = 128 bytes from flm_comm_unique_id()
+ *      on rank 0, distributed by the caller (bench.py uses torch.distributed for that). */
+int  flm_comm_unique_id(void* out128);
+int  flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int world,
+                    const void* comm_id, flm_ctx** out);
+void flm_ctx_destroy(flm_ctx* ctx);
+const char* flm_last_error(const flm_ctx* ctx);   /* ctx may be NULL: last create error */
+
+/* Hand one tensor (one layer of it) to the device: what load_tensor (flm_loader.cpp:493-559) +
+ * copy_layers (transformer.cpp:289-304) do for the CPU threads.  `values` is row-major
+ * [rows][cols] of src_qtype (fp32 when FLM_QT_NONE) with fp32 `scales` [rows][cols/gs] when
+ * quantized.  fp32 linear-layer tensors are quantized on the device with the reference's
+ * quantizer (A13).  Under tensor parallelism the FULL tensor is passed on every rank; the ctx
+ * keeps its shard. */
+int  flm_upload_tensor(flm_ctx* ctx, int kind, int layer, int src_qtype,
+                       const void* values, const float* scales, int rows, int cols);
+
+/* ---- the hot path: replaces ParallelTransformer::forward (transformer.h:99, transformer.cpp:105-161).
+ * tokens[n] enter at absolute position pos (pos = tokens already in the KV cache);
+ * logits_host[vocab] = logits of the LAST token. */
+int  flm_forward(flm_ctx* ctx, const int32_t* tokens, int n, int pos, float* logits_host);
+/* same + sample_argmax (src/transformer/sampler.cpp:36-47, first maximum wins) on the device */
+int  flm_forward_argmax(flm_ctx* ctx, const int32_t* tokens, int n, int pos, int32_t* next_token);
+/* Device-resident greedy loop == the body of ParallelTransformer::generate (transformer.cpp:92-101)
+ * at temperature 0: feeds `first_token` at `pos`, then n_steps-1 further argmax tokens, no host
+ * round trip between tokens.  out_tokens[n_steps] receives every sampled token.  Does not stop
+ * on token 0 (the caller truncates). */
+int  flm_decode_greedy(flm_ctx* ctx, int32_t first_token, int pos, int n_steps, int32_t* out_tokens);
+/* Same loop, nothing copied back; *ms = device time of the n_steps tokens measured with HIP events
+ * on the ctx's stream (bench.py's timed region; call flm_sync afterwards is not needed). */
+int  flm_decode_timed(flm_ctx* ctx, int32_t first_token, int pos, int n_steps, float* ms);
+int  flm_reset_kv(flm_ctx* ctx);
+int  flm_sync(flm_ctx* ctx);
+
+/* Per-kernel timing of ONE decode token at position pos, HIP events around every launch on the
+ * ctx's stream, averaged over `iters` tokens.  Classes: 0 embed, 1 qkv, 2 attn, 3 attn_o, 4 ffn13,
+ * 5 ffn2, 6 cls, 7 argmax, 8 allreduce.  avg_us[c] = mean duration of ONE launch of class c,
+ * count[c] = launches of that class per token. */
+#define FLM_KCLASSES 9
+int  flm_kernel_times(flm_ctx* ctx, int pos, int iters, float* avg_us, int32_t* count);
+/* weight + scale bytes one launch of class c streams (the algorithmic bytes of DESIGN.md) */
+int  flm_kernel_bytes(flm_ctx* ctx, int kclass, int pos, double* bytes);
+
+/* tuning knobs (0 = default): workgroups per CU for the GEMV kernels, hipGraph on/off */
+int  flm_set_option(flm_ctx* ctx, const char* key, int value);
+
+/* ---- op level: 1:1 mirrors of the reference operator seam, host pointers in / out, running the
+ *      same device code as the fused path.  Used by the parity tests. ----------------------- */
+/* quant::quantize (quant_operators.cpp:78-97) */
+int  flm_op_quantize(int qt, void* qx, float* qs, const float* x, size_t n, int gs);
+/* quant::matmul (quant_operators.cpp:571-591), same argument order: out[w][m] */
+int  flm_op_matmul_q(int qt, float* out, const void* mat1, const float* scales1,
+                     const void* mat2, const float* scales2, int m, int n, int w, int gs);
+/* simd::rmsnorm(o,x,w,n) (x86_simd.cpp:1754-1764) */
+int  flm_op_rmsnorm(float* o, const float* x, const float* w, size_t n);
+/* simd::swiglu(xo,xr,n) (x86_simd.cpp:1766-1770) */
+int  flm_op_swiglu(float* xo, const float* xr, size_t n);
+/* rope_v2 (tf_operators.cpp:352-402): one head row of n_dims at position pos */
+int  flm_op_rope(float* o, const float* x, int n_dims, int pos);
+/* softmax_sisd over the first n entries (tf_operators.cpp:176-186) */
+int  flm_op_softmax(float* x, int n);
+/* the ATTN task (execute_attn, transformer.cpp:397-455) for n_heads heads of one new token at
+ * position pos: q,k,v are [n_heads*hs]; kc,vc are [n_heads][max_seq][hs] caches (updated);
+ * out [n_heads*hs].  n_splits = 0 lets the library choose its split count. */
+int  flm_op_attention(float* out, float* kc, float* vc, const float* q, const float* k, const float* v,
+                      int n_heads, int hs, int max_seq, int pos, int n_splits);
+
+/* ---- tensor-parallel shard plan (pure host arithmetic, no GPU needed).
+ * Mirrors the reference's per-thread row split (split_rows, transformer.cpp:264-287) with the
+ * extra rule that quantization groups never straddle ranks. */
+typedef struct flm_shard_plan {
+    int32_t head_begin, head_count;        /* attention heads owned (q,k,v rows; O-proj columns) */
+    int32_t hidden_begin, hidden_count;    /* FFN rows of W1/W3 == columns of W2, multiples of gs */
+    int32_t vocab_begin, vocab_count;      /* classifier rows */
+} flm_shard_plan;
+int  flm_plan_shards(const flm_model_desc* desc, int rank, int world, flm_shard_plan* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,132 @@
+"""Model-level parity on the GPU: logits within 1e-3 relative (north_star tolerance), greedy ids identical,
+against the CPU oracle (bit-exact with the reference, tests/test_oracle_vs_reference.py) and the
+committed golden logits generated from the reference itself."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_py as O
+from fast_llama_amd import flmfile as ff, synth
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-3      # BASELINE.json north_star: logits within 1e-3 relative fp32 tolerance
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel_err(a, b):
+    return float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+
+
+def _prompt(V, n):
+    return np.array([1] + [int(x) for x in (np.arange(1, n) * 7919) % V], dtype=np.int32)
+
+
+@pytest.mark.parametrize("shape,qt,fp32_master", [("tiny", ff.QT_INT8, False), ("tiny", ff.QT_INT16, False), ("tiny128", ff.QT_INT8, False),
+                                                  ("tiny", ff.QT_INT8, True), ("small", ff.QT_INT8, False), ("small", ff.QT_INT16, False)])
+def test_logits_and_greedy_vs_oracle(gpu, shape, qt, fp32_master):
+    cfg = synth.make_config(shape, qt)
+    tensors = synth.make_tensors(cfg, seed=1234, fp32_master=fp32_master)
+    ctx = gpu.Ctx(gpu.desc_from_config(cfg))
+    ctx.upload_all(tensors)
+    om = O.OracleModel(cfg, tensors)
+    prompt = _prompt(cfg.vocab_size, 8)
+    lg = ctx.forward(prompt, 0); lo = om.forward(prompt, 0)
+    assert rel_err(lg, lo) < REL_TOL
+    pos, cur = len(prompt), int(np.argmax(lo))
+    assert int(np.argmax(lg)) == cur
+    worst = 0.0
+    for _ in range(16):
+        t = np.array([cur], dtype=np.int32)
+        lg = ctx.forward(t, pos); lo = om.forward(t, pos)
+        worst = max(worst, rel_err(lg, lo))
+        srt = np.sort(lo)
+        if srt[-1] - srt[-2] > 1e-4 * abs(srt[-1]):          # away from a numerical tie the ids must agree
+            assert int(np.argmax(lg)) == int(np.argmax(lo))
+        cur = int(np.argmax(lo)); pos += 1
+    assert worst < REL_TOL
+    ctx.close()
+
+
+def test_device_greedy_loop_matches_stepwise(gpu):
+    """flm_decode_greedy (hipGraph replay, device-resident state) == step-by-step flm_forward_argmax == oracle."""
+    cfg = synth.make_config("small", ff.QT_INT8)
+    tensors = synth.make_tensors(cfg, seed=77)
+    ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
+    om = O.OracleModel(cfg, tensors)
+    prompt = _prompt(cfg.vocab_size, 6)
+    first = ctx.forward_argmax(prompt, 0)
+    assert first == int(np.argmax(om.forward(prompt, 0)))
+    n = 40
+    ids = ctx.decode_greedy(first, len(prompt), n)
+    # stepwise on a fresh cache
+    ctx.reset_kv()
+    assert ctx.forward_argmax(prompt, 0) == first
+    cur, pos, step_ids, orc_ids = first, len(prompt), [], []
+    ocur = first
+    for _ in range(n):
+        cur = ctx.forward_argmax(np.array([cur], np.int32), pos); step_ids.append(cur)
+        ocur = int(np.argmax(om.forward(np.array([ocur], np.int32), pos))); orc_ids.append(ocur)
+        pos += 1
+    assert list(ids) == step_ids
+    assert list(ids) == orc_ids
+    # graph on/off and attention split counts give identical tokens
+    for key, val in (("use_graph", 0), ("attn_splits", 4), ("wg_per_cu", 4)):
+        ctx.set_option(key, val); ctx.reset_kv()
+        assert ctx.forward_argmax(prompt, 0) == first
+        assert list(ctx.decode_greedy(first, len(prompt), n)) == list(ids)
+    ctx.close()
+
+
+def test_long_context_positions(gpu):
+    """positions up to max_seq_len-1 (1024 clamp, transformer.cpp:32): prefill 1000 tokens on the GPU and the oracle."""
+    cfg = synth.make_config("tiny", ff.QT_INT8)
+    tensors = synth.make_tensors(cfg, seed=5)
+    ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
+    om = O.OracleModel(cfg, tensors)
+    prompt = _prompt(cfg.vocab_size, 1000)
+    lg = ctx.forward(prompt, 0); lo = om.forward(prompt, 0)
+    assert rel_err(lg, lo) < REL_TOL
+    t = np.array([int(np.argmax(lo))], np.int32)
+    for pos in range(1000, 1024):
+        lg = ctx.forward(t, pos); lo = om.forward(t, pos)
+        assert rel_err(lg, lo) < REL_TOL
+        t = np.array([int(np.argmax(lo))], np.int32)
+    with pytest.raises(gpu.FlmError):
+        ctx.forward(t, 1024)                      # beyond max_seq_len is an error, not a silent wrap
+    ctx.close()
+
+
+def test_errors(gpu):
+    cfg = synth.make_config("tiny", ff.QT_INT8)
+    d = gpu.desc_from_config(cfg)
+    ctx = gpu.Ctx(d)
+    with pytest.raises(gpu.FlmError):             # forward before upload
+        ctx.forward(np.array([1], np.int32), 0)
+    ctx.close()
+    d2 = gpu.desc_from_config(cfg); d2.n_kv_heads = 2
+    with pytest.raises(gpu.FlmError):             # GQA unsupported (reference path is broken)
+        gpu.Ctx(d2)
+    d3 = gpu.desc_from_config(cfg); d3.quant_group_size = 32
+    with pytest.raises(gpu.FlmError):
+        gpu.Ctx(d3)
+
+
+def test_golden_logits_from_reference(gpu):
+    """committed golden vectors produced by the reference binary itself (tests/golden/make_golden.py)."""
+    path = os.path.join(GOLD, "model_tiny_int8.npz")
+    g = np.load(path)
+    cfg = synth.make_config("tiny", ff.QT_INT8)
+    tensors = synth.make_tensors(cfg, seed=int(g["seed"]))
+    ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
+    prompt = g["prompt"]
+    lg = ctx.forward(prompt, 0)
+    assert rel_err(lg, g["logits"][0]) < REL_TOL
+    pos = len(prompt)
+    for i, tok in enumerate(g["ids"][:-1]):
+        lg = ctx.forward(np.array([tok], np.int32), pos)
+        assert rel_err(lg, g["logits"][i + 1]) < REL_TOL
+        if g["margin"][i + 1] > 1e-4:
+            assert int(np.argmax(lg)) == int(g["ids"][i + 1])
+        pos += 1
+    ctx.close()
