@@ -21,9 +21,9 @@ KCLASSES = ("embed", "qkv", "attn", "attn_o", "ffn13", "ffn2", "cls", "argmax", 
 SYMBOLS = (
     "flm_comm_unique_id", "flm_ctx_create", "flm_ctx_destroy", "flm_last_error", "flm_upload_tensor",
     "flm_forward", "flm_forward_argmax", "flm_decode_greedy", "flm_decode_timed", "flm_reset_kv", "flm_sync",
-    "flm_kernel_times", "flm_kernel_bytes", "flm_set_option",
+    "flm_kernel_times", "flm_kernel_bytes", "flm_set_option", "flm_debug_read",
     "flm_op_quantize", "flm_op_matmul_q", "flm_op_rmsnorm", "flm_op_swiglu", "flm_op_rope", "flm_op_softmax",
-    "flm_op_attention", "flm_plan_shards",
+    "flm_op_attention", "flm_op_expf", "flm_op_math", "flm_plan_shards",
 )
 
 
@@ -146,6 +146,12 @@ class Ctx:
     def set_option(self, key, value):
         _check(lib().flm_set_option(self._h, key.encode(), int(value)), self._h)
 
+    def debug_read(self, what, layer, n):
+        names = {"x1": 0, "q": 1, "att_out": 2, "hd": 3, "kcache": 4, "vcache": 5, "logits": 6}
+        out = np.empty(n, dtype=np.float32)
+        _check(lib().flm_debug_read(self._h, names[what], int(layer), _p(out), C.c_size_t(n)), self._h)
+        return out
+
     def kernel_times(self, pos, iters=3):
         avg = np.zeros(len(KCLASSES), dtype=np.float32); cnt = np.zeros(len(KCLASSES), dtype=np.int32)
         _check(lib().flm_kernel_times(self._h, int(pos), int(iters), _p(avg), _p(cnt)), self._h)
@@ -200,11 +206,24 @@ def op_softmax(x, n=None):
     return a
 
 
-def op_attention(kc, vc, q, k, v, n_heads, hs, max_seq, pos, n_splits=0):
+def op_expf(x):
+    a = np.array(x, dtype=np.float32, copy=True).reshape(-1)
+    _check(lib().flm_op_expf(_p(a), C.c_size_t(a.size)))
+    return a
+
+
+def op_math(fn, x, y=None):
+    a = np.array(x, dtype=np.float32, copy=True).reshape(-1)
+    b = None if y is None else np.ascontiguousarray(y, dtype=np.float32).reshape(-1)
+    _check(lib().flm_op_math(int(fn), _p(a), _p(b), C.c_size_t(a.size)))
+    return a
+
+
+def op_attention(kc, vc, q, k, v, n_heads, hs, max_seq, pos):
     """kc, vc [n_heads, max_seq, hs] are updated in place; returns out [n_heads*hs]."""
     out = np.empty(n_heads * hs, dtype=np.float32)
     for a in (kc, vc):
         assert a.dtype == np.float32 and a.flags.c_contiguous
     q = np.ascontiguousarray(q, dtype=np.float32); k = np.ascontiguousarray(k, dtype=np.float32); v = np.ascontiguousarray(v, dtype=np.float32)
-    _check(lib().flm_op_attention(_p(out), _p(kc), _p(vc), _p(q), _p(k), _p(v), n_heads, hs, max_seq, int(pos), int(n_splits)))
+    _check(lib().flm_op_attention(_p(out), _p(kc), _p(vc), _p(q), _p(k), _p(v), n_heads, hs, max_seq, int(pos)))
     return out

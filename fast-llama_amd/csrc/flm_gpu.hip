@@ -52,15 +52,15 @@ struct flm_ctx {
     QMat cls; bool got_cls = false;
 
     float *kcache = nullptr, *vcache = nullptr;       // [L][heads_local][max_seq][hs]
-    float *x1 = nullptr, *qbuf = nullptr, *att_out = nullptr, *att_part = nullptr, *hd = nullptr;
+    float *x1 = nullptr, *qbuf = nullptr, *att_out = nullptr, *hd = nullptr;
     float *partial = nullptr, *logits = nullptr;
     float *rope_cos = nullptr, *rope_sin = nullptr;
     DecodeState* state = nullptr; int* prompt_dev = nullptr; int* out_tokens_dev = nullptr;
     int prompt_cap = 0, out_cap = 0;
 
     // options
-    int wg_per_cu = 2; int use_graph = 1; int attn_splits = 0; int attn_wg = 0;
-    std::map<int, hipGraphExec_t> graphs;             // key = splits*4 + with_cls*2 + advance
+    int wg_per_cu = 2; int use_graph = 1;
+    std::map<int, hipGraphExec_t> graphs;             // key = with_cls*4 + advance
     std::vector<TimedLaunch>* timing = nullptr;
     std::string err;
 };
@@ -90,9 +90,9 @@ void split_even(int total, int parts, int idx, int* begin, int* count) {
 // ---------------------------------------------------------------------------------------------
 template <int QT, int PRO, int EPI>
 int launch_gemv_xr(flm_ctx* c, hipStream_t st, const GemvArgs& a, int grid) {
-    const size_t lds = gemv_lds_bytes(a.n, QTraits<QT>::kEsz);
+    const size_t lds = gemv_lds_layout(a.n, QTraits<QT>::kEsz, PRO == PRO_RMSNORM_QUANT).total;
     const int rounds = (a.n + kBlock * 4 - 1) / (kBlock * 4);
-    if (PRO == PRO_NONE || PRO == PRO_ATTN_COMBINE_QUANT) hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 0>), dim3(grid), dim3(kBlock), lds, st, a);
+    if (PRO == PRO_NONE)   hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 0>),  dim3(grid), dim3(kBlock), lds, st, a);
     else if (rounds <= 4)  hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 4>),  dim3(grid), dim3(kBlock), lds, st, a);
     else if (rounds <= 12) hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 12>), dim3(grid), dim3(kBlock), lds, st, a);
     else                   hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 0>),  dim3(grid), dim3(kBlock), lds, st, a);
@@ -102,7 +102,7 @@ int launch_gemv_xr(flm_ctx* c, hipStream_t st, const GemvArgs& a, int grid) {
 template <int PRO, int EPI>
 int launch_gemv(flm_ctx* c, hipStream_t st, int qt, const GemvArgs& a, int grid) {
     if (a.n % kGroup != 0 || a.n <= 0) return fail(c, FLM_ERR_INVALID, "gemv: n must be a positive multiple of 64");
-    if (gemv_lds_bytes(a.n, esz_of(qt)) > 160 * 1024) return fail(c, FLM_ERR_UNSUPPORTED, "gemv: activation vector does not fit LDS");
+    if (gemv_lds_layout(a.n, esz_of(qt), PRO == PRO_RMSNORM_QUANT).total > 160 * 1024) return fail(c, FLM_ERR_UNSUPPORTED, "gemv: activation vector does not fit LDS");
     if (qt == FLM_QT_INT8)  return launch_gemv_xr<QT_INT8, PRO, EPI>(c, st, a, grid);
     if (qt == FLM_QT_INT16) return launch_gemv_xr<QT_INT16, PRO, EPI>(c, st, a, grid);
     return fail(c, FLM_ERR_UNSUPPORTED, "gemv: quant type must be INT8 or INT16");
@@ -213,15 +213,6 @@ bool model_complete(const flm_ctx* c) {
     return true;
 }
 
-int attn_splits_for(const flm_ctx* c, int pos) {
-    if (c->attn_splits > 0) return c->attn_splits;
-    // keep >= ~32 positions per workgroup, at most 8 splits (heads*splits workgroups fill the chip)
-    const int T = pos + 1;
-    int s = 1;
-    while (s < 8 && T / (s * 2) >= 32) s *= 2;
-    return s;
-}
-
 struct Tick {
     flm_ctx* c; hipStream_t st; int kclass; hipEvent_t e0 = nullptr, e1 = nullptr;
     Tick(flm_ctx* c_, hipStream_t st_, int k) : c(c_), st(st_), kclass(k) {
@@ -236,7 +227,7 @@ struct Tick {
 //   with_cls  : run the final norm + classifier (+ argmax)
 //   advance   : 1 = greedy (tok <- argmax, pos++), 0 = leave state (caller copies logits), 2 = prompt feed
 // ---------------------------------------------------------------------------------------------
-int enqueue_token(flm_ctx* c, hipStream_t st, int n_splits, bool with_cls, int advance) {
+int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance) {
     const auto& d = c->d;
     const int qt = d.quant_type, hs = c->hs, L = d.n_layers;
     const bool tp = c->world > 1;
@@ -263,22 +254,19 @@ int enqueue_token(flm_ctx* c, hipStream_t st, int n_splits, bool with_cls, int a
         {   // ATTN task (execute_attn :441-449)
             AttnArgs a{};
             a.q = c->qbuf; a.kcache = c->kcache + (size_t)l * kv_layer; a.vcache = c->vcache + (size_t)l * kv_layer;
-            a.out = n_splits == 1 ? c->att_out : c->att_part; a.pos_ptr = pos_ptr; a.hs = hs; a.max_seq = d.max_seq_len; a.n_splits = n_splits;
-            const int per_max = (d.max_seq_len + n_splits - 1) / n_splits;
+            a.out = c->att_out; a.pos_ptr = pos_ptr; a.hs = hs; a.max_seq = d.max_seq_len;
             Tick t(c, st, KC_ATTN);
-            hipLaunchKernelGGL(k_attn_decode, dim3(c->heads_local, n_splits), dim3(kBlock), attn_lds_bytes(per_max, hs), st, a);
+            hipLaunchKernelGGL(k_attn_decode, dim3(c->heads_local), dim3(kBlock), attn_lds_bytes(d.max_seq_len, hs), st, a);
             HIPC(c, hipGetLastError());
         }
         {   // ATTN_O task + residual (transformer.cpp:138-139, execute_attn_o :457-466)
             GemvArgs a{};
             a.W = w.o.q; a.sW = w.o.s; a.n = c->dim_local; a.items = d.dim;
-            a.x = c->att_out; a.att_part = c->att_part; a.n_splits = n_splits; a.hs = hs;
+            a.x = c->att_out;
             a.out = tp ? c->partial : c->x1;
             Tick t(c, st, KC_ATTN_O);
             const int grid = gemv_grid(c->cu_count, c->wg_per_cu, a.items, 1);
-            int r;
-            if (n_splits == 1) r = tp ? launch_gemv<PRO_QUANT, EPI_STORE>(c, st, qt, a, grid) : launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, a, grid);
-            else r = tp ? launch_gemv<PRO_ATTN_COMBINE_QUANT, EPI_STORE>(c, st, qt, a, grid) : launch_gemv<PRO_ATTN_COMBINE_QUANT, EPI_RESIDUAL>(c, st, qt, a, grid);
+            int r = tp ? launch_gemv<PRO_QUANT, EPI_STORE>(c, st, qt, a, grid) : launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, a, grid);
             if (r) return r;
         }
         if (tp) {
@@ -337,15 +325,14 @@ int enqueue_token(flm_ctx* c, hipStream_t st, int n_splits, bool with_cls, int a
 }
 
 // run one token, through a cached hipGraph when enabled
-int run_token(flm_ctx* c, int pos_host, bool with_cls, int advance) {
-    const int S = attn_splits_for(c, pos_host);
-    if (!c->use_graph || c->timing || c->world > 1) return enqueue_token(c, c->stream, S, with_cls, advance);
-    const int key = S * 8 + (with_cls ? 4 : 0) + advance;
+int run_token(flm_ctx* c, bool with_cls, int advance) {
+    if (!c->use_graph || c->timing || c->world > 1) return enqueue_token(c, c->stream, with_cls, advance);
+    const int key = (with_cls ? 4 : 0) + advance;
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
         hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
         HIPC(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        int r = enqueue_token(c, c->stream, S, with_cls, advance);
+        int r = enqueue_token(c, c->stream, with_cls, advance);
         hipError_t e = hipStreamEndCapture(c->stream, &g);
         if (r) { if (g) hipGraphDestroy(g); return r; }
         HIPC(c, e);
@@ -392,14 +379,14 @@ int feed(flm_ctx* c, const int32_t* tokens, int n, int pos, int final_advance) {
     HIPC(c, hipMemcpyAsync(c->prompt_dev, tokens, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
     DecodeState s{pos, tokens[0], 0, 0};
     HIPC(c, hipMemcpyAsync(c->state, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
-    for (int i = 0; i + 1 < n; ++i) { r = run_token(c, pos + i, false, 2); if (r) return r; }
+    for (int i = 0; i + 1 < n; ++i) { r = run_token(c, false, 2); if (r) return r; }
     // last token: classifier; state.step is reset so out_tokens[0] receives the argmax
     if (n > 1) {
         // step was used as the prompt cursor; zero it for the argmax slot
         hipLaunchKernelGGL(k_set_step, dim3(1), dim3(64), 0, c->stream, c->state, 0);
         HIPC(c, hipGetLastError());
     }
-    return run_token(c, pos + n - 1, true, final_advance);
+    return run_token(c, true, final_advance);
 }
 
 } // namespace
@@ -456,7 +443,7 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
     if (d.n_kv_heads != d.n_heads) return fail(nullptr, FLM_ERR_UNSUPPORTED, "n_kv_heads != n_heads: the reference's grouped-query path is broken (transformer.cpp:449); not reproduced");
     if (d.dim % d.n_heads || d.dim % kGroup || d.hidden_dim % kGroup) return fail(nullptr, FLM_ERR_INVALID, "dim/hidden_dim must be multiples of 64 and dim of n_heads");
     const int hs = d.dim / d.n_heads;
-    if (hs % 4 || hs > 256 || hs < 8) return fail(nullptr, FLM_ERR_UNSUPPORTED, "head_size must be a multiple of 4 in [8,256]");
+    if (hs % 8 || hs < 32) return fail(nullptr, FLM_ERR_UNSUPPORTED, "head_size must be a multiple of 8 and >= 32 (the reference's 8-lane dot_product path, x86_simd.cpp:1677-1699)");
     if (world < 1 || rank < 0 || rank >= world) return fail(nullptr, FLM_ERR_INVALID, "rank/world");
     if (world > 1 && (hs % kGroup)) return fail(nullptr, FLM_ERR_UNSUPPORTED, "tensor parallelism needs head_size % 64 == 0 (quant groups may not straddle ranks)");
     if (world > 1 && !comm_id) return fail(nullptr, FLM_ERR_INVALID, "comm_id required when world > 1");
@@ -495,7 +482,6 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
     HIPB(hipMemsetAsync(c->kcache, 0, kvn * 4, c->stream)); HIPB(hipMemsetAsync(c->vcache, 0, kvn * 4, c->stream));
     HIPB(hipMalloc((void**)&c->x1, d.dim * 4)); HIPB(hipMalloc((void**)&c->qbuf, c->dim_local * 4));
     HIPB(hipMalloc((void**)&c->att_out, c->dim_local * 4));
-    HIPB(hipMalloc((void**)&c->att_part, (size_t)c->heads_local * 8 * (hs + kAttnPartPad) * 4));
     HIPB(hipMalloc((void**)&c->hd, c->hidden_local * 4)); HIPB(hipMalloc((void**)&c->partial, d.dim * 4));
     HIPB(hipMalloc((void**)&c->logits, (size_t)c->vocab_slot * world * 4));
     HIPB(hipMemsetAsync(c->logits, 0, (size_t)c->vocab_slot * world * 4, c->stream));
@@ -520,7 +506,7 @@ void flm_ctx_destroy(flm_ctx* c) {
     auto fq = [](QMat& m) { if (m.q) hipFree(m.q); if (m.s) hipFree(m.s); };
     for (auto& l : c->layers) { fq(l.qkv); fq(l.o); fq(l.w1); fq(l.w3); fq(l.w2); if (l.att_norm) hipFree(l.att_norm); if (l.ffn_norm) hipFree(l.ffn_norm); }
     fq(c->cls);
-    void* ptrs[] = {c->emb, c->emb_s, c->out_norm, c->kcache, c->vcache, c->x1, c->qbuf, c->att_out, c->att_part, c->hd, c->partial,
+    void* ptrs[] = {c->emb, c->emb_s, c->out_norm, c->kcache, c->vcache, c->x1, c->qbuf, c->att_out, c->hd, c->partial,
                     c->logits, c->rope_cos, c->rope_sin, c->state, c->prompt_dev, c->out_tokens_dev};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->comm) ncclCommDestroy(c->comm);
@@ -533,7 +519,6 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     std::string k(key);
     if (k == "wg_per_cu") c->wg_per_cu = value > 0 ? value : 2;
     else if (k == "use_graph") c->use_graph = value;
-    else if (k == "attn_splits") c->attn_splits = value;
     else return fail(c, FLM_ERR_INVALID, "unknown option");
     for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
     c->graphs.clear();
@@ -610,6 +595,28 @@ int flm_reset_kv(flm_ctx* c) {
     return FLM_OK;
 }
 
+// debugging tap (tests): copy an internal device buffer to the host. what: 0 x1, 1 q, 2 att_out, 3 hd, 4 kcache(layer), 5 vcache(layer), 6 logits
+int flm_debug_read(flm_ctx* c, int what, int layer, float* out, size_t n) {
+    if (!c || !out) return FLM_ERR_INVALID;
+    HIPC(c, hipSetDevice(c->device));
+    const size_t kvl = (size_t)c->heads_local * c->d.max_seq_len * c->hs;
+    const float* src = nullptr; size_t cap = 0;
+    switch (what) {
+    case 0: src = c->x1; cap = c->d.dim; break;
+    case 1: src = c->qbuf; cap = c->dim_local; break;
+    case 2: src = c->att_out; cap = c->dim_local; break;
+    case 3: src = c->hd; cap = c->hidden_local; break;
+    case 4: src = c->kcache + (size_t)layer * kvl; cap = kvl; break;
+    case 5: src = c->vcache + (size_t)layer * kvl; cap = kvl; break;
+    case 6: src = c->logits; cap = (size_t)c->vocab_slot * c->world; break;
+    default: return fail(c, FLM_ERR_INVALID, "debug_read: unknown buffer");
+    }
+    if (n > cap || layer < 0 || layer >= c->d.n_layers) return fail(c, FLM_ERR_INVALID, "debug_read: size/layer");
+    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipMemcpy(out, src, n * 4, hipMemcpyDeviceToHost));
+    return FLM_OK;
+}
+
 int flm_sync(flm_ctx* c) { if (!c) return FLM_ERR_INVALID; HIPC(c, hipSetDevice(c->device)); HIPC(c, hipStreamSynchronize(c->stream)); return FLM_OK; }
 
 int flm_forward(flm_ctx* c, const int32_t* tokens, int n, int pos, float* logits_host) {
@@ -637,7 +644,7 @@ static int decode_loop(flm_ctx* c, int32_t first_token, int pos, int n_steps, hi
     DecodeState s{pos, first_token, 0, 0};
     HIPC(c, hipMemcpyAsync(c->state, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
     if (e0) HIPC(c, hipEventRecord(e0, c->stream));
-    for (int i = 0; i < n_steps; ++i) { r = run_token(c, pos + i, true, 1); if (r) return r; }
+    for (int i = 0; i < n_steps; ++i) { r = run_token(c, true, 1); if (r) return r; }
     if (e1) HIPC(c, hipEventRecord(e1, c->stream));
     return FLM_OK;
 }
@@ -669,7 +676,7 @@ int flm_kernel_times(flm_ctx* c, int pos, int iters, float* avg_us, int32_t* cou
         DecodeState s{pos, 1 % c->d.vocab_size, 0, 0};
         HIPC(c, hipMemcpyAsync(c->state, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
         std::vector<TimedLaunch> tl; c->timing = &tl;
-        r = enqueue_token(c, c->stream, attn_splits_for(c, pos), true, 1);
+        r = enqueue_token(c, c->stream, true, 1);
         c->timing = nullptr;
         hipStreamSynchronize(c->stream);
         for (auto& t : tl) {
@@ -790,14 +797,13 @@ int flm_op_softmax(float* x, int n) {
 }
 
 int flm_op_attention(float* out, float* kc, float* vc, const float* q, const float* k, const float* v,
-                     int n_heads, int hs, int max_seq, int pos, int n_splits) {
-    if (!out || !kc || !vc || !q || !k || !v || n_heads < 1 || hs < 8 || hs % 4 || hs > 256 || pos < 0 || pos >= max_seq) return FLM_ERR_INVALID;
-    if (n_splits < 0 || n_splits > 8) return FLM_ERR_INVALID;
+                     int n_heads, int hs, int max_seq, int pos) {
+    if (!out || !kc || !vc || !q || !k || !v || n_heads < 1 || hs < 32 || hs % 8 || pos < 0 || pos >= max_seq) return FLM_ERR_INVALID;
     const size_t nd = (size_t)n_heads * hs, nc = (size_t)n_heads * max_seq * hs, h2 = hs / 2;
     std::vector<float> cs, sn; build_rope_table(hs, pos + 1, cs, sn);
-    DevBuf dq, dk, dv, dkc, dvc, dout, dpart, dc, dsn, dpos;
+    DevBuf dq, dk, dv, dkc, dvc, dout, dc, dsn, dpos;
     if (dq.alloc(nd * 4) || dk.alloc(nd * 4) || dv.alloc(nd * 4) || dkc.alloc(nc * 4) || dvc.alloc(nc * 4) || dout.alloc(nd * 4) ||
-        dpart.alloc((size_t)n_heads * 8 * (hs + kAttnPartPad) * 4) || dc.alloc(h2 * 4) || dsn.alloc(h2 * 4) || dpos.alloc(4)) return FLM_ERR_OOM;
+        dc.alloc(h2 * 4) || dsn.alloc(h2 * 4) || dpos.alloc(4)) return FLM_ERR_OOM;
     OPC(hipMemcpy(dq.p, q, nd * 4, hipMemcpyHostToDevice)); OPC(hipMemcpy(dk.p, k, nd * 4, hipMemcpyHostToDevice)); OPC(hipMemcpy(dv.p, v, nd * 4, hipMemcpyHostToDevice));
     OPC(hipMemcpy(dkc.p, kc, nc * 4, hipMemcpyHostToDevice)); OPC(hipMemcpy(dvc.p, vc, nc * 4, hipMemcpyHostToDevice));
     OPC(hipMemcpy(dc.p, cs.data() + (size_t)pos * h2, h2 * 4, hipMemcpyHostToDevice)); OPC(hipMemcpy(dsn.p, sn.data() + (size_t)pos * h2, h2 * 4, hipMemcpyHostToDevice));
@@ -805,17 +811,27 @@ int flm_op_attention(float* out, float* kc, float* vc, const float* q, const flo
     hipLaunchKernelGGL(k_op_kv_append, dim3((unsigned)((nd / 2 + 255) / 256)), dim3(256), 0, 0, dq.as<float>(), (const float*)dk.as<float>(), (const float*)dv.as<float>(),
                        dkc.as<float>(), dvc.as<float>(), (const float*)dc.as<float>(), (const float*)dsn.as<float>(), n_heads, hs, max_seq, pos);
     OPC(hipGetLastError());
-    int S = n_splits;
-    if (S == 0) { S = 1; while (S < 8 && (pos + 1) / (S * 2) >= 32) S *= 2; }
-    AttnArgs a{}; a.q = dq.as<float>(); a.kcache = dkc.as<float>(); a.vcache = dvc.as<float>(); a.pos_ptr = dpos.as<int>(); a.hs = hs; a.max_seq = max_seq; a.n_splits = S;
-    a.out = S == 1 ? dout.as<float>() : dpart.as<float>();
-    hipLaunchKernelGGL(k_attn_decode, dim3(n_heads, S), dim3(kBlock), attn_lds_bytes((max_seq + S - 1) / S, hs), 0, a);
+    AttnArgs a{}; a.q = dq.as<float>(); a.kcache = dkc.as<float>(); a.vcache = dvc.as<float>(); a.pos_ptr = dpos.as<int>(); a.hs = hs; a.max_seq = max_seq;
+    a.out = dout.as<float>();
+    hipLaunchKernelGGL(k_attn_decode, dim3(n_heads), dim3(kBlock), attn_lds_bytes(max_seq, hs), 0, a);
     OPC(hipGetLastError());
-    if (S > 1) { hipLaunchKernelGGL(k_op_attn_combine, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, 0, dout.as<float>(), (const float*)dpart.as<float>(), n_heads, hs, S); OPC(hipGetLastError()); }
     OPC(hipDeviceSynchronize());
     OPC(hipMemcpy(out, dout.p, nd * 4, hipMemcpyDeviceToHost));
     OPC(hipMemcpy(kc, dkc.p, nc * 4, hipMemcpyDeviceToHost)); OPC(hipMemcpy(vc, dvc.p, nc * 4, hipMemcpyDeviceToHost));
     return FLM_OK;
 }
+
+/* elementary functions exactly as the kernels evaluate them (tests pin them against the host's IEEE results) */
+int flm_op_math(int fn, float* x, const float* y, size_t n) {
+    if (!x || n == 0 || fn < 0 || fn > 3 || (fn >= 2 && !y)) return FLM_ERR_INVALID;
+    DevBuf d, e; if (d.alloc(n * 4) || e.alloc(n * 4)) return FLM_ERR_OOM;
+    OPC(hipMemcpy(d.p, x, n * 4, hipMemcpyHostToDevice));
+    if (y) OPC(hipMemcpy(e.p, y, n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_op_math, dim3(1024), dim3(256), 0, 0, fn, d.as<float>(), (const float*)e.as<float>(), n);
+    OPC(hipGetLastError()); OPC(hipDeviceSynchronize());
+    OPC(hipMemcpy(x, d.p, n * 4, hipMemcpyDeviceToHost));
+    return FLM_OK;
+}
+int flm_op_expf(float* x, size_t n) { return flm_op_math(0, x, nullptr, n); }
 
 } // extern "C"

@@ -3,16 +3,35 @@
 // Everything here is written for wave64 / MI355X only.  Reference citations are paths inside
 // CoderLSF/fast-llama (the CPU engine whose arithmetic these kernels reproduce).
 //
+// DESIGN RULE: every fp32 value is produced with the SAME operations in the SAME order as the
+// reference's x86 build (-O3 -mfma, FMA-contracted), so results are BIT-IDENTICAL to the CPU path.
+// This is not pedantry: the reference quantizer q = trunc(x / (max|x|/127)) puts the largest
+// element of every 64-group exactly on a truncation boundary (x_max/scale = 127 +- 1 ulp), so a
+// 1-ulp difference anywhere upstream flips int8 values 126 <-> 127 chaotically and logits drift by
+// 1e-2 -- far outside the 1e-3 parity bound.  Integer work (the int8/int16 dots, max, argmax) is
+// order-free and fully parallel; every fp32 accumulation is a chain in reference order:
+//   * GEMV      : exact int32 group dots in parallel, then acc = fma(sW*sX, float(dot_g), acc), g ascending
+//   * rmsnorm   : sum of squares as the reference's 4 strided SSE lanes, each a sequential FMA chain
+//   * attention : q.k as 8 strided lanes + sequential lane sum; glibc-exact expf; sequential softmax
+//                 sum; weighted V sum sequential over positions
+//
 // Kernel inventory (one decode token = embed + L x {qkv, attn, attn_o, ffn13, ffn2} + cls + argmax):
-//   k_gemv<QT,PRO,EPI>   group-quantized GEMV  out = W.q(x), HBM-bound; fused prologue
-//                        (rmsnorm+quantize | quantize | split-attention combine+quantize) and
-//                        epilogue (store | residual add | SwiGLU | RoPE + KV-cache append)
-//   k_attn_decode        fp32 single-query attention over the fp32 KV cache, split over positions
-//   k_embed, k_argmax    embedding row gather, first-max argmax
+//   k_gemv<QT,PRO,EPI,XR> group-quantized GEMV, HBM-bound; fused prologue (rmsnorm+quantize | quantize)
+//                         and epilogue (store | residual add | SwiGLU | RoPE + KV-cache append)
+//   k_attn_decode         fp32 single-query attention over the fp32 KV cache
+//   k_embed, k_argmax_advance
 // plus small op-level kernels that expose the same __device__ functions to the parity tests.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+// Bit-exactness hygiene (see DESIGN RULE above):
+//  * no implicit FMA contraction anywhere in this TU -- every fused multiply-add is written as fmaf()/fma().
+//    (HIP's __fmul_rn/__fadd_rn are plain operators and WOULD be contracted under the default
+//    -ffp-contract=fast; __graft_entry__.build() also passes -ffp-contract=off.)
+//  * sqrt via __builtin_sqrtf / division via operator/ : IEEE-correct under hipcc's default
+//    -fhip-fp32-correctly-rounded-divide-sqrt.  HIP's __fsqrt_rn maps to the 1-ulp native sqrt: never used.
+#pragma clang fp contract(off)
 
 namespace flm {
 
@@ -22,34 +41,21 @@ constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kGroup = 64;            // quantization group (QUANT_GROUP_SIZE, the only value the reference uses)
 
 enum { QT_INT16 = 1, QT_INT8 = 2 };
-enum Prologue { PRO_NONE = 0, PRO_QUANT = 1, PRO_RMSNORM_QUANT = 2, PRO_ATTN_COMBINE_QUANT = 3 };
+enum Prologue { PRO_NONE = 0, PRO_QUANT = 1, PRO_RMSNORM_QUANT = 2 };
 enum Epilogue { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_ROPE_KV = 3 };
 
 template <int QT> struct QTraits;
 template <> struct QTraits<QT_INT8>  { using elem = int8_t;  static constexpr int kEsz = 1; static constexpr int kEPC = 16; static constexpr float kF = 127.0f; };
 template <> struct QTraits<QT_INT16> { using elem = int16_t; static constexpr int kEsz = 2; static constexpr int kEPC = 8;  static constexpr float kF = 5792.0f; };
-// kEPC = elements per 16-byte chunk; lanes per quant group = 64 / kEPC
+// kEPC = elements per 16-byte chunk; lanes per quant group = 64 / kEPC (4 for int8, 8 for int16)
 
 // ------------------------------------------------------------------------------------------
-// wave / block reductions (wave64: DPP-backed __shfl_xor)
+// block reductions for ORDER-FREE quantities only (max): wave64 xor butterflies
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
-    return v;
-}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
     return v;
-}
-// sum over the 256 threads of the block in a fixed order; red = 4 floats of LDS.  All threads get the result.
-__device__ __forceinline__ float block_sum(float v, float* red) {
-    v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return ((red[0] + red[1]) + red[2]) + red[3];
 }
 __device__ __forceinline__ float block_max(float v, float* red) {
     v = wave_max(v);
@@ -58,10 +64,60 @@ __device__ __forceinline__ float block_max(float v, float* red) {
     __syncthreads();
     return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
+// exact integer sum over the 4 lanes of a quad (DPP quad_perm, no LDS)
+__device__ __forceinline__ int quad_sum(int p) {
+    p += __builtin_amdgcn_update_dpp(0, p, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+    p += __builtin_amdgcn_update_dpp(0, p, 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, true);
+    return p;
+}
 
 // ------------------------------------------------------------------------------------------
 // scalar pieces shared by the fused kernels and the op-level test kernels
 // ------------------------------------------------------------------------------------------
+// glibc 2.35 expf (sysdeps/ieee754/flt-32/e_expf.c, the Arm optimized-routines algorithm): the
+// reference calls libm's expf in softmax_sisd (tf_operators.cpp:180) and swiglu (x86_simd.cpp:1768).
+// Evaluated in double exactly as libm does: z = x*N/ln2, k = round(z), 2^(k/N) from a 32-entry table,
+// cubic in r = z - k.  The table is tab[i] = bits(2^(i/32)) - (i << 47), recomputed at 60 digits;
+// this routine was checked bit-for-bit against libm's expf on 6e7 inputs on the build host
+// (tools/check_expf.c) and is checked again on the GPU by tests/test_gpu_ops.py::test_expf_bit_exact.
+__device__ const unsigned long long kExp2fTab[32] = {
+    0x3ff0000000000000ULL, 0x3fefd9b0d3158574ULL, 0x3fefb5586cf9890fULL, 0x3fef9301d0125b51ULL,
+    0x3fef72b83c7d517bULL, 0x3fef54873168b9aaULL, 0x3fef387a6e756238ULL, 0x3fef1e9df51fdee1ULL,
+    0x3fef06fe0a31b715ULL, 0x3feef1a7373aa9cbULL, 0x3feedea64c123422ULL, 0x3feece086061892dULL,
+    0x3feebfdad5362a27ULL, 0x3feeb42b569d4f82ULL, 0x3feeab07dd485429ULL, 0x3feea47eb03a5585ULL,
+    0x3feea09e667f3bcdULL, 0x3fee9f75e8ec5f74ULL, 0x3feea11473eb0187ULL, 0x3feea589994cce13ULL,
+    0x3feeace5422aa0dbULL, 0x3feeb737b0cdc5e5ULL, 0x3feec49182a3f090ULL, 0x3feed503b23e255dULL,
+    0x3feee89f995ad3adULL, 0x3feeff76f2fb5e47ULL, 0x3fef199bdd85529cULL, 0x3fef3720dcef9069ULL,
+    0x3fef5818dcfba487ULL, 0x3fef7c97337b9b5fULL, 0x3fefa4afa2a490daULL, 0x3fefd0765b6e4540ULL};
+
+__device__ __forceinline__ float expf_ref(float x) {
+    const uint32_t ix = __float_as_uint(x);
+    const uint32_t abstop = (ix >> 20) & 0x7ff;
+    if (abstop >= (0x42b00000u >> 20)) {                       // |x| >= 88 or NaN/inf
+        if (ix == 0xff800000u) return 0.0f;                    // -inf
+        if (abstop >= (0x7f800000u >> 20)) return x + x;       // +inf, NaN
+        if (x > 0x1.62e42ep6f) return INFINITY;                // overflow
+        if (x < -0x1.9fe368p6f) return 0.0f;                   // underflow
+        if (x < -0x1.9d1d9ep6f) return __fmul_rn(0x1.4p-75f, 0x1.4p-75f);   // __math_may_uflowf
+    }
+    constexpr double N = 32.0;
+    constexpr double InvLn2N = 0x1.71547652b82fep+0 * N, SHIFT = 0x1.8p+52;
+    constexpr double C0 = 0x1.c6af84b912394p-5 / N / N / N, C1 = 0x1.ebfce50fac4f3p-3 / N / N, C2 = 0x1.62e42ff0c52d6p-1 / N;
+    double z = __dmul_rn(InvLn2N, (double)x);
+    double kd = __dadd_rn(z, SHIFT);
+    const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+    kd = __dsub_rn(kd, SHIFT);
+    const double r = __dsub_rn(z, kd);
+    const unsigned long long t = kExp2fTab[ki % 32] + (ki << 47);
+    const double s = __longlong_as_double((long long)t);
+    z = __fma_rn(C0, r, C1);
+    const double r2 = __dmul_rn(r, r);
+    double y = __fma_rn(C2, r, 1.0);
+    y = __fma_rn(z, r2, y);
+    y = __dmul_rn(y, s);
+    return (float)y;
+}
+
 // quant::quantize<T> element step (src/blas/quant_operators.cpp:26-47): q = (T)(x / r), C truncation.
 // r == 0 (all-zero group): x/r is NaN; the x86 reference yields 0, stated explicitly here.
 __device__ __forceinline__ int quant_elem(float x, float r) {
@@ -71,11 +127,12 @@ __device__ __forceinline__ int quant_elem(float x, float r) {
 // simd::rmsnorm scale (src/platforms/arch/x86_simd.cpp:1754-1756): r = float(1. / sqrtf(ss/n + 1e-5f))
 __device__ __forceinline__ float rms_scale(float ss, int n) {
     float v = __fadd_rn(__fdiv_rn(ss, (float)n), 1e-5f);
-    return (float)(1.0 / (double)__fsqrt_rn(v));
+    return (float)(1.0 / (double)__builtin_sqrtf(v));
 }
-// simd::swiglu (x86_simd.cpp:1766-1770): evaluated in double, rounded to float
+// simd::swiglu (x86_simd.cpp:1766-1770): xo / (1. + expf(-xo)) * xr evaluated in double, rounded to float
 __device__ __forceinline__ float swiglu_elem(float a, float b) {
-    return (float)((double)a / (1.0 + (double)expf(-a)) * (double)b);
+    const double e = (double)expf_ref(-a);
+    return (float)__dmul_rn(__ddiv_rn((double)a, __dadd_rn(1.0, e)), (double)b);
 }
 // rope_v2 pair (src/blas/tf_operators.cpp:398-401) with the reference build's FMA contraction
 __device__ __forceinline__ void rope_pair(float x0, float x1, float c, float s, float& o0, float& o1) {
@@ -92,11 +149,13 @@ __device__ __forceinline__ int dot16_i8(const v4i& w, const v4i& a, int acc) {
     return acc;
 }
 typedef short short2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ short2_t as_short2(int v) { return __builtin_bit_cast(short2_t, v); }   // by value: bit_cast of a vector-element lvalue miscompiles
 __device__ __forceinline__ int dot8_i16(const v4i& w, const v4i& a, int acc) {
-    acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, w.x), __builtin_bit_cast(short2_t, a.x), acc, false);
-    acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, w.y), __builtin_bit_cast(short2_t, a.y), acc, false);
-    acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, w.z), __builtin_bit_cast(short2_t, a.z), acc, false);
-    acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, w.w), __builtin_bit_cast(short2_t, a.w), acc, false);
+    const int w0 = w.x, w1 = w.y, w2 = w.z, w3 = w.w, a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w;
+    acc = __builtin_amdgcn_sdot2(as_short2(w0), as_short2(a0), acc, false);
+    acc = __builtin_amdgcn_sdot2(as_short2(w1), as_short2(a1), acc, false);
+    acc = __builtin_amdgcn_sdot2(as_short2(w2), as_short2(a2), acc, false);
+    acc = __builtin_amdgcn_sdot2(as_short2(w3), as_short2(a3), acc, false);
     return acc;
 }
 template <int QT> __device__ __forceinline__ int dot_chunk(const v4i& w, const v4i& a) {
@@ -116,20 +175,40 @@ struct GemvArgs {
     const float* x;                             // fp32 activation [n]          (QUANT / RMSNORM_QUANT)
     const float* norm_w;                        // rmsnorm weight [n]           (RMSNORM_QUANT)
     const void*  xq; const float* xs;           // pre-quantized activation     (NONE)
-    const float* att_part; int n_splits; int hs;// split-attention partials     (ATTN_COMBINE_QUANT)
     // epilogue outputs
     float* out;                                 // STORE: out[row]; RESIDUAL: out[row] += ; SWIGLU: hd[i]; ROPE_KV: q[row]
     float* kcache; float* vcache;               // ROPE_KV: this layer's caches [heads][max_seq][hs]
     const float* rope_cos; const float* rope_sin; // [max_seq][hs/2]
     const int* pos_ptr;                         // device-resident position
-    int dim; int kv_dim; int max_seq;           // ROPE_KV geometry (hs reused)
+    int dim; int kv_dim; int max_seq; int hs;   // ROPE_KV geometry
     // debugging taps used by the op-level exports (may be null)
     void* dbg_xq; float* dbg_xs; float* dbg_xn;
 };
 
-// LDS layout: [xq : n*esz bytes (16-aligned)] [xs : n/64 floats] [red : 8 floats]
-__host__ __device__ inline size_t gemv_lds_bytes(int n, int esz) {
-    return (size_t)n * esz + (size_t)(n / kGroup) * 4 + 64;
+constexpr int kRows = 4;               // rows per wave batch (4 rows x 4 chunks x 16 B in flight per lane)
+constexpr int kChainPad = 4;           // LDS row padding (dwords) of the per-wave chain scratch: no bank conflicts, keeps 16-B alignment
+
+// LDS layout: [xq : n*esz] [xs : n/64 floats, padded to 16 B] [red : 16 floats] [scratch]
+// scratch = max( rmsnorm transpose staging 4n bytes , 4 waves x { dsub[kRows][dstride] ints, sprod[kRows][sstride] floats } )
+struct GemvLds {
+    int off_xs, off_red, off_scr;     // byte offsets
+    int dstride, sstride;             // dwords; multiples of 4 so every row strip is 16-B aligned
+    int wave_bytes;                   // chain scratch per wave
+    int total;                        // bytes
+};
+__host__ __device__ inline GemvLds gemv_lds_layout(int n, int esz, bool norm) {
+    GemvLds L;
+    const int sn = n / kGroup, nq = n * esz / 64;
+    L.off_xs = n * esz;
+    L.off_red = L.off_xs + ((sn * 4 + 15) & ~15);
+    L.off_scr = L.off_red + 64;
+    L.dstride = ((nq + 3) & ~3) + kChainPad;
+    L.sstride = ((sn + 3) & ~3) + kChainPad;
+    L.wave_bytes = kRows * (L.dstride + L.sstride) * 4;
+    int scratch = L.wave_bytes * kWavesPerBlock;
+    if (norm && n * 4 > scratch) scratch = n * 4;
+    L.total = L.off_scr + scratch;
+    return L;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -138,13 +217,11 @@ __host__ __device__ inline size_t gemv_lds_bytes(int n, int esz) {
 //   RMSNORM_QUANT == x2.rmsnorm(x1, w) ; qx.quantize(x2)   (transformer.cpp:132-134, 144-146, 155-156)
 //   QUANT         == qx.quantize(x2) / qh.quantize(hd)     (transformer.cpp:138, 149)
 // Thread t owns elements 4t..4t+3 (+1024 per round): 16 consecutive lanes own one 64-group, so the
-// group max is a 16-lane xor-butterfly.
-// ------------------------------------------------------------------------------------------
+// group max (order-free) is a 16-lane xor-butterfly.
 // The first XR rounds of x (and of the norm weight) are handed in as registers that the caller
 // loaded BEFORE issuing its first batch of weight loads: loads return in issue order, so an x load
 // issued behind 32 HBM weight loads would make the whole prologue wait for them.
-constexpr int kAttnPartPad = 4;       // split-attention partial record: [m, l, -, -, o[hs]]
-
+// ------------------------------------------------------------------------------------------
 template <int QT, int PRO, int XR>
 __device__ __forceinline__ void gemv_preload(const GemvArgs& a, float4 (&xv)[XR > 0 ? XR : 1], float4 (&wv)[XR > 0 ? XR : 1]) {
     if constexpr (PRO == PRO_QUANT || PRO == PRO_RMSNORM_QUANT) {
@@ -163,9 +240,11 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
     using T = QTraits<QT>;
     const int n = a.n;
     const int tid = threadIdx.x;
+    const GemvLds L = gemv_lds_layout(n, T::kEsz, PRO == PRO_RMSNORM_QUANT);
     char*  xq = lds;
-    float* xs = reinterpret_cast<float*>(lds + (size_t)n * T::kEsz);
-    float* red = xs + n / kGroup;
+    float* xs = reinterpret_cast<float*>(lds + L.off_xs);
+    float* red = reinterpret_cast<float*>(lds + L.off_red);
+    float* scratch = reinterpret_cast<float*>(lds + L.off_scr);
 
     if constexpr (PRO == PRO_NONE) {
         // copy pre-quantized activation (op-level matmul and generic callers)
@@ -177,21 +256,39 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
         return;
     } else {
         const int rounds = (n + kBlock * 4 - 1) / (kBlock * 4);
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         float r = 1.0f;
         if constexpr (PRO == PRO_RMSNORM_QUANT) {
-            float ss = 0.f;
-            auto sq = [&](const float4& v) {
-                ss = __fmaf_rn(v.x, v.x, ss); ss = __fmaf_rn(v.y, v.y, ss);
-                ss = __fmaf_rn(v.z, v.z, ss); ss = __fmaf_rn(v.w, v.w, ss);
+            // simd::square_sum -> square_sum_avx128 (x86_simd.cpp:942-960; the AVX2 branch is dead, :1093):
+            // lane c of 4 accumulates x[c], x[c+4], x[c+8]... by FMA, then res = ((0+l0)+l1)+l2)+l3.
+            // Stage x transposed ([4][n/4]) so that 4 threads can each walk one strided lane sequentially.
+            const int n4 = n / 4;
+            auto stage = [&](int i, const float4& v) {
+                const int k = tid + i * kBlock;
+                if (k < n4) { scratch[k] = v.x; scratch[n4 + k] = v.y; scratch[2 * n4 + k] = v.z; scratch[3 * n4 + k] = v.w; }
             };
 #pragma unroll
-            for (int i = 0; i < XR; ++i) sq(xv[i]);                     // out-of-range lanes hold zeros
+            for (int i = 0; i < XR; ++i) { if (i < rounds) stage(i, xv[i]); }
             for (int i = XR; i < rounds; ++i) {
                 const int e = tid * 4 + i * kBlock * 4;
-                if (e < n) sq(*reinterpret_cast<const float4*>(a.x + e));
+                if (e < n) stage(i, *reinterpret_cast<const float4*>(a.x + e));
             }
-            ss = block_sum(ss, red);
+            __syncthreads();
+            if (tid < 4) {
+                const float* p = scratch + tid * n4;
+                float l = 0.f;
+                int k = 0;
+                for (; k + 3 < n4; k += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(p + k);
+                    l = __fmaf_rn(v.x, v.x, l); l = __fmaf_rn(v.y, v.y, l); l = __fmaf_rn(v.z, v.z, l); l = __fmaf_rn(v.w, v.w, l);
+                }
+                for (; k < n4; ++k) l = __fmaf_rn(p[k], p[k], l);
+                red[8 + tid] = l;
+            }
+            __syncthreads();
+            const float ss = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, red[8]), red[9]), red[10]), red[11]);
             r = rms_scale(ss, n);
+            __syncthreads();                                   // scratch is reused by the GEMV waves below
         }
         // one round: (normalise,) group max over 16 lanes, quantize, pack into LDS
         auto round = [&](int i, float4 v, float4 w) {
@@ -222,46 +319,16 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
                 if ((tid & 15) == 0) xs[e / kGroup] = sc;
             }
         };
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (PRO == PRO_ATTN_COMBINE_QUANT) {
-            for (int i = 0; i < rounds; ++i) {
-                const int e = tid * 4 + i * kBlock * 4;
-                float4 v = z4;
-                if (e < n) {
-                    // merge the split-attention partials of the head that owns e: [m, l, -, -, o[hs]] per split
-                    const int hs = a.hs, S = a.n_splits, ps_stride = hs + kAttnPartPad;
-                    const int h = e / hs, d = e - h * hs;
-                    const float* p = a.att_part + (size_t)h * S * ps_stride;
-                    float M = -INFINITY;
-                    for (int s = 0; s < S; ++s) M = fmaxf(M, p[(size_t)s * ps_stride]);
-                    float L = 0.f; float4 o = z4;
-                    for (int s = 0; s < S; ++s) {
-                        const float* ps = p + (size_t)s * ps_stride;
-                        const float ls = ps[1];
-                        if (ls > 0.f) {
-                            const float w = expf(ps[0] - M);
-                            L = __fmaf_rn(ls, w, L);
-                            const float4 os = *reinterpret_cast<const float4*>(ps + kAttnPartPad + d);
-                            o.x = __fmaf_rn(os.x, w, o.x); o.y = __fmaf_rn(os.y, w, o.y);
-                            o.z = __fmaf_rn(os.z, w, o.z); o.w = __fmaf_rn(os.w, w, o.w);
-                        }
-                    }
-                    v = make_float4(__fdiv_rn(o.x, L), __fdiv_rn(o.y, L), __fdiv_rn(o.z, L), __fdiv_rn(o.w, L));
-                }
-                round(i, v, z4);
-            }
-        } else {
 #pragma unroll
-            for (int i = 0; i < XR; ++i) { if (i < rounds) round(i, xv[i], wv[i]); }
-            for (int i = XR; i < rounds; ++i) {
-                const int e = tid * 4 + i * kBlock * 4;
-                float4 v = z4, w = z4;
-                if (e < n) {
-                    v = *reinterpret_cast<const float4*>(a.x + e);
-                    if constexpr (PRO == PRO_RMSNORM_QUANT) w = *reinterpret_cast<const float4*>(a.norm_w + e);
-                }
-                round(i, v, w);
+        for (int i = 0; i < XR; ++i) { if (i < rounds) round(i, xv[i], wv[i]); }
+        for (int i = XR; i < rounds; ++i) {
+            const int e = tid * 4 + i * kBlock * 4;
+            float4 v = z4, w = z4;
+            if (e < n) {
+                v = *reinterpret_cast<const float4*>(a.x + e);
+                if constexpr (PRO == PRO_RMSNORM_QUANT) w = *reinterpret_cast<const float4*>(a.norm_w + e);
             }
+            round(i, v, w);
         }
         __syncthreads();
         if (a.dbg_xq && blockIdx.x == 0) {
@@ -274,16 +341,17 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
 
 // ------------------------------------------------------------------------------------------
 // The GEMV.  quant::matmul<T> at w == 1 (src/blas/quant_operators.cpp:252-284):
-//     out[r] = sum_g (sW[r,g] * sX[g]) * float( sum_{k<64} W[r,64g+k] * X[64g+k] )
-// Mapping: one wave per row, lanes along K in 16-byte chunks (lane l owns chunks l, l+64, ...), so
-// every weight load is a fully coalesced 1 KiB global_load_dwordx4 and a row is contiguous in HBM.
-// Each lane applies the group scale to its own 16-element (8 for int16) partial dot -- exact in
-// fp32 for int8 (|partial| < 2^24) -- and a 6-step xor butterfly finishes the row.
-// Rows are processed kRows at a time so that kRows*4 x 16 B loads per lane are in flight; with
-// several workgroups per CU that keeps > 100 KB outstanding per CU, enough to cover HBM latency.
+//     out[r] = sum_g (sW[r,g] * sX[g]) * float( sum_{k<64} W[r,64g+k] * X[64g+k] ),   g ASCENDING, FMA per group
+// Mapping: one wave per row batch, lanes along K in 16-byte chunks (lane l owns chunks l, l+64, ...),
+// so every weight load is a fully coalesced 1 KiB global_load_dwordx4 and a row is contiguous in HBM.
+//   1. int32 partial dot per 16-byte chunk (v_dot4 / v_dot2), exact;
+//   2. DPP quad sum -> one int32 per 64 B of the row (= one int8 group; half an int16 group), exact;
+//   3. quad leaders park {int32 sub-dot, sW*sX} in a wave-private LDS strip;
+//   4. lane rr (< kRows) walks row rr's groups in ascending order: acc = fma(sW*sX, float(dot), acc)
+//      -- the reference's summation order, so the fp32 result is bit-identical;
+//   5. lane rr runs the epilogue for row rr.
+// kRows rows are processed per batch so that kRows*4 x 16 B loads per lane are in flight.
 // ------------------------------------------------------------------------------------------
-constexpr int kRows = 4;
-
 template <int QT, int PRO, int EPI, int XR>
 __global__ void __launch_bounds__(kBlock) k_gemv(const GemvArgs a) {
     using T = QTraits<QT>;
@@ -296,7 +364,9 @@ __global__ void __launch_bounds__(kBlock) k_gemv(const GemvArgs a) {
     const int rowbytes = n * T::kEsz;
     const int nchunks = rowbytes / 16;
     const int sn = n / kGroup;
+    const int nq = nchunks / 4;                                               // quads (64-byte pieces) per row
     constexpr int LPG = 64 / T::kEPC;                                         // lanes per quant group
+    constexpr int QPG = LPG / 4;                                              // quads per quant group (1 int8, 2 int16)
 
     // balanced contiguous item range for this wave
     const long long nw = (long long)gridDim.x * kWavesPerBlock;
@@ -357,8 +427,15 @@ __global__ void __launch_bounds__(kBlock) k_gemv(const GemvArgs a) {
 
     gemv_prologue<QT, PRO, XR>(a, lds, xv, nv);
 
+    const GemvLds L = gemv_lds_layout(n, T::kEsz, PRO == PRO_RMSNORM_QUANT);
     const v4i*   xq = reinterpret_cast<const v4i*>(lds);
-    const float* xs = reinterpret_cast<const float*>(lds + (size_t)n * T::kEsz);
+    const float* xs = reinterpret_cast<const float*>(lds + L.off_xs);
+    // wave-private chain scratch
+    const int dstride = L.dstride, sstride = L.sstride;
+    char* wscr = lds + L.off_scr + L.wave_bytes * wave;
+    int*   dsub  = reinterpret_cast<int*>(wscr);                               // [kRows][dstride]
+    float* sprod = reinterpret_cast<float*>(wscr) + kRows * dstride;           // [kRows][sstride]
+    const bool vec_ok = (sn % 4) == 0;                                         // 16-B LDS reads need whole float4s per row
     const int NJ = (nchunks + 63) / 64;
     int pos = 0;
     if constexpr (EPI == EPI_ROPE_KV) pos = *a.pos_ptr;
@@ -370,67 +447,90 @@ __global__ void __launch_bounds__(kBlock) k_gemv(const GemvArgs a) {
             if (lane < kRows && item0 + lane < it1) resid = a.out[item0 + lane];
         }
         if constexpr (EPI == EPI_ROPE_KV) {
-            const int i = item0 + lane;
-            if (lane < IPB && i < it1 && 2 * i < a.dim + a.kv_dim) {
+            const int i = item0 + lane / 2;                 // lanes 2k, 2k+1 serve item k (rows 2i, 2i+1)
+            if (lane < kRows && i < it1 && 2 * i < a.dim + a.kv_dim) {
                 const int row = 2 * i, rr = row < a.dim ? row : row - a.dim;
                 const int d = rr % a.hs;
                 rc = a.rope_cos[(size_t)pos * (a.hs / 2) + d / 2];
                 rs = a.rope_sin[(size_t)pos * (a.hs / 2) + d / 2];
             }
         }
-        float acc[kRows];
-#pragma unroll
-        for (int rr = 0; rr < kRows; ++rr) acc[rr] = 0.f;
         for (int jb = 0; jb < NJ; jb += 4) {
             if (!(item0 == it0 && jb == 0)) load_batch(item0, jb);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int c = lane + 64 * (jb + jj);
-                if (c < nchunks) {
-                    const v4i av = xq[c];
-                    const float sx = xs[c / LPG];
+                const bool cv = c < nchunks;                     // whole quads are in or out (nchunks % 4 == 0)
+                const v4i z = {0, 0, 0, 0};
+                const v4i av = cv ? xq[c] : z;
+                const float sx = cv ? xs[c / LPG] : 0.f;
 #pragma unroll
-                    for (int rr = 0; rr < kRows; ++rr) {
-                        const int p = dot_chunk<QT>(w[rr][jj], av);
-                        acc[rr] = __fmaf_rn(__fmul_rn(sw[rr][jj], sx), (float)p, acc[rr]);
-                    }
+                for (int rr = 0; rr < kRows; ++rr) {
+                    const int d = quad_sum(dot_chunk<QT>(w[rr][jj], av));        // DPP: executed by all lanes
+                    if (cv && (lane & 3) == 0) dsub[rr * dstride + c / 4] = d;
+                    if (cv && (lane & (LPG - 1)) == 0) sprod[rr * sstride + c / LPG] = __fmul_rn(sw[rr][jj], sx);   // s = sW * sX (quant_operators.cpp:274)
                 }
             }
         }
-#pragma unroll
-        for (int rr = 0; rr < kRows; ++rr) acc[rr] = wave_sum(acc[rr]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the reference's fp32 chain, one lane per row: o[j] += s * dot  (FMA), groups ascending
+        float acc = 0.f;
+        if (lane < kRows) {
+            const int*   dp = dsub + lane * dstride;
+            const float* sp = sprod + lane * sstride;
+            int g = 0;
+            for (; vec_ok && g + 3 < sn; g += 4) {
+                const float4 s4 = *reinterpret_cast<const float4*>(sp + g);
+                if constexpr (QPG == 1) {
+                    const int4 d4 = *reinterpret_cast<const int4*>(dp + g);
+                    acc = __fmaf_rn(s4.x, (float)d4.x, acc); acc = __fmaf_rn(s4.y, (float)d4.y, acc);
+                    acc = __fmaf_rn(s4.z, (float)d4.z, acc); acc = __fmaf_rn(s4.w, (float)d4.w, acc);
+                } else {
+                    const int4 da = *reinterpret_cast<const int4*>(dp + 2 * g), db = *reinterpret_cast<const int4*>(dp + 2 * g + 4);
+                    acc = __fmaf_rn(s4.x, (float)(da.x + da.y), acc); acc = __fmaf_rn(s4.y, (float)(da.z + da.w), acc);
+                    acc = __fmaf_rn(s4.z, (float)(db.x + db.y), acc); acc = __fmaf_rn(s4.w, (float)(db.z + db.w), acc);
+                }
+            }
+            for (; g < sn; ++g) {
+                int d = dp[QPG * g];
+                if constexpr (QPG == 2) d += dp[2 * g + 1];
+                acc = __fmaf_rn(sp[g], (float)d, acc);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                         // scratch is rewritten by the next batch
 
-        // ---------------- epilogues (lane ii handles item item0+ii) ----------------
+        // ---------------- epilogues (lane rr holds row rr of the batch) ----------------
         if constexpr (EPI == EPI_STORE || EPI == EPI_RESIDUAL) {
-            const float v = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
             const int row = item0 + lane;
             if (lane < kRows && row < it1) {
-                if constexpr (EPI == EPI_STORE) a.out[row] = v;
-                else a.out[row] = __fadd_rn(resid, v);               // o.add(tmp, offset) transformer.cpp:465,493
+                if constexpr (EPI == EPI_STORE) a.out[row] = acc;
+                else a.out[row] = __fadd_rn(resid, acc);             // o.add(tmp, offset) transformer.cpp:465,493
             }
-        } else if constexpr (EPI == EPI_SWIGLU) {
-            // o1.swiglu(o3) transformer.cpp:481
-            const float g = lane == 0 ? acc[0] : acc[2];
-            const float u = lane == 0 ? acc[1] : acc[3];
-            const int i = item0 + lane;
-            if (lane < IPB && i < it1) a.out[i] = swiglu_elem(g, u);
-        } else {   // EPI_ROPE_KV: rows (2i, 2i+1) of [Wq;Wk;Wv]; RoPE on q and k, append k,v to the cache
-            const float x0 = lane == 0 ? acc[0] : acc[2];
-            const float x1 = lane == 0 ? acc[1] : acc[3];
-            const int i = item0 + lane;
-            if (lane < IPB && i < it1) {
-                const int row = 2 * i, hs = a.hs;
-                if (row < a.dim + a.kv_dim) {
-                    const int rr = row < a.dim ? row : row - a.dim;
-                    const int h = rr / hs, d = rr - h * hs;
-                    float o0, o1;
-                    rope_pair(x0, x1, rc, rs, o0, o1);
-                    if (row < a.dim) { a.out[row] = o0; a.out[row + 1] = o1; }
-                    else { float* kp = a.kcache + ((size_t)h * a.max_seq + pos) * hs + d; kp[0] = o0; kp[1] = o1; }
-                } else {
-                    const int rr = row - a.dim - a.kv_dim;
-                    const int h = rr / hs, d = rr - h * hs;
-                    float* vp = a.vcache + ((size_t)h * a.max_seq + pos) * hs + d; vp[0] = x0; vp[1] = x1;
+        } else {
+            // two-row items: lane 2k has row 0 of item k, lane 2k+1 row 1; bring the partner value over
+            const float other = __shfl_xor(acc, 1, kWave);
+            const int i = item0 + lane / 2;
+            if (lane < kRows && (lane & 1) == 0 && i < it1) {
+                if constexpr (EPI == EPI_SWIGLU) {
+                    a.out[i] = swiglu_elem(acc, other);              // o1.swiglu(o3) transformer.cpp:481
+                } else {   // EPI_ROPE_KV: rows (2i, 2i+1) of [Wq;Wk;Wv]; RoPE on q and k, append k,v to the cache
+                    const float x0 = acc, x1 = other;
+                    const int row = 2 * i, hs = a.hs;
+                    if (row < a.dim + a.kv_dim) {
+                        const int rr = row < a.dim ? row : row - a.dim;
+                        const int h = rr / hs, d = rr - h * hs;
+                        float o0, o1;
+                        rope_pair(x0, x1, rc, rs, o0, o1);
+                        if (row < a.dim) { a.out[row] = o0; a.out[row + 1] = o1; }
+                        else { float* kp = a.kcache + ((size_t)h * a.max_seq + pos) * hs + d; kp[0] = o0; kp[1] = o1; }
+                    } else {
+                        const int rr = row - a.dim - a.kv_dim;
+                        const int h = rr / hs, d = rr - h * hs;
+                        float* vp = a.vcache + ((size_t)h * a.max_seq + pos) * hs + d; vp[0] = x0; vp[1] = x1;
+                    }
                 }
             }
         }
@@ -438,84 +538,83 @@ __global__ void __launch_bounds__(kBlock) k_gemv(const GemvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Decode attention (execute_attn at bs == 1, transformer.cpp:397-455), all fp32.
-//   att[t] = (K[t].q) * 1/sqrt(hs) ; softmax over t <= pos ; o = sum_t att[t] V[t]
-// grid = (heads, splits); a split covers a contiguous range of positions.  With one split the
-// kernel writes the normalised head output; with several it writes (max, sum, unnormalised o) and
-// the consumer's prologue (PRO_ATTN_COMBINE_QUANT) merges them.
-// K/V rows are hs fp32 = hs/4 lanes x float4, so a wave64 load covers 256/hs positions.
+// Decode attention (execute_attn at bs == 1, transformer.cpp:397-455), all fp32, one workgroup per
+// head, bit-exact with the reference's order of operations:
+//   att[t] = dot(K[t], q)           dot_product_avx256 (x86_simd.cpp:1447-1467): 8 strided FMA lanes, summed 0..7
+//   att   *= 1/sqrt(hs)             quant::mul (quant_operators.cpp:425-428)
+//   softmax                         softmax_sisd (tf_operators.cpp:176-186): max, expf, sequential sum, divide
+//   o      = sum_t att[t] V[t]      batch weighted_sum (tf_operators.cpp:325-350): t ascending, FMA,
+//                                   rows t >= 1 with |w| <= 1e-15 skipped
+// Parallelism: phase 1 one position per thread (8 register accumulators), phase 4 one output
+// dimension per thread, sequential over positions -- the chains the reference defines.
 // ------------------------------------------------------------------------------------------
 struct AttnArgs {
     const float* q;          // [heads*hs], RoPE already applied
     const float* kcache;     // [heads][max_seq][hs]
     const float* vcache;
-    float* out;              // n_splits == 1: [heads*hs]; else partials [heads][splits][hs+4] = [m, l, -, -, o[hs]]
+    float* out;              // [heads*hs]
     const int* pos_ptr;
-    int hs, max_seq, n_splits;
+    int hs, max_seq;
 };
 
 __global__ void __launch_bounds__(kBlock) k_attn_decode(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int hs = a.hs, h = blockIdx.x, S = a.n_splits, sp = blockIdx.y;
+    const int hs = a.hs, h = blockIdx.x;
     const int T = *a.pos_ptr + 1;
-    const int per = (T + S - 1) / S;
-    const int t0 = sp * per, t1 = min(T, t0 + per);
-    const int cnt = max(0, t1 - t0);
-    float* sc  = reinterpret_cast<float*>(lds);                 // [per] scores -> probabilities
-    float* red = sc + ((per + 3) & ~3);                          // 8
-    float* ow  = red + 8;                                        // [4][hs] per-wave partial outputs
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int lpp = 1; while (lpp * 4 < hs) lpp <<= 1;                 // lanes per position (power of two)
-    const int ppw = 64 / lpp;                                    // positions per wave instruction
-    const int sub = lane / lpp, li = lane % lpp;
-    const bool dl = li * 4 < hs;                                 // lane carries real dims
+    float* qs  = reinterpret_cast<float*>(lds);                  // [hs]
+    float* red = qs + hs;                                        // 16
+    float* sc  = red + 16;                                       // [T] scores -> probabilities
     const float* K = a.kcache + (size_t)h * a.max_seq * hs;
     const float* V = a.vcache + (size_t)h * a.max_seq * hs;
-    const float scale = (float)(1.0 / (double)__fsqrt_rn((float)hs));   // attn_scale, transformer.cpp:418
+    const float scale = (float)(1.0 / (double)__builtin_sqrtf((float)hs));   // attn_scale, transformer.cpp:418
 
-    float4 qv = dl ? *reinterpret_cast<const float4*>(a.q + (size_t)h * hs + li * 4) : make_float4(0, 0, 0, 0);
+    for (int d = threadIdx.x; d < hs; d += kBlock) qs[d] = a.q[(size_t)h * hs + d];
+    __syncthreads();
     float lmax = -INFINITY;
-    for (int tb = wave * ppw; tb < cnt; tb += kWavesPerBlock * ppw) {
-        const int t = tb + sub;
-        const bool v = t < cnt && dl;
-        float4 kv = v ? *reinterpret_cast<const float4*>(K + (size_t)(t0 + t) * hs + li * 4) : make_float4(0, 0, 0, 0);
-        float d = __fmaf_rn(kv.w, qv.w, __fmaf_rn(kv.z, qv.z, __fmaf_rn(kv.y, qv.y, __fmul_rn(kv.x, qv.x))));
-        for (int o = lpp >> 1; o > 0; o >>= 1) d += __shfl_xor(d, o, kWave);
-        d = __fmul_rn(d, scale);                                // att.multiply(attn_scale) :443
-        if (t < cnt) { if (li == 0) sc[t] = d; lmax = fmaxf(lmax, d); }
-    }
-    const float m = block_max(lmax, red);
-    float lsum = 0.f;
-    for (int t = threadIdx.x; t < cnt; t += kBlock) { const float e = expf(sc[t] - m); sc[t] = e; lsum += e; }   // softmax_sisd :180-183
-    const float L = block_sum(lsum, red);
-    // single split: p = e / L first (softmax_sisd :184-186), then weighted_sum (tf_operators.cpp:325-350)
-    const float inv_mode = (S == 1) ? 1.f : 0.f;
-    float4 o = make_float4(0, 0, 0, 0);
-    for (int tb = wave * ppw; tb < cnt; tb += kWavesPerBlock * ppw) {
-        const int t = tb + sub;
-        if (t < cnt && dl) {
-            const float4 vv = *reinterpret_cast<const float4*>(V + (size_t)(t0 + t) * hs + li * 4);
-            const float p = inv_mode != 0.f ? __fdiv_rn(sc[t], L) : sc[t];
-            o.x = __fmaf_rn(vv.x, p, o.x); o.y = __fmaf_rn(vv.y, p, o.y); o.z = __fmaf_rn(vv.z, p, o.z); o.w = __fmaf_rn(vv.w, p, o.w);
+    for (int t = threadIdx.x; t < T; t += kBlock) {
+        const float* kr = K + (size_t)t * hs;
+        float l[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < hs; i += 8) {
+            const float4 k0 = *reinterpret_cast<const float4*>(kr + i), k1 = *reinterpret_cast<const float4*>(kr + i + 4);
+            const float4 q0 = *reinterpret_cast<const float4*>(qs + i), q1 = *reinterpret_cast<const float4*>(qs + i + 4);
+            l[0] = __fmaf_rn(k0.x, q0.x, l[0]); l[1] = __fmaf_rn(k0.y, q0.y, l[1]); l[2] = __fmaf_rn(k0.z, q0.z, l[2]); l[3] = __fmaf_rn(k0.w, q0.w, l[3]);
+            l[4] = __fmaf_rn(k1.x, q1.x, l[4]); l[5] = __fmaf_rn(k1.y, q1.y, l[5]); l[6] = __fmaf_rn(k1.z, q1.z, l[6]); l[7] = __fmaf_rn(k1.w, q1.w, l[7]);
         }
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tot = __fadd_rn(tot, l[k]);
+        const float s = __fmul_rn(tot, scale);
+        sc[t] = s;
+        lmax = fmaxf(lmax, s);
     }
-    for (int off = lpp; off < 64; off <<= 1) {
-        o.x += __shfl_xor(o.x, off, kWave); o.y += __shfl_xor(o.y, off, kWave);
-        o.z += __shfl_xor(o.z, off, kWave); o.w += __shfl_xor(o.w, off, kWave);
+    const float m = block_max(lmax, red);                          // array_max is order-free
+    for (int t = threadIdx.x; t < T; t += kBlock) sc[t] = expf_ref(__fsub_rn(sc[t], m));
+    __syncthreads();
+    if (threadIdx.x == 0) {                                        // sum += x[i], i ascending (tf_operators.cpp:180-183)
+        float sum = 0.f;
+        int t = 0;
+        for (; t + 3 < T; t += 4) {
+            const float4 e = *reinterpret_cast<const float4*>(sc + t);
+            sum = __fadd_rn(sum, e.x); sum = __fadd_rn(sum, e.y); sum = __fadd_rn(sum, e.z); sum = __fadd_rn(sum, e.w);
+        }
+        for (; t < T; ++t) sum = __fadd_rn(sum, sc[t]);
+        red[8] = sum;
     }
-    if (sub == 0 && dl) *reinterpret_cast<float4*>(ow + wave * hs + li * 4) = o;
+    __syncthreads();
+    const float sum = red[8];
+    for (int t = threadIdx.x; t < T; t += kBlock) sc[t] = __fdiv_rn(sc[t], sum);
     __syncthreads();
     for (int d = threadIdx.x; d < hs; d += kBlock) {
-        const float r = ((ow[d] + ow[hs + d]) + ow[2 * hs + d]) + ow[3 * hs + d];
-        if (S == 1) a.out[(size_t)h * hs + d] = r;
-        else a.out[((size_t)h * S + sp) * (hs + kAttnPartPad) + kAttnPartPad + d] = r;
-    }
-    if (S > 1 && threadIdx.x == 0) {
-        float* p = a.out + ((size_t)h * S + sp) * (hs + kAttnPartPad);
-        p[0] = cnt > 0 ? m : -INFINITY; p[1] = cnt > 0 ? L : 0.f;
+        float o = __fmul_rn(V[d], sc[0]);                          // row 0 always (tf_operators.cpp:331-336)
+        for (int t = 1; t < T; ++t) {
+            const float w = sc[t];
+            if (fabsf(w) <= 1e-15f) continue;                      // weight threshold, transformer.cpp:449
+            o = __fmaf_rn(V[(size_t)t * hs + d], w, o);
+        }
+        a.out[(size_t)h * hs + d] = o;
     }
 }
-__host__ inline size_t attn_lds_bytes(int per, int hs) { return (size_t)(((per + 3) & ~3) + 8 + 4 * hs) * 4; }
+__host__ inline size_t attn_lds_bytes(int max_seq, int hs) { return (size_t)(hs + 16 + ((max_seq + 3) & ~3)) * 4; }
 
 // ------------------------------------------------------------------------------------------
 // small kernels
@@ -561,7 +660,6 @@ __global__ void __launch_bounds__(1024) k_argmax_advance(const float* logits, in
 __global__ void k_advance_prompt(DecodeState* st, const int* prompt) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { st->step += 1; st->pos += 1; st->tok = prompt[st->step]; }
 }
-
 __global__ void k_set_step(DecodeState* st, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) st->step = v; }
 // x += y (tensor-parallel path: residual add after the all-reduce; Tensor::add, tensor.cpp:723-743)
 __global__ void k_add_inplace(float* x, const float* y, int n) {
@@ -573,19 +671,28 @@ __global__ void k_add_inplace(float* x, const float* y, int n) {
 __global__ void k_op_swiglu(float* xo, const float* xr, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) xo[i] = swiglu_elem(xo[i], xr[i]);
 }
+// elementary functions as the kernels evaluate them: fn 0 expf_ref(x), 1 sqrtf(x), 2 x / y, 3 rms_scale(x, n = (int)y)
+__global__ void k_op_math(int fn, float* x, const float* y, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        x[i] = fn == 0 ? expf_ref(v) : fn == 1 ? __builtin_sqrtf(v) : fn == 2 ? __fdiv_rn(v, y[i]) : rms_scale(v, (int)y[i]);
+    }
+}
 __global__ void k_op_rope(float* o, const float* x, int n_dims, const float* c, const float* s) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (2 * i + 1 < n_dims) rope_pair(x[2 * i], x[2 * i + 1], c[i], s[i], o[2 * i], o[2 * i + 1]);
 }
-// softmax_sisd over n entries, one workgroup
+// softmax_sisd over n entries, one workgroup (same statements as k_attn_decode's softmax)
 __global__ void __launch_bounds__(kBlock) k_op_softmax(float* x, int n) {
-    __shared__ float red[8];
+    __shared__ float red[16];
     float lm = -INFINITY;
     for (int i = threadIdx.x; i < n; i += kBlock) lm = fmaxf(lm, x[i]);
     const float m = block_max(lm, red);
-    float ls = 0.f;
-    for (int i = threadIdx.x; i < n; i += kBlock) { const float e = expf(x[i] - m); x[i] = e; ls += e; }
-    const float L = block_sum(ls, red);
+    for (int i = threadIdx.x; i < n; i += kBlock) x[i] = expf_ref(__fsub_rn(x[i], m));
+    __syncthreads();
+    if (threadIdx.x == 0) { float s = 0.f; for (int i = 0; i < n; ++i) s = __fadd_rn(s, x[i]); red[8] = s; }
+    __syncthreads();
+    const float L = red[8];
     for (int i = threadIdx.x; i < n; i += kBlock) x[i] = __fdiv_rn(x[i], L);
 }
 // append one token's k (with RoPE), v to the caches and rotate q: what EPI_ROPE_KV does, for flm_op_attention
@@ -599,22 +706,6 @@ __global__ void k_op_kv_append(float* q, const float* k, const float* v, float* 
     rope_pair(k[2 * i], k[2 * i + 1], c[d / 2], s[d / 2], o0, o1);
     float* kp = kc + ((size_t)h * max_seq + pos) * hs + d; kp[0] = o0; kp[1] = o1;
     float* vp = vc + ((size_t)h * max_seq + pos) * hs + d; vp[0] = v[2 * i]; vp[1] = v[2 * i + 1];
-}
-// merge split-attention partials into [heads*hs] (same math as PRO_ATTN_COMBINE_QUANT), for flm_op_attention
-__global__ void k_op_attn_combine(float* out, const float* part, int n_heads, int hs, int S) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_heads * hs) return;
-    const int h = e / hs, d = e - h * hs;
-    const int st = hs + kAttnPartPad;
-    const float* p = part + (size_t)h * S * st;
-    float M = -INFINITY;
-    for (int s = 0; s < S; ++s) M = fmaxf(M, p[(size_t)s * st]);
-    float L = 0.f, o = 0.f;
-    for (int s = 0; s < S; ++s) {
-        const float* ps = p + (size_t)s * st;
-        if (ps[1] > 0.f) { const float w = expf(ps[0] - M); L = __fmaf_rn(ps[1], w, L); o = __fmaf_rn(ps[kAttnPartPad + d], w, o); }
-    }
-    out[e] = __fdiv_rn(o, L);
 }
 
 } // namespace flm

@@ -111,7 +111,12 @@ int  flm_kernel_times(flm_ctx* ctx, int pos, int iters, float* avg_us, int32_t* 
 /* weight + scale bytes one launch of class c streams (the algorithmic bytes of DESIGN.md) */
 int  flm_kernel_bytes(flm_ctx* ctx, int kclass, int pos, double* bytes);
 
-/* tuning knobs (0 = default): workgroups per CU for the GEMV kernels, hipGraph on/off */
+/* debugging tap for the parity tests: copy an internal fp32 device buffer to the host.
+ * what: 0 residual x1[dim], 1 q[dim], 2 attention output[dim], 3 hd[hidden], 4 K cache of `layer`
+ * [heads][max_seq][hs], 5 V cache of `layer`, 6 logits. */
+int  flm_debug_read(flm_ctx* ctx, int what, int layer, float* out, size_t n);
+
+/* tuning knobs: "wg_per_cu" workgroups per CU for the GEMV kernels, "use_graph" hipGraph replay on/off */
 int  flm_set_option(flm_ctx* ctx, const char* key, int value);
 
 /* ---- op level: 1:1 mirrors of the reference operator seam, host pointers in / out, running the
@@ -131,9 +136,15 @@ int  flm_op_rope(float* o, const float* x, int n_dims, int pos);
 int  flm_op_softmax(float* x, int n);
 /* the ATTN task (execute_attn, transformer.cpp:397-455) for n_heads heads of one new token at
  * position pos: q,k,v are [n_heads*hs]; kc,vc are [n_heads][max_seq][hs] caches (updated);
- * out [n_heads*hs].  n_splits = 0 lets the library choose its split count. */
+ * out [n_heads*hs]. */
 int  flm_op_attention(float* out, float* kc, float* vc, const float* q, const float* k, const float* v,
-                      int n_heads, int hs, int max_seq, int pos, int n_splits);
+                      int n_heads, int hs, int max_seq, int pos);
+/* libm expf as the device evaluates it (the reference calls glibc expf in softmax_sisd and swiglu);
+ * in place over n floats.  Lets the tests pin the device routine against glibc bit for bit. */
+int  flm_op_expf(float* x, size_t n);
+/* elementary fp32 functions as the kernels evaluate them, in place over x[n]:
+ * fn 0 expf(x), 1 sqrtf(x), 2 x / y, 3 rmsnorm scale 1/sqrtf(x/n + 1e-5) with n = (int)y[i]. */
+int  flm_op_math(int fn, float* x, const float* y, size_t n);
 
 /* ---- tensor-parallel shard plan (pure host arithmetic, no GPU needed).
  * Mirrors the reference's per-thread row split (split_rows, transformer.cpp:264-287) with the

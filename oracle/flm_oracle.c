@@ -317,6 +317,8 @@ int orc_model_set_tensor(orc_model* m, int kind, int layer, int src_qt, const vo
 }
 
 const float* orc_model_tap_x(orc_model* m) { return m->tap_x; }
+const float* orc_model_kcache(orc_model* m, int layer) { return m->kcache + (size_t)layer * m->KVH * m->max_seq * m->hs; }
+const float* orc_model_vcache(orc_model* m, int layer) { return m->vcache + (size_t)layer * m->KVH * m->max_seq * m->hs; }
 
 /* ParallelTransformer::forward -- src/transformer/transformer.cpp:105-161 (line refs inline) */
 int orc_model_forward(orc_model* m, const int32_t* tokens, int n, int pos, float* logits) {

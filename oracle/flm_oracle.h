@@ -63,6 +63,8 @@ int        orc_model_forward(orc_model* m, const int32_t* tokens, int n, int pos
 void       orc_model_reset(orc_model* m);
 /* debugging taps: copies of intermediate activations of the last forward (last row) */
 const float* orc_model_tap_x(orc_model* m);   /* residual stream after the last layer [dim] */
+const float* orc_model_kcache(orc_model* m, int layer);   /* [heads][max_seq][hs] */
+const float* orc_model_vcache(orc_model* m, int layer);
 
 #ifdef __cplusplus
 }

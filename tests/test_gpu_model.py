@@ -1,6 +1,7 @@
-"""Model-level parity on the GPU: logits within 1e-3 relative (north_star tolerance), greedy ids identical,
-against the CPU oracle (bit-exact with the reference, tests/test_oracle_vs_reference.py) and the
-committed golden logits generated from the reference itself."""
+"""Model-level parity on the GPU.  The north_star bound is 1e-3 relative on the logits with identical greedy
+ids; the kernels are built to be BIT-IDENTICAL to the reference CPU path, so these tests assert exact
+equality of every logit against the CPU oracle (itself bit-exact with the reference,
+tests/test_oracle_vs_reference.py) and against the committed golden logits produced by the reference."""
 import os
 
 import numpy as np
@@ -12,6 +13,10 @@ from fast_llama_amd import flmfile as ff, synth
 pytestmark = pytest.mark.gpu
 REL_TOL = 1e-3      # BASELINE.json north_star: logits within 1e-3 relative fp32 tolerance
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def bits_equal(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
 
 
 def rel_err(a, b):
@@ -33,18 +38,13 @@ def test_logits_and_greedy_vs_oracle(gpu, shape, qt, fp32_master):
     prompt = _prompt(cfg.vocab_size, 8)
     lg = ctx.forward(prompt, 0); lo = om.forward(prompt, 0)
     assert rel_err(lg, lo) < REL_TOL
+    assert bits_equal(lg, lo)
     pos, cur = len(prompt), int(np.argmax(lo))
-    assert int(np.argmax(lg)) == cur
-    worst = 0.0
     for _ in range(16):
         t = np.array([cur], dtype=np.int32)
         lg = ctx.forward(t, pos); lo = om.forward(t, pos)
-        worst = max(worst, rel_err(lg, lo))
-        srt = np.sort(lo)
-        if srt[-1] - srt[-2] > 1e-4 * abs(srt[-1]):          # away from a numerical tie the ids must agree
-            assert int(np.argmax(lg)) == int(np.argmax(lo))
+        assert bits_equal(lg, lo), f"pos {pos}: rel {rel_err(lg, lo):.3e}"
         cur = int(np.argmax(lo)); pos += 1
-    assert worst < REL_TOL
     ctx.close()
 
 
@@ -71,7 +71,7 @@ def test_device_greedy_loop_matches_stepwise(gpu):
     assert list(ids) == step_ids
     assert list(ids) == orc_ids
     # graph on/off and attention split counts give identical tokens
-    for key, val in (("use_graph", 0), ("attn_splits", 4), ("wg_per_cu", 4)):
+    for key, val in (("use_graph", 0), ("wg_per_cu", 1), ("wg_per_cu", 4)):
         ctx.set_option(key, val); ctx.reset_kv()
         assert ctx.forward_argmax(prompt, 0) == first
         assert list(ctx.decode_greedy(first, len(prompt), n)) == list(ids)
@@ -86,11 +86,11 @@ def test_long_context_positions(gpu):
     om = O.OracleModel(cfg, tensors)
     prompt = _prompt(cfg.vocab_size, 1000)
     lg = ctx.forward(prompt, 0); lo = om.forward(prompt, 0)
-    assert rel_err(lg, lo) < REL_TOL
+    assert bits_equal(lg, lo)
     t = np.array([int(np.argmax(lo))], np.int32)
     for pos in range(1000, 1024):
         lg = ctx.forward(t, pos); lo = om.forward(t, pos)
-        assert rel_err(lg, lo) < REL_TOL
+        assert bits_equal(lg, lo)
         t = np.array([int(np.argmax(lo))], np.int32)
     with pytest.raises(gpu.FlmError):
         ctx.forward(t, 1024)                      # beyond max_seq_len is an error, not a silent wrap
@@ -112,21 +112,22 @@ def test_errors(gpu):
         gpu.Ctx(d3)
 
 
-def test_golden_logits_from_reference(gpu):
+@pytest.mark.parametrize("name,shape,qt,f32", [("model_tiny_int8", "tiny", ff.QT_INT8, False), ("model_tiny_int16", "tiny", ff.QT_INT16, False),
+                                               ("model_tiny128_int8", "tiny128", ff.QT_INT8, False), ("model_tiny_int8_f32master", "tiny", ff.QT_INT8, True),
+                                               ("model_small_int8", "small", ff.QT_INT8, False)])
+def test_golden_logits_from_reference(gpu, name, shape, qt, f32):
     """committed golden vectors produced by the reference binary itself (tests/golden/make_golden.py)."""
-    path = os.path.join(GOLD, "model_tiny_int8.npz")
-    g = np.load(path)
-    cfg = synth.make_config("tiny", ff.QT_INT8)
-    tensors = synth.make_tensors(cfg, seed=int(g["seed"]))
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg = synth.make_config(shape, qt)
+    tensors = synth.make_tensors(cfg, seed=int(g["seed"]), fp32_master=f32)
     ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
     prompt = g["prompt"]
     lg = ctx.forward(prompt, 0)
-    assert rel_err(lg, g["logits"][0]) < REL_TOL
+    assert bits_equal(lg, g["logits"][0])
     pos = len(prompt)
     for i, tok in enumerate(g["ids"][:-1]):
         lg = ctx.forward(np.array([tok], np.int32), pos)
-        assert rel_err(lg, g["logits"][i + 1]) < REL_TOL
-        if g["margin"][i + 1] > 1e-4:
-            assert int(np.argmax(lg)) == int(g["ids"][i + 1])
+        assert bits_equal(lg, g["logits"][i + 1])
+        assert int(np.argmax(lg)) == int(g["ids"][i + 1])
         pos += 1
     ctx.close()
