@@ -59,7 +59,7 @@ struct flm_ctx {
     int prompt_cap = 0, out_cap = 0;
 
     // options
-    int wg_per_cu = 2; int use_graph = 1;
+    int wg_per_cu = 2; int use_graph = 1; int ablate = 0;
     std::map<int, hipGraphExec_t> graphs;             // key = with_cls*4 + advance
     std::vector<TimedLaunch>* timing = nullptr;
     std::string err;
@@ -88,34 +88,59 @@ void split_even(int total, int parts, int idx, int* begin, int* count) {
 // ---------------------------------------------------------------------------------------------
 // GEMV dispatch
 // ---------------------------------------------------------------------------------------------
+// Pass geometry of k_gemv for one launch (see the kernel's header comment).
+//   cb_shift : CB = largest power of two <= 64 dividing K/16, so every 1 KiB wave load is full
+//   R        : rows per workgroup pass; bounded by the kMaxBlk loads a wave keeps in flight, by LDS
+//              (two {dF,sP} strip buffers) and by 64 chain lanes; chosen so that the passes divide
+//              evenly over `wgs` workgroups (CU-level balance is what matters for an HBM-bound kernel)
+struct GemvPlan { int R, cb_shift, grid; size_t lds; };
+GemvPlan gemv_plan(int n, int esz, int total_rows, int rpi, bool norm, int wgs) {
+    GemvPlan P{};
+    const int nchunks = n * esz / 16, sn = n / kGroup;
+    int cbs = 0; while (cbs < 6 && (nchunks % (2 << cbs)) == 0) ++cbs;       // nchunks % 4 == 0 always
+    const int RB = 64 >> cbs, nbc = nchunks >> cbs;
+    int mult = RB > 2 ? RB : 2; if (rpi == 2) mult = 2 * RB;                 // SWIGLU: R/2 rows per matrix, a multiple of RB
+    int rmax = 64;                                                           // one chain lane per row
+    const int gstride = ((sn + 3) & ~3) + kChainPad;
+    const int fixed = n * esz + ((sn * 4 + 15) & ~15) + 64;
+    const int lds_budget = 72 * 1024;                                        // two workgroups per CU out of 160 KiB
+    const int r_lds = (lds_budget - fixed) / (16 * gstride) - 1;            // two {dF,sP} buffers of R+1 strips
+    if (rmax > r_lds) rmax = r_lds;
+    if (rmax > 64) rmax = 64;
+    rmax = rmax / mult * mult; if (rmax < mult) rmax = mult;
+    int ppw = (total_rows + wgs * rmax - 1) / (wgs * rmax);                  // passes per workgroup
+    if (ppw < 1) ppw = 1;
+    int R = (total_rows + wgs * ppw - 1) / (wgs * ppw);
+    R = (R + mult - 1) / mult * mult; if (R > rmax) R = rmax; if (R < mult) R = mult;
+    const int npass = (total_rows + R - 1) / R;
+    P.R = R; P.cb_shift = cbs; P.grid = npass < wgs ? npass : wgs; if (P.grid < 1) P.grid = 1;
+    P.lds = (size_t)gemv_lds_layout(n, esz, norm, R).total;
+    return P;
+}
+
 template <int QT, int PRO, int EPI>
-int launch_gemv_xr(flm_ctx* c, hipStream_t st, const GemvArgs& a, int grid) {
-    const size_t lds = gemv_lds_layout(a.n, QTraits<QT>::kEsz, PRO == PRO_RMSNORM_QUANT).total;
-    const int rounds = (a.n + kBlock * 4 - 1) / (kBlock * 4);
-    if (PRO == PRO_NONE)   hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 0>),  dim3(grid), dim3(kBlock), lds, st, a);
-    else if (rounds <= 4)  hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 4>),  dim3(grid), dim3(kBlock), lds, st, a);
-    else if (rounds <= 12) hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 12>), dim3(grid), dim3(kBlock), lds, st, a);
-    else                   hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 0>),  dim3(grid), dim3(kBlock), lds, st, a);
+int launch_gemv_xr(flm_ctx* c, hipStream_t st, GemvArgs a, int wgs) {
+    constexpr int RPI = (EPI == EPI_SWIGLU || EPI == EPI_ROPE_KV) ? 2 : 1;
+    const GemvPlan P = gemv_plan(a.n, QTraits<QT>::kEsz, a.items * RPI, RPI, PRO == PRO_RMSNORM_QUANT, wgs);
+    if (P.lds > 160 * 1024) return fail(c, FLM_ERR_UNSUPPORTED, "gemv: activation vector does not fit LDS");
+    a.rows_per_pass = P.R; a.cb_shift = P.cb_shift;
+    const int rounds = (a.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4);
+    if (PRO == PRO_NONE)   hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 0>), dim3(P.grid), dim3(kGemvBlock), P.lds, st, a);
+    else if (rounds <= 2)  hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 2>), dim3(P.grid), dim3(kGemvBlock), P.lds, st, a);
+    else if (rounds <= 6)  hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 6>), dim3(P.grid), dim3(kGemvBlock), P.lds, st, a);
+    else                   hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 0>), dim3(P.grid), dim3(kGemvBlock), P.lds, st, a);
     HIPC(c, hipGetLastError());
     return FLM_OK;
 }
 template <int PRO, int EPI>
-int launch_gemv(flm_ctx* c, hipStream_t st, int qt, const GemvArgs& a, int grid) {
+int launch_gemv(flm_ctx* c, hipStream_t st, int qt, const GemvArgs& a, int wgs) {
     if (a.n % kGroup != 0 || a.n <= 0) return fail(c, FLM_ERR_INVALID, "gemv: n must be a positive multiple of 64");
-    if (gemv_lds_layout(a.n, esz_of(qt), PRO == PRO_RMSNORM_QUANT).total > 160 * 1024) return fail(c, FLM_ERR_UNSUPPORTED, "gemv: activation vector does not fit LDS");
-    if (qt == FLM_QT_INT8)  return launch_gemv_xr<QT_INT8, PRO, EPI>(c, st, a, grid);
-    if (qt == FLM_QT_INT16) return launch_gemv_xr<QT_INT16, PRO, EPI>(c, st, a, grid);
+    if (qt == FLM_QT_INT8)  return launch_gemv_xr<QT_INT8, PRO, EPI>(c, st, a, wgs);
+    if (qt == FLM_QT_INT16) return launch_gemv_xr<QT_INT16, PRO, EPI>(c, st, a, wgs);
     return fail(c, FLM_ERR_UNSUPPORTED, "gemv: quant type must be INT8 or INT16");
 }
-// grid: wg_per_cu workgroups per CU, but never more waves than batches of work
-int gemv_grid(int cu_count, int wg_per_cu, int items, int rows_per_item) {
-    const int ipb = kRows / rows_per_item;
-    const int batches = (items + ipb - 1) / ipb;
-    int wgs = cu_count * wg_per_cu;
-    const int need = (batches + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (wgs > need) wgs = need;
-    return wgs < 1 ? 1 : wgs;
-}
+// workgroups to spread a GEMV over: wg_per_cu per CU
+int gemv_grid(int cu_count, int wg_per_cu, int /*items*/, int /*rows_per_item*/) { return cu_count * wg_per_cu; }
 
 // quantize a flat fp32 array on the device with the fused path's quantizer (A13, load time):
 // one 16-lane group per 64-element group.
@@ -128,9 +153,7 @@ __global__ void k_quantize_flat(void* q, float* s, const float* x, size_t n) {
         const size_t e = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4 + it * stride;
         const bool act = e < n;
         float4 v = act ? *reinterpret_cast<const float4*>(x + e) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, kWave));
+        const float mx = row16_max(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
         const float sc = __fdiv_rn(mx, T::kF);
         if (act) {
             const int q0 = quant_elem(v.x, sc), q1 = quant_elem(v.y, sc), q2 = quant_elem(v.z, sc), q3 = quant_elem(v.w, sc);
@@ -241,7 +264,7 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance) {
     for (int l = 0; l < L; ++l) {
         LayerW& w = c->layers[l];
         {   // QKV task + RoPE + KV append (transformer.cpp:132-135, execute_qkv :386-395, execute_attn :431-439)
-            GemvArgs a{};
+            GemvArgs a{}; a.ablate = c->ablate;
             a.W = w.qkv.q; a.sW = w.qkv.s; a.n = d.dim; a.items = w.qkv.rows / 2;
             a.x = c->x1; a.norm_w = w.att_norm;
             a.out = c->qbuf; a.kcache = c->kcache + (size_t)l * kv_layer; a.vcache = c->vcache + (size_t)l * kv_layer;
@@ -260,7 +283,7 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance) {
             HIPC(c, hipGetLastError());
         }
         {   // ATTN_O task + residual (transformer.cpp:138-139, execute_attn_o :457-466)
-            GemvArgs a{};
+            GemvArgs a{}; a.ablate = c->ablate;
             a.W = w.o.q; a.sW = w.o.s; a.n = c->dim_local; a.items = d.dim;
             a.x = c->att_out;
             a.out = tp ? c->partial : c->x1;
@@ -276,7 +299,7 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance) {
             HIPC(c, hipGetLastError());
         }
         {   // FFN13 task + SwiGLU (transformer.cpp:144-147, execute_ffn13 :468-483)
-            GemvArgs a{};
+            GemvArgs a{}; a.ablate = c->ablate;
             a.W = w.w1.q; a.sW = w.w1.s; a.W2nd = w.w3.q; a.sW2nd = w.w3.s; a.n = d.dim; a.items = c->hidden_local;
             a.x = c->x1; a.norm_w = w.ffn_norm; a.out = c->hd;
             Tick t(c, st, KC_FFN13);
@@ -284,7 +307,7 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance) {
             if (r) return r;
         }
         {   // FFN2 task + residual (transformer.cpp:149-150, execute_ffn2 :485-494)
-            GemvArgs a{};
+            GemvArgs a{}; a.ablate = c->ablate;
             a.W = w.w2.q; a.sW = w.w2.s; a.n = c->hidden_local; a.items = d.dim;
             a.x = c->hd; a.out = tp ? c->partial : c->x1;
             Tick t(c, st, KC_FFN2);
@@ -301,7 +324,7 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance) {
     }
     if (with_cls) {
         {   // final norm + CLS task (transformer.cpp:154-160, execute_cls :496-505)
-            GemvArgs a{};
+            GemvArgs a{}; a.ablate = c->ablate;
             a.W = c->cls.q; a.sW = c->cls.s; a.n = d.dim; a.items = c->cls.rows;
             a.x = c->x1; a.norm_w = c->out_norm; a.out = c->logits + (tp ? (size_t)c->rank * c->vocab_slot : 0);
             Tick t(c, st, KC_CLS);
@@ -519,6 +542,7 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     std::string k(key);
     if (k == "wg_per_cu") c->wg_per_cu = value > 0 ? value : 2;
     else if (k == "use_graph") c->use_graph = value;
+    else if (k == "ablate") c->ablate = value;
     else return fail(c, FLM_ERR_INVALID, "unknown option");
     for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
     c->graphs.clear();

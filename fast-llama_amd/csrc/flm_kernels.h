@@ -36,8 +36,9 @@
 namespace flm {
 
 constexpr int kWave = 64;
-constexpr int kBlock = 256;           // 4 waves per workgroup everywhere
-constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kBlock = 256;           // attention / small kernels: 4 waves per workgroup
+constexpr int kGemvBlock = 512;       // GEMV: 8 waves per workgroup, >= 2 workgroups per CU (<= 128 VGPRs)
+constexpr int kWavesPerBlock = kGemvBlock / kWave;
 constexpr int kGroup = 64;            // quantization group (QUANT_GROUP_SIZE, the only value the reference uses)
 
 enum { QT_INT16 = 1, QT_INT8 = 2 };
@@ -63,6 +64,18 @@ __device__ __forceinline__ float block_max(float v, float* red) {
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+// max over each aligned group of 16 lanes (one DPP row), result in all 16 lanes; order-free, no LDS
+__device__ __forceinline__ float row16_max(float v) {
+    const int i0 = __float_as_int(v);
+    float t = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(i0, i0, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true)));
+    int i1 = __float_as_int(t);
+    t = fmaxf(t, __int_as_float(__builtin_amdgcn_update_dpp(i1, i1, 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, true)));
+    i1 = __float_as_int(t);
+    t = fmaxf(t, __int_as_float(__builtin_amdgcn_update_dpp(i1, i1, 0x141 /* row_half_mirror */, 0xF, 0xF, true)));
+    i1 = __float_as_int(t);
+    t = fmaxf(t, __int_as_float(__builtin_amdgcn_update_dpp(i1, i1, 0x140 /* row_mirror */, 0xF, 0xF, true)));
+    return t;
 }
 // exact integer sum over the 4 lanes of a quad (DPP quad_perm, no LDS)
 __device__ __forceinline__ int quad_sum(int p) {
@@ -171,6 +184,8 @@ struct GemvArgs {
     const void*  W2nd; const float* sW2nd;
     int n;                                      // K (columns), multiple of 64
     int items;                                  // rows (STORE/RESIDUAL), hidden (SWIGLU), row pairs (ROPE_KV)
+    int rows_per_pass;                          // R: rows one workgroup reduces per pass (multiple of 64 >> cb_shift and of 2)
+    int cb_shift;                               // log2(CB): a 1 KiB wave load covers (64 >> cb_shift) rows x CB 16-byte chunks
     // prologue inputs
     const float* x;                             // fp32 activation [n]          (QUANT / RMSNORM_QUANT)
     const float* norm_w;                        // rmsnorm weight [n]           (RMSNORM_QUANT)
@@ -183,29 +198,30 @@ struct GemvArgs {
     int dim; int kv_dim; int max_seq; int hs;   // ROPE_KV geometry
     // debugging taps used by the op-level exports (may be null)
     void* dbg_xq; float* dbg_xs; float* dbg_xn;
+    int ablate;                                 // perf exploration only (results invalid when != 0): 1 no group chain, 2 no rmsnorm chain, 4 no weight loads, 8 no dots, 16 return immediately, 32 return after prologue
 };
 
-constexpr int kRows = 4;               // rows per wave batch (4 rows x 4 chunks x 16 B in flight per lane)
+constexpr int kMaxBlk = 8;             // 1 KiB wave loads in flight per wave and pass (8 KiB/wave, 64 KiB/workgroup, 128 KiB/CU)
 constexpr int kChainPad = 4;           // LDS row padding (dwords) of the per-wave chain scratch: no bank conflicts, keeps 16-B alignment
 
 // LDS layout: [xq : n*esz] [xs : n/64 floats, padded to 16 B] [red : 16 floats] [scratch]
-// scratch = max( rmsnorm transpose staging 4n bytes , 4 waves x { dsub[kRows][dstride] ints, sprod[kRows][sstride] floats } )
+// scratch = max( rmsnorm transpose staging 4n bytes ,
+//                2 buffers x { dF[R][gstride] float(group dot), sP[R][gstride] sW*sX } )
 struct GemvLds {
     int off_xs, off_red, off_scr;     // byte offsets
-    int dstride, sstride;             // dwords; multiples of 4 so every row strip is 16-B aligned
-    int wave_bytes;                   // chain scratch per wave
+    int gstride;                      // dwords per row strip; multiple of 4 (16-B aligned strips), +4 pad against bank conflicts
+    int buf_bytes;                    // one {dF, sP} buffer
     int total;                        // bytes
 };
-__host__ __device__ inline GemvLds gemv_lds_layout(int n, int esz, bool norm) {
+__host__ __device__ inline GemvLds gemv_lds_layout(int n, int esz, bool norm, int R) {
     GemvLds L;
-    const int sn = n / kGroup, nq = n * esz / 64;
+    const int sn = n / kGroup;
     L.off_xs = n * esz;
     L.off_red = L.off_xs + ((sn * 4 + 15) & ~15);
     L.off_scr = L.off_red + 64;
-    L.dstride = ((nq + 3) & ~3) + kChainPad;
-    L.sstride = ((sn + 3) & ~3) + kChainPad;
-    L.wave_bytes = kRows * (L.dstride + L.sstride) * 4;
-    int scratch = L.wave_bytes * kWavesPerBlock;
+    L.gstride = ((sn + 3) & ~3) + kChainPad;
+    L.buf_bytes = 2 * (R + 1) * L.gstride * 4;                                // +1: dummy strip that absorbs the writes of blocks past the pass
+    int scratch = 2 * L.buf_bytes;
     if (norm && n * 4 > scratch) scratch = n * 4;
     L.total = L.off_scr + scratch;
     return L;
@@ -225,12 +241,19 @@ __host__ __device__ inline GemvLds gemv_lds_layout(int n, int esz, bool norm) {
 template <int QT, int PRO, int XR>
 __device__ __forceinline__ void gemv_preload(const GemvArgs& a, float4 (&xv)[XR > 0 ? XR : 1], float4 (&wv)[XR > 0 ? XR : 1]) {
     if constexpr (PRO == PRO_QUANT || PRO == PRO_RMSNORM_QUANT) {
+        // branch-free: raw buffer loads, elements past n read as zero
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.n * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(PRO == PRO_RMSNORM_QUANT ? a.norm_w : a.x), 0, a.n * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < XR; ++i) {
-            const int e = threadIdx.x * 4 + i * kBlock * 4;
-            xv[i] = e < a.n ? *reinterpret_cast<const float4*>(a.x + e) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (PRO == PRO_RMSNORM_QUANT)
-                wv[i] = e < a.n ? *reinterpret_cast<const float4*>(a.norm_w + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int off = (threadIdx.x * 4 + i * kGemvBlock * 4) * 4;
+            const v4f v = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+            xv[i] = make_float4(v.x, v.y, v.z, v.w);
+            if constexpr (PRO == PRO_RMSNORM_QUANT) {
+                const v4f u = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rn, off, 0, 0));
+                wv[i] = make_float4(u.x, u.y, u.z, u.w);
+            }
         }
     }
 }
@@ -240,7 +263,7 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
     using T = QTraits<QT>;
     const int n = a.n;
     const int tid = threadIdx.x;
-    const GemvLds L = gemv_lds_layout(n, T::kEsz, PRO == PRO_RMSNORM_QUANT);
+    const GemvLds L = gemv_lds_layout(n, T::kEsz, PRO == PRO_RMSNORM_QUANT, a.rows_per_pass);
     char*  xq = lds;
     float* xs = reinterpret_cast<float*>(lds + L.off_xs);
     float* red = reinterpret_cast<float*>(lds + L.off_red);
@@ -249,13 +272,13 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
     if constexpr (PRO == PRO_NONE) {
         // copy pre-quantized activation (op-level matmul and generic callers)
         const int nb16 = n * T::kEsz / 16;
-        for (int c = tid; c < nb16; c += kBlock)
+        for (int c = tid; c < nb16; c += kGemvBlock)
             reinterpret_cast<int4*>(xq)[c] = reinterpret_cast<const int4*>(a.xq)[c];
-        for (int g = tid; g < n / kGroup; g += kBlock) xs[g] = a.xs[g];
+        for (int g = tid; g < n / kGroup; g += kGemvBlock) xs[g] = a.xs[g];
         __syncthreads();
         return;
     } else {
-        const int rounds = (n + kBlock * 4 - 1) / (kBlock * 4);
+        const int rounds = (n + kGemvBlock * 4 - 1) / (kGemvBlock * 4);
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         float r = 1.0f;
         if constexpr (PRO == PRO_RMSNORM_QUANT) {
@@ -264,24 +287,40 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
             // Stage x transposed ([4][n/4]) so that 4 threads can each walk one strided lane sequentially.
             const int n4 = n / 4;
             auto stage = [&](int i, const float4& v) {
-                const int k = tid + i * kBlock;
+                const int k = tid + i * kGemvBlock;
                 if (k < n4) { scratch[k] = v.x; scratch[n4 + k] = v.y; scratch[2 * n4 + k] = v.z; scratch[3 * n4 + k] = v.w; }
             };
 #pragma unroll
             for (int i = 0; i < XR; ++i) { if (i < rounds) stage(i, xv[i]); }
             for (int i = XR; i < rounds; ++i) {
-                const int e = tid * 4 + i * kBlock * 4;
+                const int e = tid * 4 + i * kGemvBlock * 4;
                 if (e < n) stage(i, *reinterpret_cast<const float4*>(a.x + e));
             }
             __syncthreads();
-            if (tid < 4) {
+            if (tid < 4 && !(a.ablate & 2)) {
+                // 4 strided lanes, each a strictly sequential FMA chain; LDS reads are issued 32 values
+                // ahead of their use so the chain runs at FMA latency, not LDS latency.
                 const float* p = scratch + tid * n4;
                 float l = 0.f;
                 int k = 0;
-                for (; k + 3 < n4; k += 4) {
-                    const float4 v = *reinterpret_cast<const float4*>(p + k);
-                    l = __fmaf_rn(v.x, v.x, l); l = __fmaf_rn(v.y, v.y, l); l = __fmaf_rn(v.z, v.z, l); l = __fmaf_rn(v.w, v.w, l);
+#define FLM_SQ4(v) l = __fmaf_rn(v.x, v.x, l); l = __fmaf_rn(v.y, v.y, l); l = __fmaf_rn(v.z, v.z, l); l = __fmaf_rn(v.w, v.w, l);
+                if (n4 >= 32) {
+                    // two named register sets, refilled alternately: the loop body is FMAs and LDS reads only
+                    float4 a0 = *reinterpret_cast<const float4*>(p), a1 = *reinterpret_cast<const float4*>(p + 4);
+                    float4 a2 = *reinterpret_cast<const float4*>(p + 8), a3 = *reinterpret_cast<const float4*>(p + 12);
+                    float4 b0, b1, b2, b3;
+                    for (; k + 32 <= n4; k += 32) {
+                        b0 = *reinterpret_cast<const float4*>(p + k + 16); b1 = *reinterpret_cast<const float4*>(p + k + 20);
+                        b2 = *reinterpret_cast<const float4*>(p + k + 24); b3 = *reinterpret_cast<const float4*>(p + k + 28);
+                        FLM_SQ4(a0) FLM_SQ4(a1) FLM_SQ4(a2) FLM_SQ4(a3)
+                        const int kn = k + 48 <= n4 ? k + 32 : k;                 // clamp (the reload is unused on the last trip)
+                        a0 = *reinterpret_cast<const float4*>(p + kn); a1 = *reinterpret_cast<const float4*>(p + kn + 4);
+                        a2 = *reinterpret_cast<const float4*>(p + kn + 8); a3 = *reinterpret_cast<const float4*>(p + kn + 12);
+                        FLM_SQ4(b0) FLM_SQ4(b1) FLM_SQ4(b2) FLM_SQ4(b3)
+                    }
+                    if (k + 16 <= n4) { FLM_SQ4(a0) FLM_SQ4(a1) FLM_SQ4(a2) FLM_SQ4(a3) k += 16; }
                 }
+#undef FLM_SQ4
                 for (; k < n4; ++k) l = __fmaf_rn(p[k], p[k], l);
                 red[8 + tid] = l;
             }
@@ -292,7 +331,7 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
         }
         // one round: (normalise,) group max over 16 lanes, quantize, pack into LDS
         auto round = [&](int i, float4 v, float4 w) {
-            const int e = tid * 4 + i * kBlock * 4;
+            const int e = tid * 4 + i * kGemvBlock * 4;
             const bool act = e < n;
             if constexpr (PRO == PRO_RMSNORM_QUANT) {
                 // multiply_avx256 (x86_simd.cpp:1360-1372): (x*w)*r
@@ -301,9 +340,7 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
             }
             if (act && a.dbg_xn && blockIdx.x == 0) *reinterpret_cast<float4*>(a.dbg_xn + e) = v;
             // group max over the 16 lanes that share this 64-element group (order-free, exact)
-            float mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, kWave));
+            const float mx = row16_max(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
             const float sc = __fdiv_rn(mx, T::kF);           // scale = max|x| / F
             if (act) {
                 const int q0 = quant_elem(v.x, sc), q1 = quant_elem(v.y, sc), q2 = quant_elem(v.z, sc), q3 = quant_elem(v.w, sc);
@@ -322,7 +359,7 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
 #pragma unroll
         for (int i = 0; i < XR; ++i) { if (i < rounds) round(i, xv[i], wv[i]); }
         for (int i = XR; i < rounds; ++i) {
-            const int e = tid * 4 + i * kBlock * 4;
+            const int e = tid * 4 + i * kGemvBlock * 4;
             float4 v = z4, w = z4;
             if (e < n) {
                 v = *reinterpret_cast<const float4*>(a.x + e);
@@ -333,8 +370,8 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
         __syncthreads();
         if (a.dbg_xq && blockIdx.x == 0) {
             const int nb4 = n * T::kEsz / 4;
-            for (int c = tid; c < nb4; c += kBlock) reinterpret_cast<uint32_t*>(a.dbg_xq)[c] = reinterpret_cast<uint32_t*>(xq)[c];
-            for (int g = tid; g < n / kGroup; g += kBlock) a.dbg_xs[g] = xs[g];
+            for (int c = tid; c < nb4; c += kGemvBlock) reinterpret_cast<uint32_t*>(a.dbg_xq)[c] = reinterpret_cast<uint32_t*>(xq)[c];
+            for (int g = tid; g < n / kGroup; g += kGemvBlock) a.dbg_xs[g] = xs[g];
         }
     }
 }
@@ -342,198 +379,251 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
 // ------------------------------------------------------------------------------------------
 // The GEMV.  quant::matmul<T> at w == 1 (src/blas/quant_operators.cpp:252-284):
 //     out[r] = sum_g (sW[r,g] * sX[g]) * float( sum_{k<64} W[r,64g+k] * X[64g+k] ),   g ASCENDING, FMA per group
-// Mapping: one wave per row batch, lanes along K in 16-byte chunks (lane l owns chunks l, l+64, ...),
-// so every weight load is a fully coalesced 1 KiB global_load_dwordx4 and a row is contiguous in HBM.
-//   1. int32 partial dot per 16-byte chunk (v_dot4 / v_dot2), exact;
-//   2. DPP quad sum -> one int32 per 64 B of the row (= one int8 group; half an int16 group), exact;
-//   3. quad leaders park {int32 sub-dot, sW*sX} in a wave-private LDS strip;
-//   4. lane rr (< kRows) walks row rr's groups in ascending order: acc = fma(sW*sX, float(dot), acc)
-//      -- the reference's summation order, so the fp32 result is bit-identical;
-//   5. lane rr runs the epilogue for row rr.
-// kRows rows are processed per batch so that kRows*4 x 16 B loads per lane are in flight.
+//
+// A workgroup (8 waves) reduces R rows per pass.  The R x K tile is cut into 1 KiB blocks of
+// (RB rows x CB chunks of 16 B), RB*CB = 64, CB = the largest power of two dividing K/16 (so a block is
+// one fully coalesced global_load_dwordx4 per wave and every lane is busy for any K); blocks are dealt
+// round-robin to the 8 waves and ALL of a wave's blocks (<= kMaxBlk) are in flight before the
+// prologue runs.  Then
+//   1. int32 dot per 16-byte chunk (v_dot4 / v_dot2), exact;
+//   2. DPP sum over the 4 (int8) / 8 (int16) lanes of a quant group -> the group's int32 dot, exact;
+//   3. group leaders park float(dot) and s = sW*sX in LDS strips dF[row][g], sP[row][g];
+//   4. after ONE workgroup barrier, one wave walks the strips, lane r = row r:
+//        acc = fma(sP[g], dF[g], acc), g ascending -- the reference's summation order, bit-identical --
+//      amortising the sequential fp32 chain over R rows instead of paying it per row;
+//   5. the same lanes run the epilogue (coalesced stores).
+// The strips are double buffered, so the other waves are already in the next pass's dots.
 // ------------------------------------------------------------------------------------------
 template <int QT, int PRO, int EPI, int XR>
-__global__ void __launch_bounds__(kBlock) k_gemv(const GemvArgs a) {
+__global__ void __launch_bounds__(kGemvBlock, 4) k_gemv(const GemvArgs a) {
     using T = QTraits<QT>;
+    typedef unsigned int u32;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int n = a.n;
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    constexpr int RPI = (EPI == EPI_SWIGLU || EPI == EPI_ROPE_KV) ? 2 : 1;   // rows per item
-    constexpr int IPB = kRows / RPI;                                          // items per batch
-    const int rowbytes = n * T::kEsz;
-    const int nchunks = rowbytes / 16;
-    const int sn = n / kGroup;
-    const int nq = nchunks / 4;                                               // quads (64-byte pieces) per row
-    constexpr int LPG = 64 / T::kEPC;                                         // lanes per quant group
-    constexpr int QPG = LPG / 4;                                              // quads per quant group (1 int8, 2 int16)
+    const u32 n = a.n;
+    const u32 lane = threadIdx.x & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr u32 LPGS = (T::kEPC == 16) ? 2 : 3;                             // log2(lanes per quant group): 4 | 8 lanes
+    constexpr u32 LPG = 1u << LPGS;
+    const u32 rowbytes = n * T::kEsz, nchunks = rowbytes / 16, sn = n / kGroup;
+    const u32 cbs = a.cb_shift, CB = 1u << cbs, RB = 64u >> cbs;
+    const u32 nbc = nchunks >> cbs;                                           // chunk blocks per row
+    const u32 R = a.rows_per_pass;
+    // SWIGLU passes hold R/2 rows of W1 followed by the R/2 matching rows of W3 (blocks never mix matrices)
+    constexpr bool TWO = EPI == EPI_SWIGLU;
+    const u32 TRm = TWO ? (u32)a.items : (u32)a.items * (EPI == EPI_ROPE_KV ? 2u : 1u);    // rows per matrix
+    const u32 Rm = TWO ? R / 2 : R;                                           // rows of one matrix per pass
+    const u32 npass = (TRm + Rm - 1) / Rm;
+    const u32 NB = (R / RB) * nbc;                                            // blocks per pass
+    const u32 nblk = (NB + kWavesPerBlock - 1 - wave) / kWavesPerBlock;       // blocks of this wave: b = wave + 8k
+    const u32 rb = lane >> cbs, cb = lane & (CB - 1);
+    // lane-constant parts of every address (the per-block parts are wave-uniform scalars)
+    const u32 lane_woff = rb * rowbytes + cb * 16;                            // weights, bytes from the block base
+    const u32 lane_soff = (rb * sn + (cb >> LPGS)) * 4;                       // scales
+    const u32 lane_xoff = cb * 16;                                            // activation chunk in LDS
+    const bool leader = (cb & (LPG - 1)) == 0;
+    // block sequence of this wave: (row block, chunk block) = divmod(wave + 8k, nbc), advanced incrementally
+    const u32 q8 = kWavesPerBlock / nbc, r8 = kWavesPerBlock - q8 * nbc;
+    const u32 rbk0 = wave / nbc, cbk0 = wave - rbk0 * nbc;
 
-    // balanced contiguous item range for this wave
-    const long long nw = (long long)gridDim.x * kWavesPerBlock;
-    const long long gw = (long long)blockIdx.x * kWavesPerBlock + wave;
-    const int it0 = (int)((long long)a.items * gw / nw);
-    const int it1 = (int)((long long)a.items * (gw + 1) / nw);
-
-    auto row_w = [&](int item, int which) -> const char* {
-        if constexpr (EPI == EPI_SWIGLU) return reinterpret_cast<const char*>(which ? a.W2nd : a.W) + (size_t)item * rowbytes;
-        else return reinterpret_cast<const char*>(a.W) + (size_t)(item * RPI + which) * rowbytes;
-    };
-    auto row_s = [&](int item, int which) -> const float* {
-        if constexpr (EPI == EPI_SWIGLU) return (which ? a.sW2nd : a.sW) + (size_t)item * sn;
-        else return a.sW + (size_t)(item * RPI + which) * sn;
-    };
-
-    // 1. the activation (L2-resident) first, 2. then the first batch of weight loads, both BEFORE
-    // the prologue: weights do not depend on the activation, so HBM latency overlaps norm/quantize.
+    // 1. the activation (L2-resident) first, 2. then every weight block of the first pass, both
+    // BEFORE the prologue: weights do not depend on the activation, so HBM latency (and the
+    // sequential rmsnorm chain) overlap the weight stream.
+    if (a.ablate & 16) return;
     float4 xv[XR > 0 ? XR : 1], nv[XR > 0 ? XR : 1];
     gemv_preload<QT, PRO, XR>(a, xv, nv);
 
-    v4i   w[kRows][4];
-    float sw[kRows][4];
-    // FULL: all kRows rows exist and all four 64-chunk columns are inside the row -> no predication,
-    // one base address per row, the four chunk loads differ by an immediate offset of 1 KiB.
-    auto load_batch = [&](int item0, int jb) {
-        const bool full = (item0 + IPB <= it1) && (64 * (jb + 4) <= nchunks);
-        if (full) {
+    // Each wave owns blocks b = wave + 8k, k < nblk, of every pass and streams them in steps of H
+    // blocks through two register sets (A, B): while one set is being reduced the other one and the
+    // refill of the first are in flight, so >= H KiB per wave (64 KiB per CU at 16 waves) are always
+    // outstanding and R is not limited by registers.
+    constexpr int H = kMaxBlk / 2;                                             // blocks per step
+    const u32 spp = ((NB + kWavesPerBlock - 1) / kWavesPerBlock + H - 1) / H;  // steps per pass (same for all waves)
+    struct Set { v4i w[H]; float sw[H]; };
+    struct Cursor { u32 pass, s, k, rbk, cbk; };                               // pass, step in pass, block counter, divmod(wave + 8k, nbc)
+    auto cursor_init = [&](Cursor& c, u32 pass) { c.pass = pass; c.s = 0; c.k = 0; c.rbk = rbk0; c.cbk = cbk0; };
+    auto cursor_next_block = [&](Cursor& c) { ++c.k; c.rbk += q8; c.cbk += r8; if (c.cbk >= nbc) { c.cbk -= nbc; ++c.rbk; } };
+    auto cursor_end_step = [&](Cursor& c) { if (++c.s == spp) cursor_init(c, c.pass + gridDim.x); };
+
+    // Weight and scale blocks are fetched with raw buffer loads: address = descriptor base + wave-uniform
+    // scalar offset (the block) + lane-constant 32-bit offset: no per-load vector address arithmetic, no
+    // branches.  A block past the pass (k >= nblk), past the last pass, or rows past the end of the
+    // matrix get an offset outside the descriptor -> the load returns zero without touching memory.
+    // "nt": each weight byte is read once per token.
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    constexpr int kRsrcFlags = 0x00020000;                                     // raw buffer, 32-bit data format (gfx9 family)
+    const __amdgpu_buffer_rsrc_t rW  = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, (int)(TRm * rowbytes), kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t rS  = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.sW), 0, (int)(TRm * sn * 4), kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t rW2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(TWO ? a.W2nd : a.W), 0, (int)(TRm * rowbytes), kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t rS2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(TWO ? a.sW2nd : a.sW), 0, (int)(TRm * sn * 4), kRsrcFlags);
+    auto load_step = [&](Set& S, Cursor& c) {
 #pragma unroll
-            for (int rr = 0; rr < kRows; ++rr) {
-                const v4i*   wp = reinterpret_cast<const v4i*>(row_w(item0 + rr / RPI, rr % RPI)) + lane + 64 * jb;
-                const float* sp = row_s(item0 + rr / RPI, rr % RPI) + lane / LPG + (64 / LPG) * jb;
+        for (int j = 0; j < H; ++j) {
+            u32 vr = c.rbk * RB;                                             // first row of the block inside the pass
+            bool second = false;
+            if constexpr (TWO) { second = vr >= Rm; vr = second ? vr - Rm : vr; }
+            const u32 row = c.pass * Rm + vr;
+            const bool live = c.k < nblk && c.pass < npass && !(a.ablate & 4);
+            const u32 wo = live ? row * rowbytes + ((c.cbk << cbs) * 16) : 0x80000000u;
+            const u32 so = live ? (row * sn + ((c.cbk << cbs) >> LPGS)) * 4 : 0x80000000u;
+            v4u wv; unsigned sv;
+            if constexpr (TWO) {
+                const __amdgpu_buffer_rsrc_t rw = second ? rW2 : rW, rs_ = second ? rS2 : rS;
+                wv = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)lane_woff, (int)wo, 2); sv = __builtin_amdgcn_raw_buffer_load_b32(rs_, (int)lane_soff, (int)so, 2);
+            } else {
+                wv = __builtin_amdgcn_raw_buffer_load_b128(rW, (int)lane_woff, (int)wo, 2); sv = __builtin_amdgcn_raw_buffer_load_b32(rS, (int)lane_soff, (int)so, 2);
+            }
+            S.w[j] = __builtin_bit_cast(v4i, wv);
+            S.sw[j] = __uint_as_float(sv);
+            cursor_next_block(c);
+        }
+        cursor_end_step(c);
+    };
+    Set setA, setB;
+    Cursor lc;                                                                 // load cursor, runs two steps ahead of the reduce cursor
+    cursor_init(lc, blockIdx.x);
+    load_step(setA, lc);
+    load_step(setB, lc);
+
+    gemv_prologue<QT, PRO, XR>(a, lds, xv, nv);
+    if (a.ablate & 32) return;
+
+    const GemvLds L = gemv_lds_layout(n, T::kEsz, PRO == PRO_RMSNORM_QUANT, R);
+    const char*  xq = lds;
+    const char*  xs = lds + L.off_xs;
+    const u32 gstride = L.gstride;
+    const u32 lane_goff = (rb * gstride + (cb >> LPGS)) * 4;                   // strip position of this lane's group, bytes
+    const bool vec_ok = (sn % 4) == 0;                                         // 16-B LDS reads need whole float4s per strip
+    int pos = 0;
+    if constexpr (EPI == EPI_ROPE_KV) pos = *a.pos_ptr;
+
+    // reduce one step: dots for all its blocks first (registers), then ONE leader-only region parks them.
+    // Blocks past the pass hold zeros; their strip writes are redirected to the dummy strip (row R).
+    auto reduce_step = [&](Set& S, Cursor c, char* dF, char* sP) {
+        int d[H];
+        {
+            Cursor q = c;
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    w[rr][jj]  = __builtin_nontemporal_load(wp + 64 * jj);
-                    sw[rr][jj] = __builtin_nontemporal_load(sp + (64 / LPG) * jj);
+            for (int j = 0; j < H; ++j) {
+                const v4i av = *reinterpret_cast<const v4i*>(xq + ((q.cbk << cbs) * 16) + lane_xoff);
+                int t = (a.ablate & 8) ? 0 : quad_sum(dot_chunk<QT>(S.w[j], av));
+                if constexpr (LPG == 8) t += __shfl_xor(t, 4, kWave);
+                d[j] = t;
+                cursor_next_block(q);
+            }
+        }
+        if (leader) {
+            Cursor q = c;
+#pragma unroll
+            for (int j = 0; j < H; ++j) {
+                const u32 g0 = (q.cbk << cbs) >> LPGS;                       // first group of the block (scalar)
+                const bool live = q.k < nblk;
+                const u32 so = ((live ? q.rbk * RB : R) * gstride + g0) * 4 + (live ? lane_goff : (cb >> LPGS) * 4);
+                const float sx = *reinterpret_cast<const float*>(xs + g0 * 4 + (cb >> LPGS) * 4);
+                *reinterpret_cast<float*>(dF + so) = (float)d[j];                          // exact int32 -> fp32, as "s * dot" does
+                *reinterpret_cast<float*>(sP + so) = __fmul_rn(S.sw[j], sx);               // s = sW * sX (quant_operators.cpp:274)
+                cursor_next_block(q);
+            }
+        }
+    };
+
+    // the end of a pass: one barrier, then ONE wave runs the fp32 chains of all R rows and the epilogue
+    auto finish_pass = [&](u32 pass, u32 it, char* dF, char* sP) {
+        const bool chain_wave = wave == (it & (kWavesPerBlock - 1));
+        // epilogue operands of the chain wave, fetched before the barrier (lane r = row r of the pass)
+        float resid = 0.f, rc = 0.f, rs = 0.f;
+        const u32 row = pass * Rm + (TWO ? (lane < Rm ? lane : lane - Rm) : lane);   // row inside its matrix
+        const bool rv = chain_wave && lane < R && row < TRm;
+        if constexpr (EPI == EPI_RESIDUAL) { if (rv) resid = a.out[row]; }
+        if constexpr (EPI == EPI_ROPE_KV) {
+            if (rv && row < (u32)(a.dim + a.kv_dim)) {
+                const u32 r2 = (row < (u32)a.dim ? row : row - a.dim) & ~1u;
+                const u32 dd = r2 % (u32)a.hs;
+                rc = a.rope_cos[(size_t)pos * (a.hs / 2) + dd / 2];
+                rs = a.rope_sin[(size_t)pos * (a.hs / 2) + dd / 2];
+            }
+        }
+        __syncthreads();
+        if (!chain_wave) return;
+        // ---- the reference's fp32 chain, lane r = row r: o[j] += s * dot (FMA), groups ascending.
+        //      LDS reads run 8 groups ahead of the FMAs so the chain advances at FMA latency.
+        float acc = 0.f;
+        if (lane < R && !(a.ablate & 1)) {
+            const float* dp = reinterpret_cast<const float*>(dF) + lane * gstride;
+            const float* sp = reinterpret_cast<const float*>(sP) + lane * gstride;
+            u32 g = 0;
+            if (vec_ok) {
+                float4 sa = {0.f, 0.f, 0.f, 0.f}, sb = sa, sc = sa, sd = sa, da = sa, db = sa, dc = sa, dd = sa;
+                if (sn >= 8) { sa = *reinterpret_cast<const float4*>(sp); da = *reinterpret_cast<const float4*>(dp);
+                               sb = *reinterpret_cast<const float4*>(sp + 4); db = *reinterpret_cast<const float4*>(dp + 4); }
+                for (; g + 16 <= sn; g += 16) {
+                    sc = *reinterpret_cast<const float4*>(sp + g + 8);  dc = *reinterpret_cast<const float4*>(dp + g + 8);
+                    sd = *reinterpret_cast<const float4*>(sp + g + 12); dd = *reinterpret_cast<const float4*>(dp + g + 12);
+                    acc = __fmaf_rn(sa.x, da.x, acc); acc = __fmaf_rn(sa.y, da.y, acc); acc = __fmaf_rn(sa.z, da.z, acc); acc = __fmaf_rn(sa.w, da.w, acc);
+                    acc = __fmaf_rn(sb.x, db.x, acc); acc = __fmaf_rn(sb.y, db.y, acc); acc = __fmaf_rn(sb.z, db.z, acc); acc = __fmaf_rn(sb.w, db.w, acc);
+                    if (g + 24 <= sn) { sa = *reinterpret_cast<const float4*>(sp + g + 16); da = *reinterpret_cast<const float4*>(dp + g + 16);
+                                        sb = *reinterpret_cast<const float4*>(sp + g + 20); db = *reinterpret_cast<const float4*>(dp + g + 20); }
+                    acc = __fmaf_rn(sc.x, dc.x, acc); acc = __fmaf_rn(sc.y, dc.y, acc); acc = __fmaf_rn(sc.z, dc.z, acc); acc = __fmaf_rn(sc.w, dc.w, acc);
+                    acc = __fmaf_rn(sd.x, dd.x, acc); acc = __fmaf_rn(sd.y, dd.y, acc); acc = __fmaf_rn(sd.z, dd.z, acc); acc = __fmaf_rn(sd.w, dd.w, acc);
+                }
+                if (g + 8 <= sn) {          // sa/sb hold groups g..g+7
+                    acc = __fmaf_rn(sa.x, da.x, acc); acc = __fmaf_rn(sa.y, da.y, acc); acc = __fmaf_rn(sa.z, da.z, acc); acc = __fmaf_rn(sa.w, da.w, acc);
+                    acc = __fmaf_rn(sb.x, db.x, acc); acc = __fmaf_rn(sb.y, db.y, acc); acc = __fmaf_rn(sb.z, db.z, acc); acc = __fmaf_rn(sb.w, db.w, acc);
+                    g += 8;
+                }
+                for (; g + 4 <= sn; g += 4) {
+                    const float4 s4 = *reinterpret_cast<const float4*>(sp + g), d4 = *reinterpret_cast<const float4*>(dp + g);
+                    acc = __fmaf_rn(s4.x, d4.x, acc); acc = __fmaf_rn(s4.y, d4.y, acc); acc = __fmaf_rn(s4.z, d4.z, acc); acc = __fmaf_rn(s4.w, d4.w, acc);
                 }
             }
-        } else {
-#pragma unroll
-            for (int rr = 0; rr < kRows; ++rr) {
-                const int item = item0 + rr / RPI;
-                const bool rv = item < it1;
-                const char*  wp = row_w(rv ? item : it0, rr % RPI);
-                const float* sp = row_s(rv ? item : it0, rr % RPI);
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const int c = lane + 64 * (jb + jj);
-                    const bool v = rv && c < nchunks;
-                    const v4i z = {0, 0, 0, 0};
-                    w[rr][jj] = v ? __builtin_nontemporal_load(reinterpret_cast<const v4i*>(wp) + c) : z;
-                    sw[rr][jj] = v ? __builtin_nontemporal_load(sp + c / LPG) : 0.f;
+            for (; g < sn; ++g) acc = __fmaf_rn(sp[g], dp[g], acc);
+        }
+        // ---------------- epilogues ----------------
+        if constexpr (EPI == EPI_STORE || EPI == EPI_RESIDUAL) {
+            if (rv) {
+                if constexpr (EPI == EPI_STORE) a.out[row] = acc;
+                else a.out[row] = __fadd_rn(resid, acc);             // o.add(tmp, offset) transformer.cpp:465,493
+            }
+        } else if constexpr (EPI == EPI_SWIGLU) {
+            // lane r < R/2 holds W1[row].x, lane r + R/2 holds W3[row].x
+            const float up = __shfl(acc, (int)(lane + Rm), kWave);
+            if (rv && lane < Rm) a.out[row] = swiglu_elem(acc, up);  // o1.swiglu(o3) transformer.cpp:481
+        } else {   // EPI_ROPE_KV: rows (2i, 2i+1) of [Wq;Wk;Wv]; RoPE on q and k, append k,v to the cache
+            const float other = __shfl_xor(acc, 1, kWave);
+            if (rv && (lane & 1) == 0) {
+                const float x0 = acc, x1 = other;
+                const u32 hs = a.hs;
+                if (row < (u32)(a.dim + a.kv_dim)) {
+                    const u32 rr = row < (u32)a.dim ? row : row - a.dim;
+                    const u32 h = rr / hs, d = rr - h * hs;
+                    float o0, o1;
+                    rope_pair(x0, x1, rc, rs, o0, o1);
+                    if (row < (u32)a.dim) { a.out[row] = o0; a.out[row + 1] = o1; }
+                    else { float* kp = a.kcache + ((size_t)h * a.max_seq + pos) * hs + d; kp[0] = o0; kp[1] = o1; }
+                } else {
+                    const u32 rr = row - a.dim - a.kv_dim;
+                    const u32 h = rr / hs, d = rr - h * hs;
+                    float* vp = a.vcache + ((size_t)h * a.max_seq + pos) * hs + d; vp[0] = x0; vp[1] = x1;
                 }
             }
         }
     };
-    if (it0 < it1) load_batch(it0, 0);
 
-    gemv_prologue<QT, PRO, XR>(a, lds, xv, nv);
-
-    const GemvLds L = gemv_lds_layout(n, T::kEsz, PRO == PRO_RMSNORM_QUANT);
-    const v4i*   xq = reinterpret_cast<const v4i*>(lds);
-    const float* xs = reinterpret_cast<const float*>(lds + L.off_xs);
-    // wave-private chain scratch
-    const int dstride = L.dstride, sstride = L.sstride;
-    char* wscr = lds + L.off_scr + L.wave_bytes * wave;
-    int*   dsub  = reinterpret_cast<int*>(wscr);                               // [kRows][dstride]
-    float* sprod = reinterpret_cast<float*>(wscr) + kRows * dstride;           // [kRows][sstride]
-    const bool vec_ok = (sn % 4) == 0;                                         // 16-B LDS reads need whole float4s per row
-    const int NJ = (nchunks + 63) / 64;
-    int pos = 0;
-    if constexpr (EPI == EPI_ROPE_KV) pos = *a.pos_ptr;
-
-    for (int item0 = it0; item0 < it1; item0 += IPB) {
-        // epilogue operands that live in memory are fetched up front (behind the weight loads, no extra round trip)
-        float resid = 0.f, rc = 0.f, rs = 0.f;
-        if constexpr (EPI == EPI_RESIDUAL) {
-            if (lane < kRows && item0 + lane < it1) resid = a.out[item0 + lane];
-        }
-        if constexpr (EPI == EPI_ROPE_KV) {
-            const int i = item0 + lane / 2;                 // lanes 2k, 2k+1 serve item k (rows 2i, 2i+1)
-            if (lane < kRows && i < it1 && 2 * i < a.dim + a.kv_dim) {
-                const int row = 2 * i, rr = row < a.dim ? row : row - a.dim;
-                const int d = rr % a.hs;
-                rc = a.rope_cos[(size_t)pos * (a.hs / 2) + d / 2];
-                rs = a.rope_sin[(size_t)pos * (a.hs / 2) + d / 2];
-            }
-        }
-        for (int jb = 0; jb < NJ; jb += 4) {
-            if (!(item0 == it0 && jb == 0)) load_batch(item0, jb);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int c = lane + 64 * (jb + jj);
-                const bool cv = c < nchunks;                     // whole quads are in or out (nchunks % 4 == 0)
-                const v4i z = {0, 0, 0, 0};
-                const v4i av = cv ? xq[c] : z;
-                const float sx = cv ? xs[c / LPG] : 0.f;
-#pragma unroll
-                for (int rr = 0; rr < kRows; ++rr) {
-                    const int d = quad_sum(dot_chunk<QT>(w[rr][jj], av));        // DPP: executed by all lanes
-                    if (cv && (lane & 3) == 0) dsub[rr * dstride + c / 4] = d;
-                    if (cv && (lane & (LPG - 1)) == 0) sprod[rr * sstride + c / LPG] = __fmul_rn(sw[rr][jj], sx);   // s = sW * sX (quant_operators.cpp:274)
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // the reference's fp32 chain, one lane per row: o[j] += s * dot  (FMA), groups ascending
-        float acc = 0.f;
-        if (lane < kRows) {
-            const int*   dp = dsub + lane * dstride;
-            const float* sp = sprod + lane * sstride;
-            int g = 0;
-            for (; vec_ok && g + 3 < sn; g += 4) {
-                const float4 s4 = *reinterpret_cast<const float4*>(sp + g);
-                if constexpr (QPG == 1) {
-                    const int4 d4 = *reinterpret_cast<const int4*>(dp + g);
-                    acc = __fmaf_rn(s4.x, (float)d4.x, acc); acc = __fmaf_rn(s4.y, (float)d4.y, acc);
-                    acc = __fmaf_rn(s4.z, (float)d4.z, acc); acc = __fmaf_rn(s4.w, (float)d4.w, acc);
-                } else {
-                    const int4 da = *reinterpret_cast<const int4*>(dp + 2 * g), db = *reinterpret_cast<const int4*>(dp + 2 * g + 4);
-                    acc = __fmaf_rn(s4.x, (float)(da.x + da.y), acc); acc = __fmaf_rn(s4.y, (float)(da.z + da.w), acc);
-                    acc = __fmaf_rn(s4.z, (float)(db.x + db.y), acc); acc = __fmaf_rn(s4.w, (float)(db.z + db.w), acc);
-                }
-            }
-            for (; g < sn; ++g) {
-                int d = dp[QPG * g];
-                if constexpr (QPG == 2) d += dp[2 * g + 1];
-                acc = __fmaf_rn(sp[g], (float)d, acc);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();                         // scratch is rewritten by the next batch
-
-        // ---------------- epilogues (lane rr holds row rr of the batch) ----------------
-        if constexpr (EPI == EPI_STORE || EPI == EPI_RESIDUAL) {
-            const int row = item0 + lane;
-            if (lane < kRows && row < it1) {
-                if constexpr (EPI == EPI_STORE) a.out[row] = acc;
-                else a.out[row] = __fadd_rn(resid, acc);             // o.add(tmp, offset) transformer.cpp:465,493
-            }
-        } else {
-            // two-row items: lane 2k has row 0 of item k, lane 2k+1 row 1; bring the partner value over
-            const float other = __shfl_xor(acc, 1, kWave);
-            const int i = item0 + lane / 2;
-            if (lane < kRows && (lane & 1) == 0 && i < it1) {
-                if constexpr (EPI == EPI_SWIGLU) {
-                    a.out[i] = swiglu_elem(acc, other);              // o1.swiglu(o3) transformer.cpp:481
-                } else {   // EPI_ROPE_KV: rows (2i, 2i+1) of [Wq;Wk;Wv]; RoPE on q and k, append k,v to the cache
-                    const float x0 = acc, x1 = other;
-                    const int row = 2 * i, hs = a.hs;
-                    if (row < a.dim + a.kv_dim) {
-                        const int rr = row < a.dim ? row : row - a.dim;
-                        const int h = rr / hs, d = rr - h * hs;
-                        float o0, o1;
-                        rope_pair(x0, x1, rc, rs, o0, o1);
-                        if (row < a.dim) { a.out[row] = o0; a.out[row + 1] = o1; }
-                        else { float* kp = a.kcache + ((size_t)h * a.max_seq + pos) * hs + d; kp[0] = o0; kp[1] = o1; }
-                    } else {
-                        const int rr = row - a.dim - a.kv_dim;
-                        const int h = rr / hs, d = rr - h * hs;
-                        float* vp = a.vcache + ((size_t)h * a.max_seq + pos) * hs + d; vp[0] = x0; vp[1] = x1;
-                    }
-                }
-            }
-        }
+    Cursor rc_;                                                                // reduce cursor
+    cursor_init(rc_, blockIdx.x);
+    u32 it = 0;                                                                // pass counter of this workgroup
+    auto do_step = [&](Set& S) {
+        char* dF = lds + L.off_scr + (it & 1) * L.buf_bytes;                   // float [R+1][gstride], double buffered across passes
+        char* sP = dF + (R + 1) * gstride * 4;
+        reduce_step(S, rc_, dF, sP);
+        const u32 pass = rc_.pass; const bool last = rc_.s + 1 == spp;
+        for (int j = 0; j < H; ++j) cursor_next_block(rc_);
+        cursor_end_step(rc_);
+        load_step(S, lc);                                                      // refill this set: two steps ahead
+        if (last) { finish_pass(pass, it, dF, sP); ++it; }
+    };
+    while (rc_.pass < npass) {
+        do_step(setA);
+        if (rc_.pass < npass) do_step(setB);
     }
 }
 
@@ -561,31 +651,45 @@ __global__ void __launch_bounds__(kBlock) k_attn_decode(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int hs = a.hs, h = blockIdx.x;
     const int T = *a.pos_ptr + 1;
-    float* qs  = reinterpret_cast<float*>(lds);                  // [hs]
-    float* red = qs + hs;                                        // 16
-    float* sc  = red + 16;                                       // [T] scores -> probabilities
+    float* qs   = reinterpret_cast<float*>(lds);                 // [hs]
+    float* red  = qs + hs;                                       // 16
+    float* part = red + 16;                                      // [4 waves][8 positions][8 lanes] partial dots
+    float* sc   = part + 256;                                    // [T] scores -> probabilities
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* K = a.kcache + (size_t)h * a.max_seq * hs;
     const float* V = a.vcache + (size_t)h * a.max_seq * hs;
     const float scale = (float)(1.0 / (double)__builtin_sqrtf((float)hs));   // attn_scale, transformer.cpp:418
 
     for (int d = threadIdx.x; d < hs; d += kBlock) qs[d] = a.q[(size_t)h * hs + d];
     __syncthreads();
+
+    // ---- scores: lane = (position p = lane/8, strided accumulator k = lane%8) -- the 8 lanes of
+    //      dot_product_avx256; each lane's chain is i ascending, then the 8 partials are added 0..7.
+    const int p = lane >> 3, k = lane & 7;
+    float* wpart = part + wave * 64;
     float lmax = -INFINITY;
-    for (int t = threadIdx.x; t < T; t += kBlock) {
-        const float* kr = K + (size_t)t * hs;
-        float l[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int i = 0; i < hs; i += 8) {
-            const float4 k0 = *reinterpret_cast<const float4*>(kr + i), k1 = *reinterpret_cast<const float4*>(kr + i + 4);
-            const float4 q0 = *reinterpret_cast<const float4*>(qs + i), q1 = *reinterpret_cast<const float4*>(qs + i + 4);
-            l[0] = __fmaf_rn(k0.x, q0.x, l[0]); l[1] = __fmaf_rn(k0.y, q0.y, l[1]); l[2] = __fmaf_rn(k0.z, q0.z, l[2]); l[3] = __fmaf_rn(k0.w, q0.w, l[3]);
-            l[4] = __fmaf_rn(k1.x, q1.x, l[4]); l[5] = __fmaf_rn(k1.y, q1.y, l[5]); l[6] = __fmaf_rn(k1.z, q1.z, l[6]); l[7] = __fmaf_rn(k1.w, q1.w, l[7]);
+    for (int tb = wave * 8; tb < T; tb += 4 * 8) {
+        const int t = tb + p;
+        const bool tv = t < T;
+        const float* kr = K + (size_t)(tv ? t : 0) * hs + k;
+        float l = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < hs; i += 8) l = __fmaf_rn(tv ? kr[i] : 0.f, qs[i + k], l);
+        wpart[lane] = l;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (k == 0 && tv) {
+            const float4 u = *reinterpret_cast<const float4*>(wpart + lane), v = *reinterpret_cast<const float4*>(wpart + lane + 4);
+            float tot = __fadd_rn(0.f, u.x);
+            tot = __fadd_rn(tot, u.y); tot = __fadd_rn(tot, u.z); tot = __fadd_rn(tot, u.w);
+            tot = __fadd_rn(tot, v.x); tot = __fadd_rn(tot, v.y); tot = __fadd_rn(tot, v.z); tot = __fadd_rn(tot, v.w);
+            const float sv = __fmul_rn(tot, scale);             // att.multiply(attn_scale) :443
+            sc[t] = sv;
+            lmax = fmaxf(lmax, sv);
         }
-        float tot = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) tot = __fadd_rn(tot, l[k]);
-        const float s = __fmul_rn(tot, scale);
-        sc[t] = s;
-        lmax = fmaxf(lmax, s);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
     const float m = block_max(lmax, red);                          // array_max is order-free
     for (int t = threadIdx.x; t < T; t += kBlock) sc[t] = expf_ref(__fsub_rn(sc[t], m));
@@ -593,9 +697,19 @@ __global__ void __launch_bounds__(kBlock) k_attn_decode(const AttnArgs a) {
     if (threadIdx.x == 0) {                                        // sum += x[i], i ascending (tf_operators.cpp:180-183)
         float sum = 0.f;
         int t = 0;
-        for (; t + 3 < T; t += 4) {
-            const float4 e = *reinterpret_cast<const float4*>(sc + t);
-            sum = __fadd_rn(sum, e.x); sum = __fadd_rn(sum, e.y); sum = __fadd_rn(sum, e.z); sum = __fadd_rn(sum, e.w);
+        if (T >= 16) {                                             // reads run 16 values ahead of the dependent adds
+            float4 e0 = *reinterpret_cast<const float4*>(sc), e1 = *reinterpret_cast<const float4*>(sc + 4);
+            float4 e2 = *reinterpret_cast<const float4*>(sc + 8), e3 = *reinterpret_cast<const float4*>(sc + 12);
+            for (; t + 16 <= T; t += 16) {
+                float4 n0 = e0, n1 = e1, n2 = e2, n3 = e3;
+                if (t + 32 <= T) { n0 = *reinterpret_cast<const float4*>(sc + t + 16); n1 = *reinterpret_cast<const float4*>(sc + t + 20);
+                                   n2 = *reinterpret_cast<const float4*>(sc + t + 24); n3 = *reinterpret_cast<const float4*>(sc + t + 28); }
+                sum = __fadd_rn(sum, e0.x); sum = __fadd_rn(sum, e0.y); sum = __fadd_rn(sum, e0.z); sum = __fadd_rn(sum, e0.w);
+                sum = __fadd_rn(sum, e1.x); sum = __fadd_rn(sum, e1.y); sum = __fadd_rn(sum, e1.z); sum = __fadd_rn(sum, e1.w);
+                sum = __fadd_rn(sum, e2.x); sum = __fadd_rn(sum, e2.y); sum = __fadd_rn(sum, e2.z); sum = __fadd_rn(sum, e2.w);
+                sum = __fadd_rn(sum, e3.x); sum = __fadd_rn(sum, e3.y); sum = __fadd_rn(sum, e3.z); sum = __fadd_rn(sum, e3.w);
+                e0 = n0; e1 = n1; e2 = n2; e3 = n3;
+            }
         }
         for (; t < T; ++t) sum = __fadd_rn(sum, sc[t]);
         red[8] = sum;
@@ -604,17 +718,28 @@ __global__ void __launch_bounds__(kBlock) k_attn_decode(const AttnArgs a) {
     const float sum = red[8];
     for (int t = threadIdx.x; t < T; t += kBlock) sc[t] = __fdiv_rn(sc[t], sum);
     __syncthreads();
+    // ---- o[d] = sum_t att[t] V[t][d]: one thread per output dimension, t ascending; the V loads of
+    //      8 positions are issued ahead of the 8 dependent FMAs.
     for (int d = threadIdx.x; d < hs; d += kBlock) {
-        float o = __fmul_rn(V[d], sc[0]);                          // row 0 always (tf_operators.cpp:331-336)
-        for (int t = 1; t < T; ++t) {
+        const float* vp = V + d;
+        float o = __fmul_rn(vp[0], sc[0]);                         // row 0 always (tf_operators.cpp:331-336)
+        int t = 1;
+        for (; t + 8 <= T; t += 8) {
+            float v[8], w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { v[u] = vp[(size_t)(t + u) * hs]; w[u] = sc[t + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o = fabsf(w[u]) <= 1e-15f ? o : __fmaf_rn(v[u], w[u], o);   // threshold, transformer.cpp:449
+        }
+        for (; t < T; ++t) {
             const float w = sc[t];
-            if (fabsf(w) <= 1e-15f) continue;                      // weight threshold, transformer.cpp:449
-            o = __fmaf_rn(V[(size_t)t * hs + d], w, o);
+            if (fabsf(w) <= 1e-15f) continue;
+            o = __fmaf_rn(vp[(size_t)t * hs], w, o);
         }
         a.out[(size_t)h * hs + d] = o;
     }
 }
-__host__ inline size_t attn_lds_bytes(int max_seq, int hs) { return (size_t)(hs + 16 + ((max_seq + 3) & ~3)) * 4; }
+__host__ inline size_t attn_lds_bytes(int max_seq, int hs) { return (size_t)(hs + 16 + 256 + ((max_seq + 3) & ~3)) * 4; }
 
 // ------------------------------------------------------------------------------------------
 // small kernels
