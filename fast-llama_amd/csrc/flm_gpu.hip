@@ -59,7 +59,7 @@ struct flm_ctx {
     int prompt_cap = 0, out_cap = 0;
 
     // options
-    int wg_per_cu = 2; int use_graph = 1; int ablate = 0;
+    int wg_per_cu = 1; int use_graph = 1; int ablate = 0;
     std::map<int, hipGraphExec_t> graphs;             // key = with_cls*4 + advance
     std::vector<TimedLaunch>* timing = nullptr;
     std::string err;
@@ -103,7 +103,7 @@ GemvPlan gemv_plan(int n, int esz, int total_rows, int rpi, bool norm, int wgs) 
     int rmax = 64;                                                           // one chain lane per row
     const int gstride = ((sn + 3) & ~3) + kChainPad;
     const int fixed = n * esz + ((sn * 4 + 15) & ~15) + 64;
-    const int lds_budget = 72 * 1024;                                        // two workgroups per CU out of 160 KiB
+    const int lds_budget = 150 * 1024;                                       // one 1024-thread workgroup per CU out of 160 KiB
     const int r_lds = (lds_budget - fixed) / (16 * gstride) - 1;            // two {dF,sP} buffers of R+1 strips
     if (rmax > r_lds) rmax = r_lds;
     if (rmax > 64) rmax = 64;
@@ -126,8 +126,8 @@ int launch_gemv_xr(flm_ctx* c, hipStream_t st, GemvArgs a, int wgs) {
     a.rows_per_pass = P.R; a.cb_shift = P.cb_shift;
     const int rounds = (a.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4);
     if (PRO == PRO_NONE)   hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 0>), dim3(P.grid), dim3(kGemvBlock), P.lds, st, a);
-    else if (rounds <= 2)  hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 2>), dim3(P.grid), dim3(kGemvBlock), P.lds, st, a);
-    else if (rounds <= 6)  hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 6>), dim3(P.grid), dim3(kGemvBlock), P.lds, st, a);
+    else if (rounds <= 1)  hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 1>), dim3(P.grid), dim3(kGemvBlock), P.lds, st, a);
+    else if (rounds <= 3)  hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 3>), dim3(P.grid), dim3(kGemvBlock), P.lds, st, a);
     else                   hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 0>), dim3(P.grid), dim3(kGemvBlock), P.lds, st, a);
     HIPC(c, hipGetLastError());
     return FLM_OK;
@@ -279,7 +279,7 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance) {
             a.q = c->qbuf; a.kcache = c->kcache + (size_t)l * kv_layer; a.vcache = c->vcache + (size_t)l * kv_layer;
             a.out = c->att_out; a.pos_ptr = pos_ptr; a.hs = hs; a.max_seq = d.max_seq_len;
             Tick t(c, st, KC_ATTN);
-            hipLaunchKernelGGL(k_attn_decode, dim3(c->heads_local), dim3(kBlock), attn_lds_bytes(d.max_seq_len, hs), st, a);
+            hipLaunchKernelGGL(k_attn_decode, dim3(c->heads_local), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, hs), st, a);
             HIPC(c, hipGetLastError());
         }
         {   // ATTN_O task + residual (transformer.cpp:138-139, execute_attn_o :457-466)
@@ -540,7 +540,7 @@ void flm_ctx_destroy(flm_ctx* c) {
 int flm_set_option(flm_ctx* c, const char* key, int value) {
     if (!c || !key) return FLM_ERR_INVALID;
     std::string k(key);
-    if (k == "wg_per_cu") c->wg_per_cu = value > 0 ? value : 2;
+    if (k == "wg_per_cu") c->wg_per_cu = value > 0 ? value : 1;
     else if (k == "use_graph") c->use_graph = value;
     else if (k == "ablate") c->ablate = value;
     else return fail(c, FLM_ERR_INVALID, "unknown option");
@@ -780,7 +780,7 @@ int flm_op_matmul_q(int qt, float* out, const void* W, const float* sW, const vo
     for (int b = 0; b < w; ++b) {
         GemvArgs a{}; a.W = dW.p; a.sW = dsW.as<float>(); a.n = n; a.items = m;
         a.xq = (const char*)dX.p + (size_t)b * n * e; a.xs = dsX.as<float>() + (size_t)b * sn; a.out = dO.as<float>() + (size_t)b * m;
-        int r = launch_gemv<PRO_NONE, EPI_STORE>(nullptr, 0, qt, a, gemv_grid(cus, 2, m, 1)); if (r) return r;
+        int r = launch_gemv<PRO_NONE, EPI_STORE>(nullptr, 0, qt, a, gemv_grid(cus, 1, m, 1)); if (r) return r;
     }
     OPC(hipDeviceSynchronize());
     OPC(hipMemcpy(out, dO.p, (size_t)w * m * 4, hipMemcpyDeviceToHost));
@@ -837,7 +837,7 @@ int flm_op_attention(float* out, float* kc, float* vc, const float* q, const flo
     OPC(hipGetLastError());
     AttnArgs a{}; a.q = dq.as<float>(); a.kcache = dkc.as<float>(); a.vcache = dvc.as<float>(); a.pos_ptr = dpos.as<int>(); a.hs = hs; a.max_seq = max_seq;
     a.out = dout.as<float>();
-    hipLaunchKernelGGL(k_attn_decode, dim3(n_heads), dim3(kBlock), attn_lds_bytes(max_seq, hs), 0, a);
+    hipLaunchKernelGGL(k_attn_decode, dim3(n_heads), dim3(kAttnBlock), attn_lds_bytes(max_seq, hs), 0, a);
     OPC(hipGetLastError());
     OPC(hipDeviceSynchronize());
     OPC(hipMemcpy(out, dout.p, nd * 4, hipMemcpyDeviceToHost));

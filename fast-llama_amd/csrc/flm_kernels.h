@@ -37,7 +37,8 @@ namespace flm {
 
 constexpr int kWave = 64;
 constexpr int kBlock = 256;           // attention / small kernels: 4 waves per workgroup
-constexpr int kGemvBlock = 512;       // GEMV: 8 waves per workgroup, >= 2 workgroups per CU (<= 128 VGPRs)
+constexpr int kGemvBlock = 1024;      // GEMV: 16 waves = ONE workgroup per CU (<= 128 VGPRs): one activation prologue (and one
+                                      // sequential rmsnorm chain) per CU instead of two competing for a SIMD
 constexpr int kWavesPerBlock = kGemvBlock / kWave;
 constexpr int kGroup = 64;            // quantization group (QUANT_GROUP_SIZE, the only value the reference uses)
 
@@ -222,7 +223,7 @@ __host__ __device__ inline GemvLds gemv_lds_layout(int n, int esz, bool norm, in
     L.gstride = ((sn + 3) & ~3) + kChainPad;
     L.buf_bytes = 2 * (R + 1) * L.gstride * 4;                                // +1: dummy strip that absorbs the writes of blocks past the pass
     int scratch = 2 * L.buf_bytes;
-    if (norm && n * 4 > scratch) scratch = n * 4;
+    if (norm && n * 4 + 256 > scratch) scratch = n * 4 + 256;                   // +256: the chain ring reads up to 32 floats past the last strip
     L.total = L.off_scr + scratch;
     return L;
 }
@@ -304,22 +305,26 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
                 float l = 0.f;
                 int k = 0;
 #define FLM_SQ4(v) l = __fmaf_rn(v.x, v.x, l); l = __fmaf_rn(v.y, v.y, l); l = __fmaf_rn(v.z, v.z, l); l = __fmaf_rn(v.w, v.w, l);
+#define FLM_STEP(q, off) FLM_SQ4(q) q = *reinterpret_cast<const float4*>(pp + (off)); __builtin_amdgcn_sched_barrier(0);
                 if (n4 >= 32) {
-                    // two named register sets, refilled alternately: the loop body is FMAs and LDS reads only
-                    float4 a0 = *reinterpret_cast<const float4*>(p), a1 = *reinterpret_cast<const float4*>(p + 4);
-                    float4 a2 = *reinterpret_cast<const float4*>(p + 8), a3 = *reinterpret_cast<const float4*>(p + 12);
-                    float4 b0, b1, b2, b3;
-                    for (; k + 32 <= n4; k += 32) {
-                        b0 = *reinterpret_cast<const float4*>(p + k + 16); b1 = *reinterpret_cast<const float4*>(p + k + 20);
-                        b2 = *reinterpret_cast<const float4*>(p + k + 24); b3 = *reinterpret_cast<const float4*>(p + k + 28);
-                        FLM_SQ4(a0) FLM_SQ4(a1) FLM_SQ4(a2) FLM_SQ4(a3)
-                        const int kn = k + 48 <= n4 ? k + 32 : k;                 // clamp (the reload is unused on the last trip)
-                        a0 = *reinterpret_cast<const float4*>(p + kn); a1 = *reinterpret_cast<const float4*>(p + kn + 4);
-                        a2 = *reinterpret_cast<const float4*>(p + kn + 8); a3 = *reinterpret_cast<const float4*>(p + kn + 12);
-                        FLM_SQ4(b0) FLM_SQ4(b1) FLM_SQ4(b2) FLM_SQ4(b3)
+                    // A lone wave issues roughly one instruction every ~5 cycles, whatever its kind, so the
+                    // loop body is nothing but the 32 dependent FMAs and 8 LDS reads with immediate offsets:
+                    // a ring of 8 float4 registers, every read issued 28 FMAs before its first use (the
+                    // sched_barriers pin that order).  Reads run up to 32 floats past a lane's strip: the
+                    // staging area is sized for that (gemv_lds_layout) and those values are never consumed.
+                    const float* pp = p;
+                    float4 q0 = *reinterpret_cast<const float4*>(pp), q1 = *reinterpret_cast<const float4*>(pp + 4), q2 = *reinterpret_cast<const float4*>(pp + 8), q3 = *reinterpret_cast<const float4*>(pp + 12);
+                    float4 q4 = *reinterpret_cast<const float4*>(pp + 16), q5 = *reinterpret_cast<const float4*>(pp + 20), q6 = *reinterpret_cast<const float4*>(pp + 24), q7 = *reinterpret_cast<const float4*>(pp + 28);
+                    __builtin_amdgcn_sched_barrier(0);
+                    for (; k + 32 <= n4; k += 32, pp += 32) {
+                        FLM_STEP(q0, 32) FLM_STEP(q1, 36) FLM_STEP(q2, 40) FLM_STEP(q3, 44)
+                        FLM_STEP(q4, 48) FLM_STEP(q5, 52) FLM_STEP(q6, 56) FLM_STEP(q7, 60)
                     }
-                    if (k + 16 <= n4) { FLM_SQ4(a0) FLM_SQ4(a1) FLM_SQ4(a2) FLM_SQ4(a3) k += 16; }
+                    // the ring now holds p[k .. k+31]
+                    if (k + 4 <= n4) { FLM_SQ4(q0) k += 4; } if (k + 4 <= n4) { FLM_SQ4(q1) k += 4; } if (k + 4 <= n4) { FLM_SQ4(q2) k += 4; } if (k + 4 <= n4) { FLM_SQ4(q3) k += 4; }
+                    if (k + 4 <= n4) { FLM_SQ4(q4) k += 4; } if (k + 4 <= n4) { FLM_SQ4(q5) k += 4; } if (k + 4 <= n4) { FLM_SQ4(q6) k += 4; }
                 }
+#undef FLM_STEP
 #undef FLM_SQ4
                 for (; k < n4; ++k) l = __fmaf_rn(p[k], p[k], l);
                 red[8 + tid] = l;
@@ -647,20 +652,21 @@ struct AttnArgs {
     int hs, max_seq;
 };
 
-__global__ void __launch_bounds__(kBlock) k_attn_decode(const AttnArgs a) {
+constexpr int kAttnBlock = 1024;      // 16 waves: 128 positions are scored per sweep (8 lanes per position)
+__global__ void __launch_bounds__(kAttnBlock) k_attn_decode(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int hs = a.hs, h = blockIdx.x;
     const int T = *a.pos_ptr + 1;
     float* qs   = reinterpret_cast<float*>(lds);                 // [hs]
-    float* red  = qs + hs;                                       // 16
-    float* part = red + 16;                                      // [4 waves][8 positions][8 lanes] partial dots
-    float* sc   = part + 256;                                    // [T] scores -> probabilities
+    float* red  = qs + hs;                                       // 32
+    float* part = red + 32;                                      // [16 waves][8 positions][8 lanes] partial dots
+    float* sc   = part + 16 * 64;                                // [T] scores -> probabilities (+32 floats of slack)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* K = a.kcache + (size_t)h * a.max_seq * hs;
     const float* V = a.vcache + (size_t)h * a.max_seq * hs;
     const float scale = (float)(1.0 / (double)__builtin_sqrtf((float)hs));   // attn_scale, transformer.cpp:418
 
-    for (int d = threadIdx.x; d < hs; d += kBlock) qs[d] = a.q[(size_t)h * hs + d];
+    for (int d = threadIdx.x; d < hs; d += kAttnBlock) qs[d] = a.q[(size_t)h * hs + d];
     __syncthreads();
 
     // ---- scores: lane = (position p = lane/8, strided accumulator k = lane%8) -- the 8 lanes of
@@ -668,13 +674,13 @@ __global__ void __launch_bounds__(kBlock) k_attn_decode(const AttnArgs a) {
     const int p = lane >> 3, k = lane & 7;
     float* wpart = part + wave * 64;
     float lmax = -INFINITY;
-    for (int tb = wave * 8; tb < T; tb += 4 * 8) {
+    for (int tb = wave * 8; tb < T; tb += 16 * 8) {
         const int t = tb + p;
         const bool tv = t < T;
         const float* kr = K + (size_t)(tv ? t : 0) * hs + k;
         float l = 0.f;
-#pragma unroll 8
-        for (int i = 0; i < hs; i += 8) l = __fmaf_rn(tv ? kr[i] : 0.f, qs[i + k], l);
+#pragma unroll 16
+        for (int i = 0; i < hs; i += 8) l = __fmaf_rn(kr[i], qs[i + k], l);
         wpart[lane] = l;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -691,55 +697,63 @@ __global__ void __launch_bounds__(kBlock) k_attn_decode(const AttnArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    const float m = block_max(lmax, red);                          // array_max is order-free
-    for (int t = threadIdx.x; t < T; t += kBlock) sc[t] = expf_ref(__fsub_rn(sc[t], m));
+    // block max over 16 waves (array_max is order-free)
+    lmax = wave_max(lmax);
+    if (lane == 0) red[wave] = lmax;
+    __syncthreads();
+    float m = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+    for (int t = threadIdx.x; t < T; t += kAttnBlock) sc[t] = expf_ref(__fsub_rn(sc[t], m));
     __syncthreads();
     if (threadIdx.x == 0) {                                        // sum += x[i], i ascending (tf_operators.cpp:180-183)
+        // a lone lane: the loop is the T dependent adds plus one LDS read per four of them, reads 28 adds ahead
         float sum = 0.f;
         int t = 0;
-        if (T >= 16) {                                             // reads run 16 values ahead of the dependent adds
-            float4 e0 = *reinterpret_cast<const float4*>(sc), e1 = *reinterpret_cast<const float4*>(sc + 4);
-            float4 e2 = *reinterpret_cast<const float4*>(sc + 8), e3 = *reinterpret_cast<const float4*>(sc + 12);
-            for (; t + 16 <= T; t += 16) {
-                float4 n0 = e0, n1 = e1, n2 = e2, n3 = e3;
-                if (t + 32 <= T) { n0 = *reinterpret_cast<const float4*>(sc + t + 16); n1 = *reinterpret_cast<const float4*>(sc + t + 20);
-                                   n2 = *reinterpret_cast<const float4*>(sc + t + 24); n3 = *reinterpret_cast<const float4*>(sc + t + 28); }
-                sum = __fadd_rn(sum, e0.x); sum = __fadd_rn(sum, e0.y); sum = __fadd_rn(sum, e0.z); sum = __fadd_rn(sum, e0.w);
-                sum = __fadd_rn(sum, e1.x); sum = __fadd_rn(sum, e1.y); sum = __fadd_rn(sum, e1.z); sum = __fadd_rn(sum, e1.w);
-                sum = __fadd_rn(sum, e2.x); sum = __fadd_rn(sum, e2.y); sum = __fadd_rn(sum, e2.z); sum = __fadd_rn(sum, e2.w);
-                sum = __fadd_rn(sum, e3.x); sum = __fadd_rn(sum, e3.y); sum = __fadd_rn(sum, e3.z); sum = __fadd_rn(sum, e3.w);
-                e0 = n0; e1 = n1; e2 = n2; e3 = n3;
+#define FLM_ADD4(q) sum = __fadd_rn(sum, q.x); sum = __fadd_rn(sum, q.y); sum = __fadd_rn(sum, q.z); sum = __fadd_rn(sum, q.w);
+#define FLM_ASTEP(q, off) FLM_ADD4(q) q = *reinterpret_cast<const float4*>(pp + (off)); __builtin_amdgcn_sched_barrier(0);
+        if (T >= 32) {
+            const float* pp = sc;
+            float4 q0 = *reinterpret_cast<const float4*>(pp), q1 = *reinterpret_cast<const float4*>(pp + 4), q2 = *reinterpret_cast<const float4*>(pp + 8), q3 = *reinterpret_cast<const float4*>(pp + 12);
+            float4 q4 = *reinterpret_cast<const float4*>(pp + 16), q5 = *reinterpret_cast<const float4*>(pp + 20), q6 = *reinterpret_cast<const float4*>(pp + 24), q7 = *reinterpret_cast<const float4*>(pp + 28);
+            __builtin_amdgcn_sched_barrier(0);
+            for (; t + 32 <= T; t += 32, pp += 32) {
+                FLM_ASTEP(q0, 32) FLM_ASTEP(q1, 36) FLM_ASTEP(q2, 40) FLM_ASTEP(q3, 44)
+                FLM_ASTEP(q4, 48) FLM_ASTEP(q5, 52) FLM_ASTEP(q6, 56) FLM_ASTEP(q7, 60)
             }
+            if (t + 4 <= T) { FLM_ADD4(q0) t += 4; } if (t + 4 <= T) { FLM_ADD4(q1) t += 4; } if (t + 4 <= T) { FLM_ADD4(q2) t += 4; } if (t + 4 <= T) { FLM_ADD4(q3) t += 4; }
+            if (t + 4 <= T) { FLM_ADD4(q4) t += 4; } if (t + 4 <= T) { FLM_ADD4(q5) t += 4; } if (t + 4 <= T) { FLM_ADD4(q6) t += 4; }
         }
+#undef FLM_ASTEP
+#undef FLM_ADD4
         for (; t < T; ++t) sum = __fadd_rn(sum, sc[t]);
-        red[8] = sum;
+        red[16] = sum;
     }
     __syncthreads();
-    const float sum = red[8];
-    for (int t = threadIdx.x; t < T; t += kBlock) sc[t] = __fdiv_rn(sc[t], sum);
+    const float sum = red[16];
+    for (int t = threadIdx.x; t < T; t += kAttnBlock) sc[t] = __fdiv_rn(sc[t], sum);
     __syncthreads();
-    // ---- o[d] = sum_t att[t] V[t][d]: one thread per output dimension, t ascending; the V loads of
-    //      8 positions are issued ahead of the 8 dependent FMAs.
-    for (int d = threadIdx.x; d < hs; d += kBlock) {
+    // ---- o[d] = sum_t att[t] V[t][d]: one thread per output dimension, t ascending (the reference's
+    //      chain); 8 V rows are loaded ahead of their 8 dependent FMAs, the weights come 4 per LDS read.
+    for (int d = threadIdx.x; d < hs; d += kAttnBlock) {
         const float* vp = V + d;
         float o = __fmul_rn(vp[0], sc[0]);                         // row 0 always (tf_operators.cpp:331-336)
         int t = 1;
+        for (; t < T && (t & 3); ++t) { const float w = sc[t]; o = fabsf(w) <= 1e-15f ? o : __fmaf_rn(vp[(size_t)t * hs], w, o); }
         for (; t + 8 <= T; t += 8) {
-            float v[8], w[8];
+            float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { v[u] = vp[(size_t)(t + u) * hs]; w[u] = sc[t + u]; }
+            for (int u = 0; u < 8; ++u) v[u] = vp[(size_t)(t + u) * hs];
+            const float4 w0 = *reinterpret_cast<const float4*>(sc + t), w1 = *reinterpret_cast<const float4*>(sc + t + 4);
+            const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
             for (int u = 0; u < 8; ++u) o = fabsf(w[u]) <= 1e-15f ? o : __fmaf_rn(v[u], w[u], o);   // threshold, transformer.cpp:449
         }
-        for (; t < T; ++t) {
-            const float w = sc[t];
-            if (fabsf(w) <= 1e-15f) continue;
-            o = __fmaf_rn(vp[(size_t)t * hs], w, o);
-        }
+        for (; t < T; ++t) { const float w = sc[t]; o = fabsf(w) <= 1e-15f ? o : __fmaf_rn(vp[(size_t)t * hs], w, o); }
         a.out[(size_t)h * hs + d] = o;
     }
 }
-__host__ inline size_t attn_lds_bytes(int max_seq, int hs) { return (size_t)(hs + 16 + 256 + ((max_seq + 3) & ~3)) * 4; }
+__host__ inline size_t attn_lds_bytes(int max_seq, int hs) { return (size_t)(hs + 32 + 16 * 64 + ((max_seq + 3) & ~3) + 64) * 4; }
 
 // ------------------------------------------------------------------------------------------
 // small kernels
@@ -766,7 +780,23 @@ struct DecodeState { int pos; int tok; int step; int pad; };
 __global__ void __launch_bounds__(1024) k_argmax_advance(const float* logits, int n, DecodeState* st, int* out_tokens, int advance) {
     __shared__ float bv[16]; __shared__ int bi[16];
     float best = -INFINITY; int idx = 0x7fffffff;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) { const float v = logits[i]; if (v > best) { best = v; idx = i; } }
+    // ascending index order within a thread and strict '>' keep the FIRST maximum
+    const int n4 = n >> 2;
+    for (int j0 = 0; j0 < n4; j0 += 8 * 1024) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int j = j0 + u * 1024 + threadIdx.x; v[u] = j < n4 ? reinterpret_cast<const float4*>(logits)[j] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = (j0 + u * 1024 + threadIdx.x) * 4;
+            if (v[u].x > best) { best = v[u].x; idx = i; }
+            if (v[u].y > best) { best = v[u].y; idx = i + 1; }
+            if (v[u].z > best) { best = v[u].z; idx = i + 2; }
+            if (v[u].w > best) { best = v[u].w; idx = i + 3; }
+        }
+    }
+    for (int i = n4 * 4 + threadIdx.x; i < n; i += 1024) { const float v = logits[i]; if (v > best) { best = v; idx = i; } }
+    // lower index wins ties across threads: thread-local indices are not globally ordered, so compare (value, index)
     for (int o = 32; o > 0; o >>= 1) {
         const float ov = __shfl_xor(best, o, kWave); const int oi = __shfl_xor(idx, o, kWave);
         if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
