@@ -37,7 +37,7 @@ class ModelDesc(C.Structure):
 
 
 class ShardPlan(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("head_begin", "head_count", "hidden_begin", "hidden_count", "vocab_begin", "vocab_count")]
+    _fields_ = [(n, C.c_int32) for n in ("head_begin", "head_count", "hidden_begin", "hidden_count", "dim_begin", "dim_count", "vocab_begin", "vocab_count")]
 
 
 _lib = None

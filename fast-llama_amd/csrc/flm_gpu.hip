@@ -42,7 +42,8 @@ struct flm_ctx {
     int device = 0, rank = 0, world = 1;
     flm_shard_plan plan{};
     int hs = 0, esz = 1, cu_count = 256;
-    int dim_local = 0, hidden_local = 0, heads_local = 0, vocab_slot = 0;
+    int dim_local = 0, hidden_local = 0, heads_local = 0, vocab_slot = 0;    // dim_local = heads_local*hs: q/k/v rows and attention outputs owned
+    int drow_begin = 0, drow_count = 0;                                       // rows of Wo / W2 (= slice of the residual stream) owned
     hipStream_t stream = nullptr;
     ncclComm_t comm = nullptr;
 
@@ -53,7 +54,7 @@ struct flm_ctx {
 
     float *kcache = nullptr, *vcache = nullptr;       // [L][heads_local][max_seq][hs]
     float *x1 = nullptr, *qbuf = nullptr, *att_out = nullptr, *hd = nullptr;
-    float *partial = nullptr, *logits = nullptr;
+    float *logits = nullptr;
     float *rope_cos = nullptr, *rope_sin = nullptr;
     DecodeState* state = nullptr; int* prompt_dev = nullptr; int* out_tokens_dev = nullptr;
     int prompt_cap = 0, out_cap = 0;
@@ -274,52 +275,54 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance) {
             int r = launch_gemv<PRO_RMSNORM_QUANT, EPI_ROPE_KV>(c, st, qt, a, gemv_grid(c->cu_count, c->wg_per_cu, a.items, 2));
             if (r) return r;
         }
-        {   // ATTN task (execute_attn :441-449)
+        {   // ATTN task (execute_attn :441-449): local heads write their slice of the full att_out vector
             AttnArgs a{};
             a.q = c->qbuf; a.kcache = c->kcache + (size_t)l * kv_layer; a.vcache = c->vcache + (size_t)l * kv_layer;
-            a.out = c->att_out; a.pos_ptr = pos_ptr; a.hs = hs; a.max_seq = d.max_seq_len;
+            a.out = c->att_out + (size_t)c->plan.head_begin * hs; a.pos_ptr = pos_ptr; a.hs = hs; a.max_seq = d.max_seq_len;
             Tick t(c, st, KC_ATTN);
             hipLaunchKernelGGL(k_attn_decode, dim3(c->heads_local), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, hs), st, a);
             HIPC(c, hipGetLastError());
         }
-        {   // ATTN_O task + residual (transformer.cpp:138-139, execute_attn_o :457-466)
+        if (tp) {   // every rank needs all heads' outputs: the reference's threads share x2 in memory (transformer.cpp:451-454)
+            Tick t(c, st, KC_ALLREDUCE);
+            NCCLC(c, ncclAllGather(c->att_out + (size_t)c->plan.head_begin * hs, c->att_out, c->dim_local, ncclFloat, c->comm, st));
+        }
+        {   // ATTN_O task + residual (transformer.cpp:138-139, execute_attn_o :457-466): this rank's rows of Wo
             GemvArgs a{}; a.ablate = c->ablate;
-            a.W = w.o.q; a.sW = w.o.s; a.n = c->dim_local; a.items = d.dim;
+            a.W = w.o.q; a.sW = w.o.s; a.n = d.dim; a.items = c->drow_count;
             a.x = c->att_out;
-            a.out = tp ? c->partial : c->x1;
+            a.out = c->x1 + c->drow_begin;
             Tick t(c, st, KC_ATTN_O);
-            const int grid = gemv_grid(c->cu_count, c->wg_per_cu, a.items, 1);
-            int r = tp ? launch_gemv<PRO_QUANT, EPI_STORE>(c, st, qt, a, grid) : launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, a, grid);
+            int r = launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, a, gemv_grid(c->cu_count, c->wg_per_cu, a.items, 1));
             if (r) return r;
         }
         if (tp) {
             Tick t(c, st, KC_ALLREDUCE);
-            NCCLC(c, ncclAllReduce(c->partial, c->partial, d.dim, ncclFloat, ncclSum, c->comm, st));
-            hipLaunchKernelGGL(k_add_inplace, dim3((d.dim + 255) / 256), dim3(256), 0, st, c->x1, (const float*)c->partial, d.dim);
-            HIPC(c, hipGetLastError());
+            NCCLC(c, ncclAllGather(c->x1 + c->drow_begin, c->x1, c->drow_count, ncclFloat, c->comm, st));
         }
-        {   // FFN13 task + SwiGLU (transformer.cpp:144-147, execute_ffn13 :468-483)
+        {   // FFN13 task + SwiGLU (transformer.cpp:144-147, execute_ffn13 :468-483): this rank's rows of W1/W3
             GemvArgs a{}; a.ablate = c->ablate;
             a.W = w.w1.q; a.sW = w.w1.s; a.W2nd = w.w3.q; a.sW2nd = w.w3.s; a.n = d.dim; a.items = c->hidden_local;
-            a.x = c->x1; a.norm_w = w.ffn_norm; a.out = c->hd;
+            a.x = c->x1; a.norm_w = w.ffn_norm; a.out = c->hd + c->plan.hidden_begin;
             Tick t(c, st, KC_FFN13);
             int r = launch_gemv<PRO_RMSNORM_QUANT, EPI_SWIGLU>(c, st, qt, a, gemv_grid(c->cu_count, c->wg_per_cu, a.items, 2));
             if (r) return r;
         }
-        {   // FFN2 task + residual (transformer.cpp:149-150, execute_ffn2 :485-494)
+        if (tp) {
+            Tick t(c, st, KC_ALLREDUCE);
+            NCCLC(c, ncclAllGather(c->hd + c->plan.hidden_begin, c->hd, c->hidden_local, ncclFloat, c->comm, st));
+        }
+        {   // FFN2 task + residual (transformer.cpp:149-150, execute_ffn2 :485-494): this rank's rows of W2
             GemvArgs a{}; a.ablate = c->ablate;
-            a.W = w.w2.q; a.sW = w.w2.s; a.n = c->hidden_local; a.items = d.dim;
-            a.x = c->hd; a.out = tp ? c->partial : c->x1;
+            a.W = w.w2.q; a.sW = w.w2.s; a.n = d.hidden_dim; a.items = c->drow_count;
+            a.x = c->hd; a.out = c->x1 + c->drow_begin;
             Tick t(c, st, KC_FFN2);
-            const int grid = gemv_grid(c->cu_count, c->wg_per_cu, a.items, 1);
-            int r = tp ? launch_gemv<PRO_QUANT, EPI_STORE>(c, st, qt, a, grid) : launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, a, grid);
+            int r = launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, a, gemv_grid(c->cu_count, c->wg_per_cu, a.items, 1));
             if (r) return r;
         }
         if (tp) {
             Tick t(c, st, KC_ALLREDUCE);
-            NCCLC(c, ncclAllReduce(c->partial, c->partial, d.dim, ncclFloat, ncclSum, c->comm, st));
-            hipLaunchKernelGGL(k_add_inplace, dim3((d.dim + 255) / 256), dim3(256), 0, st, c->x1, (const float*)c->partial, d.dim);
-            HIPC(c, hipGetLastError());
+            NCCLC(c, ncclAllGather(c->x1 + c->drow_begin, c->x1, c->drow_count, ncclFloat, c->comm, st));
         }
     }
     if (with_cls) {
@@ -433,14 +436,16 @@ const char* flm_last_error(const flm_ctx* ctx) { return ctx ? ctx->err.c_str() :
 
 int flm_plan_shards(const flm_model_desc* d, int rank, int world, flm_shard_plan* out) {
     if (!d || !out || world < 1 || rank < 0 || rank >= world) return FLM_ERR_INVALID;
-    if (d->n_heads < world) return FLM_ERR_UNSUPPORTED;
-    const int gs = d->quant_group_size > 0 ? d->quant_group_size : kGroup;
-    if (d->hidden_dim % gs) return FLM_ERR_INVALID;
-    int b, n;
-    split_even(d->n_heads, world, rank, &b, &n);           out->head_begin = b; out->head_count = n;
-    split_even(d->hidden_dim / gs, world, rank, &b, &n);   out->hidden_begin = b * gs; out->hidden_count = n * gs;
-    const int slot = (d->vocab_size + world - 1) / world;  // ceil split: slot layout == vocab layout
-    b = slot * rank; n = d->vocab_size - b; if (n > slot) n = slot; if (n < 0) n = 0;
+    // Every matmul is split by OUTPUT ROWS, exactly like the reference's worker threads (split_rows,
+    // transformer.cpp:264-287): a row is always reduced on one rank in the reference's order, so sharded
+    // results stay bit-identical to the single-GPU / CPU path; ranks exchange activations by all-gather,
+    // which needs equal contiguous slices.
+    if (d->n_heads % world || d->hidden_dim % world || d->dim % world) return FLM_ERR_UNSUPPORTED;
+    out->head_count = d->n_heads / world;      out->head_begin = out->head_count * rank;
+    out->hidden_count = d->hidden_dim / world; out->hidden_begin = out->hidden_count * rank;
+    out->dim_count = d->dim / world;           out->dim_begin = out->dim_count * rank;
+    const int slot = (d->vocab_size + world - 1) / world;  // ceil split: slot layout == vocab layout, padding past vocab_size
+    int b = slot * rank, n = d->vocab_size - b; if (n > slot) n = slot; if (n < 0) n = 0;
     out->vocab_begin = b; out->vocab_count = n;
     return FLM_OK;
 }
@@ -468,7 +473,6 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
     const int hs = d.dim / d.n_heads;
     if (hs % 8 || hs < 32) return fail(nullptr, FLM_ERR_UNSUPPORTED, "head_size must be a multiple of 8 and >= 32 (the reference's 8-lane dot_product path, x86_simd.cpp:1677-1699)");
     if (world < 1 || rank < 0 || rank >= world) return fail(nullptr, FLM_ERR_INVALID, "rank/world");
-    if (world > 1 && (hs % kGroup)) return fail(nullptr, FLM_ERR_UNSUPPORTED, "tensor parallelism needs head_size % 64 == 0 (quant groups may not straddle ranks)");
     if (world > 1 && !comm_id) return fail(nullptr, FLM_ERR_INVALID, "comm_id required when world > 1");
 
     flm_ctx* c = new flm_ctx();
@@ -476,6 +480,7 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
     int r = flm_plan_shards(desc, rank, world, &c->plan);
     if (r) { delete c; return fail(nullptr, r, "cannot shard this model over the requested world size"); }
     c->heads_local = c->plan.head_count; c->dim_local = c->heads_local * hs; c->hidden_local = c->plan.hidden_count;
+    c->drow_begin = c->plan.dim_begin; c->drow_count = c->plan.dim_count;
     c->vocab_slot = (d.vocab_size + world - 1) / world;
     auto bail = [&](int code) { g_last_error = c->err; flm_ctx_destroy(c); return code; };
 #define HIPB(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { c->err = std::string(#expr " failed: ") + hipGetErrorString(e_); return bail(FLM_ERR_HIP); } } while (0)
@@ -492,9 +497,9 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
     c->layers.resize(L);
     for (int l = 0; l < L; ++l) {
         LayerW& w = c->layers[l];
-        if (alloc_qmat(c, w.qkv, 3 * c->dim_local, d.dim, qt) || alloc_qmat(c, w.o, d.dim, c->dim_local, qt) ||
+        if (alloc_qmat(c, w.qkv, 3 * c->dim_local, d.dim, qt) || alloc_qmat(c, w.o, c->drow_count, d.dim, qt) ||
             alloc_qmat(c, w.w1, c->hidden_local, d.dim, qt) || alloc_qmat(c, w.w3, c->hidden_local, d.dim, qt) ||
-            alloc_qmat(c, w.w2, d.dim, c->hidden_local, qt)) return bail(FLM_ERR_OOM);
+            alloc_qmat(c, w.w2, c->drow_count, d.hidden_dim, qt)) return bail(FLM_ERR_OOM);
         HIPB(hipMalloc((void**)&w.att_norm, d.dim * 4)); HIPB(hipMalloc((void**)&w.ffn_norm, d.dim * 4));
     }
     if (alloc_qmat(c, c->cls, c->plan.vocab_count > 0 ? c->plan.vocab_count : 1, d.dim, qt)) return bail(FLM_ERR_OOM);
@@ -504,8 +509,8 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
     HIPB(hipMalloc((void**)&c->kcache, kvn * 4)); HIPB(hipMalloc((void**)&c->vcache, kvn * 4));
     HIPB(hipMemsetAsync(c->kcache, 0, kvn * 4, c->stream)); HIPB(hipMemsetAsync(c->vcache, 0, kvn * 4, c->stream));
     HIPB(hipMalloc((void**)&c->x1, d.dim * 4)); HIPB(hipMalloc((void**)&c->qbuf, c->dim_local * 4));
-    HIPB(hipMalloc((void**)&c->att_out, c->dim_local * 4));
-    HIPB(hipMalloc((void**)&c->hd, c->hidden_local * 4)); HIPB(hipMalloc((void**)&c->partial, d.dim * 4));
+    HIPB(hipMalloc((void**)&c->att_out, d.dim * 4));                    // full vectors on every rank (all-gathered under TP)
+    HIPB(hipMalloc((void**)&c->hd, d.hidden_dim * 4));
     HIPB(hipMalloc((void**)&c->logits, (size_t)c->vocab_slot * world * 4));
     HIPB(hipMemsetAsync(c->logits, 0, (size_t)c->vocab_slot * world * 4, c->stream));
     HIPB(hipMalloc((void**)&c->state, sizeof(DecodeState)));
@@ -529,7 +534,7 @@ void flm_ctx_destroy(flm_ctx* c) {
     auto fq = [](QMat& m) { if (m.q) hipFree(m.q); if (m.s) hipFree(m.s); };
     for (auto& l : c->layers) { fq(l.qkv); fq(l.o); fq(l.w1); fq(l.w3); fq(l.w2); if (l.att_norm) hipFree(l.att_norm); if (l.ffn_norm) hipFree(l.ffn_norm); }
     fq(c->cls);
-    void* ptrs[] = {c->emb, c->emb_s, c->out_norm, c->kcache, c->vcache, c->x1, c->qbuf, c->att_out, c->hd, c->partial,
+    void* ptrs[] = {c->emb, c->emb_s, c->out_norm, c->kcache, c->vcache, c->x1, c->qbuf, c->att_out, c->hd,
                     c->logits, c->rope_cos, c->rope_sin, c->state, c->prompt_dev, c->out_tokens_dev};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->comm) ncclCommDestroy(c->comm);
@@ -589,10 +594,7 @@ int flm_upload_tensor(flm_ctx* c, int kind, int layer, int src_qt, const void* v
         return r; }
     case FLM_T_ATTN_O: {
         if (rows != d.dim || cols != d.dim) return fail(c, FLM_ERR_INVALID, "o shape");
-        if (src_qt == FLM_QT_NONE && c->world > 1) {
-            // fp32 source under TP: groups are along the columns, so quantizing the column window equals windowing the quantized matrix
-        }
-        int r = upload_window(c, c->layers[layer].o, 0, src_qt, values, scales, cols, 0, rows, hb, hn);
+        int r = upload_window(c, c->layers[layer].o, 0, src_qt, values, scales, cols, c->drow_begin, c->drow_count, 0, cols);
         if (!r) c->layers[layer].got |= 1u << 5;
         return r; }
     case FLM_T_MLP_GATE: case FLM_T_MLP_UP: {
@@ -603,7 +605,7 @@ int flm_upload_tensor(flm_ctx* c, int kind, int layer, int src_qt, const void* v
         return r; }
     case FLM_T_MLP_DOWN: {
         if (rows != d.dim || cols != d.hidden_dim) return fail(c, FLM_ERR_INVALID, "ffn2 shape");
-        int r = upload_window(c, c->layers[layer].w2, 0, src_qt, values, scales, cols, 0, rows, c->plan.hidden_begin, c->plan.hidden_count);
+        int r = upload_window(c, c->layers[layer].w2, 0, src_qt, values, scales, cols, c->drow_begin, c->drow_count, 0, cols);
         if (!r) c->layers[layer].got |= 1u << 8;
         return r; }
     default: return fail(c, FLM_ERR_INVALID, "unknown tensor kind");
@@ -628,8 +630,8 @@ int flm_debug_read(flm_ctx* c, int what, int layer, float* out, size_t n) {
     switch (what) {
     case 0: src = c->x1; cap = c->d.dim; break;
     case 1: src = c->qbuf; cap = c->dim_local; break;
-    case 2: src = c->att_out; cap = c->dim_local; break;
-    case 3: src = c->hd; cap = c->hidden_local; break;
+    case 2: src = c->att_out; cap = c->d.dim; break;
+    case 3: src = c->hd; cap = c->d.hidden_dim; break;
     case 4: src = c->kcache + (size_t)layer * kvl; cap = kvl; break;
     case 5: src = c->vcache + (size_t)layer * kvl; cap = kvl; break;
     case 6: src = c->logits; cap = (size_t)c->vocab_slot * c->world; break;
@@ -722,9 +724,9 @@ int flm_kernel_bytes(flm_ctx* c, int kclass, int pos, double* bytes) {
     case KC_EMBED:  *bytes = d.dim * 4.0; break;
     case KC_QKV:    *bytes = mat(3.0 * c->dim_local, d.dim) + d.dim * 4.0; break;               // + rmsnorm weight
     case KC_ATTN:   *bytes = 2.0 * c->heads_local * c->hs * 4.0 * (pos + 1); break;             // fp32 K and V rows
-    case KC_ATTN_O: *bytes = mat(d.dim, c->dim_local); break;
+    case KC_ATTN_O: *bytes = mat(c->drow_count, d.dim); break;
     case KC_FFN13:  *bytes = 2.0 * mat(c->hidden_local, d.dim) + d.dim * 4.0; break;
-    case KC_FFN2:   *bytes = mat(d.dim, c->hidden_local); break;
+    case KC_FFN2:   *bytes = mat(c->drow_count, d.hidden_dim); break;
     case KC_CLS:    *bytes = mat(c->cls.rows, d.dim) + d.dim * 4.0; break;
     default:        *bytes = 0; break;
     }

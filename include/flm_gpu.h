@@ -81,7 +81,7 @@ const char* flm_last_error(const flm_ctx* ctx);   /* ctx may be NULL: last creat
  * [rows][cols] of src_qtype (fp32 when FLM_QT_NONE) with fp32 `scales` [rows][cols/gs] when
  * quantized.  fp32 linear-layer tensors are quantized on the device with the reference's
  * quantizer (A13).  Under tensor parallelism the FULL tensor is passed on every rank; the ctx
- * keeps its shard. */
+ * keeps its row shard. */
 int  flm_upload_tensor(flm_ctx* ctx, int kind, int layer, int src_qtype,
                        const void* values, const float* scales, int rows, int cols);
 
@@ -147,11 +147,15 @@ int  flm_op_expf(float* x, size_t n);
 int  flm_op_math(int fn, float* x, const float* y, size_t n);
 
 /* ---- tensor-parallel shard plan (pure host arithmetic, no GPU needed).
- * Mirrors the reference's per-thread row split (split_rows, transformer.cpp:264-287) with the
- * extra rule that quantization groups never straddle ranks. */
+ * Every matmul is split by OUTPUT ROWS, as the reference splits them over its worker threads
+ * (split_rows, transformer.cpp:264-287): each output row is reduced on one rank in the reference's
+ * order, so a sharded run is bit-identical to the single-GPU / CPU run.  Ranks exchange activation
+ * slices with all-gathers (attention outputs, the residual stream twice, the FFN hidden vector, the
+ * logits), which is why every split is an equal contiguous slice. */
 typedef struct flm_shard_plan {
-    int32_t head_begin, head_count;        /* attention heads owned (q,k,v rows; O-proj columns) */
-    int32_t hidden_begin, hidden_count;    /* FFN rows of W1/W3 == columns of W2, multiples of gs */
+    int32_t head_begin, head_count;        /* attention heads owned: q,k,v rows, KV cache, attention */
+    int32_t hidden_begin, hidden_count;    /* rows of W1/W3 owned (slice of the FFN hidden vector) */
+    int32_t dim_begin, dim_count;          /* rows of Wo and W2 owned (slice of the residual stream) */
     int32_t vocab_begin, vocab_count;      /* classifier rows */
 } flm_shard_plan;
 int  flm_plan_shards(const flm_model_desc* desc, int rank, int world, flm_shard_plan* out);

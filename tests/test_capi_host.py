@@ -24,13 +24,12 @@ def test_plan_shards_7b():
     d = capi.desc_from_config(synth.make_config("7B", ff.QT_INT8))
     for world in (1, 2, 4, 8):
         plans = [capi.plan_shards(d, r, world) for r in range(world)]
-        assert sum(p.head_count for p in plans) == 32 and sum(p.hidden_count for p in plans) == 11008 and sum(p.vocab_count for p in plans) == 32000
-        for a, b in zip(plans, plans[1:]):
+        assert sum(p.head_count for p in plans) == 32 and sum(p.hidden_count for p in plans) == 11008
+        assert sum(p.dim_count for p in plans) == 4096 and sum(p.vocab_count for p in plans) == 32000
+        for a, b in zip(plans, plans[1:]):        # contiguous, equal slices (all-gather layout == tensor layout)
             assert a.head_begin + a.head_count == b.head_begin and a.hidden_begin + a.hidden_count == b.hidden_begin
-            assert a.vocab_begin + a.vocab_count == b.vocab_begin
-        assert all(p.hidden_begin % 64 == 0 and p.hidden_count % 64 == 0 for p in plans)      # quant groups never straddle ranks
-    p8 = [capi.plan_shards(d, r, 8).hidden_count // 64 for r in range(8)]
-    assert p8 == [22, 22, 22, 22, 21, 21, 21, 21]                                              # 172 groups over 8 ranks (split_rows rule)
+            assert a.dim_begin + a.dim_count == b.dim_begin and a.vocab_begin + a.vocab_count == b.vocab_begin
+            assert (a.head_count, a.hidden_count, a.dim_count) == (b.head_count, b.hidden_count, b.dim_count)
 
 
 def test_plan_shards_errors():
