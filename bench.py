@@ -7,7 +7,8 @@ One step = one greedy decode token of LLaMA2-7B int8 (synthetic weights, configs
 through the HIP path (fast-llama_amd/lib/libflm_gpu.so, C ABI include/flm_gpu.h).  All weights, the
 KV cache and the decode state are resident in HBM before the timed region; the K timed tokens run
 back to back from a hipGraph with no host round trip.  N > 1 = tensor-parallel over N GPUs (one
-process per GPU, RCCL all-reduce of the residual contribution) -> strong scaling of the same job.
+process per GPU, every matmul split by output rows + RCCL all-gather of the activations, bit-identical
+to the single-GPU result) -> strong scaling of the same job.
 
 Rank 0 prints ONE JSON line; besides the contract's keys it carries
   roofline     : dominant kernel (ffn13 GEMV) algorithmic bytes / its mean launch time measured live
@@ -77,9 +78,26 @@ def host_cores():
         return os.cpu_count() or 1, "unknown"
 
 
+def pmc_traffic(kernel_regex):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary under profiles/
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 is the gfx950 correction of
+    MI355X_MICROARCH.md; counters are in KiB).  None when no summary is there."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json")))
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+        except Exception:  # noqa: BLE001
+            continue
+        for name, c in d.items():
+            if re.search(kernel_regex, name) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                return int((2 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024), os.path.basename(f)
+    return None, None
+
+
 def cpu_baseline(cfg, budget_s=40.0):
     """Reference CPU path on a bounded sample: the reference binary decodes synthetic 7B-WIDTH models with
-    2 and 4 layers (same tensors shapes as the 32-layer model, so the same per-layer and classifier
+    4 and 12 layers (same tensor shapes as the 32-layer model, so the same per-layer and classifier
     work per token); per-token time is t(L) = t_cls + L * t_layer, fitted from the two runs and
     evaluated at L = 32.  Falls back to the C restatement (kind "port") if the binary cannot run."""
     from fast_llama_amd import flmfile as ff, synth
@@ -107,14 +125,15 @@ def cpu_baseline(cfg, budget_s=40.0):
 
     if os.path.exists(ref_main):
         try:
-            t2, w2 = run_ref(2, 24)
-            t4, w4 = run_ref(4, 24)
-            t_layer = max((t4 - t2) / 2.0, 1e-6)
-            t_cls = max(t2 - 2 * t_layer, 0.0)
+            La, Lb, ntok = 4, 12, 48
+            t2, w2 = run_ref(La, ntok)
+            t4, w4 = run_ref(Lb, ntok)
+            t_layer = max((t4 - t2) / (Lb - La), 1e-6)
+            t_cls = max(t2 - La * t_layer, 0.0)
             t_tok = t_cls + cfg.n_layers * t_layer
             res.update(value=1000.0 / t_tok, kind="reference",
                        sample=(f"reference binary (oracle/_ref/main, -O3 -march=x86-64-v3 -mfma, AVX2 kernels) -j {threads} -t 0 --mode bm, int8 .flm, "
-                               f"7B-width synthetic models with 2 and 4 layers, 24 decode tokens each: {t2:.2f} / {t4:.2f} ms per token; "
+                               f"7B-width synthetic models with {La} and {Lb} layers, {ntok} decode tokens each: {t2:.2f} / {t4:.2f} ms per token; "
                                f"t_layer={t_layer:.3f} ms, t_cls={t_cls:.3f} ms, extrapolated to 32 layers = {t_tok:.1f} ms/token "
                                f"(wall {w2 + w4:.0f}s)"))
             return res
@@ -226,6 +245,7 @@ def main():
     kernels = {k: {"us": round(v[0], 2), "per_token": v[1], "GBps": round(ctx.kernel_bytes(k, mid_pos) / (v[0] * 1e-6) / 1e9, 1) if v[0] > 0 else 0.0}
                for k, v in kt.items() if v[1] > 0}
 
+    traffic, traffic_src = pmc_traffic(r"k_gemv<2, 2, 2," if qt == ff.QT_INT8 else r"k_gemv<1, 2, 2,")
     if rank == 0:
         line = {
             "metric": "decode tokens/s LLaMA2-7B int8" if args.shape == "7B" and qt == ff.QT_INT8 else f"decode tokens/s {args.shape} {args.quant}",
@@ -240,7 +260,7 @@ def main():
                                "frac": round(token_bytes(cfg, mid_pos, esz) / world * tok_s / 1e9 / HBM_PEAK_GBS, 4)},
             "roofline": {"kernel": "k_gemv<int8,rmsnorm+quantize,swiglu> (ffn13)" if qt == ff.QT_INT8 else "k_gemv<int16,...> (ffn13)",
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_launch": int(dom_bytes), "avg_launch_us": round(dom_us, 2), "launches_per_token": dom_cnt},
             "kernels": kernels,
         }

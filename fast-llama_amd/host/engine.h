@@ -1,0 +1,40 @@
+// engine.h -- the MI355X counterpart of ParallelTransformer (src/transformer/transformer.h:76-96): same public
+// surface (load / encode / decode / generate / get_quant_type), the per-token forward runs on the GPU through
+// the C ABI in include/flm_gpu.h.
+#pragma once
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "flm_gpu.h"
+#include "model_file.h"
+#include "sampler.h"
+#include "tokenizer.h"
+
+namespace flmhost {
+
+// "title[ a,  b, ...]" with every number right-aligned to the widest one, like the reference's print_vector
+void print_vector(const char* title, const std::vector<int>& vec);
+
+class GpuTransformer {
+public:
+    explicit GpuTransformer(bool debug) : _debug(debug) {}
+    ~GpuTransformer();
+    // load(ckpt, tokenizer, file type, -q quant type, device): transformer.cpp:23-42
+    bool load(const std::string& ckpt, const std::string& tknr, FileType ft, int qtype, int device, uint64_t seed = 0);
+    std::vector<int> encode(const char* prompt) const;
+    std::string decode(const std::vector<int>& tokens) const { return _tok.decode(tokens); }
+    // generate(prompt, cb(text, n_input, n_output, ended), max_new_tokens, temperature, topp): transformer.cpp:54-103
+    bool generate(const char* prompt, const std::function<bool(const char*, int, int, bool)>& cb, int max_new_tokens, float temperature, float topp);
+    int get_quant_type() const { return _cfg.quant_type; }
+    const std::string& error() const { return _err; }
+private:
+    bool _debug;
+    Config _cfg;
+    Tokenizer _tok;
+    Sampler _sampler;
+    flm_ctx* _ctx = nullptr;
+    std::string _err;
+};
+
+} // namespace flmhost

@@ -187,12 +187,39 @@ def g_tok_sampler():
     os.remove(path)
 
 
+CLI_CASES = [   # (name, shape, qt, seed, extra CLI args)
+    ("greedy_int8", "tiny", ff.QT_INT8, 21, ["-q", "int8", "-t", "0", "-n", "24", "-i", "the shape of it"]),
+    ("sample_int16", "tiny", ff.QT_INT16, 22, ["-q", "int16", "-n", "12", "-i", "tea time!"]),
+    ("tiny128_int8", "tiny128", ff.QT_INT8, 23, ["-q", "int8", "-t", "0", "-n", "8", "-i", "Oliver lived in a small village."]),
+    # (the reference CLI overruns its 128-token batch buffers on longer prompts, e.g. its own default prompt with this vocabulary)
+    ("encode", "tiny", ff.QT_INT8, 21, ["-e", "I'm on it, OK?"]),
+    ("decode", "tiny", ff.QT_INT8, 21, ["-d", "[1, 279, 264, 260, 305]"]),
+]
+
+
+def g_cli():
+    """transcripts of the reference CLI (oracle/_ref/main) on synthetic .flm files; the summary line's timing
+    fields are stripped by the test, everything else must match byte for byte"""
+    import subprocess
+    out = {}
+    for name, shape, qt, seed, extra in CLI_CASES:
+        cfg = synth.make_config(shape, qt)
+        path = f"/tmp/golden-cli-{name}.flm"
+        synth.write_synthetic_flm(path, cfg, seed=seed)
+        r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "main"), "-c", path, "-j", "1", *extra], capture_output=True, check=True)
+        lines = [l for l in r.stdout.split(b"\n") if not l.startswith(b"DEBUG:")]
+        out[name] = np.frombuffer(b"\n".join(lines), dtype=np.uint8)
+        os.remove(path)
+    np.savez_compressed(os.path.join(HERE, "cli_transcripts.npz"), **out)
+
+
 if __name__ == "__main__":
     assert O.have_ref(), "build oracle/_ref first: make -C oracle ref"
     g_ops(); g_attention()
     g_model("tiny", O.QT_INT8, 1234); g_model("tiny", O.QT_INT16, 1234); g_model("tiny128", O.QT_INT8, 4321)
     g_model("tiny", O.QT_INT8, 1234, fp32_master=True); g_model("small", O.QT_INT8, 99, threads=4)
     g_tok_sampler()
+    g_cli()
     try:
         g_ref_writer()
     except Exception as e:   # the reference converter is Python-version sensitive; report, do not hide

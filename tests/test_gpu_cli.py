@@ -1,0 +1,63 @@
+"""The drop-in CLI (fast-llama_amd/bin/main) against transcripts of the reference CLI (tests/golden/cli_transcripts.npz,
+produced by tests/golden/make_golden.py:g_cli from oracle/_ref/main): same prompt echo, same token list, the same
+generated text, the same summary-line fields (timings aside)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as graft
+from fast_llama_amd import flmfile as ff, synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+MAIN = os.path.join(graft.PKG_DIR, "bin", "main")
+
+
+def _cases():
+    src = open(os.path.join(GOLD, "make_golden.py")).read()
+    # only the CLI_CASES literal is needed; importing the generator would pull in the reference bindings
+    m = re.search(r"CLI_CASES = \[.*?\n\]\n", src, re.S)
+    ns = {"ff": ff}
+    exec(m.group(0), ns)
+    return ns["CLI_CASES"]
+
+
+def _strip_timing(b: bytes) -> bytes:
+    b = re.sub(rb"total_latancy:.*", b"total_latancy:<t>", b)
+    return re.sub(rb"num_threads:\x1b\[33m *-?\d+\x1b\[0m", b"num_threads:<n>", b)
+
+
+def _run(name, tmp_path, extra_args=()):
+    case = next(c for c in _cases() if c[0] == name)
+    _, shape, qt, seed, extra = case
+    cfg = synth.make_config(shape, qt)
+    path = str(tmp_path / f"{name}.flm")
+    synth.write_synthetic_flm(path, cfg, seed=seed)
+    if not os.path.exists(MAIN):
+        graft.build()
+    r = subprocess.run([MAIN, "-c", path, "-j", "1", *extra, *extra_args], capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")
+    return r.stdout, bytes(np.load(os.path.join(GOLD, "cli_transcripts.npz"))[name])
+
+
+@pytest.mark.parametrize("name", ["encode", "decode"])
+def test_cli_encode_decode_modes_match_reference(name, tmp_path):
+    got, want = _run(name, tmp_path)
+    assert got == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["greedy_int8", "sample_int16", "tiny128_int8"])
+def test_cli_generation_matches_reference_transcript(gpu, name, tmp_path):
+    got, want = _run(name, tmp_path)
+    assert _strip_timing(got) == _strip_timing(want)
+
+
+@pytest.mark.gpu
+def test_cli_benchmark_mode_prints_only_summary(gpu, tmp_path):
+    got, want = _run("greedy_int8", tmp_path, ["--mode", "bm", "--rounds", "2"])
+    lines = got.split(b"\n")
+    assert not any(l.startswith(b"output:") for l in lines)
+    assert _strip_timing(lines[-2]) == _strip_timing(want.split(b"\n")[-2])
