@@ -171,6 +171,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--wg-per-cu", type=int, default=0)
     ap.add_argument("--prompt-len", type=int, default=9)
+    ap.add_argument("--mega", type=int, default=-1, help="1/0: force the persistent whole-token kernel on/off (default: library default)")
     args = ap.parse_args()
 
     import torch
@@ -204,6 +205,8 @@ def main():
     ctx = capi.Ctx(capi.desc_from_config(cfg), device=local_rank, rank=rank, world=world, comm_id=comm_id)
     if args.wg_per_cu:
         ctx.set_option("wg_per_cu", args.wg_per_cu)
+    if args.mega >= 0:
+        ctx.set_option("use_mega", args.mega)
     upload_synthetic(ctx, cfg)
 
     def barrier():

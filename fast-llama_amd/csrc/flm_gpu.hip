@@ -26,7 +26,7 @@ thread_local std::string g_last_error;
 
 struct QMat { void* q = nullptr; float* s = nullptr; int rows = 0, cols = 0; };
 struct LayerW {
-    QMat qkv, o, w1, w3, w2;
+    QMat qkv, o, w13, w2;     // w13 = [W1 (gate) ; W3 (up)] back to back: the SwiGLU GEMV walks them as one matrix
     float* att_norm = nullptr; float* ffn_norm = nullptr;
     unsigned got = 0;     // bitmask of uploaded kinds
 };
@@ -41,7 +41,7 @@ struct flm_ctx {
     flm_model_desc d{};
     int device = 0, rank = 0, world = 1;
     flm_shard_plan plan{};
-    int hs = 0, esz = 1, cu_count = 256;
+    int hs = 0, esz = 1, cu_count = 256, n_xcd = 8;
     int dim_local = 0, hidden_local = 0, heads_local = 0, vocab_slot = 0;    // dim_local = heads_local*hs: q/k/v rows and attention outputs owned
     int drow_begin = 0, drow_count = 0;                                       // rows of Wo / W2 (= slice of the residual stream) owned
     hipStream_t stream = nullptr;
@@ -61,6 +61,10 @@ struct flm_ctx {
 
     // options
     int wg_per_cu = 1; int use_graph = 1; int ablate = 0;
+    int use_mega = 0;                                  // option "use_mega": run single-GPU tokens as ONE persistent kernel (k_token); opt-in until it beats the per-phase kernels
+    GemvArgs* mega_gemv = nullptr; AttnArgs* mega_attn = nullptr; unsigned* mega_bar = nullptr; int* mega_err = nullptr;
+    size_t mega_lds = 0; int mega_ok = -1;              // -1 not built yet, 0 shape not supported by k_token, 1 ready
+    int trace_class = -1; unsigned long long* trace = nullptr;   // FLM_ABLATE builds: GEMV timeline of one kernel class
     std::map<int, hipGraphExec_t> graphs;             // key = with_cls*4 + advance
     std::vector<TimedLaunch>* timing = nullptr;
     std::string err;
@@ -91,40 +95,53 @@ void split_even(int total, int parts, int idx, int* begin, int* count) {
 // ---------------------------------------------------------------------------------------------
 // Pass geometry of k_gemv for one launch (see the kernel's header comment).
 //   cb_shift : CB = largest power of two <= 64 dividing K/16, so every 1 KiB wave load is full
-//   R        : rows per workgroup pass; bounded by the kMaxBlk loads a wave keeps in flight, by LDS
-//              (two {dF,sP} strip buffers) and by 64 chain lanes; chosen so that the passes divide
-//              evenly over `wgs` workgroups (CU-level balance is what matters for an HBM-bound kernel)
-struct GemvPlan { int R, cb_shift, grid; size_t lds; };
-GemvPlan gemv_plan(int n, int esz, int total_rows, int rpi, bool norm, int wgs) {
+//   Rm       : rows (per matrix) per workgroup pass; bounded by LDS (two strip buffers) and by 64 chain
+//              lanes; chosen so that the passes divide evenly over `wgs` workgroups (CU-level balance is
+//              what matters for an HBM-bound kernel)
+//   wc_shift : the WC x WR wave grid with the fewest blocks on the busiest wave
+struct GemvPlan { int Rm, cb_shift, wc_shift, grid; size_t lds; };
+GemvPlan gemv_plan(int n, int esz, int rows, bool two, bool pairs, bool norm, int wgs) {
     GemvPlan P{};
-    const int nchunks = n * esz / 16, sn = n / kGroup;
+    const int nchunks = n * esz / 16;
     int cbs = 0; while (cbs < 6 && (nchunks % (2 << cbs)) == 0) ++cbs;       // nchunks % 4 == 0 always
-    const int RB = 64 >> cbs, nbc = nchunks >> cbs;
-    int mult = RB > 2 ? RB : 2; if (rpi == 2) mult = 2 * RB;                 // SWIGLU: R/2 rows per matrix, a multiple of RB
-    int rmax = 64;                                                           // one chain lane per row
-    const int gstride = ((sn + 3) & ~3) + kChainPad;
-    const int fixed = n * esz + ((sn * 4 + 15) & ~15) + 64;
+    const int RB = 64 >> cbs, nbc = nchunks >> cbs, nbcv = two ? 2 * nbc : nbc;
+    const int mult = (pairs && RB < 2) ? 2 : RB;                             // ROPE_KV: row pairs stay in one pass
     const int lds_budget = 150 * 1024;                                       // one 1024-thread workgroup per CU out of 160 KiB
-    const int r_lds = (lds_budget - fixed) / (16 * gstride) - 1;            // two {dF,sP} buffers of R+1 strips
-    if (rmax > r_lds) rmax = r_lds;
-    if (rmax > 64) rmax = 64;
+    int rmax = 64;                                                           // one chain lane per row
+    while (rmax > mult && gemv_lds_layout(n, esz, norm, rmax, RB, two).total > lds_budget) rmax -= mult;
     rmax = rmax / mult * mult; if (rmax < mult) rmax = mult;
-    int ppw = (total_rows + wgs * rmax - 1) / (wgs * rmax);                  // passes per workgroup
+    if (rows < 1) rows = 1;
+    int ppw = (rows + wgs * rmax - 1) / (wgs * rmax);                        // passes per workgroup
     if (ppw < 1) ppw = 1;
-    int R = (total_rows + wgs * ppw - 1) / (wgs * ppw);
-    R = (R + mult - 1) / mult * mult; if (R > rmax) R = rmax; if (R < mult) R = mult;
-    const int npass = (total_rows + R - 1) / R;
-    P.R = R; P.cb_shift = cbs; P.grid = npass < wgs ? npass : wgs; if (P.grid < 1) P.grid = 1;
-    P.lds = (size_t)gemv_lds_layout(n, esz, norm, R).total;
+    int Rm = (rows + wgs * ppw - 1) / (wgs * ppw);
+    Rm = (Rm + mult - 1) / mult * mult; if (Rm > rmax) Rm = rmax; if (Rm < mult) Rm = mult;
+    const int npass = (rows + Rm - 1) / Rm, rbp = Rm / RB;
+    int best = 0; long best_cost = -1;
+    for (int wcs = 0; wcs <= 4; ++wcs) {
+        const int WC = 1 << wcs, WR = 16 >> wcs;
+        const long cost = (long)((nbcv + WC - 1) / WC) * ((rbp + WR - 1) / WR);
+        if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best = wcs; }   // ties: more wave columns, fewer activation reloads
+    }
+    P.Rm = Rm; P.cb_shift = cbs; P.wc_shift = best; P.grid = npass < wgs ? npass : wgs; if (P.grid < 1) P.grid = 1;
+    P.lds = (size_t)gemv_lds_layout(n, esz, norm, Rm, RB, two).total;
     return P;
 }
 
+// fill the pass geometry of one GEMV into its argument block; returns the LDS bytes and grid it needs
+template <int QT, int PRO, int EPI>
+int plan_gemv(flm_ctx* c, GemvArgs& a, int wgs, GemvPlan& P) {
+    constexpr bool TWO = EPI == EPI_SWIGLU, PAIRS = EPI == EPI_ROPE_KV;
+    const int rows = a.items * (PAIRS ? 2 : 1);
+    if ((double)rows * a.n * QTraits<QT>::kEsz * (TWO ? 2 : 1) >= 2147483648.0) return fail(c, FLM_ERR_UNSUPPORTED, "gemv: matrix of 2 GiB or more");
+    P = gemv_plan(a.n, QTraits<QT>::kEsz, rows, TWO, PAIRS, true, wgs);
+    if (P.lds > 160 * 1024) return fail(c, FLM_ERR_UNSUPPORTED, "gemv: activation vector does not fit LDS");
+    a.rows_per_pass = P.Rm; a.cb_shift = P.cb_shift; a.wc_shift = P.wc_shift;
+    return FLM_OK;
+}
 template <int QT, int PRO, int EPI>
 int launch_gemv_xr(flm_ctx* c, hipStream_t st, GemvArgs a, int wgs) {
-    constexpr int RPI = (EPI == EPI_SWIGLU || EPI == EPI_ROPE_KV) ? 2 : 1;
-    const GemvPlan P = gemv_plan(a.n, QTraits<QT>::kEsz, a.items * RPI, RPI, PRO == PRO_RMSNORM_QUANT, wgs);
-    if (P.lds > 160 * 1024) return fail(c, FLM_ERR_UNSUPPORTED, "gemv: activation vector does not fit LDS");
-    a.rows_per_pass = P.R; a.cb_shift = P.cb_shift;
+    GemvPlan P;
+    int r = plan_gemv<QT, PRO, EPI>(c, a, wgs, P); if (r) return r;
     const int rounds = (a.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4);
     if (PRO == PRO_NONE)   hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 0>), dim3(P.grid), dim3(kGemvBlock), P.lds, st, a);
     else if (rounds <= 1)  hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 1>), dim3(P.grid), dim3(kGemvBlock), P.lds, st, a);
@@ -237,6 +254,20 @@ bool model_complete(const flm_ctx* c) {
     return true;
 }
 
+// k_token reports a grid barrier that never completed (a workgroup was not resident) through *mega_err
+int mega_check(flm_ctx* c) {
+    if (c->mega_ok != 1) return FLM_OK;
+    int e = 0;
+    HIPC(c, hipMemcpy(&e, c->mega_err, 4, hipMemcpyDeviceToHost));
+    if (e) {   // fall back to the per-phase kernels for the rest of this context's life
+        hipMemset(c->mega_err, 0, 4); c->use_mega = 0;
+        for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
+        c->graphs.clear();
+        return fail(c, FLM_ERR_HIP, "k_token: a grid barrier timed out (workgroups not co-resident?); this call's results are invalid, later calls use the per-phase kernels");
+    }
+    return FLM_OK;
+}
+
 struct Tick {
     flm_ctx* c; hipStream_t st; int kclass; hipEvent_t e0 = nullptr, e1 = nullptr;
     Tick(flm_ctx* c_, hipStream_t st_, int k) : c(c_), st(st_), kclass(k) {
@@ -251,89 +282,150 @@ struct Tick {
 //   with_cls  : run the final norm + classifier (+ argmax)
 //   advance   : 1 = greedy (tok <- argmax, pos++), 0 = leave state (caller copies logits), 2 = prompt feed
 // ---------------------------------------------------------------------------------------------
+// argument blocks of the five GEMVs and the attention of layer l (shared by the per-phase launches and k_token)
+GemvArgs args_qkv(flm_ctx* c, int l) {
+    const auto& d = c->d; LayerW& w = c->layers[l];
+    const size_t kv_layer = (size_t)c->heads_local * d.max_seq_len * c->hs;
+    GemvArgs a{}; a.ablate = c->ablate;
+    a.W = w.qkv.q; a.sW = w.qkv.s; a.n = d.dim; a.items = w.qkv.rows / 2;
+    a.x = c->x1; a.norm_w = w.att_norm;
+    a.out = c->qbuf; a.kcache = c->kcache + (size_t)l * kv_layer; a.vcache = c->vcache + (size_t)l * kv_layer;
+    a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.pos_ptr = &c->state->pos;
+    a.dim = c->dim_local; a.kv_dim = c->dim_local; a.max_seq = d.max_seq_len; a.hs = c->hs;
+    return a;
+}
+AttnArgs args_attn(flm_ctx* c, int l) {
+    const auto& d = c->d;
+    const size_t kv_layer = (size_t)c->heads_local * d.max_seq_len * c->hs;
+    AttnArgs a{};
+    a.q = c->qbuf; a.kcache = c->kcache + (size_t)l * kv_layer; a.vcache = c->vcache + (size_t)l * kv_layer;
+    a.out = c->att_out + (size_t)c->plan.head_begin * c->hs; a.pos_ptr = &c->state->pos; a.hs = c->hs; a.max_seq = d.max_seq_len;
+    return a;
+}
+GemvArgs args_o(flm_ctx* c, int l) {
+    LayerW& w = c->layers[l];
+    GemvArgs a{}; a.ablate = c->ablate;
+    a.W = w.o.q; a.sW = w.o.s; a.n = c->d.dim; a.items = c->drow_count;
+    a.x = c->att_out; a.out = c->x1 + c->drow_begin;
+    return a;
+}
+GemvArgs args_ffn13(flm_ctx* c, int l) {
+    LayerW& w = c->layers[l];
+    GemvArgs a{}; a.ablate = c->ablate;
+    a.W = w.w13.q; a.sW = w.w13.s; a.n = c->d.dim; a.items = c->hidden_local;
+    a.x = c->x1; a.norm_w = w.ffn_norm; a.out = c->hd + c->plan.hidden_begin;
+    return a;
+}
+GemvArgs args_ffn2(flm_ctx* c, int l) {
+    LayerW& w = c->layers[l];
+    GemvArgs a{}; a.ablate = c->ablate;
+    a.W = w.w2.q; a.sW = w.w2.s; a.n = c->d.hidden_dim; a.items = c->drow_count;
+    a.x = c->hd; a.out = c->x1 + c->drow_begin;
+    return a;
+}
+GemvArgs args_cls(flm_ctx* c) {
+    GemvArgs a{}; a.ablate = c->ablate;
+    a.W = c->cls.q; a.sW = c->cls.s; a.n = c->d.dim; a.items = c->cls.rows;
+    a.x = c->x1; a.norm_w = c->out_norm; a.out = c->logits + (c->world > 1 ? (size_t)c->rank * c->vocab_slot : 0);
+    return a;
+}
+
+// device-resident argument tables of k_token, built once per context (and again when an option changes)
+template <int QT>
+int build_mega(flm_ctx* c) {
+    const auto& d = c->d;
+    const int L = d.n_layers, wgs = c->cu_count;
+    c->mega_ok = 0;
+    if (c->world != 1 || d.dim > kNormRounds * kGemvBlock * 4 || d.n_heads > 65535 || wgs > 512) return FLM_OK;
+    std::vector<GemvArgs> g((size_t)4 * L + 1);
+    std::vector<AttnArgs> at(L);
+    size_t lds = attn_lds_bytes(d.max_seq_len, c->hs);
+    GemvPlan P; int r;
+    for (int l = 0; l < L; ++l) {
+        g[4 * l + 0] = args_qkv(c, l);   r = plan_gemv<QT, PRO_RMSNORM_QUANT, EPI_ROPE_KV>(c, g[4 * l + 0], wgs, P); if (r) return r; if (P.lds > lds) lds = P.lds;
+        g[4 * l + 1] = args_o(c, l);     r = plan_gemv<QT, PRO_QUANT, EPI_RESIDUAL>(c, g[4 * l + 1], wgs, P);        if (r) return r; if (P.lds > lds) lds = P.lds;
+        g[4 * l + 2] = args_ffn13(c, l); r = plan_gemv<QT, PRO_RMSNORM_QUANT, EPI_SWIGLU>(c, g[4 * l + 2], wgs, P);  if (r) return r; if (P.lds > lds) lds = P.lds;
+        g[4 * l + 3] = args_ffn2(c, l);  r = plan_gemv<QT, PRO_QUANT, EPI_RESIDUAL>(c, g[4 * l + 3], wgs, P);        if (r) return r; if (P.lds > lds) lds = P.lds;
+        at[l] = args_attn(c, l);
+    }
+    g[4 * L] = args_cls(c); r = plan_gemv<QT, PRO_RMSNORM_QUANT, EPI_STORE>(c, g[4 * L], wgs, P); if (r) return r; if (P.lds > lds) lds = P.lds;
+    if (lds < 84 * 1024) lds = 84 * 1024;                 // more than half of the CU's LDS: at most ONE workgroup per CU, so all of them are resident
+    if (!c->mega_gemv) {
+        HIPC(c, hipMalloc((void**)&c->mega_gemv, g.size() * sizeof(GemvArgs)));
+        HIPC(c, hipMalloc((void**)&c->mega_attn, at.size() * sizeof(AttnArgs)));
+    }
+    HIPC(c, hipMemcpy(c->mega_gemv, g.data(), g.size() * sizeof(GemvArgs), hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(c->mega_attn, at.data(), at.size() * sizeof(AttnArgs), hipMemcpyHostToDevice));
+    HIPC(c, hipFuncSetAttribute((const void*)k_token<QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    c->mega_lds = lds; c->mega_ok = 1;
+    return FLM_OK;
+}
+
 int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance) {
     const auto& d = c->d;
     const int qt = d.quant_type, hs = c->hs, L = d.n_layers;
     const bool tp = c->world > 1;
-    const int* pos_ptr = &c->state->pos;
     {
         Tick t(c, st, KC_EMBED);
-        hipLaunchKernelGGL(k_embed, dim3((d.dim + 255) / 256), dim3(256), 0, st, c->x1, (const void*)c->emb, (const float*)c->emb_s, c->emb_qt, d.dim, (const int*)&c->state->tok);
+        hipLaunchKernelGGL(k_embed, dim3((d.dim + 255) / 256), dim3(256), 0, st, c->x1, (const void*)c->emb, (const float*)c->emb_s, c->emb_qt, d.dim, (const int*)&c->state->tok, c->mega_bar);
         HIPC(c, hipGetLastError());
     }
-    const size_t kv_layer = (size_t)c->heads_local * d.max_seq_len * hs;
-    for (int l = 0; l < L; ++l) {
-        LayerW& w = c->layers[l];
-        {   // QKV task + RoPE + KV append (transformer.cpp:132-135, execute_qkv :386-395, execute_attn :431-439)
-            GemvArgs a{}; a.ablate = c->ablate;
-            a.W = w.qkv.q; a.sW = w.qkv.s; a.n = d.dim; a.items = w.qkv.rows / 2;
-            a.x = c->x1; a.norm_w = w.att_norm;
-            a.out = c->qbuf; a.kcache = c->kcache + (size_t)l * kv_layer; a.vcache = c->vcache + (size_t)l * kv_layer;
-            a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.pos_ptr = pos_ptr;
-            a.dim = c->dim_local; a.kv_dim = c->dim_local; a.max_seq = d.max_seq_len; a.hs = hs;
-            Tick t(c, st, KC_QKV);
-            int r = launch_gemv<PRO_RMSNORM_QUANT, EPI_ROPE_KV>(c, st, qt, a, gemv_grid(c->cu_count, c->wg_per_cu, a.items, 2));
-            if (r) return r;
+    const bool mega = c->use_mega && !tp && !c->timing && c->mega_ok == 1;   // tables built by check_ready (never inside a stream capture)
+    if (mega) {
+        // the whole token as ONE persistent kernel: grid barriers instead of kernel boundaries
+        TokenArgs t{}; t.gemv = c->mega_gemv; t.attn = c->mega_attn; t.n_layers = L; t.n_heads = c->heads_local; t.with_cls = with_cls ? 1 : 0;
+        t.bar = c->mega_bar; t.err = c->mega_err; t.trace = c->trace_class == 100 ? c->trace : nullptr;
+        if (qt == FLM_QT_INT8) hipLaunchKernelGGL(k_token<QT_INT8>, dim3(c->cu_count), dim3(kGemvBlock), c->mega_lds, st, t);
+        else                   hipLaunchKernelGGL(k_token<QT_INT16>, dim3(c->cu_count), dim3(kGemvBlock), c->mega_lds, st, t);
+        HIPC(c, hipGetLastError());
+    } else {
+        const int wgs = gemv_grid(c->cu_count, c->wg_per_cu, 0, 0);
+        auto traced = [&](GemvArgs a, int kc, int l) { if (c->trace_class == kc && l == 0) a.trace = c->trace; return a; };
+        for (int l = 0; l < L; ++l) {
+            {   // QKV task + RoPE + KV append (transformer.cpp:132-135, execute_qkv :386-395, execute_attn :431-439)
+                Tick t(c, st, KC_QKV);
+                int r = launch_gemv<PRO_RMSNORM_QUANT, EPI_ROPE_KV>(c, st, qt, traced(args_qkv(c, l), KC_QKV, l), wgs); if (r) return r;
+            }
+            {   // ATTN task (execute_attn :441-449): local heads write their slice of the full att_out vector
+                Tick t(c, st, KC_ATTN);
+                hipLaunchKernelGGL(k_attn_decode, dim3(c->heads_local), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, hs), st, args_attn(c, l));
+                HIPC(c, hipGetLastError());
+            }
+            if (tp) {   // every rank needs all heads' outputs: the reference's threads share x2 in memory (transformer.cpp:451-454)
+                Tick t(c, st, KC_ALLREDUCE);
+                NCCLC(c, ncclAllGather(c->att_out + (size_t)c->plan.head_begin * hs, c->att_out, c->dim_local, ncclFloat, c->comm, st));
+            }
+            {   // ATTN_O task + residual (transformer.cpp:138-139, execute_attn_o :457-466): this rank's rows of Wo
+                Tick t(c, st, KC_ATTN_O);
+                int r = launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, traced(args_o(c, l), KC_ATTN_O, l), wgs); if (r) return r;
+            }
+            if (tp) {
+                Tick t(c, st, KC_ALLREDUCE);
+                NCCLC(c, ncclAllGather(c->x1 + c->drow_begin, c->x1, c->drow_count, ncclFloat, c->comm, st));
+            }
+            {   // FFN13 task + SwiGLU (transformer.cpp:144-147, execute_ffn13 :468-483): this rank's rows of W1/W3
+                Tick t(c, st, KC_FFN13);
+                int r = launch_gemv<PRO_RMSNORM_QUANT, EPI_SWIGLU>(c, st, qt, traced(args_ffn13(c, l), KC_FFN13, l), wgs); if (r) return r;
+            }
+            if (tp) {
+                Tick t(c, st, KC_ALLREDUCE);
+                NCCLC(c, ncclAllGather(c->hd + c->plan.hidden_begin, c->hd, c->hidden_local, ncclFloat, c->comm, st));
+            }
+            {   // FFN2 task + residual (transformer.cpp:149-150, execute_ffn2 :485-494): this rank's rows of W2
+                Tick t(c, st, KC_FFN2);
+                int r = launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, traced(args_ffn2(c, l), KC_FFN2, l), wgs); if (r) return r;
+            }
+            if (tp) {
+                Tick t(c, st, KC_ALLREDUCE);
+                NCCLC(c, ncclAllGather(c->x1 + c->drow_begin, c->x1, c->drow_count, ncclFloat, c->comm, st));
+            }
         }
-        {   // ATTN task (execute_attn :441-449): local heads write their slice of the full att_out vector
-            AttnArgs a{};
-            a.q = c->qbuf; a.kcache = c->kcache + (size_t)l * kv_layer; a.vcache = c->vcache + (size_t)l * kv_layer;
-            a.out = c->att_out + (size_t)c->plan.head_begin * hs; a.pos_ptr = pos_ptr; a.hs = hs; a.max_seq = d.max_seq_len;
-            Tick t(c, st, KC_ATTN);
-            hipLaunchKernelGGL(k_attn_decode, dim3(c->heads_local), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, hs), st, a);
-            HIPC(c, hipGetLastError());
-        }
-        if (tp) {   // every rank needs all heads' outputs: the reference's threads share x2 in memory (transformer.cpp:451-454)
-            Tick t(c, st, KC_ALLREDUCE);
-            NCCLC(c, ncclAllGather(c->att_out + (size_t)c->plan.head_begin * hs, c->att_out, c->dim_local, ncclFloat, c->comm, st));
-        }
-        {   // ATTN_O task + residual (transformer.cpp:138-139, execute_attn_o :457-466): this rank's rows of Wo
-            GemvArgs a{}; a.ablate = c->ablate;
-            a.W = w.o.q; a.sW = w.o.s; a.n = d.dim; a.items = c->drow_count;
-            a.x = c->att_out;
-            a.out = c->x1 + c->drow_begin;
-            Tick t(c, st, KC_ATTN_O);
-            int r = launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, a, gemv_grid(c->cu_count, c->wg_per_cu, a.items, 1));
-            if (r) return r;
-        }
-        if (tp) {
-            Tick t(c, st, KC_ALLREDUCE);
-            NCCLC(c, ncclAllGather(c->x1 + c->drow_begin, c->x1, c->drow_count, ncclFloat, c->comm, st));
-        }
-        {   // FFN13 task + SwiGLU (transformer.cpp:144-147, execute_ffn13 :468-483): this rank's rows of W1/W3
-            GemvArgs a{}; a.ablate = c->ablate;
-            a.W = w.w1.q; a.sW = w.w1.s; a.W2nd = w.w3.q; a.sW2nd = w.w3.s; a.n = d.dim; a.items = c->hidden_local;
-            a.x = c->x1; a.norm_w = w.ffn_norm; a.out = c->hd + c->plan.hidden_begin;
-            Tick t(c, st, KC_FFN13);
-            int r = launch_gemv<PRO_RMSNORM_QUANT, EPI_SWIGLU>(c, st, qt, a, gemv_grid(c->cu_count, c->wg_per_cu, a.items, 2));
-            if (r) return r;
-        }
-        if (tp) {
-            Tick t(c, st, KC_ALLREDUCE);
-            NCCLC(c, ncclAllGather(c->hd + c->plan.hidden_begin, c->hd, c->hidden_local, ncclFloat, c->comm, st));
-        }
-        {   // FFN2 task + residual (transformer.cpp:149-150, execute_ffn2 :485-494): this rank's rows of W2
-            GemvArgs a{}; a.ablate = c->ablate;
-            a.W = w.w2.q; a.sW = w.w2.s; a.n = d.hidden_dim; a.items = c->drow_count;
-            a.x = c->hd; a.out = c->x1 + c->drow_begin;
-            Tick t(c, st, KC_FFN2);
-            int r = launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, a, gemv_grid(c->cu_count, c->wg_per_cu, a.items, 1));
-            if (r) return r;
-        }
-        if (tp) {
-            Tick t(c, st, KC_ALLREDUCE);
-            NCCLC(c, ncclAllGather(c->x1 + c->drow_begin, c->x1, c->drow_count, ncclFloat, c->comm, st));
+        if (with_cls) {   // final norm + CLS task (transformer.cpp:154-160, execute_cls :496-505)
+            Tick t(c, st, KC_CLS);
+            int r = launch_gemv<PRO_RMSNORM_QUANT, EPI_STORE>(c, st, qt, traced(args_cls(c), KC_CLS, 0), wgs); if (r) return r;
         }
     }
     if (with_cls) {
-        {   // final norm + CLS task (transformer.cpp:154-160, execute_cls :496-505)
-            GemvArgs a{}; a.ablate = c->ablate;
-            a.W = c->cls.q; a.sW = c->cls.s; a.n = d.dim; a.items = c->cls.rows;
-            a.x = c->x1; a.norm_w = c->out_norm; a.out = c->logits + (tp ? (size_t)c->rank * c->vocab_slot : 0);
-            Tick t(c, st, KC_CLS);
-            int r = launch_gemv<PRO_RMSNORM_QUANT, EPI_STORE>(c, st, qt, a, gemv_grid(c->cu_count, c->wg_per_cu, a.items, 1));
-            if (r) return r;
-        }
         if (tp) {
             Tick t(c, st, KC_ALLREDUCE);
             NCCLC(c, ncclAllGather(c->logits + (size_t)c->rank * c->vocab_slot, c->logits, c->vocab_slot, ncclFloat, c->comm, st));
@@ -393,6 +485,10 @@ int check_ready(flm_ctx* c, int n, int pos) {
     if (!model_complete(c)) return fail(c, FLM_ERR_STATE, "forward before all tensors were uploaded");
     if (n < 1 || pos < 0 || pos + n > c->d.max_seq_len) return fail(c, FLM_ERR_INVALID, "tokens/pos outside [0, max_seq_len]");
     HIPC(c, hipSetDevice(c->device));
+    if (c->mega_ok < 0 && c->use_mega && c->world == 1) {
+        int r = c->d.quant_type == FLM_QT_INT8 ? build_mega<QT_INT8>(c) : build_mega<QT_INT16>(c);
+        if (r) return r;
+    }
     return FLM_OK;
 }
 
@@ -487,6 +583,7 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
     HIPB(hipSetDevice(device_id));
     hipDeviceProp_t prop; HIPB(hipGetDeviceProperties(&prop, device_id));
     c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
     HIPB(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     if (world > 1) {
         ncclUniqueId id; memcpy(&id, comm_id, 128);
@@ -498,7 +595,7 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
     for (int l = 0; l < L; ++l) {
         LayerW& w = c->layers[l];
         if (alloc_qmat(c, w.qkv, 3 * c->dim_local, d.dim, qt) || alloc_qmat(c, w.o, c->drow_count, d.dim, qt) ||
-            alloc_qmat(c, w.w1, c->hidden_local, d.dim, qt) || alloc_qmat(c, w.w3, c->hidden_local, d.dim, qt) ||
+            alloc_qmat(c, w.w13, 2 * c->hidden_local, d.dim, qt) ||
             alloc_qmat(c, w.w2, c->drow_count, d.hidden_dim, qt)) return bail(FLM_ERR_OOM);
         HIPB(hipMalloc((void**)&w.att_norm, d.dim * 4)); HIPB(hipMalloc((void**)&w.ffn_norm, d.dim * 4));
     }
@@ -513,6 +610,8 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
     HIPB(hipMalloc((void**)&c->hd, d.hidden_dim * 4));
     HIPB(hipMalloc((void**)&c->logits, (size_t)c->vocab_slot * world * 4));
     HIPB(hipMemsetAsync(c->logits, 0, (size_t)c->vocab_slot * world * 4, c->stream));
+    HIPB(hipMalloc((void**)&c->mega_bar, 512 * 64)); HIPB(hipMalloc((void**)&c->mega_err, 64));
+    HIPB(hipMemsetAsync(c->mega_bar, 0, 512 * 64, c->stream)); HIPB(hipMemsetAsync(c->mega_err, 0, 64, c->stream));
     HIPB(hipMalloc((void**)&c->state, sizeof(DecodeState)));
     HIPB(hipMemsetAsync(c->state, 0, sizeof(DecodeState), c->stream));
     std::vector<float> cs, sn; build_rope_table(hs, d.max_seq_len, cs, sn);
@@ -532,10 +631,11 @@ void flm_ctx_destroy(flm_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
     auto fq = [](QMat& m) { if (m.q) hipFree(m.q); if (m.s) hipFree(m.s); };
-    for (auto& l : c->layers) { fq(l.qkv); fq(l.o); fq(l.w1); fq(l.w3); fq(l.w2); if (l.att_norm) hipFree(l.att_norm); if (l.ffn_norm) hipFree(l.ffn_norm); }
+    for (auto& l : c->layers) { fq(l.qkv); fq(l.o); fq(l.w13); fq(l.w2); if (l.att_norm) hipFree(l.att_norm); if (l.ffn_norm) hipFree(l.ffn_norm); }
     fq(c->cls);
     void* ptrs[] = {c->emb, c->emb_s, c->out_norm, c->kcache, c->vcache, c->x1, c->qbuf, c->att_out, c->hd,
-                    c->logits, c->rope_cos, c->rope_sin, c->state, c->prompt_dev, c->out_tokens_dev};
+                    c->logits, c->rope_cos, c->rope_sin, c->state, c->prompt_dev, c->out_tokens_dev,
+                    c->mega_gemv, c->mega_attn, c->mega_bar, c->mega_err, c->trace};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->comm) ncclCommDestroy(c->comm);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -545,9 +645,15 @@ void flm_ctx_destroy(flm_ctx* c) {
 int flm_set_option(flm_ctx* c, const char* key, int value) {
     if (!c || !key) return FLM_ERR_INVALID;
     std::string k(key);
-    if (k == "wg_per_cu") c->wg_per_cu = value > 0 ? value : 1;
+    if (k == "wg_per_cu") { c->wg_per_cu = value > 0 ? value : 1; }
     else if (k == "use_graph") c->use_graph = value;
-    else if (k == "ablate") c->ablate = value;
+    else if (k == "ablate") { c->ablate = value; c->mega_ok = -1; }
+    else if (k == "use_mega") c->use_mega = value;
+    else if (k == "trace") {        // value = kernel class to trace (KC_*), -1 off; meaningful in FLM_ABLATE builds only
+        c->trace_class = value;
+        if (!c->trace) { HIPC(c, hipMalloc((void**)&c->trace, 4096 * 8 * 8)); }
+        HIPC(c, hipMemset(c->trace, 0, 4096 * 8 * 8));
+    }
     else return fail(c, FLM_ERR_INVALID, "unknown option");
     for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
     c->graphs.clear();
@@ -599,8 +705,7 @@ int flm_upload_tensor(flm_ctx* c, int kind, int layer, int src_qt, const void* v
         return r; }
     case FLM_T_MLP_GATE: case FLM_T_MLP_UP: {
         if (rows != d.hidden_dim || cols != d.dim) return fail(c, FLM_ERR_INVALID, "ffn1/3 shape");
-        QMat& m = kind == FLM_T_MLP_GATE ? c->layers[layer].w1 : c->layers[layer].w3;
-        int r = upload_window(c, m, 0, src_qt, values, scales, cols, c->plan.hidden_begin, c->plan.hidden_count, 0, cols);
+        int r = upload_window(c, c->layers[layer].w13, kind == FLM_T_MLP_GATE ? 0 : c->hidden_local, src_qt, values, scales, cols, c->plan.hidden_begin, c->plan.hidden_count, 0, cols);
         if (!r) c->layers[layer].got |= 1u << (kind == FLM_T_MLP_GATE ? 6 : 7);
         return r; }
     case FLM_T_MLP_DOWN: {
@@ -635,6 +740,19 @@ int flm_debug_read(flm_ctx* c, int what, int layer, float* out, size_t n) {
     case 4: src = c->kcache + (size_t)layer * kvl; cap = kvl; break;
     case 5: src = c->vcache + (size_t)layer * kvl; cap = kvl; break;
     case 6: src = c->logits; cap = (size_t)c->vocab_slot * c->world; break;
+    case 7: {   // GEMV timeline (FLM_ABLATE builds): [grid][8] ticks relative to the earliest workgroup start; column 7 = 100 MHz ticks start -> end
+        if (!c->trace || n > 4096 * 8) return fail(c, FLM_ERR_INVALID, "debug_read: no trace");
+        HIPC(c, hipStreamSynchronize(c->stream));
+        std::vector<unsigned long long> t(4096 * 8);
+        HIPC(c, hipMemcpy(t.data(), c->trace, t.size() * 8, hipMemcpyDeviceToHost));
+        // ticks relative to the first stamp of the row's workgroup (`layer` = rows per workgroup, 1 or 16): the
+        // shader clocks of different XCDs are not synchronised, and fp32 cannot hold absolute tick counts
+        const size_t rpw = layer > 0 ? (size_t)layer : 1;
+        for (size_t i = 0; i < n; ++i) {
+            const size_t row = i / 8, base = (row - row % rpw) * 8;
+            out[i] = (i % 8 == 7 && rpw == 1) ? (float)t[i] : ((t[i] && t[base]) ? (float)(long long)(t[i] - t[base]) : -1.f);
+        }
+        return FLM_OK; }
     default: return fail(c, FLM_ERR_INVALID, "debug_read: unknown buffer");
     }
     if (n > cap || layer < 0 || layer >= c->d.n_layers) return fail(c, FLM_ERR_INVALID, "debug_read: size/layer");
@@ -651,7 +769,7 @@ int flm_forward(flm_ctx* c, const int32_t* tokens, int n, int pos, float* logits
     r = feed(c, tokens, n, pos, 0); if (r) return r;
     HIPC(c, hipMemcpyAsync(logits_host, c->logits, (size_t)c->d.vocab_size * 4, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
-    return FLM_OK;
+    return mega_check(c);
 }
 
 int flm_forward_argmax(flm_ctx* c, const int32_t* tokens, int n, int pos, int32_t* next_token) {
@@ -660,7 +778,7 @@ int flm_forward_argmax(flm_ctx* c, const int32_t* tokens, int n, int pos, int32_
     r = feed(c, tokens, n, pos, 1); if (r) return r;
     HIPC(c, hipMemcpyAsync(next_token, c->out_tokens_dev, 4, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
-    return FLM_OK;
+    return mega_check(c);
 }
 
 static int decode_loop(flm_ctx* c, int32_t first_token, int pos, int n_steps, hipEvent_t e0, hipEvent_t e1) {
@@ -680,7 +798,7 @@ int flm_decode_greedy(flm_ctx* c, int32_t first_token, int pos, int n_steps, int
     int r = decode_loop(c, first_token, pos, n_steps, nullptr, nullptr); if (r) return r;
     HIPC(c, hipMemcpyAsync(out_tokens, c->out_tokens_dev, sizeof(int) * n_steps, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
-    return FLM_OK;
+    return mega_check(c);
 }
 
 int flm_decode_timed(flm_ctx* c, int32_t first_token, int pos, int n_steps, float* ms) {
@@ -690,7 +808,7 @@ int flm_decode_timed(flm_ctx* c, int32_t first_token, int pos, int n_steps, floa
     int r = decode_loop(c, first_token, pos, n_steps, e0, e1);
     if (!r) { hipError_t e = hipEventSynchronize(e1); if (e == hipSuccess) e = hipEventElapsedTime(ms, e0, e1); if (e != hipSuccess) { c->err = hipGetErrorString(e); r = FLM_ERR_HIP; } }
     hipEventDestroy(e0); hipEventDestroy(e1);
-    return r;
+    return r ? r : mega_check(c);
 }
 
 int flm_kernel_times(flm_ctx* c, int pos, int iters, float* avg_us, int32_t* count) {

@@ -154,6 +154,13 @@ __device__ __forceinline__ void rope_pair(float x0, float x1, float c, float s, 
     o1 = __fmaf_rn(x0, s, __fmul_rn(x1, c));
 }
 
+// Activations and KV-cache entries cross workgroups (and XCDs, whose L2s are not coherent with each other) INSIDE the
+// persistent kernel.  Every such access is a relaxed agent-scope atomic: stores write through to memory (sc1), loads
+// are served coherently (sc1) -- so a grid barrier needs no L2 write-back / invalidate, only 'my stores have completed'.
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+constexpr int kAuxCoherent = 17;      // raw buffer load cache policy: sc0 | sc1 (gfx940+ encoding of the aux operand)
+
 typedef int v4i __attribute__((ext_vector_type(4)));      // native vector: usable with __builtin_nontemporal_load
 __device__ __forceinline__ int dot16_i8(const v4i& w, const v4i& a, int acc) {
     acc = __builtin_amdgcn_sdot4(w.x, a.x, acc, false);
@@ -180,13 +187,14 @@ template <int QT> __device__ __forceinline__ int dot_chunk(const v4i& w, const v
 // GEMV argument block
 // ------------------------------------------------------------------------------------------
 struct GemvArgs {
-    // weights: row-major [rows][n] quantized values + natural-layout scales [rows][n/64]
-    const void*  W;   const float* sW;          // EPI_SWIGLU: W = W1 (gate), W2nd = W3 (up)
-    const void*  W2nd; const float* sW2nd;
+    // weights: row-major [rows][n] quantized values + natural-layout scales [rows][n/64].
+    // EPI_SWIGLU: W = [W1 (gate) ; W3 (up)], both [items][n], stored back to back (values and scales alike)
+    const void*  W;   const float* sW;
     int n;                                      // K (columns), multiple of 64
     int items;                                  // rows (STORE/RESIDUAL), hidden (SWIGLU), row pairs (ROPE_KV)
-    int rows_per_pass;                          // R: rows one workgroup reduces per pass (multiple of 64 >> cb_shift and of 2)
-    int cb_shift;                               // log2(CB): a 1 KiB wave load covers (64 >> cb_shift) rows x CB 16-byte chunks
+    int rows_per_pass;                          // Rm: rows (of each matrix) one workgroup reduces per pass; multiple of RB, <= 64
+    int cb_shift;                               // log2(CB): a 1 KiB wave load covers RB = (64 >> cb_shift) rows x CB 16-byte chunks
+    int wc_shift;                               // log2(WC): the 16 waves form a WC x WR grid over (column blocks x row blocks)
     // prologue inputs
     const float* x;                             // fp32 activation [n]          (QUANT / RMSNORM_QUANT)
     const float* norm_w;                        // rmsnorm weight [n]           (RMSNORM_QUANT)
@@ -199,33 +207,70 @@ struct GemvArgs {
     int dim; int kv_dim; int max_seq; int hs;   // ROPE_KV geometry
     // debugging taps used by the op-level exports (may be null)
     void* dbg_xq; float* dbg_xs; float* dbg_xn;
+    unsigned long long* trace;                  // FLM_ABLATE builds: per-workgroup timeline [grid][8] (s_memtime), else unused
     int ablate;                                 // perf exploration only (results invalid when != 0): 1 no group chain, 2 no rmsnorm chain, 4 no weight loads, 8 no dots, 16 return immediately, 32 return after prologue
 };
 
-constexpr int kMaxBlk = 8;             // 1 KiB wave loads in flight per wave and pass (8 KiB/wave, 64 KiB/workgroup, 128 KiB/CU)
-constexpr int kChainPad = 4;           // LDS row padding (dwords) of the per-wave chain scratch: no bank conflicts, keeps 16-B alignment
+#ifndef FLM_ABLATE
+#define FLM_ABLATE 0          // build with -DFLM_ABLATE=1 to compile the perf-exploration switches of GemvArgs::ablate into the hot loop
+#endif
+constexpr bool kAblate = FLM_ABLATE != 0;
+constexpr int kStepBlk = 4;            // H: 1 KiB wave loads per step; two steps (register sets) in flight: 8 KiB/wave, 128 KiB/CU
 
 // LDS layout: [xq : n*esz] [xs : n/64 floats, padded to 16 B] [red : 16 floats] [scratch]
 // scratch = max( rmsnorm transpose staging 4n bytes ,
-//                2 buffers x { dF[R][gstride] float(group dot), sP[R][gstride] sW*sX } )
+//                2 buffers x (Rm + RB) strips; strip r = { float(group dot), sW*sX } pairs of row r, groups ascending
+//                (SWIGLU: the W1 groups followed by the W3 groups) )
 struct GemvLds {
     int off_xs, off_red, off_scr;     // byte offsets
-    int gstride;                      // dwords per row strip; multiple of 4 (16-B aligned strips), +4 pad against bank conflicts
-    int buf_bytes;                    // one {dF, sP} buffer
+    int gstride;                      // BYTES per strip: 16 x odd, so that 16 lanes reading 16 B each from 16 strips hit all banks
+    int buf_bytes;                    // one strip buffer
     int total;                        // bytes
 };
-__host__ __device__ inline GemvLds gemv_lds_layout(int n, int esz, bool norm, int R) {
+__host__ __device__ inline GemvLds gemv_lds_layout(int n, int esz, bool norm, int Rm, int RB, bool two) {
     GemvLds L;
-    const int sn = n / kGroup;
+    const int sn = n / kGroup, ng = two ? 2 * sn : sn;
     L.off_xs = n * esz;
     L.off_red = L.off_xs + ((sn * 4 + 15) & ~15);
     L.off_scr = L.off_red + 64;
-    L.gstride = ((sn + 3) & ~3) + kChainPad;
-    L.buf_bytes = 2 * (R + 1) * L.gstride * 4;                                // +1: dummy strip that absorbs the writes of blocks past the pass
-    int scratch = 2 * L.buf_bytes;
-    if (norm && n * 4 + 256 > scratch) scratch = n * 4 + 256;                   // +256: the chain ring reads up to 32 floats past the last strip
+    int g16 = (ng * 8 + 15) / 16; if ((g16 & 1) == 0) ++g16;
+    L.gstride = g16 * 16;
+    L.buf_bytes = (Rm + RB) * L.gstride;                                       // + RB dummy strips that absorb the writes of padding blocks
+    int scratch = 2 * L.buf_bytes + 64;                                        // + 64: the chain's read-ahead past the last strip
+    if (norm && n * 4 + 256 > scratch) scratch = n * 4 + 256;                   // +256: the rmsnorm ring reads up to 32 floats past the last strip
     L.total = L.off_scr + scratch;
     return L;
+}
+
+// One of the 4 strided lanes of simd::square_sum -> square_sum_avx128 (x86_simd.cpp:942-960; the AVX2 branch is
+// dead, :1093): p[0..n4) = x[c], x[c+4], x[c+8], ... walked as a strictly sequential FMA chain.
+__device__ __forceinline__ float sq_chain(const float* p, int n4) {
+    float l = 0.f;
+    int k = 0;
+#define FLM_SQ4(v) l = __fmaf_rn(v.x, v.x, l); l = __fmaf_rn(v.y, v.y, l); l = __fmaf_rn(v.z, v.z, l); l = __fmaf_rn(v.w, v.w, l);
+#define FLM_STEP(q, off) FLM_SQ4(q) q = *reinterpret_cast<const float4*>(pp + (off)); __builtin_amdgcn_sched_barrier(0);
+    if (n4 >= 32) {
+        // A lone wave issues roughly one instruction every ~5 cycles, whatever its kind, so the
+        // loop body is nothing but the 32 dependent FMAs and 8 LDS reads with immediate offsets:
+        // a ring of 8 float4 registers, every read issued 28 FMAs before its first use (the
+        // sched_barriers pin that order).  Reads run up to 32 floats past a lane's strip: the
+        // staging area is sized for that (gemv_lds_layout) and those values are never consumed.
+        const float* pp = p;
+        float4 q0 = *reinterpret_cast<const float4*>(pp), q1 = *reinterpret_cast<const float4*>(pp + 4), q2 = *reinterpret_cast<const float4*>(pp + 8), q3 = *reinterpret_cast<const float4*>(pp + 12);
+        float4 q4 = *reinterpret_cast<const float4*>(pp + 16), q5 = *reinterpret_cast<const float4*>(pp + 20), q6 = *reinterpret_cast<const float4*>(pp + 24), q7 = *reinterpret_cast<const float4*>(pp + 28);
+        __builtin_amdgcn_sched_barrier(0);
+        for (; k + 32 <= n4; k += 32, pp += 32) {
+            FLM_STEP(q0, 32) FLM_STEP(q1, 36) FLM_STEP(q2, 40) FLM_STEP(q3, 44)
+            FLM_STEP(q4, 48) FLM_STEP(q5, 52) FLM_STEP(q6, 56) FLM_STEP(q7, 60)
+        }
+        // the ring now holds p[k .. k+31]
+        if (k + 4 <= n4) { FLM_SQ4(q0) k += 4; } if (k + 4 <= n4) { FLM_SQ4(q1) k += 4; } if (k + 4 <= n4) { FLM_SQ4(q2) k += 4; } if (k + 4 <= n4) { FLM_SQ4(q3) k += 4; }
+        if (k + 4 <= n4) { FLM_SQ4(q4) k += 4; } if (k + 4 <= n4) { FLM_SQ4(q5) k += 4; } if (k + 4 <= n4) { FLM_SQ4(q6) k += 4; }
+    }
+#undef FLM_STEP
+#undef FLM_SQ4
+    for (; k < n4; ++k) l = __fmaf_rn(p[k], p[k], l);
+    return l;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -264,7 +309,7 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
     using T = QTraits<QT>;
     const int n = a.n;
     const int tid = threadIdx.x;
-    const GemvLds L = gemv_lds_layout(n, T::kEsz, PRO == PRO_RMSNORM_QUANT, a.rows_per_pass);
+    const GemvLds L = gemv_lds_layout(n, T::kEsz, PRO == PRO_RMSNORM_QUANT, a.rows_per_pass, 64 >> a.cb_shift, false);   // only the fixed offsets are used here
     char*  xq = lds;
     float* xs = reinterpret_cast<float*>(lds + L.off_xs);
     float* red = reinterpret_cast<float*>(lds + L.off_red);
@@ -298,37 +343,7 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
                 if (e < n) stage(i, *reinterpret_cast<const float4*>(a.x + e));
             }
             __syncthreads();
-            if (tid < 4 && !(a.ablate & 2)) {
-                // 4 strided lanes, each a strictly sequential FMA chain; LDS reads are issued 32 values
-                // ahead of their use so the chain runs at FMA latency, not LDS latency.
-                const float* p = scratch + tid * n4;
-                float l = 0.f;
-                int k = 0;
-#define FLM_SQ4(v) l = __fmaf_rn(v.x, v.x, l); l = __fmaf_rn(v.y, v.y, l); l = __fmaf_rn(v.z, v.z, l); l = __fmaf_rn(v.w, v.w, l);
-#define FLM_STEP(q, off) FLM_SQ4(q) q = *reinterpret_cast<const float4*>(pp + (off)); __builtin_amdgcn_sched_barrier(0);
-                if (n4 >= 32) {
-                    // A lone wave issues roughly one instruction every ~5 cycles, whatever its kind, so the
-                    // loop body is nothing but the 32 dependent FMAs and 8 LDS reads with immediate offsets:
-                    // a ring of 8 float4 registers, every read issued 28 FMAs before its first use (the
-                    // sched_barriers pin that order).  Reads run up to 32 floats past a lane's strip: the
-                    // staging area is sized for that (gemv_lds_layout) and those values are never consumed.
-                    const float* pp = p;
-                    float4 q0 = *reinterpret_cast<const float4*>(pp), q1 = *reinterpret_cast<const float4*>(pp + 4), q2 = *reinterpret_cast<const float4*>(pp + 8), q3 = *reinterpret_cast<const float4*>(pp + 12);
-                    float4 q4 = *reinterpret_cast<const float4*>(pp + 16), q5 = *reinterpret_cast<const float4*>(pp + 20), q6 = *reinterpret_cast<const float4*>(pp + 24), q7 = *reinterpret_cast<const float4*>(pp + 28);
-                    __builtin_amdgcn_sched_barrier(0);
-                    for (; k + 32 <= n4; k += 32, pp += 32) {
-                        FLM_STEP(q0, 32) FLM_STEP(q1, 36) FLM_STEP(q2, 40) FLM_STEP(q3, 44)
-                        FLM_STEP(q4, 48) FLM_STEP(q5, 52) FLM_STEP(q6, 56) FLM_STEP(q7, 60)
-                    }
-                    // the ring now holds p[k .. k+31]
-                    if (k + 4 <= n4) { FLM_SQ4(q0) k += 4; } if (k + 4 <= n4) { FLM_SQ4(q1) k += 4; } if (k + 4 <= n4) { FLM_SQ4(q2) k += 4; } if (k + 4 <= n4) { FLM_SQ4(q3) k += 4; }
-                    if (k + 4 <= n4) { FLM_SQ4(q4) k += 4; } if (k + 4 <= n4) { FLM_SQ4(q5) k += 4; } if (k + 4 <= n4) { FLM_SQ4(q6) k += 4; }
-                }
-#undef FLM_STEP
-#undef FLM_SQ4
-                for (; k < n4; ++k) l = __fmaf_rn(p[k], p[k], l);
-                red[8 + tid] = l;
-            }
+            if (tid < 4 && !(a.ablate & 2)) red[8 + tid] = sq_chain(scratch + tid * n4, n4);
             __syncthreads();
             const float ss = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, red[8]), red[9]), red[10]), red[11]);
             r = rms_scale(ss, n);
@@ -385,160 +400,188 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
 // The GEMV.  quant::matmul<T> at w == 1 (src/blas/quant_operators.cpp:252-284):
 //     out[r] = sum_g (sW[r,g] * sX[g]) * float( sum_{k<64} W[r,64g+k] * X[64g+k] ),   g ASCENDING, FMA per group
 //
-// A workgroup (8 waves) reduces R rows per pass.  The R x K tile is cut into 1 KiB blocks of
+// One 16-wave workgroup per CU reduces Rm rows per pass.  The Rm x K tile is cut into 1 KiB blocks of
 // (RB rows x CB chunks of 16 B), RB*CB = 64, CB = the largest power of two dividing K/16 (so a block is
-// one fully coalesced global_load_dwordx4 per wave and every lane is busy for any K); blocks are dealt
-// round-robin to the 8 waves and ALL of a wave's blocks (<= kMaxBlk) are in flight before the
-// prologue runs.  Then
+// one fully coalesced buffer_load_dwordx4 per wave and every lane is busy for any K).  The waves form a
+// WC x WR grid: wave (wc, wr) owns the column blocks wc, wc+WC, ... and, of those, the row blocks
+// wr, wr+WR, ...; it walks them column block by column block, so that from one block to the next
+// only three scalar offsets advance by constants (the instruction stream per KiB is what limits a
+// GEMV whose operands arrive at several TB/s), and its activation chunk stays in registers.
+// SWIGLU runs [W1 ; W3] as ONE matrix with twice the column blocks: both dot products of a row land in
+// the same strip and the same chain lane.  Per block:
 //   1. int32 dot per 16-byte chunk (v_dot4 / v_dot2), exact;
 //   2. DPP sum over the 4 (int8) / 8 (int16) lanes of a quant group -> the group's int32 dot, exact;
-//   3. group leaders park float(dot) and s = sW*sX in LDS strips dF[row][g], sP[row][g];
-//   4. after ONE workgroup barrier, one wave walks the strips, lane r = row r:
-//        acc = fma(sP[g], dF[g], acc), g ascending -- the reference's summation order, bit-identical --
-//      amortising the sequential fp32 chain over R rows instead of paying it per row;
-//   5. the same lanes run the epilogue (coalesced stores).
-// The strips are double buffered, so the other waves are already in the next pass's dots.
+//   3. group leaders park { float(dot), sW*sX } in the row's LDS strip (one ds_write_b64);
+// and per pass, after ONE workgroup barrier, one wave walks the strips, lane r = row r:
+//        acc = fma(s[g], d[g], acc), g ascending -- the reference's summation order, bit-identical --
+// amortising the sequential fp32 chain over Rm rows, and runs the epilogue.  Strips are double
+// buffered, so the other waves are already in the next pass.  Two register sets of H blocks each
+// keep 8 KiB per wave (128 KiB per CU) of weight loads in flight at all times; the first 8 are
+// issued before the prologue so HBM latency and the sequential rmsnorm chain overlap the stream.
+//
+// GemvCtx is the per-wave state of one GEMV: geometry, the load cursor and the two register sets.
+// The standalone kernel k_gemv and the persistent whole-token kernel k_token both drive it:
+//     init -> issue (weight loads of the first two steps) -> [activation prologue] -> run
 // ------------------------------------------------------------------------------------------
-template <int QT, int PRO, int EPI, int XR>
-__global__ void __launch_bounds__(kGemvBlock, 4) k_gemv(const GemvArgs a) {
+typedef unsigned int u32;
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+template <int QT, int EPI>
+struct GemvCtx {
     using T = QTraits<QT>;
-    typedef unsigned int u32;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const u32 n = a.n;
-    const u32 lane = threadIdx.x & 63;
-    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr u32 LPGS = (T::kEPC == 16) ? 2 : 3;                             // log2(lanes per quant group): 4 | 8 lanes
-    constexpr u32 LPG = 1u << LPGS;
-    const u32 rowbytes = n * T::kEsz, nchunks = rowbytes / 16, sn = n / kGroup;
-    const u32 cbs = a.cb_shift, CB = 1u << cbs, RB = 64u >> cbs;
-    const u32 nbc = nchunks >> cbs;                                           // chunk blocks per row
-    const u32 R = a.rows_per_pass;
-    // SWIGLU passes hold R/2 rows of W1 followed by the R/2 matching rows of W3 (blocks never mix matrices)
-    constexpr bool TWO = EPI == EPI_SWIGLU;
-    const u32 TRm = TWO ? (u32)a.items : (u32)a.items * (EPI == EPI_ROPE_KV ? 2u : 1u);    // rows per matrix
-    const u32 Rm = TWO ? R / 2 : R;                                           // rows of one matrix per pass
-    const u32 npass = (TRm + Rm - 1) / Rm;
-    const u32 NB = (R / RB) * nbc;                                            // blocks per pass
-    const u32 nblk = (NB + kWavesPerBlock - 1 - wave) / kWavesPerBlock;       // blocks of this wave: b = wave + 8k
-    const u32 rb = lane >> cbs, cb = lane & (CB - 1);
-    // lane-constant parts of every address (the per-block parts are wave-uniform scalars)
-    const u32 lane_woff = rb * rowbytes + cb * 16;                            // weights, bytes from the block base
-    const u32 lane_soff = (rb * sn + (cb >> LPGS)) * 4;                       // scales
-    const u32 lane_xoff = cb * 16;                                            // activation chunk in LDS
-    const bool leader = (cb & (LPG - 1)) == 0;
-    // block sequence of this wave: (row block, chunk block) = divmod(wave + 8k, nbc), advanced incrementally
-    const u32 q8 = kWavesPerBlock / nbc, r8 = kWavesPerBlock - q8 * nbc;
-    const u32 rbk0 = wave / nbc, cbk0 = wave - rbk0 * nbc;
+    static constexpr u32 LPGS = (T::kEPC == 16) ? 2 : 3;                      // log2(lanes per quant group): 4 | 8 lanes
+    static constexpr u32 LPG = 1u << LPGS;
+    static constexpr bool TWO = EPI == EPI_SWIGLU;
+    static constexpr int H = kStepBlk;
+    static constexpr u32 kOOB = 0x80000000u;
 
-    // 1. the activation (L2-resident) first, 2. then every weight block of the first pass, both
-    // BEFORE the prologue: weights do not depend on the activation, so HBM latency (and the
-    // sequential rmsnorm chain) overlap the weight stream.
-    if (a.ablate & 16) return;
-    float4 xv[XR > 0 ? XR : 1], nv[XR > 0 ? XR : 1];
-    gemv_preload<QT, PRO, XR>(a, xv, nv);
-
-    // Each wave owns blocks b = wave + 8k, k < nblk, of every pass and streams them in steps of H
-    // blocks through two register sets (A, B): while one set is being reduced the other one and the
-    // refill of the first are in flight, so >= H KiB per wave (64 KiB per CU at 16 waves) are always
-    // outstanding and R is not limited by registers.
-    constexpr int H = kMaxBlk / 2;                                             // blocks per step
-    const u32 spp = ((NB + kWavesPerBlock - 1) / kWavesPerBlock + H - 1) / H;  // steps per pass (same for all waves)
     struct Set { v4i w[H]; float sw[H]; };
-    struct Cursor { u32 pass, s, k, rbk, cbk; };                               // pass, step in pass, block counter, divmod(wave + 8k, nbc)
-    auto cursor_init = [&](Cursor& c, u32 pass) { c.pass = pass; c.s = 0; c.k = 0; c.rbk = rbk0; c.cbk = cbk0; };
-    auto cursor_next_block = [&](Cursor& c) { ++c.k; c.rbk += q8; c.cbk += r8; if (c.cbk >= nbc) { c.cbk -= nbc; ++c.rbk; } };
-    auto cursor_end_step = [&](Cursor& c) { if (++c.s == spp) cursor_init(c, c.pass + gridDim.x); };
+    // The load cursor and the reduce cursor walk the same block sequence (pass, column block, row block),
+    // the load cursor two steps ahead; each carries only the running offsets its side needs.
+    struct LCur { u32 pass, ci, ri, wo, so; };
+    struct RCur { u32 pass, ci, ri, st, xo; };
 
-    // Weight and scale blocks are fetched with raw buffer loads: address = descriptor base + wave-uniform
-    // scalar offset (the block) + lane-constant 32-bit offset: no per-load vector address arithmetic, no
-    // branches.  A block past the pass (k >= nblk), past the last pass, or rows past the end of the
-    // matrix get an offset outside the descriptor -> the load returns zero without touching memory.
-    // "nt": each weight byte is read once per token.
-    typedef unsigned v4u __attribute__((ext_vector_type(4)));
-    constexpr int kRsrcFlags = 0x00020000;                                     // raw buffer, 32-bit data format (gfx9 family)
-    const __amdgpu_buffer_rsrc_t rW  = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, (int)(TRm * rowbytes), kRsrcFlags);
-    const __amdgpu_buffer_rsrc_t rS  = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.sW), 0, (int)(TRm * sn * 4), kRsrcFlags);
-    const __amdgpu_buffer_rsrc_t rW2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(TWO ? a.W2nd : a.W), 0, (int)(TRm * rowbytes), kRsrcFlags);
-    const __amdgpu_buffer_rsrc_t rS2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(TWO ? a.sW2nd : a.sW), 0, (int)(TRm * sn * 4), kRsrcFlags);
-    auto load_step = [&](Set& S, Cursor& c) {
+    // geometry (wave-uniform unless noted)
+    u32 n, lane, wave, rowbytes, sn, cbs, RB, nbc, TRm, Rm, npass, wcs, wc, wr, nrw, ncw, gstride, buf_bytes, off_xs, off_scr;
+    u32 lane_woff, lane_soff, lane_xoff, lane_sxoff, lane_goff;               // per lane
+    bool leader;                                                               // per lane
+    u32 dW, dS, dT, dummy_st, wg, nwg;
+    __amdgpu_buffer_rsrc_t rW, rS;
+    Set setA, setB;
+    LCur lc;
+    RCur rc;
+    bool stored;                                                               // this wave wrote results to global memory
+
+    __device__ __forceinline__ void init(const GemvArgs& a, u32 wg_, u32 nwg_) {
+        n = a.n; wg = wg_; nwg = nwg_;
+        lane = threadIdx.x & 63;
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        rowbytes = n * T::kEsz; sn = n / kGroup;
+        const u32 nchunks = rowbytes / 16;
+        cbs = a.cb_shift; RB = 64u >> cbs;
+        const u32 CB = 1u << cbs;
+        nbc = nchunks >> cbs;                                                  // column blocks per row
+        const u32 NBCV = TWO ? 2 * nbc : nbc;                                  // ... of the (virtual) matrix this launch walks
+        TRm = (u32)a.items * (EPI == EPI_ROPE_KV ? 2u : 1u);                   // rows per matrix
+        Rm = a.rows_per_pass;
+        const u32 RBP = Rm / RB;                                               // row blocks per pass
+        npass = (TRm + Rm - 1) / Rm;
+        wcs = a.wc_shift;
+        const u32 WC = 1u << wcs, WR = (u32)kWavesPerBlock >> wcs;
+        wc = wave & (WC - 1); wr = wave >> wcs;
+        nrw = wr < RBP ? (RBP - wr + WR - 1) / WR : 0;                         // row blocks of this wave per pass
+        ncw = (wc < NBCV && nrw) ? (NBCV - wc + WC - 1) >> wcs : 0;            // column blocks of this wave
+        const u32 rb = lane >> cbs, cb = lane & (CB - 1);
+        const GemvLds L = gemv_lds_layout(n, T::kEsz, true, Rm, RB, TWO);
+        gstride = L.gstride; buf_bytes = L.buf_bytes; off_xs = L.off_xs; off_scr = L.off_scr;
+        // lane-constant parts of every address (the per-block parts are wave-uniform scalars)
+        lane_woff = rb * rowbytes + cb * 16;                                   // weights, bytes from the block base
+        lane_soff = (rb * sn + (cb >> LPGS)) * 4;                              // scales
+        lane_xoff = cb * 16;                                                   // activation chunk in LDS
+        lane_sxoff = (cb >> LPGS) * 4;                                         // its scale
+        lane_goff = rb * gstride + (cb >> LPGS) * 8;                           // strip entry of this lane's group
+        leader = (cb & (LPG - 1)) == 0;
+        dW = WR * RB * rowbytes; dS = WR * RB * sn * 4; dT = WR * RB * gstride; // block-to-block strides
+        dummy_st = Rm * gstride;
+        // Weight and scale blocks are fetched with raw buffer loads: address = descriptor base + wave-uniform
+        // scalar offset (the block) + lane-constant 32-bit offset: no per-load vector address arithmetic, no
+        // branches.  Padding blocks and passes past the end get an offset outside the descriptor -> the load
+        // returns zero without touching memory.  "nt": each weight byte is read once per token.
+        constexpr int kRsrcFlags = 0x00020000;                                 // raw buffer, 32-bit data format (gfx9 family)
+        const u32 NM = TWO ? 2u : 1u;
+        rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, (int)(NM * TRm * rowbytes), kRsrcFlags);
+        rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.sW), 0, (int)(NM * TRm * sn * 4), kRsrcFlags);
+        stored = false;
+    }
+
+    // column block ci of this wave -> (second matrix?, column block inside the matrix)
+    __device__ __forceinline__ u32 col_of(u32 ci, bool& second) const {
+        const u32 cv = wc + (ci << wcs);
+        second = TWO && cv >= nbc;
+        return second ? cv - nbc : cv;
+    }
+    __device__ __forceinline__ void lcur_col(LCur& c) const {                  // offsets of the first row block of column block c.ci
+        bool second; const u32 cc = col_of(c.ci, second);
+        const u32 row0 = (second ? TRm : 0u) + c.pass * Rm + wr * RB;
+        c.ri = 0;
+        c.wo = row0 * rowbytes + ((cc << cbs) * 16);
+        c.so = (row0 * sn + ((cc << cbs) >> LPGS)) * 4;
+    }
+    __device__ __forceinline__ void rcur_col(RCur& c) const {
+        bool second; const u32 cc = col_of(c.ci, second);
+        c.ri = 0;
+        c.st = wr * RB * gstride + ((second ? sn : 0u) + ((cc << cbs) >> LPGS)) * 8;
+        c.xo = cc;
+    }
+    __device__ __forceinline__ void lcur_pass(LCur& c, u32 pass) const {
+        c.pass = pass; c.ci = pass < npass ? 0 : ncw; c.ri = 0; c.wo = 0; c.so = 0;
+        if (c.ci < ncw) lcur_col(c);
+    }
+    __device__ __forceinline__ void rcur_pass(RCur& c, u32 pass) const {
+        c.pass = pass; c.ci = pass < npass ? 0 : ncw; c.ri = 0; c.st = 0; c.xo = 0;
+        if (c.ci < ncw) rcur_col(c);
+    }
+    __device__ __forceinline__ void load_step(Set& S, LCur& c, int ablate) const {
 #pragma unroll
         for (int j = 0; j < H; ++j) {
-            u32 vr = c.rbk * RB;                                             // first row of the block inside the pass
-            bool second = false;
-            if constexpr (TWO) { second = vr >= Rm; vr = second ? vr - Rm : vr; }
-            const u32 row = c.pass * Rm + vr;
-            const bool live = c.k < nblk && c.pass < npass && !(a.ablate & 4);
-            const u32 wo = live ? row * rowbytes + ((c.cbk << cbs) * 16) : 0x80000000u;
-            const u32 so = live ? (row * sn + ((c.cbk << cbs) >> LPGS)) * 4 : 0x80000000u;
-            v4u wv; unsigned sv;
-            if constexpr (TWO) {
-                const __amdgpu_buffer_rsrc_t rw = second ? rW2 : rW, rs_ = second ? rS2 : rS;
-                wv = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)lane_woff, (int)wo, 2); sv = __builtin_amdgcn_raw_buffer_load_b32(rs_, (int)lane_soff, (int)so, 2);
-            } else {
-                wv = __builtin_amdgcn_raw_buffer_load_b128(rW, (int)lane_woff, (int)wo, 2); sv = __builtin_amdgcn_raw_buffer_load_b32(rS, (int)lane_soff, (int)so, 2);
-            }
+            const bool live = c.ci < ncw && !(kAblate && (ablate & 4));
+            const u32 wo = live ? c.wo : kOOB, so = live ? c.so : kOOB;
+            const v4u wv = __builtin_amdgcn_raw_buffer_load_b128(rW, (int)lane_woff, (int)wo, 2);
+            const unsigned sv = __builtin_amdgcn_raw_buffer_load_b32(rS, (int)lane_soff, (int)so, 2);
             S.w[j] = __builtin_bit_cast(v4i, wv);
             S.sw[j] = __uint_as_float(sv);
-            cursor_next_block(c);
+            c.wo += dW; c.so += dS;
+            if (++c.ri >= nrw) { ++c.ci; if (c.ci < ncw) lcur_col(c); }
         }
-        cursor_end_step(c);
-    };
-    Set setA, setB;
-    Cursor lc;                                                                 // load cursor, runs two steps ahead of the reduce cursor
-    cursor_init(lc, blockIdx.x);
-    load_step(setA, lc);
-    load_step(setB, lc);
-
-    gemv_prologue<QT, PRO, XR>(a, lds, xv, nv);
-    if (a.ablate & 32) return;
-
-    const GemvLds L = gemv_lds_layout(n, T::kEsz, PRO == PRO_RMSNORM_QUANT, R);
-    const char*  xq = lds;
-    const char*  xs = lds + L.off_xs;
-    const u32 gstride = L.gstride;
-    const u32 lane_goff = (rb * gstride + (cb >> LPGS)) * 4;                   // strip position of this lane's group, bytes
-    const bool vec_ok = (sn % 4) == 0;                                         // 16-B LDS reads need whole float4s per strip
-    int pos = 0;
-    if constexpr (EPI == EPI_ROPE_KV) pos = *a.pos_ptr;
+        if (c.ci >= ncw) lcur_pass(c, c.pass + nwg);                           // the pass ended inside this step
+    }
+    // the first two steps of weight loads: independent of the activation, so they are issued before it exists
+    __device__ __forceinline__ void issue(int ablate) {
+        lcur_pass(lc, wg);
+        load_step(setA, lc, ablate);
+        load_step(setB, lc, ablate);
+    }
 
     // reduce one step: dots for all its blocks first (registers), then ONE leader-only region parks them.
-    // Blocks past the pass hold zeros; their strip writes are redirected to the dummy strip (row R).
-    auto reduce_step = [&](Set& S, Cursor c, char* dF, char* sP) {
-        int d[H];
-        {
-            Cursor q = c;
+    // Returns true when the pass ended inside this step (the cursor then stands on the workgroup's next pass).
+    v4i xa; float sx; u32 cur_xo;                                              // activation chunk + scale of the current column block
+    __device__ __forceinline__ bool reduce_step(Set& S, RCur& c, char* lds, char* strips, int ablate) {
+        const char* xq = lds; const char* xs = lds + off_xs;
+        int d[H]; float p[H]; u32 st[H];
 #pragma unroll
-            for (int j = 0; j < H; ++j) {
-                const v4i av = *reinterpret_cast<const v4i*>(xq + ((q.cbk << cbs) * 16) + lane_xoff);
-                int t = (a.ablate & 8) ? 0 : quad_sum(dot_chunk<QT>(S.w[j], av));
-                if constexpr (LPG == 8) t += __shfl_xor(t, 4, kWave);
-                d[j] = t;
-                cursor_next_block(q);
+        for (int j = 0; j < H; ++j) {
+            const bool live = c.ci < ncw;
+            if (live && c.xo != cur_xo) {                                      // wave-uniform, rare: a new column block
+                cur_xo = c.xo;
+                xa = *reinterpret_cast<const v4i*>(xq + ((cur_xo << cbs) * 16) + lane_xoff);
+                sx = *reinterpret_cast<const float*>(xs + (((cur_xo << cbs) >> LPGS) * 4) + lane_sxoff);
             }
+            int t = (kAblate && (ablate & 8)) ? 0 : quad_sum(dot_chunk<QT>(S.w[j], xa));
+            if constexpr (LPG == 8) t += __builtin_amdgcn_update_dpp(0, t, 0x104 /* row_shl:4 */, 0xF, 0xF, true);
+            d[j] = t;
+            p[j] = __fmul_rn(S.sw[j], sx);                                     // s = sW * sX (quant_operators.cpp:274)
+            st[j] = live ? c.st : dummy_st;                                    // padding blocks hold zeros: parked in the dummy strips
+            c.st += dT;
+            if (++c.ri >= nrw) { ++c.ci; if (c.ci < ncw) rcur_col(c); }
         }
         if (leader) {
-            Cursor q = c;
 #pragma unroll
-            for (int j = 0; j < H; ++j) {
-                const u32 g0 = (q.cbk << cbs) >> LPGS;                       // first group of the block (scalar)
-                const bool live = q.k < nblk;
-                const u32 so = ((live ? q.rbk * RB : R) * gstride + g0) * 4 + (live ? lane_goff : (cb >> LPGS) * 4);
-                const float sx = *reinterpret_cast<const float*>(xs + g0 * 4 + (cb >> LPGS) * 4);
-                *reinterpret_cast<float*>(dF + so) = (float)d[j];                          // exact int32 -> fp32, as "s * dot" does
-                *reinterpret_cast<float*>(sP + so) = __fmul_rn(S.sw[j], sx);               // s = sW * sX (quant_operators.cpp:274)
-                cursor_next_block(q);
-            }
+            for (int j = 0; j < H; ++j)
+                *reinterpret_cast<float2*>(strips + st[j] + lane_goff) = make_float2((float)d[j], p[j]);   // exact int32 -> fp32, as "s * dot" does
         }
-    };
+        const bool last = c.ci >= ncw;
+        if (last) rcur_pass(c, c.pass + nwg);
+        return last;
+    }
 
-    // the end of a pass: one barrier, then ONE wave runs the fp32 chains of all R rows and the epilogue
-    auto finish_pass = [&](u32 pass, u32 it, char* dF, char* sP) {
+    // the end of a pass: one barrier, then ONE wave runs the fp32 chains of all Rm rows and the epilogue
+    __device__ __forceinline__ void finish_pass(const GemvArgs& a, u32 pass, u32 it, const char* strips, int pos) {
         const bool chain_wave = wave == (it & (kWavesPerBlock - 1));
         // epilogue operands of the chain wave, fetched before the barrier (lane r = row r of the pass)
         float resid = 0.f, rc = 0.f, rs = 0.f;
-        const u32 row = pass * Rm + (TWO ? (lane < Rm ? lane : lane - Rm) : lane);   // row inside its matrix
-        const bool rv = chain_wave && lane < R && row < TRm;
-        if constexpr (EPI == EPI_RESIDUAL) { if (rv) resid = a.out[row]; }
+        const u32 row = pass * Rm + lane;                                      // row inside its matrix
+        const bool rv = chain_wave && lane < Rm && row < TRm;
+        if constexpr (EPI == EPI_RESIDUAL) { if (rv) resid = ld_agent(a.out + row); }
         if constexpr (EPI == EPI_ROPE_KV) {
             if (rv && row < (u32)(a.dim + a.kv_dim)) {
                 const u32 r2 = (row < (u32)a.dim ? row : row - a.dim) & ~1u;
@@ -549,49 +592,42 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_gemv(const GemvArgs a) {
         }
         __syncthreads();
         if (!chain_wave) return;
+        stored = true;
         // ---- the reference's fp32 chain, lane r = row r: o[j] += s * dot (FMA), groups ascending.
-        //      LDS reads run 8 groups ahead of the FMAs so the chain advances at FMA latency.
-        float acc = 0.f;
-        if (lane < R && !(a.ablate & 1)) {
-            const float* dp = reinterpret_cast<const float*>(dF) + lane * gstride;
-            const float* sp = reinterpret_cast<const float*>(sP) + lane * gstride;
+        //      Strip entries are {d, s} pairs; reads run 8 groups ahead of the FMAs (ring of 4 float4),
+        //      so the chain advances at FMA latency.  SWIGLU: the W1 and W3 chains interleave.
+        float acc = 0.f, acc2 = 0.f;
+        if (lane < Rm && !(a.ablate & 1)) {
+            const char* sp = strips + lane * gstride;
+            const char* sp2 = sp + sn * 8;
             u32 g = 0;
-            if (vec_ok) {
-                float4 sa = {0.f, 0.f, 0.f, 0.f}, sb = sa, sc = sa, sd = sa, da = sa, db = sa, dc = sa, dd = sa;
-                if (sn >= 8) { sa = *reinterpret_cast<const float4*>(sp); da = *reinterpret_cast<const float4*>(dp);
-                               sb = *reinterpret_cast<const float4*>(sp + 4); db = *reinterpret_cast<const float4*>(dp + 4); }
-                for (; g + 16 <= sn; g += 16) {
-                    sc = *reinterpret_cast<const float4*>(sp + g + 8);  dc = *reinterpret_cast<const float4*>(dp + g + 8);
-                    sd = *reinterpret_cast<const float4*>(sp + g + 12); dd = *reinterpret_cast<const float4*>(dp + g + 12);
-                    acc = __fmaf_rn(sa.x, da.x, acc); acc = __fmaf_rn(sa.y, da.y, acc); acc = __fmaf_rn(sa.z, da.z, acc); acc = __fmaf_rn(sa.w, da.w, acc);
-                    acc = __fmaf_rn(sb.x, db.x, acc); acc = __fmaf_rn(sb.y, db.y, acc); acc = __fmaf_rn(sb.z, db.z, acc); acc = __fmaf_rn(sb.w, db.w, acc);
-                    if (g + 24 <= sn) { sa = *reinterpret_cast<const float4*>(sp + g + 16); da = *reinterpret_cast<const float4*>(dp + g + 16);
-                                        sb = *reinterpret_cast<const float4*>(sp + g + 20); db = *reinterpret_cast<const float4*>(dp + g + 20); }
-                    acc = __fmaf_rn(sc.x, dc.x, acc); acc = __fmaf_rn(sc.y, dc.y, acc); acc = __fmaf_rn(sc.z, dc.z, acc); acc = __fmaf_rn(sc.w, dc.w, acc);
-                    acc = __fmaf_rn(sd.x, dd.x, acc); acc = __fmaf_rn(sd.y, dd.y, acc); acc = __fmaf_rn(sd.z, dd.z, acc); acc = __fmaf_rn(sd.w, dd.w, acc);
-                }
-                if (g + 8 <= sn) {          // sa/sb hold groups g..g+7
-                    acc = __fmaf_rn(sa.x, da.x, acc); acc = __fmaf_rn(sa.y, da.y, acc); acc = __fmaf_rn(sa.z, da.z, acc); acc = __fmaf_rn(sa.w, da.w, acc);
-                    acc = __fmaf_rn(sb.x, db.x, acc); acc = __fmaf_rn(sb.y, db.y, acc); acc = __fmaf_rn(sb.z, db.z, acc); acc = __fmaf_rn(sb.w, db.w, acc);
-                    g += 8;
-                }
-                for (; g + 4 <= sn; g += 4) {
-                    const float4 s4 = *reinterpret_cast<const float4*>(sp + g), d4 = *reinterpret_cast<const float4*>(dp + g);
-                    acc = __fmaf_rn(s4.x, d4.x, acc); acc = __fmaf_rn(s4.y, d4.y, acc); acc = __fmaf_rn(s4.z, d4.z, acc); acc = __fmaf_rn(s4.w, d4.w, acc);
+#define FLM_CH2(q) acc = __fmaf_rn(q.y, q.x, acc); acc = __fmaf_rn(q.w, q.z, acc);
+#define FLM_CH2B(q) acc2 = __fmaf_rn(q.y, q.x, acc2); acc2 = __fmaf_rn(q.w, q.z, acc2);
+            if (sn >= 8) {
+                float4 q0 = *reinterpret_cast<const float4*>(sp), q1 = *reinterpret_cast<const float4*>(sp + 16), q2 = *reinterpret_cast<const float4*>(sp + 32), q3 = *reinterpret_cast<const float4*>(sp + 48);
+                float4 r0 = q0, r1 = q0, r2 = q0, r3 = q0;
+                if constexpr (TWO) { r0 = *reinterpret_cast<const float4*>(sp2); r1 = *reinterpret_cast<const float4*>(sp2 + 16); r2 = *reinterpret_cast<const float4*>(sp2 + 32); r3 = *reinterpret_cast<const float4*>(sp2 + 48); }
+                for (; g + 8 <= sn; g += 8) {
+                    const char* pn = sp + (g + 8) * 8; const char* pn2 = sp2 + (g + 8) * 8;     // next 8 groups (read-ahead; past the end on the last round: inside the allocation, never consumed)
+                    FLM_CH2(q0) if constexpr (TWO) { FLM_CH2B(r0) } q0 = *reinterpret_cast<const float4*>(pn);      if constexpr (TWO) r0 = *reinterpret_cast<const float4*>(pn2);
+                    FLM_CH2(q1) if constexpr (TWO) { FLM_CH2B(r1) } q1 = *reinterpret_cast<const float4*>(pn + 16); if constexpr (TWO) r1 = *reinterpret_cast<const float4*>(pn2 + 16);
+                    FLM_CH2(q2) if constexpr (TWO) { FLM_CH2B(r2) } q2 = *reinterpret_cast<const float4*>(pn + 32); if constexpr (TWO) r2 = *reinterpret_cast<const float4*>(pn2 + 32);
+                    FLM_CH2(q3) if constexpr (TWO) { FLM_CH2B(r3) } q3 = *reinterpret_cast<const float4*>(pn + 48); if constexpr (TWO) r3 = *reinterpret_cast<const float4*>(pn2 + 48);
                 }
             }
-            for (; g < sn; ++g) acc = __fmaf_rn(sp[g], dp[g], acc);
+#undef FLM_CH2
+#undef FLM_CH2B
+            for (u32 h = g; h < sn; ++h) { const float2 e = *reinterpret_cast<const float2*>(sp + h * 8); acc = __fmaf_rn(e.y, e.x, acc); }
+            if constexpr (TWO) for (u32 h = g; h < sn; ++h) { const float2 e = *reinterpret_cast<const float2*>(sp2 + h * 8); acc2 = __fmaf_rn(e.y, e.x, acc2); }
         }
         // ---------------- epilogues ----------------
         if constexpr (EPI == EPI_STORE || EPI == EPI_RESIDUAL) {
             if (rv) {
-                if constexpr (EPI == EPI_STORE) a.out[row] = acc;
-                else a.out[row] = __fadd_rn(resid, acc);             // o.add(tmp, offset) transformer.cpp:465,493
+                if constexpr (EPI == EPI_STORE) st_agent(a.out + row, acc);
+                else st_agent(a.out + row, __fadd_rn(resid, acc));   // o.add(tmp, offset) transformer.cpp:465,493
             }
         } else if constexpr (EPI == EPI_SWIGLU) {
-            // lane r < R/2 holds W1[row].x, lane r + R/2 holds W3[row].x
-            const float up = __shfl(acc, (int)(lane + Rm), kWave);
-            if (rv && lane < Rm) a.out[row] = swiglu_elem(acc, up);  // o1.swiglu(o3) transformer.cpp:481
+            if (rv) st_agent(a.out + row, swiglu_elem(acc, acc2));   // o1.swiglu(o3) transformer.cpp:481
         } else {   // EPI_ROPE_KV: rows (2i, 2i+1) of [Wq;Wk;Wv]; RoPE on q and k, append k,v to the cache
             const float other = __shfl_xor(acc, 1, kWave);
             if (rv && (lane & 1) == 0) {
@@ -602,34 +638,65 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_gemv(const GemvArgs a) {
                     const u32 h = rr / hs, d = rr - h * hs;
                     float o0, o1;
                     rope_pair(x0, x1, rc, rs, o0, o1);
-                    if (row < (u32)a.dim) { a.out[row] = o0; a.out[row + 1] = o1; }
-                    else { float* kp = a.kcache + ((size_t)h * a.max_seq + pos) * hs + d; kp[0] = o0; kp[1] = o1; }
+                    if (row < (u32)a.dim) { st_agent(a.out + row, o0); st_agent(a.out + row + 1, o1); }
+                    else { float* kp = a.kcache + ((size_t)h * a.max_seq + pos) * hs + d; st_agent(kp, o0); st_agent(kp + 1, o1); }
                 } else {
                     const u32 rr = row - a.dim - a.kv_dim;
                     const u32 h = rr / hs, d = rr - h * hs;
-                    float* vp = a.vcache + ((size_t)h * a.max_seq + pos) * hs + d; vp[0] = x0; vp[1] = x1;
+                    float* vp = a.vcache + ((size_t)h * a.max_seq + pos) * hs + d; st_agent(vp, x0); st_agent(vp + 1, x1);
                 }
             }
         }
-    };
-
-    Cursor rc_;                                                                // reduce cursor
-    cursor_init(rc_, blockIdx.x);
-    u32 it = 0;                                                                // pass counter of this workgroup
-    auto do_step = [&](Set& S) {
-        char* dF = lds + L.off_scr + (it & 1) * L.buf_bytes;                   // float [R+1][gstride], double buffered across passes
-        char* sP = dF + (R + 1) * gstride * 4;
-        reduce_step(S, rc_, dF, sP);
-        const u32 pass = rc_.pass; const bool last = rc_.s + 1 == spp;
-        for (int j = 0; j < H; ++j) cursor_next_block(rc_);
-        cursor_end_step(rc_);
-        load_step(S, lc);                                                      // refill this set: two steps ahead
-        if (last) { finish_pass(pass, it, dF, sP); ++it; }
-    };
-    while (rc_.pass < npass) {
-        do_step(setA);
-        if (rc_.pass < npass) do_step(setB);
     }
+
+    // the main loop: the quantized activation is in LDS (xq at 0, xs at off_xs); issue() has run
+    template <class Stamp>
+    __device__ __forceinline__ void run(const GemvArgs& a, char* lds, Stamp&& stamp) {
+        int pos = 0;
+        if constexpr (EPI == EPI_ROPE_KV) pos = *a.pos_ptr;
+        xa = v4i{0, 0, 0, 0}; sx = 0.f; cur_xo = 0xffffffffu;
+        rcur_pass(rc, wg);
+        u32 it = 0;                                                            // pass counter of this workgroup
+        bool tr3 = false;
+        auto do_step = [&](Set& S) {
+            char* strips = lds + off_scr + (it & 1) * buf_bytes;               // double buffered across passes
+            const u32 pass = rc.pass;
+            const bool last = reduce_step(S, rc, lds, strips, a.ablate);
+            load_step(S, lc, a.ablate);                                        // refill this set: two steps ahead
+            if (it == 0 && !tr3) { tr3 = true; stamp(3); }
+            if (last) { if (it == 0) stamp(4); finish_pass(a, pass, it, strips, pos); if (it == 0) stamp(5); ++it; }
+        };
+        while (true) {
+            if (rc.pass >= npass) break;
+            do_step(setA);
+            if (rc.pass >= npass) break;
+            do_step(setB);
+        }
+    }
+};
+
+template <int QT, int PRO, int EPI, int XR>
+__global__ void __launch_bounds__(kGemvBlock, 4) k_gemv(const GemvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    unsigned long long rt0 = 0;
+    auto stamp = [&](int k) { if (kAblate && a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime(); };
+    if (kAblate && a.trace && threadIdx.x == 0) rt0 = __builtin_amdgcn_s_memrealtime();
+    stamp(0);
+    if (a.ablate & 16) return;
+    // 1. the activation (L2-resident) first, 2. then the first two steps of weight blocks, both
+    // BEFORE the prologue: weights do not depend on the activation, and loads return in issue order.
+    float4 xv[XR > 0 ? XR : 1], nv[XR > 0 ? XR : 1];
+    gemv_preload<QT, PRO, XR>(a, xv, nv);
+    GemvCtx<QT, EPI> g;
+    g.init(a, blockIdx.x, gridDim.x);
+    g.issue(a.ablate);
+    stamp(1);
+    gemv_prologue<QT, PRO, XR>(a, lds, xv, nv);
+    stamp(2);
+    if (a.ablate & 32) return;
+    g.run(a, lds, stamp);
+    stamp(6);
+    if (kAblate && a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime() - rt0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -653,9 +720,8 @@ struct AttnArgs {
 };
 
 constexpr int kAttnBlock = 1024;      // 16 waves: 128 positions are scored per sweep (8 lanes per position)
-__global__ void __launch_bounds__(kAttnBlock) k_attn_decode(const AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int hs = a.hs, h = blockIdx.x;
+__device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* lds) {
+    const int hs = a.hs;
     const int T = *a.pos_ptr + 1;
     float* qs   = reinterpret_cast<float*>(lds);                 // [hs]
     float* red  = qs + hs;                                       // 32
@@ -664,9 +730,15 @@ __global__ void __launch_bounds__(kAttnBlock) k_attn_decode(const AttnArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* K = a.kcache + (size_t)h * a.max_seq * hs;
     const float* V = a.vcache + (size_t)h * a.max_seq * hs;
+    // K/V rows of this token were written by other workgroups of the same kernel (k_token): coherent loads (sc0|sc1)
+    // through buffer descriptors, which the compiler is free to batch (an atomic load per element would serialise)
+    const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(K), 0, a.max_seq * hs * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V), 0, a.max_seq * hs * 4, 0x00020000);
+    auto ldK = [&](int idx) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rK, idx * 4, 0, kAuxCoherent)); };
+    auto ldV = [&](int idx) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rV, idx * 4, 0, kAuxCoherent)); };
     const float scale = (float)(1.0 / (double)__builtin_sqrtf((float)hs));   // attn_scale, transformer.cpp:418
 
-    for (int d = threadIdx.x; d < hs; d += kAttnBlock) qs[d] = a.q[(size_t)h * hs + d];
+    for (int d = threadIdx.x; d < hs; d += kAttnBlock) qs[d] = ld_agent(a.q + (size_t)h * hs + d);
     __syncthreads();
 
     // ---- scores: lane = (position p = lane/8, strided accumulator k = lane%8) -- the 8 lanes of
@@ -677,10 +749,10 @@ __global__ void __launch_bounds__(kAttnBlock) k_attn_decode(const AttnArgs a) {
     for (int tb = wave * 8; tb < T; tb += 16 * 8) {
         const int t = tb + p;
         const bool tv = t < T;
-        const float* kr = K + (size_t)(tv ? t : 0) * hs + k;
+        const int kr = (tv ? t : 0) * hs + k;
         float l = 0.f;
 #pragma unroll 16
-        for (int i = 0; i < hs; i += 8) l = __fmaf_rn(kr[i], qs[i + k], l);
+        for (int i = 0; i < hs; i += 8) l = __fmaf_rn(ldK(kr + i), qs[i + k], l);
         wpart[lane] = l;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -736,31 +808,249 @@ __global__ void __launch_bounds__(kAttnBlock) k_attn_decode(const AttnArgs a) {
     // ---- o[d] = sum_t att[t] V[t][d]: one thread per output dimension, t ascending (the reference's
     //      chain); 8 V rows are loaded ahead of their 8 dependent FMAs, the weights come 4 per LDS read.
     for (int d = threadIdx.x; d < hs; d += kAttnBlock) {
-        const float* vp = V + d;
-        float o = __fmul_rn(vp[0], sc[0]);                         // row 0 always (tf_operators.cpp:331-336)
+        float o = __fmul_rn(ldV(d), sc[0]);                        // row 0 always (tf_operators.cpp:331-336)
         int t = 1;
-        for (; t < T && (t & 3); ++t) { const float w = sc[t]; o = fabsf(w) <= 1e-15f ? o : __fmaf_rn(vp[(size_t)t * hs], w, o); }
+        for (; t < T && (t & 3); ++t) { const float w = sc[t]; o = fabsf(w) <= 1e-15f ? o : __fmaf_rn(ldV(t * hs + d), w, o); }
         for (; t + 8 <= T; t += 8) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = vp[(size_t)(t + u) * hs];
+            for (int u = 0; u < 8; ++u) v[u] = ldV((t + u) * hs + d);
             const float4 w0 = *reinterpret_cast<const float4*>(sc + t), w1 = *reinterpret_cast<const float4*>(sc + t + 4);
             const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
             for (int u = 0; u < 8; ++u) o = fabsf(w[u]) <= 1e-15f ? o : __fmaf_rn(v[u], w[u], o);   // threshold, transformer.cpp:449
         }
-        for (; t < T; ++t) { const float w = sc[t]; o = fabsf(w) <= 1e-15f ? o : __fmaf_rn(vp[(size_t)t * hs], w, o); }
-        a.out[(size_t)h * hs + d] = o;
+        for (; t < T; ++t) { const float w = sc[t]; o = fabsf(w) <= 1e-15f ? o : __fmaf_rn(ldV(t * hs + d), w, o); }
+        st_agent(a.out + (size_t)h * hs + d, o);
     }
 }
+__global__ void __launch_bounds__(kAttnBlock) k_attn_decode(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    attn_head(a, blockIdx.x, lds);
+}
 __host__ inline size_t attn_lds_bytes(int max_seq, int hs) { return (size_t)(hs + 32 + 16 * 64 + ((max_seq + 3) & ~3) + 64) * 4; }
+
+// ------------------------------------------------------------------------------------------
+// The persistent whole-token kernel (single GPU).  One 16-wave workgroup per CU walks the token's
+// phases  L x { qkv, attention, attn_o, ffn13, ffn2 }, cls  with a grid barrier between phases instead of
+// a kernel boundary, so that
+//   * the weight stream does not drain at every phase change: each wave issues the first 8 KiB of the NEXT
+//     phase's weights BEFORE it arrives at the barrier (weights never depend on activations), and
+//   * there is no launch / drain / argument-fetch latency per phase.
+// Loads return in issue order, so a wave with weight loads in flight would see the new activation only
+// after them: waves 0..3 ("activation waves", one per SIMD) therefore postpone their weight prefetch
+// until they have issued the activation loads right after the barrier.
+// Every workgroup must be resident at once (grid <= CUs, one workgroup per CU by LDS footprint); a barrier
+// that does not complete within seconds sets *err and lets the kernel run to its end instead of hanging.
+// Results are the same bits as the per-phase kernels: same device functions, same chains.
+// ------------------------------------------------------------------------------------------
+struct TokenArgs {
+    const GemvArgs* gemv;        // device array: per layer { qkv, attn_o, ffn13, ffn2 }, then { cls }
+    const AttnArgs* attn;        // device array: per layer
+    int n_layers, n_heads, with_cls;
+    unsigned* bar;               // grid barrier counter, zero at kernel start (k_embed resets it)
+    int* err;
+    unsigned long long* trace;   // FLM_ABLATE builds: [workgroup][phase (<= 15)][8] s_memtime stamps of the first phases
+};
+
+// the argument tables are written by the host before the launch; every workgroup reads the same entry.  Each dword
+// goes through readfirstlane so that the compiler knows it is wave-uniform (SGPRs): a buffer descriptor built from
+// a value it believes divergent would be wrapped in a waterfall loop.
+template <class A> __device__ __forceinline__ A kload(const A* p) {
+    static_assert(sizeof(A) % 4 == 0, "dword-sized argument blocks");
+    constexpr int N = sizeof(A) / 4;
+    union { A a; unsigned u[N]; } r;
+    const unsigned* s = reinterpret_cast<const unsigned*>(p);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.u[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)s[i]);
+    return r.a;
+}
+
+constexpr int kActWaves = 4;     // activation waves
+constexpr int kNormRounds = 2;   // rmsnorm phases: n <= 2 * 4096 (host falls back to the per-phase kernels otherwise)
+
+// Grid barrier.  All global data that crosses workgroups is written with st_agent (write-through), so "release" is
+// just: each wave has waited for its own stores (vmcnt) BEFORE it queued the next phase's weight loads (token_phase
+// does that; waiting here would wait for the prefetch too).
+// Measured on MI355X, 256 workgroups (tools/ubench/barrier.hip): one atomic counter 3.7 us; 16 group counters + root
+// 2.5 us; flags packed in 1 KiB 3.2 us (write-through stores to a shared line serialise); ONE 64-BYTE LINE PER
+// WORKGROUP, polled by one lane each: 1.4 us -- less than a kernel boundary.  So: workgroup i publishes
+// flag[i] = epoch (one write-through store to its own line); lane j of the first waves polls flag[j] coherently
+// until it reaches the epoch.  No read-modify-write, no shared line.
+// t.bar: [grid] flags 64 bytes apart, zeroed by k_embed at the start of the token.
+constexpr int kFlagStride = 16;      // dwords
+__device__ __forceinline__ void grid_barrier(const TokenArgs& t, unsigned& epoch) {
+    __syncthreads();
+    epoch += 1;
+    const unsigned nwg = gridDim.x;
+    if (threadIdx.x == 0) __hip_atomic_store(t.bar + blockIdx.x * kFlagStride, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((threadIdx.x & ~63u) < nwg) {                                     // the waves that own at least one flag
+        const bool mine = threadIdx.x < nwg;
+        unsigned spins = 0;
+        while (true) {
+            const unsigned f = mine ? __hip_atomic_load(t.bar + threadIdx.x * kFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+            if (__all(f >= epoch)) break;
+            // a workgroup that never arrives (not resident) must not hang the GPU: give up after ~1 s, flag it, and let
+            // every later barrier of this token fall through at once
+            if ((++spins & 255u) == 0 && (spins > (1u << 20) || __hip_atomic_load(t.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                __hip_atomic_store(t.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// activation prologue of k_token: x (complete in global memory since the barrier) -> xq / xs in LDS
+template <int QT, int PRO, int EPI>
+__device__ __forceinline__ void mega_prologue(const GemvArgs& a, char* lds, GemvCtx<QT, EPI>& g) {
+    using T = QTraits<QT>;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const int n = a.n, tid = threadIdx.x, n4 = n / 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const GemvLds L = gemv_lds_layout(n, T::kEsz, true, a.rows_per_pass, 64 >> a.cb_shift, false);   // fixed offsets only
+    char*  xq = lds;
+    float* xs = reinterpret_cast<float*>(lds + L.off_xs);
+    float* red = reinterpret_cast<float*>(lds + L.off_red);
+    float* scratch = reinterpret_cast<float*>(lds + L.off_scr);
+    constexpr int kXChunk = 12;                                               // float4 loads per lane and chunk (256 lanes: 48 KiB)
+    const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(PRO == PRO_RMSNORM_QUANT ? a.norm_w : a.x), 0, n * 4, 0x00020000);
+    float4 nw[kNormRounds];
+    auto load_nw = [&]() {
+        if constexpr (PRO == PRO_RMSNORM_QUANT) {
+#pragma unroll
+            for (int i = 0; i < kNormRounds; ++i) {
+                const v4f u = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rn, (tid * 4 + i * kGemvBlock * 4) * 4, 0, 0));
+                nw[i] = make_float4(u.x, u.y, u.z, u.w);
+            }
+        }
+    };
+    if (wave < kActWaves) {
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, n * 4, 0x00020000);
+        for (int base = 0; base < n; base += kXChunk * kActWaves * 64 * 4) {
+            v4f v[kXChunk];
+#pragma unroll
+            for (int j = 0; j < kXChunk; ++j) v[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rx, (base + j * kActWaves * 64 * 4 + tid * 4) * 4, 0, kAuxCoherent));
+            if (base == 0) load_nw();
+#pragma unroll
+            for (int j = 0; j < kXChunk; ++j) {
+                const int e = base + j * kActWaves * 64 * 4 + tid * 4;
+                if (e < n) {
+                    if constexpr (PRO == PRO_RMSNORM_QUANT) { const int k = e >> 2; scratch[k] = v[j].x; scratch[n4 + k] = v[j].y; scratch[2 * n4 + k] = v[j].z; scratch[3 * n4 + k] = v[j].w; }
+                    else *reinterpret_cast<float4*>(scratch + e) = make_float4(v[j].x, v[j].y, v[j].z, v[j].w);
+                }
+            }
+            if (base == 0) g.issue(a.ablate);                                  // the postponed weight prefetch: behind the activation in the return order
+        }
+    } else load_nw();
+    __syncthreads();
+    float r = 1.0f;
+    if constexpr (PRO == PRO_RMSNORM_QUANT) {
+        if (tid < 4 && !(a.ablate & 2)) red[8 + tid] = sq_chain(scratch + tid * n4, n4);
+        __syncthreads();
+        const float ss = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, red[8]), red[9]), red[10]), red[11]);
+        r = rms_scale(ss, n);
+    }
+    const int rounds = (n + kGemvBlock * 4 - 1) / (kGemvBlock * 4);
+    for (int i = 0; i < rounds; ++i) {
+        const int e = tid * 4 + i * kGemvBlock * 4;
+        const bool act = e < n;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (act) {
+            if constexpr (PRO == PRO_RMSNORM_QUANT) { const int k = e >> 2; v = make_float4(scratch[k], scratch[n4 + k], scratch[2 * n4 + k], scratch[3 * n4 + k]); }
+            else v = *reinterpret_cast<const float4*>(scratch + e);
+        }
+        if constexpr (PRO == PRO_RMSNORM_QUANT) {
+            const float4 w = i == 0 ? nw[0] : nw[kNormRounds - 1];
+            // multiply_avx256 (x86_simd.cpp:1360-1372): (x*w)*r
+            v.x = __fmul_rn(__fmul_rn(v.x, w.x), r); v.y = __fmul_rn(__fmul_rn(v.y, w.y), r);
+            v.z = __fmul_rn(__fmul_rn(v.z, w.z), r); v.w = __fmul_rn(__fmul_rn(v.w, w.w), r);
+        }
+        // group max over the 16 lanes that share this 64-element group (order-free, exact)
+        const float mx = row16_max(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        const float sc = __fdiv_rn(mx, T::kF);           // scale = max|x| / F
+        if (act) {
+            const int q0 = quant_elem(v.x, sc), q1 = quant_elem(v.y, sc), q2 = quant_elem(v.z, sc), q3 = quant_elem(v.w, sc);
+            if constexpr (QT == QT_INT8) {
+                *reinterpret_cast<uint32_t*>(xq + e) = (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
+            } else {
+                uint2 pk;
+                pk.x = (uint32_t)(q0 & 0xffff) | ((uint32_t)(q1 & 0xffff) << 16);
+                pk.y = (uint32_t)(q2 & 0xffff) | ((uint32_t)(q3 & 0xffff) << 16);
+                *reinterpret_cast<uint2*>(xq + (size_t)e * 2) = pk;
+            }
+            if ((tid & 15) == 0) xs[e / kGroup] = sc;
+        }
+    }
+    __syncthreads();
+}
+
+// One GEMV phase of k_token: [release my stores] -> prefetch the phase's first weights -> grid barrier ->
+// activation prologue -> GEMV.  ATTN_O runs the attention heads between two barriers first.
+// Deliberately NOT inlined: one register allocation per phase keeps the prefetched weight sets in
+// registers (inlined into one body, the allocator spills them across the neighbouring phases).
+struct TokenState { unsigned epoch; int stored; int phase; };
+
+template <int QT, int PRO, int EPI, bool ATTN>
+__device__ __attribute__((noinline)) void token_phase(const TokenArgs& t, const GemvArgs* ap, const AttnArgs* aap, char* lds, TokenState& ts, const int barrier) {
+    const u32 wg = blockIdx.x, nwg = gridDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    auto nostamp = [](int) {};
+    GemvCtx<QT, EPI> g;
+    auto stamp = [&](int k) { if (kAblate && t.trace && threadIdx.x == 0 && ts.phase < 16) t.trace[((size_t)blockIdx.x * 16 + ts.phase) * 8 + k] = __builtin_amdgcn_s_memtime(); };
+    stamp(0);
+    const GemvArgs a = kload(ap);
+    unsigned epoch = ts.epoch;
+    // the phase's first weight loads; activation waves wait until they have asked for the activation
+    auto prefetch = [&]() { g.init(a, wg, nwg); if (wave >= kActWaves) g.issue(a.ablate); };
+    // my stores of the previous phase must have completed before the prefetch is queued behind them (one vmcnt counter)
+    if (ts.stored) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if constexpr (ATTN) {
+        const bool attn_wg = (int)wg < t.n_heads;                               // this workgroup runs attention heads next
+        if (!attn_wg) prefetch();                                               // (a head's K/V loads must not queue behind weight loads)
+        grid_barrier(t, epoch);
+        if (attn_wg) {   // one head per workgroup
+            const AttnArgs aa = kload(aap);
+            for (int h = wg; h < t.n_heads; h += nwg) { attn_head(aa, h, lds); __syncthreads(); }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            prefetch();
+        }
+        stamp(1);
+        grid_barrier(t, epoch);
+    } else {
+        prefetch();
+        stamp(1);
+        if (barrier) grid_barrier(t, epoch);
+    }
+    stamp(2);
+    mega_prologue<QT, PRO, EPI>(a, lds, g);
+    stamp(3);
+    g.run(a, lds, nostamp);
+    stamp(4);
+    ts.epoch = epoch; ts.stored = g.stored ? 1 : 0; ts.phase += 1;
+}
+
+template <int QT>
+__global__ void __launch_bounds__(kGemvBlock, 4) k_token(const TokenArgs t) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    TokenState ts{0u, 0, 0};
+    for (int l = 0; l < t.n_layers; ++l) {
+        const GemvArgs* ga = t.gemv + 4 * l;
+        token_phase<QT, PRO_RMSNORM_QUANT, EPI_ROPE_KV, false>(t, ga + 0, nullptr, lds, ts, l > 0);   // layer 0: the residual stream comes from k_embed
+        token_phase<QT, PRO_QUANT, EPI_RESIDUAL, true>(t, ga + 1, t.attn + l, lds, ts, 1);            // attention, ATTN_O + residual
+        token_phase<QT, PRO_RMSNORM_QUANT, EPI_SWIGLU, false>(t, ga + 2, nullptr, lds, ts, 1);        // FFN13 + SwiGLU
+        token_phase<QT, PRO_QUANT, EPI_RESIDUAL, false>(t, ga + 3, nullptr, lds, ts, 1);              // FFN2 + residual
+    }
+    if (t.with_cls) token_phase<QT, PRO_RMSNORM_QUANT, EPI_STORE, false>(t, t.gemv + 4 * t.n_layers, nullptr, lds, ts, 1);   // final norm + classifier
+}
 
 // ------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------
 // x1 = embedding[token] (copy or dequantize; transformer.cpp:115-122)
-__global__ void k_embed(float* x, const void* emb, const float* emb_s, int emb_qt, int dim, const int* tok_ptr) {
+__global__ void k_embed(float* x, const void* emb, const float* emb_s, int emb_qt, int dim, const int* tok_ptr, unsigned* bar) {
     const int tok = *tok_ptr;
+    if (bar && blockIdx.x == 0) { bar[threadIdx.x * 16] = 0; bar[(threadIdx.x + blockDim.x) * 16] = 0; }   // grid barrier flags (<= 512 workgroups, 64 B apart) of the k_token that follows
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < dim; e += gridDim.x * blockDim.x) {
         float v;
         if (emb_qt == 0) v = reinterpret_cast<const float*>(emb)[(size_t)tok * dim + e];
