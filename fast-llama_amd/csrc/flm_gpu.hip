@@ -61,6 +61,8 @@ struct flm_ctx {
 
     // options
     int wg_per_cu = 1; int use_graph = 1; int ablate = 0;
+    int use_ring = 0;                                  // option "use_ring": LDS weight ring (direct-to-LDS loads) in the rmsnorm GEMVs; measured neutral on MI355X (the
+                                                       // extra 64 KiB/CU in flight shorten the stream by ~1.3 us and lengthen the prologue by as much), so off
     int use_mega = 0;                                  // option "use_mega": run single-GPU tokens as ONE persistent kernel (k_token); opt-in until it beats the per-phase kernels
     GemvArgs* mega_gemv = nullptr; AttnArgs* mega_attn = nullptr; unsigned* mega_bar = nullptr; int* mega_err = nullptr;
     size_t mega_lds = 0; int mega_ok = -1;              // -1 not built yet, 0 shape not supported by k_token, 1 ready
@@ -99,8 +101,8 @@ void split_even(int total, int parts, int idx, int* begin, int* count) {
 //              lanes; chosen so that the passes divide evenly over `wgs` workgroups (CU-level balance is
 //              what matters for an HBM-bound kernel)
 //   wc_shift : the WC x WR wave grid with the fewest blocks on the busiest wave
-struct GemvPlan { int Rm, cb_shift, wc_shift, grid; size_t lds; };
-GemvPlan gemv_plan(int n, int esz, int rows, bool two, bool pairs, bool norm, int wgs) {
+struct GemvPlan { int Rm, cb_shift, wc_shift, grid, ring, nbuf; size_t lds; };
+GemvPlan gemv_plan(int n, int esz, int rows, bool two, bool pairs, bool norm, int wgs, bool use_ring) {
     GemvPlan P{};
     const int nchunks = n * esz / 16;
     int cbs = 0; while (cbs < 6 && (nchunks % (2 << cbs)) == 0) ++cbs;       // nchunks % 4 == 0 always
@@ -123,7 +125,15 @@ GemvPlan gemv_plan(int n, int esz, int rows, bool two, bool pairs, bool norm, in
         if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best = wcs; }   // ties: more wave columns, fewer activation reloads
     }
     P.Rm = Rm; P.cb_shift = cbs; P.wc_shift = best; P.grid = npass < wgs ? npass : wgs; if (P.grid < 1) P.grid = 1;
-    P.lds = (size_t)gemv_lds_layout(n, esz, norm, Rm, RB, two).total;
+    // the LDS weight ring lives in the top kRingBytes: use it when the launch's own LDS fits below it (with one strip
+    // buffer if every workgroup has a single pass) and the stream is long enough to matter
+    P.ring = 0; P.nbuf = 2;
+    const long blocks_per_wave = best_cost;
+    if (use_ring && blocks_per_wave > 2 * kStepBlk) {
+        if (gemv_lds_layout(n, esz, norm, Rm, RB, two, 2).total <= kRingOff) P.ring = 1;
+        else if (npass <= wgs && gemv_lds_layout(n, esz, norm, Rm, RB, two, 1).total <= kRingOff) { P.ring = 1; P.nbuf = 1; }
+    }
+    P.lds = P.ring ? (size_t)kLdsBytes : (size_t)gemv_lds_layout(n, esz, norm, Rm, RB, two, P.nbuf).total;
     return P;
 }
 
@@ -133,9 +143,10 @@ int plan_gemv(flm_ctx* c, GemvArgs& a, int wgs, GemvPlan& P) {
     constexpr bool TWO = EPI == EPI_SWIGLU, PAIRS = EPI == EPI_ROPE_KV;
     const int rows = a.items * (PAIRS ? 2 : 1);
     if ((double)rows * a.n * QTraits<QT>::kEsz * (TWO ? 2 : 1) >= 2147483648.0) return fail(c, FLM_ERR_UNSUPPORTED, "gemv: matrix of 2 GiB or more");
-    P = gemv_plan(a.n, QTraits<QT>::kEsz, rows, TWO, PAIRS, true, wgs);
+    // the ring pays only where a long prologue (the rmsnorm chain) gives it time to arrive
+    P = gemv_plan(a.n, QTraits<QT>::kEsz, rows, TWO, PAIRS, true, wgs, PRO == PRO_RMSNORM_QUANT && (c ? c->use_ring != 0 : true));
     if (P.lds > 160 * 1024) return fail(c, FLM_ERR_UNSUPPORTED, "gemv: activation vector does not fit LDS");
-    a.rows_per_pass = P.Rm; a.cb_shift = P.cb_shift; a.wc_shift = P.wc_shift;
+    a.rows_per_pass = P.Rm; a.cb_shift = P.cb_shift; a.wc_shift = P.wc_shift; a.ring = P.ring; a.nbuf = P.nbuf;
     return FLM_OK;
 }
 template <int QT, int PRO, int EPI>
@@ -567,7 +578,7 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
     if (d.n_kv_heads != d.n_heads) return fail(nullptr, FLM_ERR_UNSUPPORTED, "n_kv_heads != n_heads: the reference's grouped-query path is broken (transformer.cpp:449); not reproduced");
     if (d.dim % d.n_heads || d.dim % kGroup || d.hidden_dim % kGroup) return fail(nullptr, FLM_ERR_INVALID, "dim/hidden_dim must be multiples of 64 and dim of n_heads");
     const int hs = d.dim / d.n_heads;
-    if (hs % 8 || hs < 32) return fail(nullptr, FLM_ERR_UNSUPPORTED, "head_size must be a multiple of 8 and >= 32 (the reference's 8-lane dot_product path, x86_simd.cpp:1677-1699)");
+    if (hs % 8 || hs < 32 || hs > 256) return fail(nullptr, FLM_ERR_UNSUPPORTED, "head_size must be a multiple of 8 in [32, 256] (the reference's 8-lane dot_product path, x86_simd.cpp:1677-1699; 256: the attention tile staging)");
     if (world < 1 || rank < 0 || rank >= world) return fail(nullptr, FLM_ERR_INVALID, "rank/world");
     if (world > 1 && !comm_id) return fail(nullptr, FLM_ERR_INVALID, "comm_id required when world > 1");
 
@@ -649,6 +660,7 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (k == "use_graph") c->use_graph = value;
     else if (k == "ablate") { c->ablate = value; c->mega_ok = -1; }
     else if (k == "use_mega") c->use_mega = value;
+    else if (k == "use_ring") { c->use_ring = value; c->mega_ok = -1; }
     else if (k == "trace") {        // value = kernel class to trace (KC_*), -1 off; meaningful in FLM_ABLATE builds only
         c->trace_class = value;
         if (!c->trace) { HIPC(c, hipMalloc((void**)&c->trace, 4096 * 8 * 8)); }
@@ -942,7 +954,7 @@ int flm_op_softmax(float* x, int n) {
 
 int flm_op_attention(float* out, float* kc, float* vc, const float* q, const float* k, const float* v,
                      int n_heads, int hs, int max_seq, int pos) {
-    if (!out || !kc || !vc || !q || !k || !v || n_heads < 1 || hs < 32 || hs % 8 || pos < 0 || pos >= max_seq) return FLM_ERR_INVALID;
+    if (!out || !kc || !vc || !q || !k || !v || n_heads < 1 || hs < 32 || hs > 256 || hs % 8 || pos < 0 || pos >= max_seq) return FLM_ERR_INVALID;
     const size_t nd = (size_t)n_heads * hs, nc = (size_t)n_heads * max_seq * hs, h2 = hs / 2;
     std::vector<float> cs, sn; build_rope_table(hs, pos + 1, cs, sn);
     DevBuf dq, dk, dv, dkc, dvc, dout, dc, dsn, dpos;

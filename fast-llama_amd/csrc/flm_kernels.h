@@ -195,6 +195,8 @@ struct GemvArgs {
     int rows_per_pass;                          // Rm: rows (of each matrix) one workgroup reduces per pass; multiple of RB, <= 64
     int cb_shift;                               // log2(CB): a 1 KiB wave load covers RB = (64 >> cb_shift) rows x CB 16-byte chunks
     int wc_shift;                               // log2(WC): the 16 waves form a WC x WR grid over (column blocks x row blocks)
+    int ring;                                   // 1: a third step of weight blocks is kept in flight in LDS (direct-to-LDS loads), the top kRingBytes of LDS
+    int nbuf;                                   // strip buffers: 2, or 1 when each workgroup has a single pass and LDS is short
     // prologue inputs
     const float* x;                             // fp32 activation [n]          (QUANT / RMSNORM_QUANT)
     const float* norm_w;                        // rmsnorm weight [n]           (RMSNORM_QUANT)
@@ -227,7 +229,7 @@ struct GemvLds {
     int buf_bytes;                    // one strip buffer
     int total;                        // bytes
 };
-__host__ __device__ inline GemvLds gemv_lds_layout(int n, int esz, bool norm, int Rm, int RB, bool two) {
+__host__ __device__ inline GemvLds gemv_lds_layout(int n, int esz, bool norm, int Rm, int RB, bool two, int nbuf = 2) {
     GemvLds L;
     const int sn = n / kGroup, ng = two ? 2 * sn : sn;
     L.off_xs = n * esz;
@@ -236,11 +238,18 @@ __host__ __device__ inline GemvLds gemv_lds_layout(int n, int esz, bool norm, in
     int g16 = (ng * 8 + 15) / 16; if ((g16 & 1) == 0) ++g16;
     L.gstride = g16 * 16;
     L.buf_bytes = (Rm + RB) * L.gstride;                                       // + RB dummy strips that absorb the writes of padding blocks
-    int scratch = 2 * L.buf_bytes + 64;                                        // + 64: the chain's read-ahead past the last strip
-    if (norm && n * 4 + 256 > scratch) scratch = n * 4 + 256;                   // +256: the rmsnorm ring reads up to 32 floats past the last strip
+    int scratch = nbuf * L.buf_bytes + 64;                                     // + 64: the chain's read-ahead past the last strip
+    if (norm && n * 4 + 512 > scratch) scratch = n * 4 + 512;                   // 4 strips of n/4 + 8 floats (+8: the 4 chain lanes read different banks) + the ring's read-ahead past the last strip
     L.total = L.off_scr + scratch;
     return L;
 }
+// The LDS weight ring: one step (kStepBlk blocks) per wave, a block = 1 KiB of weights + 256 B of scales, written by
+// direct-to-LDS buffer loads.  It always sits in the TOP kRingBytes of the CU's 160 KiB, whatever the phase's own
+// layout below it, so that k_token can prefetch the next phase's blocks while slower waves still use this phase's strips.
+constexpr int kLdsBytes = 160 * 1024;
+constexpr int kRingSlot = 1024 + 256;
+constexpr int kRingBytes = kWavesPerBlock * kStepBlk * kRingSlot;              // 80 KiB
+constexpr int kRingOff = kLdsBytes - kRingBytes;
 
 // One of the 4 strided lanes of simd::square_sum -> square_sum_avx128 (x86_simd.cpp:942-960; the AVX2 branch is
 // dead, :1093): p[0..n4) = x[c], x[c+4], x[c+8], ... walked as a strictly sequential FMA chain.
@@ -248,26 +257,33 @@ __device__ __forceinline__ float sq_chain(const float* p, int n4) {
     float l = 0.f;
     int k = 0;
 #define FLM_SQ4(v) l = __fmaf_rn(v.x, v.x, l); l = __fmaf_rn(v.y, v.y, l); l = __fmaf_rn(v.z, v.z, l); l = __fmaf_rn(v.w, v.w, l);
-#define FLM_STEP(q, off) FLM_SQ4(q) q = *reinterpret_cast<const float4*>(pp + (off)); __builtin_amdgcn_sched_barrier(0);
+#define FLM_RD4(a, b, c, d, base) a = *reinterpret_cast<const float4*>(pp + (base)); b = *reinterpret_cast<const float4*>(pp + (base) + 4); c = *reinterpret_cast<const float4*>(pp + (base) + 8); d = *reinterpret_cast<const float4*>(pp + (base) + 12);
     if (n4 >= 32) {
-        // A lone wave issues roughly one instruction every ~5 cycles, whatever its kind, so the
-        // loop body is nothing but the 32 dependent FMAs and 8 LDS reads with immediate offsets:
-        // a ring of 8 float4 registers, every read issued 28 FMAs before its first use (the
-        // sched_barriers pin that order).  Reads run up to 32 floats past a lane's strip: the
-        // staging area is sized for that (gemv_lds_layout) and those values are never consumed.
+        // A lone wave issues roughly one instruction every ~5 cycles, whatever its kind, so the loop body must be
+        // little more than the dependent FMAs: two rings of 4 float4 registers; while the 16 FMAs of one ring run,
+        // the 4 LDS reads of the other are in flight, and ONE explicit s_waitcnt per 16 FMAs (instead of the
+        // compiler's one per read) covers them.  Reads run up to 32 floats past a lane's strip: the staging area
+        // is sized for that (gemv_lds_layout) and those values are never consumed.
         const float* pp = p;
-        float4 q0 = *reinterpret_cast<const float4*>(pp), q1 = *reinterpret_cast<const float4*>(pp + 4), q2 = *reinterpret_cast<const float4*>(pp + 8), q3 = *reinterpret_cast<const float4*>(pp + 12);
-        float4 q4 = *reinterpret_cast<const float4*>(pp + 16), q5 = *reinterpret_cast<const float4*>(pp + 20), q6 = *reinterpret_cast<const float4*>(pp + 24), q7 = *reinterpret_cast<const float4*>(pp + 28);
-        __builtin_amdgcn_sched_barrier(0);
+        float4 a0, a1, a2, a3, b0, b1, b2, b3;
+        FLM_RD4(a0, a1, a2, a3, 0)
+#pragma unroll 2
         for (; k + 32 <= n4; k += 32, pp += 32) {
-            FLM_STEP(q0, 32) FLM_STEP(q1, 36) FLM_STEP(q2, 40) FLM_STEP(q3, 44)
-            FLM_STEP(q4, 48) FLM_STEP(q5, 52) FLM_STEP(q6, 56) FLM_STEP(q7, 60)
+            FLM_RD4(b0, b1, b2, b3, 16)
+            __builtin_amdgcn_s_waitcnt(0xC47F);        // lgkmcnt <= 4: ring A has landed (vmcnt / expcnt untouched)
+            __builtin_amdgcn_sched_barrier(0);
+            FLM_SQ4(a0) FLM_SQ4(a1) FLM_SQ4(a2) FLM_SQ4(a3)
+            __builtin_amdgcn_sched_barrier(0);
+            FLM_RD4(a0, a1, a2, a3, 32)
+            __builtin_amdgcn_s_waitcnt(0xC47F);        // ring B has landed
+            __builtin_amdgcn_sched_barrier(0);
+            FLM_SQ4(b0) FLM_SQ4(b1) FLM_SQ4(b2) FLM_SQ4(b3)
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // the ring now holds p[k .. k+31]
-        if (k + 4 <= n4) { FLM_SQ4(q0) k += 4; } if (k + 4 <= n4) { FLM_SQ4(q1) k += 4; } if (k + 4 <= n4) { FLM_SQ4(q2) k += 4; } if (k + 4 <= n4) { FLM_SQ4(q3) k += 4; }
-        if (k + 4 <= n4) { FLM_SQ4(q4) k += 4; } if (k + 4 <= n4) { FLM_SQ4(q5) k += 4; } if (k + 4 <= n4) { FLM_SQ4(q6) k += 4; }
+        // ring A holds p[k .. k+15]
+        if (k + 4 <= n4) { FLM_SQ4(a0) k += 4; } if (k + 4 <= n4) { FLM_SQ4(a1) k += 4; } if (k + 4 <= n4) { FLM_SQ4(a2) k += 4; } if (k + 4 <= n4) { FLM_SQ4(a3) k += 4; }
     }
-#undef FLM_STEP
+#undef FLM_RD4
 #undef FLM_SQ4
     for (; k < n4; ++k) l = __fmaf_rn(p[k], p[k], l);
     return l;
@@ -304,8 +320,13 @@ __device__ __forceinline__ void gemv_preload(const GemvArgs& a, float4 (&xv)[XR 
     }
 }
 
-template <int QT, int PRO, int XR>
-__device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, float4 (&xv)[XR > 0 ? XR : 1], float4 (&wv)[XR > 0 ? XR : 1]) {
+#ifdef FLM_TRACE_PRO
+#define FLM_PRO_STAMP(k) if (kAblate && a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define FLM_PRO_STAMP(k)
+#endif
+template <int QT, int PRO, int XR, class AfterStage>
+__device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, float4 (&xv)[XR > 0 ? XR : 1], float4 (&wv)[XR > 0 ? XR : 1], AfterStage&& after_stage) {
     using T = QTraits<QT>;
     const int n = a.n;
     const int tid = threadIdx.x;
@@ -327,14 +348,19 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
         const int rounds = (n + kGemvBlock * 4 - 1) / (kGemvBlock * 4);
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         float r = 1.0f;
+        if constexpr (PRO == PRO_QUANT) {
+            // no staging here: the hook (the weight prefetch) runs as soon as this thread's activation registers have landed
+            if constexpr (XR > 0) { asm volatile("" :: "v"(xv[XR - 1].w)); }
+            after_stage();
+        }
         if constexpr (PRO == PRO_RMSNORM_QUANT) {
             // simd::square_sum -> square_sum_avx128 (x86_simd.cpp:942-960; the AVX2 branch is dead, :1093):
             // lane c of 4 accumulates x[c], x[c+4], x[c+8]... by FMA, then res = ((0+l0)+l1)+l2)+l3.
             // Stage x transposed ([4][n/4]) so that 4 threads can each walk one strided lane sequentially.
-            const int n4 = n / 4;
+            const int n4 = n / 4, ns = n4 + 8;                  // strip stride: +8 floats so that the 4 chain lanes' 16-byte reads hit different banks
             auto stage = [&](int i, const float4& v) {
                 const int k = tid + i * kGemvBlock;
-                if (k < n4) { scratch[k] = v.x; scratch[n4 + k] = v.y; scratch[2 * n4 + k] = v.z; scratch[3 * n4 + k] = v.w; }
+                if (k < n4) { scratch[k] = v.x; scratch[ns + k] = v.y; scratch[2 * ns + k] = v.z; scratch[3 * ns + k] = v.w; }
             };
 #pragma unroll
             for (int i = 0; i < XR; ++i) { if (i < rounds) stage(i, xv[i]); }
@@ -343,11 +369,19 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
                 if (e < n) stage(i, *reinterpret_cast<const float4*>(a.x + e));
             }
             __syncthreads();
-            if (tid < 4 && !(a.ablate & 2)) red[8 + tid] = sq_chain(scratch + tid * n4, n4);
+            FLM_PRO_STAMP(3)
+            // the hook issues the weight prefetch.  Wave 0 goes first (the others give it ~128 cycles): its 16 loads
+            // enter an empty memory pipeline at once and it is free for the chain; queued behind the other 15 waves'
+            // 240 loads it would stall for ~1 us before (or after) the chain.
+            if (tid >= kWave) __builtin_amdgcn_s_sleep(2);
+            after_stage();
+            if (tid < 4 && !(a.ablate & 2)) red[8 + tid] = sq_chain(scratch + tid * ns, n4);
+            FLM_PRO_STAMP(4)
             __syncthreads();
             const float ss = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, red[8]), red[9]), red[10]), red[11]);
             r = rms_scale(ss, n);
             __syncthreads();                                   // scratch is reused by the GEMV waves below
+            FLM_PRO_STAMP(5)
         }
         // one round: (normalise,) group max over 16 lanes, quantize, pack into LDS
         auto round = [&](int i, float4 v, float4 w) {
@@ -446,6 +480,7 @@ struct GemvCtx {
     u32 lane_woff, lane_soff, lane_xoff, lane_sxoff, lane_goff;               // per lane
     bool leader;                                                               // per lane
     u32 dW, dS, dT, dummy_st, wg, nwg;
+    u32 ring, ring_off, nbuf;                                                  // LDS weight ring of this wave (0: none)
     __amdgpu_buffer_rsrc_t rW, rS;
     Set setA, setB;
     LCur lc;
@@ -472,7 +507,8 @@ struct GemvCtx {
         nrw = wr < RBP ? (RBP - wr + WR - 1) / WR : 0;                         // row blocks of this wave per pass
         ncw = (wc < NBCV && nrw) ? (NBCV - wc + WC - 1) >> wcs : 0;            // column blocks of this wave
         const u32 rb = lane >> cbs, cb = lane & (CB - 1);
-        const GemvLds L = gemv_lds_layout(n, T::kEsz, true, Rm, RB, TWO);
+        nbuf = a.nbuf > 0 ? a.nbuf : 2; ring = a.ring; ring_off = kRingOff + wave * (kStepBlk * kRingSlot);
+        const GemvLds L = gemv_lds_layout(n, T::kEsz, true, Rm, RB, TWO, nbuf);
         gstride = L.gstride; buf_bytes = L.buf_bytes; off_xs = L.off_xs; off_scr = L.off_scr;
         // lane-constant parts of every address (the per-block parts are wave-uniform scalars)
         lane_woff = rb * rowbytes + cb * 16;                                   // weights, bytes from the block base
@@ -535,17 +571,35 @@ struct GemvCtx {
         }
         if (c.ci >= ncw) lcur_pass(c, c.pass + nwg);                           // the pass ended inside this step
     }
-    // the first two steps of weight loads: independent of the activation, so they are issued before it exists
-    __device__ __forceinline__ void issue(int ablate) {
+    // one step of blocks straight into this wave's LDS ring slots (buffer_load ... lds: no registers held while in flight)
+    __device__ __forceinline__ void load_step_lds(LCur& c, char* lds, int ablate) const {
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            const bool live = c.ci < ncw && !(kAblate && (ablate & 4));
+            const u32 wo = live ? c.wo : kOOB, so = live ? c.so : kOOB;
+            char* slot = lds + ring_off + j * kRingSlot;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)slot, 16, (int)lane_woff, (int)wo, 0, 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, (__attribute__((address_space(3))) void*)(slot + 1024), 4, (int)lane_soff, (int)so, 0, 2);
+            c.wo += dW; c.so += dS;
+            if (++c.ri >= nrw) { ++c.ci; if (c.ci < ncw) lcur_col(c); }
+        }
+        if (c.ci >= ncw) lcur_pass(c, c.pass + nwg);
+    }
+    // the first steps of weight loads: independent of the activation, so they are issued before it exists
+    __device__ __forceinline__ void issue(int ablate, char* lds) {
         lcur_pass(lc, wg);
         load_step(setA, lc, ablate);
         load_step(setB, lc, ablate);
     }
+    // The third step goes to the LDS ring.  It is issued a little later, from inside the activation prologue (after
+    // its staging barrier): a CU's memory pipeline accepts only so many loads at once, and 24 loads per wave queued
+    // up front delayed the prologue itself (measured) -- the ring still has the whole rmsnorm chain to arrive.
+    __device__ __forceinline__ void issue_ring(int ablate, char* lds) { if (ring) load_step_lds(lc, lds, ablate); }
 
     // reduce one step: dots for all its blocks first (registers), then ONE leader-only region parks them.
     // Returns true when the pass ended inside this step (the cursor then stands on the workgroup's next pass).
     v4i xa; float sx; u32 cur_xo;                                              // activation chunk + scale of the current column block
-    __device__ __forceinline__ bool reduce_step(Set& S, RCur& c, char* lds, char* strips, int ablate) {
+    __device__ __forceinline__ bool reduce_step(const Set& S, RCur& c, char* lds, char* strips, int ablate) {
         const char* xq = lds; const char* xs = lds + off_xs;
         int d[H]; float p[H]; u32 st[H];
 #pragma unroll
@@ -658,20 +712,60 @@ struct GemvCtx {
         rcur_pass(rc, wg);
         u32 it = 0;                                                            // pass counter of this workgroup
         bool tr3 = false;
+        auto step_tail = [&](bool last, u32 pass, char* strips) {
+#ifndef FLM_TRACE_PRO
+            if (it == 0 && !tr3) { tr3 = true; stamp(3); }
+#endif
+            if (last) {
+#ifndef FLM_TRACE_PRO
+                if (it == 0) stamp(4);
+#endif
+                finish_pass(a, pass, it, strips, pos);
+#ifndef FLM_TRACE_PRO
+                if (it == 0) stamp(5);
+#endif
+                ++it;
+            }
+        };
         auto do_step = [&](Set& S) {
-            char* strips = lds + off_scr + (it & 1) * buf_bytes;               // double buffered across passes
+            char* strips = lds + off_scr + (nbuf > 1 ? (it & 1) * buf_bytes : 0u);   // double buffered across passes
             const u32 pass = rc.pass;
             const bool last = reduce_step(S, rc, lds, strips, a.ablate);
-            load_step(S, lc, a.ablate);                                        // refill this set: two steps ahead
-            if (it == 0 && !tr3) { tr3 = true; stamp(3); }
-            if (last) { if (it == 0) stamp(4); finish_pass(a, pass, it, strips, pos); if (it == 0) stamp(5); ++it; }
+            load_step(S, lc, a.ablate);                                        // refill this set: a full cycle ahead
+            step_tail(last, pass, strips);
+        };
+        auto do_step_lds = [&]() {
+            char* strips = lds + off_scr + (nbuf > 1 ? (it & 1) * buf_bytes : 0u);
+            const u32 pass = rc.pass;
+            // The compiler does not know that the direct-to-LDS loads feed the ds_reads below, so the wait is spelled
+            // out: the ring step was issued before the refills of the two register sets (2 x 8 loads); loads retire
+            // in issue order, so "at most 16 outstanding" means the ring has landed.  ("memory": nothing moves across.)
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            Set S;
+#pragma unroll
+            for (int j = 0; j < H; ++j) {
+                const char* slot = lds + ring_off + j * kRingSlot;
+                S.w[j] = *reinterpret_cast<const v4i*>(slot + lane * 16);
+                S.sw[j] = *reinterpret_cast<const float*>(slot + 1024 + lane * 4);
+            }
+            const bool last = reduce_step(S, rc, lds, strips, a.ablate);
+            asm volatile("" ::: "memory");                                     // the slots have been read (their values were consumed above)
+            load_step_lds(lc, lds, a.ablate);                                  // refill the slots
+            step_tail(last, pass, strips);
         };
         while (true) {
             if (rc.pass >= npass) break;
             do_step(setA);
             if (rc.pass >= npass) break;
             do_step(setB);
+            if (ring) {
+                if (rc.pass >= npass) break;
+                do_step_lds();
+            }
         }
+        // loads of padding / past-the-end blocks may still be in flight towards the ring: they must have landed before
+        // anybody reuses that LDS (the next phase of k_token, or the next kernel's workgroup on this CU)
+        if (ring) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 };
 
@@ -683,15 +777,18 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_gemv(const GemvArgs a) {
     if (kAblate && a.trace && threadIdx.x == 0) rt0 = __builtin_amdgcn_s_memrealtime();
     stamp(0);
     if (a.ablate & 16) return;
-    // 1. the activation (L2-resident) first, 2. then the first two steps of weight blocks, both
-    // BEFORE the prologue: weights do not depend on the activation, and loads return in issue order.
+    // The activation first, and the weight prefetch only once it HAS ARRIVED (the hook runs after the staging barrier /
+    // after the activation registers landed).  Weights do not depend on the activation and were once requested up
+    // front -- but workgroups start ~1 us apart, and the activation loads of the late ones then queued in HBM behind
+    // 32 MB of weight requests of the early ones: the activation came back 2.6 us later (measured), delaying the
+    // whole rmsnorm chain.  Issued after the activation, the first 128 KiB per CU still arrive under the chain.
     float4 xv[XR > 0 ? XR : 1], nv[XR > 0 ? XR : 1];
     gemv_preload<QT, PRO, XR>(a, xv, nv);
     GemvCtx<QT, EPI> g;
     g.init(a, blockIdx.x, gridDim.x);
-    g.issue(a.ablate);
+    if constexpr (PRO == PRO_NONE) g.issue(a.ablate, lds);
     stamp(1);
-    gemv_prologue<QT, PRO, XR>(a, lds, xv, nv);
+    gemv_prologue<QT, PRO, XR>(a, lds, xv, nv, [&]() { g.issue(a.ablate, lds); g.issue_ring(a.ablate, lds); });
     stamp(2);
     if (a.ablate & 32) return;
     g.run(a, lds, stamp);
@@ -707,8 +804,12 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_gemv(const GemvArgs a) {
 //   softmax                         softmax_sisd (tf_operators.cpp:176-186): max, expf, sequential sum, divide
 //   o      = sum_t att[t] V[t]      batch weighted_sum (tf_operators.cpp:325-350): t ascending, FMA,
 //                                   rows t >= 1 with |w| <= 1e-15 skipped
-// Parallelism: phase 1 one position per thread (8 register accumulators), phase 4 one output
-// dimension per thread, sequential over positions -- the chains the reference defines.
+// The chains are the reference's; what is engineered is LATENCY (this kernel sits on the token's critical path):
+// K and V stream through LDS in tiles of 64 positions -- every thread fetches coalesced 16-byte pieces of the NEXT
+// tile while the current one is consumed, so a tile costs compute time, not a memory round trip -- and the first
+// K tile, the first V tile and q are all requested at once when the kernel starts.  Scores: lane = (position,
+// one of the 8 strided accumulators), operands from LDS (row stride hs+8 floats: conflict-free), the 8 partials
+// are added in order with DPP shifts.  PV: one thread per output dimension walks the tile's positions in order.
 // ------------------------------------------------------------------------------------------
 struct AttnArgs {
     const float* q;          // [heads*hs], RoPE already applied
@@ -719,66 +820,97 @@ struct AttnArgs {
     int hs, max_seq;
 };
 
-constexpr int kAttnBlock = 1024;      // 16 waves: 128 positions are scored per sweep (8 lanes per position)
+constexpr int kAttnBlock = 1024;      // 16 waves
+constexpr int kAttnTile = 64;         // positions per LDS tile
+constexpr int kAttnNF = 4;            // 16-byte pieces of a tile per thread: hs <= 256
+__host__ __device__ inline int attn_row_stride(int hs) { return hs + 8; }
+__host__ inline size_t attn_lds_bytes(int max_seq, int hs) { return (size_t)(hs + 32 + ((max_seq + 3) & ~3) + 64 + 2 * kAttnTile * attn_row_stride(hs)) * 4; }
+
 __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* lds) {
-    const int hs = a.hs;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const int hs = a.hs, tid = threadIdx.x;
     const int T = *a.pos_ptr + 1;
+    const int rs = attn_row_stride(hs), f4r = hs >> 2, tile_f4 = kAttnTile * f4r;
     float* qs   = reinterpret_cast<float*>(lds);                 // [hs]
     float* red  = qs + hs;                                       // 32
-    float* part = red + 32;                                      // [16 waves][8 positions][8 lanes] partial dots
-    float* sc   = part + 16 * 64;                                // [T] scores -> probabilities (+32 floats of slack)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* sc   = red + 32;                                      // [T] scores -> probabilities (+ slack for the sum ring's read-ahead)
+    float* tile0 = sc + ((a.max_seq + 3) & ~3) + 64;
+    float* tile1 = tile0 + kAttnTile * rs;
+    const int lane = tid & 63, wave = tid >> 6;
     const float* K = a.kcache + (size_t)h * a.max_seq * hs;
     const float* V = a.vcache + (size_t)h * a.max_seq * hs;
-    // K/V rows of this token were written by other workgroups of the same kernel (k_token): coherent loads (sc0|sc1)
-    // through buffer descriptors, which the compiler is free to batch (an atomic load per element would serialise)
+    // K/V rows of this token may have been written by other workgroups of the same kernel (k_token): coherent loads
+    // (sc0|sc1) through buffer descriptors; positions past T get an out-of-range offset and read as zero
     const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(K), 0, a.max_seq * hs * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V), 0, a.max_seq * hs * 4, 0x00020000);
-    auto ldK = [&](int idx) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rK, idx * 4, 0, kAuxCoherent)); };
-    auto ldV = [&](int idx) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rV, idx * 4, 0, kAuxCoherent)); };
     const float scale = (float)(1.0 / (double)__builtin_sqrtf((float)hs));   // attn_scale, transformer.cpp:418
+    const int nt = (T + kAttnTile - 1) / kAttnTile;
 
-    for (int d = threadIdx.x; d < hs; d += kAttnBlock) qs[d] = ld_agent(a.q + (size_t)h * hs + d);
+    auto load_tile = [&](const __amdgpu_buffer_rsrc_t& r, int tile, v4f (&reg)[kAttnNF]) {
+#pragma unroll
+        for (int j = 0; j < kAttnNF; ++j) {
+            const int f = tid + j * kAttnBlock, row = f / f4r, c4 = f - row * f4r, t = tile * kAttnTile + row;
+            const unsigned off = (f < tile_f4 && t < T) ? (unsigned)(t * hs + c4 * 4) * 4u : 0x80000000u;
+            reg[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, kAuxCoherent));
+        }
+    };
+    auto store_tile = [&](float* buf, const v4f (&reg)[kAttnNF]) {
+#pragma unroll
+        for (int j = 0; j < kAttnNF; ++j) {
+            const int f = tid + j * kAttnBlock, row = f / f4r, c4 = f - row * f4r;
+            if (f < tile_f4) *reinterpret_cast<float4*>(buf + row * rs + c4 * 4) = make_float4(reg[j].x, reg[j].y, reg[j].z, reg[j].w);
+        }
+    };
+
+    v4f kr[kAttnNF], vr[kAttnNF];
+    load_tile(rK, 0, kr);
+    load_tile(rV, 0, vr);
+    for (int d = tid; d < hs; d += kAttnBlock) qs[d] = ld_agent(a.q + (size_t)h * hs + d);
+    store_tile(tile0, kr);
     __syncthreads();
 
-    // ---- scores: lane = (position p = lane/8, strided accumulator k = lane%8) -- the 8 lanes of
-    //      dot_product_avx256; each lane's chain is i ascending, then the 8 partials are added 0..7.
-    const int p = lane >> 3, k = lane & 7;
-    float* wpart = part + wave * 64;
+    // ---- scores: lane = (position p, strided accumulator k) -- the 8 lanes of dot_product_avx256; each lane's
+    //      chain is i ascending, then the 8 partials are added 0..7 (lane k = 0 collects them with DPP row shifts).
     float lmax = -INFINITY;
-    for (int tb = wave * 8; tb < T; tb += 16 * 8) {
-        const int t = tb + p;
-        const bool tv = t < T;
-        const int kr = (tv ? t : 0) * hs + k;
-        float l = 0.f;
+    for (int i = 0; i < nt; ++i) {
+        const float* cur = (i & 1) ? tile1 : tile0;
+        float* nxt = (i & 1) ? tile0 : tile1;
+        if (i + 1 < nt) load_tile(rK, i + 1, kr);
+        if (tid < kAttnTile * 8) {
+            const int p = tid >> 3, k = tid & 7, t = i * kAttnTile + p;
+            const float* kp = cur + p * rs + k;
+            float l = 0.f;
 #pragma unroll 16
-        for (int i = 0; i < hs; i += 8) l = __fmaf_rn(ldK(kr + i), qs[i + k], l);
-        wpart[lane] = l;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (k == 0 && tv) {
-            const float4 u = *reinterpret_cast<const float4*>(wpart + lane), v = *reinterpret_cast<const float4*>(wpart + lane + 4);
-            float tot = __fadd_rn(0.f, u.x);
-            tot = __fadd_rn(tot, u.y); tot = __fadd_rn(tot, u.z); tot = __fadd_rn(tot, u.w);
-            tot = __fadd_rn(tot, v.x); tot = __fadd_rn(tot, v.y); tot = __fadd_rn(tot, v.z); tot = __fadd_rn(tot, v.w);
-            const float sv = __fmul_rn(tot, scale);             // att.multiply(attn_scale) :443
-            sc[t] = sv;
-            lmax = fmaxf(lmax, sv);
+            for (int j = 0; j < hs; j += 8) l = __fmaf_rn(kp[j], qs[j + k], l);
+            const int li = __float_as_int(l);
+            float tot = __fadd_rn(0.f, l);
+            tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x101 /* row_shl:1 */, 0xF, 0xF, true)));
+            tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x102, 0xF, 0xF, true)));
+            tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x103, 0xF, 0xF, true)));
+            tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x104, 0xF, 0xF, true)));
+            tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x105, 0xF, 0xF, true)));
+            tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x106, 0xF, 0xF, true)));
+            tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x107, 0xF, 0xF, true)));
+            if (k == 0 && t < T) {
+                const float sv = __fmul_rn(tot, scale);             // att.multiply(attn_scale) :443
+                sc[t] = sv;
+                lmax = fmaxf(lmax, sv);
+            }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        if (i + 1 < nt) store_tile(nxt, kr);
+        __syncthreads();
     }
     // block max over 16 waves (array_max is order-free)
     lmax = wave_max(lmax);
     if (lane == 0) red[wave] = lmax;
+    store_tile(tile0, vr);                                         // the K tiles are done: first V tile (requested at the start)
     __syncthreads();
     float m = red[0];
 #pragma unroll
     for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
-    for (int t = threadIdx.x; t < T; t += kAttnBlock) sc[t] = expf_ref(__fsub_rn(sc[t], m));
+    for (int t = tid; t < T; t += kAttnBlock) sc[t] = expf_ref(__fsub_rn(sc[t], m));
     __syncthreads();
-    if (threadIdx.x == 0) {                                        // sum += x[i], i ascending (tf_operators.cpp:180-183)
+    if (tid == 0) {                                                // sum += x[i], i ascending (tf_operators.cpp:180-183)
         // a lone lane: the loop is the T dependent adds plus one LDS read per four of them, reads 28 adds ahead
         float sum = 0.f;
         int t = 0;
@@ -803,32 +935,41 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
     }
     __syncthreads();
     const float sum = red[16];
-    for (int t = threadIdx.x; t < T; t += kAttnBlock) sc[t] = __fdiv_rn(sc[t], sum);
+    for (int t = tid; t < T; t += kAttnBlock) sc[t] = __fdiv_rn(sc[t], sum);
     __syncthreads();
-    // ---- o[d] = sum_t att[t] V[t][d]: one thread per output dimension, t ascending (the reference's
-    //      chain); 8 V rows are loaded ahead of their 8 dependent FMAs, the weights come 4 per LDS read.
-    for (int d = threadIdx.x; d < hs; d += kAttnBlock) {
-        float o = __fmul_rn(ldV(d), sc[0]);                        // row 0 always (tf_operators.cpp:331-336)
-        int t = 1;
-        for (; t < T && (t & 3); ++t) { const float w = sc[t]; o = fabsf(w) <= 1e-15f ? o : __fmaf_rn(ldV(t * hs + d), w, o); }
-        for (; t + 8 <= T; t += 8) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = ldV((t + u) * hs + d);
-            const float4 w0 = *reinterpret_cast<const float4*>(sc + t), w1 = *reinterpret_cast<const float4*>(sc + t + 4);
-            const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-            for (int u = 0; u < 8; ++u) o = fabsf(w[u]) <= 1e-15f ? o : __fmaf_rn(v[u], w[u], o);   // threshold, transformer.cpp:449
+    // ---- o[d] = sum_t att[t] V[t][d]: one thread per output dimension, t ascending (the reference's chain) over
+    //      the LDS tiles; the next tile is in flight while this one is walked.
+    float o = 0.f;
+    for (int i = 0; i < nt; ++i) {
+        const float* cur = (i & 1) ? tile1 : tile0;
+        float* nxt = (i & 1) ? tile0 : tile1;
+        if (i + 1 < nt) load_tile(rV, i + 1, vr);
+        if (tid < hs) {
+            const float* vp = cur + tid;
+            const float* wp = sc + i * kAttnTile;
+            const int np = (T - i * kAttnTile) < kAttnTile ? (T - i * kAttnTile) : kAttnTile;
+            int p = 0;
+            if (i == 0) { o = __fmul_rn(vp[0], wp[0]); p = 1; }     // row 0 always (tf_operators.cpp:331-336)
+            for (; p < np && (p & 3); ++p) { const float w = wp[p]; o = fabsf(w) <= 1e-15f ? o : __fmaf_rn(vp[p * rs], w, o); }
+            for (; p + 4 <= np; p += 4) {
+                const float4 w4 = *reinterpret_cast<const float4*>(wp + p);
+                const float v0 = vp[p * rs], v1 = vp[(p + 1) * rs], v2 = vp[(p + 2) * rs], v3 = vp[(p + 3) * rs];
+                o = fabsf(w4.x) <= 1e-15f ? o : __fmaf_rn(v0, w4.x, o);   // threshold, transformer.cpp:449
+                o = fabsf(w4.y) <= 1e-15f ? o : __fmaf_rn(v1, w4.y, o);
+                o = fabsf(w4.z) <= 1e-15f ? o : __fmaf_rn(v2, w4.z, o);
+                o = fabsf(w4.w) <= 1e-15f ? o : __fmaf_rn(v3, w4.w, o);
+            }
+            for (; p < np; ++p) { const float w = wp[p]; o = fabsf(w) <= 1e-15f ? o : __fmaf_rn(vp[p * rs], w, o); }
         }
-        for (; t < T; ++t) { const float w = sc[t]; o = fabsf(w) <= 1e-15f ? o : __fmaf_rn(ldV(t * hs + d), w, o); }
-        st_agent(a.out + (size_t)h * hs + d, o);
+        if (i + 1 < nt) store_tile(nxt, vr);
+        __syncthreads();
     }
+    if (tid < hs) st_agent(a.out + (size_t)h * hs + tid, o);
 }
 __global__ void __launch_bounds__(kAttnBlock) k_attn_decode(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     attn_head(a, blockIdx.x, lds);
 }
-__host__ inline size_t attn_lds_bytes(int max_seq, int hs) { return (size_t)(hs + 32 + 16 * 64 + ((max_seq + 3) & ~3) + 64) * 4; }
 
 // ------------------------------------------------------------------------------------------
 // The persistent whole-token kernel (single GPU).  One 16-wave workgroup per CU walks the token's
@@ -906,7 +1047,7 @@ template <int QT, int PRO, int EPI>
 __device__ __forceinline__ void mega_prologue(const GemvArgs& a, char* lds, GemvCtx<QT, EPI>& g) {
     using T = QTraits<QT>;
     typedef float v4f __attribute__((ext_vector_type(4)));
-    const int n = a.n, tid = threadIdx.x, n4 = n / 4;
+    const int n = a.n, tid = threadIdx.x, n4 = n / 4, ns = n4 + 8;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const GemvLds L = gemv_lds_layout(n, T::kEsz, true, a.rows_per_pass, 64 >> a.cb_shift, false);   // fixed offsets only
     char*  xq = lds;
@@ -936,17 +1077,19 @@ __device__ __forceinline__ void mega_prologue(const GemvArgs& a, char* lds, Gemv
             for (int j = 0; j < kXChunk; ++j) {
                 const int e = base + j * kActWaves * 64 * 4 + tid * 4;
                 if (e < n) {
-                    if constexpr (PRO == PRO_RMSNORM_QUANT) { const int k = e >> 2; scratch[k] = v[j].x; scratch[n4 + k] = v[j].y; scratch[2 * n4 + k] = v[j].z; scratch[3 * n4 + k] = v[j].w; }
+                    if constexpr (PRO == PRO_RMSNORM_QUANT) { const int k = e >> 2; scratch[k] = v[j].x; scratch[ns + k] = v[j].y; scratch[2 * ns + k] = v[j].z; scratch[3 * ns + k] = v[j].w; }
                     else *reinterpret_cast<float4*>(scratch + e) = make_float4(v[j].x, v[j].y, v[j].z, v[j].w);
                 }
             }
-            if (base == 0) g.issue(a.ablate);                                  // the postponed weight prefetch: behind the activation in the return order
+            if (base == 0) g.issue(a.ablate, lds);                             // the postponed weight prefetch: behind the activation in the return order
         }
     } else load_nw();
     __syncthreads();
     float r = 1.0f;
     if constexpr (PRO == PRO_RMSNORM_QUANT) {
-        if (tid < 4 && !(a.ablate & 2)) red[8 + tid] = sq_chain(scratch + tid * n4, n4);
+        if (tid >= kWave) g.issue_ring(a.ablate, lds);         // (wave 0 must not queue behind a full memory pipeline before its chain)
+        if (tid < 4 && !(a.ablate & 2)) red[8 + tid] = sq_chain(scratch + tid * ns, n4);
+        if (tid < kWave) g.issue_ring(a.ablate, lds);
         __syncthreads();
         const float ss = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, red[8]), red[9]), red[10]), red[11]);
         r = rms_scale(ss, n);
@@ -957,7 +1100,7 @@ __device__ __forceinline__ void mega_prologue(const GemvArgs& a, char* lds, Gemv
         const bool act = e < n;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (act) {
-            if constexpr (PRO == PRO_RMSNORM_QUANT) { const int k = e >> 2; v = make_float4(scratch[k], scratch[n4 + k], scratch[2 * n4 + k], scratch[3 * n4 + k]); }
+            if constexpr (PRO == PRO_RMSNORM_QUANT) { const int k = e >> 2; v = make_float4(scratch[k], scratch[ns + k], scratch[2 * ns + k], scratch[3 * ns + k]); }
             else v = *reinterpret_cast<const float4*>(scratch + e);
         }
         if constexpr (PRO == PRO_RMSNORM_QUANT) {
@@ -1002,7 +1145,7 @@ __device__ __attribute__((noinline)) void token_phase(const TokenArgs& t, const 
     const GemvArgs a = kload(ap);
     unsigned epoch = ts.epoch;
     // the phase's first weight loads; activation waves wait until they have asked for the activation
-    auto prefetch = [&]() { g.init(a, wg, nwg); if (wave >= kActWaves) g.issue(a.ablate); };
+    auto prefetch = [&]() { g.init(a, wg, nwg); if (wave >= kActWaves) g.issue(a.ablate, lds); };
     // my stores of the previous phase must have completed before the prefetch is queued behind them (one vmcnt counter)
     if (ts.stored) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if constexpr (ATTN) {
