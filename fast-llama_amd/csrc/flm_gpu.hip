@@ -399,7 +399,8 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance) {
             }
             {   // ATTN task (execute_attn :441-449): local heads write their slice of the full att_out vector
                 Tick t(c, st, KC_ATTN);
-                hipLaunchKernelGGL(k_attn_decode, dim3(c->heads_local), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, hs), st, args_attn(c, l));
+                AttnArgs aa = args_attn(c, l); if (c->trace_class == KC_ATTN && l == 0) aa.trace = c->trace;
+                hipLaunchKernelGGL(k_attn_decode, dim3(c->heads_local), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, hs), st, aa);
                 HIPC(c, hipGetLastError());
             }
             if (tp) {   // every rank needs all heads' outputs: the reference's threads share x2 in memory (transformer.cpp:451-454)

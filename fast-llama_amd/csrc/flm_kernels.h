@@ -818,19 +818,28 @@ struct AttnArgs {
     float* out;              // [heads*hs]
     const int* pos_ptr;
     int hs, max_seq;
+    unsigned long long* trace;   // FLM_ABLATE builds: [head][8] s_memtime stamps
 };
 
 constexpr int kAttnBlock = 1024;      // 16 waves
 constexpr int kAttnTile = 64;         // positions per LDS tile
-constexpr int kAttnNF = 4;            // 16-byte pieces of a tile per thread: hs <= 256
-__host__ __device__ inline int attn_row_stride(int hs) { return hs + 8; }
-__host__ inline size_t attn_lds_bytes(int max_seq, int hs) { return (size_t)(hs + 32 + ((max_seq + 3) & ~3) + 64 + 2 * kAttnTile * attn_row_stride(hs)) * 4; }
+constexpr int kAttnDepth = 2;         // tiles in flight per stream (K, V), register rings: both streams start when the kernel does
+// LDS row stride of a tile in floats: compile-time per instantiation (64*NF + 8), so that the chains' LDS reads use
+// immediate offsets; +8: the 8x8 (position, accumulator) score lanes and the PV lanes hit distinct banks
+__host__ __device__ inline int attn_row_stride(int hs) { const int nf = hs <= 64 ? 1 : hs <= 128 ? 2 : 4; return nf * 64 + 8; }
+__host__ inline size_t attn_lds_bytes(int max_seq, int hs) { return (size_t)(hs + 32 + ((max_seq + 3) & ~3) + 64 + (2 * kAttnTile + 4) * attn_row_stride(hs)) * 4; }   // + 4 slack rows: the PV read-ahead
 
+// NF = 16-byte pieces of a tile per thread = ceil(hs / 64)
+template <int NF>
 __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* lds) {
     typedef float v4f __attribute__((ext_vector_type(4)));
+    constexpr int D = kAttnDepth;
     const int hs = a.hs, tid = threadIdx.x;
     const int T = *a.pos_ptr + 1;
-    const int rs = attn_row_stride(hs), f4r = hs >> 2, tile_f4 = kAttnTile * f4r;
+    auto stamp = [&](int k) { if (kAblate && a.trace && threadIdx.x == 0) a.trace[h * 8 + k] = __builtin_amdgcn_s_memtime(); };
+    stamp(0);
+    constexpr int rs = NF * 64 + 8;
+    const int f4r = hs >> 2, tile_f4 = kAttnTile * f4r;
     float* qs   = reinterpret_cast<float*>(lds);                 // [hs]
     float* red  = qs + hs;                                       // 32
     float* sc   = red + 32;                                      // [T] scores -> probabilities (+ slack for the sum ring's read-ahead)
@@ -845,71 +854,85 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
     const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V), 0, a.max_seq * hs * 4, 0x00020000);
     const float scale = (float)(1.0 / (double)__builtin_sqrtf((float)hs));   // attn_scale, transformer.cpp:418
     const int nt = (T + kAttnTile - 1) / kAttnTile;
-
-    auto load_tile = [&](const __amdgpu_buffer_rsrc_t& r, int tile, v4f (&reg)[kAttnNF]) {
+    // Two streams of tiles (K for the scores, V for the weighted sum), each through a ring of D register sets; both are
+    // requested when the kernel starts (the V tiles arrive under the softmax), tile i+D when tile i has been parked.
+    v4f ringK[D][NF], ringV[D][NF];
+    // this thread's pieces of a tile: row / byte offsets computed once (an integer division per piece per tile would
+    // cost more than the tile's arithmetic)
+    int prow[NF], goff[NF], loff[NF];
 #pragma unroll
-        for (int j = 0; j < kAttnNF; ++j) {
-            const int f = tid + j * kAttnBlock, row = f / f4r, c4 = f - row * f4r, t = tile * kAttnTile + row;
-            const unsigned off = (f < tile_f4 && t < T) ? (unsigned)(t * hs + c4 * 4) * 4u : 0x80000000u;
+    for (int j = 0; j < NF; ++j) {
+        const int f = tid + j * kAttnBlock, row = f / f4r, c4 = f - row * f4r;
+        prow[j] = f < tile_f4 ? row : (1 << 28);                    // pieces past the tile never pass the t < T test
+        goff[j] = (row * hs + c4 * 4) * 4;
+        loff[j] = row * rs + c4 * 4;
+    }
+    const int tile_bytes = kAttnTile * hs * 4;
+    auto request = [&](const __amdgpu_buffer_rsrc_t& r, int tile, v4f (&reg)[NF]) {
+        const int t0 = tile * kAttnTile;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const unsigned off = (tile < nt && t0 + prow[j] < T) ? (unsigned)(tile * tile_bytes + goff[j]) : 0x80000000u;
             reg[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, kAuxCoherent));
         }
     };
-    auto store_tile = [&](float* buf, const v4f (&reg)[kAttnNF]) {
+    auto park = [&](float* buf, const v4f (&reg)[NF]) {
 #pragma unroll
-        for (int j = 0; j < kAttnNF; ++j) {
-            const int f = tid + j * kAttnBlock, row = f / f4r, c4 = f - row * f4r;
-            if (f < tile_f4) *reinterpret_cast<float4*>(buf + row * rs + c4 * 4) = make_float4(reg[j].x, reg[j].y, reg[j].z, reg[j].w);
-        }
+        for (int j = 0; j < NF; ++j)
+            if (prow[j] < kAttnTile) *reinterpret_cast<float4*>(buf + loff[j]) = make_float4(reg[j].x, reg[j].y, reg[j].z, reg[j].w);
     };
-
-    v4f kr[kAttnNF], vr[kAttnNF];
-    load_tile(rK, 0, kr);
-    load_tile(rV, 0, vr);
+#pragma unroll
+    for (int u = 0; u < D; ++u) request(rK, u, ringK[u]);
+#pragma unroll
+    for (int u = 0; u < D; ++u) request(rV, u, ringV[u]);
     for (int d = tid; d < hs; d += kAttnBlock) qs[d] = ld_agent(a.q + (size_t)h * hs + d);
-    store_tile(tile0, kr);
-    __syncthreads();
 
     // ---- scores: lane = (position p, strided accumulator k) -- the 8 lanes of dot_product_avx256; each lane's
     //      chain is i ascending, then the 8 partials are added 0..7 (lane k = 0 collects them with DPP row shifts).
     float lmax = -INFINITY;
-    for (int i = 0; i < nt; ++i) {
-        const float* cur = (i & 1) ? tile1 : tile0;
-        float* nxt = (i & 1) ? tile0 : tile1;
-        if (i + 1 < nt) load_tile(rK, i + 1, kr);
-        if (tid < kAttnTile * 8) {
-            const int p = tid >> 3, k = tid & 7, t = i * kAttnTile + p;
-            const float* kp = cur + p * rs + k;
-            float l = 0.f;
+    for (int base = 0; base < nt; base += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int s = base + u;
+            if (s >= nt) break;                                     // (uniform)
+            float* cur = (u & 1) ? tile1 : tile0;                   // D is even: tile parity == slot parity
+            park(cur, ringK[u]);
+            __syncthreads();
+            request(rK, s + D, ringK[u]);
+            if (tid < kAttnTile * 8) {
+                const int p = tid >> 3, k = tid & 7, t = s * kAttnTile + p;
+                const float* kp = cur + p * rs + k;
+                float l = 0.f;
 #pragma unroll 16
-            for (int j = 0; j < hs; j += 8) l = __fmaf_rn(kp[j], qs[j + k], l);
-            const int li = __float_as_int(l);
-            float tot = __fadd_rn(0.f, l);
-            tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x101 /* row_shl:1 */, 0xF, 0xF, true)));
-            tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x102, 0xF, 0xF, true)));
-            tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x103, 0xF, 0xF, true)));
-            tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x104, 0xF, 0xF, true)));
-            tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x105, 0xF, 0xF, true)));
-            tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x106, 0xF, 0xF, true)));
-            tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x107, 0xF, 0xF, true)));
-            if (k == 0 && t < T) {
-                const float sv = __fmul_rn(tot, scale);             // att.multiply(attn_scale) :443
-                sc[t] = sv;
-                lmax = fmaxf(lmax, sv);
+                for (int j = 0; j < hs; j += 8) l = __fmaf_rn(kp[j], qs[j + k], l);
+                const int li = __float_as_int(l);
+                float tot = __fadd_rn(0.f, l);
+                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x101 /* row_shl:1 */, 0xF, 0xF, true)));
+                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x102, 0xF, 0xF, true)));
+                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x103, 0xF, 0xF, true)));
+                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x104, 0xF, 0xF, true)));
+                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x105, 0xF, 0xF, true)));
+                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x106, 0xF, 0xF, true)));
+                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x107, 0xF, 0xF, true)));
+                if (k == 0 && t < T) {
+                    const float sv = __fmul_rn(tot, scale);         // att.multiply(attn_scale) :443
+                    sc[t] = sv;
+                    lmax = fmaxf(lmax, sv);
+                }
             }
         }
-        if (i + 1 < nt) store_tile(nxt, kr);
-        __syncthreads();
     }
+    stamp(1);
     // block max over 16 waves (array_max is order-free)
     lmax = wave_max(lmax);
     if (lane == 0) red[wave] = lmax;
-    store_tile(tile0, vr);                                         // the K tiles are done: first V tile (requested at the start)
     __syncthreads();
     float m = red[0];
 #pragma unroll
     for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
     for (int t = tid; t < T; t += kAttnBlock) sc[t] = expf_ref(__fsub_rn(sc[t], m));
     __syncthreads();
+    stamp(2);
     if (tid == 0) {                                                // sum += x[i], i ascending (tf_operators.cpp:180-183)
         // a lone lane: the loop is the T dependent adds plus one LDS read per four of them, reads 28 adds ahead
         float sum = 0.f;
@@ -934,41 +957,70 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
         red[16] = sum;
     }
     __syncthreads();
+    stamp(3);
     const float sum = red[16];
-    for (int t = tid; t < T; t += kAttnBlock) sc[t] = __fdiv_rn(sc[t], sum);
-    __syncthreads();
+    // att[t] = exp / sum; rows t >= 1 with |att| <= 1e-15 are skipped by the weighted sum (transformer.cpp:449): they are
+    // stored as exact zeros so that the PV chain can tell them apart with one wave-uniform test per four positions
+    for (int t = tid; t < T; t += kAttnBlock) { const float w = __fdiv_rn(sc[t], sum); sc[t] = (t > 0 && fabsf(w) <= 1e-15f) ? 0.f : w; }
+    // (the first barrier of the loop below orders these writes before the PV reads)
     // ---- o[d] = sum_t att[t] V[t][d]: one thread per output dimension, t ascending (the reference's chain) over
-    //      the LDS tiles; the next tile is in flight while this one is walked.
+    //      the LDS tiles.
     float o = 0.f;
-    for (int i = 0; i < nt; ++i) {
-        const float* cur = (i & 1) ? tile1 : tile0;
-        float* nxt = (i & 1) ? tile0 : tile1;
-        if (i + 1 < nt) load_tile(rV, i + 1, vr);
-        if (tid < hs) {
-            const float* vp = cur + tid;
-            const float* wp = sc + i * kAttnTile;
-            const int np = (T - i * kAttnTile) < kAttnTile ? (T - i * kAttnTile) : kAttnTile;
-            int p = 0;
-            if (i == 0) { o = __fmul_rn(vp[0], wp[0]); p = 1; }     // row 0 always (tf_operators.cpp:331-336)
-            for (; p < np && (p & 3); ++p) { const float w = wp[p]; o = fabsf(w) <= 1e-15f ? o : __fmaf_rn(vp[p * rs], w, o); }
-            for (; p + 4 <= np; p += 4) {
-                const float4 w4 = *reinterpret_cast<const float4*>(wp + p);
-                const float v0 = vp[p * rs], v1 = vp[(p + 1) * rs], v2 = vp[(p + 2) * rs], v3 = vp[(p + 3) * rs];
-                o = fabsf(w4.x) <= 1e-15f ? o : __fmaf_rn(v0, w4.x, o);   // threshold, transformer.cpp:449
-                o = fabsf(w4.y) <= 1e-15f ? o : __fmaf_rn(v1, w4.y, o);
-                o = fabsf(w4.z) <= 1e-15f ? o : __fmaf_rn(v2, w4.z, o);
-                o = fabsf(w4.w) <= 1e-15f ? o : __fmaf_rn(v3, w4.w, o);
+    for (int base = 0; base < nt; base += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int i = base + u;
+            if (i >= nt) break;                                     // (uniform)
+            float* cur = (u & 1) ? tile1 : tile0;
+            park(cur, ringV[u]);
+            __syncthreads();
+            request(rV, i + D, ringV[u]);
+            if (tid < hs) {
+                const float* vp = cur + tid;
+                const float* wp = sc + i * kAttnTile;
+                const int np = (T - i * kAttnTile) < kAttnTile ? (T - i * kAttnTile) : kAttnTile;
+                // weights are wave-uniform (one per position): lane p looks at weight p once per tile; if no row of the
+                // tile is skipped, the walk is nothing but LDS reads at immediate offsets and dependent FMAs
+                const float wl = lane < np ? wp[lane] : 1.f;
+                const bool dense = __all(wl != 0.f) != 0;
+                int p = 0;
+                if (i == 0) { o = __fmul_rn(vp[0], wp[0]); p = 1; }  // row 0 always (tf_operators.cpp:331-336)
+                if (dense) {
+                    for (; p < np && (p & 7); ++p) o = __fmaf_rn(vp[p * rs], wp[p], o);
+                    if (p + 8 <= np) {
+                        const float* vq = vp + p * rs; const float* wq = wp + p;
+                        float4 wa = *reinterpret_cast<const float4*>(wq), wb = *reinterpret_cast<const float4*>(wq + 4);
+                        float a0 = vq[0], a1 = vq[rs], a2 = vq[2 * rs], a3 = vq[3 * rs], a4 = vq[4 * rs], a5 = vq[5 * rs], a6 = vq[6 * rs], a7 = vq[7 * rs];
+                        for (; p + 16 <= np; p += 8) {
+                            vq += 8 * rs; wq += 8;
+                            const float4 wc = *reinterpret_cast<const float4*>(wq), wd = *reinterpret_cast<const float4*>(wq + 4);
+                            const float b0 = vq[0], b1 = vq[rs], b2 = vq[2 * rs], b3 = vq[3 * rs], b4 = vq[4 * rs], b5 = vq[5 * rs], b6 = vq[6 * rs], b7 = vq[7 * rs];
+                            o = __fmaf_rn(a0, wa.x, o); o = __fmaf_rn(a1, wa.y, o); o = __fmaf_rn(a2, wa.z, o); o = __fmaf_rn(a3, wa.w, o);
+                            o = __fmaf_rn(a4, wb.x, o); o = __fmaf_rn(a5, wb.y, o); o = __fmaf_rn(a6, wb.z, o); o = __fmaf_rn(a7, wb.w, o);
+                            wa = wc; wb = wd; a0 = b0; a1 = b1; a2 = b2; a3 = b3; a4 = b4; a5 = b5; a6 = b6; a7 = b7;
+                        }
+                        o = __fmaf_rn(a0, wa.x, o); o = __fmaf_rn(a1, wa.y, o); o = __fmaf_rn(a2, wa.z, o); o = __fmaf_rn(a3, wa.w, o);
+                        o = __fmaf_rn(a4, wb.x, o); o = __fmaf_rn(a5, wb.y, o); o = __fmaf_rn(a6, wb.z, o); o = __fmaf_rn(a7, wb.w, o);
+                        p += 8;
+                    }
+                    for (; p < np; ++p) o = __fmaf_rn(vp[p * rs], wp[p], o);
+                } else {
+                    // some row is skipped (weight stored as exact 0, threshold of transformer.cpp:449): it leaves o untouched
+                    for (; p < np; ++p) { const float w = wp[p]; o = w == 0.f ? o : __fmaf_rn(vp[p * rs], w, o); }
+                }
             }
-            for (; p < np; ++p) { const float w = wp[p]; o = fabsf(w) <= 1e-15f ? o : __fmaf_rn(vp[p * rs], w, o); }
         }
-        if (i + 1 < nt) store_tile(nxt, vr);
-        __syncthreads();
     }
+    stamp(4);
     if (tid < hs) st_agent(a.out + (size_t)h * hs + tid, o);
+    __syncthreads();                                                // the LDS is free for whoever runs next on it (k_token)
+}
+__device__ __forceinline__ void attn_head_any(const AttnArgs& a, const int h, char* lds) {
+    if (a.hs <= 64) attn_head<1>(a, h, lds); else if (a.hs <= 128) attn_head<2>(a, h, lds); else attn_head<4>(a, h, lds);
 }
 __global__ void __launch_bounds__(kAttnBlock) k_attn_decode(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    attn_head(a, blockIdx.x, lds);
+    attn_head_any(a, blockIdx.x, lds);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1154,7 +1206,7 @@ __device__ __attribute__((noinline)) void token_phase(const TokenArgs& t, const 
         grid_barrier(t, epoch);
         if (attn_wg) {   // one head per workgroup
             const AttnArgs aa = kload(aap);
-            for (int h = wg; h < t.n_heads; h += nwg) { attn_head(aa, h, lds); __syncthreads(); }
+            for (int h = wg; h < t.n_heads; h += nwg) attn_head_any(aa, h, lds);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             prefetch();
         }
