@@ -171,6 +171,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--wg-per-cu", type=int, default=0)
     ap.add_argument("--prompt-len", type=int, default=9)
+    ap.add_argument("--ring", type=int, default=-1, help="1/0: LDS weight ring on/off (default: library default)")
     ap.add_argument("--mega", type=int, default=-1, help="1/0: force the persistent whole-token kernel on/off (default: library default)")
     args = ap.parse_args()
 
@@ -207,6 +208,8 @@ def main():
         ctx.set_option("wg_per_cu", args.wg_per_cu)
     if args.mega >= 0:
         ctx.set_option("use_mega", args.mega)
+    if args.ring >= 0:
+        ctx.set_option("use_ring", args.ring)
     upload_synthetic(ctx, cfg)
 
     def barrier():

@@ -824,27 +824,73 @@ int flm_decode_timed(flm_ctx* c, int32_t first_token, int pos, int n_steps, floa
     return r ? r : mega_check(c);
 }
 
+// Per-class kernel time, measured live with HIP events on the ctx stream.  Single GPU: for each class the L launches
+// of one token (layer 0 .. L-1, the real argument blocks) are enqueued back to back between ONE pair of events, so the
+// average is launch duration + the dependent-dispatch gap and agrees with a rocprofv3 kernel trace; an event pair per
+// launch would add ~5 us of marker latency to each.  The launches run out of token order, so the activations, the KV
+// row at `pos` and the decode state are meaningless afterwards: call flm_reset_kv / feed a new prompt before decoding on.
+// Tensor-parallel contexts time whole tokens with an event pair per launch (the collectives need token order).
 int flm_kernel_times(flm_ctx* c, int pos, int iters, float* avg_us, int32_t* count) {
     if (!avg_us || !count || iters < 1) return FLM_ERR_INVALID;
     int r = check_ready(c, 1, pos); if (r) return r;
     double tot[FLM_KCLASSES] = {0}; long cnt[FLM_KCLASSES] = {0};
     r = ensure_token_bufs(c, 1, 1); if (r) return r;
-    for (int it = 0; it < iters + 1; ++it) {
-        DecodeState s{pos, 1 % c->d.vocab_size, 0, 0};
-        HIPC(c, hipMemcpyAsync(c->state, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
-        std::vector<TimedLaunch> tl; c->timing = &tl;
-        r = enqueue_token(c, c->stream, true, 1);
-        c->timing = nullptr;
-        hipStreamSynchronize(c->stream);
-        for (auto& t : tl) {
-            float ms = 0.f;
-            if (!r && it > 0 && hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) { tot[t.kclass] += ms * 1000.0; cnt[t.kclass] += 1; }
-            hipEventDestroy(t.e0); hipEventDestroy(t.e1);
+    if (c->world > 1) {
+        for (int it = 0; it < iters + 1; ++it) {
+            DecodeState s{pos, 1 % c->d.vocab_size, 0, 0};
+            HIPC(c, hipMemcpyAsync(c->state, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
+            std::vector<TimedLaunch> tl; c->timing = &tl;
+            r = enqueue_token(c, c->stream, true, 1);
+            c->timing = nullptr;
+            hipStreamSynchronize(c->stream);
+            for (auto& t : tl) {
+                float ms = 0.f;
+                if (!r && it > 0 && hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) { tot[t.kclass] += ms * 1000.0; cnt[t.kclass] += 1; }
+                hipEventDestroy(t.e0); hipEventDestroy(t.e1);
+            }
+            if (r) return r;
         }
-        if (r) return r;
+        for (int k = 0; k < FLM_KCLASSES; ++k) { avg_us[k] = cnt[k] ? (float)(tot[k] / cnt[k]) : 0.f; count[k] = (int32_t)(cnt[k] / iters); }
+        return FLM_OK;
     }
-    for (int k = 0; k < FLM_KCLASSES; ++k) { avg_us[k] = cnt[k] ? (float)(tot[k] / cnt[k]) : 0.f; count[k] = (int32_t)(cnt[k] / iters); }
-    return FLM_OK;
+    const auto& d = c->d;
+    const int qt = d.quant_type, L = d.n_layers, wgs = gemv_grid(c->cu_count, c->wg_per_cu, 0, 0);
+    hipStream_t st = c->stream;
+    DecodeState s{pos, 1 % d.vocab_size, 0, 0};
+    HIPC(c, hipMemcpyAsync(c->state, &s, sizeof s, hipMemcpyHostToDevice, st));
+    hipEvent_t e0, e1; HIPC(c, hipEventCreate(&e0)); HIPC(c, hipEventCreate(&e1));
+    auto launch = [&](int kc, int l) -> int {
+        switch (kc) {
+        case KC_EMBED:  hipLaunchKernelGGL(k_embed, dim3((d.dim + 255) / 256), dim3(256), 0, st, c->x1, (const void*)c->emb, (const float*)c->emb_s, c->emb_qt, d.dim, (const int*)&c->state->tok, c->mega_bar); return FLM_OK;
+        case KC_QKV:    return launch_gemv<PRO_RMSNORM_QUANT, EPI_ROPE_KV>(c, st, qt, args_qkv(c, l), wgs);
+        case KC_ATTN:   hipLaunchKernelGGL(k_attn_decode, dim3(c->heads_local), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, c->hs), st, args_attn(c, l)); return FLM_OK;
+        case KC_ATTN_O: return launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, args_o(c, l), wgs);
+        case KC_FFN13:  return launch_gemv<PRO_RMSNORM_QUANT, EPI_SWIGLU>(c, st, qt, args_ffn13(c, l), wgs);
+        case KC_FFN2:   return launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, args_ffn2(c, l), wgs);
+        case KC_CLS:    return launch_gemv<PRO_RMSNORM_QUANT, EPI_STORE>(c, st, qt, args_cls(c), wgs);
+        case KC_ARGMAX: hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, st, (const float*)c->logits, d.vocab_size, c->state, c->out_tokens_dev, 0); return FLM_OK;
+        default: return FLM_OK;
+        }
+    };
+    const int classes[] = {KC_EMBED, KC_QKV, KC_ATTN, KC_ATTN_O, KC_FFN13, KC_FFN2, KC_CLS, KC_ARGMAX};
+    for (int kc : classes) {
+        const bool per_layer = kc >= KC_QKV && kc <= KC_FFN2;
+        const int n = per_layer ? L : 8;
+        for (int it = 0; it < iters + 1 && !r; ++it) {          // first round: warm-up
+            HIPC(c, hipEventRecord(e0, st));
+            for (int i = 0; i < n && !r; ++i) r = launch(kc, per_layer ? i : 0);
+            HIPC(c, hipEventRecord(e1, st));
+            HIPC(c, hipEventSynchronize(e1));
+            float ms = 0.f; HIPC(c, hipEventElapsedTime(&ms, e0, e1));
+            if (it > 0) { tot[kc] += ms * 1000.0 / n; cnt[kc] += 1; }
+        }
+        avg_us[kc] = cnt[kc] ? (float)(tot[kc] / cnt[kc]) : 0.f;
+        count[kc] = per_layer ? L : 1;
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    for (int k = 0; k < FLM_KCLASSES; ++k) if (k != KC_EMBED && (k < KC_QKV || k > KC_ARGMAX)) { avg_us[k] = 0.f; count[k] = 0; }
+    if (r) return r;
+    return flm_reset_kv(c);
 }
 
 int flm_kernel_bytes(flm_ctx* c, int kclass, int pos, double* bytes) {

@@ -102,10 +102,12 @@ int  flm_decode_timed(flm_ctx* ctx, int32_t first_token, int pos, int n_steps, f
 int  flm_reset_kv(flm_ctx* ctx);
 int  flm_sync(flm_ctx* ctx);
 
-/* Per-kernel timing of ONE decode token at position pos, HIP events around every launch on the
- * ctx's stream, averaged over `iters` tokens.  Classes: 0 embed, 1 qkv, 2 attn, 3 attn_o, 4 ffn13,
- * 5 ffn2, 6 cls, 7 argmax, 8 allreduce.  avg_us[c] = mean duration of ONE launch of class c,
- * count[c] = launches of that class per token. */
+/* Per-kernel timing at position pos with HIP events on the ctx's stream, averaged over `iters` rounds.
+ * Classes: 0 embed, 1 qkv, 2 attn, 3 attn_o, 4 ffn13, 5 ffn2, 6 cls, 7 argmax, 8 allreduce.
+ * avg_us[c] = mean duration of ONE launch of class c (single GPU: the class's launches of one token are
+ * enqueued back to back between one pair of events, so the figure is launch duration + dispatch gap and
+ * agrees with a rocprofv3 kernel trace), count[c] = launches of that class per token.
+ * Side effect: the KV cache is cleared and the decode state is undefined afterwards. */
 #define FLM_KCLASSES 9
 int  flm_kernel_times(flm_ctx* ctx, int pos, int iters, float* avg_us, int32_t* count);
 /* weight + scale bytes one launch of class c streams (the algorithmic bytes of DESIGN.md) */
@@ -116,7 +118,9 @@ int  flm_kernel_bytes(flm_ctx* ctx, int kclass, int pos, double* bytes);
  * [heads][max_seq][hs], 5 V cache of `layer`, 6 logits. */
 int  flm_debug_read(flm_ctx* ctx, int what, int layer, float* out, size_t n);
 
-/* tuning knobs: "wg_per_cu" workgroups per CU for the GEMV kernels, "use_graph" hipGraph replay on/off */
+/* tuning knobs: "wg_per_cu" workgroups per CU for the GEMV kernels, "use_graph" hipGraph replay on/off,
+ * "use_mega" 1 = run single-GPU tokens as one persistent kernel (k_token; experimental, default 0),
+ * "use_ring" 1 = LDS weight ring in the rmsnorm GEMVs (default 0) */
 int  flm_set_option(flm_ctx* ctx, const char* key, int value);
 
 /* ---- op level: 1:1 mirrors of the reference operator seam, host pointers in / out, running the
