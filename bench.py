@@ -125,6 +125,18 @@ def cpu_baseline(cfg, budget_s=40.0):
 
     if os.path.exists(ref_main):
         try:
+            import shutil
+            free_gb = shutil.disk_usage("/tmp").free / 1e9
+            need_gb = token_bytes(cfg, 0) / 1e9 * 1.15
+            if free_gb > need_gb + 2:
+                # the whole model: the reference binary decodes the same 32-layer shape, no extrapolation
+                ntok = 160
+                t_tok, wall = run_ref(cfg.n_layers, ntok)
+                res.update(value=1000.0 / t_tok, kind="reference",
+                           sample=(f"reference binary (oracle/_ref/main, -O3 -march=x86-64-v3 -mfma, AVX2 kernels) -j {threads} -t 0 --mode bm --uma, the full "
+                                   f"{cfg.n_layers}-layer LLaMA2-7B-shaped int8 .flm (synthetic weights, identical tensors in every layer), prompt 13 tokens + {ntok} "
+                                   f"decode tokens: {t_tok:.2f} ms per output token (wall {wall:.0f}s incl. writing and loading the file)"))
+                return res
             La, Lb, ntok = 4, 12, 48
             t2, w2 = run_ref(La, ntok)
             t4, w4 = run_ref(Lb, ntok)
@@ -135,7 +147,7 @@ def cpu_baseline(cfg, budget_s=40.0):
                        sample=(f"reference binary (oracle/_ref/main, -O3 -march=x86-64-v3 -mfma, AVX2 kernels) -j {threads} -t 0 --mode bm, int8 .flm, "
                                f"7B-width synthetic models with {La} and {Lb} layers, {ntok} decode tokens each: {t2:.2f} / {t4:.2f} ms per token; "
                                f"t_layer={t_layer:.3f} ms, t_cls={t_cls:.3f} ms, extrapolated to 32 layers = {t_tok:.1f} ms/token "
-                               f"(wall {w2 + w4:.0f}s)"))
+                               f"(wall {w2 + w4:.0f}s; /tmp too small for the full model)"))
             return res
         except Exception as e:  # noqa: BLE001
             log("cpu_baseline: reference binary unusable here:", e)
