@@ -6,9 +6,12 @@
 One step = one greedy decode token of LLaMA2-7B int8 (synthetic weights, configs[2] of BASELINE.json)
 through the HIP path (fast-llama_amd/lib/libflm_gpu.so, C ABI include/flm_gpu.h).  All weights, the
 KV cache and the decode state are resident in HBM before the timed region; the K timed tokens run
-back to back from a hipGraph with no host round trip.  N > 1 = tensor-parallel over N GPUs (one
-process per GPU, every matmul split by output rows + RCCL all-gather of the activations, bit-identical
-to the single-GPU result) -> strong scaling of the same job.
+back to back from a hipGraph with no host round trip.
+N > 1 (one process per GPU): by default N REPLICAS, each GPU decoding its own sequence -- single-stream
+decode is a chain of dependent ~20 us kernels, so splitting one sequence over GPUs buys capacity, not speed
+(DESIGN.md section 8); whole-job tokens/s = N*K / max over ranks of the wall time, "scaling": "weak", no
+data-path collective.  --parallel tp runs ONE sequence tensor-parallel instead (every matmul split by
+output rows + RCCL all-gather of the activations, bit-identical to the single-GPU result; "strong").
 
 Rank 0 prints ONE JSON line; besides the contract's keys it carries
   roofline     : dominant kernel (ffn13 GEMV) algorithmic bytes / its mean launch time measured live
@@ -173,6 +176,27 @@ def cpu_baseline(cfg, budget_s=40.0):
     return res
 
 
+def max_over_ranks(x: float) -> float:
+    """MAX of a per-rank scalar over the process group (1-process runs: identity)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(x)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def job_throughput(local_elapsed_s: float, steps: int, world: int, mode: str):
+    """whole-job tokens/s from each rank's own wall time for its K timed steps.
+    replicas: every rank decoded K tokens of its own sequence  -> N*K tokens in max(elapsed)   (weak scaling)
+    tp      : all ranks decoded the same K tokens together     ->   K tokens in max(elapsed)   (strong scaling)"""
+    elapsed = max_over_ranks(local_elapsed_s)
+    tokens = steps * (world if mode == "replicas" else 1)
+    return tokens / elapsed, elapsed
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,6 +207,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--wg-per-cu", type=int, default=0)
     ap.add_argument("--prompt-len", type=int, default=9)
+    ap.add_argument("--parallel", default="replicas", choices=["replicas", "tp"],
+                    help="N > 1: 'replicas' = one independent sequence per GPU, no data-path collective (default); "
+                         "'tp' = one sequence, every matmul split by output rows over the GPUs, RCCL all-gathers")
     ap.add_argument("--ring", type=int, default=-1, help="1/0: LDS weight ring on/off (default: library default)")
     ap.add_argument("--mega", type=int, default=-1, help="1/0: force the persistent whole-token kernel on/off (default: library default)")
     args = ap.parse_args()
@@ -201,21 +228,24 @@ def main():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     comm_id = None
+    mode = "single" if world == 1 else args.parallel
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
-        dist.broadcast(idt, 0)
-        comm_id = bytes(idt.cpu().numpy().tobytes())
+        if mode == "tp":
+            idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            comm_id = bytes(idt.cpu().numpy().tobytes())
+    tp = world if mode == "tp" else 1
 
     qt = ff.QT_INT8 if args.quant == "int8" else ff.QT_INT16
     cfg = synth.make_config(args.shape, qt)
     if rank == 0:
-        log(f"bench: {args.shape} {args.quant}, world={world}, steps={args.steps}, warmup={args.warmup}")
-    ctx = capi.Ctx(capi.desc_from_config(cfg), device=local_rank, rank=rank, world=world, comm_id=comm_id)
+        log(f"bench: {args.shape} {args.quant}, world={world} ({mode}), steps={args.steps}, warmup={args.warmup}")
+    ctx = capi.Ctx(capi.desc_from_config(cfg), device=local_rank, rank=rank if tp > 1 else 0, world=tp, comm_id=comm_id)
     if args.wg_per_cu:
         ctx.set_option("wg_per_cu", args.wg_per_cu)
     if args.mega >= 0:
@@ -232,7 +262,8 @@ def main():
 
     # prompt (untimed): BOS + 8 tokens, then W warm-up decode steps (also captures the hipGraphs)
     V = cfg.vocab_size
-    prompt = np.array([1] + [int(x) for x in (np.arange(1, args.prompt_len) * 7919) % V], dtype=np.int32)
+    seq = rank if mode == "replicas" else 0            # replicas decode different sequences
+    prompt = np.array([1] + [int(x) for x in ((np.arange(1, args.prompt_len) + 131 * seq) * 7919) % V], dtype=np.int32)
     first = ctx.forward_argmax(prompt, 0)
     pos = len(prompt)
     if args.warmup > 0:
@@ -244,13 +275,7 @@ def main():
     torch.cuda.synchronize()
     barrier_t = time.perf_counter() - t0
     barrier()
-    elapsed = barrier_t
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    tok_s = args.steps / elapsed
+    tok_s, elapsed = job_throughput(barrier_t, args.steps, world, mode)
     mid_pos = pos + args.steps // 2
     esz = 1 if qt == ff.QT_INT8 else 2
 
@@ -269,13 +294,16 @@ def main():
             "metric": "decode tokens/s LLaMA2-7B int8" if args.shape == "7B" and qt == ff.QT_INT8 else f"decode tokens/s {args.shape} {args.quant}",
             "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * elapsed / args.steps, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "int8" if qt == ff.QT_INT8 else "int16", "data": "synthetic",
+            "scaling": "strong" if mode == "tp" else "weak", "vs_baseline": None, "dtype": "int8" if qt == ff.QT_INT8 else "int16", "data": "synthetic",
             "config": {"workload": f"LLaMA2-{args.shape} {args.quant} .flm-layout synthetic weights, single-stream greedy decode, "
                                    f"prompt {len(prompt)} tokens, positions {pos}..{pos + args.steps - 1}, fp32 KV cache, max_seq 1024",
-                       "parallelism": f"tp{world}" if world > 1 else "single-gpu", "device_ms_per_step": round(ms_dev / args.steps, 4)},
-            "token_roofline": {"bytes_per_token": int(token_bytes(cfg, mid_pos, esz) / world), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "achieved": round(token_bytes(cfg, mid_pos, esz) / world * tok_s / 1e9, 1),
-                               "frac": round(token_bytes(cfg, mid_pos, esz) / world * tok_s / 1e9 / HBM_PEAK_GBS, 4)},
+                       "parallelism": {"single": "single-gpu", "tp": f"tp{world}: one sequence, matmuls split by output rows, RCCL all-gathers",
+                                       "replicas": f"{world} replicas: one independent sequence per GPU, no data-path collective"}[mode],
+                       "device_ms_per_step": round(ms_dev / args.steps, 4)},
+            # per GPU: bytes each GPU streams per token it works on, at the rate it produces them
+            "token_roofline": {"bytes_per_token": int(token_bytes(cfg, mid_pos, esz) / tp), "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
+                               "achieved": round(token_bytes(cfg, mid_pos, esz) / tp * (tok_s / (world / tp)) / 1e9, 1),
+                               "frac": round(token_bytes(cfg, mid_pos, esz) / tp * (tok_s / (world / tp)) / 1e9 / HBM_PEAK_GBS, 4)},
             "roofline": {"kernel": "k_gemv<int8,rmsnorm+quantize,swiglu> (ffn13)" if qt == ff.QT_INT8 else "k_gemv<int16,...> (ffn13)",
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
