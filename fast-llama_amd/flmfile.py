@@ -80,6 +80,7 @@ class FlmConfig:
     rms_norm_eps: float = 1e-5
     rope_theta: float = 10000.0
     quant_group_size: int = GROUP
+    act_type_str: str | None = None   # the reference converter stores config.json's "hidden_act" string under act_type (convert_flm.py:369-383)
 
     @property
     def head_size(self):
@@ -160,7 +161,10 @@ class FlmWriter:
         b = self.string_block("name", c.name)   # nested blocks are laid out from offset 0 of the dict payload
         for k in ("model_type", "act_type", "quant_type", "vocab_size", "dim", "hidden_dim", "n_heads", "n_kv_heads",
                   "n_layers", "max_length", "bos_token_id", "eos_token_id", "pad_token_id"):
-            b += self.base_item(k, "i", DT_INT32, int(getattr(c, k)))
+            if k == "act_type" and c.act_type_str is not None:
+                b += self.string_block(k, c.act_type_str)
+            else:
+                b += self.base_item(k, "i", DT_INT32, int(getattr(c, k)))
         b += self.base_item("rms_norm_eps", "f", DT_FLOAT32, float(c.rms_norm_eps))
         b += self.base_item("rope_theta", "f", DT_FLOAT32, float(c.rope_theta))
         b += self.base_item("quant_group_size", "i", DT_INT32, int(c.quant_group_size))
@@ -181,6 +185,7 @@ class FlmWriter:
             tok += struct.pack("<iiif", ip, sp, int(ty), float(score))
         conn_pos = len(txt)
         txt += _pad_to(conn.encode() + b"\0", 8)
+        # SpecialTokenType: NONE 0, BOS 1, EOS 2, PAD 3, MAX 8 (convert_flm.py:50-57)
         special = [-1] * 8
         special[1], special[2], special[3] = t.bos, t.eos, t.pad
         blob = struct.pack("<II", t.vocab_type, conn_pos) + struct.pack("<8i", *special)
