@@ -61,6 +61,9 @@ struct flm_ctx {
 
     // options
     int wg_per_cu = 1; int use_graph = 1; int ablate = 0;
+    int use_prefill = 1;                               // option "use_prefill": prompts of >= kPrefillMin+1 tokens go through the batched kernels
+    int pf_cap = 0;                                    // token capacity of the batched-prefill buffers below
+    float *pf_x = nullptr, *pf_qkv = nullptr, *pf_q = nullptr, *pf_att = nullptr, *pf_gu = nullptr, *pf_hd = nullptr, *pf_xs = nullptr; void* pf_xq = nullptr;
     int use_ring = 0;                                  // option "use_ring": LDS weight ring (direct-to-LDS loads) in the rmsnorm GEMVs; measured neutral on MI355X (the
                                                        // extra 64 KiB/CU in flight shorten the stream by ~1.3 us and lengthen the prologue by as much), so off
     int use_mega = 0;                                  // option "use_mega": run single-GPU tokens as ONE persistent kernel (k_token); opt-in until it beats the per-phase kernels
@@ -504,6 +507,96 @@ int check_ready(flm_ctx* c, int n, int pos) {
     return FLM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Batched prefill of B prompt tokens at positions pos .. pos+B-1 (single GPU): leaves their K/V rows in the cache, exactly
+// the rows the token-by-token path would write (flm_kernels.h, "Batched prefill").  The prompt's LAST token is not part
+// of the batch: it runs through the decode kernels and produces the logits.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPrefillMin = 4;
+
+int ensure_prefill_bufs(flm_ctx* c, int B) {
+    if (B <= c->pf_cap) return FLM_OK;
+    void* old[] = {c->pf_x, c->pf_qkv, c->pf_q, c->pf_att, c->pf_gu, c->pf_hd, c->pf_xs, c->pf_xq};
+    for (void* p : old) if (p) hipFree(p);
+    c->pf_x = c->pf_qkv = c->pf_q = c->pf_att = c->pf_gu = c->pf_hd = c->pf_xs = nullptr; c->pf_xq = nullptr; c->pf_cap = 0;
+    const auto& d = c->d;
+    const size_t cap = B < 64 ? 64 : (size_t)B, nmax = d.hidden_dim > d.dim ? d.hidden_dim : d.dim;
+    HIPC(c, hipMalloc((void**)&c->pf_x, cap * d.dim * 4));
+    HIPC(c, hipMalloc((void**)&c->pf_qkv, cap * 3 * d.dim * 4));
+    HIPC(c, hipMalloc((void**)&c->pf_q, cap * d.dim * 4));
+    HIPC(c, hipMalloc((void**)&c->pf_att, cap * d.dim * 4));
+    HIPC(c, hipMalloc((void**)&c->pf_gu, cap * 2 * d.hidden_dim * 4));
+    HIPC(c, hipMalloc((void**)&c->pf_hd, cap * d.hidden_dim * 4));
+    HIPC(c, hipMalloc((void**)&c->pf_xs, cap * (nmax / kGroup) * 4));
+    HIPC(c, hipMalloc(&c->pf_xq, cap * nmax * c->esz));
+    c->pf_cap = (int)cap;
+    return FLM_OK;
+}
+
+template <int QT, int PRO>
+int launch_rows(flm_ctx* c, hipStream_t st, const RowsArgs& r, int B) {
+    const size_t lds = (size_t)gemv_lds_layout(r.n, QTraits<QT>::kEsz, true, 4, 4, false).total;
+    const int rounds = (r.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4);
+    if (rounds <= 1)      hipLaunchKernelGGL((k_rows_prologue<QT, PRO, 1>), dim3(B), dim3(kGemvBlock), lds, st, r);
+    else if (rounds <= 3) hipLaunchKernelGGL((k_rows_prologue<QT, PRO, 3>), dim3(B), dim3(kGemvBlock), lds, st, r);
+    else                  hipLaunchKernelGGL((k_rows_prologue<QT, PRO, 0>), dim3(B), dim3(kGemvBlock), lds, st, r);
+    HIPC(c, hipGetLastError());
+    return FLM_OK;
+}
+template <int QT, int EPI>
+int launch_gemm(flm_ctx* c, hipStream_t st, const GemmArgs& g) {
+    const int tiles = ((g.rows + 63) / 64) * ((g.B + 63) / 64);
+    hipLaunchKernelGGL((k_gemm_q<QT, EPI>), dim3(tiles), dim3(256), 0, st, g);
+    HIPC(c, hipGetLastError());
+    return FLM_OK;
+}
+
+template <int QT>
+int prefill_batched(flm_ctx* c, int B, int pos) {
+    const auto& d = c->d;
+    const int L = d.n_layers, dim = d.dim, hid = d.hidden_dim, hs = c->hs;
+    hipStream_t st = c->stream;
+    int r = ensure_prefill_bufs(c, B); if (r) return r;
+    const size_t kv_layer = (size_t)c->heads_local * d.max_seq_len * hs;
+    hipLaunchKernelGGL(k_embed_rows, dim3(B), dim3(256), 0, st, c->pf_x, (const void*)c->emb, (const float*)c->emb_s, c->emb_qt, dim, (const int*)c->prompt_dev);
+    HIPC(c, hipGetLastError());
+    for (int l = 0; l < L; ++l) {
+        LayerW& w = c->layers[l];
+        // x2 = rmsnorm(x1); qx = quantize(x2); q,k,v = W x; RoPE; cache rows   (transformer.cpp:132-135, 386-395, 431-439)
+        RowsArgs ra{c->pf_x, w.att_norm, c->pf_xq, c->pf_xs, dim};
+        r = launch_rows<QT, PRO_RMSNORM_QUANT>(c, st, ra, B); if (r) return r;
+        GemmArgs g{w.qkv.q, w.qkv.s, c->pf_xq, c->pf_xs, c->pf_qkv, 3 * dim, dim, 3 * dim, B};
+        r = launch_gemm<QT, EPI_STORE>(c, st, g); if (r) return r;
+        hipLaunchKernelGGL(k_rope_kv_rows, dim3(B), dim3(256), 0, st, (const float*)c->pf_qkv, c->pf_q, c->kcache + (size_t)l * kv_layer, c->vcache + (size_t)l * kv_layer,
+                           (const float*)c->rope_cos, (const float*)c->rope_sin, dim, hs, d.max_seq_len, pos);
+        HIPC(c, hipGetLastError());
+        if (l == L - 1) break;                            // the batch only has to fill the cache: nothing downstream of the last layer's K/V is needed
+        // attention of every query over the cache rows 0 .. its own position   (execute_attn :441-449)
+        AttnArgs aa{}; aa.q = c->pf_q; aa.kcache = c->kcache + (size_t)l * kv_layer; aa.vcache = c->vcache + (size_t)l * kv_layer;
+        aa.out = c->pf_att; aa.pos_ptr = &c->state->pos; aa.hs = hs; aa.max_seq = d.max_seq_len;
+        hipLaunchKernelGGL(k_attn_prefill, dim3(c->heads_local, B), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, hs), st, aa, pos, dim);
+        HIPC(c, hipGetLastError());
+        // x1 += Wo quantize(att)   (transformer.cpp:138-139, 457-466)
+        RowsArgs rq{c->pf_att, nullptr, c->pf_xq, c->pf_xs, dim};
+        r = launch_rows<QT, PRO_QUANT>(c, st, rq, B); if (r) return r;
+        GemmArgs go{w.o.q, w.o.s, c->pf_xq, c->pf_xs, c->pf_x, dim, dim, dim, B};
+        r = launch_gemm<QT, EPI_RESIDUAL>(c, st, go); if (r) return r;
+        // hd = swiglu(W1 qx, W3 qx) with qx = quantize(rmsnorm(x1))   (transformer.cpp:144-147, 468-483)
+        RowsArgs rf{c->pf_x, w.ffn_norm, c->pf_xq, c->pf_xs, dim};
+        r = launch_rows<QT, PRO_RMSNORM_QUANT>(c, st, rf, B); if (r) return r;
+        GemmArgs g13{w.w13.q, w.w13.s, c->pf_xq, c->pf_xs, c->pf_gu, 2 * hid, dim, 2 * hid, B};
+        r = launch_gemm<QT, EPI_STORE>(c, st, g13); if (r) return r;
+        hipLaunchKernelGGL(k_swiglu_rows, dim3(B), dim3(256), 0, st, c->pf_hd, (const float*)c->pf_gu, hid);
+        HIPC(c, hipGetLastError());
+        // x1 += W2 quantize(hd)   (transformer.cpp:149-150, 485-494)
+        RowsArgs rh{c->pf_hd, nullptr, c->pf_xq, c->pf_xs, hid};
+        r = launch_rows<QT, PRO_QUANT>(c, st, rh, B); if (r) return r;
+        GemmArgs g2{w.w2.q, w.w2.s, c->pf_xq, c->pf_xs, c->pf_x, dim, hid, dim, B};
+        r = launch_gemm<QT, EPI_RESIDUAL>(c, st, g2); if (r) return r;
+    }
+    return FLM_OK;
+}
+
 // feed tokens[0..n) sequentially (row i of the reference's batched prefill depends only on rows
 // <= i through the KV cache, so token-by-token evaluation performs the same per-row arithmetic).
 int feed(flm_ctx* c, const int32_t* tokens, int n, int pos, int final_advance) {
@@ -511,6 +604,14 @@ int feed(flm_ctx* c, const int32_t* tokens, int n, int pos, int final_advance) {
     if (r) return r;
     for (int i = 0; i < n; ++i) if (tokens[i] < 0 || tokens[i] >= c->d.vocab_size) return fail(c, FLM_ERR_INVALID, "token id out of range");
     HIPC(c, hipMemcpyAsync(c->prompt_dev, tokens, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
+    if (c->use_prefill && c->world == 1 && n - 1 >= kPrefillMin && c->hidden_local == c->d.hidden_dim) {
+        // all tokens but the last in one batch (cache rows only), then the last one through the decode kernels
+        r = c->d.quant_type == FLM_QT_INT8 ? prefill_batched<QT_INT8>(c, n - 1, pos) : prefill_batched<QT_INT16>(c, n - 1, pos);
+        if (r) return r;
+        DecodeState s{pos + n - 1, tokens[n - 1], 0, 0};
+        HIPC(c, hipMemcpyAsync(c->state, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
+        return run_token(c, true, final_advance);
+    }
     DecodeState s{pos, tokens[0], 0, 0};
     HIPC(c, hipMemcpyAsync(c->state, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
     for (int i = 0; i + 1 < n; ++i) { r = run_token(c, false, 2); if (r) return r; }
@@ -647,7 +748,8 @@ void flm_ctx_destroy(flm_ctx* c) {
     fq(c->cls);
     void* ptrs[] = {c->emb, c->emb_s, c->out_norm, c->kcache, c->vcache, c->x1, c->qbuf, c->att_out, c->hd,
                     c->logits, c->rope_cos, c->rope_sin, c->state, c->prompt_dev, c->out_tokens_dev,
-                    c->mega_gemv, c->mega_attn, c->mega_bar, c->mega_err, c->trace};
+                    c->mega_gemv, c->mega_attn, c->mega_bar, c->mega_err, c->trace,
+                    c->pf_x, c->pf_qkv, c->pf_q, c->pf_att, c->pf_gu, c->pf_hd, c->pf_xs, c->pf_xq};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->comm) ncclCommDestroy(c->comm);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -661,6 +763,7 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (k == "use_graph") c->use_graph = value;
     else if (k == "ablate") { c->ablate = value; c->mega_ok = -1; }
     else if (k == "use_mega") c->use_mega = value;
+    else if (k == "use_prefill") c->use_prefill = value;
     else if (k == "use_ring") { c->use_ring = value; c->mega_ok = -1; }
     else if (k == "trace") {        // value = kernel class to trace (KC_*), -1 off; meaningful in FLM_ABLATE builds only
         c->trace_class = value;

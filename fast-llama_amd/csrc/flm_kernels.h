@@ -831,11 +831,10 @@ __host__ inline size_t attn_lds_bytes(int max_seq, int hs) { return (size_t)(hs 
 
 // NF = 16-byte pieces of a tile per thread = ceil(hs / 64)
 template <int NF>
-__device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* lds) {
+__device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     constexpr int D = kAttnDepth;
     const int hs = a.hs, tid = threadIdx.x;
-    const int T = *a.pos_ptr + 1;
     auto stamp = [&](int k) { if (kAblate && a.trace && threadIdx.x == 0) a.trace[h * 8 + k] = __builtin_amdgcn_s_memtime(); };
     stamp(0);
     constexpr int rs = NF * 64 + 8;
@@ -885,7 +884,7 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
     for (int u = 0; u < D; ++u) request(rK, u, ringK[u]);
 #pragma unroll
     for (int u = 0; u < D; ++u) request(rV, u, ringV[u]);
-    for (int d = tid; d < hs; d += kAttnBlock) qs[d] = ld_agent(a.q + (size_t)h * hs + d);
+    for (int d = tid; d < hs; d += kAttnBlock) qs[d] = ld_agent(qrow + (size_t)h * hs + d);
 
     // ---- scores: lane = (position p, strided accumulator k) -- the 8 lanes of dot_product_avx256; each lane's
     //      chain is i ascending, then the 8 partials are added 0..7 (lane k = 0 collects them with DPP row shifts).
@@ -1012,11 +1011,18 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
         }
     }
     stamp(4);
-    if (tid < hs) st_agent(a.out + (size_t)h * hs + tid, o);
+    if (tid < hs) st_agent(orow + (size_t)h * hs + tid, o);
     __syncthreads();                                                // the LDS is free for whoever runs next on it (k_token)
 }
-__device__ __forceinline__ void attn_head_any(const AttnArgs& a, const int h, char* lds) {
-    if (a.hs <= 64) attn_head<1>(a, h, lds); else if (a.hs <= 128) attn_head<2>(a, h, lds); else attn_head<4>(a, h, lds);
+__device__ __forceinline__ void attn_head_any(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow) {
+    if (a.hs <= 64) attn_head<1>(a, h, lds, T, qrow, orow); else if (a.hs <= 128) attn_head<2>(a, h, lds, T, qrow, orow); else attn_head<4>(a, h, lds, T, qrow, orow);
+}
+__device__ __forceinline__ void attn_head_any(const AttnArgs& a, const int h, char* lds) { attn_head_any(a, h, lds, *a.pos_ptr + 1, a.q, a.out); }
+// batched prefill: workgroup (h, i) is query i of the batch, at position pos0 + i, over the cache rows 0 .. pos0 + i
+__global__ void __launch_bounds__(kAttnBlock) k_attn_prefill(const AttnArgs a, int pos0, int row_stride) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int i = blockIdx.y;
+    attn_head_any(a, blockIdx.x, lds, pos0 + i + 1, a.q + (size_t)i * row_stride, a.out + (size_t)i * row_stride);
 }
 __global__ void __launch_bounds__(kAttnBlock) k_attn_decode(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -1237,6 +1243,182 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_token(const TokenArgs t) {
         token_phase<QT, PRO_QUANT, EPI_RESIDUAL, false>(t, ga + 3, nullptr, lds, ts, 1);              // FFN2 + residual
     }
     if (t.with_cls) token_phase<QT, PRO_RMSNORM_QUANT, EPI_STORE, false>(t, t.gemv + 4 * t.n_layers, nullptr, lds, ts, 1);   // final norm + classifier
+}
+
+// ------------------------------------------------------------------------------------------
+// Batched prefill (ParallelTransformer::forward with bs > 1, transformer.cpp:105-161).  A prompt's tokens before the
+// last one only have to leave their K/V rows in the cache; every (token, row) value is produced by the SAME chain as in
+// the single-token kernels (group dots exact, acc = fma(sW*sX, float(dot), acc) with groups ascending; per-row rmsnorm
+// chains; per-query attention), so the cache -- and therefore the logits of the last token, which runs through the
+// decode kernels -- is bit-identical to feeding the prompt token by token, at a fraction of the time: the weights are
+// streamed once per 64 tokens instead of once per token.
+//   k_embed_rows        x[b] = embedding[token b]
+//   k_rows_prologue     per token row: (rmsnorm,) quantize -> xq[b], xs[b]   (the decode prologue, one workgroup per row)
+//   k_gemm_q            out[b][r] (+)= W[r] . xq[b] for a 64 x 64 (rows x tokens) tile per workgroup
+//   k_rope_kv_rows      RoPE on q and k of every token, K/V rows appended to the cache
+//   k_attn_prefill      causal attention: one workgroup per (head, query), the decode attention with T = pos + i + 1
+//   k_swiglu_rows       hd[b] = swiglu(gate[b], up[b])
+// ------------------------------------------------------------------------------------------
+__global__ void k_embed_rows(float* x, const void* emb, const float* emb_s, int emb_qt, int dim, const int* tokens) {
+    const int tok = tokens[blockIdx.x];
+    float* xo = x + (size_t)blockIdx.x * dim;
+    for (int e = threadIdx.x; e < dim; e += blockDim.x) {
+        float v;
+        if (emb_qt == 0) v = reinterpret_cast<const float*>(emb)[(size_t)tok * dim + e];
+        else {
+            const float s = emb_s[((size_t)tok * dim + e) / kGroup];
+            const int q = emb_qt == QT_INT8 ? (int)reinterpret_cast<const int8_t*>(emb)[(size_t)tok * dim + e]
+                                            : (int)reinterpret_cast<const int16_t*>(emb)[(size_t)tok * dim + e];
+            v = __fmul_rn((float)q, s);                              // dequantize_ quant_operators.cpp:49-65
+        }
+        xo[e] = v;
+    }
+}
+
+struct RowsArgs {
+    const float* x;          // [B][n]
+    const float* norm_w;     // [n] (RMSNORM_QUANT)
+    void* xq; float* xs;     // [B][n] quantized, [B][n/64] scales
+    int n;
+};
+template <int QT, int PRO, int XR>
+__global__ void __launch_bounds__(kGemvBlock) k_rows_prologue(const RowsArgs r) {
+    using T = QTraits<QT>;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    GemvArgs a{};
+    a.n = r.n; a.x = r.x + (size_t)blockIdx.x * r.n; a.norm_w = r.norm_w;
+    a.rows_per_pass = 4; a.cb_shift = 4;                                     // (only the fixed LDS offsets are used)
+    float4 xv[XR > 0 ? XR : 1], nv[XR > 0 ? XR : 1];
+    gemv_preload<QT, PRO, XR>(a, xv, nv);
+    gemv_prologue<QT, PRO, XR>(a, lds, xv, nv, []() {});
+    const GemvLds L = gemv_lds_layout(r.n, T::kEsz, true, 4, 4, false);
+    const int nb16 = r.n * T::kEsz / 16, sn = r.n / kGroup;
+    int4* qo = reinterpret_cast<int4*>(reinterpret_cast<char*>(r.xq) + (size_t)blockIdx.x * r.n * T::kEsz);
+    for (int c = threadIdx.x; c < nb16; c += kGemvBlock) qo[c] = reinterpret_cast<const int4*>(lds)[c];
+    const float* xs = reinterpret_cast<const float*>(lds + L.off_xs);
+    for (int g = threadIdx.x; g < sn; g += kGemvBlock) r.xs[(size_t)blockIdx.x * sn + g] = xs[g];
+}
+
+struct GemmArgs {
+    const void* W; const float* sW;      // [rows][n], [rows][n/64]
+    const void* Xq; const float* Xs;     // [B][n], [B][n/64]
+    float* out; int ldo;                 // out[b * ldo + row]
+    int n, rows, B;
+};
+// One workgroup: 64 rows x 64 tokens, thread (ty, tx) owns rows 4ty..4ty+3 x tokens 4tx..4tx+3.  Per quant group the
+// 64-row and 64-token slices (64 or 128 bytes each) go through LDS (double buffered; rows padded by 16 B: conflict-free
+// 16-byte reads), int32 dots with v_dot4 / v_dot2, then the reference's fp32 chain step for the 16 outputs of the thread.
+template <int QT, int EPI>
+__global__ void __launch_bounds__(256) k_gemm_q(const GemmArgs a) {
+    using T = QTraits<QT>;
+    constexpr int GB = kGroup * T::kEsz;          // bytes of a group in one row
+    constexpr int NCH = GB / 16;                  // 16-byte chunks per group
+    constexpr int LS = GB + 16;                   // LDS row stride
+    constexpr int NLD = 64 * NCH / 256;           // 16-byte pieces per thread and tile
+    __shared__ __attribute__((aligned(16))) char Wt[2][64 * LS];
+    __shared__ __attribute__((aligned(16))) char Xt[2][64 * LS];
+    __shared__ float sWt[2][64], sXt[2][64];
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int ntt = (a.B + 63) / 64;
+    const int r0 = (blockIdx.x / ntt) * 64, b0 = (blockIdx.x % ntt) * 64;   // token tile fastest: neighbours share the weight rows
+    const int sn = a.n / kGroup;
+    const size_t rowbytes = (size_t)a.n * T::kEsz;
+    const char* Wb = reinterpret_cast<const char*>(a.W);
+    const char* Xb = reinterpret_cast<const char*>(a.Xq);
+    v4i wr[NLD], xr[NLD]; float sr = 0.f;
+    auto fetch = [&](int g) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = tid + k * 256, row = idx / NCH, ch = idx % NCH;
+            wr[k] = (r0 + row < a.rows) ? *reinterpret_cast<const v4i*>(Wb + (size_t)(r0 + row) * rowbytes + (size_t)g * GB + ch * 16) : v4i{0, 0, 0, 0};
+            xr[k] = (b0 + row < a.B)    ? *reinterpret_cast<const v4i*>(Xb + (size_t)(b0 + row) * rowbytes + (size_t)g * GB + ch * 16) : v4i{0, 0, 0, 0};
+        }
+        if (tid < 64) sr = (r0 + tid < a.rows) ? a.sW[(size_t)(r0 + tid) * sn + g] : 0.f;
+        else if (tid < 128) sr = (b0 + tid - 64 < a.B) ? a.Xs[(size_t)(b0 + tid - 64) * sn + g] : 0.f;
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = tid + k * 256, row = idx / NCH, ch = idx % NCH;
+            *reinterpret_cast<v4i*>(&Wt[buf][row * LS + ch * 16]) = wr[k];
+            *reinterpret_cast<v4i*>(&Xt[buf][row * LS + ch * 16]) = xr[k];
+        }
+        if (tid < 64) sWt[buf][tid] = sr; else if (tid < 128) sXt[buf][tid - 64] = sr;
+    };
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    fetch(0); park(0);
+    __syncthreads();
+    for (int g = 0; g < sn; ++g) {
+        const int buf = g & 1;
+        if (g + 1 < sn) fetch(g + 1);
+        int d[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[i][j] = 0;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            v4i w[4], x[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[i] = *reinterpret_cast<const v4i*>(&Wt[buf][(ty * 4 + i) * LS + ch * 16]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = *reinterpret_cast<const v4i*>(&Xt[buf][(tx * 4 + j) * LS + ch * 16]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (QT == QT_INT8) d[i][j] = dot16_i8(w[i], x[j], d[i][j]); else d[i][j] = dot8_i16(w[i], x[j], d[i][j]);
+                }
+        }
+        float sw[4], sx[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sw[i] = sWt[buf][ty * 4 + i]; sx[i] = sXt[buf][tx * 4 + i]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __fmaf_rn(__fmul_rn(sw[i], sx[j]), (float)d[i][j], acc[i][j]);   // quant_operators.cpp:274
+        if (g + 1 < sn) park(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int b = b0 + tx * 4 + j;
+        if (b >= a.B) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = r0 + ty * 4 + i;
+            if (row >= a.rows) continue;
+            float* o = a.out + (size_t)b * a.ldo + row;
+            if constexpr (EPI == EPI_RESIDUAL) *o = __fadd_rn(*o, acc[i][j]); else *o = acc[i][j];
+        }
+    }
+}
+
+// qkv[b] = [q ; k ; v] (dim each) of token b at position pos0 + b: RoPE on q and k (rope_v2 pairs), q -> qout[b], k / v -> cache rows
+__global__ void k_rope_kv_rows(const float* qkv, float* qout, float* kcache, float* vcache, const float* rope_cos, const float* rope_sin,
+                               int dim, int hs, int max_seq, int pos0) {
+    const int b = blockIdx.x, pos = pos0 + b;
+    const float* in = qkv + (size_t)b * 3 * dim;
+    for (int i = threadIdx.x; i < dim / 2; i += blockDim.x) {
+        const int row = 2 * i, h = row / hs, d = row - h * hs;
+        const float c = rope_cos[(size_t)pos * (hs / 2) + d / 2], s = rope_sin[(size_t)pos * (hs / 2) + d / 2];
+        float o0, o1;
+        rope_pair(in[row], in[row + 1], c, s, o0, o1);
+        qout[(size_t)b * dim + row] = o0; qout[(size_t)b * dim + row + 1] = o1;
+        rope_pair(in[dim + row], in[dim + row + 1], c, s, o0, o1);
+        float* kp = kcache + ((size_t)h * max_seq + pos) * hs + d; kp[0] = o0; kp[1] = o1;
+        float* vp = vcache + ((size_t)h * max_seq + pos) * hs + d; vp[0] = in[2 * dim + row]; vp[1] = in[2 * dim + row + 1];
+    }
+}
+
+__global__ void k_swiglu_rows(float* hd, const float* gu, int hidden) {
+    const float* g = gu + (size_t)blockIdx.x * 2 * hidden;
+    float* o = hd + (size_t)blockIdx.x * hidden;
+    for (int i = threadIdx.x; i < hidden; i += blockDim.x) o[i] = swiglu_elem(g[i], g[hidden + i]);   // o1.swiglu(o3) transformer.cpp:481
 }
 
 // ------------------------------------------------------------------------------------------

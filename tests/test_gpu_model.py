@@ -104,6 +104,39 @@ def test_7b_width_layer_every_code_path_vs_oracle(gpu, qt):
         ctx.close()
 
 
+@pytest.mark.parametrize("shape,qt,layers,n", [("tiny", ff.QT_INT8, None, 70), ("tiny128", ff.QT_INT16, None, 33), ("small", ff.QT_INT8, None, 129),
+                                               ("small", ff.QT_INT16, None, 65), ("7B", ff.QT_INT8, 2, 67)])
+def test_batched_prefill_is_bit_identical_to_token_by_token(gpu, shape, qt, layers, n):
+    """prompts go through the batched kernels (GEMM tiles, per-row prologues, causal attention); the cache rows they leave and
+    the logits of the last token must be the bits of the token-by-token path (and of the oracle)"""
+    cfg = synth.make_config(shape, qt)
+    if layers:
+        cfg.n_layers = layers
+    tensors = synth.make_tensors(cfg, seed=8)
+    prompt = _prompt(cfg.vocab_size, n)
+    outs = {}
+    for mode in (0, 1):
+        ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
+        ctx.set_option("use_prefill", mode)
+        lg = ctx.forward(prompt[:5], 0)                       # short prompts stay on the token-by-token path
+        lg = ctx.forward(prompt[5:], 5)                       # the batch starts at a non-zero position
+        kv = [ctx.debug_read("kcache", l, cfg.n_heads * cfg.max_length * cfg.head_size).reshape(cfg.n_heads, cfg.max_length, -1)[:, :n].copy()
+              for l in range(cfg.n_layers)]
+        vv = [ctx.debug_read("vcache", l, cfg.n_heads * cfg.max_length * cfg.head_size).reshape(cfg.n_heads, cfg.max_length, -1)[:, :n].copy()
+              for l in range(cfg.n_layers)]
+        nxt = ctx.forward(np.array([int(np.argmax(lg))], np.int32), n)
+        outs[mode] = (lg, kv, vv, nxt)
+        ctx.close()
+    assert bits_equal(outs[0][0], outs[1][0])
+    for l in range(cfg.n_layers):
+        assert bits_equal(outs[0][1][l], outs[1][1][l]), f"K cache layer {l}"
+        assert bits_equal(outs[0][2][l], outs[1][2][l]), f"V cache layer {l}"
+    assert bits_equal(outs[0][3], outs[1][3])
+    if shape != "7B":
+        om = O.OracleModel(cfg, tensors)
+        assert bits_equal(outs[1][0], om.forward(prompt, 0))
+
+
 def test_long_context_positions(gpu):
     """positions up to max_seq_len-1 (1024 clamp, transformer.cpp:32): prefill 1000 tokens on the GPU and the oracle."""
     cfg = synth.make_config("tiny", ff.QT_INT8)
