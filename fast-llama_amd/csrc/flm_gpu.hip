@@ -61,6 +61,7 @@ struct flm_ctx {
 
     // options
     int wg_per_cu = 1; int use_graph = 1; int ablate = 0;
+    int use_mfma = 1;                                  // option "use_mfma": int8 prefill GEMM on v_mfma_i32_32x32x32_i8 (0: v_dot4)
     int use_prefill = 1;                               // option "use_prefill": prompts of >= kPrefillMin+1 tokens go through the batched kernels
     int pf_cap = 0;                                    // token capacity of the batched-prefill buffers below
     float *pf_x = nullptr, *pf_qkv = nullptr, *pf_q = nullptr, *pf_att = nullptr, *pf_gu = nullptr, *pf_hd = nullptr, *pf_xs = nullptr; void* pf_xq = nullptr;
@@ -546,7 +547,8 @@ int launch_rows(flm_ctx* c, hipStream_t st, const RowsArgs& r, int B) {
 template <int QT, int EPI>
 int launch_gemm(flm_ctx* c, hipStream_t st, const GemmArgs& g) {
     const int tiles = ((g.rows + 63) / 64) * ((g.B + 63) / 64);
-    hipLaunchKernelGGL((k_gemm_q<QT, EPI>), dim3(tiles), dim3(256), 0, st, g);
+    if (QT == QT_INT8 && c->use_mfma) hipLaunchKernelGGL((k_gemm_q8_mfma<EPI>), dim3(tiles), dim3(256), 0, st, g);   // matrix cores: exact int32 group dots
+    else hipLaunchKernelGGL((k_gemm_q<QT, EPI>), dim3(tiles), dim3(256), 0, st, g);
     HIPC(c, hipGetLastError());
     return FLM_OK;
 }
@@ -764,6 +766,7 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (k == "ablate") { c->ablate = value; c->mega_ok = -1; }
     else if (k == "use_mega") c->use_mega = value;
     else if (k == "use_prefill") c->use_prefill = value;
+    else if (k == "use_mfma") c->use_mfma = value;
     else if (k == "use_ring") { c->use_ring = value; c->mega_ok = -1; }
     else if (k == "trace") {        // value = kernel class to trace (KC_*), -1 off; meaningful in FLM_ABLATE builds only
         c->trace_class = value;

@@ -1398,6 +1398,79 @@ __global__ void __launch_bounds__(256) k_gemm_q(const GemmArgs a) {
     }
 }
 
+// The int8 GEMM on the matrix cores (gfx950 v_mfma_i32_32x32x32_i8): same 64 x 64 workgroup tile, four waves each owning a
+// 32 x 32 (rows x tokens) quadrant.  Per quant group two MFMAs (K = 2 x 32) accumulate the group's 1024 int32 dots exactly
+// (integer sums are order-free; A and B use the same byte -> k assignment: lane half h takes bytes 32kk + 16h .. +15 of the
+// group); then every lane applies the reference's fp32 chain step to its 16 results -- that VALU work, not the MFMA, is what
+// bounds the kernel.  C/D layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+typedef int v16i __attribute__((ext_vector_type(16)));
+template <int EPI>
+__global__ void __launch_bounds__(256) k_gemm_q8_mfma(const GemmArgs a) {
+    constexpr int GB = kGroup;                    // bytes of a group in one row (int8)
+    constexpr int LS = GB + 16;                   // LDS row stride
+    __shared__ __attribute__((aligned(16))) char Wt[2][64 * LS];
+    __shared__ __attribute__((aligned(16))) char Xt[2][64 * LS];
+    __shared__ __attribute__((aligned(16))) float sWt[2][64];
+    __shared__ float sXt[2][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntt = (a.B + 63) / 64;
+    const int r0 = (blockIdx.x / ntt) * 64, b0 = (blockIdx.x % ntt) * 64;   // token tile fastest: neighbours share the weight rows
+    const int wr0 = (wave >> 1) * 32, wc0 = (wave & 1) * 32;                // this wave's quadrant inside the tile
+    const int sn = a.n / kGroup;
+    const size_t rowbytes = (size_t)a.n;
+    const char* Wb = reinterpret_cast<const char*>(a.W);
+    const char* Xb = reinterpret_cast<const char*>(a.Xq);
+    v4i wr, xr; float sr = 0.f;
+    const int lrow = tid >> 2, lch = tid & 3;                               // loader: 64 rows x 4 chunks of 16 B
+    auto fetch = [&](int g) {
+        wr = (r0 + lrow < a.rows) ? *reinterpret_cast<const v4i*>(Wb + (size_t)(r0 + lrow) * rowbytes + (size_t)g * GB + lch * 16) : v4i{0, 0, 0, 0};
+        xr = (b0 + lrow < a.B)    ? *reinterpret_cast<const v4i*>(Xb + (size_t)(b0 + lrow) * rowbytes + (size_t)g * GB + lch * 16) : v4i{0, 0, 0, 0};
+        if (tid < 64) sr = (r0 + tid < a.rows) ? a.sW[(size_t)(r0 + tid) * sn + g] : 0.f;
+        else if (tid < 128) sr = (b0 + tid - 64 < a.B) ? a.Xs[(size_t)(b0 + tid - 64) * sn + g] : 0.f;
+    };
+    auto park = [&](int buf) {
+        *reinterpret_cast<v4i*>(&Wt[buf][lrow * LS + lch * 16]) = wr;
+        *reinterpret_cast<v4i*>(&Xt[buf][lrow * LS + lch * 16]) = xr;
+        if (tid < 64) sWt[buf][tid] = sr; else if (tid < 128) sXt[buf][tid - 64] = sr;
+    };
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int am = wr0 + (lane & 31), bn = wc0 + (lane & 31), kh = (lane >> 5) * 16;
+    fetch(0); park(0);
+    __syncthreads();
+    for (int g = 0; g < sn; ++g) {
+        const int buf = g & 1;
+        if (g + 1 < sn) fetch(g + 1);
+        const v4i a0 = *reinterpret_cast<const v4i*>(&Wt[buf][am * LS + kh]), a1 = *reinterpret_cast<const v4i*>(&Wt[buf][am * LS + 32 + kh]);
+        const v4i x0 = *reinterpret_cast<const v4i*>(&Xt[buf][bn * LS + kh]), x1 = *reinterpret_cast<const v4i*>(&Xt[buf][bn * LS + 32 + kh]);
+        v16i d = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        d = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, x0, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, x1, d, 0, 0, 0);
+        const float sx = sXt[buf][bn];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 sw = *reinterpret_cast<const float4*>(&sWt[buf][wr0 + 8 * q + 4 * (lane >> 5)]);
+            acc[4 * q + 0] = __fmaf_rn(__fmul_rn(sw.x, sx), (float)d[4 * q + 0], acc[4 * q + 0]);   // quant_operators.cpp:274
+            acc[4 * q + 1] = __fmaf_rn(__fmul_rn(sw.y, sx), (float)d[4 * q + 1], acc[4 * q + 1]);
+            acc[4 * q + 2] = __fmaf_rn(__fmul_rn(sw.z, sx), (float)d[4 * q + 2], acc[4 * q + 2]);
+            acc[4 * q + 3] = __fmaf_rn(__fmul_rn(sw.w, sx), (float)d[4 * q + 3], acc[4 * q + 3]);
+        }
+        if (g + 1 < sn) park(buf ^ 1);
+        __syncthreads();
+    }
+    const int b = b0 + bn;
+    if (b < a.B) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = r0 + wr0 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+            if (row >= a.rows) continue;
+            float* o = a.out + (size_t)b * a.ldo + row;
+            if constexpr (EPI == EPI_RESIDUAL) *o = __fadd_rn(*o, acc[i]); else *o = acc[i];
+        }
+    }
+}
+
 // qkv[b] = [q ; k ; v] (dim each) of token b at position pos0 + b: RoPE on q and k (rope_v2 pairs), q -> qout[b], k / v -> cache rows
 __global__ void k_rope_kv_rows(const float* qkv, float* qout, float* kcache, float* vcache, const float* rope_cos, const float* rope_sin,
                                int dim, int hs, int max_seq, int pos0) {

@@ -115,9 +115,9 @@ def test_batched_prefill_is_bit_identical_to_token_by_token(gpu, shape, qt, laye
     tensors = synth.make_tensors(cfg, seed=8)
     prompt = _prompt(cfg.vocab_size, n)
     outs = {}
-    for mode in (0, 1):
+    for mode in (0, 1, 2):                                      # 0 token by token, 1 batched (int8 GEMM on MFMA), 2 batched with v_dot4
         ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
-        ctx.set_option("use_prefill", mode)
+        ctx.set_option("use_prefill", 1 if mode else 0); ctx.set_option("use_mfma", 1 if mode == 1 else 0)
         lg = ctx.forward(prompt[:5], 0)                       # short prompts stay on the token-by-token path
         lg = ctx.forward(prompt[5:], 5)                       # the batch starts at a non-zero position
         kv = [ctx.debug_read("kcache", l, cfg.n_heads * cfg.max_length * cfg.head_size).reshape(cfg.n_heads, cfg.max_length, -1)[:, :n].copy()
@@ -127,11 +127,12 @@ def test_batched_prefill_is_bit_identical_to_token_by_token(gpu, shape, qt, laye
         nxt = ctx.forward(np.array([int(np.argmax(lg))], np.int32), n)
         outs[mode] = (lg, kv, vv, nxt)
         ctx.close()
-    assert bits_equal(outs[0][0], outs[1][0])
-    for l in range(cfg.n_layers):
-        assert bits_equal(outs[0][1][l], outs[1][1][l]), f"K cache layer {l}"
-        assert bits_equal(outs[0][2][l], outs[1][2][l]), f"V cache layer {l}"
-    assert bits_equal(outs[0][3], outs[1][3])
+    for m in (1, 2):
+        assert bits_equal(outs[0][0], outs[m][0]), m
+        for l in range(cfg.n_layers):
+            assert bits_equal(outs[0][1][l], outs[m][1][l]), f"mode {m}: K cache layer {l}"
+            assert bits_equal(outs[0][2][l], outs[m][2][l]), f"mode {m}: V cache layer {l}"
+        assert bits_equal(outs[0][3], outs[m][3]), m
     if shape != "7B":
         om = O.OracleModel(cfg, tensors)
         assert bits_equal(outs[1][0], om.forward(prompt, 0))
