@@ -87,7 +87,8 @@ int  flm_upload_tensor(flm_ctx* ctx, int kind, int layer, int src_qtype,
 
 /* ---- the hot path: replaces ParallelTransformer::forward (transformer.h:99, transformer.cpp:105-161).
  * tokens[n] enter at absolute position pos (pos = tokens already in the KV cache);
- * logits_host[vocab] = logits of the LAST token. */
+ * logits_host[vocab] = logits of the LAST token.  n > 5: the first n-1 tokens are evaluated as one batch (MFMA int8 GEMM,
+ * causal attention per query) that leaves the same cache rows as feeding them one by one -- bit-identical results. */
 int  flm_forward(flm_ctx* ctx, const int32_t* tokens, int n, int pos, float* logits_host);
 /* same + sample_argmax (src/transformer/sampler.cpp:36-47, first maximum wins) on the device */
 int  flm_forward_argmax(flm_ctx* ctx, const int32_t* tokens, int n, int pos, int32_t* next_token);
@@ -120,7 +121,8 @@ int  flm_debug_read(flm_ctx* ctx, int what, int layer, float* out, size_t n);
 
 /* tuning knobs: "wg_per_cu" workgroups per CU for the GEMV kernels, "use_graph" hipGraph replay on/off,
  * "use_mega" 1 = run single-GPU tokens as one persistent kernel (k_token; experimental, default 0),
- * "use_ring" 1 = LDS weight ring in the rmsnorm GEMVs (default 0) */
+ * "use_ring" 1 = LDS weight ring in the rmsnorm GEMVs (default 0), "use_prefill" 0 = feed prompts token by token
+ * (default 1: batched), "use_mfma" 0 = int8 prefill GEMM on v_dot4 instead of the matrix cores (default 1) */
 int  flm_set_option(flm_ctx* ctx, const char* key, int value);
 
 /* ---- op level: 1:1 mirrors of the reference operator seam, host pointers in / out, running the
