@@ -830,7 +830,9 @@ __host__ __device__ inline int attn_row_stride(int hs) { const int nf = hs <= 64
 __host__ inline size_t attn_lds_bytes(int max_seq, int hs) { return (size_t)(hs + 32 + ((max_seq + 3) & ~3) + 64 + (2 * kAttnTile + 4) * attn_row_stride(hs)) * 4; }   // + 4 slack rows: the PV read-ahead
 
 // NF = 16-byte pieces of a tile per thread = ceil(hs / 64)
-template <int NF>
+// COH: K/V/q were (partly) written by other workgroups of the SAME kernel (k_token) -> coherent sc0|sc1 loads; the
+// per-phase kernels read them after a kernel boundary and use ordinary cached loads
+template <int NF, bool COH>
 __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     constexpr int D = kAttnDepth;
@@ -872,7 +874,7 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
             const unsigned off = (tile < nt && t0 + prow[j] < T) ? (unsigned)(tile * tile_bytes + goff[j]) : 0x80000000u;
-            reg[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, kAuxCoherent));
+            reg[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, COH ? kAuxCoherent : 0));
         }
     };
     auto park = [&](float* buf, const v4f (&reg)[NF]) {
@@ -884,7 +886,7 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
     for (int u = 0; u < D; ++u) request(rK, u, ringK[u]);
 #pragma unroll
     for (int u = 0; u < D; ++u) request(rV, u, ringV[u]);
-    for (int d = tid; d < hs; d += kAttnBlock) qs[d] = ld_agent(qrow + (size_t)h * hs + d);
+    for (int d = tid; d < hs; d += kAttnBlock) qs[d] = COH ? ld_agent(qrow + (size_t)h * hs + d) : qrow[(size_t)h * hs + d];
 
     // ---- scores: lane = (position p, strided accumulator k) -- the 8 lanes of dot_product_avx256; each lane's
     //      chain is i ascending, then the 8 partials are added 0..7 (lane k = 0 collects them with DPP row shifts).
@@ -1014,19 +1016,19 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
     if (tid < hs) st_agent(orow + (size_t)h * hs + tid, o);
     __syncthreads();                                                // the LDS is free for whoever runs next on it (k_token)
 }
+template <bool COH>
 __device__ __forceinline__ void attn_head_any(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow) {
-    if (a.hs <= 64) attn_head<1>(a, h, lds, T, qrow, orow); else if (a.hs <= 128) attn_head<2>(a, h, lds, T, qrow, orow); else attn_head<4>(a, h, lds, T, qrow, orow);
+    if (a.hs <= 64) attn_head<1, COH>(a, h, lds, T, qrow, orow); else if (a.hs <= 128) attn_head<2, COH>(a, h, lds, T, qrow, orow); else attn_head<4, COH>(a, h, lds, T, qrow, orow);
 }
-__device__ __forceinline__ void attn_head_any(const AttnArgs& a, const int h, char* lds) { attn_head_any(a, h, lds, *a.pos_ptr + 1, a.q, a.out); }
 // batched prefill: workgroup (h, i) is query i of the batch, at position pos0 + i, over the cache rows 0 .. pos0 + i
 __global__ void __launch_bounds__(kAttnBlock) k_attn_prefill(const AttnArgs a, int pos0, int row_stride) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int i = blockIdx.y;
-    attn_head_any(a, blockIdx.x, lds, pos0 + i + 1, a.q + (size_t)i * row_stride, a.out + (size_t)i * row_stride);
+    attn_head_any<false>(a, blockIdx.x, lds, pos0 + i + 1, a.q + (size_t)i * row_stride, a.out + (size_t)i * row_stride);
 }
 __global__ void __launch_bounds__(kAttnBlock) k_attn_decode(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    attn_head_any(a, blockIdx.x, lds);
+    attn_head_any<false>(a, blockIdx.x, lds, *a.pos_ptr + 1, a.q, a.out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1212,7 +1214,7 @@ __device__ __attribute__((noinline)) void token_phase(const TokenArgs& t, const 
         grid_barrier(t, epoch);
         if (attn_wg) {   // one head per workgroup
             const AttnArgs aa = kload(aap);
-            for (int h = wg; h < t.n_heads; h += nwg) attn_head_any(aa, h, lds);
+            for (int h = wg; h < t.n_heads; h += nwg) attn_head_any<true>(aa, h, lds, *aa.pos_ptr + 1, aa.q, aa.out);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             prefetch();
         }
