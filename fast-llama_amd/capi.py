@@ -23,7 +23,7 @@ SYMBOLS = (
     "flm_forward", "flm_forward_argmax", "flm_decode_greedy", "flm_decode_timed", "flm_reset_kv", "flm_sync",
     "flm_kernel_times", "flm_kernel_bytes", "flm_set_option", "flm_debug_read",
     "flm_op_quantize", "flm_op_matmul_q", "flm_op_rmsnorm", "flm_op_swiglu", "flm_op_rope", "flm_op_softmax",
-    "flm_op_attention", "flm_op_expf", "flm_op_math", "flm_plan_shards",
+    "flm_op_attention", "flm_op_expf", "flm_op_math", "flm_op_square_sum", "flm_plan_shards",
 )
 
 
@@ -186,6 +186,14 @@ def op_rmsnorm(x, w):
     o = np.empty_like(x)
     _check(lib().flm_op_rmsnorm(_p(o), _p(x), _p(w), C.c_size_t(x.size)))
     return o
+
+
+def op_square_sum(x):
+    """-> (total from the wave-parallel evaluation, total from the sequential chains, the 4 strided partial sums)"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    o = np.empty(6, dtype=np.float32)
+    _check(lib().flm_op_square_sum(_p(x), C.c_size_t(x.size), _p(o)))
+    return o[0], o[1], o[2:6]
 
 
 def op_swiglu(xo, xr):

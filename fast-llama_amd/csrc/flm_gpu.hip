@@ -1040,6 +1040,19 @@ int flm_op_quantize(int qt, void* qx, float* qs, const float* x, size_t n, int g
     return FLM_OK;
 }
 
+// square_sum (x86_simd.cpp:942-960) of x[n], n a multiple of 16: out6 = { wave-parallel total, sequential total, the 4 strided lanes }
+int flm_op_square_sum(const float* x, size_t n, float* out6) {
+    if (!x || !out6 || n % 16 || n == 0 || n > 32768) return FLM_ERR_INVALID;
+    DevBuf dx, dout;
+    if (dx.alloc(n * 4) || dout.alloc(16 * 4)) return FLM_ERR_OOM;
+    OPC(hipMemcpy(dx.p, x, n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_op_square_sum, dim3(1), dim3(256), (n + 32 + 64) * 4, 0, dout.as<float>(), dx.as<float>(), (int)n);
+    OPC(hipGetLastError()); OPC(hipDeviceSynchronize());
+    OPC(hipMemcpy(out6, dout.p, 6 * 4, hipMemcpyDeviceToHost));
+    if (getenv("FLM_SQ_ITERS")) { float it[4]; hipMemcpy(it, (char*)dout.p + 24, 16, hipMemcpyDeviceToHost); fprintf(stderr, "sq_chain_wave iterations per chain: %g %g %g %g\n", it[0], it[1], it[2], it[3]); }
+    return FLM_OK;
+}
+
 int flm_op_rmsnorm(float* o, const float* x, const float* w, size_t n) {
     if (!o || !x || !w || n % kGroup || n > 16384 || n == 0) return FLM_ERR_INVALID;
     DevBuf dx, dw, dn, dq, ds;

@@ -289,6 +289,100 @@ __device__ __forceinline__ float sq_chain(const float* p, int n4) {
     return l;
 }
 
+// The same chain -- l <- fma(x_k, x_k, l), k ascending, bit for bit -- evaluated by a WHOLE WAVE in far fewer than n
+// dependent steps.  The terms are non-negative, so l only grows, and while l stays inside one binade [2^E, 2^(E+1)) every
+// step rounds l + x^2 to a multiple of u = ulp(l).  Within the binade the increment t_k = fl(l + x_k^2) - l does not depend
+// on l (except for exact ties): it is what ONE fma against the bottom of the binade gives, t_k = fma(x_k, x_k, 2^E) - 2^E,
+// a multiple of u, and sums of such multiples below 2^(E+1) are exact in fp32 in ANY order -- a prefix sum.  Lane L takes
+// elements 4L..4L+3 of a 256-element block, a wave scan adds them up.  Two kinds of element stop the scan: one on which l
+// leaves the binade (fma(x, x, l_before) >= 2^(E+1): the rounding unit changes) and one whose x^2 lies exactly halfway
+// between two multiples of u (round-half-even then looks at the parity of l: detected as |fma(x, x, -t)| == u/2).  The scan
+// commits everything before the first such element, that element takes one real fma, and the scan resumes behind it with the
+// new binade.  l doubles only ~log2(n) times over a chain, mostly within the first elements, which are simply run in order.
+// STATUS: exact (tests/test_gpu_ops.py::test_square_sum_wave_parallel_is_bit_exact, adversarial ties / overflow / denormals)
+// but NOT used by the product path: a lone wave pays ~7 cycles per instruction whatever it does, this formulation runs
+// ~150 instructions per scan round and needs 4 rounds + one per binade change (8-9 for n/4 = 1024), i.e. about as many
+// instructions as the 1024 dependent FMAs and their LDS reads (measured 7.1 us against 4.3 us in the prologue).  It pays
+// only below ~75 instructions per round; kept, tested, for the round that hand-schedules it.
+__device__ __forceinline__ float wave_scan_incl(float v) {
+#define FLM_SCAN_STEP(ctrl, rmask, bc) v = __fadd_rn(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xF, bc)));
+    FLM_SCAN_STEP(0x111 /* row_shr:1 */, 0xF, true) FLM_SCAN_STEP(0x112 /* row_shr:2 */, 0xF, true)
+    FLM_SCAN_STEP(0x114 /* row_shr:4 */, 0xF, true) FLM_SCAN_STEP(0x118 /* row_shr:8 */, 0xF, true)
+    FLM_SCAN_STEP(0x142 /* row_bcast:15 */, 0xA, false) FLM_SCAN_STEP(0x143 /* row_bcast:31 */, 0xC, false)
+#undef FLM_SCAN_STEP
+    return v;
+}
+__device__ __forceinline__ float sq_chain_wave(const float* p, int n4, int* iters = nullptr) {
+    const int lane = threadIdx.x & 63;
+    int n_it = 0;
+    constexpr int kHead = 64;                                      // elements run in order first (l crosses most binades here)
+    float acc = 0.f;
+    int k = 0;
+    for (; k + 4 <= n4 && k < kHead; k += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(p + k);
+        acc = __fmaf_rn(v.x, v.x, acc); acc = __fmaf_rn(v.y, v.y, acc); acc = __fmaf_rn(v.z, v.z, acc); acc = __fmaf_rn(v.w, v.w, acc);
+    }
+    for (int base = 0; base < n4; base += 256) {
+        const int e0 = base + 4 * lane;
+        float x0 = 0.f, x1 = 0.f, x2 = 0.f, x3 = 0.f;
+        if (e0 + 4 <= n4) { const float4 v = *reinterpret_cast<const float4*>(p + e0); x0 = v.x; x1 = v.y; x2 = v.z; x3 = v.w; }
+        else { if (e0 < n4) x0 = p[e0]; if (e0 + 1 < n4) x1 = p[e0 + 1]; if (e0 + 2 < n4) x2 = p[e0 + 2]; }
+        int done = k > base ? k - base : 0;                                                // elements of this block already consumed (uniform)
+        const int limit = (n4 - base) < 256 ? (n4 - base) : 256;
+        auto pick = [&](int i) { return i == 0 ? x0 : i == 1 ? x1 : i == 2 ? x2 : x3; };
+        while (done < limit) {
+            ++n_it;
+            const unsigned ab = __builtin_amdgcn_readfirstlane(__float_as_uint(acc));
+            const unsigned eb = ab & 0x7f800000u;
+            if (eb < (32u << 23) || eb >= (254u << 23)) {
+                // l is zero / tiny / not finite: no usable binade -- one plain step, then look again
+                const float xs = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(pick(done & 3)), done >> 2));
+                acc = __fmaf_rn(xs, xs, acc);
+                ++done;
+                continue;
+            }
+            const float aref = __uint_as_float(eb), top = __fadd_rn(aref, aref), half_u = __uint_as_float(eb - (24u << 23));
+            const int el = 4 * lane;
+            const bool v0 = el >= done, v1 = el + 1 >= done, v2 = el + 2 >= done, v3 = el + 3 >= done;
+            // increments (multiples of u) and exact ties
+            const float t0 = v0 ? __fsub_rn(__fmaf_rn(x0, x0, aref), aref) : 0.f, t1 = v1 ? __fsub_rn(__fmaf_rn(x1, x1, aref), aref) : 0.f;
+            const float t2 = v2 ? __fsub_rn(__fmaf_rn(x2, x2, aref), aref) : 0.f, t3 = v3 ? __fsub_rn(__fmaf_rn(x3, x3, aref), aref) : 0.f;
+            bool s0 = v0 && fabsf(__fmaf_rn(x0, x0, -t0)) == half_u, s1 = v1 && fabsf(__fmaf_rn(x1, x1, -t1)) == half_u;
+            bool s2 = v2 && fabsf(__fmaf_rn(x2, x2, -t2)) == half_u, s3 = v3 && fabsf(__fmaf_rn(x3, x3, -t3)) == half_u;
+            const float c0 = t0, c1 = __fadd_rn(c0, t1), c2 = __fadd_rn(c1, t2), c3 = __fadd_rn(c2, t3);
+            const float incl = wave_scan_incl(c3);
+            // l in front of this lane's first element: the inclusive sum of the lane BELOW (incl - c3 would not do: the lane of a
+            // binade-leaving element holds a huge increment, incl is rounded there, and the difference is off by an ulp)
+            const float lb = __fadd_rn(acc, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(incl), 0x138 /* wave_shr:1 */, 0xF, 0xF, true)));
+            // does l leave the binade on this element?  (exact test: the real step from the value in front of it)
+            s0 = s0 || (v0 && __fmaf_rn(x0, x0, lb) >= top);
+            s1 = s1 || (v1 && __fmaf_rn(x1, x1, __fadd_rn(lb, c0)) >= top);
+            s2 = s2 || (v2 && __fmaf_rn(x2, x2, __fadd_rn(lb, c1)) >= top);
+            s3 = s3 || (v3 && __fmaf_rn(x3, x3, __fadd_rn(lb, c2)) >= top);
+            const int fi = s0 ? 0 : s1 ? 1 : s2 ? 2 : s3 ? 3 : 4;
+            const float before = __fadd_rn(lb, s0 ? 0.f : s1 ? c0 : s2 ? c1 : c2);          // l in front of the lane's first special element
+            const unsigned long long sm = __ballot(fi < 4);
+            if (sm) {
+                const int Ls = __ffsll((long long)sm) - 1;
+                const int fs = __builtin_amdgcn_readlane(fi, Ls);
+                acc = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(before), Ls));
+                done = 4 * Ls + fs;
+                if (done < limit) {
+                    const float xs = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(pick(fs)), Ls));
+                    acc = __fmaf_rn(xs, xs, acc);                                           // the special element: one real step
+                    ++done;
+                }
+            } else {
+                acc = __fadd_rn(acc, __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(incl), 63)));
+                done = limit;
+            }
+        }
+        k = base + 256;
+    }
+    if (iters) *iters = n_it;
+    return acc;
+}
+
 // ------------------------------------------------------------------------------------------
 // Prologue: produce the quantized activation vector in LDS.  Every workgroup recomputes it
 // (n <= 16K floats out of L2) so that no separate norm/quantize kernel sits on the critical path.
@@ -1565,6 +1659,25 @@ __global__ void k_add_inplace(float* x, const float* y, int n) {
 }
 
 // ---- op-level test kernels: thin launchers over the same __device__ functions ----
+// square_sum both ways: out[0] the wave-parallel evaluation (sq_chain_wave), out[1] the plain sequential chains (sq_chain)
+__global__ void __launch_bounds__(256) k_op_square_sum(float* out, const float* x, int n) {
+    extern __shared__ float sm[];
+    const int n4 = n / 4, ns = n4 + 8;
+    for (int e = threadIdx.x; e < n4 * 4; e += blockDim.x) sm[(e & 3) * ns + (e >> 2)] = x[e];
+    for (int i = threadIdx.x; i < 4 * 8; i += blockDim.x) sm[(i >> 3) * ns + n4 + (i & 7)] = 0.f;
+    __shared__ float red[8];
+    __syncthreads();
+    int its = 0;
+    const float l = sq_chain_wave(sm + (threadIdx.x >> 6) * ns, n4, &its);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = l; out[6 + (threadIdx.x >> 6)] = (float)its; }
+    if (threadIdx.x < 4) red[4 + threadIdx.x] = sq_chain(sm + threadIdx.x * ns, n4);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, red[0]), red[1]), red[2]), red[3]);
+        out[1] = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, red[4]), red[5]), red[6]), red[7]);
+        out[2] = red[0]; out[3] = red[1]; out[4] = red[2]; out[5] = red[3];
+    }
+}
 __global__ void k_op_swiglu(float* xo, const float* xr, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) xo[i] = swiglu_elem(xo[i], xr[i]);
 }

@@ -134,6 +134,9 @@ int  flm_op_matmul_q(int qt, float* out, const void* mat1, const float* scales1,
                      const void* mat2, const float* scales2, int m, int n, int w, int gs);
 /* simd::rmsnorm(o,x,w,n) (x86_simd.cpp:1754-1764) */
 int  flm_op_rmsnorm(float* o, const float* x, const float* w, size_t n);
+/* simd::square_sum (x86_simd.cpp:942-960), n % 16 == 0: out6 = { total from the wave-parallel evaluation, total from the
+ * sequential chains, the 4 strided partial sums }; the two totals must be the same bits */
+int  flm_op_square_sum(const float* x, size_t n, float* out6);
 /* simd::swiglu(xo,xr,n) (x86_simd.cpp:1766-1770) */
 int  flm_op_swiglu(float* xo, const float* xr, size_t n);
 /* rope_v2 (tf_operators.cpp:352-402): one head row of n_dims at position pos */

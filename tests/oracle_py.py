@@ -80,6 +80,11 @@ def matmul_q(qt, W, sW, X, sX, gs=64, lib=None):
     return out
 
 
+def square_sum(x, lib=None):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    return np.float32((orc().orc_square_sum if lib is None else lib.ref_square_sum)(_p(x), C.c_size_t(x.size)))
+
+
 def rmsnorm(x, w, lib=None):
     x = np.ascontiguousarray(x, dtype=np.float32); w = np.ascontiguousarray(w, dtype=np.float32)
     o = np.zeros_like(x)

@@ -134,3 +134,49 @@ def test_attention_decode(gpu, hs, heads):
         assert np.array_equal(vc_g[:, pos].view(np.uint32), vc_o[:, pos].view(np.uint32))
         assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), f"pos {pos}"
         pos += 1
+
+
+def _sq_cases():
+    rng = np.random.default_rng(42)
+    cases = []
+    for n in (64, 256, 1024, 4096, 11008, 4096 + 16):
+        cases.append(("normal", rng.standard_normal(n).astype(np.float32)))
+        cases.append(("wide range", (rng.standard_normal(n) * np.exp2(rng.integers(-40, 40, n))).astype(np.float32)))
+        cases.append(("growing", (np.arange(1, n + 1) * 0.37).astype(np.float32)))
+        cases.append(("shrinking", (1000.0 / np.arange(1, n + 1)).astype(np.float32)))
+        cases.append(("powers of two (exact ties)", np.exp2(rng.integers(-14, 3, n)).astype(np.float32)))
+        cases.append(("ones", np.ones(n, np.float32)))
+        cases.append(("small integers", rng.integers(-5, 6, n).astype(np.float32)))
+        z = rng.standard_normal(n).astype(np.float32); z[rng.random(n) < 0.7] = 0
+        cases.append(("mostly zeros", z))
+        cases.append(("all zeros", np.zeros(n, np.float32)))
+        cases.append(("tiny / denormal squares", (rng.standard_normal(n) * 1e-22).astype(np.float32)))
+        cases.append(("huge", (rng.standard_normal(n) * 1e18).astype(np.float32)))
+        h = rng.standard_normal(n).astype(np.float32); h[n // 2] = 3e19                 # a square that overflows fp32
+        cases.append(("overflow to inf", h))
+        big = rng.standard_normal(n).astype(np.float32) * 1e-3; big[5] = 4096.0        # one dominant early term: later ones are below half an ulp
+        cases.append(("dominant first term", big))
+        t = np.full(n, 2.0 ** -12, np.float32); t[0] = 1.0                              # every later term is EXACTLY half an ulp of the sum: ties all the way
+        cases.append(("all ties", t))
+    return cases
+
+
+def test_square_sum_wave_parallel_is_bit_exact(gpu):
+    """the wave-parallel evaluation of the rmsnorm sum of squares (flm_kernels.h: sq_chain_wave) == the sequential
+    chains on the GPU == the CPU oracle's restatement of the reference, on friendly and on adversarial data"""
+    for name, x in _sq_cases():
+        fast, seq, lanes = gpu.op_square_sum(x)
+        want = O.square_sum(x)
+        f, s, w = np.float32(fast).view(np.uint32), np.float32(seq).view(np.uint32), np.float32(want).view(np.uint32)
+        assert s == w, (name, x.size, seq, want)
+        assert f == w, (name, x.size, fast, want)
+    rng = np.random.default_rng(7)
+    for it in range(300):                                   # random magnitudes, a share of exactly representable "round" values
+        n = int(rng.choice([256, 1024, 4096]))
+        x = (rng.standard_normal(n) * np.exp2(rng.integers(-12, 12) + rng.integers(-6, 7, n) * (it % 3))).astype(np.float32)
+        if it % 4 == 0:
+            idx = rng.random(n) < 0.3
+            x[idx] = np.exp2(rng.integers(-13, 4, idx.sum())).astype(np.float32) * rng.choice([1.0, 1.5, 3.0], idx.sum()).astype(np.float32)
+        fast, seq, lanes = gpu.op_square_sum(x)
+        want = O.square_sum(x)
+        assert np.float32(fast).view(np.uint32) == np.float32(want).view(np.uint32) == np.float32(seq).view(np.uint32), (it, n, fast, seq, want)
