@@ -208,6 +208,171 @@ bool load_llama2c(const std::string& ckpt, const std::string& tok_path, bool tok
     for (auto& t : m.tensors) { t.values = t.owned_values.data(); t.scales = t.owned_scales.empty() ? nullptr : t.owned_scales.data(); }
     return true;
 }
+
+// ---------------------------------------------------------------------------------------------
+// gguf (v2 / v3), LLaMA architecture, F32 and F16 tensors.  Same meaning as the reference's reader
+// (src/model_loaders/gguf_loader.cpp:205-489): the hyper-parameters come from the llama.* keys, the tokenizer from
+// tokenizer.ggml.{tokens,scores,token_type,bos/eos/padding_token_id}, tensors are named the llama.cpp way and already
+// carry the interleaved q/k row order; fp32 weights are handed to the device as fp32 masters and quantized there with
+// the -q type.  Unlike the reference this reader skips keys it does not know instead of refusing the file, and it
+// converts F16 tensors (the reference reads them and forgets to convert, :466); Q8_0 (32-element groups, which the
+// engine's 64-element operators cannot run) is refused.
+// ---------------------------------------------------------------------------------------------
+enum { GV_UINT8 = 0, GV_INT8, GV_UINT16, GV_INT16, GV_UINT32, GV_INT32, GV_FLOAT32, GV_BOOL, GV_STRING, GV_ARRAY, GV_UINT64, GV_INT64, GV_FLOAT64 };
+int gv_size(int t) { static const int sz[] = {1, 1, 2, 2, 4, 4, 4, 1, -1, -1, 8, 8, 8}; return (t >= 0 && t <= GV_FLOAT64) ? sz[t] : 0; }
+
+struct GgufReader {
+    Cursor c; size_t pos = 0; bool bad = false;
+    template <class T> T get() { if (!c.ok(pos, sizeof(T))) { bad = true; return T(); } T v = c.at<T>(pos); pos += sizeof(T); return v; }
+    std::string str() {
+        const uint64_t n = get<uint64_t>();
+        if (bad || !c.ok(pos, n)) { bad = true; return std::string(); }
+        std::string s(reinterpret_cast<const char*>(c.base + pos), (size_t)n); pos += n; return s;
+    }
+    double number(int t) {
+        switch (t) {
+        case GV_UINT8: case GV_BOOL: return get<uint8_t>(); case GV_INT8: return get<int8_t>(); case GV_UINT16: return get<uint16_t>();
+        case GV_INT16: return get<int16_t>(); case GV_UINT32: return get<uint32_t>(); case GV_INT32: return get<int32_t>();
+        case GV_FLOAT32: return get<float>(); case GV_UINT64: return (double)get<uint64_t>(); case GV_INT64: return (double)get<int64_t>();
+        case GV_FLOAT64: return get<double>(); default: bad = true; return 0;
+        }
+    }
+    void skip(int t) {
+        if (t == GV_STRING) { str(); return; }
+        if (t == GV_ARRAY) { const int et = get<int32_t>(); const uint64_t n = get<uint64_t>(); for (uint64_t i = 0; i < n && !bad; ++i) skip(et); return; }
+        const int sz = gv_size(t);
+        if (sz <= 0 || !c.ok(pos, (size_t)sz)) { bad = true; return; }
+        pos += (size_t)sz;
+    }
+};
+
+float half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
+    uint32_t bits;
+    if (exp == 0) {
+        if (man == 0) bits = sign;
+        else { int e = -1; uint32_t m = man; do { ++e; m <<= 1; } while (!(m & 0x400u)); bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((m & 0x3ffu) << 13); }
+    } else if (exp == 31) bits = sign | 0x7f800000u | (man << 13);
+    else bits = sign | ((exp + 112u) << 23) | (man << 13);
+    float f; memcpy(&f, &bits, 4); return f;
+}
+
+bool load_gguf(const std::string& path, bool tokenizer_only, bool debug, ModelFile& m, std::string& err) {
+    int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) { err = "Failed to open gguf file:" + path; return false; }
+    struct stat st; fstat(fd, &st);
+    m.map_size = (size_t)st.st_size;
+    m.map_base = mmap(nullptr, m.map_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m.map_base == MAP_FAILED) { m.map_base = nullptr; err = "mmap failed:" + path; return false; }
+    GgufReader r{Cursor{reinterpret_cast<const uint8_t*>(m.map_base), m.map_size}};
+    const uint32_t magic = r.get<uint32_t>(), version = r.get<uint32_t>();
+    const int64_t n_tensors = r.get<int64_t>(), n_kv = r.get<int64_t>();
+    if (r.bad || magic != 0x46554747u || n_tensors < 1 || n_kv < 1) { err = "Not a valid gguf file:" + path; return false; }
+    if (debug) fprintf(stderr, "gguf version:%u tensors:%ld keys:%ld\n", version, (long)n_tensors, (long)n_kv);
+    Config& cf = m.cfg; Vocab& vc = m.vocab;
+    cf.quant_type = 0; cf.quant_group_size = 64;
+    size_t alignment = 32; int rope_dims = 0;
+    std::vector<std::string> texts; std::vector<float> scores; std::vector<int> types;
+    for (int64_t i = 0; i < n_kv && !r.bad; ++i) {
+        const std::string key = r.str();
+        const int t = r.get<int32_t>();
+        const bool num = t != GV_STRING && t != GV_ARRAY;
+        if (key == "general.architecture" && t == GV_STRING) { const std::string a = r.str(); if (a != "llama") { err = "Unsupported architecture:" + a; return false; } }
+        else if (key == "general.name" && t == GV_STRING) cf.name = r.str();
+        else if (key == "general.file_type" && num) { const int ft = (int)r.number(t); if (ft != 0 && ft != 1) { err = "Unsupported gguf file type " + std::to_string(ft) + " (F32 and F16 files load; Q8_0 uses 32-element groups the engine cannot run)"; return false; } }
+        else if (key == "general.alignment" && num) alignment = (size_t)r.number(t);
+        else if (key == "llama.context_length" && num) cf.max_seq_len = (int)r.number(t);
+        else if (key == "llama.embedding_length" && num) cf.dim = (int)r.number(t);
+        else if (key == "llama.block_count" && num) cf.n_layers = (int)r.number(t);
+        else if (key == "llama.feed_forward_length" && num) cf.hidden_dim = (int)r.number(t);
+        else if (key == "llama.attention.head_count" && num) cf.n_heads = (int)r.number(t);
+        else if (key == "llama.attention.head_count_kv" && num) cf.n_kv_heads = (int)r.number(t);
+        else if (key == "llama.rope.dimension_count" && num) rope_dims = (int)r.number(t);
+        else if (key == "tokenizer.ggml.bos_token_id" && num) vc.bos = (int)r.number(t);
+        else if (key == "tokenizer.ggml.eos_token_id" && num) vc.eos = (int)r.number(t);
+        else if (key == "tokenizer.ggml.padding_token_id" && num) vc.pad = (int)r.number(t);
+        else if (key == "tokenizer.ggml.tokens" && t == GV_ARRAY) {
+            const int et = r.get<int32_t>(); const uint64_t n = r.get<uint64_t>();
+            if (et != GV_STRING || n > (1ull << 24)) { err = "Reading tokens error"; return false; }
+            texts.resize((size_t)n); for (auto& s : texts) s = r.str();
+        } else if (key == "tokenizer.ggml.scores" && t == GV_ARRAY) {
+            const int et = r.get<int32_t>(); const uint64_t n = r.get<uint64_t>();
+            if (n > (1ull << 24)) { err = "Reading scores error"; return false; }
+            scores.resize((size_t)n); for (auto& v : scores) v = (float)r.number(et);
+        } else if (key == "tokenizer.ggml.token_type" && t == GV_ARRAY) {
+            const int et = r.get<int32_t>(); const uint64_t n = r.get<uint64_t>();
+            if (n > (1ull << 24)) { err = "Reading token types error"; return false; }
+            types.resize((size_t)n); for (auto& v : types) v = (int)r.number(et);
+        } else r.skip(t);                                   // rope.freq_base, rms epsilon (the operators hard-code both), merges, ...
+    }
+    if (r.bad) { err = "Reading gguf key/value section error:" + path; return false; }
+    const int hs = cf.n_heads > 0 ? cf.dim / cf.n_heads : 0;
+    if (cf.n_kv_heads < 1) cf.n_kv_heads = cf.n_heads;
+    if (cf.n_heads < 1 || cf.dim % cf.n_heads != 0 || (rope_dims > 0 && rope_dims != hs)) { err = "Invalid dim / n_heads / rope dimension count in gguf file"; return false; }
+    if (texts.empty()) { err = "gguf file without tokenizer.ggml.tokens"; return false; }
+    cf.vocab_size = (int)texts.size();
+    vc.tokens.resize(texts.size());
+    for (size_t i = 0; i < texts.size(); ++i) {            // Tokenizer::set_token_texts (tokenizer.cpp:73-120): "▁xyz" is shown as " xyz"
+        VocabEntry& e = vc.tokens[i];
+        e.index_text = texts[i];
+        e.show_text = texts[i].compare(0, vc.conn_tag.size(), vc.conn_tag) == 0 ? " " + texts[i].substr(vc.conn_tag.size()) : texts[i];
+        e.score = i < scores.size() ? scores[i] : 0.f;
+        e.type = i < types.size() ? types[i] : 1;
+    }
+    if (tokenizer_only) return true;
+
+    struct Info { std::string name; int kind = 0, layer = 0, dtype = 0; int64_t dims[4] = {1, 1, 1, 1}; int nd = 0; uint64_t off = 0; };
+    std::vector<Info> infos((size_t)n_tensors);
+    for (auto& ti : infos) {
+        ti.name = r.str();
+        ti.nd = (int)r.get<uint32_t>();
+        if (r.bad || ti.nd < 1 || ti.nd > 4) { err = "Invalid shape of tensor:" + ti.name; return false; }
+        for (int j = 0; j < ti.nd; ++j) ti.dims[j] = r.get<int64_t>();
+        ti.dtype = r.get<int32_t>(); ti.off = r.get<uint64_t>();
+        // names -> .flm tensor kinds
+        static const struct { const char* n; int kind; } top[] = {{"token_embd.weight", 1}, {"output_norm.weight", 2}, {"output.weight", 3}};
+        static const struct { const char* n; int kind; } per[] = {{"attn_norm.weight", 17}, {"attn_q.weight", 18}, {"attn_k.weight", 19}, {"attn_v.weight", 20},
+            {"attn_output.weight", 21}, {"ffn_gate.weight", 22}, {"ffn_up.weight", 23}, {"ffn_down.weight", 24}, {"ffn_norm.weight", 25}};
+        for (auto& e : top) if (ti.name == e.n) ti.kind = e.kind;
+        if (!ti.kind && ti.name.compare(0, 4, "blk.") == 0) {
+            const size_t dot = ti.name.find('.', 4);
+            if (dot != std::string::npos) {
+                ti.layer = atoi(ti.name.c_str() + 4);
+                for (auto& e : per) if (ti.name.compare(dot + 1, std::string::npos, e.n) == 0) ti.kind = e.kind;
+            }
+        }
+        if (!ti.kind || ti.layer < 0 || ti.layer >= cf.n_layers) { err = "Invalid tensor name:" + ti.name; return false; }
+    }
+    if (r.bad) { err = "Reading gguf tensor infos error:" + path; return false; }
+    const size_t data0 = (r.pos + alignment - 1) / alignment * alignment;
+    bool have_cls = false;
+    for (auto& ti : infos) {
+        size_t items = 1; for (int j = 0; j < ti.nd; ++j) items *= (size_t)ti.dims[j];
+        const size_t bytes = ti.dtype == 0 ? items * 4 : ti.dtype == 1 ? items * 2 : 0;
+        if (!bytes) { err = "Tensor " + ti.name + ": this data type is not supported (F32 and F16 are)"; return false; }
+        if (!r.c.ok(data0 + ti.off, bytes)) { err = "Tensor data exceeds the file:" + ti.name; return false; }
+        HostTensor t; t.kind = ti.kind; t.layer = ti.layer; t.qtype = 0;
+        t.cols = (int)ti.dims[0]; t.rows = ti.nd > 1 ? (int)ti.dims[1] : 1;
+        const uint8_t* src = r.c.base + data0 + ti.off;
+        if (ti.dtype == 0) t.values = src;                                  // zero copy out of the mapping
+        else {
+            t.owned_values.resize(items * 4);
+            float* dst = reinterpret_cast<float*>(t.owned_values.data());
+            for (size_t i = 0; i < items; ++i) { uint16_t h; memcpy(&h, src + 2 * i, 2); dst[i] = half_to_float(h); }
+        }
+        if (ti.kind == 3) have_cls = true;
+        m.tensors.push_back(std::move(t));
+    }
+    for (auto& t : m.tensors) if (!t.owned_values.empty()) t.values = t.owned_values.data();
+    if (!have_cls) {                                       // tied embeddings: the classifier is the embedding table
+        for (size_t i = 0; i < m.tensors.size(); ++i) if (m.tensors[i].kind == 1) {
+            HostTensor t; t.kind = 3; t.layer = 0; t.qtype = 0; t.rows = m.tensors[i].rows; t.cols = m.tensors[i].cols; t.values = m.tensors[i].values;
+            m.tensors.push_back(std::move(t)); break;
+        }
+    }
+    return true;
+}
 } // namespace
 
 ModelFile::~ModelFile() { if (map_base) munmap(map_base, map_size); }
@@ -252,7 +417,7 @@ bool load_model_file(const std::string& ckpt, const std::string& tokenizer_path,
     switch (ft) {
     case FileType::FLM: return load_flm(ckpt, tokenizer_only, debug, out, err);
     case FileType::LLAMA2C: return load_llama2c(ckpt, tokenizer_path, tokenizer_only, out, err);
-    case FileType::GGUF: err = "gguf files are not supported by this build yet (F32 gguf is planned; the reference's Q8_0 path is broken, utility.cpp:64)"; return false;
+    case FileType::GGUF: return load_gguf(ckpt, tokenizer_only, debug, out, err);
     default: if (err.empty()) err = "Unsupported model file type"; return false;
     }
 }

@@ -196,6 +196,11 @@ CLI_CASES = [   # (name, shape, qt, seed, extra CLI args)
     ("decode", "tiny", ff.QT_INT8, 21, ["-d", "[1, 279, 264, 260, 305]"]),
 ]
 
+GGUF_CASES = [  # (name, shape, seed, f16, extra CLI args): fp32 masters written as gguf by fast_llama_amd/gguffile.py
+    ("gguf_f32_int8", "tiny", 33, False, ["-f", "gguf", "-q", "int8", "-t", "0", "-n", "16", "-i", "the shape of it"]),
+    ("gguf_f32_int16", "tiny128", 34, False, ["-f", "gguf", "-q", "int16", "-t", "0", "-n", "8", "-i", "tea time!"]),
+]
+
 
 def g_cli():
     """transcripts of the reference CLI (oracle/_ref/main) on synthetic .flm files; the summary line's timing
@@ -206,6 +211,15 @@ def g_cli():
         cfg = synth.make_config(shape, qt)
         path = f"/tmp/golden-cli-{name}.flm"
         synth.write_synthetic_flm(path, cfg, seed=seed)
+        r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "main"), "-c", path, "-j", "1", *extra], capture_output=True, check=True)
+        lines = [l for l in r.stdout.split(b"\n") if not l.startswith(b"DEBUG:")]
+        out[name] = np.frombuffer(b"\n".join(lines), dtype=np.uint8)
+        os.remove(path)
+    from fast_llama_amd import gguffile
+    for name, shape, seed, f16, extra in GGUF_CASES:
+        cfg = synth.make_config(shape, ff.QT_NONE)
+        path = f"/tmp/golden-cli-{name}.gguf"
+        gguffile.write_gguf(path, cfg, synth.make_tokenizer(cfg.vocab_size), synth.make_tensors(cfg, seed=seed, fp32_master=True), f16=f16)
         r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "main"), "-c", path, "-j", "1", *extra], capture_output=True, check=True)
         lines = [l for l in r.stdout.split(b"\n") if not l.startswith(b"DEBUG:")]
         out[name] = np.frombuffer(b"\n".join(lines), dtype=np.uint8)

@@ -21,7 +21,8 @@ def _cases():
     m = re.search(r"CLI_CASES = \[.*?\n\]\n", src, re.S)
     ns = {"ff": ff}
     exec(m.group(0), ns)
-    return ns["CLI_CASES"]
+    exec(re.search(r"GGUF_CASES = \[.*?\n\]\n", src, re.S).group(0), ns)
+    return ns["CLI_CASES"], ns["GGUF_CASES"]
 
 
 def _strip_timing(b: bytes) -> bytes:
@@ -30,7 +31,7 @@ def _strip_timing(b: bytes) -> bytes:
 
 
 def _run(name, tmp_path, extra_args=()):
-    case = next(c for c in _cases() if c[0] == name)
+    case = next(c for c in _cases()[0] if c[0] == name)
     _, shape, qt, seed, extra = case
     cfg = synth.make_config(shape, qt)
     path = str(tmp_path / f"{name}.flm")
@@ -61,3 +62,26 @@ def test_cli_benchmark_mode_prints_only_summary(gpu, tmp_path):
     lines = got.split(b"\n")
     assert not any(l.startswith(b"output:") for l in lines)
     assert _strip_timing(lines[-2]) == _strip_timing(want.split(b"\n")[-2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["gguf_f32_int8", "gguf_f32_int16"])
+def test_cli_on_gguf_matches_reference_transcript(gpu, name, tmp_path):
+    """F32 gguf (gguf_loader.cpp:205-489): fp32 masters quantized with -q on the device, no q/k permutation; transcripts of the reference
+    binary on the same file.  The same tensors in an fp32-master .flm give the same output again."""
+    from fast_llama_amd import gguffile
+    _, shape, seed, f16, extra = next(c for c in _cases()[1] if c[0] == name)
+    cfg = synth.make_config(shape, ff.QT_NONE)
+    tensors = synth.make_tensors(cfg, seed=seed, fp32_master=True)
+    path = str(tmp_path / f"{name}.gguf")
+    gguffile.write_gguf(path, cfg, synth.make_tokenizer(cfg.vocab_size), tensors, f16=f16)
+    r = subprocess.run([MAIN, "-c", path, "-j", "1", *extra], capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")
+    want = bytes(np.load(os.path.join(GOLD, "cli_transcripts.npz"))[name])
+    assert _strip_timing(r.stdout) == _strip_timing(want)
+    flm = str(tmp_path / f"{name}.flm")
+    synth.write_synthetic_flm(flm, cfg, tensors=tensors, fp32_master=True)
+    r2 = subprocess.run([MAIN, "-c", flm, "-j", "1", *[a for a in extra if a not in ("-f", "gguf")]], capture_output=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr.decode(errors="replace")
+    strip_name = lambda b: re.sub(rb"model:[^\t]*", b"model:<m>", _strip_timing(b))
+    assert strip_name(r2.stdout) == strip_name(r.stdout)
