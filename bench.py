@@ -210,7 +210,6 @@ def main():
     ap.add_argument("--parallel", default="replicas", choices=["replicas", "tp"],
                     help="N > 1: 'replicas' = one independent sequence per GPU, no data-path collective (default); "
                          "'tp' = one sequence, every matmul split by output rows over the GPUs, RCCL all-gathers")
-    ap.add_argument("--ring", type=int, default=-1, help="1/0: LDS weight ring on/off (default: library default)")
     ap.add_argument("--mega", type=int, default=-1, help="1/0: force the persistent whole-token kernel on/off (default: library default)")
     args = ap.parse_args()
 
@@ -250,8 +249,6 @@ def main():
         ctx.set_option("wg_per_cu", args.wg_per_cu)
     if args.mega >= 0:
         ctx.set_option("use_mega", args.mega)
-    if args.ring >= 0:
-        ctx.set_option("use_ring", args.ring)
     upload_synthetic(ctx, cfg)
 
     def barrier():

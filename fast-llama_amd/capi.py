@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libflm_gpu.so")
+LIB_PATH = os.environ.get("FLM_GPU_LIB") or os.path.join(_HERE, "lib", "libflm_gpu.so")   # FLM_GPU_LIB: tools/variants.sh builds
 
 QT_NONE, QT_INT16, QT_INT8 = 0, 1, 2
 KCLASSES = ("embed", "qkv", "attn", "attn_o", "ffn13", "ffn2", "cls", "argmax", "allreduce")

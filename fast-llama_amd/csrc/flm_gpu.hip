@@ -65,8 +65,6 @@ struct flm_ctx {
     int use_prefill = 1;                               // option "use_prefill": prompts of >= kPrefillMin+1 tokens go through the batched kernels
     int pf_cap = 0;                                    // token capacity of the batched-prefill buffers below
     float *pf_x = nullptr, *pf_qkv = nullptr, *pf_q = nullptr, *pf_att = nullptr, *pf_gu = nullptr, *pf_hd = nullptr, *pf_xs = nullptr; void* pf_xq = nullptr;
-    int use_ring = 0;                                  // option "use_ring": LDS weight ring (direct-to-LDS loads) in the rmsnorm GEMVs; measured neutral on MI355X (the
-                                                       // extra 64 KiB/CU in flight shorten the stream by ~1.3 us and lengthen the prologue by as much), so off
     int use_mega = 0;                                  // option "use_mega": run single-GPU tokens as ONE persistent kernel (k_token); opt-in until it beats the per-phase kernels
     GemvArgs* mega_gemv = nullptr; AttnArgs* mega_attn = nullptr; unsigned* mega_bar = nullptr; int* mega_err = nullptr;
     size_t mega_lds = 0; int mega_ok = -1;              // -1 not built yet, 0 shape not supported by k_token, 1 ready
@@ -103,14 +101,13 @@ void split_even(int total, int parts, int idx, int* begin, int* count) {
 //   cb_shift : CB = largest power of two <= 64 dividing K/16, so every 1 KiB wave load is full
 //   Rm       : rows (per matrix) per workgroup pass; bounded by LDS (two strip buffers) and by 64 chain
 //              lanes; chosen so that the passes divide evenly over `wgs` workgroups (CU-level balance is
-//              what matters for an HBM-bound kernel)
-//   wc_shift : the WC x WR wave grid with the fewest blocks on the busiest wave
-struct GemvPlan { int Rm, cb_shift, wc_shift, grid, ring, nbuf; size_t lds; };
-GemvPlan gemv_plan(int n, int esz, int rows, bool two, bool pairs, bool norm, int wgs, bool use_ring) {
+//              what matters for an HBM-bound kernel; inside a workgroup the waves draw steps from a counter)
+struct GemvPlan { int Rm, cb_shift, grid, nbuf; size_t lds; };
+GemvPlan gemv_plan(int n, int esz, int rows, bool two, bool pairs, bool norm, int wgs) {
     GemvPlan P{};
     const int nchunks = n * esz / 16;
     int cbs = 0; while (cbs < 6 && (nchunks % (2 << cbs)) == 0) ++cbs;       // nchunks % 4 == 0 always
-    const int RB = 64 >> cbs, nbc = nchunks >> cbs, nbcv = two ? 2 * nbc : nbc;
+    const int RB = 64 >> cbs;
     const int mult = (pairs && RB < 2) ? 2 : RB;                             // ROPE_KV: row pairs stay in one pass
     const int lds_budget = 150 * 1024;                                       // one 1024-thread workgroup per CU out of 160 KiB
     int rmax = 64;                                                           // one chain lane per row
@@ -121,23 +118,10 @@ GemvPlan gemv_plan(int n, int esz, int rows, bool two, bool pairs, bool norm, in
     if (ppw < 1) ppw = 1;
     int Rm = (rows + wgs * ppw - 1) / (wgs * ppw);
     Rm = (Rm + mult - 1) / mult * mult; if (Rm > rmax) Rm = rmax; if (Rm < mult) Rm = mult;
-    const int npass = (rows + Rm - 1) / Rm, rbp = Rm / RB;
-    int best = 0; long best_cost = -1;
-    for (int wcs = 0; wcs <= 4; ++wcs) {
-        const int WC = 1 << wcs, WR = 16 >> wcs;
-        const long cost = (long)((nbcv + WC - 1) / WC) * ((rbp + WR - 1) / WR);
-        if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best = wcs; }   // ties: more wave columns, fewer activation reloads
-    }
-    P.Rm = Rm; P.cb_shift = cbs; P.wc_shift = best; P.grid = npass < wgs ? npass : wgs; if (P.grid < 1) P.grid = 1;
-    // the LDS weight ring lives in the top kRingBytes: use it when the launch's own LDS fits below it (with one strip
-    // buffer if every workgroup has a single pass) and the stream is long enough to matter
-    P.ring = 0; P.nbuf = 2;
-    const long blocks_per_wave = best_cost;
-    if (use_ring && blocks_per_wave > 2 * kStepBlk) {
-        if (gemv_lds_layout(n, esz, norm, Rm, RB, two, 2).total <= kRingOff) P.ring = 1;
-        else if (npass <= wgs && gemv_lds_layout(n, esz, norm, Rm, RB, two, 1).total <= kRingOff) { P.ring = 1; P.nbuf = 1; }
-    }
-    P.lds = P.ring ? (size_t)kLdsBytes : (size_t)gemv_lds_layout(n, esz, norm, Rm, RB, two, P.nbuf).total;
+    const int npass = (rows + Rm - 1) / Rm;
+    P.Rm = Rm; P.cb_shift = cbs; P.grid = npass < wgs ? npass : wgs; if (P.grid < 1) P.grid = 1;
+    P.nbuf = 2;
+    P.lds = (size_t)gemv_lds_layout(n, esz, norm, Rm, RB, two, P.nbuf).total;
     return P;
 }
 
@@ -147,10 +131,9 @@ int plan_gemv(flm_ctx* c, GemvArgs& a, int wgs, GemvPlan& P) {
     constexpr bool TWO = EPI == EPI_SWIGLU, PAIRS = EPI == EPI_ROPE_KV;
     const int rows = a.items * (PAIRS ? 2 : 1);
     if ((double)rows * a.n * QTraits<QT>::kEsz * (TWO ? 2 : 1) >= 2147483648.0) return fail(c, FLM_ERR_UNSUPPORTED, "gemv: matrix of 2 GiB or more");
-    // the ring pays only where a long prologue (the rmsnorm chain) gives it time to arrive
-    P = gemv_plan(a.n, QTraits<QT>::kEsz, rows, TWO, PAIRS, true, wgs, PRO == PRO_RMSNORM_QUANT && (c ? c->use_ring != 0 : true));
+    P = gemv_plan(a.n, QTraits<QT>::kEsz, rows, TWO, PAIRS, true, wgs);
     if (P.lds > 160 * 1024) return fail(c, FLM_ERR_UNSUPPORTED, "gemv: activation vector does not fit LDS");
-    a.rows_per_pass = P.Rm; a.cb_shift = P.cb_shift; a.wc_shift = P.wc_shift; a.ring = P.ring; a.nbuf = P.nbuf;
+    a.rows_per_pass = P.Rm; a.cb_shift = P.cb_shift; a.nbuf = P.nbuf;
     return FLM_OK;
 }
 template <int QT, int PRO, int EPI>
@@ -365,6 +348,8 @@ int build_mega(flm_ctx* c) {
     }
     g[4 * L] = args_cls(c); r = plan_gemv<QT, PRO_RMSNORM_QUANT, EPI_STORE>(c, g[4 * L], wgs, P); if (r) return r; if (P.lds > lds) lds = P.lds;
     if (lds < 84 * 1024) lds = 84 * 1024;                 // more than half of the CU's LDS: at most ONE workgroup per CU, so all of them are resident
+    lds = (lds + 15) / 16 * 16 + 16;                       // the step counters of all phases at one fixed place (the phases' own layouts differ): consecutive phases alternate
+    for (size_t i = 0; i < g.size(); ++i) g[i].ctr_off = (int)(lds - 16 + 4 * (i & 1));
     if (!c->mega_gemv) {
         HIPC(c, hipMalloc((void**)&c->mega_gemv, g.size() * sizeof(GemvArgs)));
         HIPC(c, hipMalloc((void**)&c->mega_attn, at.size() * sizeof(AttnArgs)));
@@ -767,7 +752,6 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (k == "use_mega") c->use_mega = value;
     else if (k == "use_prefill") c->use_prefill = value;
     else if (k == "use_mfma") c->use_mfma = value;
-    else if (k == "use_ring") { c->use_ring = value; c->mega_ok = -1; }
     else if (k == "trace") {        // value = kernel class to trace (KC_*), -1 off; meaningful in FLM_ABLATE builds only
         c->trace_class = value;
         if (!c->trace) { HIPC(c, hipMalloc((void**)&c->trace, 4096 * 8 * 8)); }

@@ -194,8 +194,7 @@ struct GemvArgs {
     int items;                                  // rows (STORE/RESIDUAL), hidden (SWIGLU), row pairs (ROPE_KV)
     int rows_per_pass;                          // Rm: rows (of each matrix) one workgroup reduces per pass; multiple of RB, <= 64
     int cb_shift;                               // log2(CB): a 1 KiB wave load covers RB = (64 >> cb_shift) rows x CB 16-byte chunks
-    int wc_shift;                               // log2(WC): the 16 waves form a WC x WR grid over (column blocks x row blocks)
-    int ring;                                   // 1: a third step of weight blocks is kept in flight in LDS (direct-to-LDS loads), the top kRingBytes of LDS
+    int ctr_off;                                // LDS byte offset of the two step counters; 0: the layout's own (k_token keeps them at a fixed place across phases)
     int nbuf;                                   // strip buffers: 2, or 1 when each workgroup has a single pass and LDS is short
     // prologue inputs
     const float* x;                             // fp32 activation [n]          (QUANT / RMSNORM_QUANT)
@@ -224,7 +223,7 @@ constexpr int kStepBlk = 4;            // H: 1 KiB wave loads per step; two step
 //                2 buffers x (Rm + RB) strips; strip r = { float(group dot), sW*sX } pairs of row r, groups ascending
 //                (SWIGLU: the W1 groups followed by the W3 groups) )
 struct GemvLds {
-    int off_xs, off_red, off_scr;     // byte offsets
+    int off_xs, off_red, off_ctr, off_scr;     // byte offsets (off_ctr: the two step counters of GemvCtx)
     int gstride;                      // BYTES per strip: 16 x odd, so that 16 lanes reading 16 B each from 16 strips hit all banks
     int buf_bytes;                    // one strip buffer
     int total;                        // bytes
@@ -234,23 +233,16 @@ __host__ __device__ inline GemvLds gemv_lds_layout(int n, int esz, bool norm, in
     const int sn = n / kGroup, ng = two ? 2 * sn : sn;
     L.off_xs = n * esz;
     L.off_red = L.off_xs + ((sn * 4 + 15) & ~15);
-    L.off_scr = L.off_red + 64;
+    L.off_ctr = L.off_red + 64;
+    L.off_scr = L.off_ctr + 16;
     int g16 = (ng * 8 + 15) / 16; if ((g16 & 1) == 0) ++g16;
     L.gstride = g16 * 16;
     L.buf_bytes = (Rm + RB) * L.gstride;                                       // + RB dummy strips that absorb the writes of padding blocks
     int scratch = nbuf * L.buf_bytes + 64;                                     // + 64: the chain's read-ahead past the last strip
-    if (norm && n * 4 + 512 > scratch) scratch = n * 4 + 512;                   // 4 strips of n/4 + 8 floats (+8: the 4 chain lanes read different banks) + the ring's read-ahead past the last strip
+    if (norm && n * 4 + 512 > scratch) scratch = n * 4 + 512;                   // 4 strips of n/4 + 8 floats (+8: the 4 chain lanes read different banks); + the chain's read-ahead past the last strip
     L.total = L.off_scr + scratch;
     return L;
 }
-// The LDS weight ring: one step (kStepBlk blocks) per wave, a block = 1 KiB of weights + 256 B of scales, written by
-// direct-to-LDS buffer loads.  It always sits in the TOP kRingBytes of the CU's 160 KiB, whatever the phase's own
-// layout below it, so that k_token can prefetch the next phase's blocks while slower waves still use this phase's strips.
-constexpr int kLdsBytes = 160 * 1024;
-constexpr int kRingSlot = 1024 + 256;
-constexpr int kRingBytes = kWavesPerBlock * kStepBlk * kRingSlot;              // 80 KiB
-constexpr int kRingOff = kLdsBytes - kRingBytes;
-
 // One of the 4 strided lanes of simd::square_sum -> square_sum_avx128 (x86_simd.cpp:942-960; the AVX2 branch is
 // dead, :1093): p[0..n4) = x[c], x[c+4], x[c+8], ... walked as a strictly sequential FMA chain.
 __device__ __forceinline__ float sq_chain(const float* p, int n4) {
@@ -414,6 +406,9 @@ __device__ __forceinline__ void gemv_preload(const GemvArgs& a, float4 (&xv)[XR 
     }
 }
 
+#ifndef FLM_WSLEEP
+#define FLM_WSLEEP 2
+#endif
 #ifdef FLM_TRACE_PRO
 #define FLM_PRO_STAMP(k) if (kAblate && a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime();
 #else
@@ -467,9 +462,15 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
             // the hook issues the weight prefetch.  Wave 0 goes first (the others give it ~128 cycles): its 16 loads
             // enter an empty memory pipeline at once and it is free for the chain; queued behind the other 15 waves'
             // 240 loads it would stall for ~1 us before (or after) the chain.
-            if (tid >= kWave) __builtin_amdgcn_s_sleep(2);
+#ifdef FLM_W0_LATE
+            if (tid >= kWave) after_stage();
+            if (tid < 4 && !(a.ablate & 2)) red[8 + tid] = sq_chain(scratch + tid * ns, n4);
+            if (tid < kWave) after_stage();
+#else
+            if (tid >= kWave) __builtin_amdgcn_s_sleep(FLM_WSLEEP);
             after_stage();
             if (tid < 4 && !(a.ablate & 2)) red[8 + tid] = sq_chain(scratch + tid * ns, n4);
+#endif
             FLM_PRO_STAMP(4)
             __syncthreads();
             const float ss = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, red[8]), red[9]), red[10]), red[11]);
@@ -563,25 +564,35 @@ struct GemvCtx {
     static constexpr int H = kStepBlk;
     static constexpr u32 kOOB = 0x80000000u;
 
-    struct Set { v4i w[H]; float sw[H]; };
-    // The load cursor and the reduce cursor walk the same block sequence (pass, column block, row block),
-    // the load cursor two steps ahead; each carries only the running offsets its side needs.
-    struct LCur { u32 pass, ci, ri, wo, so; };
-    struct RCur { u32 pass, ci, ri, st, xo; };
+    // A STEP is H consecutive row blocks of one column block of one pass: H weight loads of 1 KiB per wave plus ONE scale
+    // load (lane (j, g) fetches the scale of block j's g-th quant group -- 64 / LPG groups per block, so for int8 the
+    // step's 64 scales fill the wave exactly; a separate scale load per block cost as much of the CU's address
+    // pipeline as the weight load itself).  The steps of a workgroup -- its passes in order, inside a pass row chunk by
+    // row chunk, a chunk's column blocks next to each other -- are numbered, and handed out through a counter in LDS: a
+    // wave takes the next number whenever it refills a register set.  With a fixed wave grid the waves that the CU's
+    // memory pipeline serves last (it is a FIFO: wave 15's requests queue behind everybody else's every round) ended
+    // 3 us after the first ones, on a 12 us main loop; the wave that runs a pass's chain falls behind as well.
+    // Numbered steps cost two scalar multiply-high's to decode, and the activation chunk is re-read from LDS when the
+    // column block changes (one ds_read_b128 per step at most).
+    struct Set { v4i w[H]; float sw; u32 itl, st, xo, nlive; };               // itl: workgroup-local pass index (np_wg: no work left)
 
     // geometry (wave-uniform unless noted)
-    u32 n, lane, wave, rowbytes, sn, cbs, RB, nbc, TRm, Rm, npass, wcs, wc, wr, nrw, ncw, gstride, buf_bytes, off_xs, off_scr;
-    u32 lane_woff, lane_soff, lane_xoff, lane_sxoff, lane_goff;               // per lane
+    u32 n, lane, wave, rowbytes, sn, cbs, RB, nbc, NBCV, TRm, Rm, RBP, SP, NS, np_wg, npass, gstride, buf_bytes, off_xs, off_scr, ctr_off;
+    u32 inv_SP, inv_NBCV;                                                      // ceil(2^32 / d): exact quotients for the step numbers that occur (< 2^16)
+    u32 lane_woff, lane_xoff, lane_goff;                                       // per lane: weight chunk, activation chunk, strip entry (dot)
+    u32 lane_j, lane_s2off, lane_sx2off, lane_poff;                            // per lane, scale role: block of the step, its scale, the activation scale, strip entry (s)
     bool leader;                                                               // per lane
-    u32 dW, dS, dT, dummy_st, wg, nwg;
-    u32 ring, ring_off, nbuf;                                                  // LDS weight ring of this wave (0: none)
+    u32 dW, dS, dT, dummy_st, wg, nwg, nbuf;
     __amdgpu_buffer_rsrc_t rW, rS;
     Set setA, setB;
-    LCur lc;
-    RCur rc;
     bool stored;                                                               // this wave wrote results to global memory
 
-    __device__ __forceinline__ void init(const GemvArgs& a, u32 wg_, u32 nwg_) {
+    static __device__ __forceinline__ u32 inv_of(u32 d) { return d > 1 ? 0xFFFFFFFFu / d + 1u : 0u; }
+    static __device__ __forceinline__ u32 udiv(u32 x, u32 d, u32 inv) { return d > 1 ? __umulhi(x, inv) : x; }
+
+    // ctr_slot: which of the two step counters in LDS this GEMV uses (k_token alternates them from phase to phase: a
+    // fast wave initialises the next phase while slow ones still draw from this phase's counter)
+    __device__ __forceinline__ void init(const GemvArgs& a, u32 wg_, u32 nwg_, char* lds, u32 ctr_slot = 0) {
         n = a.n; wg = wg_; nwg = nwg_;
         lane = threadIdx.x & 63;
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -590,136 +601,102 @@ struct GemvCtx {
         cbs = a.cb_shift; RB = 64u >> cbs;
         const u32 CB = 1u << cbs;
         nbc = nchunks >> cbs;                                                  // column blocks per row
-        const u32 NBCV = TWO ? 2 * nbc : nbc;                                  // ... of the (virtual) matrix this launch walks
+        NBCV = TWO ? 2 * nbc : nbc;                                            // ... of the (virtual) matrix this launch walks
         TRm = (u32)a.items * (EPI == EPI_ROPE_KV ? 2u : 1u);                   // rows per matrix
         Rm = a.rows_per_pass;
-        const u32 RBP = Rm / RB;                                               // row blocks per pass
+        RBP = Rm / RB;                                                         // row blocks per pass
         npass = (TRm + Rm - 1) / Rm;
-        wcs = a.wc_shift;
-        const u32 WC = 1u << wcs, WR = (u32)kWavesPerBlock >> wcs;
-        wc = wave & (WC - 1); wr = wave >> wcs;
-        nrw = wr < RBP ? (RBP - wr + WR - 1) / WR : 0;                         // row blocks of this wave per pass
-        ncw = (wc < NBCV && nrw) ? (NBCV - wc + WC - 1) >> wcs : 0;            // column blocks of this wave
-        const u32 rb = lane >> cbs, cb = lane & (CB - 1);
-        nbuf = a.nbuf > 0 ? a.nbuf : 2; ring = a.ring; ring_off = kRingOff + wave * (kStepBlk * kRingSlot);
+        np_wg = wg < npass ? (npass - wg + nwg - 1) / nwg : 0;                 // passes of this workgroup
+        SP = ((RBP + H - 1) / H) * NBCV;                                       // steps per pass
+        NS = np_wg * SP;
+        inv_SP = inv_of(SP); inv_NBCV = inv_of(NBCV);
+        nbuf = a.nbuf > 0 ? a.nbuf : 2;
         const GemvLds L = gemv_lds_layout(n, T::kEsz, true, Rm, RB, TWO, nbuf);
-        gstride = L.gstride; buf_bytes = L.buf_bytes; off_xs = L.off_xs; off_scr = L.off_scr;
-        // lane-constant parts of every address (the per-block parts are wave-uniform scalars)
+        gstride = L.gstride; buf_bytes = L.buf_bytes; off_xs = L.off_xs; off_scr = L.off_scr; ctr_off = a.ctr_off ? (u32)a.ctr_off : (u32)L.off_ctr + 4 * (ctr_slot & 1);
+        dW = RB * rowbytes; dS = RB * sn * 4; dT = RB * gstride;               // row block to row block
+        dummy_st = Rm * gstride;
+        // lane-constant parts of every address (the per-step parts are wave-uniform scalars)
+        const u32 rb = lane >> cbs, cb = lane & (CB - 1);
         lane_woff = rb * rowbytes + cb * 16;                                   // weights, bytes from the block base
-        lane_soff = (rb * sn + (cb >> LPGS)) * 4;                              // scales
         lane_xoff = cb * 16;                                                   // activation chunk in LDS
-        lane_sxoff = (cb >> LPGS) * 4;                                         // its scale
         lane_goff = rb * gstride + (cb >> LPGS) * 8;                           // strip entry of this lane's group
         leader = (cb & (LPG - 1)) == 0;
-        dW = WR * RB * rowbytes; dS = WR * RB * sn * 4; dT = WR * RB * gstride; // block-to-block strides
-        dummy_st = Rm * gstride;
-        // Weight and scale blocks are fetched with raw buffer loads: address = descriptor base + wave-uniform
-        // scalar offset (the block) + lane-constant 32-bit offset: no per-load vector address arithmetic, no
-        // branches.  Padding blocks and passes past the end get an offset outside the descriptor -> the load
-        // returns zero without touching memory.  "nt": each weight byte is read once per token.
+        // scale role: lane -> (block j of the step, quant group g of the block); g's leader lane is g * LPG
+        constexpr u32 GPB = 64u / LPG;
+        lane_j = lane / GPB;                                                   // >= H: no scale role (int16: lanes 32..63)
+        const u32 ll = (lane % GPB) * LPG, rb2 = ll >> cbs, cb2 = ll & (CB - 1);
+        lane_s2off = lane_j * dS + (rb2 * sn + (cb2 >> LPGS)) * 4;
+        lane_sx2off = (cb2 >> LPGS) * 4;
+        lane_poff = lane_j * dT + rb2 * gstride + (cb2 >> LPGS) * 8 + 4;
+        // Weight and scale blocks are fetched with raw buffer loads whose whole offset sits in the VGPR operand (lane
+        // constant + the step's scalar): that operand is what the hardware bounds-checks, so padding blocks, rows past
+        // the end of the matrix and steps past the end of the work (offset kOOB) return zero without touching memory.
+        // "nt": each weight byte is read once per token.
         constexpr int kRsrcFlags = 0x00020000;                                 // raw buffer, 32-bit data format (gfx9 family)
         const u32 NM = TWO ? 2u : 1u;
         rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, (int)(NM * TRm * rowbytes), kRsrcFlags);
         rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.sW), 0, (int)(NM * TRm * sn * 4), kRsrcFlags);
         stored = false;
+        // the first two steps of every wave are fixed (wave, wave + 16): they are requested before any barrier
+        if (threadIdx.x == 0) *reinterpret_cast<u32*>(lds + ctr_off) = 2 * kWavesPerBlock;
     }
 
-    // column block ci of this wave -> (second matrix?, column block inside the matrix)
-    __device__ __forceinline__ u32 col_of(u32 ci, bool& second) const {
-        const u32 cv = wc + (ci << wcs);
-        second = TWO && cv >= nbc;
-        return second ? cv - nbc : cv;
+    // step number -> the set's bookkeeping and the scalar offsets of its first block
+    __device__ __forceinline__ void decode(u32 s, Set& S, u32& wo, u32& so) const {
+        if (s >= NS) { S.itl = np_wg; S.st = 0; S.xo = 0; S.nlive = 0; wo = kOOB; so = kOOB; return; }
+        const u32 itl = udiv(s, SP, inv_SP), rem = s - itl * SP;
+        const u32 q = udiv(rem, NBCV, inv_NBCV), cv = rem - q * NBCV;
+        const bool second = TWO && cv >= nbc;
+        const u32 cc = second ? cv - nbc : cv, g0 = (cc << cbs) >> LPGS;       // column block inside its matrix, its first quant group
+        const u32 rb0 = q * H, row0 = (second ? TRm : 0u) + (wg + itl * nwg) * Rm + rb0 * RB;
+        wo = row0 * rowbytes + ((cc << cbs) * 16);
+        so = (row0 * sn + g0) * 4;
+        S.itl = itl; S.xo = cc; S.nlive = RBP - rb0 < (u32)H ? RBP - rb0 : (u32)H;
+        S.st = rb0 * RB * gstride + ((second ? sn : 0u) + g0) * 8;
     }
-    __device__ __forceinline__ void lcur_col(LCur& c) const {                  // offsets of the first row block of column block c.ci
-        bool second; const u32 cc = col_of(c.ci, second);
-        const u32 row0 = (second ? TRm : 0u) + c.pass * Rm + wr * RB;
-        c.ri = 0;
-        c.wo = row0 * rowbytes + ((cc << cbs) * 16);
-        c.so = (row0 * sn + ((cc << cbs) >> LPGS)) * 4;
-    }
-    __device__ __forceinline__ void rcur_col(RCur& c) const {
-        bool second; const u32 cc = col_of(c.ci, second);
-        c.ri = 0;
-        c.st = wr * RB * gstride + ((second ? sn : 0u) + ((cc << cbs) >> LPGS)) * 8;
-        c.xo = cc;
-    }
-    __device__ __forceinline__ void lcur_pass(LCur& c, u32 pass) const {
-        c.pass = pass; c.ci = pass < npass ? 0 : ncw; c.ri = 0; c.wo = 0; c.so = 0;
-        if (c.ci < ncw) lcur_col(c);
-    }
-    __device__ __forceinline__ void rcur_pass(RCur& c, u32 pass) const {
-        c.pass = pass; c.ci = pass < npass ? 0 : ncw; c.ri = 0; c.st = 0; c.xo = 0;
-        if (c.ci < ncw) rcur_col(c);
-    }
-    __device__ __forceinline__ void load_step(Set& S, LCur& c, int ablate) const {
+    __device__ __forceinline__ void load_step(Set& S, u32 s, int ablate) const {
+        u32 wo, so;
+        decode(s, S, wo, so);
+        u32 nl = S.nlive;
+        if (kAblate && (ablate & 4)) { nl = 0; so = kOOB; }
 #pragma unroll
         for (int j = 0; j < H; ++j) {
-            const bool live = c.ci < ncw && !(kAblate && (ablate & 4));
-            const u32 wo = live ? c.wo : kOOB, so = live ? c.so : kOOB;
-            const v4u wv = __builtin_amdgcn_raw_buffer_load_b128(rW, (int)lane_woff, (int)wo, 2);
-            const unsigned sv = __builtin_amdgcn_raw_buffer_load_b32(rS, (int)lane_soff, (int)so, 2);
-            S.w[j] = __builtin_bit_cast(v4i, wv);
-            S.sw[j] = __uint_as_float(sv);
-            c.wo += dW; c.so += dS;
-            if (++c.ri >= nrw) { ++c.ci; if (c.ci < ncw) lcur_col(c); }
+            const u32 woj = (u32)j < nl ? wo + j * dW : kOOB;
+            S.w[j] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rW, (int)(lane_woff + woj), 0, 2));
         }
-        if (c.ci >= ncw) lcur_pass(c, c.pass + nwg);                           // the pass ended inside this step
+        const u32 svo = lane_j < nl ? lane_s2off + so : kOOB;
+        S.sw = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rS, (int)svo, 0, 2));
     }
-    // one step of blocks straight into this wave's LDS ring slots (buffer_load ... lds: no registers held while in flight)
-    __device__ __forceinline__ void load_step_lds(LCur& c, char* lds, int ablate) const {
-#pragma unroll
-        for (int j = 0; j < H; ++j) {
-            const bool live = c.ci < ncw && !(kAblate && (ablate & 4));
-            const u32 wo = live ? c.wo : kOOB, so = live ? c.so : kOOB;
-            char* slot = lds + ring_off + j * kRingSlot;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)slot, 16, (int)lane_woff, (int)wo, 0, 2);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, (__attribute__((address_space(3))) void*)(slot + 1024), 4, (int)lane_soff, (int)so, 0, 2);
-            c.wo += dW; c.so += dS;
-            if (++c.ri >= nrw) { ++c.ci; if (c.ci < ncw) lcur_col(c); }
-        }
-        if (c.ci >= ncw) lcur_pass(c, c.pass + nwg);
+    // the first two steps of weight loads: independent of the activation
+    __device__ __forceinline__ void issue(int ablate) {
+        load_step(setA, wave, ablate);
+        load_step(setB, wave + kWavesPerBlock, ablate);
     }
-    // the first steps of weight loads: independent of the activation, so they are issued before it exists
-    __device__ __forceinline__ void issue(int ablate, char* lds) {
-        lcur_pass(lc, wg);
-        load_step(setA, lc, ablate);
-        load_step(setB, lc, ablate);
-    }
-    // The third step goes to the LDS ring.  It is issued a little later, from inside the activation prologue (after
-    // its staging barrier): a CU's memory pipeline accepts only so many loads at once, and 24 loads per wave queued
-    // up front delayed the prologue itself (measured) -- the ring still has the whole rmsnorm chain to arrive.
-    __device__ __forceinline__ void issue_ring(int ablate, char* lds) { if (ring) load_step_lds(lc, lds, ablate); }
 
-    // reduce one step: dots for all its blocks first (registers), then ONE leader-only region parks them.
-    // Returns true when the pass ended inside this step (the cursor then stands on the workgroup's next pass).
-    v4i xa; float sx; u32 cur_xo;                                              // activation chunk + scale of the current column block
-    __device__ __forceinline__ bool reduce_step(const Set& S, RCur& c, char* lds, char* strips, int ablate) {
+    // reduce one step: the group dots of its H blocks (registers), then the leaders park them; the scale-role lanes park s = sW * sX
+    v4i xa; float sx2; u32 cur_xo;                                             // activation chunk (dot role) / activation scale (scale role) of the current column block
+    __device__ __forceinline__ void reduce_step(const Set& S, char* lds, char* strips, int ablate) {
         const char* xq = lds; const char* xs = lds + off_xs;
-        int d[H]; float p[H]; u32 st[H];
+        if (S.xo != cur_xo) {                                                  // wave-uniform: a new column block
+            cur_xo = S.xo;
+            xa = *reinterpret_cast<const v4i*>(xq + ((cur_xo << cbs) * 16) + lane_xoff);
+            sx2 = *reinterpret_cast<const float*>(xs + (((cur_xo << cbs) >> LPGS) * 4) + lane_sx2off);
+        }
+        float d[H];
 #pragma unroll
         for (int j = 0; j < H; ++j) {
-            const bool live = c.ci < ncw;
-            if (live && c.xo != cur_xo) {                                      // wave-uniform, rare: a new column block
-                cur_xo = c.xo;
-                xa = *reinterpret_cast<const v4i*>(xq + ((cur_xo << cbs) * 16) + lane_xoff);
-                sx = *reinterpret_cast<const float*>(xs + (((cur_xo << cbs) >> LPGS) * 4) + lane_sxoff);
-            }
             int t = (kAblate && (ablate & 8)) ? 0 : quad_sum(dot_chunk<QT>(S.w[j], xa));
             if constexpr (LPG == 8) t += __builtin_amdgcn_update_dpp(0, t, 0x104 /* row_shl:4 */, 0xF, 0xF, true);
-            d[j] = t;
-            p[j] = __fmul_rn(S.sw[j], sx);                                     // s = sW * sX (quant_operators.cpp:274)
-            st[j] = live ? c.st : dummy_st;                                    // padding blocks hold zeros: parked in the dummy strips
-            c.st += dT;
-            if (++c.ri >= nrw) { ++c.ci; if (c.ci < ncw) rcur_col(c); }
+            d[j] = (float)t;                                                   // exact int32 -> fp32, as "s * dot" does
         }
         if (leader) {
 #pragma unroll
-            for (int j = 0; j < H; ++j)
-                *reinterpret_cast<float2*>(strips + st[j] + lane_goff) = make_float2((float)d[j], p[j]);   // exact int32 -> fp32, as "s * dot" does
+            for (int j = 0; j < H; ++j) {
+                const u32 stj = (u32)j < S.nlive ? S.st + j * dT : dummy_st;   // padding blocks hold zeros: parked in the dummy strips
+                *reinterpret_cast<float*>(strips + stj + lane_goff) = d[j];
+            }
         }
-        const bool last = c.ci >= ncw;
-        if (last) rcur_pass(c, c.pass + nwg);
-        return last;
+        if (lane_j < S.nlive) *reinterpret_cast<float*>(strips + S.st + lane_poff) = __fmul_rn(S.sw, sx2);   // s = sW * sX (quant_operators.cpp:274)
     }
 
     // the end of a pass: one barrier, then ONE wave runs the fp32 chains of all Rm rows and the epilogue
@@ -740,6 +717,9 @@ struct GemvCtx {
         }
         __syncthreads();
         if (!chain_wave) return;
+#ifdef FLM_TRACE_BAR
+        if (kAblate && a.trace && threadIdx.x == 0 && it == 0) a.trace[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memtime();
+#endif
         stored = true;
         // ---- the reference's fp32 chain, lane r = row r: o[j] += s * dot (FMA), groups ascending.
         //      Strip entries are {d, s} pairs; reads run 8 groups ahead of the FMAs (ring of 4 float4),
@@ -802,64 +782,36 @@ struct GemvCtx {
     __device__ __forceinline__ void run(const GemvArgs& a, char* lds, Stamp&& stamp) {
         int pos = 0;
         if constexpr (EPI == EPI_ROPE_KV) pos = *a.pos_ptr;
-        xa = v4i{0, 0, 0, 0}; sx = 0.f; cur_xo = 0xffffffffu;
-        rcur_pass(rc, wg);
-        u32 it = 0;                                                            // pass counter of this workgroup
+        xa = v4i{0, 0, 0, 0}; sx2 = 0.f; cur_xo = 0xffffffffu;
+        u32* ctr = reinterpret_cast<u32*>(lds + ctr_off);
+        u32 it = 0;                                                            // pass of this workgroup this wave is in
         bool tr3 = false;
-        auto step_tail = [&](bool last, u32 pass, char* strips) {
-#ifndef FLM_TRACE_PRO
-            if (it == 0 && !tr3) { tr3 = true; stamp(3); }
-#endif
-            if (last) {
-#ifndef FLM_TRACE_PRO
+        // a wave's step numbers only grow, so when a set belongs to a later pass every earlier pass is complete for this wave
+        auto do_set = [&](Set& S) -> bool {
+            while (it < S.itl) {
+                char* strips = lds + off_scr + (nbuf > 1 ? (it & 1) * buf_bytes : 0u);   // double buffered across passes
+#ifdef FLM_TRACE_WAVES
+                if (kAblate && a.trace && it == 0 && lane == 0 && wave % 3 == 0) a.trace[blockIdx.x * 8 + 1 + wave / 3] = __builtin_amdgcn_s_memtime();
+#elif !defined(FLM_TRACE_PRO)
                 if (it == 0) stamp(4);
 #endif
-                finish_pass(a, pass, it, strips, pos);
+                finish_pass(a, wg + it * nwg, it, strips, pos);
 #ifndef FLM_TRACE_PRO
                 if (it == 0) stamp(5);
 #endif
                 ++it;
             }
+            if (S.itl >= np_wg) return false;                                  // no work left (every later number is past the end too)
+            reduce_step(S, lds, lds + off_scr + (nbuf > 1 ? (S.itl & 1) * buf_bytes : 0u), a.ablate);
+            u32 s = 0;
+            if (lane == 0) s = atomicAdd(ctr, 1u);
+            load_step(S, __builtin_amdgcn_readfirstlane(s), a.ablate);         // refill this set: a full cycle ahead
+#if !defined(FLM_TRACE_PRO) && !defined(FLM_TRACE_BAR)
+            if (!tr3) { tr3 = true; stamp(3); }
+#endif
+            return true;
         };
-        auto do_step = [&](Set& S) {
-            char* strips = lds + off_scr + (nbuf > 1 ? (it & 1) * buf_bytes : 0u);   // double buffered across passes
-            const u32 pass = rc.pass;
-            const bool last = reduce_step(S, rc, lds, strips, a.ablate);
-            load_step(S, lc, a.ablate);                                        // refill this set: a full cycle ahead
-            step_tail(last, pass, strips);
-        };
-        auto do_step_lds = [&]() {
-            char* strips = lds + off_scr + (nbuf > 1 ? (it & 1) * buf_bytes : 0u);
-            const u32 pass = rc.pass;
-            // The compiler does not know that the direct-to-LDS loads feed the ds_reads below, so the wait is spelled
-            // out: the ring step was issued before the refills of the two register sets (2 x 8 loads); loads retire
-            // in issue order, so "at most 16 outstanding" means the ring has landed.  ("memory": nothing moves across.)
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            Set S;
-#pragma unroll
-            for (int j = 0; j < H; ++j) {
-                const char* slot = lds + ring_off + j * kRingSlot;
-                S.w[j] = *reinterpret_cast<const v4i*>(slot + lane * 16);
-                S.sw[j] = *reinterpret_cast<const float*>(slot + 1024 + lane * 4);
-            }
-            const bool last = reduce_step(S, rc, lds, strips, a.ablate);
-            asm volatile("" ::: "memory");                                     // the slots have been read (their values were consumed above)
-            load_step_lds(lc, lds, a.ablate);                                  // refill the slots
-            step_tail(last, pass, strips);
-        };
-        while (true) {
-            if (rc.pass >= npass) break;
-            do_step(setA);
-            if (rc.pass >= npass) break;
-            do_step(setB);
-            if (ring) {
-                if (rc.pass >= npass) break;
-                do_step_lds();
-            }
-        }
-        // loads of padding / past-the-end blocks may still be in flight towards the ring: they must have landed before
-        // anybody reuses that LDS (the next phase of k_token, or the next kernel's workgroup on this CU)
-        if (ring) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        while (do_set(setA) && do_set(setB)) {}
     }
 };
 
@@ -867,7 +819,11 @@ template <int QT, int PRO, int EPI, int XR>
 __global__ void __launch_bounds__(kGemvBlock, 4) k_gemv(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     unsigned long long rt0 = 0;
+#ifdef FLM_TRACE_WAVES
+    auto stamp = [&](int k) { if (kAblate && a.trace && threadIdx.x == 0 && k == 0) a.trace[blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime(); };
+#else
     auto stamp = [&](int k) { if (kAblate && a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime(); };
+#endif
     if (kAblate && a.trace && threadIdx.x == 0) rt0 = __builtin_amdgcn_s_memrealtime();
     stamp(0);
     if (a.ablate & 16) return;
@@ -879,10 +835,10 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_gemv(const GemvArgs a) {
     float4 xv[XR > 0 ? XR : 1], nv[XR > 0 ? XR : 1];
     gemv_preload<QT, PRO, XR>(a, xv, nv);
     GemvCtx<QT, EPI> g;
-    g.init(a, blockIdx.x, gridDim.x);
-    if constexpr (PRO == PRO_NONE) g.issue(a.ablate, lds);
+    g.init(a, blockIdx.x, gridDim.x, lds);
+    if constexpr (PRO == PRO_NONE) g.issue(a.ablate);
     stamp(1);
-    gemv_prologue<QT, PRO, XR>(a, lds, xv, nv, [&]() { g.issue(a.ablate, lds); g.issue_ring(a.ablate, lds); });
+    gemv_prologue<QT, PRO, XR>(a, lds, xv, nv, [&]() { g.issue(a.ablate); });
     stamp(2);
     if (a.ablate & 32) return;
     g.run(a, lds, stamp);
@@ -1235,15 +1191,13 @@ __device__ __forceinline__ void mega_prologue(const GemvArgs& a, char* lds, Gemv
                     else *reinterpret_cast<float4*>(scratch + e) = make_float4(v[j].x, v[j].y, v[j].z, v[j].w);
                 }
             }
-            if (base == 0) g.issue(a.ablate, lds);                             // the postponed weight prefetch: behind the activation in the return order
+            if (base == 0) g.issue(a.ablate);                             // the postponed weight prefetch: behind the activation in the return order
         }
     } else load_nw();
     __syncthreads();
     float r = 1.0f;
     if constexpr (PRO == PRO_RMSNORM_QUANT) {
-        if (tid >= kWave) g.issue_ring(a.ablate, lds);         // (wave 0 must not queue behind a full memory pipeline before its chain)
         if (tid < 4 && !(a.ablate & 2)) red[8 + tid] = sq_chain(scratch + tid * ns, n4);
-        if (tid < kWave) g.issue_ring(a.ablate, lds);
         __syncthreads();
         const float ss = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, red[8]), red[9]), red[10]), red[11]);
         r = rms_scale(ss, n);
@@ -1299,7 +1253,7 @@ __device__ __attribute__((noinline)) void token_phase(const TokenArgs& t, const 
     const GemvArgs a = kload(ap);
     unsigned epoch = ts.epoch;
     // the phase's first weight loads; activation waves wait until they have asked for the activation
-    auto prefetch = [&]() { g.init(a, wg, nwg); if (wave >= kActWaves) g.issue(a.ablate, lds); };
+    auto prefetch = [&]() { g.init(a, wg, nwg, lds); if (wave >= kActWaves) g.issue(a.ablate); };
     // my stores of the previous phase must have completed before the prefetch is queued behind them (one vmcnt counter)
     if (ts.stored) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if constexpr (ATTN) {

@@ -12,7 +12,6 @@ cfg = synth.make_config("7B", ff.QT_INT8); cfg.n_layers = L
 ctx = capi.Ctx(capi.desc_from_config(cfg))
 ctx.upload_all(synth.make_tensors(cfg, seed=1))
 if abl: ctx.set_option("ablate", abl)
-if os.environ.get("FLM_RING") is not None: ctx.set_option("use_ring", int(os.environ["FLM_RING"]))
 prompt = np.arange(1, pos + 1, dtype=np.int32) % cfg.vocab_size
 first = ctx.forward_argmax(prompt, 0)
 ctx.decode_greedy(first, pos, 8)
