@@ -406,9 +406,6 @@ __device__ __forceinline__ void gemv_preload(const GemvArgs& a, float4 (&xv)[XR 
     }
 }
 
-#ifndef FLM_WSLEEP
-#define FLM_WSLEEP 2
-#endif
 #ifdef FLM_TRACE_PRO
 #define FLM_PRO_STAMP(k) if (kAblate && a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime();
 #else
@@ -440,7 +437,9 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
         if constexpr (PRO == PRO_QUANT) {
             // no staging here: the hook (the weight prefetch) runs as soon as this thread's activation registers have landed
             if constexpr (XR > 0) { asm volatile("" :: "v"(xv[XR - 1].w)); }
-            after_stage();
+            FLM_PRO_STAMP(3)
+            after_stage(0);
+            FLM_PRO_STAMP(4)
         }
         if constexpr (PRO == PRO_RMSNORM_QUANT) {
             // simd::square_sum -> square_sum_avx128 (x86_simd.cpp:942-960; the AVX2 branch is dead, :1093):
@@ -462,15 +461,9 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
             // the hook issues the weight prefetch.  Wave 0 goes first (the others give it ~128 cycles): its 16 loads
             // enter an empty memory pipeline at once and it is free for the chain; queued behind the other 15 waves'
             // 240 loads it would stall for ~1 us before (or after) the chain.
-#ifdef FLM_W0_LATE
-            if (tid >= kWave) after_stage();
+            if (tid >= kWave) __builtin_amdgcn_s_sleep(2);
+            after_stage(0);
             if (tid < 4 && !(a.ablate & 2)) red[8 + tid] = sq_chain(scratch + tid * ns, n4);
-            if (tid < kWave) after_stage();
-#else
-            if (tid >= kWave) __builtin_amdgcn_s_sleep(FLM_WSLEEP);
-            after_stage();
-            if (tid < 4 && !(a.ablate & 2)) red[8 + tid] = sq_chain(scratch + tid * ns, n4);
-#endif
             FLM_PRO_STAMP(4)
             __syncthreads();
             const float ss = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, red[8]), red[9]), red[10]), red[11]);
@@ -515,6 +508,9 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
                 if constexpr (PRO == PRO_RMSNORM_QUANT) w = *reinterpret_cast<const float4*>(a.norm_w + e);
             }
             round(i, v, w);
+        }
+        if constexpr (PRO == PRO_QUANT) {
+            FLM_PRO_STAMP(5)
         }
         __syncthreads();
         if (a.dbg_xq && blockIdx.x == 0) {
@@ -636,7 +632,7 @@ struct GemvCtx {
         const u32 NM = TWO ? 2u : 1u;
         rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, (int)(NM * TRm * rowbytes), kRsrcFlags);
         rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.sW), 0, (int)(NM * TRm * sn * 4), kRsrcFlags);
-        stored = false;
+        stored = false; primedA = primedB = false;
         // the first two steps of every wave are fixed (wave, wave + 16): they are requested before any barrier
         if (threadIdx.x == 0) *reinterpret_cast<u32*>(lds + ctr_off) = 2 * kWavesPerBlock;
     }
@@ -668,9 +664,11 @@ struct GemvCtx {
         S.sw = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rS, (int)svo, 0, 2));
     }
     // the first two steps of weight loads: independent of the activation
-    __device__ __forceinline__ void issue(int ablate) {
-        load_step(setA, wave, ablate);
-        load_step(setB, wave + kWavesPerBlock, ablate);
+    // (part 1 / 2: only the first / second set; a set that was never requested is drawn at the start of run())
+    bool primedA, primedB;
+    __device__ __forceinline__ void issue(int ablate, int part = 0) {
+        if (part != 2) { load_step(setA, wave, ablate); primedA = true; }
+        if (part != 1) { load_step(setB, wave + kWavesPerBlock, ablate); primedB = true; }
     }
 
     // reduce one step: the group dots of its H blocks (registers), then the leaders park them; the scale-role lanes park s = sW * sX
@@ -811,6 +809,8 @@ struct GemvCtx {
 #endif
             return true;
         };
+        if (!primedA) load_step(setA, wave, a.ablate);                         // (a wave that was busy elsewhere during the prologue)
+        if (!primedB) load_step(setB, wave + kWavesPerBlock, a.ablate);
         while (do_set(setA) && do_set(setB)) {}
     }
 };
@@ -838,7 +838,7 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_gemv(const GemvArgs a) {
     g.init(a, blockIdx.x, gridDim.x, lds);
     if constexpr (PRO == PRO_NONE) g.issue(a.ablate);
     stamp(1);
-    gemv_prologue<QT, PRO, XR>(a, lds, xv, nv, [&]() { g.issue(a.ablate); });
+    gemv_prologue<QT, PRO, XR>(a, lds, xv, nv, [&](int part) { g.issue(a.ablate, part); });
     stamp(2);
     if (a.ablate & 32) return;
     g.run(a, lds, stamp);
@@ -1340,7 +1340,7 @@ __global__ void __launch_bounds__(kGemvBlock) k_rows_prologue(const RowsArgs r) 
     a.rows_per_pass = 4; a.cb_shift = 4;                                     // (only the fixed LDS offsets are used)
     float4 xv[XR > 0 ? XR : 1], nv[XR > 0 ? XR : 1];
     gemv_preload<QT, PRO, XR>(a, xv, nv);
-    gemv_prologue<QT, PRO, XR>(a, lds, xv, nv, []() {});
+    gemv_prologue<QT, PRO, XR>(a, lds, xv, nv, [](int) {});
     const GemvLds L = gemv_lds_layout(r.n, T::kEsz, true, 4, 4, false);
     const int nb16 = r.n * T::kEsz / 16, sn = r.n / kGroup;
     int4* qo = reinterpret_cast<int4*>(reinterpret_cast<char*>(r.xq) + (size_t)blockIdx.x * r.n * T::kEsz);
