@@ -221,7 +221,7 @@ constexpr int kStepBlk = 4;            // H: 1 KiB wave loads per step; two step
 // LDS layout: [xq : n*esz] [xs : n/64 floats, padded to 16 B] [red : 16 floats] [scratch]
 // scratch = max( rmsnorm transpose staging 4n bytes ,
 //                2 buffers x (Rm + RB) strips; strip r = { float(group dot), sW*sX } pairs of row r, groups ascending
-//                (SWIGLU: the W1 groups followed by the W3 groups) )
+//                (SWIGLU: entries { d(W1), d(W3), s(W1), s(W3) }: the two chains are the halves of one packed FMA) )
 struct GemvLds {
     int off_xs, off_red, off_ctr, off_scr;     // byte offsets (off_ctr: the two step counters of GemvCtx)
     int gstride;                      // BYTES per strip: 16 x odd, so that 16 lanes reading 16 B each from 16 strips hit all banks
@@ -558,6 +558,7 @@ struct GemvCtx {
     static constexpr u32 LPG = 1u << LPGS;
     static constexpr bool TWO = EPI == EPI_SWIGLU;
     static constexpr int H = kStepBlk;
+    static constexpr u32 ES = TWO ? 16 : 8;                                    // bytes per strip entry: {d, s}, SWIGLU {d1, d3, s1, s3}
     static constexpr u32 kOOB = 0x80000000u;
 
     // A STEP is H consecutive row blocks of one column block of one pass: H weight loads of 1 KiB per wave plus ONE scale
@@ -615,7 +616,7 @@ struct GemvCtx {
         const u32 rb = lane >> cbs, cb = lane & (CB - 1);
         lane_woff = rb * rowbytes + cb * 16;                                   // weights, bytes from the block base
         lane_xoff = cb * 16;                                                   // activation chunk in LDS
-        lane_goff = rb * gstride + (cb >> LPGS) * 8;                           // strip entry of this lane's group
+        lane_goff = rb * gstride + (cb >> LPGS) * ES;                          // strip entry of this lane's group
         leader = (cb & (LPG - 1)) == 0;
         // scale role: lane -> (block j of the step, quant group g of the block); g's leader lane is g * LPG
         constexpr u32 GPB = 64u / LPG;
@@ -623,7 +624,7 @@ struct GemvCtx {
         const u32 ll = (lane % GPB) * LPG, rb2 = ll >> cbs, cb2 = ll & (CB - 1);
         lane_s2off = lane_j * dS + (rb2 * sn + (cb2 >> LPGS)) * 4;
         lane_sx2off = (cb2 >> LPGS) * 4;
-        lane_poff = lane_j * dT + rb2 * gstride + (cb2 >> LPGS) * 8 + 4;
+        lane_poff = lane_j * dT + rb2 * gstride + (cb2 >> LPGS) * ES + ES / 2;
         // Weight and scale blocks are fetched with raw buffer loads whose whole offset sits in the VGPR operand (lane
         // constant + the step's scalar): that operand is what the hardware bounds-checks, so padding blocks, rows past
         // the end of the matrix and steps past the end of the work (offset kOOB) return zero without touching memory.
@@ -648,7 +649,7 @@ struct GemvCtx {
         wo = row0 * rowbytes + ((cc << cbs) * 16);
         so = (row0 * sn + g0) * 4;
         S.itl = itl; S.xo = cc; S.nlive = RBP - rb0 < (u32)H ? RBP - rb0 : (u32)H;
-        S.st = rb0 * RB * gstride + ((second ? sn : 0u) + g0) * 8;
+        S.st = rb0 * RB * gstride + g0 * ES + (second ? 4u : 0u);
     }
     __device__ __forceinline__ void load_step(Set& S, u32 s, int ablate) const {
         u32 wo, so;
@@ -720,31 +721,66 @@ struct GemvCtx {
 #endif
         stored = true;
         // ---- the reference's fp32 chain, lane r = row r: o[j] += s * dot (FMA), groups ascending.
-        //      Strip entries are {d, s} pairs; reads run 8 groups ahead of the FMAs (ring of 4 float4),
-        //      so the chain advances at FMA latency.  SWIGLU: the W1 and W3 chains interleave.
+        //      A lone wave issues an instruction every ~5-7 cycles whatever its kind, so the loop is little more than the
+        //      dependent FMAs: strip entries are read 4 at a time into two register rings, one ring's reads fly while the
+        //      other ring's FMAs run, ONE explicit s_waitcnt per ring.  SWIGLU: an entry is {d1, d3, s1, s3}, and the W1
+        //      and W3 chains are the two halves of one v_pk_fma_f32 (each half an IEEE fma), operands in place.
         float acc = 0.f, acc2 = 0.f;
         if (lane < Rm && !(a.ablate & 1)) {
             const char* sp = strips + lane * gstride;
-            const char* sp2 = sp + sn * 8;
             u32 g = 0;
-#define FLM_CH2(q) acc = __fmaf_rn(q.y, q.x, acc); acc = __fmaf_rn(q.w, q.z, acc);
-#define FLM_CH2B(q) acc2 = __fmaf_rn(q.y, q.x, acc2); acc2 = __fmaf_rn(q.w, q.z, acc2);
-            if (sn >= 8) {
-                float4 q0 = *reinterpret_cast<const float4*>(sp), q1 = *reinterpret_cast<const float4*>(sp + 16), q2 = *reinterpret_cast<const float4*>(sp + 32), q3 = *reinterpret_cast<const float4*>(sp + 48);
-                float4 r0 = q0, r1 = q0, r2 = q0, r3 = q0;
-                if constexpr (TWO) { r0 = *reinterpret_cast<const float4*>(sp2); r1 = *reinterpret_cast<const float4*>(sp2 + 16); r2 = *reinterpret_cast<const float4*>(sp2 + 32); r3 = *reinterpret_cast<const float4*>(sp2 + 48); }
-                for (; g + 8 <= sn; g += 8) {
-                    const char* pn = sp + (g + 8) * 8; const char* pn2 = sp2 + (g + 8) * 8;     // next 8 groups (read-ahead; past the end on the last round: inside the allocation, never consumed)
-                    FLM_CH2(q0) if constexpr (TWO) { FLM_CH2B(r0) } q0 = *reinterpret_cast<const float4*>(pn);      if constexpr (TWO) r0 = *reinterpret_cast<const float4*>(pn2);
-                    FLM_CH2(q1) if constexpr (TWO) { FLM_CH2B(r1) } q1 = *reinterpret_cast<const float4*>(pn + 16); if constexpr (TWO) r1 = *reinterpret_cast<const float4*>(pn2 + 16);
-                    FLM_CH2(q2) if constexpr (TWO) { FLM_CH2B(r2) } q2 = *reinterpret_cast<const float4*>(pn + 32); if constexpr (TWO) r2 = *reinterpret_cast<const float4*>(pn2 + 32);
-                    FLM_CH2(q3) if constexpr (TWO) { FLM_CH2B(r3) } q3 = *reinterpret_cast<const float4*>(pn + 48); if constexpr (TWO) r3 = *reinterpret_cast<const float4*>(pn2 + 48);
+#define FLM_RD4(r0, r1, r2, r3, ptr) r0 = *reinterpret_cast<const float4*>(ptr); r1 = *reinterpret_cast<const float4*>((ptr) + 16); r2 = *reinterpret_cast<const float4*>((ptr) + 32); r3 = *reinterpret_cast<const float4*>((ptr) + 48);
+            if constexpr (TWO) {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                f2 ac = {0.f, 0.f};
+#define FLM_CH(q) ac = __builtin_elementwise_fma(f2{q.z, q.w}, f2{q.x, q.y}, ac);
+                if (sn >= 8) {
+                    float4 a0, a1, a2, a3, b0, b1, b2, b3;
+                    FLM_RD4(a0, a1, a2, a3, sp)
+                    for (; g + 8 <= sn; g += 8) {
+                        const char* pn = sp + (g + 4) * 16;
+                        FLM_RD4(b0, b1, b2, b3, pn)
+                        __builtin_amdgcn_s_waitcnt(0xC47F);        // lgkmcnt <= 4: ring A has landed
+                        __builtin_amdgcn_sched_barrier(0);
+                        FLM_CH(a0) FLM_CH(a1) FLM_CH(a2) FLM_CH(a3)
+                        __builtin_amdgcn_sched_barrier(0);
+                        FLM_RD4(a0, a1, a2, a3, pn + 64)           // (past the end on the last round: inside the allocation, never consumed)
+                        __builtin_amdgcn_s_waitcnt(0xC47F);        // ring B has landed
+                        __builtin_amdgcn_sched_barrier(0);
+                        FLM_CH(b0) FLM_CH(b1) FLM_CH(b2) FLM_CH(b3)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // ring A holds groups g .. g+3
+                    if (g < sn) { FLM_CH(a0) ++g; } if (g < sn) { FLM_CH(a1) ++g; } if (g < sn) { FLM_CH(a2) ++g; } if (g < sn) { FLM_CH(a3) ++g; }
                 }
+                for (; g < sn; ++g) { const float4 e = *reinterpret_cast<const float4*>(sp + g * 16); FLM_CH(e) }
+#undef FLM_CH
+                acc = ac.x; acc2 = ac.y;
+            } else {
+#define FLM_CH(q) acc = __fmaf_rn(q.y, q.x, acc); acc = __fmaf_rn(q.w, q.z, acc);
+                if (sn >= 16) {
+                    float4 a0, a1, a2, a3, b0, b1, b2, b3;
+                    FLM_RD4(a0, a1, a2, a3, sp)
+                    for (; g + 16 <= sn; g += 16) {
+                        const char* pn = sp + (g + 8) * 8;
+                        FLM_RD4(b0, b1, b2, b3, pn)
+                        __builtin_amdgcn_s_waitcnt(0xC47F);
+                        __builtin_amdgcn_sched_barrier(0);
+                        FLM_CH(a0) FLM_CH(a1) FLM_CH(a2) FLM_CH(a3)
+                        __builtin_amdgcn_sched_barrier(0);
+                        FLM_RD4(a0, a1, a2, a3, pn + 64)
+                        __builtin_amdgcn_s_waitcnt(0xC47F);
+                        __builtin_amdgcn_sched_barrier(0);
+                        FLM_CH(b0) FLM_CH(b1) FLM_CH(b2) FLM_CH(b3)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // ring A holds groups g .. g+7; a pair is consumed only when both of its groups exist
+                    if (g + 2 <= sn) { FLM_CH(a0) g += 2; } if (g + 2 <= sn) { FLM_CH(a1) g += 2; } if (g + 2 <= sn) { FLM_CH(a2) g += 2; } if (g + 2 <= sn) { FLM_CH(a3) g += 2; }
+                }
+#undef FLM_CH
+                for (; g < sn; ++g) { const float2 e = *reinterpret_cast<const float2*>(sp + g * 8); acc = __fmaf_rn(e.y, e.x, acc); }
             }
-#undef FLM_CH2
-#undef FLM_CH2B
-            for (u32 h = g; h < sn; ++h) { const float2 e = *reinterpret_cast<const float2*>(sp + h * 8); acc = __fmaf_rn(e.y, e.x, acc); }
-            if constexpr (TWO) for (u32 h = g; h < sn; ++h) { const float2 e = *reinterpret_cast<const float2*>(sp2 + h * 8); acc2 = __fmaf_rn(e.y, e.x, acc2); }
+#undef FLM_RD4
         }
         // ---------------- epilogues ----------------
         if constexpr (EPI == EPI_STORE || EPI == EPI_RESIDUAL) {
