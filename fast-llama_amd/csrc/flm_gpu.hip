@@ -67,6 +67,7 @@ struct flm_ctx {
     float *pf_x = nullptr, *pf_qkv = nullptr, *pf_q = nullptr, *pf_att = nullptr, *pf_gu = nullptr, *pf_hd = nullptr, *pf_xs = nullptr; void* pf_xq = nullptr;
     int use_mega = 0;                                  // option "use_mega": run single-GPU tokens as ONE persistent kernel (k_token); opt-in until it beats the per-phase kernels
     GemvArgs* mega_gemv = nullptr; AttnArgs* mega_attn = nullptr; unsigned* mega_bar = nullptr; int* mega_err = nullptr;
+    int fuse_attn_o = 1;                               // option "fuse_attn_o": attention + Wo GEMV in one launch (k_attn_o; single GPU)
     size_t mega_lds = 0; int mega_ok = -1;              // -1 not built yet, 0 shape not supported by k_token, 1 ready
     int trace_class = -1; unsigned long long* trace = nullptr;   // FLM_ABLATE builds: GEMV timeline of one kernel class
     std::map<int, hipGraphExec_t> graphs;             // key = with_cls*4 + advance
@@ -252,16 +253,16 @@ bool model_complete(const flm_ctx* c) {
     return true;
 }
 
-// k_token reports a grid barrier that never completed (a workgroup was not resident) through *mega_err
+// k_token / k_attn_o report a wait that never completed (a workgroup was not resident) through *mega_err
 int mega_check(flm_ctx* c) {
-    if (c->mega_ok != 1) return FLM_OK;
+    if (c->world != 1 || (c->mega_ok != 1 && !c->fuse_attn_o)) return FLM_OK;
     int e = 0;
     HIPC(c, hipMemcpy(&e, c->mega_err, 4, hipMemcpyDeviceToHost));
     if (e) {   // fall back to the per-phase kernels for the rest of this context's life
-        hipMemset(c->mega_err, 0, 4); c->use_mega = 0;
+        hipMemset(c->mega_err, 0, 4); c->use_mega = 0; c->fuse_attn_o = 0;
         for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
         c->graphs.clear();
-        return fail(c, FLM_ERR_HIP, "k_token: a grid barrier timed out (workgroups not co-resident?); this call's results are invalid, later calls use the per-phase kernels");
+        return fail(c, FLM_ERR_HIP, "a cross-workgroup wait timed out (workgroups not co-resident?); this call's results are invalid, later calls use one kernel per phase");
     }
     return FLM_OK;
 }
@@ -361,6 +362,28 @@ int build_mega(flm_ctx* c) {
     return FLM_OK;
 }
 
+// attention + Wo GEMV of layer l in one launch (k_attn_o); returns FLM_ERR_UNSUPPORTED when the shape does not allow it
+template <int QT>
+int launch_attn_o(flm_ctx* c, hipStream_t st, int l) {
+    const auto& d = c->d;
+    const int heads = c->heads_local, wgs = c->cu_count - heads;
+    if (wgs < 1 || heads > 512) return FLM_ERR_UNSUPPORTED;
+    GemvArgs a = args_o(c, l);
+    if (c->trace_class == 101 && l == 0) a.trace = c->trace;     // tools/trace_ao.py
+    GemvPlan P;
+    int r = plan_gemv<QT, PRO_QUANT, EPI_RESIDUAL>(c, a, wgs, P); if (r) return r;
+    const int rounds = (a.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4);
+    if (rounds > 3) return FLM_ERR_UNSUPPORTED;
+    size_t lds = attn_lds_bytes(d.max_seq_len, c->hs); if (P.lds > lds) lds = P.lds;
+    const AttnArgs aa = args_attn(c, l);
+    unsigned* flag = c->mega_bar;                                // one 64-byte line per head, value = layer + 1; k_embed clears them at the start of the token
+    const dim3 grid(heads + P.grid), block(kGemvBlock);
+    if (rounds <= 1) hipLaunchKernelGGL((k_attn_o<QT, 1>), grid, block, lds, st, aa, a, heads, flag, (unsigned)(l + 1), c->mega_err);
+    else             hipLaunchKernelGGL((k_attn_o<QT, 3>), grid, block, lds, st, aa, a, heads, flag, (unsigned)(l + 1), c->mega_err);
+    HIPC(c, hipGetLastError());
+    return FLM_OK;
+}
+
 int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance) {
     const auto& d = c->d;
     const int qt = d.quant_type, hs = c->hs, L = d.n_layers;
@@ -386,7 +409,12 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance) {
                 Tick t(c, st, KC_QKV);
                 int r = launch_gemv<PRO_RMSNORM_QUANT, EPI_ROPE_KV>(c, st, qt, traced(args_qkv(c, l), KC_QKV, l), wgs); if (r) return r;
             }
-            {   // ATTN task (execute_attn :441-449): local heads write their slice of the full att_out vector
+            bool fused = false;
+            if (!tp && c->fuse_attn_o && !c->timing && (c->trace_class < 0 || c->trace_class == 101)) {   // attention + ATTN_O in one launch
+                const int r = qt == FLM_QT_INT8 ? launch_attn_o<QT_INT8>(c, st, l) : launch_attn_o<QT_INT16>(c, st, l);
+                if (r == FLM_OK) fused = true; else if (r != FLM_ERR_UNSUPPORTED) return r;
+            }
+            if (!fused) {   // ATTN task (execute_attn :441-449): local heads write their slice of the full att_out vector
                 Tick t(c, st, KC_ATTN);
                 AttnArgs aa = args_attn(c, l); if (c->trace_class == KC_ATTN && l == 0) aa.trace = c->trace;
                 hipLaunchKernelGGL(k_attn_decode, dim3(c->heads_local), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, hs), st, aa);
@@ -396,7 +424,7 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance) {
                 Tick t(c, st, KC_ALLREDUCE);
                 NCCLC(c, ncclAllGather(c->att_out + (size_t)c->plan.head_begin * hs, c->att_out, c->dim_local, ncclFloat, c->comm, st));
             }
-            {   // ATTN_O task + residual (transformer.cpp:138-139, execute_attn_o :457-466): this rank's rows of Wo
+            if (!fused) {   // ATTN_O task + residual (transformer.cpp:138-139, execute_attn_o :457-466): this rank's rows of Wo
                 Tick t(c, st, KC_ATTN_O);
                 int r = launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, traced(args_o(c, l), KC_ATTN_O, l), wgs); if (r) return r;
             }
@@ -752,6 +780,7 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (k == "use_mega") c->use_mega = value;
     else if (k == "use_prefill") c->use_prefill = value;
     else if (k == "use_mfma") c->use_mfma = value;
+    else if (k == "fuse_attn_o") c->fuse_attn_o = value;
     else if (k == "trace") {        // value = kernel class to trace (KC_*), -1 off; meaningful in FLM_ABLATE builds only
         c->trace_class = value;
         if (!c->trace) { HIPC(c, hipMalloc((void**)&c->trace, 4096 * 8 * 8)); }

@@ -386,7 +386,8 @@ __device__ __forceinline__ float sq_chain_wave(const float* p, int n4, int* iter
 // loaded BEFORE issuing its first batch of weight loads: loads return in issue order, so an x load
 // issued behind 32 HBM weight loads would make the whole prologue wait for them.
 // ------------------------------------------------------------------------------------------
-template <int QT, int PRO, int XR>
+// COH: the activation was written by other workgroups of the SAME kernel (k_attn_o) -> coherent sc0|sc1 loads
+template <int QT, int PRO, int XR, bool COH = false>
 __device__ __forceinline__ void gemv_preload(const GemvArgs& a, float4 (&xv)[XR > 0 ? XR : 1], float4 (&wv)[XR > 0 ? XR : 1]) {
     if constexpr (PRO == PRO_QUANT || PRO == PRO_RMSNORM_QUANT) {
         // branch-free: raw buffer loads, elements past n read as zero
@@ -396,7 +397,7 @@ __device__ __forceinline__ void gemv_preload(const GemvArgs& a, float4 (&xv)[XR 
 #pragma unroll
         for (int i = 0; i < XR; ++i) {
             const int off = (threadIdx.x * 4 + i * kGemvBlock * 4) * 4;
-            const v4f v = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+            const v4f v = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, COH ? kAuxCoherent : 0));
             xv[i] = make_float4(v.x, v.y, v.z, v.w);
             if constexpr (PRO == PRO_RMSNORM_QUANT) {
                 const v4f u = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rn, off, 0, 0));
@@ -1118,6 +1119,54 @@ __global__ void __launch_bounds__(kAttnBlock) k_attn_decode(const AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Attention and the output projection in ONE launch (single GPU): workgroups [0, n_heads) run one attention head each,
+// the others run the Wo GEMV.  The GEMV workgroups request their first steps of Wo -- with 16.8 MB over ~224 CUs that is
+// every block they will ever need -- the moment the kernel starts, and only then wait for the heads: the weight fetch,
+// ~3.5 us of the stand-alone attn_o kernel, and one kernel boundary (1.6 us) disappear behind the attention.
+// The heads publish their output with write-through stores (st_agent) and, once those have completed, each writes `target`
+// (layer + 1) into its own 64-byte flag line; in every GEMV workgroup lane i polls head i's line (the pattern of
+// grid_barrier: a shared counter cost 2.7 us from the last head's bump to the last poll's success), then the activation
+// is read with coherent loads.  All workgroups are resident (grid <= CUs, one 1024-thread workgroup per CU); a poll that
+// never succeeds gives up after ~20 ms and raises *err.  The flag lines are zero when the token starts (k_embed).
+constexpr int kFlagStride = 16;      // dwords
+template <int QT, int XR>
+__global__ void __launch_bounds__(kGemvBlock, 4) k_attn_o(const AttnArgs aa, const GemvArgs a, const int n_heads, unsigned* flag, const unsigned target, int* err) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    auto stamp = [&](int k) { if (kAblate && a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime(); };   // tools/trace_ao.py
+    stamp(0);
+    if ((int)blockIdx.x < n_heads) {
+        attn_head_any<false>(aa, blockIdx.x, lds, *aa.pos_ptr + 1, aa.q, aa.out);
+        stamp(1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                  // this wave's stores have completed
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(flag + blockIdx.x * kFlagStride, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stamp(4);
+        return;
+    }
+    GemvCtx<QT, EPI_RESIDUAL> g;
+    g.init(a, blockIdx.x - n_heads, gridDim.x - n_heads, lds);
+    g.issue(a.ablate);
+    stamp(1);
+    if ((int)(threadIdx.x & ~63u) < n_heads) {                              // the waves that own at least one head's flag: lane i polls head i's line
+        const bool mine = (int)threadIdx.x < n_heads;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (true) {
+            const unsigned f = mine ? __hip_atomic_load(flag + threadIdx.x * kFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
+            if (__all(f >= target)) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+    }
+    __syncthreads();
+    stamp(2);
+    float4 xv[XR > 0 ? XR : 1], nv[XR > 0 ? XR : 1];
+    gemv_preload<QT, PRO_QUANT, XR, true>(a, xv, nv);
+    gemv_prologue<QT, PRO_QUANT, XR>(a, lds, xv, nv, [](int) {});
+    stamp(3);
+    g.run(a, lds, [](int) {});
+    stamp(4);
+}
+
+// ------------------------------------------------------------------------------------------
 // The persistent whole-token kernel (single GPU).  One 16-wave workgroup per CU walks the token's
 // phases  L x { qkv, attention, attn_o, ffn13, ffn2 }, cls  with a grid barrier between phases instead of
 // a kernel boundary, so that
@@ -1165,7 +1214,6 @@ constexpr int kNormRounds = 2;   // rmsnorm phases: n <= 2 * 4096 (host falls ba
 // flag[i] = epoch (one write-through store to its own line); lane j of the first waves polls flag[j] coherently
 // until it reaches the epoch.  No read-modify-write, no shared line.
 // t.bar: [grid] flags 64 bytes apart, zeroed by k_embed at the start of the token.
-constexpr int kFlagStride = 16;      // dwords
 __device__ __forceinline__ void grid_barrier(const TokenArgs& t, unsigned& epoch) {
     __syncthreads();
     epoch += 1;

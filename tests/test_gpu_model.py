@@ -71,7 +71,7 @@ def test_device_greedy_loop_matches_stepwise(gpu):
     assert list(ids) == step_ids
     assert list(ids) == orc_ids
     # graph on/off and attention split counts give identical tokens
-    for key, val in (("use_graph", 0), ("wg_per_cu", 1), ("wg_per_cu", 4), ("use_graph", 1), ("use_mega", 1)):
+    for key, val in (("use_graph", 0), ("wg_per_cu", 1), ("wg_per_cu", 4), ("use_graph", 1), ("fuse_attn_o", 0), ("fuse_attn_o", 1), ("use_mega", 1)):
         ctx.set_option(key, val); ctx.reset_kv()
         assert ctx.forward_argmax(prompt, 0) == first
         assert list(ctx.decode_greedy(first, len(prompt), n)) == list(ids)
@@ -90,7 +90,7 @@ def test_7b_width_layer_every_code_path_vs_oracle(gpu, qt):
     cur, pos = int(np.argmax(want[0])), len(prompt)
     for _ in range(3):
         want.append(om.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(want[-1])); pos += 1
-    for opts in ({}, {"use_mega": 1}):
+    for opts in ({}, {"fuse_attn_o": 0}, {"use_mega": 1}):
         ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
         for k, v in opts.items():
             ctx.set_option(k, v)
