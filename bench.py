@@ -306,6 +306,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_launch": int(dom_bytes), "avg_launch_us": round(dom_us, 2), "launches_per_token": dom_cnt},
             "kernels": kernels,
+            "kernels_note": "per-class times of the stand-alone kernels (back-to-back launches); the decode loop runs attention + attn_o as one launch (k_attn_o) on a single GPU",
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
