@@ -9,6 +9,7 @@ pos = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 cfg = synth.make_config("7B", ff.QT_INT8); cfg.n_layers = L
 ctx = capi.Ctx(capi.desc_from_config(cfg))
 ctx.upload_all(synth.make_tensors(cfg, seed=1))
+ctx.set_option("use_mega", 1)
 prompt = np.arange(1, pos + 1, dtype=np.int32) % cfg.vocab_size
 first = ctx.forward_argmax(prompt, 0)
 ctx.decode_greedy(first, pos, 8)
