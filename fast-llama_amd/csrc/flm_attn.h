@@ -1,0 +1,294 @@
+// flm_attn.h -- single-query attention (attn_head, k_attn_decode, k_attn_prefill) and the fused attention + Wo launch (k_attn_o).
+// Part of flm_kernels.h (hand-written gfx950 / CDNA4 kernels of the fast-llama per-token hot path); include that header.
+#pragma once
+#include "flm_math.h"
+#include "flm_gemv.h"
+// (bit-exactness hygiene: see flm_math.h -- no implicit FMA contraction in any of these headers)
+#pragma clang fp contract(off)
+
+namespace flm {
+
+// ------------------------------------------------------------------------------------------
+// Decode attention (execute_attn at bs == 1, transformer.cpp:397-455), all fp32, one workgroup per
+// head, bit-exact with the reference's order of operations:
+//   att[t] = dot(K[t], q)           dot_product_avx256 (x86_simd.cpp:1447-1467): 8 strided FMA lanes, summed 0..7
+//   att   *= 1/sqrt(hs)             quant::mul (quant_operators.cpp:425-428)
+//   softmax                         softmax_sisd (tf_operators.cpp:176-186): max, expf, sequential sum, divide
+//   o      = sum_t att[t] V[t]      batch weighted_sum (tf_operators.cpp:325-350): t ascending, FMA,
+//                                   rows t >= 1 with |w| <= 1e-15 skipped
+// The chains are the reference's; what is engineered is LATENCY (this kernel sits on the token's critical path):
+// K and V stream through LDS in tiles of 64 positions -- every thread fetches coalesced 16-byte pieces of the NEXT
+// tile while the current one is consumed, so a tile costs compute time, not a memory round trip -- and the first
+// K tile, the first V tile and q are all requested at once when the kernel starts.  Scores: lane = (position,
+// one of the 8 strided accumulators), operands from LDS (row stride hs+8 floats: conflict-free), the 8 partials
+// are added in order with DPP shifts.  PV: one thread per output dimension walks the tile's positions in order.
+// ------------------------------------------------------------------------------------------
+struct AttnArgs {
+    const float* q;          // [heads*hs], RoPE already applied
+    const float* kcache;     // [heads][max_seq][hs]
+    const float* vcache;
+    float* out;              // [heads*hs]
+    const int* pos_ptr;
+    int hs, max_seq;
+    unsigned long long* trace;   // FLM_ABLATE builds: [head][8] s_memtime stamps
+};
+
+constexpr int kAttnBlock = 1024;      // 16 waves
+constexpr int kAttnTile = 64;         // positions per LDS tile
+constexpr int kAttnDepth = 2;         // tiles in flight per stream (K, V), register rings: both streams start when the kernel does
+// LDS row stride of a tile in floats: compile-time per instantiation (64*NF + 8), so that the chains' LDS reads use
+// immediate offsets; +8: the 8x8 (position, accumulator) score lanes and the PV lanes hit distinct banks
+__host__ __device__ inline int attn_row_stride(int hs) { const int nf = hs <= 64 ? 1 : hs <= 128 ? 2 : 4; return nf * 64 + 8; }
+__host__ inline size_t attn_lds_bytes(int max_seq, int hs) { return (size_t)(hs + 32 + ((max_seq + 3) & ~3) + 64 + (2 * kAttnTile + 4) * attn_row_stride(hs)) * 4; }   // + 4 slack rows: the PV read-ahead
+
+// NF = 16-byte pieces of a tile per thread = ceil(hs / 64)
+// COH: K/V/q were (partly) written by other workgroups of the SAME kernel (k_token) -> coherent sc0|sc1 loads; the
+// per-phase kernels read them after a kernel boundary and use ordinary cached loads
+template <int NF, bool COH>
+__device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    constexpr int D = kAttnDepth;
+    const int hs = a.hs, tid = threadIdx.x;
+    auto stamp = [&](int k) { if (kAblate && a.trace && threadIdx.x == 0) a.trace[h * 8 + k] = __builtin_amdgcn_s_memtime(); };
+    stamp(0);
+    constexpr int rs = NF * 64 + 8;
+    const int f4r = hs >> 2, tile_f4 = kAttnTile * f4r;
+    float* qs   = reinterpret_cast<float*>(lds);                 // [hs]
+    float* red  = qs + hs;                                       // 32
+    float* sc   = red + 32;                                      // [T] scores -> probabilities (+ slack for the sum ring's read-ahead)
+    float* tile0 = sc + ((a.max_seq + 3) & ~3) + 64;
+    float* tile1 = tile0 + kAttnTile * rs;
+    const int lane = tid & 63, wave = tid >> 6;
+    const float* K = a.kcache + (size_t)h * a.max_seq * hs;
+    const float* V = a.vcache + (size_t)h * a.max_seq * hs;
+    // K/V rows of this token may have been written by other workgroups of the same kernel (k_token): coherent loads
+    // (sc0|sc1) through buffer descriptors; positions past T get an out-of-range offset and read as zero
+    const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(K), 0, a.max_seq * hs * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V), 0, a.max_seq * hs * 4, 0x00020000);
+    const float scale = (float)(1.0 / (double)__builtin_sqrtf((float)hs));   // attn_scale, transformer.cpp:418
+    const int nt = (T + kAttnTile - 1) / kAttnTile;
+    // Two streams of tiles (K for the scores, V for the weighted sum), each through a ring of D register sets; both are
+    // requested when the kernel starts (the V tiles arrive under the softmax), tile i+D when tile i has been parked.
+    v4f ringK[D][NF], ringV[D][NF];
+    // this thread's pieces of a tile: row / byte offsets computed once (an integer division per piece per tile would
+    // cost more than the tile's arithmetic)
+    int prow[NF], goff[NF], loff[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int f = tid + j * kAttnBlock, row = f / f4r, c4 = f - row * f4r;
+        prow[j] = f < tile_f4 ? row : (1 << 28);                    // pieces past the tile never pass the t < T test
+        goff[j] = (row * hs + c4 * 4) * 4;
+        loff[j] = row * rs + c4 * 4;
+    }
+    const int tile_bytes = kAttnTile * hs * 4;
+    auto request = [&](const __amdgpu_buffer_rsrc_t& r, int tile, v4f (&reg)[NF]) {
+        const int t0 = tile * kAttnTile;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const unsigned off = (tile < nt && t0 + prow[j] < T) ? (unsigned)(tile * tile_bytes + goff[j]) : 0x80000000u;
+            reg[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, COH ? kAuxCoherent : 0));
+        }
+    };
+    auto park = [&](float* buf, const v4f (&reg)[NF]) {
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+            if (prow[j] < kAttnTile) *reinterpret_cast<float4*>(buf + loff[j]) = make_float4(reg[j].x, reg[j].y, reg[j].z, reg[j].w);
+    };
+#pragma unroll
+    for (int u = 0; u < D; ++u) request(rK, u, ringK[u]);
+#pragma unroll
+    for (int u = 0; u < D; ++u) request(rV, u, ringV[u]);
+    for (int d = tid; d < hs; d += kAttnBlock) qs[d] = COH ? ld_agent(qrow + (size_t)h * hs + d) : qrow[(size_t)h * hs + d];
+
+    // ---- scores: lane = (position p, strided accumulator k) -- the 8 lanes of dot_product_avx256; each lane's
+    //      chain is i ascending, then the 8 partials are added 0..7 (lane k = 0 collects them with DPP row shifts).
+    float lmax = -INFINITY;
+    for (int base = 0; base < nt; base += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int s = base + u;
+            if (s >= nt) break;                                     // (uniform)
+            float* cur = (u & 1) ? tile1 : tile0;                   // D is even: tile parity == slot parity
+            park(cur, ringK[u]);
+            __syncthreads();
+            request(rK, s + D, ringK[u]);
+            if (tid < kAttnTile * 8) {
+                const int p = tid >> 3, k = tid & 7, t = s * kAttnTile + p;
+                const float* kp = cur + p * rs + k;
+                float l = 0.f;
+#pragma unroll 16
+                for (int j = 0; j < hs; j += 8) l = __fmaf_rn(kp[j], qs[j + k], l);
+                const int li = __float_as_int(l);
+                float tot = __fadd_rn(0.f, l);
+                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x101 /* row_shl:1 */, 0xF, 0xF, true)));
+                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x102, 0xF, 0xF, true)));
+                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x103, 0xF, 0xF, true)));
+                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x104, 0xF, 0xF, true)));
+                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x105, 0xF, 0xF, true)));
+                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x106, 0xF, 0xF, true)));
+                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x107, 0xF, 0xF, true)));
+                if (k == 0 && t < T) {
+                    const float sv = __fmul_rn(tot, scale);         // att.multiply(attn_scale) :443
+                    sc[t] = sv;
+                    lmax = fmaxf(lmax, sv);
+                }
+            }
+        }
+    }
+    stamp(1);
+    // block max over 16 waves (array_max is order-free)
+    lmax = wave_max(lmax);
+    if (lane == 0) red[wave] = lmax;
+    __syncthreads();
+    float m = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+    for (int t = tid; t < T; t += kAttnBlock) sc[t] = expf_ref(__fsub_rn(sc[t], m));
+    __syncthreads();
+    stamp(2);
+    if (tid == 0) {                                                // sum += x[i], i ascending (tf_operators.cpp:180-183)
+        // a lone lane: the loop is the T dependent adds plus one LDS read per four of them, reads 28 adds ahead
+        float sum = 0.f;
+        int t = 0;
+#define FLM_ADD4(q) sum = __fadd_rn(sum, q.x); sum = __fadd_rn(sum, q.y); sum = __fadd_rn(sum, q.z); sum = __fadd_rn(sum, q.w);
+#define FLM_ASTEP(q, off) FLM_ADD4(q) q = *reinterpret_cast<const float4*>(pp + (off)); __builtin_amdgcn_sched_barrier(0);
+        if (T >= 32) {
+            const float* pp = sc;
+            float4 q0 = *reinterpret_cast<const float4*>(pp), q1 = *reinterpret_cast<const float4*>(pp + 4), q2 = *reinterpret_cast<const float4*>(pp + 8), q3 = *reinterpret_cast<const float4*>(pp + 12);
+            float4 q4 = *reinterpret_cast<const float4*>(pp + 16), q5 = *reinterpret_cast<const float4*>(pp + 20), q6 = *reinterpret_cast<const float4*>(pp + 24), q7 = *reinterpret_cast<const float4*>(pp + 28);
+            __builtin_amdgcn_sched_barrier(0);
+            for (; t + 32 <= T; t += 32, pp += 32) {
+                FLM_ASTEP(q0, 32) FLM_ASTEP(q1, 36) FLM_ASTEP(q2, 40) FLM_ASTEP(q3, 44)
+                FLM_ASTEP(q4, 48) FLM_ASTEP(q5, 52) FLM_ASTEP(q6, 56) FLM_ASTEP(q7, 60)
+            }
+            if (t + 4 <= T) { FLM_ADD4(q0) t += 4; } if (t + 4 <= T) { FLM_ADD4(q1) t += 4; } if (t + 4 <= T) { FLM_ADD4(q2) t += 4; } if (t + 4 <= T) { FLM_ADD4(q3) t += 4; }
+            if (t + 4 <= T) { FLM_ADD4(q4) t += 4; } if (t + 4 <= T) { FLM_ADD4(q5) t += 4; } if (t + 4 <= T) { FLM_ADD4(q6) t += 4; }
+        }
+#undef FLM_ASTEP
+#undef FLM_ADD4
+        for (; t < T; ++t) sum = __fadd_rn(sum, sc[t]);
+        red[16] = sum;
+    }
+    __syncthreads();
+    stamp(3);
+    const float sum = red[16];
+    // att[t] = exp / sum; rows t >= 1 with |att| <= 1e-15 are skipped by the weighted sum (transformer.cpp:449): they are
+    // stored as exact zeros so that the PV chain can tell them apart with one wave-uniform test per four positions
+    for (int t = tid; t < T; t += kAttnBlock) { const float w = __fdiv_rn(sc[t], sum); sc[t] = (t > 0 && fabsf(w) <= 1e-15f) ? 0.f : w; }
+    // (the first barrier of the loop below orders these writes before the PV reads)
+    // ---- o[d] = sum_t att[t] V[t][d]: one thread per output dimension, t ascending (the reference's chain) over
+    //      the LDS tiles.
+    float o = 0.f;
+    for (int base = 0; base < nt; base += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int i = base + u;
+            if (i >= nt) break;                                     // (uniform)
+            float* cur = (u & 1) ? tile1 : tile0;
+            park(cur, ringV[u]);
+            __syncthreads();
+            request(rV, i + D, ringV[u]);
+            if (tid < hs) {
+                const float* vp = cur + tid;
+                const float* wp = sc + i * kAttnTile;
+                const int np = (T - i * kAttnTile) < kAttnTile ? (T - i * kAttnTile) : kAttnTile;
+                // weights are wave-uniform (one per position): lane p looks at weight p once per tile; if no row of the
+                // tile is skipped, the walk is nothing but LDS reads at immediate offsets and dependent FMAs
+                const float wl = lane < np ? wp[lane] : 1.f;
+                const bool dense = __all(wl != 0.f) != 0;
+                int p = 0;
+                if (i == 0) { o = __fmul_rn(vp[0], wp[0]); p = 1; }  // row 0 always (tf_operators.cpp:331-336)
+                if (dense) {
+                    for (; p < np && (p & 7); ++p) o = __fmaf_rn(vp[p * rs], wp[p], o);
+                    if (p + 8 <= np) {
+                        const float* vq = vp + p * rs; const float* wq = wp + p;
+                        float4 wa = *reinterpret_cast<const float4*>(wq), wb = *reinterpret_cast<const float4*>(wq + 4);
+                        float a0 = vq[0], a1 = vq[rs], a2 = vq[2 * rs], a3 = vq[3 * rs], a4 = vq[4 * rs], a5 = vq[5 * rs], a6 = vq[6 * rs], a7 = vq[7 * rs];
+                        for (; p + 16 <= np; p += 8) {
+                            vq += 8 * rs; wq += 8;
+                            const float4 wc = *reinterpret_cast<const float4*>(wq), wd = *reinterpret_cast<const float4*>(wq + 4);
+                            const float b0 = vq[0], b1 = vq[rs], b2 = vq[2 * rs], b3 = vq[3 * rs], b4 = vq[4 * rs], b5 = vq[5 * rs], b6 = vq[6 * rs], b7 = vq[7 * rs];
+                            o = __fmaf_rn(a0, wa.x, o); o = __fmaf_rn(a1, wa.y, o); o = __fmaf_rn(a2, wa.z, o); o = __fmaf_rn(a3, wa.w, o);
+                            o = __fmaf_rn(a4, wb.x, o); o = __fmaf_rn(a5, wb.y, o); o = __fmaf_rn(a6, wb.z, o); o = __fmaf_rn(a7, wb.w, o);
+                            wa = wc; wb = wd; a0 = b0; a1 = b1; a2 = b2; a3 = b3; a4 = b4; a5 = b5; a6 = b6; a7 = b7;
+                        }
+                        o = __fmaf_rn(a0, wa.x, o); o = __fmaf_rn(a1, wa.y, o); o = __fmaf_rn(a2, wa.z, o); o = __fmaf_rn(a3, wa.w, o);
+                        o = __fmaf_rn(a4, wb.x, o); o = __fmaf_rn(a5, wb.y, o); o = __fmaf_rn(a6, wb.z, o); o = __fmaf_rn(a7, wb.w, o);
+                        p += 8;
+                    }
+                    for (; p < np; ++p) o = __fmaf_rn(vp[p * rs], wp[p], o);
+                } else {
+                    // some row is skipped (weight stored as exact 0, threshold of transformer.cpp:449): it leaves o untouched
+                    for (; p < np; ++p) { const float w = wp[p]; o = w == 0.f ? o : __fmaf_rn(vp[p * rs], w, o); }
+                }
+            }
+        }
+    }
+    stamp(4);
+    if (tid < hs) st_agent(orow + (size_t)h * hs + tid, o);
+    __syncthreads();                                                // the LDS is free for whoever runs next on it (k_token)
+}
+template <bool COH>
+__device__ __forceinline__ void attn_head_any(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow) {
+    if (a.hs <= 64) attn_head<1, COH>(a, h, lds, T, qrow, orow); else if (a.hs <= 128) attn_head<2, COH>(a, h, lds, T, qrow, orow); else attn_head<4, COH>(a, h, lds, T, qrow, orow);
+}
+// batched prefill: workgroup (h, i) is query i of the batch, at position pos0 + i, over the cache rows 0 .. pos0 + i
+__global__ void __launch_bounds__(kAttnBlock) k_attn_prefill(const AttnArgs a, int pos0, int row_stride) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int i = blockIdx.y;
+    attn_head_any<false>(a, blockIdx.x, lds, pos0 + i + 1, a.q + (size_t)i * row_stride, a.out + (size_t)i * row_stride);
+}
+__global__ void __launch_bounds__(kAttnBlock) k_attn_decode(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    attn_head_any<false>(a, blockIdx.x, lds, *a.pos_ptr + 1, a.q, a.out);
+}
+
+// ------------------------------------------------------------------------------------------
+// Attention and the output projection in ONE launch (single GPU): workgroups [0, n_heads) run one attention head each,
+// the others run the Wo GEMV.  The GEMV workgroups request their first steps of Wo -- with 16.8 MB over ~224 CUs that is
+// every block they will ever need -- the moment the kernel starts, and only then wait for the heads: the weight fetch,
+// ~3.5 us of the stand-alone attn_o kernel, and one kernel boundary (1.6 us) disappear behind the attention.
+// The heads publish their output with write-through stores (st_agent) and, once those have completed, each writes `target`
+// (layer + 1) into its own 64-byte flag line; in every GEMV workgroup lane i polls head i's line (the pattern of
+// grid_barrier: a shared counter cost 2.7 us from the last head's bump to the last poll's success), then the activation
+// is read with coherent loads.  All workgroups are resident (grid <= CUs, one 1024-thread workgroup per CU); a poll that
+// never succeeds gives up after ~20 ms and raises *err.  The flag lines are zero when the token starts (k_embed).
+constexpr int kFlagStride = 16;      // dwords
+template <int QT, int XR>
+__global__ void __launch_bounds__(kGemvBlock, 4) k_attn_o(const AttnArgs aa, const GemvArgs a, const int n_heads, unsigned* flag, const unsigned target, int* err) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    auto stamp = [&](int k) { if (kAblate && a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime(); };   // tools/trace_ao.py
+    stamp(0);
+    if ((int)blockIdx.x < n_heads) {
+        attn_head_any<false>(aa, blockIdx.x, lds, *aa.pos_ptr + 1, aa.q, aa.out);
+        stamp(1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                  // this wave's stores have completed
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(flag + blockIdx.x * kFlagStride, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stamp(4);
+        return;
+    }
+    GemvCtx<QT, EPI_RESIDUAL> g;
+    g.init(a, blockIdx.x - n_heads, gridDim.x - n_heads, lds);
+    g.issue(a.ablate);
+    stamp(1);
+    if ((int)(threadIdx.x & ~63u) < n_heads) {                              // the waves that own at least one head's flag: lane i polls head i's line
+        const bool mine = (int)threadIdx.x < n_heads;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (true) {
+            const unsigned f = mine ? __hip_atomic_load(flag + threadIdx.x * kFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
+            if (__all(f >= target)) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+    }
+    __syncthreads();
+    stamp(2);
+    float4 xv[XR > 0 ? XR : 1], nv[XR > 0 ? XR : 1];
+    gemv_preload<QT, PRO_QUANT, XR, true>(a, xv, nv);
+    gemv_prologue<QT, PRO_QUANT, XR>(a, lds, xv, nv, [](int) {});
+    stamp(3);
+    g.run(a, lds, [](int) {});
+    stamp(4);
+}
+
+} // namespace flm

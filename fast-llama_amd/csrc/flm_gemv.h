@@ -1,0 +1,710 @@
+// flm_gemv.h -- the group-quantized GEMV (k_gemv): argument block, LDS layout, the rmsnorm chain, activation prologues, GemvCtx.
+// Part of flm_kernels.h (hand-written gfx950 / CDNA4 kernels of the fast-llama per-token hot path); include that header.
+#pragma once
+#include "flm_math.h"
+// (bit-exactness hygiene: see flm_math.h -- no implicit FMA contraction in any of these headers)
+#pragma clang fp contract(off)
+
+namespace flm {
+
+// ------------------------------------------------------------------------------------------
+// GEMV argument block
+// ------------------------------------------------------------------------------------------
+struct GemvArgs {
+    // weights: row-major [rows][n] quantized values + natural-layout scales [rows][n/64].
+    // EPI_SWIGLU: W = [W1 (gate) ; W3 (up)], both [items][n], stored back to back (values and scales alike)
+    const void*  W;   const float* sW;
+    int n;                                      // K (columns), multiple of 64
+    int items;                                  // rows (STORE/RESIDUAL), hidden (SWIGLU), row pairs (ROPE_KV)
+    int rows_per_pass;                          // Rm: rows (of each matrix) one workgroup reduces per pass; multiple of RB, <= 64
+    int cb_shift;                               // log2(CB): a 1 KiB wave load covers RB = (64 >> cb_shift) rows x CB 16-byte chunks
+    int ctr_off;                                // LDS byte offset of the two step counters; 0: the layout's own (k_token keeps them at a fixed place across phases)
+    int nbuf;                                   // strip buffers: 2, or 1 when each workgroup has a single pass and LDS is short
+    // prologue inputs
+    const float* x;                             // fp32 activation [n]          (QUANT / RMSNORM_QUANT)
+    const float* norm_w;                        // rmsnorm weight [n]           (RMSNORM_QUANT)
+    const void*  xq; const float* xs;           // pre-quantized activation     (NONE)
+    // epilogue outputs
+    float* out;                                 // STORE: out[row]; RESIDUAL: out[row] += ; SWIGLU: hd[i]; ROPE_KV: q[row]
+    float* kcache; float* vcache;               // ROPE_KV: this layer's caches [heads][max_seq][hs]
+    const float* rope_cos; const float* rope_sin; // [max_seq][hs/2]
+    const int* pos_ptr;                         // device-resident position
+    int dim; int kv_dim; int max_seq; int hs;   // ROPE_KV geometry
+    // debugging taps used by the op-level exports (may be null)
+    void* dbg_xq; float* dbg_xs; float* dbg_xn;
+    unsigned long long* trace;                  // FLM_ABLATE builds: per-workgroup timeline [grid][8] (s_memtime), else unused
+    int ablate;                                 // perf exploration only (results invalid when != 0): 1 no group chain, 2 no rmsnorm chain, 4 no weight loads, 8 no dots, 16 return immediately, 32 return after prologue
+};
+
+#ifndef FLM_ABLATE
+#define FLM_ABLATE 0          // build with -DFLM_ABLATE=1 to compile the perf-exploration switches of GemvArgs::ablate into the hot loop
+#endif
+constexpr bool kAblate = FLM_ABLATE != 0;
+constexpr int kStepBlk = 4;            // H: 1 KiB wave loads per step; two steps (register sets) in flight: 8 KiB/wave, 128 KiB/CU
+
+// LDS layout: [xq : n*esz] [xs : n/64 floats, padded to 16 B] [red : 16 floats] [scratch]
+// scratch = max( rmsnorm transpose staging 4n bytes ,
+//                2 buffers x (Rm + RB) strips; strip r = { float(group dot), sW*sX } pairs of row r, groups ascending
+//                (SWIGLU: entries { d(W1), d(W3), s(W1), s(W3) }: the two chains are the halves of one packed FMA) )
+struct GemvLds {
+    int off_xs, off_red, off_ctr, off_scr;     // byte offsets (off_ctr: the two step counters of GemvCtx)
+    int gstride;                      // BYTES per strip: 16 x odd, so that 16 lanes reading 16 B each from 16 strips hit all banks
+    int buf_bytes;                    // one strip buffer
+    int total;                        // bytes
+};
+__host__ __device__ inline GemvLds gemv_lds_layout(int n, int esz, bool norm, int Rm, int RB, bool two, int nbuf = 2) {
+    GemvLds L;
+    const int sn = n / kGroup, ng = two ? 2 * sn : sn;
+    L.off_xs = n * esz;
+    L.off_red = L.off_xs + ((sn * 4 + 15) & ~15);
+    L.off_ctr = L.off_red + 64;
+    L.off_scr = L.off_ctr + 16;
+    int g16 = (ng * 8 + 15) / 16; if ((g16 & 1) == 0) ++g16;
+    L.gstride = g16 * 16;
+    L.buf_bytes = (Rm + RB) * L.gstride;                                       // + RB dummy strips that absorb the writes of padding blocks
+    int scratch = nbuf * L.buf_bytes + 64;                                     // + 64: the chain's read-ahead past the last strip
+    if (norm && n * 4 + 512 > scratch) scratch = n * 4 + 512;                   // 4 strips of n/4 + 8 floats (+8: the 4 chain lanes read different banks); + the chain's read-ahead past the last strip
+    L.total = L.off_scr + scratch;
+    return L;
+}
+// One of the 4 strided lanes of simd::square_sum -> square_sum_avx128 (x86_simd.cpp:942-960; the AVX2 branch is
+// dead, :1093): p[0..n4) = x[c], x[c+4], x[c+8], ... walked as a strictly sequential FMA chain.
+__device__ __forceinline__ float sq_chain(const float* p, int n4) {
+    float l = 0.f;
+    int k = 0;
+#define FLM_SQ4(v) l = __fmaf_rn(v.x, v.x, l); l = __fmaf_rn(v.y, v.y, l); l = __fmaf_rn(v.z, v.z, l); l = __fmaf_rn(v.w, v.w, l);
+#define FLM_RD4(a, b, c, d, base) a = *reinterpret_cast<const float4*>(pp + (base)); b = *reinterpret_cast<const float4*>(pp + (base) + 4); c = *reinterpret_cast<const float4*>(pp + (base) + 8); d = *reinterpret_cast<const float4*>(pp + (base) + 12);
+    if (n4 >= 32) {
+        // A lone wave issues roughly one instruction every ~5 cycles, whatever its kind, so the loop body must be
+        // little more than the dependent FMAs: two rings of 4 float4 registers; while the 16 FMAs of one ring run,
+        // the 4 LDS reads of the other are in flight, and ONE explicit s_waitcnt per 16 FMAs (instead of the
+        // compiler's one per read) covers them.  Reads run up to 32 floats past a lane's strip: the staging area
+        // is sized for that (gemv_lds_layout) and those values are never consumed.
+        const float* pp = p;
+        float4 a0, a1, a2, a3, b0, b1, b2, b3;
+        FLM_RD4(a0, a1, a2, a3, 0)
+#pragma unroll 2
+        for (; k + 32 <= n4; k += 32, pp += 32) {
+            FLM_RD4(b0, b1, b2, b3, 16)
+            __builtin_amdgcn_s_waitcnt(0xC47F);        // lgkmcnt <= 4: ring A has landed (vmcnt / expcnt untouched)
+            __builtin_amdgcn_sched_barrier(0);
+            FLM_SQ4(a0) FLM_SQ4(a1) FLM_SQ4(a2) FLM_SQ4(a3)
+            __builtin_amdgcn_sched_barrier(0);
+            FLM_RD4(a0, a1, a2, a3, 32)
+            __builtin_amdgcn_s_waitcnt(0xC47F);        // ring B has landed
+            __builtin_amdgcn_sched_barrier(0);
+            FLM_SQ4(b0) FLM_SQ4(b1) FLM_SQ4(b2) FLM_SQ4(b3)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ring A holds p[k .. k+15]
+        if (k + 4 <= n4) { FLM_SQ4(a0) k += 4; } if (k + 4 <= n4) { FLM_SQ4(a1) k += 4; } if (k + 4 <= n4) { FLM_SQ4(a2) k += 4; } if (k + 4 <= n4) { FLM_SQ4(a3) k += 4; }
+    }
+#undef FLM_RD4
+#undef FLM_SQ4
+    for (; k < n4; ++k) l = __fmaf_rn(p[k], p[k], l);
+    return l;
+}
+
+// The same chain -- l <- fma(x_k, x_k, l), k ascending, bit for bit -- evaluated by a WHOLE WAVE in far fewer than n
+// dependent steps.  The terms are non-negative, so l only grows, and while l stays inside one binade [2^E, 2^(E+1)) every
+// step rounds l + x^2 to a multiple of u = ulp(l).  Within the binade the increment t_k = fl(l + x_k^2) - l does not depend
+// on l (except for exact ties): it is what ONE fma against the bottom of the binade gives, t_k = fma(x_k, x_k, 2^E) - 2^E,
+// a multiple of u, and sums of such multiples below 2^(E+1) are exact in fp32 in ANY order -- a prefix sum.  Lane L takes
+// elements 4L..4L+3 of a 256-element block, a wave scan adds them up.  Two kinds of element stop the scan: one on which l
+// leaves the binade (fma(x, x, l_before) >= 2^(E+1): the rounding unit changes) and one whose x^2 lies exactly halfway
+// between two multiples of u (round-half-even then looks at the parity of l: detected as |fma(x, x, -t)| == u/2).  The scan
+// commits everything before the first such element, that element takes one real fma, and the scan resumes behind it with the
+// new binade.  l doubles only ~log2(n) times over a chain, mostly within the first elements, which are simply run in order.
+// STATUS: exact (tests/test_gpu_ops.py::test_square_sum_wave_parallel_is_bit_exact, adversarial ties / overflow / denormals)
+// but NOT used by the product path: a lone wave pays ~7 cycles per instruction whatever it does, this formulation runs
+// ~150 instructions per scan round and needs 4 rounds + one per binade change (8-9 for n/4 = 1024), i.e. about as many
+// instructions as the 1024 dependent FMAs and their LDS reads (measured 7.1 us against 4.3 us in the prologue).  It pays
+// only below ~75 instructions per round; kept, tested, for the round that hand-schedules it.
+__device__ __forceinline__ float wave_scan_incl(float v) {
+#define FLM_SCAN_STEP(ctrl, rmask, bc) v = __fadd_rn(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xF, bc)));
+    FLM_SCAN_STEP(0x111 /* row_shr:1 */, 0xF, true) FLM_SCAN_STEP(0x112 /* row_shr:2 */, 0xF, true)
+    FLM_SCAN_STEP(0x114 /* row_shr:4 */, 0xF, true) FLM_SCAN_STEP(0x118 /* row_shr:8 */, 0xF, true)
+    FLM_SCAN_STEP(0x142 /* row_bcast:15 */, 0xA, false) FLM_SCAN_STEP(0x143 /* row_bcast:31 */, 0xC, false)
+#undef FLM_SCAN_STEP
+    return v;
+}
+__device__ __forceinline__ float sq_chain_wave(const float* p, int n4, int* iters = nullptr) {
+    const int lane = threadIdx.x & 63;
+    int n_it = 0;
+    constexpr int kHead = 64;                                      // elements run in order first (l crosses most binades here)
+    float acc = 0.f;
+    int k = 0;
+    for (; k + 4 <= n4 && k < kHead; k += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(p + k);
+        acc = __fmaf_rn(v.x, v.x, acc); acc = __fmaf_rn(v.y, v.y, acc); acc = __fmaf_rn(v.z, v.z, acc); acc = __fmaf_rn(v.w, v.w, acc);
+    }
+    for (int base = 0; base < n4; base += 256) {
+        const int e0 = base + 4 * lane;
+        float x0 = 0.f, x1 = 0.f, x2 = 0.f, x3 = 0.f;
+        if (e0 + 4 <= n4) { const float4 v = *reinterpret_cast<const float4*>(p + e0); x0 = v.x; x1 = v.y; x2 = v.z; x3 = v.w; }
+        else { if (e0 < n4) x0 = p[e0]; if (e0 + 1 < n4) x1 = p[e0 + 1]; if (e0 + 2 < n4) x2 = p[e0 + 2]; }
+        int done = k > base ? k - base : 0;                                                // elements of this block already consumed (uniform)
+        const int limit = (n4 - base) < 256 ? (n4 - base) : 256;
+        auto pick = [&](int i) { return i == 0 ? x0 : i == 1 ? x1 : i == 2 ? x2 : x3; };
+        while (done < limit) {
+            ++n_it;
+            const unsigned ab = __builtin_amdgcn_readfirstlane(__float_as_uint(acc));
+            const unsigned eb = ab & 0x7f800000u;
+            if (eb < (32u << 23) || eb >= (254u << 23)) {
+                // l is zero / tiny / not finite: no usable binade -- one plain step, then look again
+                const float xs = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(pick(done & 3)), done >> 2));
+                acc = __fmaf_rn(xs, xs, acc);
+                ++done;
+                continue;
+            }
+            const float aref = __uint_as_float(eb), top = __fadd_rn(aref, aref), half_u = __uint_as_float(eb - (24u << 23));
+            const int el = 4 * lane;
+            const bool v0 = el >= done, v1 = el + 1 >= done, v2 = el + 2 >= done, v3 = el + 3 >= done;
+            // increments (multiples of u) and exact ties
+            const float t0 = v0 ? __fsub_rn(__fmaf_rn(x0, x0, aref), aref) : 0.f, t1 = v1 ? __fsub_rn(__fmaf_rn(x1, x1, aref), aref) : 0.f;
+            const float t2 = v2 ? __fsub_rn(__fmaf_rn(x2, x2, aref), aref) : 0.f, t3 = v3 ? __fsub_rn(__fmaf_rn(x3, x3, aref), aref) : 0.f;
+            bool s0 = v0 && fabsf(__fmaf_rn(x0, x0, -t0)) == half_u, s1 = v1 && fabsf(__fmaf_rn(x1, x1, -t1)) == half_u;
+            bool s2 = v2 && fabsf(__fmaf_rn(x2, x2, -t2)) == half_u, s3 = v3 && fabsf(__fmaf_rn(x3, x3, -t3)) == half_u;
+            const float c0 = t0, c1 = __fadd_rn(c0, t1), c2 = __fadd_rn(c1, t2), c3 = __fadd_rn(c2, t3);
+            const float incl = wave_scan_incl(c3);
+            // l in front of this lane's first element: the inclusive sum of the lane BELOW (incl - c3 would not do: the lane of a
+            // binade-leaving element holds a huge increment, incl is rounded there, and the difference is off by an ulp)
+            const float lb = __fadd_rn(acc, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(incl), 0x138 /* wave_shr:1 */, 0xF, 0xF, true)));
+            // does l leave the binade on this element?  (exact test: the real step from the value in front of it)
+            s0 = s0 || (v0 && __fmaf_rn(x0, x0, lb) >= top);
+            s1 = s1 || (v1 && __fmaf_rn(x1, x1, __fadd_rn(lb, c0)) >= top);
+            s2 = s2 || (v2 && __fmaf_rn(x2, x2, __fadd_rn(lb, c1)) >= top);
+            s3 = s3 || (v3 && __fmaf_rn(x3, x3, __fadd_rn(lb, c2)) >= top);
+            const int fi = s0 ? 0 : s1 ? 1 : s2 ? 2 : s3 ? 3 : 4;
+            const float before = __fadd_rn(lb, s0 ? 0.f : s1 ? c0 : s2 ? c1 : c2);          // l in front of the lane's first special element
+            const unsigned long long sm = __ballot(fi < 4);
+            if (sm) {
+                const int Ls = __ffsll((long long)sm) - 1;
+                const int fs = __builtin_amdgcn_readlane(fi, Ls);
+                acc = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(before), Ls));
+                done = 4 * Ls + fs;
+                if (done < limit) {
+                    const float xs = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(pick(fs)), Ls));
+                    acc = __fmaf_rn(xs, xs, acc);                                           // the special element: one real step
+                    ++done;
+                }
+            } else {
+                acc = __fadd_rn(acc, __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(incl), 63)));
+                done = limit;
+            }
+        }
+        k = base + 256;
+    }
+    if (iters) *iters = n_it;
+    return acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// Prologue: produce the quantized activation vector in LDS.  Every workgroup recomputes it
+// (n <= 16K floats out of L2) so that no separate norm/quantize kernel sits on the critical path.
+//   RMSNORM_QUANT == x2.rmsnorm(x1, w) ; qx.quantize(x2)   (transformer.cpp:132-134, 144-146, 155-156)
+//   QUANT         == qx.quantize(x2) / qh.quantize(hd)     (transformer.cpp:138, 149)
+// Thread t owns elements 4t..4t+3 (+1024 per round): 16 consecutive lanes own one 64-group, so the
+// group max (order-free) is a 16-lane xor-butterfly.
+// The first XR rounds of x (and of the norm weight) are handed in as registers that the caller
+// loaded BEFORE issuing its first batch of weight loads: loads return in issue order, so an x load
+// issued behind 32 HBM weight loads would make the whole prologue wait for them.
+// ------------------------------------------------------------------------------------------
+// COH: the activation was written by other workgroups of the SAME kernel (k_attn_o) -> coherent sc0|sc1 loads
+template <int QT, int PRO, int XR, bool COH = false>
+__device__ __forceinline__ void gemv_preload(const GemvArgs& a, float4 (&xv)[XR > 0 ? XR : 1], float4 (&wv)[XR > 0 ? XR : 1]) {
+    if constexpr (PRO == PRO_QUANT || PRO == PRO_RMSNORM_QUANT) {
+        // branch-free: raw buffer loads, elements past n read as zero
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.n * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(PRO == PRO_RMSNORM_QUANT ? a.norm_w : a.x), 0, a.n * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            const int off = (threadIdx.x * 4 + i * kGemvBlock * 4) * 4;
+            const v4f v = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, COH ? kAuxCoherent : 0));
+            xv[i] = make_float4(v.x, v.y, v.z, v.w);
+            if constexpr (PRO == PRO_RMSNORM_QUANT) {
+                const v4f u = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rn, off, 0, 0));
+                wv[i] = make_float4(u.x, u.y, u.z, u.w);
+            }
+        }
+    }
+}
+
+#ifdef FLM_TRACE_PRO
+#define FLM_PRO_STAMP(k) if (kAblate && a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define FLM_PRO_STAMP(k)
+#endif
+template <int QT, int PRO, int XR, class AfterStage>
+__device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, float4 (&xv)[XR > 0 ? XR : 1], float4 (&wv)[XR > 0 ? XR : 1], AfterStage&& after_stage) {
+    using T = QTraits<QT>;
+    const int n = a.n;
+    const int tid = threadIdx.x;
+    const GemvLds L = gemv_lds_layout(n, T::kEsz, PRO == PRO_RMSNORM_QUANT, a.rows_per_pass, 64 >> a.cb_shift, false);   // only the fixed offsets are used here
+    char*  xq = lds;
+    float* xs = reinterpret_cast<float*>(lds + L.off_xs);
+    float* red = reinterpret_cast<float*>(lds + L.off_red);
+    float* scratch = reinterpret_cast<float*>(lds + L.off_scr);
+
+    if constexpr (PRO == PRO_NONE) {
+        // copy pre-quantized activation (op-level matmul and generic callers)
+        const int nb16 = n * T::kEsz / 16;
+        for (int c = tid; c < nb16; c += kGemvBlock)
+            reinterpret_cast<int4*>(xq)[c] = reinterpret_cast<const int4*>(a.xq)[c];
+        for (int g = tid; g < n / kGroup; g += kGemvBlock) xs[g] = a.xs[g];
+        __syncthreads();
+        return;
+    } else {
+        const int rounds = (n + kGemvBlock * 4 - 1) / (kGemvBlock * 4);
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float r = 1.0f;
+        if constexpr (PRO == PRO_QUANT) {
+            // no staging here: the hook (the weight prefetch) runs as soon as this thread's activation registers have landed
+            if constexpr (XR > 0) { asm volatile("" :: "v"(xv[XR - 1].w)); }
+            FLM_PRO_STAMP(3)
+            after_stage(0);
+            FLM_PRO_STAMP(4)
+        }
+        if constexpr (PRO == PRO_RMSNORM_QUANT) {
+            // simd::square_sum -> square_sum_avx128 (x86_simd.cpp:942-960; the AVX2 branch is dead, :1093):
+            // lane c of 4 accumulates x[c], x[c+4], x[c+8]... by FMA, then res = ((0+l0)+l1)+l2)+l3.
+            // Stage x transposed ([4][n/4]) so that 4 threads can each walk one strided lane sequentially.
+            const int n4 = n / 4, ns = n4 + 8;                  // strip stride: +8 floats so that the 4 chain lanes' 16-byte reads hit different banks
+            auto stage = [&](int i, const float4& v) {
+                const int k = tid + i * kGemvBlock;
+                if (k < n4) { scratch[k] = v.x; scratch[ns + k] = v.y; scratch[2 * ns + k] = v.z; scratch[3 * ns + k] = v.w; }
+            };
+#pragma unroll
+            for (int i = 0; i < XR; ++i) { if (i < rounds) stage(i, xv[i]); }
+            for (int i = XR; i < rounds; ++i) {
+                const int e = tid * 4 + i * kGemvBlock * 4;
+                if (e < n) stage(i, *reinterpret_cast<const float4*>(a.x + e));
+            }
+            __syncthreads();
+            FLM_PRO_STAMP(3)
+            // the hook issues the weight prefetch.  Wave 0 goes first (the others give it ~128 cycles): its 16 loads
+            // enter an empty memory pipeline at once and it is free for the chain; queued behind the other 15 waves'
+            // 240 loads it would stall for ~1 us before (or after) the chain.
+            if (tid >= kWave) __builtin_amdgcn_s_sleep(2);
+            after_stage(0);
+            if (tid < 4 && !(a.ablate & 2)) red[8 + tid] = sq_chain(scratch + tid * ns, n4);
+            FLM_PRO_STAMP(4)
+            __syncthreads();
+            const float ss = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, red[8]), red[9]), red[10]), red[11]);
+            r = rms_scale(ss, n);
+            __syncthreads();                                   // scratch is reused by the GEMV waves below
+            FLM_PRO_STAMP(5)
+        }
+        // one round: (normalise,) group max over 16 lanes, quantize, pack into LDS
+        auto round = [&](int i, float4 v, float4 w) {
+            const int e = tid * 4 + i * kGemvBlock * 4;
+            const bool act = e < n;
+            if constexpr (PRO == PRO_RMSNORM_QUANT) {
+                // multiply_avx256 (x86_simd.cpp:1360-1372): (x*w)*r
+                v.x = __fmul_rn(__fmul_rn(v.x, w.x), r); v.y = __fmul_rn(__fmul_rn(v.y, w.y), r);
+                v.z = __fmul_rn(__fmul_rn(v.z, w.z), r); v.w = __fmul_rn(__fmul_rn(v.w, w.w), r);
+            }
+            if (act && a.dbg_xn && blockIdx.x == 0) *reinterpret_cast<float4*>(a.dbg_xn + e) = v;
+            // group max over the 16 lanes that share this 64-element group (order-free, exact)
+            const float mx = row16_max(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            const float sc = __fdiv_rn(mx, T::kF);           // scale = max|x| / F
+            if (act) {
+                const int q0 = quant_elem(v.x, sc), q1 = quant_elem(v.y, sc), q2 = quant_elem(v.z, sc), q3 = quant_elem(v.w, sc);
+                if constexpr (QT == QT_INT8) {
+                    const uint32_t pk = (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
+                    *reinterpret_cast<uint32_t*>(xq + e) = pk;
+                } else {
+                    uint2 pk;
+                    pk.x = (uint32_t)(q0 & 0xffff) | ((uint32_t)(q1 & 0xffff) << 16);
+                    pk.y = (uint32_t)(q2 & 0xffff) | ((uint32_t)(q3 & 0xffff) << 16);
+                    *reinterpret_cast<uint2*>(xq + (size_t)e * 2) = pk;
+                }
+                if ((tid & 15) == 0) xs[e / kGroup] = sc;
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < XR; ++i) { if (i < rounds) round(i, xv[i], wv[i]); }
+        for (int i = XR; i < rounds; ++i) {
+            const int e = tid * 4 + i * kGemvBlock * 4;
+            float4 v = z4, w = z4;
+            if (e < n) {
+                v = *reinterpret_cast<const float4*>(a.x + e);
+                if constexpr (PRO == PRO_RMSNORM_QUANT) w = *reinterpret_cast<const float4*>(a.norm_w + e);
+            }
+            round(i, v, w);
+        }
+        if constexpr (PRO == PRO_QUANT) {
+            FLM_PRO_STAMP(5)
+        }
+        __syncthreads();
+        if (a.dbg_xq && blockIdx.x == 0) {
+            const int nb4 = n * T::kEsz / 4;
+            for (int c = tid; c < nb4; c += kGemvBlock) reinterpret_cast<uint32_t*>(a.dbg_xq)[c] = reinterpret_cast<uint32_t*>(xq)[c];
+            for (int g = tid; g < n / kGroup; g += kGemvBlock) a.dbg_xs[g] = xs[g];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The GEMV.  quant::matmul<T> at w == 1 (src/blas/quant_operators.cpp:252-284):
+//     out[r] = sum_g (sW[r,g] * sX[g]) * float( sum_{k<64} W[r,64g+k] * X[64g+k] ),   g ASCENDING, FMA per group
+//
+// One 16-wave workgroup per CU reduces Rm rows per pass.  The Rm x K tile is cut into 1 KiB blocks of
+// (RB rows x CB chunks of 16 B), RB*CB = 64, CB = the largest power of two dividing K/16 (so a block is
+// one fully coalesced buffer_load_dwordx4 per wave and every lane is busy for any K).  The waves form a
+// WC x WR grid: wave (wc, wr) owns the column blocks wc, wc+WC, ... and, of those, the row blocks
+// wr, wr+WR, ...; it walks them column block by column block, so that from one block to the next
+// only three scalar offsets advance by constants (the instruction stream per KiB is what limits a
+// GEMV whose operands arrive at several TB/s), and its activation chunk stays in registers.
+// SWIGLU runs [W1 ; W3] as ONE matrix with twice the column blocks: both dot products of a row land in
+// the same strip and the same chain lane.  Per block:
+//   1. int32 dot per 16-byte chunk (v_dot4 / v_dot2), exact;
+//   2. DPP sum over the 4 (int8) / 8 (int16) lanes of a quant group -> the group's int32 dot, exact;
+//   3. group leaders park { float(dot), sW*sX } in the row's LDS strip (one ds_write_b64);
+// and per pass, after ONE workgroup barrier, one wave walks the strips, lane r = row r:
+//        acc = fma(s[g], d[g], acc), g ascending -- the reference's summation order, bit-identical --
+// amortising the sequential fp32 chain over Rm rows, and runs the epilogue.  Strips are double
+// buffered, so the other waves are already in the next pass.  Two register sets of H blocks each
+// keep 8 KiB per wave (128 KiB per CU) of weight loads in flight at all times; the first 8 are
+// issued before the prologue so HBM latency and the sequential rmsnorm chain overlap the stream.
+//
+// GemvCtx is the per-wave state of one GEMV: geometry, the load cursor and the two register sets.
+// The standalone kernel k_gemv and the persistent whole-token kernel k_token both drive it:
+//     init -> issue (weight loads of the first two steps) -> [activation prologue] -> run
+// ------------------------------------------------------------------------------------------
+typedef unsigned int u32;
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+template <int QT, int EPI>
+struct GemvCtx {
+    using T = QTraits<QT>;
+    static constexpr u32 LPGS = (T::kEPC == 16) ? 2 : 3;                      // log2(lanes per quant group): 4 | 8 lanes
+    static constexpr u32 LPG = 1u << LPGS;
+    static constexpr bool TWO = EPI == EPI_SWIGLU;
+    static constexpr int H = kStepBlk;
+    static constexpr u32 ES = TWO ? 16 : 8;                                    // bytes per strip entry: {d, s}, SWIGLU {d1, d3, s1, s3}
+    static constexpr u32 kOOB = 0x80000000u;
+
+    // A STEP is H consecutive row blocks of one column block of one pass: H weight loads of 1 KiB per wave plus ONE scale
+    // load (lane (j, g) fetches the scale of block j's g-th quant group -- 64 / LPG groups per block, so for int8 the
+    // step's 64 scales fill the wave exactly; a separate scale load per block cost as much of the CU's address
+    // pipeline as the weight load itself).  The steps of a workgroup -- its passes in order, inside a pass row chunk by
+    // row chunk, a chunk's column blocks next to each other -- are numbered, and handed out through a counter in LDS: a
+    // wave takes the next number whenever it refills a register set.  With a fixed wave grid the waves that the CU's
+    // memory pipeline serves last (it is a FIFO: wave 15's requests queue behind everybody else's every round) ended
+    // 3 us after the first ones, on a 12 us main loop; the wave that runs a pass's chain falls behind as well.
+    // Numbered steps cost two scalar multiply-high's to decode, and the activation chunk is re-read from LDS when the
+    // column block changes (one ds_read_b128 per step at most).
+    struct Set { v4i w[H]; float sw; u32 itl, st, xo, nlive; };               // itl: workgroup-local pass index (np_wg: no work left)
+
+    // geometry (wave-uniform unless noted)
+    u32 n, lane, wave, rowbytes, sn, cbs, RB, nbc, NBCV, TRm, Rm, RBP, SP, NS, np_wg, npass, gstride, buf_bytes, off_xs, off_scr, ctr_off;
+    u32 inv_SP, inv_NBCV;                                                      // ceil(2^32 / d): exact quotients for the step numbers that occur (< 2^16)
+    u32 lane_woff, lane_xoff, lane_goff;                                       // per lane: weight chunk, activation chunk, strip entry (dot)
+    u32 lane_j, lane_s2off, lane_sx2off, lane_poff;                            // per lane, scale role: block of the step, its scale, the activation scale, strip entry (s)
+    bool leader;                                                               // per lane
+    u32 dW, dS, dT, dummy_st, wg, nwg, nbuf;
+    __amdgpu_buffer_rsrc_t rW, rS;
+    Set setA, setB;
+    bool stored;                                                               // this wave wrote results to global memory
+
+    static __device__ __forceinline__ u32 inv_of(u32 d) { return d > 1 ? 0xFFFFFFFFu / d + 1u : 0u; }
+    static __device__ __forceinline__ u32 udiv(u32 x, u32 d, u32 inv) { return d > 1 ? __umulhi(x, inv) : x; }
+
+    // ctr_slot: which of the two step counters in LDS this GEMV uses (k_token alternates them from phase to phase: a
+    // fast wave initialises the next phase while slow ones still draw from this phase's counter)
+    __device__ __forceinline__ void init(const GemvArgs& a, u32 wg_, u32 nwg_, char* lds, u32 ctr_slot = 0) {
+        n = a.n; wg = wg_; nwg = nwg_;
+        lane = threadIdx.x & 63;
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        rowbytes = n * T::kEsz; sn = n / kGroup;
+        const u32 nchunks = rowbytes / 16;
+        cbs = a.cb_shift; RB = 64u >> cbs;
+        const u32 CB = 1u << cbs;
+        nbc = nchunks >> cbs;                                                  // column blocks per row
+        NBCV = TWO ? 2 * nbc : nbc;                                            // ... of the (virtual) matrix this launch walks
+        TRm = (u32)a.items * (EPI == EPI_ROPE_KV ? 2u : 1u);                   // rows per matrix
+        Rm = a.rows_per_pass;
+        RBP = Rm / RB;                                                         // row blocks per pass
+        npass = (TRm + Rm - 1) / Rm;
+        np_wg = wg < npass ? (npass - wg + nwg - 1) / nwg : 0;                 // passes of this workgroup
+        SP = ((RBP + H - 1) / H) * NBCV;                                       // steps per pass
+        NS = np_wg * SP;
+        inv_SP = inv_of(SP); inv_NBCV = inv_of(NBCV);
+        nbuf = a.nbuf > 0 ? a.nbuf : 2;
+        const GemvLds L = gemv_lds_layout(n, T::kEsz, true, Rm, RB, TWO, nbuf);
+        gstride = L.gstride; buf_bytes = L.buf_bytes; off_xs = L.off_xs; off_scr = L.off_scr; ctr_off = a.ctr_off ? (u32)a.ctr_off : (u32)L.off_ctr + 4 * (ctr_slot & 1);
+        dW = RB * rowbytes; dS = RB * sn * 4; dT = RB * gstride;               // row block to row block
+        dummy_st = Rm * gstride;
+        // lane-constant parts of every address (the per-step parts are wave-uniform scalars)
+        const u32 rb = lane >> cbs, cb = lane & (CB - 1);
+        lane_woff = rb * rowbytes + cb * 16;                                   // weights, bytes from the block base
+        lane_xoff = cb * 16;                                                   // activation chunk in LDS
+        lane_goff = rb * gstride + (cb >> LPGS) * ES;                          // strip entry of this lane's group
+        leader = (cb & (LPG - 1)) == 0;
+        // scale role: lane -> (block j of the step, quant group g of the block); g's leader lane is g * LPG
+        constexpr u32 GPB = 64u / LPG;
+        lane_j = lane / GPB;                                                   // >= H: no scale role (int16: lanes 32..63)
+        const u32 ll = (lane % GPB) * LPG, rb2 = ll >> cbs, cb2 = ll & (CB - 1);
+        lane_s2off = lane_j * dS + (rb2 * sn + (cb2 >> LPGS)) * 4;
+        lane_sx2off = (cb2 >> LPGS) * 4;
+        lane_poff = lane_j * dT + rb2 * gstride + (cb2 >> LPGS) * ES + ES / 2;
+        // Weight and scale blocks are fetched with raw buffer loads whose whole offset sits in the VGPR operand (lane
+        // constant + the step's scalar): that operand is what the hardware bounds-checks, so padding blocks, rows past
+        // the end of the matrix and steps past the end of the work (offset kOOB) return zero without touching memory.
+        // "nt": each weight byte is read once per token.
+        constexpr int kRsrcFlags = 0x00020000;                                 // raw buffer, 32-bit data format (gfx9 family)
+        const u32 NM = TWO ? 2u : 1u;
+        rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, (int)(NM * TRm * rowbytes), kRsrcFlags);
+        rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.sW), 0, (int)(NM * TRm * sn * 4), kRsrcFlags);
+        stored = false; primedA = primedB = false;
+        // the first two steps of every wave are fixed (wave, wave + 16): they are requested before any barrier
+        if (threadIdx.x == 0) *reinterpret_cast<u32*>(lds + ctr_off) = 2 * kWavesPerBlock;
+    }
+
+    // step number -> the set's bookkeeping and the scalar offsets of its first block
+    __device__ __forceinline__ void decode(u32 s, Set& S, u32& wo, u32& so) const {
+        if (s >= NS) { S.itl = np_wg; S.st = 0; S.xo = 0; S.nlive = 0; wo = kOOB; so = kOOB; return; }
+        const u32 itl = udiv(s, SP, inv_SP), rem = s - itl * SP;
+        const u32 q = udiv(rem, NBCV, inv_NBCV), cv = rem - q * NBCV;
+        const bool second = TWO && cv >= nbc;
+        const u32 cc = second ? cv - nbc : cv, g0 = (cc << cbs) >> LPGS;       // column block inside its matrix, its first quant group
+        const u32 rb0 = q * H, row0 = (second ? TRm : 0u) + (wg + itl * nwg) * Rm + rb0 * RB;
+        wo = row0 * rowbytes + ((cc << cbs) * 16);
+        so = (row0 * sn + g0) * 4;
+        S.itl = itl; S.xo = cc; S.nlive = RBP - rb0 < (u32)H ? RBP - rb0 : (u32)H;
+        S.st = rb0 * RB * gstride + g0 * ES + (second ? 4u : 0u);
+    }
+    __device__ __forceinline__ void load_step(Set& S, u32 s, int ablate) const {
+        u32 wo, so;
+        decode(s, S, wo, so);
+        u32 nl = S.nlive;
+        if (kAblate && (ablate & 4)) { nl = 0; so = kOOB; }
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            const u32 woj = (u32)j < nl ? wo + j * dW : kOOB;
+            S.w[j] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rW, (int)(lane_woff + woj), 0, 2));
+        }
+        const u32 svo = lane_j < nl ? lane_s2off + so : kOOB;
+        S.sw = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rS, (int)svo, 0, 2));
+    }
+    // the first two steps of weight loads: independent of the activation
+    // (part 1 / 2: only the first / second set; a set that was never requested is drawn at the start of run())
+    bool primedA, primedB;
+    __device__ __forceinline__ void issue(int ablate, int part = 0) {
+        if (part != 2) { load_step(setA, wave, ablate); primedA = true; }
+        if (part != 1) { load_step(setB, wave + kWavesPerBlock, ablate); primedB = true; }
+    }
+
+    // reduce one step: the group dots of its H blocks (registers), then the leaders park them; the scale-role lanes park s = sW * sX
+    v4i xa; float sx2; u32 cur_xo;                                             // activation chunk (dot role) / activation scale (scale role) of the current column block
+    __device__ __forceinline__ void reduce_step(const Set& S, char* lds, char* strips, int ablate) {
+        const char* xq = lds; const char* xs = lds + off_xs;
+        if (S.xo != cur_xo) {                                                  // wave-uniform: a new column block
+            cur_xo = S.xo;
+            xa = *reinterpret_cast<const v4i*>(xq + ((cur_xo << cbs) * 16) + lane_xoff);
+            sx2 = *reinterpret_cast<const float*>(xs + (((cur_xo << cbs) >> LPGS) * 4) + lane_sx2off);
+        }
+        float d[H];
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            int t = (kAblate && (ablate & 8)) ? 0 : quad_sum(dot_chunk<QT>(S.w[j], xa));
+            if constexpr (LPG == 8) t += __builtin_amdgcn_update_dpp(0, t, 0x104 /* row_shl:4 */, 0xF, 0xF, true);
+            d[j] = (float)t;                                                   // exact int32 -> fp32, as "s * dot" does
+        }
+        if (leader) {
+#pragma unroll
+            for (int j = 0; j < H; ++j) {
+                const u32 stj = (u32)j < S.nlive ? S.st + j * dT : dummy_st;   // padding blocks hold zeros: parked in the dummy strips
+                *reinterpret_cast<float*>(strips + stj + lane_goff) = d[j];
+            }
+        }
+        if (lane_j < S.nlive) *reinterpret_cast<float*>(strips + S.st + lane_poff) = __fmul_rn(S.sw, sx2);   // s = sW * sX (quant_operators.cpp:274)
+    }
+
+    // the end of a pass: one barrier, then ONE wave runs the fp32 chains of all Rm rows and the epilogue
+    __device__ __forceinline__ void finish_pass(const GemvArgs& a, u32 pass, u32 it, const char* strips, int pos) {
+        const bool chain_wave = wave == (it & (kWavesPerBlock - 1));
+        // epilogue operands of the chain wave, fetched before the barrier (lane r = row r of the pass)
+        float resid = 0.f, rc = 0.f, rs = 0.f;
+        const u32 row = pass * Rm + lane;                                      // row inside its matrix
+        const bool rv = chain_wave && lane < Rm && row < TRm;
+        if constexpr (EPI == EPI_RESIDUAL) { if (rv) resid = ld_agent(a.out + row); }
+        if constexpr (EPI == EPI_ROPE_KV) {
+            if (rv && row < (u32)(a.dim + a.kv_dim)) {
+                const u32 r2 = (row < (u32)a.dim ? row : row - a.dim) & ~1u;
+                const u32 dd = r2 % (u32)a.hs;
+                rc = a.rope_cos[(size_t)pos * (a.hs / 2) + dd / 2];
+                rs = a.rope_sin[(size_t)pos * (a.hs / 2) + dd / 2];
+            }
+        }
+        __syncthreads();
+        if (!chain_wave) return;
+#ifdef FLM_TRACE_BAR
+        if (kAblate && a.trace && threadIdx.x == 0 && it == 0) a.trace[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memtime();
+#endif
+        stored = true;
+        // ---- the reference's fp32 chain, lane r = row r: o[j] += s * dot (FMA), groups ascending.
+        //      A lone wave issues an instruction every ~5-7 cycles whatever its kind, so the loop is little more than the
+        //      dependent FMAs: strip entries are read 4 at a time into two register rings, one ring's reads fly while the
+        //      other ring's FMAs run, ONE explicit s_waitcnt per ring.  SWIGLU: an entry is {d1, d3, s1, s3}, and the W1
+        //      and W3 chains are the two halves of one v_pk_fma_f32 (each half an IEEE fma), operands in place.
+        float acc = 0.f, acc2 = 0.f;
+        if (lane < Rm && !(a.ablate & 1)) {
+            const char* sp = strips + lane * gstride;
+            u32 g = 0;
+#define FLM_RD4(r0, r1, r2, r3, ptr) r0 = *reinterpret_cast<const float4*>(ptr); r1 = *reinterpret_cast<const float4*>((ptr) + 16); r2 = *reinterpret_cast<const float4*>((ptr) + 32); r3 = *reinterpret_cast<const float4*>((ptr) + 48);
+            if constexpr (TWO) {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                f2 ac = {0.f, 0.f};
+#define FLM_CH(q) ac = __builtin_elementwise_fma(f2{q.z, q.w}, f2{q.x, q.y}, ac);
+                if (sn >= 8) {
+                    float4 a0, a1, a2, a3, b0, b1, b2, b3;
+                    FLM_RD4(a0, a1, a2, a3, sp)
+                    for (; g + 8 <= sn; g += 8) {
+                        const char* pn = sp + (g + 4) * 16;
+                        FLM_RD4(b0, b1, b2, b3, pn)
+                        __builtin_amdgcn_s_waitcnt(0xC47F);        // lgkmcnt <= 4: ring A has landed
+                        __builtin_amdgcn_sched_barrier(0);
+                        FLM_CH(a0) FLM_CH(a1) FLM_CH(a2) FLM_CH(a3)
+                        __builtin_amdgcn_sched_barrier(0);
+                        FLM_RD4(a0, a1, a2, a3, pn + 64)           // (past the end on the last round: inside the allocation, never consumed)
+                        __builtin_amdgcn_s_waitcnt(0xC47F);        // ring B has landed
+                        __builtin_amdgcn_sched_barrier(0);
+                        FLM_CH(b0) FLM_CH(b1) FLM_CH(b2) FLM_CH(b3)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // ring A holds groups g .. g+3
+                    if (g < sn) { FLM_CH(a0) ++g; } if (g < sn) { FLM_CH(a1) ++g; } if (g < sn) { FLM_CH(a2) ++g; } if (g < sn) { FLM_CH(a3) ++g; }
+                }
+                for (; g < sn; ++g) { const float4 e = *reinterpret_cast<const float4*>(sp + g * 16); FLM_CH(e) }
+#undef FLM_CH
+                acc = ac.x; acc2 = ac.y;
+            } else {
+#define FLM_CH(q) acc = __fmaf_rn(q.y, q.x, acc); acc = __fmaf_rn(q.w, q.z, acc);
+                if (sn >= 16) {
+                    float4 a0, a1, a2, a3, b0, b1, b2, b3;
+                    FLM_RD4(a0, a1, a2, a3, sp)
+                    for (; g + 16 <= sn; g += 16) {
+                        const char* pn = sp + (g + 8) * 8;
+                        FLM_RD4(b0, b1, b2, b3, pn)
+                        __builtin_amdgcn_s_waitcnt(0xC47F);
+                        __builtin_amdgcn_sched_barrier(0);
+                        FLM_CH(a0) FLM_CH(a1) FLM_CH(a2) FLM_CH(a3)
+                        __builtin_amdgcn_sched_barrier(0);
+                        FLM_RD4(a0, a1, a2, a3, pn + 64)
+                        __builtin_amdgcn_s_waitcnt(0xC47F);
+                        __builtin_amdgcn_sched_barrier(0);
+                        FLM_CH(b0) FLM_CH(b1) FLM_CH(b2) FLM_CH(b3)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // ring A holds groups g .. g+7; a pair is consumed only when both of its groups exist
+                    if (g + 2 <= sn) { FLM_CH(a0) g += 2; } if (g + 2 <= sn) { FLM_CH(a1) g += 2; } if (g + 2 <= sn) { FLM_CH(a2) g += 2; } if (g + 2 <= sn) { FLM_CH(a3) g += 2; }
+                }
+#undef FLM_CH
+                for (; g < sn; ++g) { const float2 e = *reinterpret_cast<const float2*>(sp + g * 8); acc = __fmaf_rn(e.y, e.x, acc); }
+            }
+#undef FLM_RD4
+        }
+        // ---------------- epilogues ----------------
+        if constexpr (EPI == EPI_STORE || EPI == EPI_RESIDUAL) {
+            if (rv) {
+                if constexpr (EPI == EPI_STORE) st_agent(a.out + row, acc);
+                else st_agent(a.out + row, __fadd_rn(resid, acc));   // o.add(tmp, offset) transformer.cpp:465,493
+            }
+        } else if constexpr (EPI == EPI_SWIGLU) {
+            if (rv) st_agent(a.out + row, swiglu_elem(acc, acc2));   // o1.swiglu(o3) transformer.cpp:481
+        } else {   // EPI_ROPE_KV: rows (2i, 2i+1) of [Wq;Wk;Wv]; RoPE on q and k, append k,v to the cache
+            const float other = __shfl_xor(acc, 1, kWave);
+            if (rv && (lane & 1) == 0) {
+                const float x0 = acc, x1 = other;
+                const u32 hs = a.hs;
+                if (row < (u32)(a.dim + a.kv_dim)) {
+                    const u32 rr = row < (u32)a.dim ? row : row - a.dim;
+                    const u32 h = rr / hs, d = rr - h * hs;
+                    float o0, o1;
+                    rope_pair(x0, x1, rc, rs, o0, o1);
+                    if (row < (u32)a.dim) { st_agent(a.out + row, o0); st_agent(a.out + row + 1, o1); }
+                    else { float* kp = a.kcache + ((size_t)h * a.max_seq + pos) * hs + d; st_agent(kp, o0); st_agent(kp + 1, o1); }
+                } else {
+                    const u32 rr = row - a.dim - a.kv_dim;
+                    const u32 h = rr / hs, d = rr - h * hs;
+                    float* vp = a.vcache + ((size_t)h * a.max_seq + pos) * hs + d; st_agent(vp, x0); st_agent(vp + 1, x1);
+                }
+            }
+        }
+    }
+
+    // the main loop: the quantized activation is in LDS (xq at 0, xs at off_xs); issue() has run
+    template <class Stamp>
+    __device__ __forceinline__ void run(const GemvArgs& a, char* lds, Stamp&& stamp) {
+        int pos = 0;
+        if constexpr (EPI == EPI_ROPE_KV) pos = *a.pos_ptr;
+        xa = v4i{0, 0, 0, 0}; sx2 = 0.f; cur_xo = 0xffffffffu;
+        u32* ctr = reinterpret_cast<u32*>(lds + ctr_off);
+        u32 it = 0;                                                            // pass of this workgroup this wave is in
+        bool tr3 = false;
+        // a wave's step numbers only grow, so when a set belongs to a later pass every earlier pass is complete for this wave
+        auto do_set = [&](Set& S) -> bool {
+            while (it < S.itl) {
+                char* strips = lds + off_scr + (nbuf > 1 ? (it & 1) * buf_bytes : 0u);   // double buffered across passes
+#ifdef FLM_TRACE_WAVES
+                if (kAblate && a.trace && it == 0 && lane == 0 && wave % 3 == 0) a.trace[blockIdx.x * 8 + 1 + wave / 3] = __builtin_amdgcn_s_memtime();
+#elif !defined(FLM_TRACE_PRO)
+                if (it == 0) stamp(4);
+#endif
+                finish_pass(a, wg + it * nwg, it, strips, pos);
+#ifndef FLM_TRACE_PRO
+                if (it == 0) stamp(5);
+#endif
+                ++it;
+            }
+            if (S.itl >= np_wg) return false;                                  // no work left (every later number is past the end too)
+            reduce_step(S, lds, lds + off_scr + (nbuf > 1 ? (S.itl & 1) * buf_bytes : 0u), a.ablate);
+            u32 s = 0;
+            if (lane == 0) s = atomicAdd(ctr, 1u);
+            load_step(S, __builtin_amdgcn_readfirstlane(s), a.ablate);         // refill this set: a full cycle ahead
+#if !defined(FLM_TRACE_PRO) && !defined(FLM_TRACE_BAR)
+            if (!tr3) { tr3 = true; stamp(3); }
+#endif
+            return true;
+        };
+        if (!primedA) load_step(setA, wave, a.ablate);                         // (a wave that was busy elsewhere during the prologue)
+        if (!primedB) load_step(setB, wave + kWavesPerBlock, a.ablate);
+        while (do_set(setA) && do_set(setB)) {}
+    }
+};
+
+template <int QT, int PRO, int EPI, int XR>
+__global__ void __launch_bounds__(kGemvBlock, 4) k_gemv(const GemvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    unsigned long long rt0 = 0;
+#ifdef FLM_TRACE_WAVES
+    auto stamp = [&](int k) { if (kAblate && a.trace && threadIdx.x == 0 && k == 0) a.trace[blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime(); };
+#else
+    auto stamp = [&](int k) { if (kAblate && a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime(); };
+#endif
+    if (kAblate && a.trace && threadIdx.x == 0) rt0 = __builtin_amdgcn_s_memrealtime();
+    stamp(0);
+    if (a.ablate & 16) return;
+    // The activation first, and the weight prefetch only once it HAS ARRIVED (the hook runs after the staging barrier /
+    // after the activation registers landed).  Weights do not depend on the activation and were once requested up
+    // front -- but workgroups start ~1 us apart, and the activation loads of the late ones then queued in HBM behind
+    // 32 MB of weight requests of the early ones: the activation came back 2.6 us later (measured), delaying the
+    // whole rmsnorm chain.  Issued after the activation, the first 128 KiB per CU still arrive under the chain.
+    float4 xv[XR > 0 ? XR : 1], nv[XR > 0 ? XR : 1];
+    gemv_preload<QT, PRO, XR>(a, xv, nv);
+    GemvCtx<QT, EPI> g;
+    g.init(a, blockIdx.x, gridDim.x, lds);
+    if constexpr (PRO == PRO_NONE) g.issue(a.ablate);
+    stamp(1);
+    gemv_prologue<QT, PRO, XR>(a, lds, xv, nv, [&](int part) { g.issue(a.ablate, part); });
+    stamp(2);
+    if (a.ablate & 32) return;
+    g.run(a, lds, stamp);
+    stamp(6);
+    if (kAblate && a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime() - rt0;
+}
+
+} // namespace flm

@@ -1,0 +1,139 @@
+// flm_misc.h -- embedding, argmax + state advance, and the op-level kernels of the parity tests.
+// Part of flm_kernels.h (hand-written gfx950 / CDNA4 kernels of the fast-llama per-token hot path); include that header.
+#pragma once
+#include "flm_math.h"
+#include "flm_gemv.h"
+// (bit-exactness hygiene: see flm_math.h -- no implicit FMA contraction in any of these headers)
+#pragma clang fp contract(off)
+
+namespace flm {
+
+// ------------------------------------------------------------------------------------------
+// small kernels
+// ------------------------------------------------------------------------------------------
+// x1 = embedding[token] (copy or dequantize; transformer.cpp:115-122)
+__global__ void k_embed(float* x, const void* emb, const float* emb_s, int emb_qt, int dim, const int* tok_ptr, unsigned* bar) {
+    const int tok = *tok_ptr;
+    if (bar && blockIdx.x == 0) { bar[threadIdx.x * 16] = 0; bar[(threadIdx.x + blockDim.x) * 16] = 0; }   // grid barrier flags (<= 512 workgroups, 64 B apart) of the k_token that follows
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < dim; e += gridDim.x * blockDim.x) {
+        float v;
+        if (emb_qt == 0) v = reinterpret_cast<const float*>(emb)[(size_t)tok * dim + e];
+        else {
+            const float s = emb_s[((size_t)tok * dim + e) / kGroup];
+            const int q = emb_qt == QT_INT8 ? (int)reinterpret_cast<const int8_t*>(emb)[(size_t)tok * dim + e]
+                                            : (int)reinterpret_cast<const int16_t*>(emb)[(size_t)tok * dim + e];
+            v = __fmul_rn((float)q, s);                              // dequantize_ quant_operators.cpp:49-65
+        }
+        x[e] = v;
+    }
+}
+
+// sample_argmax (src/transformer/sampler.cpp:36-47): first maximum wins.  One workgroup.
+// Also advances the device-resident decode state: tok <- argmax, pos <- pos+1, out[step++] <- argmax.
+struct DecodeState { int pos; int tok; int step; int pad; };
+__global__ void __launch_bounds__(1024) k_argmax_advance(const float* logits, int n, DecodeState* st, int* out_tokens, int advance) {
+    __shared__ float bv[16]; __shared__ int bi[16];
+    float best = -INFINITY; int idx = 0x7fffffff;
+    // ascending index order within a thread and strict '>' keep the FIRST maximum
+    const int n4 = n >> 2;
+    for (int j0 = 0; j0 < n4; j0 += 8 * 1024) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int j = j0 + u * 1024 + threadIdx.x; v[u] = j < n4 ? reinterpret_cast<const float4*>(logits)[j] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = (j0 + u * 1024 + threadIdx.x) * 4;
+            if (v[u].x > best) { best = v[u].x; idx = i; }
+            if (v[u].y > best) { best = v[u].y; idx = i + 1; }
+            if (v[u].z > best) { best = v[u].z; idx = i + 2; }
+            if (v[u].w > best) { best = v[u].w; idx = i + 3; }
+        }
+    }
+    for (int i = n4 * 4 + threadIdx.x; i < n; i += 1024) { const float v = logits[i]; if (v > best) { best = v; idx = i; } }
+    // lower index wins ties across threads: thread-local indices are not globally ordered, so compare (value, index)
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, kWave); const int oi = __shfl_xor(idx, o, kWave);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        if (idx == 0x7fffffff) idx = 0;      // all -inf / NaN: reference returns index 0
+        if (out_tokens) out_tokens[st->step] = idx;
+        if (advance) { st->tok = idx; st->pos += 1; }
+        st->step += 1;
+    }
+}
+// prompt feeding: pos <- pos+1, tok <- prompt[++step]
+__global__ void k_advance_prompt(DecodeState* st, const int* prompt) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { st->step += 1; st->pos += 1; st->tok = prompt[st->step]; }
+}
+__global__ void k_set_step(DecodeState* st, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) st->step = v; }
+// x += y (tensor-parallel path: residual add after the all-reduce; Tensor::add, tensor.cpp:723-743)
+__global__ void k_add_inplace(float* x, const float* y, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = __fadd_rn(x[i], y[i]);
+}
+
+// ---- op-level test kernels: thin launchers over the same __device__ functions ----
+// square_sum both ways: out[0] the wave-parallel evaluation (sq_chain_wave), out[1] the plain sequential chains (sq_chain)
+__global__ void __launch_bounds__(256) k_op_square_sum(float* out, const float* x, int n) {
+    extern __shared__ float sm[];
+    const int n4 = n / 4, ns = n4 + 8;
+    for (int e = threadIdx.x; e < n4 * 4; e += blockDim.x) sm[(e & 3) * ns + (e >> 2)] = x[e];
+    for (int i = threadIdx.x; i < 4 * 8; i += blockDim.x) sm[(i >> 3) * ns + n4 + (i & 7)] = 0.f;
+    __shared__ float red[8];
+    __syncthreads();
+    int its = 0;
+    const float l = sq_chain_wave(sm + (threadIdx.x >> 6) * ns, n4, &its);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = l; out[6 + (threadIdx.x >> 6)] = (float)its; }
+    if (threadIdx.x < 4) red[4 + threadIdx.x] = sq_chain(sm + threadIdx.x * ns, n4);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, red[0]), red[1]), red[2]), red[3]);
+        out[1] = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, red[4]), red[5]), red[6]), red[7]);
+        out[2] = red[0]; out[3] = red[1]; out[4] = red[2]; out[5] = red[3];
+    }
+}
+__global__ void k_op_swiglu(float* xo, const float* xr, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) xo[i] = swiglu_elem(xo[i], xr[i]);
+}
+// elementary functions as the kernels evaluate them: fn 0 expf_ref(x), 1 sqrtf(x), 2 x / y, 3 rms_scale(x, n = (int)y)
+__global__ void k_op_math(int fn, float* x, const float* y, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        x[i] = fn == 0 ? expf_ref(v) : fn == 1 ? __builtin_sqrtf(v) : fn == 2 ? __fdiv_rn(v, y[i]) : rms_scale(v, (int)y[i]);
+    }
+}
+__global__ void k_op_rope(float* o, const float* x, int n_dims, const float* c, const float* s) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (2 * i + 1 < n_dims) rope_pair(x[2 * i], x[2 * i + 1], c[i], s[i], o[2 * i], o[2 * i + 1]);
+}
+// softmax_sisd over n entries, one workgroup (same statements as k_attn_decode's softmax)
+__global__ void __launch_bounds__(kBlock) k_op_softmax(float* x, int n) {
+    __shared__ float red[16];
+    float lm = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += kBlock) lm = fmaxf(lm, x[i]);
+    const float m = block_max(lm, red);
+    for (int i = threadIdx.x; i < n; i += kBlock) x[i] = expf_ref(__fsub_rn(x[i], m));
+    __syncthreads();
+    if (threadIdx.x == 0) { float s = 0.f; for (int i = 0; i < n; ++i) s = __fadd_rn(s, x[i]); red[8] = s; }
+    __syncthreads();
+    const float L = red[8];
+    for (int i = threadIdx.x; i < n; i += kBlock) x[i] = __fdiv_rn(x[i], L);
+}
+// append one token's k (with RoPE), v to the caches and rotate q: what EPI_ROPE_KV does, for flm_op_attention
+__global__ void k_op_kv_append(float* q, const float* k, const float* v, float* kc, float* vc, const float* c, const float* s,
+                               int n_heads, int hs, int max_seq, int pos) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // pair index over heads*hs/2
+    if (i >= n_heads * hs / 2) return;
+    const int h = (2 * i) / hs, d = 2 * i - h * hs;
+    float o0, o1;
+    rope_pair(q[2 * i], q[2 * i + 1], c[d / 2], s[d / 2], o0, o1); q[2 * i] = o0; q[2 * i + 1] = o1;
+    rope_pair(k[2 * i], k[2 * i + 1], c[d / 2], s[d / 2], o0, o1);
+    float* kp = kc + ((size_t)h * max_seq + pos) * hs + d; kp[0] = o0; kp[1] = o1;
+    float* vp = vc + ((size_t)h * max_seq + pos) * hs + d; vp[0] = v[2 * i]; vp[1] = v[2 * i + 1];
+}
+
+} // namespace flm

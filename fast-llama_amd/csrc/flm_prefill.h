@@ -1,0 +1,260 @@
+// flm_prefill.h -- batched prompt processing: row prologues, int8/int16 GEMM tiles (MFMA / v_dot), RoPE + KV rows, SwiGLU rows.
+// Part of flm_kernels.h (hand-written gfx950 / CDNA4 kernels of the fast-llama per-token hot path); include that header.
+#pragma once
+#include "flm_math.h"
+#include "flm_gemv.h"
+// (bit-exactness hygiene: see flm_math.h -- no implicit FMA contraction in any of these headers)
+#pragma clang fp contract(off)
+
+namespace flm {
+
+// ------------------------------------------------------------------------------------------
+// Batched prefill (ParallelTransformer::forward with bs > 1, transformer.cpp:105-161).  A prompt's tokens before the
+// last one only have to leave their K/V rows in the cache; every (token, row) value is produced by the SAME chain as in
+// the single-token kernels (group dots exact, acc = fma(sW*sX, float(dot), acc) with groups ascending; per-row rmsnorm
+// chains; per-query attention), so the cache -- and therefore the logits of the last token, which runs through the
+// decode kernels -- is bit-identical to feeding the prompt token by token, at a fraction of the time: the weights are
+// streamed once per 64 tokens instead of once per token.
+//   k_embed_rows        x[b] = embedding[token b]
+//   k_rows_prologue     per token row: (rmsnorm,) quantize -> xq[b], xs[b]   (the decode prologue, one workgroup per row)
+//   k_gemm_q            out[b][r] (+)= W[r] . xq[b] for a 64 x 64 (rows x tokens) tile per workgroup
+//   k_rope_kv_rows      RoPE on q and k of every token, K/V rows appended to the cache
+//   k_attn_prefill      causal attention: one workgroup per (head, query), the decode attention with T = pos + i + 1
+//   k_swiglu_rows       hd[b] = swiglu(gate[b], up[b])
+// ------------------------------------------------------------------------------------------
+__global__ void k_embed_rows(float* x, const void* emb, const float* emb_s, int emb_qt, int dim, const int* tokens) {
+    const int tok = tokens[blockIdx.x];
+    float* xo = x + (size_t)blockIdx.x * dim;
+    for (int e = threadIdx.x; e < dim; e += blockDim.x) {
+        float v;
+        if (emb_qt == 0) v = reinterpret_cast<const float*>(emb)[(size_t)tok * dim + e];
+        else {
+            const float s = emb_s[((size_t)tok * dim + e) / kGroup];
+            const int q = emb_qt == QT_INT8 ? (int)reinterpret_cast<const int8_t*>(emb)[(size_t)tok * dim + e]
+                                            : (int)reinterpret_cast<const int16_t*>(emb)[(size_t)tok * dim + e];
+            v = __fmul_rn((float)q, s);                              // dequantize_ quant_operators.cpp:49-65
+        }
+        xo[e] = v;
+    }
+}
+
+struct RowsArgs {
+    const float* x;          // [B][n]
+    const float* norm_w;     // [n] (RMSNORM_QUANT)
+    void* xq; float* xs;     // [B][n] quantized, [B][n/64] scales
+    int n;
+};
+template <int QT, int PRO, int XR>
+__global__ void __launch_bounds__(kGemvBlock) k_rows_prologue(const RowsArgs r) {
+    using T = QTraits<QT>;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    GemvArgs a{};
+    a.n = r.n; a.x = r.x + (size_t)blockIdx.x * r.n; a.norm_w = r.norm_w;
+    a.rows_per_pass = 4; a.cb_shift = 4;                                     // (only the fixed LDS offsets are used)
+    float4 xv[XR > 0 ? XR : 1], nv[XR > 0 ? XR : 1];
+    gemv_preload<QT, PRO, XR>(a, xv, nv);
+    gemv_prologue<QT, PRO, XR>(a, lds, xv, nv, [](int) {});
+    const GemvLds L = gemv_lds_layout(r.n, T::kEsz, true, 4, 4, false);
+    const int nb16 = r.n * T::kEsz / 16, sn = r.n / kGroup;
+    int4* qo = reinterpret_cast<int4*>(reinterpret_cast<char*>(r.xq) + (size_t)blockIdx.x * r.n * T::kEsz);
+    for (int c = threadIdx.x; c < nb16; c += kGemvBlock) qo[c] = reinterpret_cast<const int4*>(lds)[c];
+    const float* xs = reinterpret_cast<const float*>(lds + L.off_xs);
+    for (int g = threadIdx.x; g < sn; g += kGemvBlock) r.xs[(size_t)blockIdx.x * sn + g] = xs[g];
+}
+
+struct GemmArgs {
+    const void* W; const float* sW;      // [rows][n], [rows][n/64]
+    const void* Xq; const float* Xs;     // [B][n], [B][n/64]
+    float* out; int ldo;                 // out[b * ldo + row]
+    int n, rows, B;
+};
+// One workgroup: 64 rows x 64 tokens, thread (ty, tx) owns rows 4ty..4ty+3 x tokens 4tx..4tx+3.  Per quant group the
+// 64-row and 64-token slices (64 or 128 bytes each) go through LDS (double buffered; rows padded by 16 B: conflict-free
+// 16-byte reads), int32 dots with v_dot4 / v_dot2, then the reference's fp32 chain step for the 16 outputs of the thread.
+template <int QT, int EPI>
+__global__ void __launch_bounds__(256) k_gemm_q(const GemmArgs a) {
+    using T = QTraits<QT>;
+    constexpr int GB = kGroup * T::kEsz;          // bytes of a group in one row
+    constexpr int NCH = GB / 16;                  // 16-byte chunks per group
+    constexpr int LS = GB + 16;                   // LDS row stride
+    constexpr int NLD = 64 * NCH / 256;           // 16-byte pieces per thread and tile
+    __shared__ __attribute__((aligned(16))) char Wt[2][64 * LS];
+    __shared__ __attribute__((aligned(16))) char Xt[2][64 * LS];
+    __shared__ float sWt[2][64], sXt[2][64];
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int ntt = (a.B + 63) / 64;
+    const int r0 = (blockIdx.x / ntt) * 64, b0 = (blockIdx.x % ntt) * 64;   // token tile fastest: neighbours share the weight rows
+    const int sn = a.n / kGroup;
+    const size_t rowbytes = (size_t)a.n * T::kEsz;
+    const char* Wb = reinterpret_cast<const char*>(a.W);
+    const char* Xb = reinterpret_cast<const char*>(a.Xq);
+    v4i wr[NLD], xr[NLD]; float sr = 0.f;
+    auto fetch = [&](int g) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = tid + k * 256, row = idx / NCH, ch = idx % NCH;
+            wr[k] = (r0 + row < a.rows) ? *reinterpret_cast<const v4i*>(Wb + (size_t)(r0 + row) * rowbytes + (size_t)g * GB + ch * 16) : v4i{0, 0, 0, 0};
+            xr[k] = (b0 + row < a.B)    ? *reinterpret_cast<const v4i*>(Xb + (size_t)(b0 + row) * rowbytes + (size_t)g * GB + ch * 16) : v4i{0, 0, 0, 0};
+        }
+        if (tid < 64) sr = (r0 + tid < a.rows) ? a.sW[(size_t)(r0 + tid) * sn + g] : 0.f;
+        else if (tid < 128) sr = (b0 + tid - 64 < a.B) ? a.Xs[(size_t)(b0 + tid - 64) * sn + g] : 0.f;
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = tid + k * 256, row = idx / NCH, ch = idx % NCH;
+            *reinterpret_cast<v4i*>(&Wt[buf][row * LS + ch * 16]) = wr[k];
+            *reinterpret_cast<v4i*>(&Xt[buf][row * LS + ch * 16]) = xr[k];
+        }
+        if (tid < 64) sWt[buf][tid] = sr; else if (tid < 128) sXt[buf][tid - 64] = sr;
+    };
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    fetch(0); park(0);
+    __syncthreads();
+    for (int g = 0; g < sn; ++g) {
+        const int buf = g & 1;
+        if (g + 1 < sn) fetch(g + 1);
+        int d[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[i][j] = 0;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            v4i w[4], x[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[i] = *reinterpret_cast<const v4i*>(&Wt[buf][(ty * 4 + i) * LS + ch * 16]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = *reinterpret_cast<const v4i*>(&Xt[buf][(tx * 4 + j) * LS + ch * 16]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (QT == QT_INT8) d[i][j] = dot16_i8(w[i], x[j], d[i][j]); else d[i][j] = dot8_i16(w[i], x[j], d[i][j]);
+                }
+        }
+        float sw[4], sx[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sw[i] = sWt[buf][ty * 4 + i]; sx[i] = sXt[buf][tx * 4 + i]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __fmaf_rn(__fmul_rn(sw[i], sx[j]), (float)d[i][j], acc[i][j]);   // quant_operators.cpp:274
+        if (g + 1 < sn) park(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int b = b0 + tx * 4 + j;
+        if (b >= a.B) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = r0 + ty * 4 + i;
+            if (row >= a.rows) continue;
+            float* o = a.out + (size_t)b * a.ldo + row;
+            if constexpr (EPI == EPI_RESIDUAL) *o = __fadd_rn(*o, acc[i][j]); else *o = acc[i][j];
+        }
+    }
+}
+
+// The int8 GEMM on the matrix cores (gfx950 v_mfma_i32_32x32x32_i8): same 64 x 64 workgroup tile, four waves each owning a
+// 32 x 32 (rows x tokens) quadrant.  Per quant group two MFMAs (K = 2 x 32) accumulate the group's 1024 int32 dots exactly
+// (integer sums are order-free; A and B use the same byte -> k assignment: lane half h takes bytes 32kk + 16h .. +15 of the
+// group); then every lane applies the reference's fp32 chain step to its 16 results -- that VALU work, not the MFMA, is what
+// bounds the kernel.  C/D layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+typedef int v16i __attribute__((ext_vector_type(16)));
+template <int EPI>
+__global__ void __launch_bounds__(256) k_gemm_q8_mfma(const GemmArgs a) {
+    constexpr int GB = kGroup;                    // bytes of a group in one row (int8)
+    constexpr int LS = GB + 16;                   // LDS row stride
+    __shared__ __attribute__((aligned(16))) char Wt[2][64 * LS];
+    __shared__ __attribute__((aligned(16))) char Xt[2][64 * LS];
+    __shared__ __attribute__((aligned(16))) float sWt[2][64];
+    __shared__ float sXt[2][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntt = (a.B + 63) / 64;
+    const int r0 = (blockIdx.x / ntt) * 64, b0 = (blockIdx.x % ntt) * 64;   // token tile fastest: neighbours share the weight rows
+    const int wr0 = (wave >> 1) * 32, wc0 = (wave & 1) * 32;                // this wave's quadrant inside the tile
+    const int sn = a.n / kGroup;
+    const size_t rowbytes = (size_t)a.n;
+    const char* Wb = reinterpret_cast<const char*>(a.W);
+    const char* Xb = reinterpret_cast<const char*>(a.Xq);
+    v4i wr, xr; float sr = 0.f;
+    const int lrow = tid >> 2, lch = tid & 3;                               // loader: 64 rows x 4 chunks of 16 B
+    auto fetch = [&](int g) {
+        wr = (r0 + lrow < a.rows) ? *reinterpret_cast<const v4i*>(Wb + (size_t)(r0 + lrow) * rowbytes + (size_t)g * GB + lch * 16) : v4i{0, 0, 0, 0};
+        xr = (b0 + lrow < a.B)    ? *reinterpret_cast<const v4i*>(Xb + (size_t)(b0 + lrow) * rowbytes + (size_t)g * GB + lch * 16) : v4i{0, 0, 0, 0};
+        if (tid < 64) sr = (r0 + tid < a.rows) ? a.sW[(size_t)(r0 + tid) * sn + g] : 0.f;
+        else if (tid < 128) sr = (b0 + tid - 64 < a.B) ? a.Xs[(size_t)(b0 + tid - 64) * sn + g] : 0.f;
+    };
+    auto park = [&](int buf) {
+        *reinterpret_cast<v4i*>(&Wt[buf][lrow * LS + lch * 16]) = wr;
+        *reinterpret_cast<v4i*>(&Xt[buf][lrow * LS + lch * 16]) = xr;
+        if (tid < 64) sWt[buf][tid] = sr; else if (tid < 128) sXt[buf][tid - 64] = sr;
+    };
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int am = wr0 + (lane & 31), bn = wc0 + (lane & 31), kh = (lane >> 5) * 16;
+    fetch(0); park(0);
+    __syncthreads();
+    for (int g = 0; g < sn; ++g) {
+        const int buf = g & 1;
+        if (g + 1 < sn) fetch(g + 1);
+        const v4i a0 = *reinterpret_cast<const v4i*>(&Wt[buf][am * LS + kh]), a1 = *reinterpret_cast<const v4i*>(&Wt[buf][am * LS + 32 + kh]);
+        const v4i x0 = *reinterpret_cast<const v4i*>(&Xt[buf][bn * LS + kh]), x1 = *reinterpret_cast<const v4i*>(&Xt[buf][bn * LS + 32 + kh]);
+        v16i d = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        d = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, x0, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, x1, d, 0, 0, 0);
+        const float sx = sXt[buf][bn];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 sw = *reinterpret_cast<const float4*>(&sWt[buf][wr0 + 8 * q + 4 * (lane >> 5)]);
+            acc[4 * q + 0] = __fmaf_rn(__fmul_rn(sw.x, sx), (float)d[4 * q + 0], acc[4 * q + 0]);   // quant_operators.cpp:274
+            acc[4 * q + 1] = __fmaf_rn(__fmul_rn(sw.y, sx), (float)d[4 * q + 1], acc[4 * q + 1]);
+            acc[4 * q + 2] = __fmaf_rn(__fmul_rn(sw.z, sx), (float)d[4 * q + 2], acc[4 * q + 2]);
+            acc[4 * q + 3] = __fmaf_rn(__fmul_rn(sw.w, sx), (float)d[4 * q + 3], acc[4 * q + 3]);
+        }
+        if (g + 1 < sn) park(buf ^ 1);
+        __syncthreads();
+    }
+    const int b = b0 + bn;
+    if (b < a.B) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = r0 + wr0 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+            if (row >= a.rows) continue;
+            float* o = a.out + (size_t)b * a.ldo + row;
+            if constexpr (EPI == EPI_RESIDUAL) *o = __fadd_rn(*o, acc[i]); else *o = acc[i];
+        }
+    }
+}
+
+// qkv[b] = [q ; k ; v] (dim each) of token b at position pos0 + b: RoPE on q and k (rope_v2 pairs), q -> qout[b], k / v -> cache rows
+__global__ void k_rope_kv_rows(const float* qkv, float* qout, float* kcache, float* vcache, const float* rope_cos, const float* rope_sin,
+                               int dim, int hs, int max_seq, int pos0) {
+    const int b = blockIdx.x, pos = pos0 + b;
+    const float* in = qkv + (size_t)b * 3 * dim;
+    for (int i = threadIdx.x; i < dim / 2; i += blockDim.x) {
+        const int row = 2 * i, h = row / hs, d = row - h * hs;
+        const float c = rope_cos[(size_t)pos * (hs / 2) + d / 2], s = rope_sin[(size_t)pos * (hs / 2) + d / 2];
+        float o0, o1;
+        rope_pair(in[row], in[row + 1], c, s, o0, o1);
+        qout[(size_t)b * dim + row] = o0; qout[(size_t)b * dim + row + 1] = o1;
+        rope_pair(in[dim + row], in[dim + row + 1], c, s, o0, o1);
+        float* kp = kcache + ((size_t)h * max_seq + pos) * hs + d; kp[0] = o0; kp[1] = o1;
+        float* vp = vcache + ((size_t)h * max_seq + pos) * hs + d; vp[0] = in[2 * dim + row]; vp[1] = in[2 * dim + row + 1];
+    }
+}
+
+__global__ void k_swiglu_rows(float* hd, const float* gu, int hidden) {
+    const float* g = gu + (size_t)blockIdx.x * 2 * hidden;
+    float* o = hd + (size_t)blockIdx.x * hidden;
+    for (int i = threadIdx.x; i < hidden; i += blockDim.x) o[i] = swiglu_elem(g[i], g[hidden + i]);   // o1.swiglu(o3) transformer.cpp:481
+}
+
+} // namespace flm

@@ -33,7 +33,7 @@ def test_quantize_bit_exact(gpu, qt, dt, lim, n):
 
 
 @pytest.mark.parametrize("qt,dt,lim", QTS)
-@pytest.mark.parametrize("m,n,w", [(96, 256, 1), (96, 256, 3), (64, 11008, 1), (130, 512, 5), (4096, 4096, 1), (7, 64, 2), (1000, 768, 1)])
+@pytest.mark.parametrize("m,n,w", [(96, 256, 1), (96, 256, 3), (64, 11008, 1), (130, 512, 5), (4096, 4096, 1), (7, 64, 2), (1000, 768, 1), (33000, 128, 1), (20000, 1024, 2)])
 def test_matmul_q(gpu, qt, dt, lim, m, n, w):
     rng = np.random.default_rng(m * 7 + n + w + qt)
     W = rng.integers(-lim, lim + 1, (m, n)).astype(dt)
