@@ -352,25 +352,23 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
 //
 // One 16-wave workgroup per CU reduces Rm rows per pass.  The Rm x K tile is cut into 1 KiB blocks of
 // (RB rows x CB chunks of 16 B), RB*CB = 64, CB = the largest power of two dividing K/16 (so a block is
-// one fully coalesced buffer_load_dwordx4 per wave and every lane is busy for any K).  The waves form a
-// WC x WR grid: wave (wc, wr) owns the column blocks wc, wc+WC, ... and, of those, the row blocks
-// wr, wr+WR, ...; it walks them column block by column block, so that from one block to the next
-// only three scalar offsets advance by constants (the instruction stream per KiB is what limits a
-// GEMV whose operands arrive at several TB/s), and its activation chunk stays in registers.
-// SWIGLU runs [W1 ; W3] as ONE matrix with twice the column blocks: both dot products of a row land in
-// the same strip and the same chain lane.  Per block:
+// one fully coalesced buffer_load_dwordx4 per wave and every lane is busy for any K).  H consecutive row
+// blocks of one column block form a STEP; the workgroup's steps are numbered and drawn by the waves from a
+// counter in LDS (see GemvCtx::Set).  SWIGLU runs [W1 ; W3] as ONE matrix with twice the column blocks: both
+// dot products of a row land in the same strip entry and the same chain lane.  Per block:
 //   1. int32 dot per 16-byte chunk (v_dot4 / v_dot2), exact;
 //   2. DPP sum over the 4 (int8) / 8 (int16) lanes of a quant group -> the group's int32 dot, exact;
-//   3. group leaders park { float(dot), sW*sX } in the row's LDS strip (one ds_write_b64);
+//   3. group leaders park float(dot), the step's scale-role lanes park sW*sX, in the row's LDS strip;
 // and per pass, after ONE workgroup barrier, one wave walks the strips, lane r = row r:
 //        acc = fma(s[g], d[g], acc), g ascending -- the reference's summation order, bit-identical --
 // amortising the sequential fp32 chain over Rm rows, and runs the epilogue.  Strips are double
-// buffered, so the other waves are already in the next pass.  Two register sets of H blocks each
-// keep 8 KiB per wave (128 KiB per CU) of weight loads in flight at all times; the first 8 are
-// issued before the prologue so HBM latency and the sequential rmsnorm chain overlap the stream.
+// buffered, so the other waves are already in the next pass.  Two register sets of one step each
+// keep 8 KiB per wave (128 KiB per CU) of weight loads in flight at all times; the first two steps of
+// every wave are requested as soon as the activation has arrived, so HBM latency and the sequential
+// rmsnorm chain overlap the stream.
 //
-// GemvCtx is the per-wave state of one GEMV: geometry, the load cursor and the two register sets.
-// The standalone kernel k_gemv and the persistent whole-token kernel k_token both drive it:
+// GemvCtx is the per-wave state of one GEMV: geometry, the step decoder and the two register sets.
+// k_gemv, k_attn_o and the persistent whole-token kernel k_token all drive it:
 //     init -> issue (weight loads of the first two steps) -> [activation prologue] -> run
 // ------------------------------------------------------------------------------------------
 typedef unsigned int u32;

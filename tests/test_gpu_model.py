@@ -80,7 +80,7 @@ def test_device_greedy_loop_matches_stepwise(gpu):
 
 @pytest.mark.parametrize("qt", [ff.QT_INT8, ff.QT_INT16])
 def test_7b_width_layer_every_code_path_vs_oracle(gpu, qt):
-    """one LLaMA2-7B-width layer + the 32000-row classifier: the production wave grids, pass geometry and LDS layouts
+    """one LLaMA2-7B-width layer + the 32000-row classifier: the production pass geometry, step numbering and LDS layouts
     (the tiny shapes use other ones), with the per-phase kernels and the persistent token kernel."""
     cfg = synth.make_config("7B", qt); cfg.n_layers = 1
     tensors = synth.make_tensors(cfg, seed=31)
