@@ -292,8 +292,7 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
             FLM_PRO_STAMP(4)
             __syncthreads();
             const float ss = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, red[8]), red[9]), red[10]), red[11]);
-            r = rms_scale(ss, n);
-            __syncthreads();                                   // scratch is reused by the GEMV waves below
+            r = rms_scale(ss, n);                               // (scratch is not touched again before the barrier that ends the prologue)
             FLM_PRO_STAMP(5)
         }
         // one round: (normalise,) group max over 16 lanes, quantize, pack into LDS
