@@ -157,6 +157,25 @@ def test_long_context_positions(gpu):
     ctx.close()
 
 
+def test_fused_attention_decode_over_the_whole_context_matches_two_launches(gpu):
+    """7B width, one layer: 1000 greedy tokens (positions 8..1007: 1 to 16 K/V tiles per head) with attention + Wo as one launch
+    and as two -- the same ids and, at the end, the same logits bits; no cross-workgroup wait may time out on the way."""
+    cfg = synth.make_config("7B", ff.QT_INT8); cfg.n_layers = 1
+    tensors = synth.make_tensors(cfg, seed=77)
+    prompt = _prompt(cfg.vocab_size, 8)
+    res = []
+    for fuse in (1, 0):
+        ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
+        ctx.set_option("fuse_attn_o", fuse)
+        first = ctx.forward_argmax(prompt, 0)
+        ids = list(ctx.decode_greedy(first, len(prompt), 1000))
+        lg = ctx.forward(np.array([ids[-1]], np.int32), len(prompt) + 1000)
+        res.append((first, ids, lg.copy()))
+        ctx.close()
+    assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
+    assert bits_equal(res[0][2], res[1][2])
+
+
 def test_errors(gpu):
     cfg = synth.make_config("tiny", ff.QT_INT8)
     d = gpu.desc_from_config(cfg)
