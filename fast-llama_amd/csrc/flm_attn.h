@@ -238,6 +238,172 @@ __global__ void __launch_bounds__(kAttnBlock) k_attn_prefill(const AttnArgs a, i
     const int i = blockIdx.y;
     attn_head_any<false>(a, blockIdx.x, lds, pos0 + i + 1, a.q + (size_t)i * row_stride, a.out + (size_t)i * row_stride);
 }
+// ------------------------------------------------------------------------------------------
+// Batched prefill, several queries per workgroup (hs <= 128).  Workgroup (h, g) takes the kMqQueries consecutive queries
+// i0 = g * kMqQueries ... of head h: every K and V tile is brought to LDS ONCE for all of them, and the 16 waves are all busy
+// with chains (scores: 4 queries per thread on the same K operands; softmax: one wave per query; PV: one thread per (query,
+// output dimension)) where the one-query kernel keeps 2 of them busy.  Every query's arithmetic is attn_head's, operation
+// for operation: 8 strided accumulators added 0..7, * attn_scale, max, expf_ref, the sum t ascending, divide, row 0 by
+// multiplication, rows t >= 1 by FMA with |w| <= 1e-15 skipped (causal: query j sees the rows t < T_j only).
+// ------------------------------------------------------------------------------------------
+constexpr int kMqQueries = 8;
+__host__ inline size_t attn_mq_lds_bytes(int max_seq, int hs) {
+    return (size_t)(kMqQueries * hs + kMqQueries * (((max_seq + 3) & ~3) + 8) + 2 * kAttnTile * attn_row_stride(hs)) * 4;
+}
+template <int NF>
+__device__ __forceinline__ void attn_prefill_mq(const AttnArgs& a, const int h, char* lds, const int pos0, const int i0, const int nq, const int row_stride) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    constexpr int NQ = kMqQueries, rs = NF * 64 + 8;
+    const int hs = a.hs, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int scs = ((a.max_seq + 3) & ~3) + 8;                                 // stride of a query's score row
+    float* qs = reinterpret_cast<float*>(lds);                                  // [NQ][hs]
+    float* sc = qs + NQ * hs;                                                   // [NQ][scs]
+    float* tile0 = sc + NQ * scs;
+    float* tile1 = tile0 + kAttnTile * rs;
+    const int Tmax = pos0 + i0 + nq;                                            // rows the last query of this workgroup sees
+    const int nt = (Tmax + kAttnTile - 1) / kAttnTile;
+    const float* K = a.kcache + (size_t)h * a.max_seq * hs;
+    const float* V = a.vcache + (size_t)h * a.max_seq * hs;
+    const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(K), 0, a.max_seq * hs * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V), 0, a.max_seq * hs * 4, 0x00020000);
+    const float scale = (float)(1.0 / (double)__builtin_sqrtf((float)hs));      // attn_scale, transformer.cpp:418
+    // this thread's pieces of a tile (as in attn_head)
+    const int f4r = hs >> 2, tile_f4 = kAttnTile * f4r, tile_bytes = kAttnTile * hs * 4;
+    int prow[NF], goff[NF], loff[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int f = tid + j * kAttnBlock, row = f / f4r, c4 = f - row * f4r;
+        prow[j] = f < tile_f4 ? row : (1 << 28);
+        goff[j] = (row * hs + c4 * 4) * 4;
+        loff[j] = row * rs + c4 * 4;
+    }
+    auto request = [&](const __amdgpu_buffer_rsrc_t& r, int tile, v4f (&reg)[NF]) {
+        const int t0 = tile * kAttnTile;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const unsigned off = (tile < nt && t0 + prow[j] < Tmax) ? (unsigned)(tile * tile_bytes + goff[j]) : 0x80000000u;
+            reg[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+        }
+    };
+    auto park = [&](float* buf, const v4f (&reg)[NF]) {
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+            if (prow[j] < kAttnTile) *reinterpret_cast<float4*>(buf + loff[j]) = make_float4(reg[j].x, reg[j].y, reg[j].z, reg[j].w);
+    };
+    v4f ring[NF];
+    request(rK, 0, ring);
+    for (int e = tid; e < NQ * hs; e += kAttnBlock) {
+        const int j = e / hs, d = e - j * hs;
+        qs[e] = j < nq ? a.q[(size_t)(i0 + j) * row_stride + (size_t)h * hs + d] : 0.f;
+    }
+    // ---- scores.  thread = (query half, position p, accumulator k); its 4 queries share the K operand of every step
+    {
+        const int k = tid & 7, p = (tid >> 3) & 63, jh = (tid >> 9) * 4;
+        for (int s = 0; s < nt; ++s) {
+            float* cur = (s & 1) ? tile1 : tile0;
+            park(cur, ring);
+            __syncthreads();                                                    // (also orders qs before its first use)
+            request(rK, s + 1, ring);
+            const float* kp = cur + p * rs + k;
+            const float* q0 = qs + (jh + 0) * hs + k; const float* q1 = qs + (jh + 1) * hs + k;
+            const float* q2 = qs + (jh + 2) * hs + k; const float* q3 = qs + (jh + 3) * hs + k;
+            float l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
+#pragma unroll 8
+            for (int i = 0; i < hs; i += 8) {
+                const float kv = kp[i];
+                l0 = __fmaf_rn(kv, q0[i], l0); l1 = __fmaf_rn(kv, q1[i], l1); l2 = __fmaf_rn(kv, q2[i], l2); l3 = __fmaf_rn(kv, q3[i], l3);
+            }
+            const int t = s * kAttnTile + p;
+            auto fold = [&](float l, int j) {                                   // the 8 partials added 0..7 (lane k = 0 collects them)
+                const int li = __float_as_int(l);
+                float tot = __fadd_rn(0.f, l);
+                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x101 /* row_shl:1 */, 0xF, 0xF, true)));
+                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x102, 0xF, 0xF, true)));
+                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x103, 0xF, 0xF, true)));
+                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x104, 0xF, 0xF, true)));
+                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x105, 0xF, 0xF, true)));
+                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x106, 0xF, 0xF, true)));
+                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x107, 0xF, 0xF, true)));
+                if (k == 0 && j < nq && t < pos0 + i0 + j + 1) sc[j * scs + t] = __fmul_rn(tot, scale);   // att.multiply(attn_scale) :443
+            };
+            fold(l0, jh + 0); fold(l1, jh + 1); fold(l2, jh + 2); fold(l3, jh + 3);
+        }
+    }
+    request(rV, 0, ring);                                                       // the first V tile travels under the softmax
+    __syncthreads();
+    // ---- softmax: wave j = query j (max is order-free; the sum is the reference's sequential one, tf_operators.cpp:180-183)
+    if (wave < nq) {
+        const int T = pos0 + i0 + wave + 1;
+        float* row = sc + wave * scs;
+        float m = -INFINITY;
+        for (int t = lane; t < T; t += 64) m = fmaxf(m, row[t]);
+        m = wave_max(m);
+        for (int t = lane; t < T; t += 64) row[t] = expf_ref(__fsub_rn(row[t], m));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                  // (LDS writes of the other lanes before lane 0's reads: same wave, in order)
+        float sum = 0.f;
+        if (lane == 0) {                                                        // T dependent adds; the LDS reads run 16 elements ahead
+            int t = 0;
+            if (T >= 16) {
+                const float4* r4 = reinterpret_cast<const float4*>(row);
+                float4 a0 = r4[0], a1 = r4[1], a2 = r4[2], a3 = r4[3];
+#define FLM_ADD4(q) sum = __fadd_rn(sum, q.x); sum = __fadd_rn(sum, q.y); sum = __fadd_rn(sum, q.z); sum = __fadd_rn(sum, q.w);
+                for (; t + 32 <= T; t += 16) {
+                    const float4 b0 = r4[t / 4 + 4], b1 = r4[t / 4 + 5], b2 = r4[t / 4 + 6], b3 = r4[t / 4 + 7];
+                    FLM_ADD4(a0) FLM_ADD4(a1) FLM_ADD4(a2) FLM_ADD4(a3)
+                    a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+                }
+                FLM_ADD4(a0) FLM_ADD4(a1) FLM_ADD4(a2) FLM_ADD4(a3)
+#undef FLM_ADD4
+                t += 16;
+            }
+            for (; t < T; ++t) sum = __fadd_rn(sum, row[t]);
+        }
+        sum = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(sum)));
+        // att[t] = exp / sum; rows t >= 1 with |att| <= 1e-15 are skipped by the weighted sum (transformer.cpp:449): stored as exact zeros
+        for (int t = lane; t < T; t += 64) { const float w = __fdiv_rn(row[t], sum); row[t] = (t > 0 && fabsf(w) <= 1e-15f) ? 0.f : w; }
+    }
+    // ---- o[j][d] = sum_t att_j[t] V[t][d]: one thread per (query, output dimension), t ascending, over the shared V tiles
+    const int tpq = hs <= 64 ? 64 : 128;                                        // threads per query (a multiple of the wave: the skip test stays wave-uniform)
+    const int j = tid / tpq, d = tid - j * tpq;
+    const bool mine = j < nq && d < hs;
+    const int Tj = pos0 + i0 + j + 1;
+    float o = 0.f;
+    for (int i = 0; i < nt; ++i) {
+        float* cur = (i & 1) ? tile1 : tile0;
+        park(cur, ring);
+        __syncthreads();                                                        // (the first one also orders the softmax's writes before the reads below)
+        request(rV, i + 1, ring);
+        if (mine) {
+            const float* vp = cur + d;
+            const float* wp = sc + j * scs + i * kAttnTile;
+            int np = Tj - i * kAttnTile; np = np < 0 ? 0 : (np > kAttnTile ? kAttnTile : np);
+            int p = 0;
+            if (i == 0 && np > 0) { o = __fmul_rn(vp[0], wp[0]); p = 1; }       // row 0 always (tf_operators.cpp:331-336)
+            // the weights are wave-uniform (a wave's lanes belong to ONE query): if no row of the tile is skipped the walk is reads at
+            // immediate offsets, 8 positions ahead of the 8 dependent FMAs (as in attn_head)
+            const float wl = lane < np ? wp[lane] : 1.f;
+            if (__all(wl != 0.f)) {
+                for (; p < np && (p & 7); ++p) o = __fmaf_rn(vp[p * rs], wp[p], o);
+                for (; p + 8 <= np; p += 8) {
+                    const float* vq = vp + p * rs;
+                    const float4 wa = *reinterpret_cast<const float4*>(wp + p), wb = *reinterpret_cast<const float4*>(wp + p + 4);
+                    const float a0 = vq[0], a1 = vq[rs], a2 = vq[2 * rs], a3 = vq[3 * rs], a4 = vq[4 * rs], a5 = vq[5 * rs], a6 = vq[6 * rs], a7 = vq[7 * rs];
+                    o = __fmaf_rn(a0, wa.x, o); o = __fmaf_rn(a1, wa.y, o); o = __fmaf_rn(a2, wa.z, o); o = __fmaf_rn(a3, wa.w, o);
+                    o = __fmaf_rn(a4, wb.x, o); o = __fmaf_rn(a5, wb.y, o); o = __fmaf_rn(a6, wb.z, o); o = __fmaf_rn(a7, wb.w, o);
+                }
+                for (; p < np; ++p) o = __fmaf_rn(vp[p * rs], wp[p], o);
+            } else {
+                for (; p < np; ++p) { const float w = wp[p]; o = w == 0.f ? o : __fmaf_rn(vp[p * rs], w, o); }
+            }
+        }
+    }
+    if (mine) a.out[(size_t)(i0 + j) * row_stride + (size_t)h * hs + d] = o;
+}
+__global__ void __launch_bounds__(kAttnBlock) k_attn_prefill_mq(const AttnArgs a, int pos0, int row_stride, int B) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int i0 = blockIdx.y * kMqQueries, nq = B - i0 < kMqQueries ? B - i0 : kMqQueries;
+    if (a.hs <= 64) attn_prefill_mq<1>(a, blockIdx.x, lds, pos0, i0, nq, row_stride); else attn_prefill_mq<2>(a, blockIdx.x, lds, pos0, i0, nq, row_stride);
+}
 __global__ void __launch_bounds__(kAttnBlock) k_attn_decode(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     attn_head_any<false>(a, blockIdx.x, lds, *a.pos_ptr + 1, a.q, a.out);

@@ -67,6 +67,7 @@ struct flm_ctx {
     float *pf_x = nullptr, *pf_qkv = nullptr, *pf_q = nullptr, *pf_att = nullptr, *pf_gu = nullptr, *pf_hd = nullptr, *pf_xs = nullptr; void* pf_xq = nullptr;
     int use_mega = 0;                                  // option "use_mega": run single-GPU tokens as ONE persistent kernel (k_token); opt-in until it beats the per-phase kernels
     GemvArgs* mega_gemv = nullptr; AttnArgs* mega_attn = nullptr; unsigned* mega_bar = nullptr; int* mega_err = nullptr;
+    int use_prefill_mq = 1;                            // option "use_prefill_mq": batched prefill attention with 8 queries per workgroup (0: one query per workgroup)
     int fuse_attn_o = 1;                               // option "fuse_attn_o": attention + Wo GEMV in one launch (k_attn_o; single GPU)
     size_t mega_lds = 0; int mega_ok = -1;              // -1 not built yet, 0 shape not supported by k_token, 1 ready
     int trace_class = -1; unsigned long long* trace = nullptr;   // FLM_ABLATE builds: GEMV timeline of one kernel class
@@ -589,7 +590,10 @@ int prefill_batched(flm_ctx* c, int B, int pos) {
         // attention of every query over the cache rows 0 .. its own position   (execute_attn :441-449)
         AttnArgs aa{}; aa.q = c->pf_q; aa.kcache = c->kcache + (size_t)l * kv_layer; aa.vcache = c->vcache + (size_t)l * kv_layer;
         aa.out = c->pf_att; aa.pos_ptr = &c->state->pos; aa.hs = hs; aa.max_seq = d.max_seq_len;
-        hipLaunchKernelGGL(k_attn_prefill, dim3(c->heads_local, B), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, hs), st, aa, pos, dim);
+        if (hs <= 128 && c->use_prefill_mq)      // kMqQueries queries per workgroup share every K/V tile
+            hipLaunchKernelGGL(k_attn_prefill_mq, dim3(c->heads_local, (B + kMqQueries - 1) / kMqQueries), dim3(kAttnBlock), attn_mq_lds_bytes(d.max_seq_len, hs), st, aa, pos, dim, B);
+        else
+            hipLaunchKernelGGL(k_attn_prefill, dim3(c->heads_local, B), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, hs), st, aa, pos, dim);
         HIPC(c, hipGetLastError());
         // x1 += Wo quantize(att)   (transformer.cpp:138-139, 457-466)
         RowsArgs rq{c->pf_att, nullptr, c->pf_xq, c->pf_xs, dim};
@@ -781,6 +785,7 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (k == "use_prefill") c->use_prefill = value;
     else if (k == "use_mfma") c->use_mfma = value;
     else if (k == "fuse_attn_o") c->fuse_attn_o = value;
+    else if (k == "use_prefill_mq") c->use_prefill_mq = value;
     else if (k == "trace") {        // value = kernel class to trace (KC_*), -1 off; meaningful in FLM_ABLATE builds only
         c->trace_class = value;
         if (!c->trace) { HIPC(c, hipMalloc((void**)&c->trace, 4096 * 8 * 8)); }
