@@ -83,7 +83,12 @@ __global__ void __launch_bounds__(256) k_gemm_q(const GemmArgs a) {
     __shared__ float sWt[2][64], sXt[2][64];
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
     const int ntt = (a.B + 63) / 64;
-    const int r0 = (blockIdx.x / ntt) * 64, b0 = (blockIdx.x % ntt) * 64;   // token tile fastest: neighbours share the weight rows
+    // token tile fastest: the ntt tiles that share 64 weight rows are neighbours in the LOGICAL order -- and workgroup b runs on XCD
+    // b mod 8 with its own L2, so the logical order is dealt to the XCDs in contiguous runs: the weight rows are then fetched from HBM
+    // once per XCD that needs them instead of once per token tile (8x the traffic at 512 tokens)
+    const int nb = gridDim.x, per = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7;
+    const int tile = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
+    const int r0 = (tile / ntt) * 64, b0 = (tile % ntt) * 64;
     const int sn = a.n / kGroup;
     const size_t rowbytes = (size_t)a.n * T::kEsz;
     const char* Wb = reinterpret_cast<const char*>(a.W);
@@ -177,34 +182,49 @@ __global__ void __launch_bounds__(256) k_gemm_q8_mfma(const GemmArgs a) {
     __shared__ float sXt[2][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntt = (a.B + 63) / 64;
-    const int r0 = (blockIdx.x / ntt) * 64, b0 = (blockIdx.x % ntt) * 64;   // token tile fastest: neighbours share the weight rows
+    // token tile fastest: the ntt tiles that share 64 weight rows are neighbours in the LOGICAL order -- and workgroup b runs on XCD
+    // b mod 8 with its own L2, so the logical order is dealt to the XCDs in contiguous runs: the weight rows are then fetched from HBM
+    // once per XCD that needs them instead of once per token tile (8x the traffic at 512 tokens)
+    const int nb = gridDim.x, per = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7;
+    const int tile = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
+    const int r0 = (tile / ntt) * 64, b0 = (tile % ntt) * 64;
     const int wr0 = (wave >> 1) * 32, wc0 = (wave & 1) * 32;                // this wave's quadrant inside the tile
     const int sn = a.n / kGroup;
     const size_t rowbytes = (size_t)a.n;
     const char* Wb = reinterpret_cast<const char*>(a.W);
     const char* Xb = reinterpret_cast<const char*>(a.Xq);
-    v4i wr, xr; float sr = 0.f;
+    // A tile's iteration (one quant group: 2 MFMAs + 16 chain steps per lane) takes ~0.1 us, a global load ~1-2 us: the loads run
+    // kPF groups ahead through a register ring (one group of look-ahead left the kernel latency-bound at a quarter of its VALU rate)
+    constexpr int kPF = 4;
+    v4i wr[kPF], xr[kPF]; float sr[kPF];
     const int lrow = tid >> 2, lch = tid & 3;                               // loader: 64 rows x 4 chunks of 16 B
-    auto fetch = [&](int g) {
-        wr = (r0 + lrow < a.rows) ? *reinterpret_cast<const v4i*>(Wb + (size_t)(r0 + lrow) * rowbytes + (size_t)g * GB + lch * 16) : v4i{0, 0, 0, 0};
-        xr = (b0 + lrow < a.B)    ? *reinterpret_cast<const v4i*>(Xb + (size_t)(b0 + lrow) * rowbytes + (size_t)g * GB + lch * 16) : v4i{0, 0, 0, 0};
-        if (tid < 64) sr = (r0 + tid < a.rows) ? a.sW[(size_t)(r0 + tid) * sn + g] : 0.f;
-        else if (tid < 128) sr = (b0 + tid - 64 < a.B) ? a.Xs[(size_t)(b0 + tid - 64) * sn + g] : 0.f;
+    const bool wok = r0 + lrow < a.rows, xok = b0 + lrow < a.B;
+    const char* wsrc = Wb + (size_t)(r0 + lrow) * rowbytes + lch * 16;
+    const char* xsrc = Xb + (size_t)(b0 + lrow) * rowbytes + lch * 16;
+    const float* ssrc = tid < 64 ? a.sW + (size_t)(r0 + tid) * sn : a.Xs + (size_t)(b0 + tid - 64) * sn;
+    const bool sok = tid < 64 ? (r0 + tid < a.rows) : (tid < 128 && b0 + tid - 64 < a.B);
+    auto fetch = [&](int g, int slot) {
+        const bool in = g < sn;
+        wr[slot] = (in && wok) ? *reinterpret_cast<const v4i*>(wsrc + (size_t)g * GB) : v4i{0, 0, 0, 0};
+        xr[slot] = (in && xok) ? *reinterpret_cast<const v4i*>(xsrc + (size_t)g * GB) : v4i{0, 0, 0, 0};
+        sr[slot] = (in && sok) ? ssrc[g] : 0.f;
     };
-    auto park = [&](int buf) {
-        *reinterpret_cast<v4i*>(&Wt[buf][lrow * LS + lch * 16]) = wr;
-        *reinterpret_cast<v4i*>(&Xt[buf][lrow * LS + lch * 16]) = xr;
-        if (tid < 64) sWt[buf][tid] = sr; else if (tid < 128) sXt[buf][tid - 64] = sr;
+    auto park = [&](int buf, int slot) {
+        *reinterpret_cast<v4i*>(&Wt[buf][lrow * LS + lch * 16]) = wr[slot];
+        *reinterpret_cast<v4i*>(&Xt[buf][lrow * LS + lch * 16]) = xr[slot];
+        if (tid < 64) sWt[buf][tid] = sr[slot]; else if (tid < 128) sXt[buf][tid - 64] = sr[slot];
     };
     float acc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     const int am = wr0 + (lane & 31), bn = wc0 + (lane & 31), kh = (lane >> 5) * 16;
-    fetch(0); park(0);
+#pragma unroll
+    for (int u = 0; u < kPF; ++u) fetch(u, u);
+    park(0, 0);
+    fetch(kPF, 0);
     __syncthreads();
-    for (int g = 0; g < sn; ++g) {
+    auto step = [&](int g, int next_slot) {                                 // group g is in LDS buffer g & 1; group g + 1 waits in ring slot next_slot
         const int buf = g & 1;
-        if (g + 1 < sn) fetch(g + 1);
         const v4i a0 = *reinterpret_cast<const v4i*>(&Wt[buf][am * LS + kh]), a1 = *reinterpret_cast<const v4i*>(&Wt[buf][am * LS + 32 + kh]);
         const v4i x0 = *reinterpret_cast<const v4i*>(&Xt[buf][bn * LS + kh]), x1 = *reinterpret_cast<const v4i*>(&Xt[buf][bn * LS + 32 + kh]);
         v16i d = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -219,8 +239,14 @@ __global__ void __launch_bounds__(256) k_gemm_q8_mfma(const GemmArgs a) {
             acc[4 * q + 2] = __fmaf_rn(__fmul_rn(sw.z, sx), (float)d[4 * q + 2], acc[4 * q + 2]);
             acc[4 * q + 3] = __fmaf_rn(__fmul_rn(sw.w, sx), (float)d[4 * q + 3], acc[4 * q + 3]);
         }
-        if (g + 1 < sn) park(buf ^ 1);
+        if (g + 1 < sn) { park(buf ^ 1, next_slot); fetch(g + 1 + kPF, next_slot); }
         __syncthreads();
+    };
+    for (int g = 0; g < sn; g += kPF) {                                     // (ring slots are compile-time indices)
+        step(g, 1);
+        if (g + 1 < sn) step(g + 1, 2);
+        if (g + 2 < sn) step(g + 2, 3);
+        if (g + 3 < sn) step(g + 3, 0);
     }
     const int b = b0 + bn;
     if (b < a.B) {
