@@ -339,7 +339,6 @@ __device__ __forceinline__ void attn_prefill_mq(const AttnArgs& a, const int h, 
         for (int t = lane; t < T; t += 64) m = fmaxf(m, row[t]);
         m = wave_max(m);
         for (int t = lane; t < T; t += 64) row[t] = expf_ref(__fsub_rn(row[t], m));
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                  // (LDS writes of the other lanes before lane 0's reads: same wave, in order)
         float sum = 0.f;
         if (lane == 0) {                                                        // T dependent adds; the LDS reads run 16 elements ahead
             int t = 0;
@@ -428,7 +427,7 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_attn_o(const AttnArgs aa, con
     if ((int)blockIdx.x < n_heads) {
         attn_head_any<false>(aa, blockIdx.x, lds, *aa.pos_ptr + 1, aa.q, aa.out);
         stamp(1);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                  // this wave's stores have completed
+        wait_stores_done();                                                     // every wave: its part of the head's output is where the others will read it
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(flag + blockIdx.x * kFlagStride, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         stamp(4);

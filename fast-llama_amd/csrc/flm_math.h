@@ -159,6 +159,10 @@ __device__ __forceinline__ void rope_pair(float x0, float x1, float c, float s, 
 // are served coherently (sc1) -- so a grid barrier needs no L2 write-back / invalidate, only 'my stores have completed'.
 __device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// "My global stores have COMPLETED" (written through to where other workgroups read them): the vector-memory counter at zero.
+// A workgroup-scope release fence is NOT that -- the compiler emits only s_waitcnt lgkmcnt(0) for it (one CU, one L1: nothing
+// to wait for inside a workgroup), and a flag raised by another wave of the workgroup could then overtake the data.
+__device__ __forceinline__ void wait_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 constexpr int kAuxCoherent = 17;      // raw buffer load cache policy: sc0 | sc1 (gfx940+ encoding of the aux operand)
 
 typedef int v4i __attribute__((ext_vector_type(4)));      // native vector: usable with __builtin_nontemporal_load

@@ -182,7 +182,7 @@ __device__ __attribute__((noinline)) void token_phase(const TokenArgs& t, const 
     // the phase's first weight loads; activation waves wait until they have asked for the activation
     auto prefetch = [&]() { g.init(a, wg, nwg, lds); if (wave >= kActWaves) g.issue(a.ablate); };
     // my stores of the previous phase must have completed before the prefetch is queued behind them (one vmcnt counter)
-    if (ts.stored) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (ts.stored) wait_stores_done();
     if constexpr (ATTN) {
         const bool attn_wg = (int)wg < t.n_heads;                               // this workgroup runs attention heads next
         if (!attn_wg) prefetch();                                               // (a head's K/V loads must not queue behind weight loads)
@@ -190,7 +190,7 @@ __device__ __attribute__((noinline)) void token_phase(const TokenArgs& t, const 
         if (attn_wg) {   // one head per workgroup
             const AttnArgs aa = kload(aap);
             for (int h = wg; h < t.n_heads; h += nwg) attn_head_any<true>(aa, h, lds, *aa.pos_ptr + 1, aa.q, aa.out);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            wait_stores_done();
             prefetch();
         }
         stamp(1);
