@@ -1,0 +1,32 @@
+"""hand-off stress: long greedy decodes on a 7B-width model with the fused / persistent kernels against one launch per phase;
+any stale cross-workgroup read changes the token ids.  python tools/stress.py [layers] [tokens] [reps]"""
+import sys, os
+sys.path.insert(0, os.getcwd())
+import numpy as np
+import __graft_entry__ as g; g.load_package()
+from fast_llama_amd import capi, synth, flmfile as ff
+L = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+bad = 0
+for qt, name in ((ff.QT_INT8, "int8"), (ff.QT_INT16, "int16")):
+    cfg = synth.make_config("7B", qt); cfg.n_layers = L
+    tensors = synth.make_tensors(cfg, seed=3, share_layers=True)
+    prompt = (np.arange(1, 9, dtype=np.int64) * 7919 % cfg.vocab_size).astype(np.int32)
+    ref = None
+    for opts in ({"fuse_attn_o": 0}, {}, {"use_graph": 0}, {"use_mega": 1}):
+        ctx = capi.Ctx(capi.desc_from_config(cfg)); ctx.upload_all(tensors)
+        for k, v in opts.items(): ctx.set_option(k, v)
+        for r in range(reps if opts != {"fuse_attn_o": 0} else 1):
+            ctx.reset_kv()
+            first = ctx.forward_argmax(prompt, 0)
+            ids = [first] + list(ctx.decode_greedy(first, len(prompt), n))
+            if ref is None: ref = ids
+            ok = ids == ref
+            if not ok:
+                bad += 1
+                k = next(i for i, (a, b) in enumerate(zip(ids, ref)) if a != b)
+                print(f"{name} {opts} rep {r}: MISMATCH at generated token {k}")
+        print(f"{name} {opts}: done", flush=True)
+        ctx.close()
+print("stress:", "FAILED" if bad else "ok")
