@@ -171,48 +171,67 @@ __global__ void __launch_bounds__(256) k_gemm_q(const GemmArgs a) {
 // (integer sums are order-free; A and B use the same byte -> k assignment: lane half h takes bytes 32kk + 16h .. +15 of the
 // group); then every lane applies the reference's fp32 chain step to its 16 results -- that VALU work, not the MFMA, is what
 // bounds the kernel.  C/D layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+// NW = waves per tile side: 2 -> the 64 x 64 tile (256 threads), 4 -> a 128 x 128 tile (1024 threads) for batches of more than 64
+// tokens: a workgroup iteration then loads 16 KB for four times the products (the 64 x 64 tile pulls 8 KB per iteration through a
+// CU's ~30 KB/us memory pipeline, which -- not the VALU -- bounded it at 35 % of the VALU rate).
 typedef int v16i __attribute__((ext_vector_type(16)));
-template <int EPI>
-__global__ void __launch_bounds__(256) k_gemm_q8_mfma(const GemmArgs a) {
+template <int EPI, int NW>
+__global__ void __launch_bounds__(64 * NW * NW) k_gemm_q8_mfma(const GemmArgs a) {
     constexpr int GB = kGroup;                    // bytes of a group in one row (int8)
     constexpr int LS = GB + 16;                   // LDS row stride
-    __shared__ __attribute__((aligned(16))) char Wt[2][64 * LS];
-    __shared__ __attribute__((aligned(16))) char Xt[2][64 * LS];
-    __shared__ __attribute__((aligned(16))) float sWt[2][64];
-    __shared__ float sXt[2][64];
+    constexpr int TS = 32 * NW;                   // tile side
+    constexpr int NT = 64 * NW * NW;              // threads
+    __shared__ __attribute__((aligned(16))) char Wt[2][TS * LS];
+    __shared__ __attribute__((aligned(16))) char Xt[2][TS * LS];
+    __shared__ __attribute__((aligned(16))) float sWt[2][TS];
+    __shared__ float sXt[2][TS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ntt = (a.B + 63) / 64;
-    // token tile fastest: the ntt tiles that share 64 weight rows are neighbours in the LOGICAL order -- and workgroup b runs on XCD
+    const int ntt = (a.B + TS - 1) / TS;
+    // token tile fastest: the ntt tiles that share the weight rows are neighbours in the LOGICAL order -- and workgroup b runs on XCD
     // b mod 8 with its own L2, so the logical order is dealt to the XCDs in contiguous runs: the weight rows are then fetched from HBM
-    // once per XCD that needs them instead of once per token tile (8x the traffic at 512 tokens)
+    // once per XCD that needs them instead of once per token tile
     const int nb = gridDim.x, per = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7;
     const int tile = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
-    const int r0 = (tile / ntt) * 64, b0 = (tile % ntt) * 64;
-    const int wr0 = (wave >> 1) * 32, wc0 = (wave & 1) * 32;                // this wave's quadrant inside the tile
+    const int r0 = (tile / ntt) * TS, b0 = (tile % ntt) * TS;
+    const int wr0 = (wave / NW) * 32, wc0 = (wave % NW) * 32;               // this wave's 32 x 32 inside the tile
     const int sn = a.n / kGroup;
     const size_t rowbytes = (size_t)a.n;
     const char* Wb = reinterpret_cast<const char*>(a.W);
     const char* Xb = reinterpret_cast<const char*>(a.Xq);
-    // A tile's iteration (one quant group: 2 MFMAs + 16 chain steps per lane) takes ~0.1 us, a global load ~1-2 us: the loads run
-    // kPF groups ahead through a register ring (one group of look-ahead left the kernel latency-bound at a quarter of its VALU rate)
+    // An iteration (one quant group: 2 MFMAs + 16 chain steps per lane) takes ~0.1 us, a global load ~1-2 us: the loads run
+    // kPF groups ahead through a register ring
     constexpr int kPF = 4;
-    v4i wr[kPF], xr[kPF]; float sr[kPF];
-    const int lrow = tid >> 2, lch = tid & 3;                               // loader: 64 rows x 4 chunks of 16 B
-    const bool wok = r0 + lrow < a.rows, xok = b0 + lrow < a.B;
+    // loader: TS rows x 4 chunks of 16 B for the weights and as many for the activations.  NW == 2: every thread loads one piece of
+    // each; NW == 4: threads 0..511 load weights, 512..1023 activations
+    constexpr bool kSplit = NW == 4;
+    const bool ldw = !kSplit || tid < NT / 2, ldx = !kSplit || tid >= NT / 2;
+    const int lt = kSplit ? (tid & (NT / 2 - 1)) : tid;
+    const int lrow = lt >> 2, lch = lt & 3;
+    v4i wr[kPF], xr[kSplit ? 1 : kPF]; float sr[kPF];
+    const bool wok = ldw && r0 + lrow < a.rows, xok = ldx && b0 + lrow < a.B;
     const char* wsrc = Wb + (size_t)(r0 + lrow) * rowbytes + lch * 16;
     const char* xsrc = Xb + (size_t)(b0 + lrow) * rowbytes + lch * 16;
-    const float* ssrc = tid < 64 ? a.sW + (size_t)(r0 + tid) * sn : a.Xs + (size_t)(b0 + tid - 64) * sn;
-    const bool sok = tid < 64 ? (r0 + tid < a.rows) : (tid < 128 && b0 + tid - 64 < a.B);
+    const float* ssrc = tid < TS ? a.sW + (size_t)(r0 + tid) * sn : a.Xs + (size_t)(b0 + tid - TS) * sn;
+    const bool sok = tid < TS ? (r0 + tid < a.rows) : (tid < 2 * TS && b0 + tid - TS < a.B);
     auto fetch = [&](int g, int slot) {
         const bool in = g < sn;
-        wr[slot] = (in && wok) ? *reinterpret_cast<const v4i*>(wsrc + (size_t)g * GB) : v4i{0, 0, 0, 0};
-        xr[slot] = (in && xok) ? *reinterpret_cast<const v4i*>(xsrc + (size_t)g * GB) : v4i{0, 0, 0, 0};
+        if constexpr (kSplit) {   // one register per slot: a weight piece or an activation piece
+            wr[slot] = (in && wok) ? *reinterpret_cast<const v4i*>(wsrc + (size_t)g * GB) : (in && xok) ? *reinterpret_cast<const v4i*>(xsrc + (size_t)g * GB) : v4i{0, 0, 0, 0};
+        } else {
+            wr[slot] = (in && wok) ? *reinterpret_cast<const v4i*>(wsrc + (size_t)g * GB) : v4i{0, 0, 0, 0};
+            xr[slot] = (in && xok) ? *reinterpret_cast<const v4i*>(xsrc + (size_t)g * GB) : v4i{0, 0, 0, 0};
+        }
         sr[slot] = (in && sok) ? ssrc[g] : 0.f;
     };
     auto park = [&](int buf, int slot) {
-        *reinterpret_cast<v4i*>(&Wt[buf][lrow * LS + lch * 16]) = wr[slot];
-        *reinterpret_cast<v4i*>(&Xt[buf][lrow * LS + lch * 16]) = xr[slot];
-        if (tid < 64) sWt[buf][tid] = sr[slot]; else if (tid < 128) sXt[buf][tid - 64] = sr[slot];
+        if constexpr (kSplit) {
+            char* dst = ldw ? &Wt[buf][lrow * LS + lch * 16] : &Xt[buf][lrow * LS + lch * 16];
+            *reinterpret_cast<v4i*>(dst) = wr[slot];
+        } else {
+            *reinterpret_cast<v4i*>(&Wt[buf][lrow * LS + lch * 16]) = wr[slot];
+            *reinterpret_cast<v4i*>(&Xt[buf][lrow * LS + lch * 16]) = xr[slot];
+        }
+        if (tid < TS) sWt[buf][tid] = sr[slot]; else if (tid < 2 * TS) sXt[buf][tid - TS] = sr[slot];
     };
     float acc[16];
 #pragma unroll
