@@ -176,6 +176,29 @@ def test_fused_attention_decode_over_the_whole_context_matches_two_launches(gpu)
     assert bits_equal(res[0][2], res[1][2])
 
 
+def test_cross_workgroup_handoff_is_stable(gpu):
+    """the fused attention + Wo launch hands the heads' output to the GEMV workgroups inside one kernel.  100 replays of a 5-token
+    prompt fed token by token plus three more tokens (int16, 7B width: the configuration in which a hand-off that did not wait for the
+    heads' stores failed about one replay in fifty) must give the same logits bits every time (tools/stress2.py runs more)."""
+    cfg = synth.make_config("7B", ff.QT_INT16); cfg.n_layers = 1
+    tensors = synth.make_tensors(cfg, seed=31)
+    prompt = _prompt(cfg.vocab_size, 5)
+    ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
+    ctx.set_option("use_prefill", 0)
+    ref = None
+    for rep in range(100):
+        ctx.reset_kv()
+        out = [ctx.forward(prompt, 0).copy()]
+        cur, pos = int(np.argmax(out[0])), len(prompt)
+        for _ in range(3):
+            out.append(ctx.forward(np.array([cur], np.int32), pos).copy()); cur = int(np.argmax(out[-1])); pos += 1
+        if ref is None:
+            ref = out
+        for i, (a, b) in enumerate(zip(out, ref)):
+            assert bits_equal(a, b), f"replay {rep}, forward {i}"
+    ctx.close()
+
+
 def test_errors(gpu):
     cfg = synth.make_config("tiny", ff.QT_INT8)
     d = gpu.desc_from_config(cfg)
