@@ -562,8 +562,8 @@ template <int QT, int EPI>
 int launch_gemm(flm_ctx* c, hipStream_t st, const GemmArgs& g) {
     const int tiles = ((g.rows + 63) / 64) * ((g.B + 63) / 64);
     if (QT == QT_INT8 && c->use_mfma) {   // matrix cores: exact int32 group dots
-        if (g.B >= 384 && c->use_mfma != 2) {   // 128 x 128 tiles: half the bytes per product through the CU's memory pipeline; pays from ~3 token tiles on
-                                                  // (measured: 1000 tokens -7 %, 512 tokens even, 128 tokens +19 % -- too few workgroups); "use_mfma" 2: 64 x 64 always
+        if (g.B >= 768 && c->use_mfma != 2) {   // 128 x 128 tiles: half the bytes per product through the CU's memory pipeline; pays for long prompts only
+                                                  // (measured, 4 layers of 7B width: 1000 tokens 5.99 vs 6.49 ms, 512 tokens 3.33 vs 3.05 ms); "use_mfma" 2: 64 x 64 always
             const int tiles128 = ((g.rows + 127) / 128) * ((g.B + 127) / 128);
             hipLaunchKernelGGL((k_gemm_q8_mfma<EPI, 4>), dim3(tiles128), dim3(1024), 0, st, g);
         } else hipLaunchKernelGGL((k_gemm_q8_mfma<EPI, 2>), dim3(tiles), dim3(256), 0, st, g);

@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(64 * NW * NW) k_gemm_q8_mfma(const GemmArgs a)
     const char* Xb = reinterpret_cast<const char*>(a.Xq);
     // An iteration (one quant group: 2 MFMAs + 16 chain steps per lane) takes ~0.1 us, a global load ~1-2 us: the loads run
     // kPF groups ahead through a register ring
-    constexpr int kPF = 4;
+    constexpr int kPF = NW == 4 ? 2 : 4;          // (the 16-wave tile has 128 registers per lane: a 4-deep ring spills)
     // loader: TS rows x 4 chunks of 16 B for the weights and as many for the activations.  NW == 2: every thread loads one piece of
     // each; NW == 4: threads 0..511 load weights, 512..1023 activations
     constexpr bool kSplit = NW == 4;
@@ -208,20 +208,29 @@ __global__ void __launch_bounds__(64 * NW * NW) k_gemm_q8_mfma(const GemmArgs a)
     const int lt = kSplit ? (tid & (NT / 2 - 1)) : tid;
     const int lrow = lt >> 2, lch = lt & 3;
     v4i wr[kPF], xr[kSplit ? 1 : kPF]; float sr[kPF];
+    // branch-free raw buffer loads (pieces outside the matrix / past the last group get an out-of-range offset and read as zero):
+    // with the loads under control flow the compiler waited for vmcnt(0) in every iteration, i.e. for the load it had just issued
+    constexpr unsigned kOOB = 0x80000000u;
+    const unsigned nW = (unsigned)a.rows * (unsigned)rowbytes, nX = (unsigned)a.B * (unsigned)rowbytes;
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Wb), 0, (int)nW, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Xb), 0, (int)nX, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rSW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.sW), 0, (int)((unsigned)a.rows * sn * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rSX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Xs), 0, (int)((unsigned)a.B * sn * 4), 0x00020000);
     const bool wok = ldw && r0 + lrow < a.rows, xok = ldx && b0 + lrow < a.B;
-    const char* wsrc = Wb + (size_t)(r0 + lrow) * rowbytes + lch * 16;
-    const char* xsrc = Xb + (size_t)(b0 + lrow) * rowbytes + lch * 16;
-    const float* ssrc = tid < TS ? a.sW + (size_t)(r0 + tid) * sn : a.Xs + (size_t)(b0 + tid - TS) * sn;
-    const bool sok = tid < TS ? (r0 + tid < a.rows) : (tid < 2 * TS && b0 + tid - TS < a.B);
+    const unsigned woff = wok ? (unsigned)(r0 + lrow) * (unsigned)rowbytes + lch * 16 : kOOB;
+    const unsigned xoff = xok ? (unsigned)(b0 + lrow) * (unsigned)rowbytes + lch * 16 : kOOB;
+    const bool s_w = tid < TS, s_x = tid >= TS && tid < 2 * TS;
+    const unsigned swoff = (s_w && r0 + tid < a.rows) ? (unsigned)(r0 + tid) * sn * 4 : kOOB;
+    const unsigned sxoff = (s_x && b0 + tid - TS < a.B) ? (unsigned)(b0 + tid - TS) * sn * 4 : kOOB;
     auto fetch = [&](int g, int slot) {
         const bool in = g < sn;
-        if constexpr (kSplit) {   // one register per slot: a weight piece or an activation piece
-            wr[slot] = (in && wok) ? *reinterpret_cast<const v4i*>(wsrc + (size_t)g * GB) : (in && xok) ? *reinterpret_cast<const v4i*>(xsrc + (size_t)g * GB) : v4i{0, 0, 0, 0};
-        } else {
-            wr[slot] = (in && wok) ? *reinterpret_cast<const v4i*>(wsrc + (size_t)g * GB) : v4i{0, 0, 0, 0};
-            xr[slot] = (in && xok) ? *reinterpret_cast<const v4i*>(xsrc + (size_t)g * GB) : v4i{0, 0, 0, 0};
-        }
-        sr[slot] = (in && sok) ? ssrc[g] : 0.f;
+        const unsigned wo = (in && woff != kOOB) ? woff + (unsigned)g * GB : kOOB, xo = (in && xoff != kOOB) ? xoff + (unsigned)g * GB : kOOB;
+        const unsigned so = (in && swoff != kOOB) ? swoff + (unsigned)g * 4 : kOOB, sxo = (in && sxoff != kOOB) ? sxoff + (unsigned)g * 4 : kOOB;
+        const v4u w = __builtin_amdgcn_raw_buffer_load_b128(rW, (int)wo, 0, 0);
+        const v4u x = __builtin_amdgcn_raw_buffer_load_b128(rX, (int)xo, 0, 0);
+        if constexpr (kSplit) wr[slot] = __builtin_bit_cast(v4i, ldw ? w : x);       // one register per slot: a weight piece or an activation piece (the other load is out of range)
+        else { wr[slot] = __builtin_bit_cast(v4i, w); xr[slot] = __builtin_bit_cast(v4i, x); }
+        sr[slot] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rSW, (int)so, 0, 0) | __builtin_amdgcn_raw_buffer_load_b32(rSX, (int)sxo, 0, 0));
     };
     auto park = [&](int buf, int slot) {
         if constexpr (kSplit) {
@@ -258,15 +267,13 @@ __global__ void __launch_bounds__(64 * NW * NW) k_gemm_q8_mfma(const GemmArgs a)
             acc[4 * q + 2] = __fmaf_rn(__fmul_rn(sw.z, sx), (float)d[4 * q + 2], acc[4 * q + 2]);
             acc[4 * q + 3] = __fmaf_rn(__fmul_rn(sw.w, sx), (float)d[4 * q + 3], acc[4 * q + 3]);
         }
-        if (g + 1 < sn) { park(buf ^ 1, next_slot); fetch(g + 1 + kPF, next_slot); }
-        __syncthreads();
+        park(buf ^ 1, next_slot); fetch(g + 1 + kPF, next_slot);           // unconditional (groups past the end are zeros): under a branch the
+        __syncthreads();                                                    // compiler loses count of the loads in flight and waits for all of them
     };
-    for (int g = 0; g < sn; g += kPF) {                                     // (ring slots are compile-time indices)
-        step(g, 1);
-        if (g + 1 < sn) step(g + 1, 2);
-        if (g + 2 < sn) step(g + 2, 3);
-        if (g + 3 < sn) step(g + 3, 0);
-    }
+    // ring slots are compile-time indices; the group count is rounded up to a multiple of kPF -- a group past the end contributes
+    // fma(0, 0, acc) = acc (acc is never -0: it starts at +0 and every product s * float(dot) with dot == 0 is +0)
+    if constexpr (kPF == 4) { for (int g = 0; g < sn; g += 4) { step(g, 1); step(g + 1, 2); step(g + 2, 3); step(g + 3, 0); } }
+    else                    { for (int g = 0; g < sn; g += 2) { step(g, 1); step(g + 1, 0); } }
     const int b = b0 + bn;
     if (b < a.B) {
 #pragma unroll
