@@ -94,15 +94,31 @@ __global__ void __launch_bounds__(256) k_gemm_q(const GemmArgs a) {
     const char* Wb = reinterpret_cast<const char*>(a.W);
     const char* Xb = reinterpret_cast<const char*>(a.Xq);
     v4i wr[NLD], xr[NLD]; float sr = 0.f;
+    // branch-free raw buffer loads (rows outside the matrix / groups past the end: out-of-range offset, zeros): under control flow the
+    // compiler waits for vmcnt(0) in every iteration
+    constexpr unsigned kOOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Wb), 0, (int)((unsigned)a.rows * (unsigned)rowbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Xb), 0, (int)((unsigned)a.B * (unsigned)rowbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rSW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.sW), 0, (int)((unsigned)a.rows * sn * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rSX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Xs), 0, (int)((unsigned)a.B * sn * 4), 0x00020000);
+    unsigned woff[NLD], xoff[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int idx = tid + k * 256, row = idx / NCH, ch = idx % NCH;
+        woff[k] = (r0 + row < a.rows) ? (unsigned)(r0 + row) * (unsigned)rowbytes + ch * 16 : kOOB;
+        xoff[k] = (b0 + row < a.B)    ? (unsigned)(b0 + row) * (unsigned)rowbytes + ch * 16 : kOOB;
+    }
+    const unsigned swoff = (tid < 64 && r0 + tid < a.rows) ? (unsigned)(r0 + tid) * sn * 4 : kOOB;
+    const unsigned sxoff = (tid >= 64 && tid < 128 && b0 + tid - 64 < a.B) ? (unsigned)(b0 + tid - 64) * sn * 4 : kOOB;
     auto fetch = [&](int g) {
+        const bool in = g < sn;
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
-            const int idx = tid + k * 256, row = idx / NCH, ch = idx % NCH;
-            wr[k] = (r0 + row < a.rows) ? *reinterpret_cast<const v4i*>(Wb + (size_t)(r0 + row) * rowbytes + (size_t)g * GB + ch * 16) : v4i{0, 0, 0, 0};
-            xr[k] = (b0 + row < a.B)    ? *reinterpret_cast<const v4i*>(Xb + (size_t)(b0 + row) * rowbytes + (size_t)g * GB + ch * 16) : v4i{0, 0, 0, 0};
+            wr[k] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rW, (int)((in && woff[k] != kOOB) ? woff[k] + (unsigned)g * GB : kOOB), 0, 0));
+            xr[k] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rX, (int)((in && xoff[k] != kOOB) ? xoff[k] + (unsigned)g * GB : kOOB), 0, 0));
         }
-        if (tid < 64) sr = (r0 + tid < a.rows) ? a.sW[(size_t)(r0 + tid) * sn + g] : 0.f;
-        else if (tid < 128) sr = (b0 + tid - 64 < a.B) ? a.Xs[(size_t)(b0 + tid - 64) * sn + g] : 0.f;
+        sr = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rSW, (int)((in && swoff != kOOB) ? swoff + (unsigned)g * 4 : kOOB), 0, 0)
+                           | __builtin_amdgcn_raw_buffer_load_b32(rSX, (int)((in && sxoff != kOOB) ? sxoff + (unsigned)g * 4 : kOOB), 0, 0));
     };
     auto park = [&](int buf) {
 #pragma unroll
@@ -122,7 +138,7 @@ __global__ void __launch_bounds__(256) k_gemm_q(const GemmArgs a) {
     __syncthreads();
     for (int g = 0; g < sn; ++g) {
         const int buf = g & 1;
-        if (g + 1 < sn) fetch(g + 1);
+        fetch(g + 1);                                                         // (past the end: zeros, never parked)
         int d[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -149,7 +165,7 @@ __global__ void __launch_bounds__(256) k_gemm_q(const GemmArgs a) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __fmaf_rn(__fmul_rn(sw[i], sx[j]), (float)d[i][j], acc[i][j]);   // quant_operators.cpp:274
-        if (g + 1 < sn) park(buf ^ 1);
+        park(buf ^ 1);                                                        // (unconditional: the last one parks zeros)
         __syncthreads();
     }
 #pragma unroll
