@@ -94,11 +94,16 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
         for (int j = 0; j < NF; ++j)
             if (prow[j] < kAttnTile) *reinterpret_cast<float4*>(buf + loff[j]) = make_float4(reg[j].x, reg[j].y, reg[j].z, reg[j].w);
     };
+    // q first: loads return in issue order, and q requested behind the K and V tiles would arrive behind 4 tiles of data
+    float qv[NF * 64 / kAttnBlock + 1];
+#pragma unroll
+    for (int i = 0; i < NF * 64 / kAttnBlock + 1; ++i) { const int d = tid + i * kAttnBlock; qv[i] = d < hs ? (COH ? ld_agent(qrow + (size_t)h * hs + d) : qrow[(size_t)h * hs + d]) : 0.f; }
 #pragma unroll
     for (int u = 0; u < D; ++u) request(rK, u, ringK[u]);
 #pragma unroll
     for (int u = 0; u < D; ++u) request(rV, u, ringV[u]);
-    for (int d = tid; d < hs; d += kAttnBlock) qs[d] = COH ? ld_agent(qrow + (size_t)h * hs + d) : qrow[(size_t)h * hs + d];
+#pragma unroll
+    for (int i = 0; i < NF * 64 / kAttnBlock + 1; ++i) { const int d = tid + i * kAttnBlock; if (d < hs) qs[d] = qv[i]; }
 
     // ---- scores: lane = (position p, strided accumulator k) -- the 8 lanes of dot_product_avx256; each lane's
     //      chain is i ascending, then the 8 partials are added 0..7 (lane k = 0 collects them with DPP row shifts).
