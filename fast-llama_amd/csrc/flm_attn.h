@@ -107,17 +107,18 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
 
     // ---- scores: lane = (position p, strided accumulator k) -- the 8 lanes of dot_product_avx256; each lane's
     //      chain is i ascending, then the 8 partials are added 0..7 (lane k = 0 collects them with DPP row shifts).
+    // (no early exit from the unrolled tile loops: with a break inside them the compiler loses count of the loads in flight and
+    //  waits for nearly all of them -- the V tiles included -- before the first K tile is parked.  A tile past the end is zeros.)
     float lmax = -INFINITY;
     for (int base = 0; base < nt; base += D) {
 #pragma unroll
         for (int u = 0; u < D; ++u) {
             const int s = base + u;
-            if (s >= nt) break;                                     // (uniform)
             float* cur = (u & 1) ? tile1 : tile0;                   // D is even: tile parity == slot parity
             park(cur, ringK[u]);
             __syncthreads();
             request(rK, s + D, ringK[u]);
-            if (tid < kAttnTile * 8) {
+            if (s < nt && tid < kAttnTile * 8) {
                 const int p = tid >> 3, k = tid & 7, t = s * kAttnTile + p;
                 const float* kp = cur + p * rs + k;
                 float l = 0.f;
@@ -188,12 +189,11 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
 #pragma unroll
         for (int u = 0; u < D; ++u) {
             const int i = base + u;
-            if (i >= nt) break;                                     // (uniform)
             float* cur = (u & 1) ? tile1 : tile0;
             park(cur, ringV[u]);
             __syncthreads();
             request(rV, i + D, ringV[u]);
-            if (tid < hs) {
+            if (i < nt && tid < hs) {
                 const float* vp = cur + tid;
                 const float* wp = sc + i * kAttnTile;
                 const int np = (T - i * kAttnTile) < kAttnTile ? (T - i * kAttnTile) : kAttnTile;
