@@ -122,7 +122,8 @@ int  flm_debug_read(flm_ctx* ctx, int what, int layer, float* out, size_t n);
 /* tuning knobs: "wg_per_cu" workgroups per CU for the GEMV kernels, "use_graph" hipGraph replay on/off,
  * "use_mega" 1 = run single-GPU tokens as one persistent kernel (k_token; experimental, default 0),
  * "fuse_attn_o" 0 = attention and the Wo GEMV as two launches (default 1: one launch, single GPU),
- * "use_prefill" 0 = feed prompts token by token (default 1: batched), "use_mfma" 0 = int8 prefill GEMM on v_dot4 instead of the matrix cores (default 1) */
+ * "use_prefill" 0 = feed prompts token by token (default 1: batched), "use_prefill_mq" 0 = batched attention with one query per
+ * workgroup (default 1: eight), "use_mfma" 0 = int8 prefill GEMM on v_dot4 instead of the matrix cores (default 1; 2 = matrix cores, 64 x 64 tiles always) */
 int  flm_set_option(flm_ctx* ctx, const char* key, int value);
 
 /* ---- op level: 1:1 mirrors of the reference operator seam, host pointers in / out, running the
