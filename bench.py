@@ -49,25 +49,48 @@ def token_bytes(cfg, pos, esz=1):
     return eq * esz + eq / 64 * 4 + (2 * L + 1) * dim * 4 + dim * 4 + 2 * L * kvd * 4 * (pos + 1)
 
 
-def upload_synthetic(ctx, cfg, seed=20260928, log_every=8):
-    """stream the synthetic checkpoint tensor by tensor (peak host RAM = one tensor)."""
+def upload_synthetic(ctx, cfg, log_every=8, threads=None):
+    """stream the PORTABLE synthetic checkpoint (fast_llama_amd/synth.py: every value a splitmix64 function of tensor id and
+    element index, norm weights 1.0 -- SURVEY.md 8d; the same tensors tests/golden/make_golden_r2.py fed to the reference)
+    tensor by tensor: a few generator threads run ahead of the upload, peak host RAM = a few tensors."""
+    from concurrent.futures import ThreadPoolExecutor
     from fast_llama_amd import flmfile as ff, synth
-    gs = cfg.quant_group_size
     t0 = time.time()
-    rng = np.random.default_rng(seed)
-    ctx.upload(ff.T_TOKEN_EMBD, 0, rng.standard_normal((cfg.vocab_size, cfg.dim), dtype=np.float32))
+    jobs = [((ff.T_TOKEN_EMBD, 0), lambda: synth.portable_embedding(cfg.vocab_size, cfg.dim))]
+    ones = np.ones(cfg.dim, np.float32)
     for l in range(cfg.n_layers):
-        lr = np.random.default_rng([seed, 1000 + l])
-        ctx.upload(ff.T_INPUT_NORM, l, (0.8 + 0.4 * lr.random(cfg.dim, dtype=np.float32)).astype(np.float32))
-        ctx.upload(ff.T_POST_NORM, l, (0.8 + 0.4 * lr.random(cfg.dim, dtype=np.float32)).astype(np.float32))
+        jobs.append(((ff.T_INPUT_NORM, l), lambda: ones)); jobs.append(((ff.T_POST_NORM, l), lambda: ones))
         for kind, (r, k) in synth.linear_shapes(cfg).items():
-            ctx.upload(kind, l, synth._qweights(lr, r, k, cfg.quant_type, gs))
-        if l % log_every == 0:
-            log(f"  uploaded layer {l}/{cfg.n_layers} ({time.time() - t0:.1f}s)")
-    fr = np.random.default_rng([seed, 999])
-    ctx.upload(ff.T_OUTPUT_NORM, 0, (0.8 + 0.4 * fr.random(cfg.dim, dtype=np.float32)).astype(np.float32))
-    ctx.upload(ff.T_CLASSIFIER, 0, synth._qweights(fr, cfg.vocab_size, cfg.dim, cfg.quant_type, gs))
+            jobs.append(((kind, l), lambda kind=kind, l=l, r=r, k=k: synth.portable_qweights(kind, l, r, k, cfg.quant_type)))
+    jobs.append(((ff.T_OUTPUT_NORM, 0), lambda: ones))
+    jobs.append(((ff.T_CLASSIFIER, 0), lambda: synth.portable_qweights(ff.T_CLASSIFIER, 0, cfg.vocab_size, cfg.dim, cfg.quant_type)))
+    nthreads = threads or max(1, min(16, (os.cpu_count() or 2) - 1))
+    with ThreadPoolExecutor(nthreads) as ex:
+        window, it = [], iter(jobs)
+        def push():
+            j = next(it, None)
+            if j is not None:
+                window.append((j[0], ex.submit(j[1])))
+        for _ in range(nthreads + 2):
+            push()
+        while window:
+            (kind, layer), fut = window.pop(0)
+            ctx.upload(kind, layer, fut.result())
+            push()
+            if kind == ff.T_MLP_DOWN and layer % log_every == 0:
+                log(f"  uploaded layer {layer}/{cfg.n_layers} ({time.time() - t0:.1f}s)")
     log(f"  synthetic checkpoint resident in HBM after {time.time() - t0:.1f}s")
+
+
+def golden_ids(cfg, qt, prompt_len):
+    """the reference's greedy ids for this exact model and prompt (tests/golden/model_7B_int8_L32.npz, produced by
+    tests/golden/make_golden_r2.py from oracle/_ref/libflref.so), or None when there is no fixture for the configuration"""
+    from fast_llama_amd import flmfile as ff
+    path = os.path.join(ROOT, "tests", "golden", "model_7B_int8_L32.npz")
+    if not (cfg.name.endswith("7B") and cfg.n_layers == 32 and qt == ff.QT_INT8 and prompt_len == 9 and os.path.exists(path)):
+        return None
+    g = np.load(path)
+    return [int(x) for x in g["ids"]]
 
 
 def host_cores():
@@ -197,6 +220,40 @@ def job_throughput(local_elapsed_s: float, steps: int, world: int, mode: str):
     return tokens / elapsed, elapsed
 
 
+def time_decode(ctx, cfg, args, prompt, barrier, gold):
+    """prompt (untimed) -> greedy decode up to the start position (untimed; at least W steps, which also capture the
+    hipGraphs) -> EXACTLY K timed steps between barriers -> the ids for the parity field, and a second pass with an event
+    per token for the median.  Returns a dict of measurements."""
+    import torch
+    first = ctx.forward_argmax(prompt, 0)
+    ids = [int(first)]
+    pos = len(prompt)
+    n_pre = max(args.warmup, (args.pos - pos) if args.pos is not None else 0)
+    if n_pre > 0:
+        pre = ctx.decode_greedy(first, pos, n_pre)
+        ids += [int(x) for x in pre]; first = int(pre[-1]); pos += n_pre
+    if pos + args.steps > 1024:
+        sys.exit(f"bench.py: positions {pos}..{pos + args.steps - 1} exceed max_seq_len 1024")
+    barrier()
+    t0 = time.perf_counter()
+    ms_dev = ctx.decode_timed(first, pos, args.steps)      # enqueues EXACTLY K tokens and waits for the last one
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    barrier()
+    ids += [int(x) for x in ctx.last_tokens(args.steps)]
+    each = ctx.decode_timed_each(first, pos, args.steps)    # same tokens again (same cache rows), one event per token
+    again = [int(x) for x in ctx.last_tokens(args.steps)]
+    parity = {"against": None, "ids_checked": 0, "match": None, "replay_identical": again == ids[-args.steps:]}
+    if gold is not None:
+        n = min(len(ids), len(gold))
+        mism = next((i for i in range(n) if ids[i] != gold[i]), None)
+        parity.update(against="greedy ids of the reference CPU path (oracle/_ref/libflref.so, ParallelTransformer::forward) on this model and prompt: "
+                              "tests/golden/model_7B_int8_L32.npz; the same fixture's logits digests are checked bit for bit by tests/test_gpu_configs.py",
+                      ids_checked=n, match=mism is None, first_mismatch=mism)
+    return {"wall_s": wall, "ms_dev": ms_dev, "pos": pos, "ids": ids, "parity": parity,
+            "p50_ms": float(np.median(each)), "p90_ms": float(np.percentile(each, 90)), "each_mean_ms": float(np.mean(each))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,13 +261,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--shape", default="7B")
     ap.add_argument("--quant", default="int8", choices=["int8", "int16"])
+    ap.add_argument("--pos", type=int, default=None, help="start the timed steps at this position (the prompt's greedy continuation is decoded, untimed, up to it); "
+                                                          "default: prompt length + warmup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--wg-per-cu", type=int, default=0)
     ap.add_argument("--prompt-len", type=int, default=9)
-    ap.add_argument("--parallel", default="replicas", choices=["replicas", "tp"],
-                    help="N > 1: 'replicas' = one independent sequence per GPU, no data-path collective (default); "
-                         "'tp' = one sequence, every matmul split by output rows over the GPUs, RCCL all-gathers")
-    ap.add_argument("--mega", type=int, default=-1, help="1/0: force the persistent whole-token kernel on/off (default: library default)")
+    ap.add_argument("--parallel", default="tp", choices=["replicas", "tp"],
+                    help="N > 1: 'tp' (default) = ONE sequence, every matmul split by output rows over the GPUs (strong scaling, the headline value; "
+                         "the replicas figure is reported beside it); 'replicas' = one independent sequence per GPU only")
     args = ap.parse_args()
 
     import torch
@@ -226,55 +284,57 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    comm_id = None
-    mode = "single" if world == 1 else args.parallel
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        if mode == "tp":
-            idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
-            if rank == 0:
-                idt.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
-            dist.broadcast(idt, 0)
-            comm_id = bytes(idt.cpu().numpy().tobytes())
-    tp = world if mode == "tp" else 1
-
-    qt = ff.QT_INT8 if args.quant == "int8" else ff.QT_INT16
-    cfg = synth.make_config(args.shape, qt)
-    if rank == 0:
-        log(f"bench: {args.shape} {args.quant}, world={world} ({mode}), steps={args.steps}, warmup={args.warmup}")
-    ctx = capi.Ctx(capi.desc_from_config(cfg), device=local_rank, rank=rank if tp > 1 else 0, world=tp, comm_id=comm_id)
-    if args.wg_per_cu:
-        ctx.set_option("wg_per_cu", args.wg_per_cu)
-    if args.mega >= 0:
-        ctx.set_option("use_mega", args.mega)
-    upload_synthetic(ctx, cfg)
 
     def barrier():
-        if world > 1:
-            import torch.distributed as dist
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # prompt (untimed): BOS + 8 tokens, then W warm-up decode steps (also captures the hipGraphs)
-    V = cfg.vocab_size
-    seq = rank if mode == "replicas" else 0            # replicas decode different sequences
-    prompt = np.array([1] + [int(x) for x in ((np.arange(1, args.prompt_len) + 131 * seq) * 7919) % V], dtype=np.int32)
-    first = ctx.forward_argmax(prompt, 0)
-    pos = len(prompt)
-    if args.warmup > 0:
-        ids = ctx.decode_greedy(first, pos, args.warmup)
-        first = int(ids[-1]); pos += args.warmup
-    barrier()
-    t0 = time.perf_counter()
-    ms_dev = ctx.decode_timed(first, pos, args.steps)      # enqueues EXACTLY K tokens and waits for the last one
-    torch.cuda.synchronize()
-    barrier_t = time.perf_counter() - t0
-    barrier()
-    tok_s, elapsed = job_throughput(barrier_t, args.steps, world, mode)
-    mid_pos = pos + args.steps // 2
+    qt = ff.QT_INT8 if args.quant == "int8" else ff.QT_INT16
     esz = 1 if qt == ff.QT_INT8 else 2
+    cfg = synth.make_config(args.shape, qt)
+    V = cfg.vocab_size
+    gold = golden_ids(cfg, qt, args.prompt_len)
+
+    def prompt_for(seq):
+        return np.array([1] + [int(x) for x in ((np.arange(1, args.prompt_len) + 131 * seq) * 7919) % V], dtype=np.int32)
+
+    if rank == 0:
+        log(f"bench: {args.shape} {args.quant}, world={world}, steps={args.steps}, warmup={args.warmup}")
+
+    # ---- the headline run: single GPU, or ONE sequence tensor-parallel over all ranks -----------------------------------
+    mode = "single" if world == 1 else args.parallel
+    tp_note = None
+    m = None
+    if mode == "tp":
+        try:
+            ctx = open_tp_ctx(capi, cfg, rank, world, local_rank, dist, torch)
+            upload_synthetic(ctx, cfg)
+            m = time_decode(ctx, cfg, args, prompt_for(0), barrier, gold)
+            ok = 1
+        except Exception as e:  # noqa: BLE001
+            log(f"rank {rank}: tensor-parallel run failed: {e}")
+            tp_note = f"tensor-parallel run failed on rank {rank}: {e}"
+            ok = 0
+        okt = torch.tensor([ok], device="cuda"); dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if int(okt.item()) == 0:
+            mode, m = "replicas", None
+            tp_note = tp_note or "tensor-parallel run failed on another rank"
+    if mode != "tp":
+        ctx = capi.Ctx(capi.desc_from_config(cfg), device=local_rank)
+        if args.wg_per_cu:
+            ctx.set_option("wg_per_cu", args.wg_per_cu)
+        upload_synthetic(ctx, cfg)
+        m = time_decode(ctx, cfg, args, prompt_for(rank if mode == "replicas" else 0), barrier, gold if (mode == "single" or rank == 0) else None)
+    tok_s, elapsed = job_throughput(m["wall_s"], args.steps, world, mode)
+    pos = m["pos"]
+    mid_pos = pos + args.steps // 2
+    tp = world if mode == "tp" else 1
 
     # per-kernel times, live, HIP events on the ctx stream (eager launches, same kernels as the graph)
     kt = ctx.kernel_times(mid_pos, iters=3)
@@ -284,23 +344,41 @@ def main():
     achieved = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
     kernels = {k: {"us": round(v[0], 2), "per_token": v[1], "GBps": round(ctx.kernel_bytes(k, mid_pos) / (v[0] * 1e-6) / 1e9, 1) if v[0] > 0 else 0.0}
                for k, v in kt.items() if v[1] > 0}
+    ctx.close()
+
+    # ---- N > 1: the replicas figure beside the tensor-parallel headline (one independent sequence per GPU, no collective) ----
+    replicas = None
+    if mode == "tp":
+        try:
+            rctx = capi.Ctx(capi.desc_from_config(cfg), device=local_rank)
+            upload_synthetic(rctx, cfg)
+            rm = time_decode(rctx, cfg, args, prompt_for(rank), barrier, None)
+            r_tok_s, r_elapsed = job_throughput(rm["wall_s"], args.steps, world, "replicas")
+            replicas = {"value": round(r_tok_s, 2), "unit": "tokens/s", "scaling": "weak", "ms_per_step": round(1000.0 * r_elapsed / args.steps, 4),
+                        "note": f"{world} independent sequences, one whole model per GPU, no data-path collective; whole-job tokens/s = N*K / max over ranks"}
+            rctx.close()
+        except Exception as e:  # noqa: BLE001
+            replicas = {"value": None, "note": f"failed: {e}"}
 
     traffic, traffic_src = pmc_traffic(r"k_gemv<2, 2, 2," if qt == ff.QT_INT8 else r"k_gemv<1, 2, 2,")
     if rank == 0:
+        tb = token_bytes(cfg, mid_pos, esz)
         line = {
             "metric": "decode tokens/s LLaMA2-7B int8" if args.shape == "7B" and qt == ff.QT_INT8 else f"decode tokens/s {args.shape} {args.quant}",
             "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * elapsed / args.steps, 4), "higher_is_better": True,
             "scaling": "strong" if mode == "tp" else "weak", "vs_baseline": None, "dtype": "int8" if qt == ff.QT_INT8 else "int16", "data": "synthetic",
-            "config": {"workload": f"LLaMA2-{args.shape} {args.quant} .flm-layout synthetic weights, single-stream greedy decode, "
-                                   f"prompt {len(prompt)} tokens, positions {pos}..{pos + args.steps - 1}, fp32 KV cache, max_seq 1024",
-                       "parallelism": {"single": "single-gpu", "tp": f"tp{world}: one sequence, matmuls split by output rows, RCCL all-gathers",
+            "config": {"workload": f"LLaMA2-{args.shape} {args.quant} .flm-layout synthetic weights (portable splitmix64 checkpoint, norm weights 1.0), single-stream greedy decode, "
+                                   f"prompt {args.prompt_len} tokens, positions {pos}..{pos + args.steps - 1}, fp32 KV cache, max_seq 1024",
+                       "parallelism": {"single": "single-gpu", "tp": f"tp{world}: ONE sequence, every matmul split by output rows over {world} GPUs, activation slices exchanged peer to peer over xGMI",
                                        "replicas": f"{world} replicas: one independent sequence per GPU, no data-path collective"}[mode],
-                       "device_ms_per_step": round(ms_dev / args.steps, 4)},
+                       "device_ms_per_step": round(m["ms_dev"] / args.steps, 4)},
+            "p50_ms_per_step": round(m["p50_ms"], 4), "p90_ms_per_step": round(m["p90_ms"], 4),
+            "parity": m["parity"],
             # per GPU: bytes each GPU streams per token it works on, at the rate it produces them
-            "token_roofline": {"bytes_per_token": int(token_bytes(cfg, mid_pos, esz) / tp), "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
-                               "achieved": round(token_bytes(cfg, mid_pos, esz) / tp * (tok_s / (world / tp)) / 1e9, 1),
-                               "frac": round(token_bytes(cfg, mid_pos, esz) / tp * (tok_s / (world / tp)) / 1e9 / HBM_PEAK_GBS, 4)},
+            "token_roofline": {"bytes_per_token": int(tb / tp), "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU", "pos": mid_pos,
+                               "achieved": round(tb / tp * (tok_s / (world / tp)) / 1e9, 1),
+                               "frac": round(tb / tp * (tok_s / (world / tp)) / 1e9 / HBM_PEAK_GBS, 4)},
             "roofline": {"kernel": "k_gemv<int8,rmsnorm+quantize,swiglu> (ffn13)" if qt == ff.QT_INT8 else "k_gemv<int16,...> (ffn13)",
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -308,17 +386,28 @@ def main():
             "kernels": kernels,
             "kernels_note": "per-class times of the stand-alone kernels (back-to-back launches); the decode loop runs attention + attn_o as one launch (k_attn_o) on a single GPU",
         }
+        if replicas is not None:
+            line["replicas"] = replicas
+        if tp_note:
+            line["tp_note"] = tp_note
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(cfg)
             except Exception as e:  # noqa: BLE001
                 line["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(line), flush=True)
-    ctx.close()
-    if world > 1:
-        import torch.distributed as dist
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def open_tp_ctx(capi, cfg, rank, world, local_rank, dist, torch):
+    """one tensor-parallel context per rank: the RCCL id travels by broadcast, the peer-to-peer handles by all_gather"""
+    idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+    if rank == 0:
+        idt.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
+    dist.broadcast(idt, 0)
+    return capi.Ctx(capi.desc_from_config(cfg), device=local_rank, rank=rank, world=world, comm_id=bytes(idt.cpu().numpy().tobytes()))
 
 
 if __name__ == "__main__":

@@ -20,10 +20,10 @@ KCLASSES = ("embed", "qkv", "attn", "attn_o", "ffn13", "ffn2", "cls", "argmax", 
 # every symbol include/flm_gpu.h declares (tests check the library exports all of them)
 SYMBOLS = (
     "flm_comm_unique_id", "flm_ctx_create", "flm_ctx_destroy", "flm_last_error", "flm_upload_tensor",
-    "flm_forward", "flm_forward_argmax", "flm_decode_greedy", "flm_decode_timed", "flm_reset_kv", "flm_sync",
+    "flm_forward", "flm_forward_argmax", "flm_decode_greedy", "flm_decode_timed", "flm_decode_timed_each", "flm_last_tokens", "flm_reset_kv", "flm_sync",
     "flm_kernel_times", "flm_kernel_bytes", "flm_set_option", "flm_debug_read",
     "flm_op_quantize", "flm_op_matmul_q", "flm_op_rmsnorm", "flm_op_swiglu", "flm_op_rope", "flm_op_softmax",
-    "flm_op_attention", "flm_op_expf", "flm_op_math", "flm_op_square_sum", "flm_plan_shards",
+    "flm_op_attention", "flm_op_expf", "flm_op_math", "flm_op_square_sum", "flm_op_argmax", "flm_plan_shards",
 )
 
 
@@ -137,6 +137,16 @@ class Ctx:
         _check(lib().flm_decode_timed(self._h, int(first_token), int(pos), int(n_steps), C.byref(ms)), self._h)
         return ms.value
 
+    def decode_timed_each(self, first_token, pos, n_steps) -> np.ndarray:
+        ms = np.zeros(n_steps, dtype=np.float32)
+        _check(lib().flm_decode_timed_each(self._h, int(first_token), int(pos), int(n_steps), _p(ms)), self._h)
+        return ms
+
+    def last_tokens(self, n) -> np.ndarray:
+        out = np.empty(n, dtype=np.int32)
+        _check(lib().flm_last_tokens(self._h, int(n), _p(out)), self._h)
+        return out
+
     def reset_kv(self):
         _check(lib().flm_reset_kv(self._h), self._h)
 
@@ -181,6 +191,13 @@ def op_matmul_q(qt, W, sW, X, sX, gs=64):
     return out
 
 
+def op_argmax(logits) -> int:
+    a = np.ascontiguousarray(logits, dtype=np.float32)
+    idx = C.c_int32(-1)
+    _check(lib().flm_op_argmax(_p(a), int(a.size), C.byref(idx)))
+    return idx.value
+
+
 def op_rmsnorm(x, w):
     x = np.ascontiguousarray(x, dtype=np.float32); w = np.ascontiguousarray(w, dtype=np.float32)
     o = np.empty_like(x)
@@ -189,7 +206,7 @@ def op_rmsnorm(x, w):
 
 
 def op_square_sum(x):
-    """-> (total from the wave-parallel evaluation, total from the sequential chains, the 4 strided partial sums)"""
+    """-> (total from the speculative wave evaluation, total from the sequential chains, the 4 strided partial sums)"""
     x = np.ascontiguousarray(x, dtype=np.float32)
     o = np.empty(6, dtype=np.float32)
     _check(lib().flm_op_square_sum(_p(x), C.c_size_t(x.size), _p(o)))

@@ -31,6 +31,9 @@ struct AttnArgs {
     const int* pos_ptr;
     int hs, max_seq;
     unsigned long long* trace;   // FLM_ABLATE builds: [head][8] s_memtime stamps
+    // k_attn_o with head_size a multiple of 64: the head also leaves its output QUANTIZED (quant::quantize, quant_operators.cpp:26-47,
+    // on the 64 values one wave holds) for the Wo GEMV that waits in the same launch: oq [heads*hs] int8 / int16, os [heads*hs/64]
+    void* oq; float* os; int oqt;
 };
 
 constexpr int kAttnBlock = 1024;      // 16 waves
@@ -42,7 +45,7 @@ __host__ __device__ inline int attn_row_stride(int hs) { const int nf = hs <= 64
 __host__ inline size_t attn_lds_bytes(int max_seq, int hs) { return (size_t)(hs + 32 + ((max_seq + 3) & ~3) + 64 + (2 * kAttnTile + 4) * attn_row_stride(hs)) * 4; }   // + 4 slack rows: the PV read-ahead
 
 // NF = 16-byte pieces of a tile per thread = ceil(hs / 64)
-// COH: K/V/q were (partly) written by other workgroups of the SAME kernel (k_token) -> coherent sc0|sc1 loads; the
+// COH: K/V/q were (partly) written by other workgroups of the SAME kernel (a fused launch) -> coherent sc0|sc1 loads; the
 // per-phase kernels read them after a kernel boundary and use ordinary cached loads
 template <int NF, bool COH>
 __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow) {
@@ -61,7 +64,7 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
     const int lane = tid & 63, wave = tid >> 6;
     const float* K = a.kcache + (size_t)h * a.max_seq * hs;
     const float* V = a.vcache + (size_t)h * a.max_seq * hs;
-    // K/V rows of this token may have been written by other workgroups of the same kernel (k_token): coherent loads
+    // K/V rows of this token may have been written by other workgroups of the same kernel (a fused launch): coherent loads
     // (sc0|sc1) through buffer descriptors; positions past T get an out-of-range offset and read as zero
     const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(K), 0, a.max_seq * hs * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V), 0, a.max_seq * hs * 4, 0x00020000);
@@ -231,7 +234,23 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
     }
     stamp(4);
     if (tid < hs) st_agent(orow + (size_t)h * hs + tid, o);
-    __syncthreads();                                                // the LDS is free for whoever runs next on it (k_token)
+    if (a.oq) {
+        // qx.quantize(x2) (transformer.cpp:138) for this head's groups: wave w holds the 64 outputs of group h * hs/64 + w;
+        // the max is order-free, the element step is quant_elem.  Packed through LDS (q's place: long since consumed) so that
+        // the values leave as dwords.
+        const int esz = a.oqt == QT_INT8 ? 1 : 2;
+        if (tid < hs) {
+            const float mx = wave_max(fabsf(o));
+            const float sc = __fdiv_rn(mx, a.oqt == QT_INT8 ? QTraits<QT_INT8>::kF : QTraits<QT_INT16>::kF);
+            const int q = quant_elem(o, sc);
+            if (esz == 1) reinterpret_cast<signed char*>(qs)[tid] = (signed char)q; else reinterpret_cast<short*>(qs)[tid] = (short)q;
+            if (lane == 0) st_agent(a.os + (size_t)h * (hs >> 6) + wave, sc);
+        }
+        __syncthreads();
+        const int nd = hs * esz / 4;
+        if (tid < nd) __hip_atomic_store(reinterpret_cast<unsigned*>(a.oq) + (size_t)h * nd + tid, reinterpret_cast<const unsigned*>(qs)[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                                                // the LDS is free for whoever runs next on it
 }
 template <bool COH>
 __device__ __forceinline__ void attn_head_any(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow) {
@@ -424,7 +443,9 @@ __global__ void __launch_bounds__(kAttnBlock) k_attn_decode(const AttnArgs a) {
 // is read with coherent loads.  All workgroups are resident (grid <= CUs, one 1024-thread workgroup per CU); a poll that
 // never succeeds gives up after ~20 ms and raises *err.  The flag lines are zero when the token starts (k_embed).
 constexpr int kFlagStride = 16;      // dwords
-template <int QT, int XR>
+// PREQ: the heads hand over their output already quantized (AttnArgs::oq/os == GemvArgs::xq/xs): the GEMV workgroups
+// copy 1 (2) bytes per element into LDS with coherent loads and skip the quantize prologue (~1.8 us of a 12.9 us launch).
+template <int QT, int XR, bool PREQ>
 __global__ void __launch_bounds__(kGemvBlock, 4) k_attn_o(const AttnArgs aa, const GemvArgs a, const int n_heads, unsigned* flag, const unsigned target, int* err) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     auto stamp = [&](int k) { if (kAblate && a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime(); };   // tools/trace_ao.py
@@ -440,7 +461,7 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_attn_o(const AttnArgs aa, con
     }
     GemvCtx<QT, EPI_RESIDUAL> g;
     g.init(a, blockIdx.x - n_heads, gridDim.x - n_heads, lds);
-    g.issue(a.ablate);
+    g.issue(kAblate ? a.ablate : 0);
     stamp(1);
     if ((int)(threadIdx.x & ~63u) < n_heads) {                              // the waves that own at least one head's flag: lane i polls head i's line
         const bool mine = (int)threadIdx.x < n_heads;
@@ -454,8 +475,12 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_attn_o(const AttnArgs aa, con
     __syncthreads();
     stamp(2);
     float4 xv[XR > 0 ? XR : 1], nv[XR > 0 ? XR : 1];
-    gemv_preload<QT, PRO_QUANT, XR, true>(a, xv, nv);
-    gemv_prologue<QT, PRO_QUANT, XR>(a, lds, xv, nv, [](int) {});
+    if constexpr (PREQ) {
+        gemv_prologue<QT, PRO_NONE, 0, true>(a, lds, xv, nv, [](int) {});
+    } else {
+        gemv_preload<QT, PRO_QUANT, XR, true>(a, xv, nv);
+        gemv_prologue<QT, PRO_QUANT, XR>(a, lds, xv, nv, [](int) {});
+    }
     stamp(3);
     g.run(a, lds, [](int) {});
     stamp(4);

@@ -18,7 +18,7 @@ struct GemvArgs {
     int items;                                  // rows (STORE/RESIDUAL), hidden (SWIGLU), row pairs (ROPE_KV)
     int rows_per_pass;                          // Rm: rows (of each matrix) one workgroup reduces per pass; multiple of RB, <= 64
     int cb_shift;                               // log2(CB): a 1 KiB wave load covers RB = (64 >> cb_shift) rows x CB 16-byte chunks
-    int ctr_off;                                // LDS byte offset of the two step counters; 0: the layout's own (k_token keeps them at a fixed place across phases)
+    int ctr_off;                                // LDS byte offset of the two step counters; 0: the layout's own
     int nbuf;                                   // strip buffers: 2, or 1 when each workgroup has a single pass and LDS is short
     // prologue inputs
     const float* x;                             // fp32 activation [n]          (QUANT / RMSNORM_QUANT)
@@ -33,7 +33,7 @@ struct GemvArgs {
     // debugging taps used by the op-level exports (may be null)
     void* dbg_xq; float* dbg_xs; float* dbg_xn;
     unsigned long long* trace;                  // FLM_ABLATE builds: per-workgroup timeline [grid][8] (s_memtime), else unused
-    int ablate;                                 // perf exploration only (results invalid when != 0): 1 no group chain, 2 no rmsnorm chain, 4 no weight loads, 8 no dots, 16 return immediately, 32 return after prologue
+    int ablate;                                 // FLM_ABLATE builds only (every test of it sits behind kAblate; product builds ignore it): 1 no group chain, 2 no rmsnorm chain, 4 no weight loads, 8 no dots, 16 return immediately, 32 return after prologue
 };
 
 #ifndef FLM_ABLATE
@@ -42,8 +42,11 @@ struct GemvArgs {
 constexpr bool kAblate = FLM_ABLATE != 0;
 constexpr int kStepBlk = 4;            // H: 1 KiB wave loads per step; two steps (register sets) in flight: 8 KiB/wave, 128 KiB/CU
 
+// staging geometry of the speculative chain: B = elements per lane = the power of two >= max(4, ceil(n/4 / 64))
+__host__ __device__ inline int chain_bshift(int n) { int s = 2; while ((64 << s) < n / 4) ++s; return s; }
+__host__ __device__ inline int chain_strip_floats(int n) { return 64 * ((1 << chain_bshift(n)) + 4); }
 // LDS layout: [xq : n*esz] [xs : n/64 floats, padded to 16 B] [red : 16 floats] [scratch]
-// scratch = max( rmsnorm transpose staging 4n bytes ,
+// scratch = max( rmsnorm staging: 4 chain strips of [64 lanes][B + 4] floats (sq_chain_spec) ,
 //                2 buffers x (Rm + RB) strips; strip r = { float(group dot), sW*sX } pairs of row r, groups ascending
 //                (SWIGLU: entries { d(W1), d(W3), s(W1), s(W3) }: the two chains are the halves of one packed FMA) )
 struct GemvLds {
@@ -63,7 +66,8 @@ __host__ __device__ inline GemvLds gemv_lds_layout(int n, int esz, bool norm, in
     L.gstride = g16 * 16;
     L.buf_bytes = (Rm + RB) * L.gstride;                                       // + RB dummy strips that absorb the writes of padding blocks
     int scratch = nbuf * L.buf_bytes + 64;                                     // + 64: the chain's read-ahead past the last strip
-    if (norm && n * 4 + 512 > scratch) scratch = n * 4 + 512;                   // 4 strips of n/4 + 8 floats (+8: the 4 chain lanes read different banks); + the chain's read-ahead past the last strip
+    const int chain = 4 * chain_strip_floats(n) * 4 + 64;                       // the 4 strided lanes of square_sum, each a lane-major strip
+    if (norm && chain > scratch) scratch = chain;
     L.total = L.off_scr + scratch;
     return L;
 }
@@ -105,21 +109,28 @@ __device__ __forceinline__ float sq_chain(const float* p, int n4) {
     return l;
 }
 
-// The same chain -- l <- fma(x_k, x_k, l), k ascending, bit for bit -- evaluated by a WHOLE WAVE in far fewer than n
-// dependent steps.  The terms are non-negative, so l only grows, and while l stays inside one binade [2^E, 2^(E+1)) every
-// step rounds l + x^2 to a multiple of u = ulp(l).  Within the binade the increment t_k = fl(l + x_k^2) - l does not depend
-// on l (except for exact ties): it is what ONE fma against the bottom of the binade gives, t_k = fma(x_k, x_k, 2^E) - 2^E,
-// a multiple of u, and sums of such multiples below 2^(E+1) are exact in fp32 in ANY order -- a prefix sum.  Lane L takes
-// elements 4L..4L+3 of a 256-element block, a wave scan adds them up.  Two kinds of element stop the scan: one on which l
-// leaves the binade (fma(x, x, l_before) >= 2^(E+1): the rounding unit changes) and one whose x^2 lies exactly halfway
-// between two multiples of u (round-half-even then looks at the parity of l: detected as |fma(x, x, -t)| == u/2).  The scan
-// commits everything before the first such element, that element takes one real fma, and the scan resumes behind it with the
-// new binade.  l doubles only ~log2(n) times over a chain, mostly within the first elements, which are simply run in order.
-// STATUS: exact (tests/test_gpu_ops.py::test_square_sum_wave_parallel_is_bit_exact, adversarial ties / overflow / denormals)
-// but NOT used by the product path: a lone wave pays ~7 cycles per instruction whatever it does, this formulation runs
-// ~150 instructions per scan round and needs 4 rounds + one per binade change (8-9 for n/4 = 1024), i.e. about as many
-// instructions as the 1024 dependent FMAs and their LDS reads (measured 7.1 us against 4.3 us in the prologue).  It pays
-// only below ~75 instructions per round; kept, tested, for the round that hand-schedules it.
+// The same chain -- l <- fma(x_k, x_k, l), k ascending, bit for bit -- evaluated by a WHOLE WAVE in a handful of rounds
+// instead of n dependent steps (tools/chain_emul.c is the build-host emulation of this function, fuzzed against the
+// sequential chain; tests/test_gpu_ops.py::test_square_sum_speculative_is_bit_exact checks the kernel).
+// The terms are non-negative, so l only grows, and while l stays inside one binade [A, 2A), A = 2^E, every step rounds
+// l + x^2 to a multiple of u = ulp(A): the increment fl(l + x^2) - l does not depend on l (exact ties aside), it is
+// t = fma(x, x, A) - A.  Lane L owns B consecutive elements (LDS strip, lane-major, row stride B + 4 floats):
+//   1. approximate prefix of sum x^2 (fp32 wave scan) -> the binade E_L the lane expects to start in;
+//   2. T_L = sum of its increments against 2^E_L (multiples of u: exact in any order), tie flag (x^2 exactly half way);
+//   3. exact exclusive prefix S_L of the T's in fp64 (every T is a multiple of 2^(Emin-23), every partial sum is below
+//      2^(Emax+2): exact while Emax - Emin <= 26, else the plain chain runs);
+//   4. rounds: given an exact (base lane, base value), lane t would start at base + (S_t - S_base); it is CONSISTENT if
+//      that start lies in its expected binade, start + T_t stays below 2^(E_t+1) and it saw no tie.  The first
+//      inconsistent lane f has an exact start (all lanes before it are consistent): its B real steps give the next base.
+// l crosses a binade ~log2(n) times, mostly early: the first H lanes' elements simply run in order, then ~4 rounds.
+__device__ __forceinline__ double wave_scan_incl_f64(double v) {
+#define FLM_SCAN64(ctrl, rmask, bc) { const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, rmask, 0xF, bc), hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, rmask, 0xF, bc); v = __dadd_rn(v, __hiloint2double(hi_, lo_)); }
+    FLM_SCAN64(0x111 /* row_shr:1 */, 0xF, true) FLM_SCAN64(0x112 /* row_shr:2 */, 0xF, true)
+    FLM_SCAN64(0x114 /* row_shr:4 */, 0xF, true) FLM_SCAN64(0x118 /* row_shr:8 */, 0xF, true)
+    FLM_SCAN64(0x142 /* row_bcast:15 */, 0xA, false) FLM_SCAN64(0x143 /* row_bcast:31 */, 0xC, false)
+#undef FLM_SCAN64
+    return v;
+}
 __device__ __forceinline__ float wave_scan_incl(float v) {
 #define FLM_SCAN_STEP(ctrl, rmask, bc) v = __fadd_rn(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xF, bc)));
     FLM_SCAN_STEP(0x111 /* row_shr:1 */, 0xF, true) FLM_SCAN_STEP(0x112 /* row_shr:2 */, 0xF, true)
@@ -128,75 +139,75 @@ __device__ __forceinline__ float wave_scan_incl(float v) {
 #undef FLM_SCAN_STEP
     return v;
 }
-__device__ __forceinline__ float sq_chain_wave(const float* p, int n4, int* iters = nullptr) {
-    const int lane = threadIdx.x & 63;
-    int n_it = 0;
-    constexpr int kHead = 64;                                      // elements run in order first (l crosses most binades here)
-    float acc = 0.f;
-    int k = 0;
-    for (; k + 4 <= n4 && k < kHead; k += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(p + k);
-        acc = __fmaf_rn(v.x, v.x, acc); acc = __fmaf_rn(v.y, v.y, acc); acc = __fmaf_rn(v.z, v.z, acc); acc = __fmaf_rn(v.w, v.w, acc);
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+constexpr int kChainHead = 4;          // lanes whose elements run in order before the speculative part
+// p: one chain's strip [64 lanes][B + 4] floats, zero-padded past the data.  Returns the chain value in every lane.
+__device__ __forceinline__ float sq_chain_spec(const float* p, const int bshift, int* rounds_out = nullptr) {
+    const int lane = threadIdx.x & 63, B = 1 << bshift, BV = B >> 2, LS = B + 4;
+    const float4* pl = reinterpret_cast<const float4*>(p + lane * LS);
+#define FLM_SQ4(l, v) l = __fmaf_rn(v.x, v.x, l); l = __fmaf_rn(v.y, v.y, l); l = __fmaf_rn(v.z, v.z, l); l = __fmaf_rn(v.w, v.w, l);
+    // 1. approximate per-lane sums, all-zero lanes (pass-through whatever l is)
+    float s = 0.f, m = 0.f;
+    for (int q = 0; q < BV; ++q) { const float4 v = pl[q]; FLM_SQ4(s, v) m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))); }
+    const bool allzero = (m == 0.f) && (s == 0.f);              // (s: a NaN among zeros must not count as zero)
+    const float P = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(wave_scan_incl(s)), 0x138 /* wave_shr:1 */, 0xF, 0xF, true));
+    // the head: lanes [0, kChainHead) in order (every lane computes it: broadcast reads)
+    float hv = 0.f;
+    for (int L = 0; L < kChainHead; ++L) { const float4* r = reinterpret_cast<const float4*>(p + L * LS); for (int q = 0; q < BV; ++q) { const float4 v = r[q]; FLM_SQ4(hv, v) } }
+    // 2. increments against the expected binade
+    const unsigned eb = __float_as_uint(P) & 0x7f800000u;
+    bool valid = lane >= kChainHead && eb >= (27u << 23) && eb <= (250u << 23);      // P finite and normal, room for u/2 and 2A
+    const unsigned ebv = valid ? eb : 0x3f800000u;
+    const float A = __uint_as_float(ebv), half_u = __uint_as_float(ebv - (24u << 23)), top = __fadd_rn(A, A);
+    float T = 0.f; bool tie = false;
+    for (int q = 0; q < BV; ++q) {
+        const float4 v = pl[q];
+#define FLM_INC(x) { const float t_ = __fsub_rn(__fmaf_rn(x, x, A), A); tie = tie || (fabsf(__fmaf_rn(x, x, -t_)) == half_u); T = __fadd_rn(T, t_); }
+        FLM_INC(v.x) FLM_INC(v.y) FLM_INC(v.z) FLM_INC(v.w)
+#undef FLM_INC
     }
-    for (int base = 0; base < n4; base += 256) {
-        const int e0 = base + 4 * lane;
-        float x0 = 0.f, x1 = 0.f, x2 = 0.f, x3 = 0.f;
-        if (e0 + 4 <= n4) { const float4 v = *reinterpret_cast<const float4*>(p + e0); x0 = v.x; x1 = v.y; x2 = v.z; x3 = v.w; }
-        else { if (e0 < n4) x0 = p[e0]; if (e0 + 1 < n4) x1 = p[e0 + 1]; if (e0 + 2 < n4) x2 = p[e0 + 2]; }
-        int done = k > base ? k - base : 0;                                                // elements of this block already consumed (uniform)
-        const int limit = (n4 - base) < 256 ? (n4 - base) : 256;
-        auto pick = [&](int i) { return i == 0 ? x0 : i == 1 ? x1 : i == 2 ? x2 : x3; };
-        while (done < limit) {
-            ++n_it;
-            const unsigned ab = __builtin_amdgcn_readfirstlane(__float_as_uint(acc));
-            const unsigned eb = ab & 0x7f800000u;
-            if (eb < (32u << 23) || eb >= (254u << 23)) {
-                // l is zero / tiny / not finite: no usable binade -- one plain step, then look again
-                const float xs = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(pick(done & 3)), done >> 2));
-                acc = __fmaf_rn(xs, xs, acc);
-                ++done;
-                continue;
-            }
-            const float aref = __uint_as_float(eb), top = __fadd_rn(aref, aref), half_u = __uint_as_float(eb - (24u << 23));
-            const int el = 4 * lane;
-            const bool v0 = el >= done, v1 = el + 1 >= done, v2 = el + 2 >= done, v3 = el + 3 >= done;
-            // increments (multiples of u) and exact ties
-            const float t0 = v0 ? __fsub_rn(__fmaf_rn(x0, x0, aref), aref) : 0.f, t1 = v1 ? __fsub_rn(__fmaf_rn(x1, x1, aref), aref) : 0.f;
-            const float t2 = v2 ? __fsub_rn(__fmaf_rn(x2, x2, aref), aref) : 0.f, t3 = v3 ? __fsub_rn(__fmaf_rn(x3, x3, aref), aref) : 0.f;
-            bool s0 = v0 && fabsf(__fmaf_rn(x0, x0, -t0)) == half_u, s1 = v1 && fabsf(__fmaf_rn(x1, x1, -t1)) == half_u;
-            bool s2 = v2 && fabsf(__fmaf_rn(x2, x2, -t2)) == half_u, s3 = v3 && fabsf(__fmaf_rn(x3, x3, -t3)) == half_u;
-            const float c0 = t0, c1 = __fadd_rn(c0, t1), c2 = __fadd_rn(c1, t2), c3 = __fadd_rn(c2, t3);
-            const float incl = wave_scan_incl(c3);
-            // l in front of this lane's first element: the inclusive sum of the lane BELOW (incl - c3 would not do: the lane of a
-            // binade-leaving element holds a huge increment, incl is rounded there, and the difference is off by an ulp)
-            const float lb = __fadd_rn(acc, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(incl), 0x138 /* wave_shr:1 */, 0xF, 0xF, true)));
-            // does l leave the binade on this element?  (exact test: the real step from the value in front of it)
-            s0 = s0 || (v0 && __fmaf_rn(x0, x0, lb) >= top);
-            s1 = s1 || (v1 && __fmaf_rn(x1, x1, __fadd_rn(lb, c0)) >= top);
-            s2 = s2 || (v2 && __fmaf_rn(x2, x2, __fadd_rn(lb, c1)) >= top);
-            s3 = s3 || (v3 && __fmaf_rn(x3, x3, __fadd_rn(lb, c2)) >= top);
-            const int fi = s0 ? 0 : s1 ? 1 : s2 ? 2 : s3 ? 3 : 4;
-            const float before = __fadd_rn(lb, s0 ? 0.f : s1 ? c0 : s2 ? c1 : c2);          // l in front of the lane's first special element
-            const unsigned long long sm = __ballot(fi < 4);
-            if (sm) {
-                const int Ls = __ffsll((long long)sm) - 1;
-                const int fs = __builtin_amdgcn_readlane(fi, Ls);
-                acc = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(before), Ls));
-                done = 4 * Ls + fs;
-                if (done < limit) {
-                    const float xs = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(pick(fs)), Ls));
-                    acc = __fmaf_rn(xs, xs, acc);                                           // the special element: one real step
-                    ++done;
-                }
-            } else {
-                acc = __fadd_rn(acc, __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(incl), 63)));
-                done = limit;
-            }
-        }
-        k = base + 256;
+    if (!(T < INFINITY)) valid = false;                         // (inf / NaN never enters the prefix)
+    if (!valid) T = 0.f;
+    // 3. fp64 exactness of the prefix
+    const unsigned long long live = __ballot(valid && !allzero);
+    bool plain = false;
+    if (live) {
+        const unsigned e0 = (unsigned)__builtin_amdgcn_readlane((int)eb, __ffsll((long long)live) - 1), e1 = (unsigned)__builtin_amdgcn_readlane((int)eb, 63 - __clzll((long long)live));
+        plain = e1 < e0 || ((e1 - e0) >> 23) > 26;
     }
-    if (iters) *iters = n_it;
-    return acc;
+    if (plain) {                                                // extreme dynamic range: the plain chain over the strip
+        float l = 0.f;
+        for (int L = 0; L < 64; ++L) { const float4* r = reinterpret_cast<const float4*>(p + L * LS); for (int q = 0; q < BV; ++q) { const float4 v = r[q]; FLM_SQ4(l, v) } }
+        if (rounds_out) *rounds_out = -1;
+        return l;
+    }
+    const double Td = (double)T, Si = wave_scan_incl_f64(Td), S = __dsub_rn(Si, Td);
+    // 4. rounds
+    int base = kChainHead, rounds = 0;
+    double bv = (double)hv, Sb = readlane_f64(S, kChainHead);
+    float res;
+    for (;;) {
+        ++rounds;
+        const double d = __dadd_rn(bv, __dsub_rn(S, Sb));
+        const float st = (float)d;
+        const bool exact = (double)st == d;
+        const bool okE = (__float_as_uint(st) & 0x7f800000u) == eb;
+        const bool okTop = __fadd_rn(st, T) < top;
+        const bool ok = lane < base || (exact && (allzero || (valid && !tie && okE && okTop)));
+        const unsigned long long bad = __ballot(!ok);
+        if (bad == 0) { res = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint((float)__dadd_rn(bv, __dsub_rn(Si, Sb))), 63)); break; }
+        const int f = __ffsll((long long)bad) - 1;
+        float l = st;                                           // every lane runs its B steps from its presumed start; lane f's start is exact
+        for (int q = 0; q < BV; ++q) { const float4 v = pl[q]; FLM_SQ4(l, v) }
+        res = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(l), f));
+        if (f == 63) break;
+        base = f + 1; bv = (double)res; Sb = readlane_f64(S, f + 1);
+    }
+#undef FLM_SQ4
+    if (rounds_out) *rounds_out = rounds;
+    return res;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -236,7 +247,8 @@ __device__ __forceinline__ void gemv_preload(const GemvArgs& a, float4 (&xv)[XR 
 #else
 #define FLM_PRO_STAMP(k)
 #endif
-template <int QT, int PRO, int XR, class AfterStage>
+// COH (PRO_NONE only): the pre-quantized activation was written by other workgroups of the SAME kernel -> coherent loads
+template <int QT, int PRO, int XR, bool COH = false, class AfterStage>
 __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, float4 (&xv)[XR > 0 ? XR : 1], float4 (&wv)[XR > 0 ? XR : 1], AfterStage&& after_stage) {
     using T = QTraits<QT>;
     const int n = a.n;
@@ -248,11 +260,18 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
     float* scratch = reinterpret_cast<float*>(lds + L.off_scr);
 
     if constexpr (PRO == PRO_NONE) {
-        // copy pre-quantized activation (op-level matmul and generic callers)
+        // copy the pre-quantized activation (op-level matmul; k_attn_o's heads hand it over quantized)
         const int nb16 = n * T::kEsz / 16;
-        for (int c = tid; c < nb16; c += kGemvBlock)
-            reinterpret_cast<int4*>(xq)[c] = reinterpret_cast<const int4*>(a.xq)[c];
-        for (int g = tid; g < n / kGroup; g += kGemvBlock) xs[g] = a.xs[g];
+        if constexpr (COH) {
+            const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.xq), 0, n * T::kEsz, 0x00020000);
+            for (int c = tid; c < nb16; c += kGemvBlock)
+                reinterpret_cast<v4i*>(xq)[c] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rq, c * 16, 0, kAuxCoherent));
+            for (int g = tid; g < n / kGroup; g += kGemvBlock) xs[g] = ld_agent(a.xs + g);
+        } else {
+            for (int c = tid; c < nb16; c += kGemvBlock)
+                reinterpret_cast<int4*>(xq)[c] = reinterpret_cast<const int4*>(a.xq)[c];
+            for (int g = tid; g < n / kGroup; g += kGemvBlock) xs[g] = a.xs[g];
+        }
         __syncthreads();
         return;
     } else {
@@ -270,25 +289,32 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
             // simd::square_sum -> square_sum_avx128 (x86_simd.cpp:942-960; the AVX2 branch is dead, :1093):
             // lane c of 4 accumulates x[c], x[c+4], x[c+8]... by FMA, then res = ((0+l0)+l1)+l2)+l3.
             // Stage x transposed ([4][n/4]) so that 4 threads can each walk one strided lane sequentially.
-            const int n4 = n / 4, ns = n4 + 8;                  // strip stride: +8 floats so that the 4 chain lanes' 16-byte reads hit different banks
+            // Stage x as 4 strips (one per strided lane c = element index mod 4), each lane-major for sq_chain_spec: chain
+            // element k lives in row k >> bs at column k & (B - 1), rows B + 4 floats apart (conflict-free 16-byte reads);
+            // slots past the data are zero (loads past n return zero).
+            const int bs = chain_bshift(n), B = 1 << bs, LS = B + 4, CS = 64 * LS, slots = 64 << bs;
             auto stage = [&](int i, const float4& v) {
                 const int k = tid + i * kGemvBlock;
-                if (k < n4) { scratch[k] = v.x; scratch[ns + k] = v.y; scratch[2 * ns + k] = v.z; scratch[3 * ns + k] = v.w; }
+                if (k < slots) { const int o = (k >> bs) * LS + (k & (B - 1)); scratch[o] = v.x; scratch[CS + o] = v.y; scratch[2 * CS + o] = v.z; scratch[3 * CS + o] = v.w; }
             };
+            const int srounds = (slots + kGemvBlock - 1) / kGemvBlock;
 #pragma unroll
-            for (int i = 0; i < XR; ++i) { if (i < rounds) stage(i, xv[i]); }
-            for (int i = XR; i < rounds; ++i) {
+            for (int i = 0; i < XR; ++i) { if (i < srounds) stage(i, xv[i]); }
+            for (int i = XR; i < srounds; ++i) {
                 const int e = tid * 4 + i * kGemvBlock * 4;
-                if (e < n) stage(i, *reinterpret_cast<const float4*>(a.x + e));
+                stage(i, e < n ? *reinterpret_cast<const float4*>(a.x + e) : z4);
             }
             __syncthreads();
             FLM_PRO_STAMP(3)
-            // the hook issues the weight prefetch.  Wave 0 goes first (the others give it ~128 cycles): its 16 loads
-            // enter an empty memory pipeline at once and it is free for the chain; queued behind the other 15 waves'
-            // 240 loads it would stall for ~1 us before (or after) the chain.
-            if (tid >= kWave) __builtin_amdgcn_s_sleep(2);
+            // the hook issues the weight prefetch.  The chain waves (0..3, one strided lane each) go first (the others give
+            // them ~128 cycles): their loads enter an empty memory pipeline at once and they are free for the chains;
+            // queued behind the other waves' loads they would stall for ~1 us before (or after) the chain.
+            if (tid >= 4 * kWave) __builtin_amdgcn_s_sleep(2);
             after_stage(0);
-            if (tid < 4 && !(a.ablate & 2)) red[8 + tid] = sq_chain(scratch + tid * ns, n4);
+            if (tid < 4 * kWave && !(kAblate && (a.ablate & 2))) {
+                const float l = sq_chain_spec(scratch + (tid >> 6) * CS, bs);
+                if ((tid & 63) == 0) red[8 + (tid >> 6)] = l;
+            }
             FLM_PRO_STAMP(4)
             __syncthreads();
             const float ss = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, red[8]), red[9]), red[10]), red[11]);
@@ -367,7 +393,7 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
 // rmsnorm chain overlap the stream.
 //
 // GemvCtx is the per-wave state of one GEMV: geometry, the step decoder and the two register sets.
-// k_gemv, k_attn_o and the persistent whole-token kernel k_token all drive it:
+// k_gemv and k_attn_o drive it:
 //     init -> issue (weight loads of the first two steps) -> [activation prologue] -> run
 // ------------------------------------------------------------------------------------------
 typedef unsigned int u32;
@@ -409,8 +435,7 @@ struct GemvCtx {
     static __device__ __forceinline__ u32 inv_of(u32 d) { return d > 1 ? 0xFFFFFFFFu / d + 1u : 0u; }
     static __device__ __forceinline__ u32 udiv(u32 x, u32 d, u32 inv) { return d > 1 ? __umulhi(x, inv) : x; }
 
-    // ctr_slot: which of the two step counters in LDS this GEMV uses (k_token alternates them from phase to phase: a
-    // fast wave initialises the next phase while slow ones still draw from this phase's counter)
+    // ctr_slot: which of the two step counters in LDS this GEMV uses
     __device__ __forceinline__ void init(const GemvArgs& a, u32 wg_, u32 nwg_, char* lds, u32 ctr_slot = 0) {
         n = a.n; wg = wg_; nwg = nwg_;
         lane = threadIdx.x & 63;
@@ -548,7 +573,7 @@ struct GemvCtx {
         //      other ring's FMAs run, ONE explicit s_waitcnt per ring.  SWIGLU: an entry is {d1, d3, s1, s3}, and the W1
         //      and W3 chains are the two halves of one v_pk_fma_f32 (each half an IEEE fma), operands in place.
         float acc = 0.f, acc2 = 0.f;
-        if (lane < Rm && !(a.ablate & 1)) {
+        if (lane < Rm && !(kAblate && (a.ablate & 1))) {
             const char* sp = strips + lane * gstride;
             u32 g = 0;
 #define FLM_RD4(r0, r1, r2, r3, ptr) r0 = *reinterpret_cast<const float4*>(ptr); r1 = *reinterpret_cast<const float4*>((ptr) + 16); r2 = *reinterpret_cast<const float4*>((ptr) + 32); r3 = *reinterpret_cast<const float4*>((ptr) + 48);
@@ -684,7 +709,7 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_gemv(const GemvArgs a) {
 #endif
     if (kAblate && a.trace && threadIdx.x == 0) rt0 = __builtin_amdgcn_s_memrealtime();
     stamp(0);
-    if (a.ablate & 16) return;
+    if (kAblate && (a.ablate & 16)) return;
     // The activation first, and the weight prefetch only once it HAS ARRIVED (the hook runs after the staging barrier /
     // after the activation registers landed).  Weights do not depend on the activation and were once requested up
     // front -- but workgroups start ~1 us apart, and the activation loads of the late ones then queued in HBM behind
@@ -694,11 +719,11 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_gemv(const GemvArgs a) {
     gemv_preload<QT, PRO, XR>(a, xv, nv);
     GemvCtx<QT, EPI> g;
     g.init(a, blockIdx.x, gridDim.x, lds);
-    if constexpr (PRO == PRO_NONE) g.issue(a.ablate);
+    if constexpr (PRO == PRO_NONE) g.issue(kAblate ? a.ablate : 0);
     stamp(1);
-    gemv_prologue<QT, PRO, XR>(a, lds, xv, nv, [&](int part) { g.issue(a.ablate, part); });
+    gemv_prologue<QT, PRO, XR>(a, lds, xv, nv, [&](int part) { g.issue(kAblate ? a.ablate : 0, part); });
     stamp(2);
-    if (a.ablate & 32) return;
+    if (kAblate && (a.ablate & 32)) return;
     g.run(a, lds, stamp);
     stamp(6);
     if (kAblate && a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime() - rt0;

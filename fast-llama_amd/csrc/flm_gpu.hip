@@ -12,6 +12,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -34,6 +35,9 @@ struct LayerW {
 enum KClass { KC_EMBED = 0, KC_QKV, KC_ATTN, KC_ATTN_O, KC_FFN13, KC_FFN2, KC_CLS, KC_ARGMAX, KC_ALLREDUCE };
 
 struct TimedLaunch { int kclass; hipEvent_t e0, e1; };
+// owners that release on every exit path (the error macros return from the middle of a function)
+struct DevMem { void* p = nullptr; ~DevMem() { if (p) hipFree(p); } };
+struct EvPair { hipEvent_t e0 = nullptr, e1 = nullptr; ~EvPair() { if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); } };
 
 } // namespace
 
@@ -65,11 +69,10 @@ struct flm_ctx {
     int use_prefill = 1;                               // option "use_prefill": prompts of >= kPrefillMin+1 tokens go through the batched kernels
     int pf_cap = 0;                                    // token capacity of the batched-prefill buffers below
     float *pf_x = nullptr, *pf_qkv = nullptr, *pf_q = nullptr, *pf_att = nullptr, *pf_gu = nullptr, *pf_hd = nullptr, *pf_xs = nullptr; void* pf_xq = nullptr;
-    int use_mega = 0;                                  // option "use_mega": run single-GPU tokens as ONE persistent kernel (k_token); opt-in until it beats the per-phase kernels
-    GemvArgs* mega_gemv = nullptr; AttnArgs* mega_attn = nullptr; unsigned* mega_bar = nullptr; int* mega_err = nullptr;
     int use_prefill_mq = 1;                            // option "use_prefill_mq": batched prefill attention with 8 queries per workgroup (0: one query per workgroup)
     int fuse_attn_o = 1;                               // option "fuse_attn_o": attention + Wo GEMV in one launch (k_attn_o; single GPU)
-    size_t mega_lds = 0; int mega_ok = -1;              // -1 not built yet, 0 shape not supported by k_token, 1 ready
+    unsigned* flag_lines = nullptr; int* xwg_err = nullptr;   // k_attn_o: one 64-byte flag line per head; "a cross-workgroup wait timed out"
+    void* att_q = nullptr; float* att_qs = nullptr;    // k_attn_o: the heads' output already quantized (head_size a multiple of 64)
     int trace_class = -1; unsigned long long* trace = nullptr;   // FLM_ABLATE builds: GEMV timeline of one kernel class
     std::map<int, hipGraphExec_t> graphs;             // key = with_cls*4 + advance
     std::vector<TimedLaunch>* timing = nullptr;
@@ -225,14 +228,14 @@ int upload_window(flm_ctx* c, QMat& m, int dst_row0, int src_qt, const void* val
     const int qt = c->d.quant_type, gs = kGroup;
     if (ncols != m.cols) return fail(c, FLM_ERR_INVALID, "upload: column window does not match the device matrix");
     if (src_qt == FLM_QT_NONE) {
-        float* stage = nullptr;
-        HIPC(c, hipMalloc((void**)&stage, (size_t)nrows * ncols * sizeof(float)));
+        DevMem stage_mem;
+        HIPC(c, hipMalloc(&stage_mem.p, (size_t)nrows * ncols * sizeof(float)));
+        float* stage = (float*)stage_mem.p;
         HIPC(c, hipMemcpy2DAsync(stage, (size_t)ncols * 4, (const float*)values + (size_t)row0 * src_cols + col0, (size_t)src_cols * 4,
                                  (size_t)ncols * 4, nrows, hipMemcpyHostToDevice, c->stream));
         int r = quantize_flat(c, c->stream, qt, (char*)m.q + (size_t)dst_row0 * ncols * c->esz, m.s + (size_t)dst_row0 * (ncols / gs), stage, (size_t)nrows * ncols);
-        if (r) { hipFree(stage); return r; }
+        if (r) return r;
         HIPC(c, hipStreamSynchronize(c->stream));
-        HIPC(c, hipFree(stage));
         return FLM_OK;
     }
     if (src_qt != qt) return fail(c, FLM_ERR_INVALID, "upload: tensor quant type differs from the model's");
@@ -254,18 +257,20 @@ bool model_complete(const flm_ctx* c) {
     return true;
 }
 
-// k_token / k_attn_o report a wait that never completed (a workgroup was not resident) through *mega_err
-int mega_check(flm_ctx* c) {
-    if (c->world != 1 || (c->mega_ok != 1 && !c->fuse_attn_o)) return FLM_OK;
+// k_attn_o reports a cross-workgroup wait that never completed (a head workgroup was not resident: another process held
+// CUs) through *xwg_err.  The call's results are then invalid: the fused launch is switched off for the rest of this
+// context's life and FLM_RETRY tells the caller (inside this library) to run the call again on one kernel per phase.
+constexpr int FLM_RETRY = 1;
+int xwg_check(flm_ctx* c) {
+    if (c->world != 1 || !c->fuse_attn_o) return FLM_OK;
     int e = 0;
-    HIPC(c, hipMemcpy(&e, c->mega_err, 4, hipMemcpyDeviceToHost));
-    if (e) {   // fall back to the per-phase kernels for the rest of this context's life
-        hipMemset(c->mega_err, 0, 4); c->use_mega = 0; c->fuse_attn_o = 0;
-        for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
-        c->graphs.clear();
-        return fail(c, FLM_ERR_HIP, "a cross-workgroup wait timed out (workgroups not co-resident?); this call's results are invalid, later calls use one kernel per phase");
-    }
-    return FLM_OK;
+    HIPC(c, hipMemcpy(&e, c->xwg_err, 4, hipMemcpyDeviceToHost));
+    if (!e) return FLM_OK;
+    HIPC(c, hipMemset(c->xwg_err, 0, 4));
+    c->fuse_attn_o = 0;
+    for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
+    c->graphs.clear();
+    return FLM_RETRY;
 }
 
 struct Tick {
@@ -330,39 +335,6 @@ GemvArgs args_cls(flm_ctx* c) {
     return a;
 }
 
-// device-resident argument tables of k_token, built once per context (and again when an option changes)
-template <int QT>
-int build_mega(flm_ctx* c) {
-    const auto& d = c->d;
-    const int L = d.n_layers, wgs = c->cu_count;
-    c->mega_ok = 0;
-    if (c->world != 1 || d.dim > kNormRounds * kGemvBlock * 4 || d.n_heads > 65535 || wgs > 512) return FLM_OK;
-    std::vector<GemvArgs> g((size_t)4 * L + 1);
-    std::vector<AttnArgs> at(L);
-    size_t lds = attn_lds_bytes(d.max_seq_len, c->hs);
-    GemvPlan P; int r;
-    for (int l = 0; l < L; ++l) {
-        g[4 * l + 0] = args_qkv(c, l);   r = plan_gemv<QT, PRO_RMSNORM_QUANT, EPI_ROPE_KV>(c, g[4 * l + 0], wgs, P); if (r) return r; if (P.lds > lds) lds = P.lds;
-        g[4 * l + 1] = args_o(c, l);     r = plan_gemv<QT, PRO_QUANT, EPI_RESIDUAL>(c, g[4 * l + 1], wgs, P);        if (r) return r; if (P.lds > lds) lds = P.lds;
-        g[4 * l + 2] = args_ffn13(c, l); r = plan_gemv<QT, PRO_RMSNORM_QUANT, EPI_SWIGLU>(c, g[4 * l + 2], wgs, P);  if (r) return r; if (P.lds > lds) lds = P.lds;
-        g[4 * l + 3] = args_ffn2(c, l);  r = plan_gemv<QT, PRO_QUANT, EPI_RESIDUAL>(c, g[4 * l + 3], wgs, P);        if (r) return r; if (P.lds > lds) lds = P.lds;
-        at[l] = args_attn(c, l);
-    }
-    g[4 * L] = args_cls(c); r = plan_gemv<QT, PRO_RMSNORM_QUANT, EPI_STORE>(c, g[4 * L], wgs, P); if (r) return r; if (P.lds > lds) lds = P.lds;
-    if (lds < 84 * 1024) lds = 84 * 1024;                 // more than half of the CU's LDS: at most ONE workgroup per CU, so all of them are resident
-    lds = (lds + 15) / 16 * 16 + 16;                       // the step counters of all phases at one fixed place (the phases' own layouts differ): consecutive phases alternate
-    for (size_t i = 0; i < g.size(); ++i) g[i].ctr_off = (int)(lds - 16 + 4 * (i & 1));
-    if (!c->mega_gemv) {
-        HIPC(c, hipMalloc((void**)&c->mega_gemv, g.size() * sizeof(GemvArgs)));
-        HIPC(c, hipMalloc((void**)&c->mega_attn, at.size() * sizeof(AttnArgs)));
-    }
-    HIPC(c, hipMemcpy(c->mega_gemv, g.data(), g.size() * sizeof(GemvArgs), hipMemcpyHostToDevice));
-    HIPC(c, hipMemcpy(c->mega_attn, at.data(), at.size() * sizeof(AttnArgs), hipMemcpyHostToDevice));
-    HIPC(c, hipFuncSetAttribute((const void*)k_token<QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    c->mega_lds = lds; c->mega_ok = 1;
-    return FLM_OK;
-}
-
 // attention + Wo GEMV of layer l in one launch (k_attn_o); returns FLM_ERR_UNSUPPORTED when the shape does not allow it
 template <int QT>
 int launch_attn_o(flm_ctx* c, hipStream_t st, int l) {
@@ -370,17 +342,24 @@ int launch_attn_o(flm_ctx* c, hipStream_t st, int l) {
     const int heads = c->heads_local, wgs = c->cu_count - heads;
     if (wgs < 1 || heads > 512) return FLM_ERR_UNSUPPORTED;
     GemvArgs a = args_o(c, l);
-    if (c->trace_class == 101 && l == 0) a.trace = c->trace;     // tools/trace_ao.py
+    if (kAblate && c->trace_class == 101 && l == 0) a.trace = c->trace;     // tools/trace_ao.py
     GemvPlan P;
     int r = plan_gemv<QT, PRO_QUANT, EPI_RESIDUAL>(c, a, wgs, P); if (r) return r;
     const int rounds = (a.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4);
     if (rounds > 3) return FLM_ERR_UNSUPPORTED;
     size_t lds = attn_lds_bytes(d.max_seq_len, c->hs); if (P.lds > lds) lds = P.lds;
-    const AttnArgs aa = args_attn(c, l);
-    unsigned* flag = c->mega_bar;                                // one 64-byte line per head, value = layer + 1; k_embed clears them at the start of the token
+    AttnArgs aa = args_attn(c, l);
+    unsigned* flag = c->flag_lines;                              // one 64-byte line per head, value = layer + 1; k_embed clears them at the start of the token
     const dim3 grid(heads + P.grid), block(kGemvBlock);
-    if (rounds <= 1) hipLaunchKernelGGL((k_attn_o<QT, 1>), grid, block, lds, st, aa, a, heads, flag, (unsigned)(l + 1), c->mega_err);
-    else             hipLaunchKernelGGL((k_attn_o<QT, 3>), grid, block, lds, st, aa, a, heads, flag, (unsigned)(l + 1), c->mega_err);
+    if (c->hs % kGroup == 0) {
+        // a head's output is whole quant groups: the head workgroups quantize it themselves (A3 on the 64 values a wave
+        // holds), the GEMV workgroups fetch 1 (2) bytes per element and skip the quantize prologue
+        aa.oq = c->att_q; aa.os = c->att_qs; aa.oqt = QT;
+        a.xq = c->att_q; a.xs = c->att_qs;
+        hipLaunchKernelGGL((k_attn_o<QT, 0, true>), grid, block, lds, st, aa, a, heads, flag, (unsigned)(l + 1), c->xwg_err);
+    }
+    else if (rounds <= 1) hipLaunchKernelGGL((k_attn_o<QT, 1, false>), grid, block, lds, st, aa, a, heads, flag, (unsigned)(l + 1), c->xwg_err);
+    else                  hipLaunchKernelGGL((k_attn_o<QT, 3, false>), grid, block, lds, st, aa, a, heads, flag, (unsigned)(l + 1), c->xwg_err);
     HIPC(c, hipGetLastError());
     return FLM_OK;
 }
@@ -391,20 +370,12 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance) {
     const bool tp = c->world > 1;
     {
         Tick t(c, st, KC_EMBED);
-        hipLaunchKernelGGL(k_embed, dim3((d.dim + 255) / 256), dim3(256), 0, st, c->x1, (const void*)c->emb, (const float*)c->emb_s, c->emb_qt, d.dim, (const int*)&c->state->tok, c->mega_bar);
+        hipLaunchKernelGGL(k_embed, dim3((d.dim + 255) / 256), dim3(256), 0, st, c->x1, (const void*)c->emb, (const float*)c->emb_s, c->emb_qt, d.dim, (const int*)&c->state->tok, c->flag_lines);
         HIPC(c, hipGetLastError());
     }
-    const bool mega = c->use_mega && !tp && !c->timing && c->mega_ok == 1;   // tables built by check_ready (never inside a stream capture)
-    if (mega) {
-        // the whole token as ONE persistent kernel: grid barriers instead of kernel boundaries
-        TokenArgs t{}; t.gemv = c->mega_gemv; t.attn = c->mega_attn; t.n_layers = L; t.n_heads = c->heads_local; t.with_cls = with_cls ? 1 : 0;
-        t.bar = c->mega_bar; t.err = c->mega_err; t.trace = c->trace_class == 100 ? c->trace : nullptr;
-        if (qt == FLM_QT_INT8) hipLaunchKernelGGL(k_token<QT_INT8>, dim3(c->cu_count), dim3(kGemvBlock), c->mega_lds, st, t);
-        else                   hipLaunchKernelGGL(k_token<QT_INT16>, dim3(c->cu_count), dim3(kGemvBlock), c->mega_lds, st, t);
-        HIPC(c, hipGetLastError());
-    } else {
+    {
         const int wgs = gemv_grid(c->cu_count, c->wg_per_cu, 0, 0);
-        auto traced = [&](GemvArgs a, int kc, int l) { if (c->trace_class == kc && l == 0) a.trace = c->trace; return a; };
+        auto traced = [&](GemvArgs a, int kc, int l) { if (kAblate && c->trace_class == kc && l == 0) a.trace = c->trace; return a; };
         for (int l = 0; l < L; ++l) {
             {   // QKV task + RoPE + KV append (transformer.cpp:132-135, execute_qkv :386-395, execute_attn :431-439)
                 Tick t(c, st, KC_QKV);
@@ -417,7 +388,7 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance) {
             }
             if (!fused) {   // ATTN task (execute_attn :441-449): local heads write their slice of the full att_out vector
                 Tick t(c, st, KC_ATTN);
-                AttnArgs aa = args_attn(c, l); if (c->trace_class == KC_ATTN && l == 0) aa.trace = c->trace;
+                AttnArgs aa = args_attn(c, l); if (kAblate && c->trace_class == KC_ATTN && l == 0) aa.trace = c->trace;
                 hipLaunchKernelGGL(k_attn_decode, dim3(c->heads_local), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, hs), st, aa);
                 HIPC(c, hipGetLastError());
             }
@@ -492,50 +463,15 @@ int run_token(flm_ctx* c, bool with_cls, int advance) {
     return FLM_OK;
 }
 
-int ensure_token_bufs(flm_ctx* c, int n_prompt, int n_out) {
-    if (n_prompt > c->prompt_cap) {
-        if (c->prompt_dev) hipFree(c->prompt_dev);
-        c->prompt_cap = n_prompt < 1024 ? 1024 : n_prompt;
-        HIPC(c, hipMalloc((void**)&c->prompt_dev, sizeof(int) * c->prompt_cap));
-        for (auto& g : c->graphs) hipGraphExecDestroy(g.second);     // graphs captured the old pointer
-        c->graphs.clear();
-    }
-    if (n_out > c->out_cap) {
-        if (c->out_tokens_dev) hipFree(c->out_tokens_dev);
-        c->out_cap = n_out < 4096 ? 4096 : n_out;
-        HIPC(c, hipMalloc((void**)&c->out_tokens_dev, sizeof(int) * c->out_cap));
-        for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
-        c->graphs.clear();
-    }
-    return FLM_OK;
-}
-
-int check_ready(flm_ctx* c, int n, int pos) {
-    if (!c) return FLM_ERR_INVALID;
-    if (!model_complete(c)) return fail(c, FLM_ERR_STATE, "forward before all tensors were uploaded");
-    if (n < 1 || pos < 0 || pos + n > c->d.max_seq_len) return fail(c, FLM_ERR_INVALID, "tokens/pos outside [0, max_seq_len]");
-    HIPC(c, hipSetDevice(c->device));
-    if (c->mega_ok < 0 && c->use_mega && c->world == 1) {
-        int r = c->d.quant_type == FLM_QT_INT8 ? build_mega<QT_INT8>(c) : build_mega<QT_INT16>(c);
-        if (r) return r;
-    }
-    return FLM_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Batched prefill of B prompt tokens at positions pos .. pos+B-1 (single GPU): leaves their K/V rows in the cache, exactly
-// the rows the token-by-token path would write (flm_kernels.h, "Batched prefill").  The prompt's LAST token is not part
-// of the batch: it runs through the decode kernels and produces the logits.
-// ---------------------------------------------------------------------------------------------
-constexpr int kPrefillMin = 4;
-
-int ensure_prefill_bufs(flm_ctx* c, int B) {
-    if (B <= c->pf_cap) return FLM_OK;
-    void* old[] = {c->pf_x, c->pf_qkv, c->pf_q, c->pf_att, c->pf_gu, c->pf_hd, c->pf_xs, c->pf_xq};
-    for (void* p : old) if (p) hipFree(p);
-    c->pf_x = c->pf_qkv = c->pf_q = c->pf_att = c->pf_gu = c->pf_hd = c->pf_xs = nullptr; c->pf_xq = nullptr; c->pf_cap = 0;
+// Everything a forward needs is allocated at flm_ctx_create ("zero allocations during inference", reference README and
+// transformer.cpp:110-130): the prompt / output id buffers and the batched-prefill activations are sized by max_seq_len.
+int alloc_run_bufs(flm_ctx* c) {
     const auto& d = c->d;
-    const size_t cap = B < 64 ? 64 : (size_t)B, nmax = d.hidden_dim > d.dim ? d.hidden_dim : d.dim;
+    c->prompt_cap = d.max_seq_len; c->out_cap = d.max_seq_len;
+    HIPC(c, hipMalloc((void**)&c->prompt_dev, sizeof(int) * c->prompt_cap));
+    HIPC(c, hipMalloc((void**)&c->out_tokens_dev, sizeof(int) * c->out_cap));
+    if (c->world != 1) return FLM_OK;                                    // batched prefill is single-GPU
+    const size_t cap = d.max_seq_len < 64 ? 64 : (size_t)d.max_seq_len, nmax = d.hidden_dim > d.dim ? d.hidden_dim : d.dim;
     HIPC(c, hipMalloc((void**)&c->pf_x, cap * d.dim * 4));
     HIPC(c, hipMalloc((void**)&c->pf_qkv, cap * 3 * d.dim * 4));
     HIPC(c, hipMalloc((void**)&c->pf_q, cap * d.dim * 4));
@@ -548,6 +484,30 @@ int ensure_prefill_bufs(flm_ctx* c, int B) {
     return FLM_OK;
 }
 
+// decode state <- {pos, tok, step}: by value through a one-thread kernel (an async copy from a host stack frame would be
+// read after the frame is gone)
+__global__ void k_set_state(DecodeState* st, int pos, int tok, int step) { if (threadIdx.x == 0 && blockIdx.x == 0) { st->pos = pos; st->tok = tok; st->step = step; st->pad = 0; } }
+int set_state(flm_ctx* c, int pos, int tok, int step) {
+    hipLaunchKernelGGL(k_set_state, dim3(1), dim3(64), 0, c->stream, c->state, pos, tok, step);
+    HIPC(c, hipGetLastError());
+    return FLM_OK;
+}
+
+int check_ready(flm_ctx* c, int n, int pos) {
+    if (!c) return FLM_ERR_INVALID;
+    if (!model_complete(c)) return fail(c, FLM_ERR_STATE, "forward before all tensors were uploaded");
+    if (n < 1 || pos < 0 || pos + n > c->d.max_seq_len) return fail(c, FLM_ERR_INVALID, "tokens/pos outside [0, max_seq_len]");
+    HIPC(c, hipSetDevice(c->device));
+    return FLM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Batched prefill of B prompt tokens at positions pos .. pos+B-1 (single GPU): leaves their K/V rows in the cache, exactly
+// the rows the token-by-token path would write (flm_kernels.h, "Batched prefill").  The prompt's LAST token is not part
+// of the batch: it runs through the decode kernels and produces the logits.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPrefillMin = 4;
+
 template <int QT, int PRO>
 int launch_rows(flm_ctx* c, hipStream_t st, const RowsArgs& r, int B) {
     const size_t lds = (size_t)gemv_lds_layout(r.n, QTraits<QT>::kEsz, true, 4, 4, false).total;
@@ -558,12 +518,13 @@ int launch_rows(flm_ctx* c, hipStream_t st, const RowsArgs& r, int B) {
     HIPC(c, hipGetLastError());
     return FLM_OK;
 }
+// use_mfma: 0 the v_dot tile kernel, 1 matrix cores (128 x 128 tiles from 768 tokens on), 2 matrix cores, 64 x 64 tiles always
 template <int QT, int EPI>
-int launch_gemm(flm_ctx* c, hipStream_t st, const GemmArgs& g) {
+int launch_gemm(flm_ctx* c, hipStream_t st, const GemmArgs& g, int use_mfma) {
     const int tiles = ((g.rows + 63) / 64) * ((g.B + 63) / 64);
-    if (QT == QT_INT8 && c->use_mfma) {   // matrix cores: exact int32 group dots
-        if (g.B >= 768 && c->use_mfma != 2) {   // 128 x 128 tiles: half the bytes per product through the CU's memory pipeline; pays for long prompts only
-                                                  // (measured, 4 layers of 7B width: 1000 tokens 5.99 vs 6.49 ms, 512 tokens 3.33 vs 3.05 ms); "use_mfma" 2: 64 x 64 always
+    if (QT == QT_INT8 && use_mfma) {   // matrix cores: exact int32 group dots
+        if (g.B >= 768 && use_mfma != 2) {   // 128 x 128 tiles: half the bytes per product through the CU's memory pipeline; pays for long prompts only
+                                              // (measured, 4 layers of 7B width: 1000 tokens 5.99 vs 6.49 ms, 512 tokens 3.33 vs 3.05 ms)
             const int tiles128 = ((g.rows + 127) / 128) * ((g.B + 127) / 128);
             hipLaunchKernelGGL((k_gemm_q8_mfma<EPI, 4>), dim3(tiles128), dim3(1024), 0, st, g);
         } else hipLaunchKernelGGL((k_gemm_q8_mfma<EPI, 2>), dim3(tiles), dim3(256), 0, st, g);
@@ -578,7 +539,7 @@ int prefill_batched(flm_ctx* c, int B, int pos) {
     const auto& d = c->d;
     const int L = d.n_layers, dim = d.dim, hid = d.hidden_dim, hs = c->hs;
     hipStream_t st = c->stream;
-    int r = ensure_prefill_bufs(c, B); if (r) return r;
+    int r = B <= c->pf_cap ? FLM_OK : fail(c, FLM_ERR_INVALID, "prefill: more tokens than max_seq_len"); if (r) return r;
     const size_t kv_layer = (size_t)c->heads_local * d.max_seq_len * hs;
     hipLaunchKernelGGL(k_embed_rows, dim3(B), dim3(256), 0, st, c->pf_x, (const void*)c->emb, (const float*)c->emb_s, c->emb_qt, dim, (const int*)c->prompt_dev);
     HIPC(c, hipGetLastError());
@@ -588,7 +549,7 @@ int prefill_batched(flm_ctx* c, int B, int pos) {
         RowsArgs ra{c->pf_x, w.att_norm, c->pf_xq, c->pf_xs, dim};
         r = launch_rows<QT, PRO_RMSNORM_QUANT>(c, st, ra, B); if (r) return r;
         GemmArgs g{w.qkv.q, w.qkv.s, c->pf_xq, c->pf_xs, c->pf_qkv, 3 * dim, dim, 3 * dim, B};
-        r = launch_gemm<QT, EPI_STORE>(c, st, g); if (r) return r;
+        r = launch_gemm<QT, EPI_STORE>(c, st, g, c->use_mfma); if (r) return r;
         hipLaunchKernelGGL(k_rope_kv_rows, dim3(B), dim3(256), 0, st, (const float*)c->pf_qkv, c->pf_q, c->kcache + (size_t)l * kv_layer, c->vcache + (size_t)l * kv_layer,
                            (const float*)c->rope_cos, (const float*)c->rope_sin, dim, hs, d.max_seq_len, pos);
         HIPC(c, hipGetLastError());
@@ -605,19 +566,19 @@ int prefill_batched(flm_ctx* c, int B, int pos) {
         RowsArgs rq{c->pf_att, nullptr, c->pf_xq, c->pf_xs, dim};
         r = launch_rows<QT, PRO_QUANT>(c, st, rq, B); if (r) return r;
         GemmArgs go{w.o.q, w.o.s, c->pf_xq, c->pf_xs, c->pf_x, dim, dim, dim, B};
-        r = launch_gemm<QT, EPI_RESIDUAL>(c, st, go); if (r) return r;
+        r = launch_gemm<QT, EPI_RESIDUAL>(c, st, go, c->use_mfma); if (r) return r;
         // hd = swiglu(W1 qx, W3 qx) with qx = quantize(rmsnorm(x1))   (transformer.cpp:144-147, 468-483)
         RowsArgs rf{c->pf_x, w.ffn_norm, c->pf_xq, c->pf_xs, dim};
         r = launch_rows<QT, PRO_RMSNORM_QUANT>(c, st, rf, B); if (r) return r;
         GemmArgs g13{w.w13.q, w.w13.s, c->pf_xq, c->pf_xs, c->pf_gu, 2 * hid, dim, 2 * hid, B};
-        r = launch_gemm<QT, EPI_STORE>(c, st, g13); if (r) return r;
+        r = launch_gemm<QT, EPI_STORE>(c, st, g13, c->use_mfma); if (r) return r;
         hipLaunchKernelGGL(k_swiglu_rows, dim3(B), dim3(256), 0, st, c->pf_hd, (const float*)c->pf_gu, hid);
         HIPC(c, hipGetLastError());
         // x1 += W2 quantize(hd)   (transformer.cpp:149-150, 485-494)
         RowsArgs rh{c->pf_hd, nullptr, c->pf_xq, c->pf_xs, hid};
         r = launch_rows<QT, PRO_QUANT>(c, st, rh, B); if (r) return r;
         GemmArgs g2{w.w2.q, w.w2.s, c->pf_xq, c->pf_xs, c->pf_x, dim, hid, dim, B};
-        r = launch_gemm<QT, EPI_RESIDUAL>(c, st, g2); if (r) return r;
+        r = launch_gemm<QT, EPI_RESIDUAL>(c, st, g2, c->use_mfma); if (r) return r;
     }
     return FLM_OK;
 }
@@ -625,20 +586,18 @@ int prefill_batched(flm_ctx* c, int B, int pos) {
 // feed tokens[0..n) sequentially (row i of the reference's batched prefill depends only on rows
 // <= i through the KV cache, so token-by-token evaluation performs the same per-row arithmetic).
 int feed(flm_ctx* c, const int32_t* tokens, int n, int pos, int final_advance) {
-    int r = ensure_token_bufs(c, n, 1);
-    if (r) return r;
+    int r;
+    if (n > c->prompt_cap) return fail(c, FLM_ERR_INVALID, "more tokens than max_seq_len");
     for (int i = 0; i < n; ++i) if (tokens[i] < 0 || tokens[i] >= c->d.vocab_size) return fail(c, FLM_ERR_INVALID, "token id out of range");
-    HIPC(c, hipMemcpyAsync(c->prompt_dev, tokens, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(c->prompt_dev, tokens, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));   // (the caller's buffer outlives the call: every entry point synchronises)
     if (c->use_prefill && c->world == 1 && n - 1 >= kPrefillMin && c->hidden_local == c->d.hidden_dim) {
         // all tokens but the last in one batch (cache rows only), then the last one through the decode kernels
         r = c->d.quant_type == FLM_QT_INT8 ? prefill_batched<QT_INT8>(c, n - 1, pos) : prefill_batched<QT_INT16>(c, n - 1, pos);
         if (r) return r;
-        DecodeState s{pos + n - 1, tokens[n - 1], 0, 0};
-        HIPC(c, hipMemcpyAsync(c->state, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
+        r = set_state(c, pos + n - 1, tokens[n - 1], 0); if (r) return r;
         return run_token(c, true, final_advance);
     }
-    DecodeState s{pos, tokens[0], 0, 0};
-    HIPC(c, hipMemcpyAsync(c->state, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
+    r = set_state(c, pos, tokens[0], 0); if (r) return r;
     for (int i = 0; i + 1 < n; ++i) { r = run_token(c, false, 2); if (r) return r; }
     // last token: classifier; state.step is reset so out_tokens[0] receives the argmax
     if (n > 1) {
@@ -748,15 +707,16 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
     HIPB(hipMalloc((void**)&c->hd, d.hidden_dim * 4));
     HIPB(hipMalloc((void**)&c->logits, (size_t)c->vocab_slot * world * 4));
     HIPB(hipMemsetAsync(c->logits, 0, (size_t)c->vocab_slot * world * 4, c->stream));
-    HIPB(hipMalloc((void**)&c->mega_bar, 512 * 64)); HIPB(hipMalloc((void**)&c->mega_err, 64));
-    HIPB(hipMemsetAsync(c->mega_bar, 0, 512 * 64, c->stream)); HIPB(hipMemsetAsync(c->mega_err, 0, 64, c->stream));
+    HIPB(hipMalloc((void**)&c->flag_lines, 512 * 64)); HIPB(hipMalloc((void**)&c->xwg_err, 64));
+    HIPB(hipMemsetAsync(c->flag_lines, 0, 512 * 64, c->stream)); HIPB(hipMemsetAsync(c->xwg_err, 0, 64, c->stream));
+    HIPB(hipMalloc(&c->att_q, (size_t)d.dim * c->esz)); HIPB(hipMalloc((void**)&c->att_qs, (size_t)(d.dim / kGroup) * 4));
     HIPB(hipMalloc((void**)&c->state, sizeof(DecodeState)));
     HIPB(hipMemsetAsync(c->state, 0, sizeof(DecodeState), c->stream));
     std::vector<float> cs, sn; build_rope_table(hs, d.max_seq_len, cs, sn);
     HIPB(hipMalloc((void**)&c->rope_cos, cs.size() * 4)); HIPB(hipMalloc((void**)&c->rope_sin, sn.size() * 4));
     HIPB(hipMemcpy(c->rope_cos, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
     HIPB(hipMemcpy(c->rope_sin, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
-    if (ensure_token_bufs(c, 1, 1)) return bail(FLM_ERR_OOM);
+    if (alloc_run_bufs(c)) return bail(FLM_ERR_OOM);
     HIPB(hipStreamSynchronize(c->stream));
 #undef HIPB
     *out = c;
@@ -773,7 +733,7 @@ void flm_ctx_destroy(flm_ctx* c) {
     fq(c->cls);
     void* ptrs[] = {c->emb, c->emb_s, c->out_norm, c->kcache, c->vcache, c->x1, c->qbuf, c->att_out, c->hd,
                     c->logits, c->rope_cos, c->rope_sin, c->state, c->prompt_dev, c->out_tokens_dev,
-                    c->mega_gemv, c->mega_attn, c->mega_bar, c->mega_err, c->trace,
+                    c->flag_lines, c->xwg_err, c->att_q, c->att_qs, c->trace,
                     c->pf_x, c->pf_qkv, c->pf_q, c->pf_att, c->pf_gu, c->pf_hd, c->pf_xs, c->pf_xq};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->comm) ncclCommDestroy(c->comm);
@@ -786,13 +746,12 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     std::string k(key);
     if (k == "wg_per_cu") { c->wg_per_cu = value > 0 ? value : 1; }
     else if (k == "use_graph") c->use_graph = value;
-    else if (k == "ablate") { c->ablate = value; c->mega_ok = -1; }
-    else if (k == "use_mega") c->use_mega = value;
     else if (k == "use_prefill") c->use_prefill = value;
     else if (k == "use_mfma") c->use_mfma = value;
     else if (k == "fuse_attn_o") c->fuse_attn_o = value;
     else if (k == "use_prefill_mq") c->use_prefill_mq = value;
-    else if (k == "trace") {        // value = kernel class to trace (KC_*), -1 off; meaningful in FLM_ABLATE builds only
+    else if (kAblate && k == "ablate") c->ablate = value;              // FLM_ABLATE builds only: a product library cannot skip work
+    else if (kAblate && k == "trace") {   // value = kernel class to trace (KC_*), -1 off
         c->trace_class = value;
         if (!c->trace) { HIPC(c, hipMalloc((void**)&c->trace, 4096 * 8 * 8)); }
         HIPC(c, hipMemset(c->trace, 0, 4096 * 8 * 8));
@@ -906,30 +865,38 @@ int flm_debug_read(flm_ctx* c, int what, int layer, float* out, size_t n) {
 
 int flm_sync(flm_ctx* c) { if (!c) return FLM_ERR_INVALID; HIPC(c, hipSetDevice(c->device)); HIPC(c, hipStreamSynchronize(c->stream)); return FLM_OK; }
 
+// Every entry point below runs its work and then looks at the cross-workgroup error flag (xwg_check); if a hand-off
+// inside the fused attention + Wo launch timed out, the SAME work runs again on one kernel per phase: the cache rows
+// and logits of the failed attempt are simply overwritten, and the caller gets correct results and FLM_OK.
 int flm_forward(flm_ctx* c, const int32_t* tokens, int n, int pos, float* logits_host) {
     if (!tokens || !logits_host) return FLM_ERR_INVALID;
     int r = check_ready(c, n, pos); if (r) return r;
-    r = feed(c, tokens, n, pos, 0); if (r) return r;
-    HIPC(c, hipMemcpyAsync(logits_host, c->logits, (size_t)c->d.vocab_size * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
-    return mega_check(c);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        r = feed(c, tokens, n, pos, 0); if (r) return r;
+        HIPC(c, hipMemcpyAsync(logits_host, c->logits, (size_t)c->d.vocab_size * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
+        r = xwg_check(c); if (r != FLM_RETRY) return r;
+    }
+    return fail(c, FLM_ERR_HIP, "cross-workgroup wait timed out twice");
 }
 
 int flm_forward_argmax(flm_ctx* c, const int32_t* tokens, int n, int pos, int32_t* next_token) {
     if (!tokens || !next_token) return FLM_ERR_INVALID;
     int r = check_ready(c, n, pos); if (r) return r;
-    r = feed(c, tokens, n, pos, 1); if (r) return r;
-    HIPC(c, hipMemcpyAsync(next_token, c->out_tokens_dev, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
-    return mega_check(c);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        r = feed(c, tokens, n, pos, 1); if (r) return r;
+        HIPC(c, hipMemcpyAsync(next_token, c->out_tokens_dev, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
+        r = xwg_check(c); if (r != FLM_RETRY) return r;
+    }
+    return fail(c, FLM_ERR_HIP, "cross-workgroup wait timed out twice");
 }
 
 static int decode_loop(flm_ctx* c, int32_t first_token, int pos, int n_steps, hipEvent_t e0, hipEvent_t e1) {
     int r = check_ready(c, n_steps, pos); if (r) return r;
     if (first_token < 0 || first_token >= c->d.vocab_size) return fail(c, FLM_ERR_INVALID, "token id out of range");
-    r = ensure_token_bufs(c, 1, n_steps); if (r) return r;
-    DecodeState s{pos, first_token, 0, 0};
-    HIPC(c, hipMemcpyAsync(c->state, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
+    if (n_steps > c->out_cap) return fail(c, FLM_ERR_INVALID, "more steps than max_seq_len");
+    r = set_state(c, pos, first_token, 0); if (r) return r;
     if (e0) HIPC(c, hipEventRecord(e0, c->stream));
     for (int i = 0; i < n_steps; ++i) { r = run_token(c, true, 1); if (r) return r; }
     if (e1) HIPC(c, hipEventRecord(e1, c->stream));
@@ -938,20 +905,54 @@ static int decode_loop(flm_ctx* c, int32_t first_token, int pos, int n_steps, hi
 
 int flm_decode_greedy(flm_ctx* c, int32_t first_token, int pos, int n_steps, int32_t* out_tokens) {
     if (!out_tokens) return FLM_ERR_INVALID;
-    int r = decode_loop(c, first_token, pos, n_steps, nullptr, nullptr); if (r) return r;
-    HIPC(c, hipMemcpyAsync(out_tokens, c->out_tokens_dev, sizeof(int) * n_steps, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
-    return mega_check(c);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        int r = decode_loop(c, first_token, pos, n_steps, nullptr, nullptr); if (r) return r;
+        HIPC(c, hipMemcpyAsync(out_tokens, c->out_tokens_dev, sizeof(int) * n_steps, hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
+        r = xwg_check(c); if (r != FLM_RETRY) return r;
+    }
+    return fail(c, FLM_ERR_HIP, "cross-workgroup wait timed out twice");
 }
 
 int flm_decode_timed(flm_ctx* c, int32_t first_token, int pos, int n_steps, float* ms) {
     if (!ms || !c) return FLM_ERR_INVALID;
     HIPC(c, hipSetDevice(c->device));
-    hipEvent_t e0, e1; HIPC(c, hipEventCreate(&e0)); HIPC(c, hipEventCreate(&e1));
-    int r = decode_loop(c, first_token, pos, n_steps, e0, e1);
-    if (!r) { hipError_t e = hipEventSynchronize(e1); if (e == hipSuccess) e = hipEventElapsedTime(ms, e0, e1); if (e != hipSuccess) { c->err = hipGetErrorString(e); r = FLM_ERR_HIP; } }
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    return r ? r : mega_check(c);
+    EvPair ev; HIPC(c, hipEventCreate(&ev.e0)); HIPC(c, hipEventCreate(&ev.e1));
+    int r = FLM_OK;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        r = decode_loop(c, first_token, pos, n_steps, ev.e0, ev.e1);
+        if (!r) { hipError_t e = hipEventSynchronize(ev.e1); if (e == hipSuccess) e = hipEventElapsedTime(ms, ev.e0, ev.e1); if (e != hipSuccess) { c->err = hipGetErrorString(e); r = FLM_ERR_HIP; } }
+        if (!r) r = xwg_check(c);
+        if (r != FLM_RETRY) break;
+    }
+    return r == FLM_RETRY ? fail(c, FLM_ERR_HIP, "cross-workgroup wait timed out twice") : r;
+}
+
+// the ids the last flm_decode_greedy / flm_decode_timed* call generated (still in device memory): out[n]
+int flm_last_tokens(flm_ctx* c, int n, int32_t* out) {
+    if (!c || !out || n < 1 || n > c->out_cap) return FLM_ERR_INVALID;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipMemcpyAsync(out, c->out_tokens_dev, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return FLM_OK;
+}
+
+// the same loop with an event after every token: ms_each[n_steps] (for a median; the events cost a few us per token, so the
+// headline figure comes from flm_decode_timed)
+int flm_decode_timed_each(flm_ctx* c, int32_t first_token, int pos, int n_steps, float* ms_each) {
+    if (!ms_each || !c || n_steps < 1) return FLM_ERR_INVALID;
+    int r = check_ready(c, n_steps, pos); if (r) return r;
+    if (first_token < 0 || first_token >= c->d.vocab_size || n_steps > c->out_cap) return fail(c, FLM_ERR_INVALID, "token id / steps out of range");
+    struct Evs { std::vector<hipEvent_t> e; ~Evs() { for (auto x : e) if (x) hipEventDestroy(x); } } ev;
+    ev.e.assign((size_t)n_steps + 1, nullptr);
+    for (auto& x : ev.e) HIPC(c, hipEventCreate(&x));
+    r = set_state(c, pos, first_token, 0); if (r) return r;
+    HIPC(c, hipEventRecord(ev.e[0], c->stream));
+    for (int i = 0; i < n_steps; ++i) { r = run_token(c, true, 1); if (r) return r; HIPC(c, hipEventRecord(ev.e[i + 1], c->stream)); }
+    HIPC(c, hipEventSynchronize(ev.e[n_steps]));
+    for (int i = 0; i < n_steps; ++i) HIPC(c, hipEventElapsedTime(&ms_each[i], ev.e[i], ev.e[i + 1]));
+    r = xwg_check(c);
+    return r == FLM_RETRY ? fail(c, FLM_ERR_HIP, "cross-workgroup wait timed out while timing") : r;
 }
 
 // Per-class kernel time, measured live with HIP events on the ctx stream.  Single GPU: for each class the L launches
@@ -964,11 +965,9 @@ int flm_kernel_times(flm_ctx* c, int pos, int iters, float* avg_us, int32_t* cou
     if (!avg_us || !count || iters < 1) return FLM_ERR_INVALID;
     int r = check_ready(c, 1, pos); if (r) return r;
     double tot[FLM_KCLASSES] = {0}; long cnt[FLM_KCLASSES] = {0};
-    r = ensure_token_bufs(c, 1, 1); if (r) return r;
     if (c->world > 1) {
         for (int it = 0; it < iters + 1; ++it) {
-            DecodeState s{pos, 1 % c->d.vocab_size, 0, 0};
-            HIPC(c, hipMemcpyAsync(c->state, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
+            r = set_state(c, pos, 1 % c->d.vocab_size, 0); if (r) return r;
             std::vector<TimedLaunch> tl; c->timing = &tl;
             r = enqueue_token(c, c->stream, true, 1);
             c->timing = nullptr;
@@ -986,19 +985,19 @@ int flm_kernel_times(flm_ctx* c, int pos, int iters, float* avg_us, int32_t* cou
     const auto& d = c->d;
     const int qt = d.quant_type, L = d.n_layers, wgs = gemv_grid(c->cu_count, c->wg_per_cu, 0, 0);
     hipStream_t st = c->stream;
-    DecodeState s{pos, 1 % d.vocab_size, 0, 0};
-    HIPC(c, hipMemcpyAsync(c->state, &s, sizeof s, hipMemcpyHostToDevice, st));
-    hipEvent_t e0, e1; HIPC(c, hipEventCreate(&e0)); HIPC(c, hipEventCreate(&e1));
+    r = set_state(c, pos, 1 % d.vocab_size, 0); if (r) return r;
+    EvPair ev; HIPC(c, hipEventCreate(&ev.e0)); HIPC(c, hipEventCreate(&ev.e1));
+    const hipEvent_t e0 = ev.e0, e1 = ev.e1;
     auto launch = [&](int kc, int l) -> int {
         switch (kc) {
-        case KC_EMBED:  hipLaunchKernelGGL(k_embed, dim3((d.dim + 255) / 256), dim3(256), 0, st, c->x1, (const void*)c->emb, (const float*)c->emb_s, c->emb_qt, d.dim, (const int*)&c->state->tok, c->mega_bar); return FLM_OK;
+        case KC_EMBED:  hipLaunchKernelGGL(k_embed, dim3((d.dim + 255) / 256), dim3(256), 0, st, c->x1, (const void*)c->emb, (const float*)c->emb_s, c->emb_qt, d.dim, (const int*)&c->state->tok, c->flag_lines); return FLM_OK;
         case KC_QKV:    return launch_gemv<PRO_RMSNORM_QUANT, EPI_ROPE_KV>(c, st, qt, args_qkv(c, l), wgs);
         case KC_ATTN:   hipLaunchKernelGGL(k_attn_decode, dim3(c->heads_local), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, c->hs), st, args_attn(c, l)); return FLM_OK;
         case KC_ATTN_O: return launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, args_o(c, l), wgs);
         case KC_FFN13:  return launch_gemv<PRO_RMSNORM_QUANT, EPI_SWIGLU>(c, st, qt, args_ffn13(c, l), wgs);
         case KC_FFN2:   return launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, args_ffn2(c, l), wgs);
         case KC_CLS:    return launch_gemv<PRO_RMSNORM_QUANT, EPI_STORE>(c, st, qt, args_cls(c), wgs);
-        case KC_ARGMAX: hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, st, (const float*)c->logits, d.vocab_size, c->state, c->out_tokens_dev, 0); return FLM_OK;
+        case KC_ARGMAX: hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, st, (const float*)c->logits, d.vocab_size, c->state, (int*)nullptr, 0); return FLM_OK;   // (no id is recorded: the step counter runs on)
         default: return FLM_OK;
         }
     };
@@ -1017,7 +1016,6 @@ int flm_kernel_times(flm_ctx* c, int pos, int iters, float* avg_us, int32_t* cou
         avg_us[kc] = cnt[kc] ? (float)(tot[kc] / cnt[kc]) : 0.f;
         count[kc] = per_layer ? L : 1;
     }
-    hipEventDestroy(e0); hipEventDestroy(e1);
     for (int k = 0; k < FLM_KCLASSES; ++k) if (k != KC_EMBED && (k < KC_QKV || k > KC_ARGMAX)) { avg_us[k] = 0.f; count[k] = 0; }
     if (r) return r;
     return flm_reset_kv(c);
@@ -1064,16 +1062,17 @@ int flm_op_quantize(int qt, void* qx, float* qs, const float* x, size_t n, int g
     return FLM_OK;
 }
 
-// square_sum (x86_simd.cpp:942-960) of x[n], n a multiple of 16: out6 = { wave-parallel total, sequential total, the 4 strided lanes }
+// square_sum (x86_simd.cpp:942-960) of x[n], n a multiple of 16: out6 = { speculative wave evaluation (sq_chain_spec), sequential total, the 4 strided lanes }
 int flm_op_square_sum(const float* x, size_t n, float* out6) {
-    if (!x || !out6 || n % 16 || n == 0 || n > 32768) return FLM_ERR_INVALID;
+    if (!x || !out6 || n % 16 || n == 0 || n > 16384) return FLM_ERR_INVALID;
     DevBuf dx, dout;
     if (dx.alloc(n * 4) || dout.alloc(16 * 4)) return FLM_ERR_OOM;
     OPC(hipMemcpy(dx.p, x, n * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_op_square_sum, dim3(1), dim3(256), (n + 32 + 64) * 4, 0, dout.as<float>(), dx.as<float>(), (int)n);
+    const size_t lds = ((size_t)4 * chain_strip_floats((int)n) + 4 * (n / 4 + 8)) * 4;
+    hipLaunchKernelGGL(k_op_square_sum, dim3(1), dim3(256), lds, 0, dout.as<float>(), dx.as<float>(), (int)n);
     OPC(hipGetLastError()); OPC(hipDeviceSynchronize());
     OPC(hipMemcpy(out6, dout.p, 6 * 4, hipMemcpyDeviceToHost));
-    if (getenv("FLM_SQ_ITERS")) { float it[4]; hipMemcpy(it, (char*)dout.p + 24, 16, hipMemcpyDeviceToHost); fprintf(stderr, "sq_chain_wave iterations per chain: %g %g %g %g\n", it[0], it[1], it[2], it[3]); }
+    if (getenv("FLM_SQ_ITERS")) { float it[4]; hipMemcpy(it, (char*)dout.p + 24, 16, hipMemcpyDeviceToHost); fprintf(stderr, "sq_chain_spec rounds per chain (-1: plain chain): %g %g %g %g\n", it[0], it[1], it[2], it[3]); }
     return FLM_OK;
 }
 
@@ -1099,13 +1098,35 @@ int flm_op_matmul_q(int qt, float* out, const void* W, const float* sW, const vo
     OPC(hipMemcpy(dW.p, W, (size_t)m * n * e, hipMemcpyHostToDevice)); OPC(hipMemcpy(dsW.p, sW, (size_t)m * sn * 4, hipMemcpyHostToDevice));
     OPC(hipMemcpy(dX.p, X, (size_t)w * n * e, hipMemcpyHostToDevice)); OPC(hipMemcpy(dsX.p, sX, (size_t)w * sn * 4, hipMemcpyHostToDevice));
     int dev = 0, cus = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    for (int b = 0; b < w; ++b) {
-        GemvArgs a{}; a.W = dW.p; a.sW = dsW.as<float>(); a.n = n; a.items = m;
-        a.xq = (const char*)dX.p + (size_t)b * n * e; a.xs = dsX.as<float>() + (size_t)b * sn; a.out = dO.as<float>() + (size_t)b * m;
-        int r = launch_gemv<PRO_NONE, EPI_STORE>(nullptr, 0, qt, a, gemv_grid(cus, 1, m, 1)); if (r) return r;
+    const char* gv = getenv("FLM_OP_GEMM");                     // tests: 0 / 1 / 2 = launch_gemm's use_mfma, "gemv" = a GEMV per batch row
+    if (w >= 16 && !(gv && !strcmp(gv, "gemv"))) {
+        // the batched path the prompt takes (quant::matmul with w > 1, quant_operators.cpp:252-284): one tile kernel
+        GemmArgs g{dW.p, dsW.as<float>(), dX.p, dsX.as<float>(), dO.as<float>(), m, n, m, w};
+        const int um = gv ? atoi(gv) : 1;
+        int r = qt == FLM_QT_INT8 ? launch_gemm<QT_INT8, EPI_STORE>(nullptr, 0, g, um) : launch_gemm<QT_INT16, EPI_STORE>(nullptr, 0, g, um);
+        if (r) return r;
+    } else {
+        for (int b = 0; b < w; ++b) {
+            GemvArgs a{}; a.W = dW.p; a.sW = dsW.as<float>(); a.n = n; a.items = m;
+            a.xq = (const char*)dX.p + (size_t)b * n * e; a.xs = dsX.as<float>() + (size_t)b * sn; a.out = dO.as<float>() + (size_t)b * m;
+            int r = launch_gemv<PRO_NONE, EPI_STORE>(nullptr, 0, qt, a, gemv_grid(cus, 1, m, 1)); if (r) return r;
+        }
     }
     OPC(hipDeviceSynchronize());
     OPC(hipMemcpy(out, dO.p, (size_t)w * m * 4, hipMemcpyDeviceToHost));
+    return FLM_OK;
+}
+
+/* sample_argmax (sampler.cpp:36-47) as k_argmax_advance evaluates it: first maximum wins */
+int flm_op_argmax(const float* logits, int n, int32_t* idx) {
+    if (!logits || !idx || n < 1) return FLM_ERR_INVALID;
+    DevBuf dl, dst, dout;
+    if (dl.alloc((size_t)n * 4) || dst.alloc(sizeof(DecodeState)) || dout.alloc(16)) return FLM_ERR_OOM;
+    OPC(hipMemcpy(dl.p, logits, (size_t)n * 4, hipMemcpyHostToDevice));
+    OPC(hipMemset(dst.p, 0, sizeof(DecodeState)));
+    hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, 0, (const float*)dl.as<float>(), n, dst.as<DecodeState>(), dout.as<int>(), 0);
+    OPC(hipGetLastError()); OPC(hipDeviceSynchronize());
+    OPC(hipMemcpy(idx, dout.p, 4, hipMemcpyDeviceToHost));
     return FLM_OK;
 }
 

@@ -19,17 +19,15 @@
 //   k_gemv<QT,PRO,EPI,XR> group-quantized GEMV, HBM-bound; fused prologue (rmsnorm+quantize | quantize)
 //                         and epilogue (store | residual add | SwiGLU | RoPE + KV-cache append)
 //   k_attn_decode         fp32 single-query attention over the fp32 KV cache
-//   k_attn_o<QT,XR>       attention heads and the Wo GEMV in one launch (single GPU)
+//   k_attn_o<QT,XR,PREQ>  attention heads and the Wo GEMV in one launch (single GPU)
 //   k_rows_prologue, k_gemm_q8_mfma / k_gemm_q, k_rope_kv_rows, k_attn_prefill, k_swiglu_rows: batched prompt processing
-//   k_token<QT>           the persistent whole-token kernel (opt-in)
 //   k_embed, k_argmax_advance
 // plus small op-level kernels that expose the same __device__ functions to the parity tests.
 //
-// The code lives in: flm_math.h (exact scalar / wave building blocks), flm_gemv.h, flm_attn.h, flm_token.h, flm_prefill.h, flm_misc.h.
+// The code lives in: flm_math.h (exact scalar / wave building blocks), flm_gemv.h, flm_attn.h, flm_prefill.h, flm_misc.h.
 #pragma once
 #include "flm_math.h"
 #include "flm_gemv.h"
 #include "flm_attn.h"
-#include "flm_token.h"
 #include "flm_prefill.h"
 #include "flm_misc.h"

@@ -14,7 +14,7 @@ namespace flm {
 // x1 = embedding[token] (copy or dequantize; transformer.cpp:115-122)
 __global__ void k_embed(float* x, const void* emb, const float* emb_s, int emb_qt, int dim, const int* tok_ptr, unsigned* bar) {
     const int tok = *tok_ptr;
-    if (bar && blockIdx.x == 0) { bar[threadIdx.x * 16] = 0; bar[(threadIdx.x + blockDim.x) * 16] = 0; }   // grid barrier flags (<= 512 workgroups, 64 B apart) of the k_token that follows
+    if (bar && blockIdx.x == 0) { bar[threadIdx.x * 16] = 0; bar[(threadIdx.x + blockDim.x) * 16] = 0; }   // the flag lines (<= 512, 64 B apart) of the fused launches that follow
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < dim; e += gridDim.x * blockDim.x) {
         float v;
         if (emb_qt == 0) v = reinterpret_cast<const float*>(emb)[(size_t)tok * dim + e];
@@ -70,25 +70,28 @@ __global__ void k_advance_prompt(DecodeState* st, const int* prompt) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { st->step += 1; st->pos += 1; st->tok = prompt[st->step]; }
 }
 __global__ void k_set_step(DecodeState* st, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) st->step = v; }
-// x += y (tensor-parallel path: residual add after the all-reduce; Tensor::add, tensor.cpp:723-743)
-__global__ void k_add_inplace(float* x, const float* y, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) x[i] = __fadd_rn(x[i], y[i]);
-}
-
 // ---- op-level test kernels: thin launchers over the same __device__ functions ----
-// square_sum both ways: out[0] the wave-parallel evaluation (sq_chain_wave), out[1] the plain sequential chains (sq_chain)
+// square_sum both ways: out[0] the speculative wave evaluation (sq_chain_spec), out[1] the plain sequential chains (sq_chain);
+// out[2..5] the 4 strided lanes from sq_chain_spec, out[6..9] its round counts (-1: it fell back to the plain chain)
 __global__ void __launch_bounds__(256) k_op_square_sum(float* out, const float* x, int n) {
     extern __shared__ float sm[];
     const int n4 = n / 4, ns = n4 + 8;
-    for (int e = threadIdx.x; e < n4 * 4; e += blockDim.x) sm[(e & 3) * ns + (e >> 2)] = x[e];
-    for (int i = threadIdx.x; i < 4 * 8; i += blockDim.x) sm[(i >> 3) * ns + n4 + (i & 7)] = 0.f;
+    const int bs = chain_bshift(n), B = 1 << bs, LS = B + 4, CS = 64 * LS;
+    float* seq = sm + 4 * CS;                                     // [4][n4 + 8] for the plain chains
+    for (int i = threadIdx.x; i < 4 * CS; i += blockDim.x) sm[i] = 0.f;
+    for (int i = threadIdx.x; i < 4 * ns; i += blockDim.x) seq[i] = 0.f;
+    __syncthreads();
+    for (int e = threadIdx.x; e < n4 * 4; e += blockDim.x) {
+        const int c = e & 3, k = e >> 2;
+        sm[c * CS + (k >> bs) * LS + (k & (B - 1))] = x[e];
+        seq[c * ns + k] = x[e];
+    }
     __shared__ float red[8];
     __syncthreads();
     int its = 0;
-    const float l = sq_chain_wave(sm + (threadIdx.x >> 6) * ns, n4, &its);
+    const float l = sq_chain_spec(sm + (threadIdx.x >> 6) * CS, bs, &its);
     if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = l; out[6 + (threadIdx.x >> 6)] = (float)its; }
-    if (threadIdx.x < 4) red[4 + threadIdx.x] = sq_chain(sm + threadIdx.x * ns, n4);
+    if (threadIdx.x < 4) red[4 + threadIdx.x] = sq_chain(seq + threadIdx.x * ns, n4);
     __syncthreads();
     if (threadIdx.x == 0) {
         out[0] = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, red[0]), red[1]), red[2]), red[3]);

@@ -11,7 +11,12 @@
  * Threading: one caller thread per ctx at a time (as ParallelTransformer::forward, single caller,
  * transformer.h:101-110).  Independent ctxs (replicas / tensor-parallel ranks) are independent.
  * Ownership: the caller owns every host pointer (copied during the call); the ctx owns all device
- * memory, allocated at create/upload time -- nothing is allocated inside flm_forward*.
+ * memory, ALL of it allocated at flm_ctx_create / flm_upload_tensor time (prompt, output-id and batched-prefill buffers are
+ * sized by max_seq_len) -- nothing is allocated inside flm_forward* / flm_decode_* (the reference's zero-allocation contract,
+ * transformer.cpp:110-130).
+ * Robustness: the fused attention + Wo launch hands data between workgroups of one kernel; if that hand-off ever times out
+ * (a workgroup not resident because another process holds CUs) the call re-runs its work on one kernel per phase and still
+ * returns FLM_OK with correct results; later calls stay on that path.
  */
 #ifndef FLM_GPU_H
 #define FLM_GPU_H
@@ -100,6 +105,10 @@ int  flm_decode_greedy(flm_ctx* ctx, int32_t first_token, int pos, int n_steps, 
 /* Same loop, nothing copied back; *ms = device time of the n_steps tokens measured with HIP events
  * on the ctx's stream (bench.py's timed region; call flm_sync afterwards is not needed). */
 int  flm_decode_timed(flm_ctx* ctx, int32_t first_token, int pos, int n_steps, float* ms);
+/* the same with an event after every token: ms_each[n_steps] (medians; the events cost a few us per token) */
+int  flm_decode_timed_each(flm_ctx* ctx, int32_t first_token, int pos, int n_steps, float* ms_each);
+/* the ids generated by the last flm_decode_greedy / flm_decode_timed* call: out[n] (n <= its n_steps) */
+int  flm_last_tokens(flm_ctx* ctx, int n, int32_t* out);
 int  flm_reset_kv(flm_ctx* ctx);
 int  flm_sync(flm_ctx* ctx);
 
@@ -120,24 +129,28 @@ int  flm_kernel_bytes(flm_ctx* ctx, int kclass, int pos, double* bytes);
 int  flm_debug_read(flm_ctx* ctx, int what, int layer, float* out, size_t n);
 
 /* tuning knobs: "wg_per_cu" workgroups per CU for the GEMV kernels, "use_graph" hipGraph replay on/off,
- * "use_mega" 1 = run single-GPU tokens as one persistent kernel (k_token; experimental, default 0),
  * "fuse_attn_o" 0 = attention and the Wo GEMV as two launches (default 1: one launch, single GPU),
  * "use_prefill" 0 = feed prompts token by token (default 1: batched), "use_prefill_mq" 0 = batched attention with one query per
- * workgroup (default 1: eight), "use_mfma" 0 = int8 prefill GEMM on v_dot4 instead of the matrix cores (default 1; 2 = matrix cores, 64 x 64 tiles always) */
+ * workgroup (default 1: eight), "use_mfma" 0 = int8 prefill GEMM on v_dot4 instead of the matrix cores (default 1; 2 = matrix cores, 64 x 64 tiles always).
+ * None of them changes a result bit.  (Perf-exploration switches that DO skip work -- "ablate", "trace" -- exist only in builds
+ * with -DFLM_ABLATE=1; the product library answers FLM_ERR_INVALID to them.) */
 int  flm_set_option(flm_ctx* ctx, const char* key, int value);
 
 /* ---- op level: 1:1 mirrors of the reference operator seam, host pointers in / out, running the
  *      same device code as the fused path.  Used by the parity tests. ----------------------- */
 /* quant::quantize (quant_operators.cpp:78-97) */
 int  flm_op_quantize(int qt, void* qx, float* qs, const float* x, size_t n, int gs);
-/* quant::matmul (quant_operators.cpp:571-591), same argument order: out[w][m] */
+/* quant::matmul (quant_operators.cpp:571-591), same argument order: out[w][m].  w < 16: one GEMV per batch row (the decode
+ * kernel); w >= 16: the tile kernels of the batched prompt path (int8 on the matrix cores, int16 on v_dot2) */
 int  flm_op_matmul_q(int qt, float* out, const void* mat1, const float* scales1,
                      const void* mat2, const float* scales2, int m, int n, int w, int gs);
 /* simd::rmsnorm(o,x,w,n) (x86_simd.cpp:1754-1764) */
 int  flm_op_rmsnorm(float* o, const float* x, const float* w, size_t n);
-/* simd::square_sum (x86_simd.cpp:942-960), n % 16 == 0: out6 = { total from the wave-parallel evaluation, total from the
- * sequential chains, the 4 strided partial sums }; the two totals must be the same bits */
+/* simd::square_sum (x86_simd.cpp:942-960), n % 16 == 0, n <= 16384: out6 = { total from the speculative wave evaluation the
+ * rmsnorm prologue uses, total from the plain sequential chains, the 4 strided partial sums }; the two totals must be the same bits */
 int  flm_op_square_sum(const float* x, size_t n, float* out6);
+/* sample_argmax (sampler.cpp:36-47): first maximum wins */
+int  flm_op_argmax(const float* logits, int n, int32_t* idx);
 /* simd::swiglu(xo,xr,n) (x86_simd.cpp:1766-1770) */
 int  flm_op_swiglu(float* xo, const float* xr, size_t n);
 /* rope_v2 (tf_operators.cpp:352-402): one head row of n_dims at position pos */

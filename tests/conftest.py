@@ -16,19 +16,31 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def _gpu_available():
-    try:
-        import torch
-        return torch.cuda.is_available()
-    except Exception:
-        return False
+def _hip_device_count():
+    """ask HIP itself (not torch): a broken torch on the GPU box must not turn the parity suite into skips"""
+    import ctypes
+    for name in ("libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"):
+        try:
+            hip = ctypes.CDLL(name)
+        except OSError:
+            continue
+        n = ctypes.c_int(0)
+        try:
+            return n.value if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
+        except Exception:
+            return 0
+    return 0
 
 
 @pytest.fixture(scope="session")
-def gpu():
-    """GPU tests must run the native HIP path: fail loudly (never skip silently to a fallback)."""
+def gpu(request):
+    """GPU tests run the native HIP path or FAIL: when the run selected them (`-m gpu`, or FLM_REQUIRE_GPU=1) a missing device
+    or a missing library is an error, never a silent skip to nothing."""
     from fast_llama_amd import capi
-    if not _gpu_available():
+    if _hip_device_count() < 1:
+        markexpr = request.config.getoption("-m") or ""
+        if os.environ.get("FLM_REQUIRE_GPU") == "1" or ("gpu" in markexpr and "not gpu" not in markexpr):
+            pytest.fail("GPU tests were selected but HIP reports no device")
         pytest.skip("no GPU in this container (selected with -m gpu on the GPU box)")
     capi.lib()   # raises FlmError if the HIP library is missing
     return capi

@@ -139,7 +139,7 @@ def test_attention_decode(gpu, hs, heads):
 def _sq_cases():
     rng = np.random.default_rng(42)
     cases = []
-    for n in (64, 256, 1024, 4096, 11008, 4096 + 16):
+    for n in (64, 256, 768, 1024, 4096, 5120, 11008, 4096 + 16, 16384):
         cases.append(("normal", rng.standard_normal(n).astype(np.float32)))
         cases.append(("wide range", (rng.standard_normal(n) * np.exp2(rng.integers(-40, 40, n))).astype(np.float32)))
         cases.append(("growing", (np.arange(1, n + 1) * 0.37).astype(np.float32)))
@@ -161,9 +161,10 @@ def _sq_cases():
     return cases
 
 
-def test_square_sum_wave_parallel_is_bit_exact(gpu):
-    """the wave-parallel evaluation of the rmsnorm sum of squares (flm_kernels.h: sq_chain_wave) == the sequential
-    chains on the GPU == the CPU oracle's restatement of the reference, on friendly and on adversarial data"""
+def test_square_sum_speculative_is_bit_exact(gpu):
+    """the speculative wave evaluation of the rmsnorm sum of squares (flm_gemv.h: sq_chain_spec, the one the prologue runs) == the
+    sequential chains on the GPU == the CPU oracle's restatement of the reference, on friendly and on adversarial data
+    (tools/chain_emul.c fuzzes the same algorithm on the build host)"""
     for name, x in _sq_cases():
         fast, seq, lanes = gpu.op_square_sum(x)
         want = O.square_sum(x)
@@ -172,7 +173,7 @@ def test_square_sum_wave_parallel_is_bit_exact(gpu):
         assert f == w, (name, x.size, fast, want)
     rng = np.random.default_rng(7)
     for it in range(300):                                   # random magnitudes, a share of exactly representable "round" values
-        n = int(rng.choice([256, 1024, 4096]))
+        n = int(rng.choice([256, 1024, 4096, 8192]))
         x = (rng.standard_normal(n) * np.exp2(rng.integers(-12, 12) + rng.integers(-6, 7, n) * (it % 3))).astype(np.float32)
         if it % 4 == 0:
             idx = rng.random(n) < 0.3

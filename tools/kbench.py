@@ -14,7 +14,6 @@ if wg: ctx.set_option("wg_per_cu", wg)
 abl = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 if abl: ctx.set_option("ablate", abl)
 if os.environ.get("FLM_FUSE") is not None: ctx.set_option("fuse_attn_o", int(os.environ["FLM_FUSE"]))
-if os.environ.get("FLM_MEGA") is not None: ctx.set_option("use_mega", int(os.environ["FLM_MEGA"]))
 prompt = np.arange(1, pos + 1, dtype=np.int32) % cfg.vocab_size
 first = ctx.forward_argmax(prompt, 0)
 ms = ctx.decode_timed(first, pos, 64)

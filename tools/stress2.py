@@ -12,7 +12,7 @@ for qt, name in ((ff.QT_INT16, "int16"), (ff.QT_INT8, "int8")):
     tensors = synth.make_tensors(cfg, seed=31)
     prompt = np.array([1] + [int(x) for x in (np.arange(1, 5) * 7919) % cfg.vocab_size], dtype=np.int32)
     ref = None
-    for opts in ({"fuse_attn_o": 0}, {}, {"use_mega": 1}, {"use_prefill": 0}):
+    for opts in ({"fuse_attn_o": 0}, {}, {"use_prefill": 0}):
         ctx = capi.Ctx(capi.desc_from_config(cfg)); ctx.upload_all(tensors)
         for k, v in opts.items(): ctx.set_option(k, v)
         nbad = 0
