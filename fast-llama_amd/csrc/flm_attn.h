@@ -34,6 +34,10 @@ struct AttnArgs {
     // k_attn_o with head_size a multiple of 64: the head also leaves its output QUANTIZED (quant::quantize, quant_operators.cpp:26-47,
     // on the 64 values one wave holds) for the Wo GEMV that waits in the same launch: oq [heads*hs] int8 / int16, os [heads*hs/64]
     void* oq; float* os; int oqt;
+    // long contexts: a head is spread over G workgroups of the same launch (attn_head, G > 1).  sc_global [heads][max_seq] carries
+    // the scores between them, flag_sc one 64-byte line per (head, part) whose value reaches `epoch` when that part's scores
+    // are in memory; err as in k_attn_o.
+    int G; float* sc_global; unsigned* flag_sc; unsigned epoch; int* err;
 };
 
 constexpr int kAttnBlock = 1024;      // 16 waves
@@ -42,17 +46,33 @@ constexpr int kAttnDepth = 2;         // tiles in flight per stream (K, V), regi
 // LDS row stride of a tile in floats: compile-time per instantiation (64*NF + 8), so that the chains' LDS reads use
 // immediate offsets; +8: the 8x8 (position, accumulator) score lanes and the PV lanes hit distinct banks
 __host__ __device__ inline int attn_row_stride(int hs) { const int nf = hs <= 64 ? 1 : hs <= 128 ? 2 : 4; return nf * 64 + 8; }
-__host__ inline size_t attn_lds_bytes(int max_seq, int hs) { return (size_t)(hs + 32 + ((max_seq + 3) & ~3) + 64 + (2 * kAttnTile + 4) * attn_row_stride(hs)) * 4; }   // + 4 slack rows: the PV read-ahead
+__host__ inline size_t attn_lds_bytes(int max_seq, int hs, bool split = false) {
+    size_t tiles = (size_t)(2 * kAttnTile + 4) * attn_row_stride(hs);                       // + 4 slack rows: the PV read-ahead
+    const size_t vslice = (size_t)(1024 + 4) * 32 + 64;                                       // split heads: the part's whole V slice, transposed [32][kSplitMaxSeq + 4], lies where the K tiles were
+    if (split && vslice > tiles) tiles = vslice;
+    return (size_t)(hs + 32 + ((max_seq + 3) & ~3) + 64 + tiles) * 4;
+}
 
 // NF = 16-byte pieces of a tile per thread = ceil(hs / 64)
 // COH: K/V/q were (partly) written by other workgroups of the SAME kernel (a fused launch) -> coherent sc0|sc1 loads; the
 // per-phase kernels read them after a kernel boundary and use ordinary cached loads
-template <int NF, bool COH>
-__device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow) {
+// G > 1 (long contexts; all G workgroups of a head run in the SAME launch): part g computes the scores of its share of the
+// position tiles (K traffic / G), the parts exchange scores through memory (flag lines, as k_attn_o's hand-off), every part
+// then runs the softmax over all T scores -- the same operations in the same order, so the same bits in every part -- and
+// the weighted V sum of ITS hs / G output dimensions over all positions (V traffic / G; t ascending per dimension: the
+// reference's chain).  A head's 2 T hs 4 bytes then flow through G CUs instead of one.
+// SPLIT (the G > 1 instantiation; nd == kSplitDims, max_seq <= kSplitMaxSeq): streaming is latency-bound -- a tile costs a memory
+// round trip unless it was requested long before it is needed -- so the K ring is 4 tiles deep (a part's whole share up to T = 1024)
+// and the part's ENTIRE V slice (T x 32 floats <= 128 KiB) is requested when the kernel starts, waits in registers (8 x 16 bytes per
+// thread) under the scores and the softmax, and is then parked in LDS where the K tiles were: the weighted sum runs without a barrier.
+constexpr int kSplitDims = 32, kSplitMaxSeq = 1024, kSplitVRegs = kSplitMaxSeq * (kSplitDims / 4) / 1024;
+template <int NF, bool COH, bool SPLIT = false>
+__device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow, const int g = 0, const int G = 1) {
     typedef float v4f __attribute__((ext_vector_type(4)));
-    constexpr int D = kAttnDepth;
+    constexpr int D = SPLIT ? 4 : kAttnDepth;         // K ring depth
+    constexpr int DV = SPLIT ? 1 : kAttnDepth;        // V ring depth (SPLIT: unused, the slice sits in vall)
     const int hs = a.hs, tid = threadIdx.x;
-    auto stamp = [&](int k) { if (kAblate && a.trace && threadIdx.x == 0) a.trace[h * 8 + k] = __builtin_amdgcn_s_memtime(); };
+    auto stamp = [&](int k) { if (kAblate && a.trace && threadIdx.x == 0) a.trace[(h * G + g) * 8 + k] = __builtin_amdgcn_s_memtime(); };
     stamp(0);
     constexpr int rs = NF * 64 + 8;
     const int f4r = hs >> 2, tile_f4 = kAttnTile * f4r;
@@ -70,41 +90,59 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
     const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V), 0, a.max_seq * hs * 4, 0x00020000);
     const float scale = (float)(1.0 / (double)__builtin_sqrtf((float)hs));   // attn_scale, transformer.cpp:418
     const int nt = (T + kAttnTile - 1) / kAttnTile;
+    // this part's share: score tiles [sb, se), output dimensions [d0, d0 + nd)
+    const int tpp = (nt + G - 1) / G, sb = g * tpp, se = (sb + tpp < nt) ? sb + tpp : nt;
+    const int nd = hs / G, d0 = g * nd, f4v = nd >> 2, tile_f4v = kAttnTile * f4v;
     // Two streams of tiles (K for the scores, V for the weighted sum), each through a ring of D register sets; both are
     // requested when the kernel starts (the V tiles arrive under the softmax), tile i+D when tile i has been parked.
-    v4f ringK[D][NF], ringV[D][NF];
+    v4f ringK[D][NF], ringV[DV][NF];
+    v4f vall[SPLIT ? kSplitVRegs : 1];
     // this thread's pieces of a tile: row / byte offsets computed once (an integer division per piece per tile would
-    // cost more than the tile's arithmetic)
-    int prow[NF], goff[NF], loff[NF];
+    // cost more than the tile's arithmetic).  K: whole rows; V: the part's nd columns of every row.
+    int prow[NF], goff[NF], loff[NF], prowv[NF], goffv[NF], loffv[NF];
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
         const int f = tid + j * kAttnBlock, row = f / f4r, c4 = f - row * f4r;
         prow[j] = f < tile_f4 ? row : (1 << 28);                    // pieces past the tile never pass the t < T test
         goff[j] = (row * hs + c4 * 4) * 4;
         loff[j] = row * rs + c4 * 4;
+        const int rowv = f / f4v, c4v = f - rowv * f4v;
+        prowv[j] = f < tile_f4v ? rowv : (1 << 28);
+        goffv[j] = (rowv * hs + d0 + c4v * 4) * 4;
+        loffv[j] = rowv * rs + c4v * 4;
     }
     const int tile_bytes = kAttnTile * hs * 4;
-    auto request = [&](const __amdgpu_buffer_rsrc_t& r, int tile, v4f (&reg)[NF]) {
+    auto request = [&](const __amdgpu_buffer_rsrc_t& r, int tile, int tile_end, const int (&pr)[NF], const int (&go)[NF], v4f (&reg)[NF]) {
         const int t0 = tile * kAttnTile;
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
-            const unsigned off = (tile < nt && t0 + prow[j] < T) ? (unsigned)(tile * tile_bytes + goff[j]) : 0x80000000u;
+            const unsigned off = (tile < tile_end && t0 + pr[j] < T) ? (unsigned)(tile * tile_bytes + go[j]) : 0x80000000u;
             reg[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, COH ? kAuxCoherent : 0));
         }
     };
-    auto park = [&](float* buf, const v4f (&reg)[NF]) {
+    auto park = [&](float* buf, const int (&pr)[NF], const int (&lo)[NF], const v4f (&reg)[NF]) {
 #pragma unroll
         for (int j = 0; j < NF; ++j)
-            if (prow[j] < kAttnTile) *reinterpret_cast<float4*>(buf + loff[j]) = make_float4(reg[j].x, reg[j].y, reg[j].z, reg[j].w);
+            if (pr[j] < kAttnTile) *reinterpret_cast<float4*>(buf + lo[j]) = make_float4(reg[j].x, reg[j].y, reg[j].z, reg[j].w);
     };
     // q first: loads return in issue order, and q requested behind the K and V tiles would arrive behind 4 tiles of data
     float qv[NF * 64 / kAttnBlock + 1];
 #pragma unroll
     for (int i = 0; i < NF * 64 / kAttnBlock + 1; ++i) { const int d = tid + i * kAttnBlock; qv[i] = d < hs ? (COH ? ld_agent(qrow + (size_t)h * hs + d) : qrow[(size_t)h * hs + d]) : 0.f; }
 #pragma unroll
-    for (int u = 0; u < D; ++u) request(rK, u, ringK[u]);
+    for (int u = 0; u < D; ++u) request(rK, sb + u, se, prow, goff, ringK[u]);
+    if constexpr (SPLIT) {
+        // piece f = tid + j * 1024 of the slice: row f / 8, 16-byte column f % 8
 #pragma unroll
-    for (int u = 0; u < D; ++u) request(rV, u, ringV[u]);
+        for (int j = 0; j < kSplitVRegs; ++j) {
+            const int row = (tid >> 3) + j * (kAttnBlock >> 3);
+            const unsigned off = row < T ? (unsigned)((row * hs + d0 + (tid & 7) * 4) * 4) : 0x80000000u;
+            vall[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rV, (int)off, 0, COH ? kAuxCoherent : 0));
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < DV; ++u) request(rV, u, nt, prowv, goffv, ringV[u]);
+    }
 #pragma unroll
     for (int i = 0; i < NF * 64 / kAttnBlock + 1; ++i) { const int d = tid + i * kAttnBlock; if (d < hs) qs[d] = qv[i]; }
 
@@ -113,38 +151,80 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
     // (no early exit from the unrolled tile loops: with a break inside them the compiler loses count of the loads in flight and
     //  waits for nearly all of them -- the V tiles included -- before the first K tile is parked.  A tile past the end is zeros.)
     float lmax = -INFINITY;
-    for (int base = 0; base < nt; base += D) {
-#pragma unroll
-        for (int u = 0; u < D; ++u) {
-            const int s = base + u;
-            float* cur = (u & 1) ? tile1 : tile0;                   // D is even: tile parity == slot parity
-            park(cur, ringK[u]);
-            __syncthreads();
-            request(rK, s + D, ringK[u]);
-            if (s < nt && tid < kAttnTile * 8) {
-                const int p = tid >> 3, k = tid & 7, t = s * kAttnTile + p;
-                const float* kp = cur + p * rs + k;
-                float l = 0.f;
+    // one (position, accumulator) lane of a tile that lies in LDS at `cur`
+    auto score_lane = [&](const float* cur, int s, int p, int k) {
+        const int t = s * kAttnTile + p;
+        const float* kp = cur + p * rs + k;
+        float l = 0.f;
 #pragma unroll 16
-                for (int j = 0; j < hs; j += 8) l = __fmaf_rn(kp[j], qs[j + k], l);
-                const int li = __float_as_int(l);
-                float tot = __fadd_rn(0.f, l);
-                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x101 /* row_shl:1 */, 0xF, 0xF, true)));
-                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x102, 0xF, 0xF, true)));
-                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x103, 0xF, 0xF, true)));
-                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x104, 0xF, 0xF, true)));
-                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x105, 0xF, 0xF, true)));
-                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x106, 0xF, 0xF, true)));
-                tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x107, 0xF, 0xF, true)));
-                if (k == 0 && t < T) {
-                    const float sv = __fmul_rn(tot, scale);         // att.multiply(attn_scale) :443
-                    sc[t] = sv;
-                    lmax = fmaxf(lmax, sv);
-                }
+        for (int j = 0; j < hs; j += 8) l = __fmaf_rn(kp[j], qs[j + k], l);
+        const int li = __float_as_int(l);
+        float tot = __fadd_rn(0.f, l);
+        tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x101 /* row_shl:1 */, 0xF, 0xF, true)));
+        tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x102, 0xF, 0xF, true)));
+        tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x103, 0xF, 0xF, true)));
+        tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x104, 0xF, 0xF, true)));
+        tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x105, 0xF, 0xF, true)));
+        tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x106, 0xF, 0xF, true)));
+        tot = __fadd_rn(tot, __int_as_float(__builtin_amdgcn_update_dpp(0, li, 0x107, 0xF, 0xF, true)));
+        if (k == 0 && t < T) {
+            const float sv = __fmul_rn(tot, scale);         // att.multiply(attn_scale) :443
+            sc[t] = sv;
+            lmax = fmaxf(lmax, sv);
+            if (G > 1) st_agent(a.sc_global + (size_t)h * a.max_seq + t, sv);
+        }
+    };
+    if constexpr (SPLIT) {
+        // two tiles per step: 128 positions x 8 accumulators keep all 16 waves busy; two barriers per step (park -> compute -> next park)
+        for (int base = sb; base < se; base += D) {
+#pragma unroll
+            for (int u = 0; u < D; u += 2) {
+                const int s = base + u;
+                park(tile0, prow, loff, ringK[u]); park(tile1, prow, loff, ringK[u + 1]);
+                __syncthreads();
+                request(rK, s + D, se, prow, goff, ringK[u]); request(rK, s + D + 1, se, prow, goff, ringK[u + 1]);
+                const int half = tid >> 9, s2 = s + half;
+                if (s2 < se) score_lane(half ? tile1 : tile0, s2, (tid >> 3) & 63, tid & 7);
+                __syncthreads();
+            }
+        }
+    } else {
+        for (int base = sb; base < se; base += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                const int s = base + u;
+                float* cur = (u & 1) ? tile1 : tile0;                   // D is even: slot parity
+                park(cur, prow, loff, ringK[u]);
+                __syncthreads();
+                request(rK, s + D, se, prow, goff, ringK[u]);
+                if (s < se && tid < kAttnTile * 8) score_lane(cur, s, tid >> 3, tid & 7);
             }
         }
     }
     stamp(1);
+    if (G > 1) {
+        // exchange: my scores are in memory -> raise my line; wait for the other parts' lines; fetch their scores
+        wait_stores_done();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(a.flag_sc + (h * G + g) * 16, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < 64) {
+            const bool mine = tid < G;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (true) {
+                const unsigned f = mine ? __hip_atomic_load(a.flag_sc + (h * G + tid) * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.epoch;
+                if (__all(f >= a.epoch)) break;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) { __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+        __syncthreads();
+        lmax = -INFINITY;
+        for (int t = tid; t < T; t += kAttnBlock) {
+            const int tl = t / kAttnTile;
+            const float sv = (tl >= sb && tl < se) ? sc[t] : ld_agent(a.sc_global + (size_t)h * a.max_seq + t);
+            sc[t] = sv;
+            lmax = fmaxf(lmax, sv);
+        }
+    }
     // block max over 16 waves (array_max is order-free)
     lmax = wave_max(lmax);
     if (lane == 0) red[wave] = lmax;
@@ -185,18 +265,67 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
     // stored as exact zeros so that the PV chain can tell them apart with one wave-uniform test per four positions
     for (int t = tid; t < T; t += kAttnBlock) { const float w = __fdiv_rn(sc[t], sum); sc[t] = (t > 0 && fabsf(w) <= 1e-15f) ? 0.f : w; }
     // (the first barrier of the loop below orders these writes before the PV reads)
-    // ---- o[d] = sum_t att[t] V[t][d]: one thread per output dimension, t ascending (the reference's chain) over
+    // ---- o[d] = sum_t att[t] V[t][d]: one thread per output dimension (of this part), t ascending (the reference's chain) over
     //      the LDS tiles.
     float o = 0.f;
-    for (int base = 0; base < nt; base += D) {
+    constexpr int vrs = rs;
+    if constexpr (SPLIT) {
+        // The part's V slice goes to LDS TRANSPOSED -- vT[d][t], rows kSplitVS floats apart (a multiple of 4, = 4 mod 64: the
+        // parking stores and the chain's 16-byte reads are conflict-free) -- so that the chain of dimension d reads four consecutive
+        // positions with one ds_read_b128.  The chain itself is the reference's (row 0 by multiplication, t ascending, FMA, rows whose
+        // weight fell under the threshold skipped); with operands streaming through a 4-slot register ring it runs at the pace
+        // of the dependent FMAs (measured before this layout: 35 cycles per position, the LDS latency of scalar reads).
+        constexpr int VS = kSplitMaxSeq + 4;
+        if (tid == 0) red[20] = 1.f;
+        __syncthreads();                                            // every wave is done with the K tiles (and has written its weights)
+        {
+            bool zero_w = false;
+            for (int t = tid; t < T; t += kAttnBlock) zero_w = zero_w || (t > 0 && sc[t] == 0.f);
+            if (zero_w) red[20] = 0.f;                              // some row is skipped: the chain takes the careful path
+        }
 #pragma unroll
-        for (int u = 0; u < D; ++u) {
+        for (int j = 0; j < kSplitVRegs; ++j) {
+            const int row = (tid >> 3) + j * (kAttnBlock >> 3);
+            if (row < T) {
+                float* dst = tile0 + (tid & 7) * 4 * VS + row;
+                dst[0] = vall[j].x; dst[VS] = vall[j].y; dst[2 * VS] = vall[j].z; dst[3 * VS] = vall[j].w;
+            }
+        }
+        __syncthreads();
+        if (tid < nd) {
+            const float* vp = tile0 + tid * VS;
+            const float* wp = sc;
+            o = __fmul_rn(vp[0], wp[0]);                            // row 0 always (tf_operators.cpp:331-336)
+            int p = 1;
+            if (red[20] != 0.f) {
+                for (; p < T && (p & 3); ++p) o = __fmaf_rn(vp[p], wp[p], o);
+#define FLM_PV4(vv, ww) o = __fmaf_rn(vv.x, ww.x, o); o = __fmaf_rn(vv.y, ww.y, o); o = __fmaf_rn(vv.z, ww.z, o); o = __fmaf_rn(vv.w, ww.w, o);
+#define FLM_PVSTEP(vv, ww, off) FLM_PV4(vv, ww) vv = *reinterpret_cast<const float4*>(vp + p + (off)); ww = *reinterpret_cast<const float4*>(wp + p + (off)); __builtin_amdgcn_sched_barrier(0);
+                if (p + 16 <= T) {
+                    float4 v0 = *reinterpret_cast<const float4*>(vp + p), v1 = *reinterpret_cast<const float4*>(vp + p + 4), v2 = *reinterpret_cast<const float4*>(vp + p + 8), v3 = *reinterpret_cast<const float4*>(vp + p + 12);
+                    float4 w0 = *reinterpret_cast<const float4*>(wp + p), w1 = *reinterpret_cast<const float4*>(wp + p + 4), w2 = *reinterpret_cast<const float4*>(wp + p + 8), w3 = *reinterpret_cast<const float4*>(wp + p + 12);
+                    __builtin_amdgcn_sched_barrier(0);
+                    for (; p + 32 <= T; p += 16) { FLM_PVSTEP(v0, w0, 16) FLM_PVSTEP(v1, w1, 20) FLM_PVSTEP(v2, w2, 24) FLM_PVSTEP(v3, w3, 28) }
+                    FLM_PV4(v0, w0) FLM_PV4(v1, w1) FLM_PV4(v2, w2) FLM_PV4(v3, w3)
+                    p += 16;
+                }
+#undef FLM_PVSTEP
+#undef FLM_PV4
+                for (; p < T; ++p) o = __fmaf_rn(vp[p], wp[p], o);
+            } else {
+                for (; p < T; ++p) { const float w = wp[p]; o = w == 0.f ? o : __fmaf_rn(vp[p], w, o); }
+            }
+        }
+    }
+    for (int base = 0; base < (SPLIT ? 0 : nt); base += DV) {
+#pragma unroll
+        for (int u = 0; u < DV; ++u) {
             const int i = base + u;
             float* cur = (u & 1) ? tile1 : tile0;
-            park(cur, ringV[u]);
+            park(cur, prowv, loffv, ringV[u]);
             __syncthreads();
-            request(rV, i + D, ringV[u]);
-            if (i < nt && tid < hs) {
+            request(rV, i + DV, nt, prowv, goffv, ringV[u]);
+            if (i < nt && tid < nd) {
                 const float* vp = cur + tid;
                 const float* wp = sc + i * kAttnTile;
                 const int np = (T - i * kAttnTile) < kAttnTile ? (T - i * kAttnTile) : kAttnTile;
@@ -207,15 +336,15 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
                 int p = 0;
                 if (i == 0) { o = __fmul_rn(vp[0], wp[0]); p = 1; }  // row 0 always (tf_operators.cpp:331-336)
                 if (dense) {
-                    for (; p < np && (p & 7); ++p) o = __fmaf_rn(vp[p * rs], wp[p], o);
+                    for (; p < np && (p & 7); ++p) o = __fmaf_rn(vp[p * vrs], wp[p], o);
                     if (p + 8 <= np) {
-                        const float* vq = vp + p * rs; const float* wq = wp + p;
+                        const float* vq = vp + p * vrs; const float* wq = wp + p;
                         float4 wa = *reinterpret_cast<const float4*>(wq), wb = *reinterpret_cast<const float4*>(wq + 4);
-                        float a0 = vq[0], a1 = vq[rs], a2 = vq[2 * rs], a3 = vq[3 * rs], a4 = vq[4 * rs], a5 = vq[5 * rs], a6 = vq[6 * rs], a7 = vq[7 * rs];
+                        float a0 = vq[0], a1 = vq[vrs], a2 = vq[2 * vrs], a3 = vq[3 * vrs], a4 = vq[4 * vrs], a5 = vq[5 * vrs], a6 = vq[6 * vrs], a7 = vq[7 * vrs];
                         for (; p + 16 <= np; p += 8) {
-                            vq += 8 * rs; wq += 8;
+                            vq += 8 * vrs; wq += 8;
                             const float4 wc = *reinterpret_cast<const float4*>(wq), wd = *reinterpret_cast<const float4*>(wq + 4);
-                            const float b0 = vq[0], b1 = vq[rs], b2 = vq[2 * rs], b3 = vq[3 * rs], b4 = vq[4 * rs], b5 = vq[5 * rs], b6 = vq[6 * rs], b7 = vq[7 * rs];
+                            const float b0 = vq[0], b1 = vq[vrs], b2 = vq[2 * vrs], b3 = vq[3 * vrs], b4 = vq[4 * vrs], b5 = vq[5 * vrs], b6 = vq[6 * vrs], b7 = vq[7 * vrs];
                             o = __fmaf_rn(a0, wa.x, o); o = __fmaf_rn(a1, wa.y, o); o = __fmaf_rn(a2, wa.z, o); o = __fmaf_rn(a3, wa.w, o);
                             o = __fmaf_rn(a4, wb.x, o); o = __fmaf_rn(a5, wb.y, o); o = __fmaf_rn(a6, wb.z, o); o = __fmaf_rn(a7, wb.w, o);
                             wa = wc; wb = wd; a0 = b0; a1 = b1; a2 = b2; a3 = b3; a4 = b4; a5 = b5; a6 = b6; a7 = b7;
@@ -224,17 +353,17 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
                         o = __fmaf_rn(a4, wb.x, o); o = __fmaf_rn(a5, wb.y, o); o = __fmaf_rn(a6, wb.z, o); o = __fmaf_rn(a7, wb.w, o);
                         p += 8;
                     }
-                    for (; p < np; ++p) o = __fmaf_rn(vp[p * rs], wp[p], o);
+                    for (; p < np; ++p) o = __fmaf_rn(vp[p * vrs], wp[p], o);
                 } else {
                     // some row is skipped (weight stored as exact 0, threshold of transformer.cpp:449): it leaves o untouched
-                    for (; p < np; ++p) { const float w = wp[p]; o = w == 0.f ? o : __fmaf_rn(vp[p * rs], w, o); }
+                    for (; p < np; ++p) { const float w = wp[p]; o = w == 0.f ? o : __fmaf_rn(vp[p * vrs], w, o); }
                 }
             }
         }
     }
     stamp(4);
-    if (tid < hs) st_agent(orow + (size_t)h * hs + tid, o);
-    if (a.oq) {
+    if (tid < nd) st_agent(orow + (size_t)h * hs + d0 + tid, o);
+    if (a.oq && G == 1) {
         // qx.quantize(x2) (transformer.cpp:138) for this head's groups: wave w holds the 64 outputs of group h * hs/64 + w;
         // the max is order-free, the element step is quant_elem.  Packed through LDS (q's place: long since consumed) so that
         // the values leave as dwords.
@@ -247,13 +376,17 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
             if (lane == 0) st_agent(a.os + (size_t)h * (hs >> 6) + wave, sc);
         }
         __syncthreads();
-        const int nd = hs * esz / 4;
-        if (tid < nd) __hip_atomic_store(reinterpret_cast<unsigned*>(a.oq) + (size_t)h * nd + tid, reinterpret_cast<const unsigned*>(qs)[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int nq = hs * esz / 4;
+        if (tid < nq) __hip_atomic_store(reinterpret_cast<unsigned*>(a.oq) + (size_t)h * nq + tid, reinterpret_cast<const unsigned*>(qs)[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();                                                // the LDS is free for whoever runs next on it
 }
 template <bool COH>
-__device__ __forceinline__ void attn_head_any(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow) {
+__device__ __forceinline__ void attn_head_any(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow, const int g = 0, const int G = 1) {
+    if (G > 1) {      // the host picks G = hs / kSplitDims (attn_parts): every part owns 32 output dimensions
+        if (a.hs <= 64) attn_head<1, COH, true>(a, h, lds, T, qrow, orow, g, G); else if (a.hs <= 128) attn_head<2, COH, true>(a, h, lds, T, qrow, orow, g, G); else attn_head<4, COH, true>(a, h, lds, T, qrow, orow, g, G);
+        return;
+    }
     if (a.hs <= 64) attn_head<1, COH>(a, h, lds, T, qrow, orow); else if (a.hs <= 128) attn_head<2, COH>(a, h, lds, T, qrow, orow); else attn_head<4, COH>(a, h, lds, T, qrow, orow);
 }
 // batched prefill: workgroup (h, i) is query i of the batch, at position pos0 + i, over the cache rows 0 .. pos0 + i
@@ -427,9 +560,11 @@ __global__ void __launch_bounds__(kAttnBlock) k_attn_prefill_mq(const AttnArgs a
     const int i0 = blockIdx.y * kMqQueries, nq = B - i0 < kMqQueries ? B - i0 : kMqQueries;
     if (a.hs <= 64) attn_prefill_mq<1>(a, blockIdx.x, lds, pos0, i0, nq, row_stride); else attn_prefill_mq<2>(a, blockIdx.x, lds, pos0, i0, nq, row_stride);
 }
+// grid = heads * G (G = a.G >= 1 parts per head; all of them resident: the parts wait for each other's scores)
 __global__ void __launch_bounds__(kAttnBlock) k_attn_decode(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    attn_head_any<false>(a, blockIdx.x, lds, *a.pos_ptr + 1, a.q, a.out);
+    const int G = a.G > 1 ? a.G : 1;
+    attn_head_any<false>(a, blockIdx.x / G, lds, *a.pos_ptr + 1, a.q, a.out, blockIdx.x % G, G);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -450,8 +585,9 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_attn_o(const AttnArgs aa, con
     extern __shared__ __attribute__((aligned(16))) char lds[];
     auto stamp = [&](int k) { if (kAblate && a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime(); };   // tools/trace_ao.py
     stamp(0);
-    if ((int)blockIdx.x < n_heads) {
-        attn_head_any<false>(aa, blockIdx.x, lds, *aa.pos_ptr + 1, aa.q, aa.out);
+    if ((int)blockIdx.x < n_heads) {                                           // n_heads counts head PARTS: heads * G
+        const int G = aa.G > 1 ? aa.G : 1;
+        attn_head_any<false>(aa, blockIdx.x / G, lds, *aa.pos_ptr + 1, aa.q, aa.out, blockIdx.x % G, G);
         stamp(1);
         wait_stores_done();                                                     // every wave: its part of the head's output is where the others will read it
         __syncthreads();

@@ -144,26 +144,42 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 }
 constexpr int kChainHead = 4;          // lanes whose elements run in order before the speculative part
 // p: one chain's strip [64 lanes][B + 4] floats, zero-padded past the data.  Returns the chain value in every lane.
-__device__ __forceinline__ float sq_chain_spec(const float* p, const int bshift, int* rounds_out = nullptr) {
-    const int lane = threadIdx.x & 63, B = 1 << bshift, BV = B >> 2, LS = B + 4;
+// BVR > 0: B = 4 * BVR is a compile-time constant and the lane's elements stay in registers (B <= 16: every model width up to
+// 4096); BVR == 0: any B, elements re-read from LDS in every pass.
+template <int BVR>
+__device__ __forceinline__ float sq_chain_spec_t(const float* p, const int bshift, int* rounds_out) {
+    const int lane = threadIdx.x & 63, B = BVR ? 4 * BVR : (1 << bshift), BV = B >> 2, LS = B + 4;
     const float4* pl = reinterpret_cast<const float4*>(p + lane * LS);
+    float4 xr[BVR ? BVR : 1];
+    if constexpr (BVR > 0) {
+#pragma unroll
+        for (int q = 0; q < BVR; ++q) xr[q] = pl[q];
+    }
+    auto elem = [&](int q) -> float4 { if constexpr (BVR > 0) return xr[q]; else return pl[q]; };
 #define FLM_SQ4(l, v) l = __fmaf_rn(v.x, v.x, l); l = __fmaf_rn(v.y, v.y, l); l = __fmaf_rn(v.z, v.z, l); l = __fmaf_rn(v.w, v.w, l);
     // 1. approximate per-lane sums, all-zero lanes (pass-through whatever l is)
     float s = 0.f, m = 0.f;
-    for (int q = 0; q < BV; ++q) { const float4 v = pl[q]; FLM_SQ4(s, v) m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))); }
+#pragma unroll
+    for (int q = 0; q < BV; ++q) { const float4 v = elem(q); FLM_SQ4(s, v) m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))); }
     const bool allzero = (m == 0.f) && (s == 0.f);              // (s: a NaN among zeros must not count as zero)
     const float P = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(wave_scan_incl(s)), 0x138 /* wave_shr:1 */, 0xF, 0xF, true));
     // the head: lanes [0, kChainHead) in order (every lane computes it: broadcast reads)
     float hv = 0.f;
-    for (int L = 0; L < kChainHead; ++L) { const float4* r = reinterpret_cast<const float4*>(p + L * LS); for (int q = 0; q < BV; ++q) { const float4 v = r[q]; FLM_SQ4(hv, v) } }
+#pragma unroll
+    for (int L = 0; L < kChainHead; ++L) {
+        const float4* r = reinterpret_cast<const float4*>(p + L * LS);
+#pragma unroll
+        for (int q = 0; q < BV; ++q) { const float4 v = r[q]; FLM_SQ4(hv, v) }
+    }
     // 2. increments against the expected binade
     const unsigned eb = __float_as_uint(P) & 0x7f800000u;
     bool valid = lane >= kChainHead && eb >= (27u << 23) && eb <= (250u << 23);      // P finite and normal, room for u/2 and 2A
     const unsigned ebv = valid ? eb : 0x3f800000u;
     const float A = __uint_as_float(ebv), half_u = __uint_as_float(ebv - (24u << 23)), top = __fadd_rn(A, A);
     float T = 0.f; bool tie = false;
+#pragma unroll
     for (int q = 0; q < BV; ++q) {
-        const float4 v = pl[q];
+        const float4 v = elem(q);
 #define FLM_INC(x) { const float t_ = __fsub_rn(__fmaf_rn(x, x, A), A); tie = tie || (fabsf(__fmaf_rn(x, x, -t_)) == half_u); T = __fadd_rn(T, t_); }
         FLM_INC(v.x) FLM_INC(v.y) FLM_INC(v.z) FLM_INC(v.w)
 #undef FLM_INC
@@ -200,7 +216,8 @@ __device__ __forceinline__ float sq_chain_spec(const float* p, const int bshift,
         if (bad == 0) { res = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint((float)__dadd_rn(bv, __dsub_rn(Si, Sb))), 63)); break; }
         const int f = __ffsll((long long)bad) - 1;
         float l = st;                                           // every lane runs its B steps from its presumed start; lane f's start is exact
-        for (int q = 0; q < BV; ++q) { const float4 v = pl[q]; FLM_SQ4(l, v) }
+#pragma unroll
+        for (int q = 0; q < BV; ++q) { const float4 v = elem(q); FLM_SQ4(l, v) }
         res = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(l), f));
         if (f == 63) break;
         base = f + 1; bv = (double)res; Sb = readlane_f64(S, f + 1);
@@ -208,6 +225,12 @@ __device__ __forceinline__ float sq_chain_spec(const float* p, const int bshift,
 #undef FLM_SQ4
     if (rounds_out) *rounds_out = rounds;
     return res;
+}
+// (BVR > 0 keeps the lane's elements in registers; inside k_gemv that costs 16+ VGPRs next to the two prefetched weight sets and the
+//  kernel SPILLS -- scratch accesses then queue behind the weight loads in the memory pipeline and the chain took 10 us instead of 2.5:
+//  measured.  The prologue therefore runs the LDS-fed form; the register form is for callers with registers to spare.)
+__device__ __forceinline__ float sq_chain_spec(const float* p, const int bshift, int* rounds_out = nullptr) {
+    return sq_chain_spec_t<0>(p, bshift, rounds_out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -309,12 +332,23 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
             // the hook issues the weight prefetch.  The chain waves (0..3, one strided lane each) go first (the others give
             // them ~128 cycles): their loads enter an empty memory pipeline at once and they are free for the chains;
             // queued behind the other waves' loads they would stall for ~1 us before (or after) the chain.
+#ifdef FLM_CHAIN_LATE_ISSUE
+            // the chain waves request their weights only AFTER the chain: 1.35 us of issue (measured) leaves the critical path
+            if (tid >= 4 * kWave) after_stage(0);
+#else
             if (tid >= 4 * kWave) __builtin_amdgcn_s_sleep(2);
             after_stage(0);
+#endif
+#ifdef FLM_TRACE_PRO2
+            FLM_PRO_STAMP(1)
+#endif
             if (tid < 4 * kWave && !(kAblate && (a.ablate & 2))) {
                 const float l = sq_chain_spec(scratch + (tid >> 6) * CS, bs);
                 if ((tid & 63) == 0) red[8 + (tid >> 6)] = l;
             }
+#ifdef FLM_CHAIN_LATE_ISSUE
+            if (tid < 4 * kWave) after_stage(0);
+#endif
             FLM_PRO_STAMP(4)
             __syncthreads();
             const float ss = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, red[8]), red[9]), red[10]), red[11]);
@@ -720,8 +754,16 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_gemv(const GemvArgs a) {
     GemvCtx<QT, EPI> g;
     g.init(a, blockIdx.x, gridDim.x, lds);
     if constexpr (PRO == PRO_NONE) g.issue(kAblate ? a.ablate : 0);
+#ifdef FLM_EARLY_ISSUE
+    constexpr int kLatePart = 2;                       // experiment: the first register set is requested right behind the activation loads
+    if constexpr (PRO != PRO_NONE) g.issue(kAblate ? a.ablate : 0, 1);
+#else
+    constexpr int kLatePart = 0;
+#endif
+#ifndef FLM_TRACE_PRO2
     stamp(1);
-    gemv_prologue<QT, PRO, XR>(a, lds, xv, nv, [&](int part) { g.issue(kAblate ? a.ablate : 0, part); });
+#endif
+    gemv_prologue<QT, PRO, XR>(a, lds, xv, nv, [&](int) { g.issue(kAblate ? a.ablate : 0, kLatePart); });
     stamp(2);
     if (kAblate && (a.ablate & 32)) return;
     g.run(a, lds, stamp);

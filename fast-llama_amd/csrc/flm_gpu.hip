@@ -73,6 +73,8 @@ struct flm_ctx {
     int fuse_attn_o = 1;                               // option "fuse_attn_o": attention + Wo GEMV in one launch (k_attn_o; single GPU)
     unsigned* flag_lines = nullptr; int* xwg_err = nullptr;   // k_attn_o: one 64-byte flag line per head; "a cross-workgroup wait timed out"
     void* att_q = nullptr; float* att_qs = nullptr;    // k_attn_o: the heads' output already quantized (head_size a multiple of 64)
+    float* att_sc = nullptr;                           // [heads_local][max_seq] scores exchanged between the parts of a split head
+    int attn_split = 1;                                // option "attn_split": 1 = spread a head over 4 workgroups from kSplitFrom (128) positions on, 0 = never, >= 2 = always that many
     int trace_class = -1; unsigned long long* trace = nullptr;   // FLM_ABLATE builds: GEMV timeline of one kernel class
     std::map<int, hipGraphExec_t> graphs;             // key = with_cls*4 + advance
     std::vector<TimedLaunch>* timing = nullptr;
@@ -262,12 +264,12 @@ bool model_complete(const flm_ctx* c) {
 // context's life and FLM_RETRY tells the caller (inside this library) to run the call again on one kernel per phase.
 constexpr int FLM_RETRY = 1;
 int xwg_check(flm_ctx* c) {
-    if (c->world != 1 || !c->fuse_attn_o) return FLM_OK;
+    if (!c->fuse_attn_o && c->attn_split == 0) return FLM_OK;
     int e = 0;
     HIPC(c, hipMemcpy(&e, c->xwg_err, 4, hipMemcpyDeviceToHost));
     if (!e) return FLM_OK;
     HIPC(c, hipMemset(c->xwg_err, 0, 4));
-    c->fuse_attn_o = 0;
+    c->fuse_attn_o = 0; c->attn_split = 0;
     for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
     c->graphs.clear();
     return FLM_RETRY;
@@ -299,12 +301,23 @@ GemvArgs args_qkv(flm_ctx* c, int l) {
     a.dim = c->dim_local; a.kv_dim = c->dim_local; a.max_seq = d.max_seq_len; a.hs = c->hs;
     return a;
 }
-AttnArgs args_attn(flm_ctx* c, int l) {
+// Parts per head for a token whose context is T positions: long contexts spread a head's K/V stream over 4 CUs (attn_head, G > 1).
+// Below kSplitFrom the exchange of scores between the parts (one more cross-workgroup hand-off) costs more than it saves.
+constexpr int kSplitFrom = 128;
+int attn_parts(const flm_ctx* c, int T) {
+    // every part owns kSplitDims = 32 output dimensions (its whole V slice then fits the registers / LDS of one workgroup)
+    const int Gfull = c->hs / kSplitDims;
+    const bool can = c->hs % kSplitDims == 0 && Gfull >= 2 && c->d.max_seq_len <= kSplitMaxSeq && c->heads_local * Gfull + 8 <= c->cu_count && c->heads_local * Gfull <= 256;
+    if (!can || c->attn_split == 0) return 1;
+    return (c->attn_split >= 2 || T >= kSplitFrom) ? Gfull : 1;
+}
+AttnArgs args_attn(flm_ctx* c, int l, int G = 1) {
     const auto& d = c->d;
     const size_t kv_layer = (size_t)c->heads_local * d.max_seq_len * c->hs;
     AttnArgs a{};
     a.q = c->qbuf; a.kcache = c->kcache + (size_t)l * kv_layer; a.vcache = c->vcache + (size_t)l * kv_layer;
     a.out = c->att_out + (size_t)c->plan.head_begin * c->hs; a.pos_ptr = &c->state->pos; a.hs = c->hs; a.max_seq = d.max_seq_len;
+    a.G = G; a.sc_global = c->att_sc; a.flag_sc = c->flag_lines + 256 * 16; a.epoch = (unsigned)(l + 1); a.err = c->xwg_err;
     return a;
 }
 GemvArgs args_o(flm_ctx* c, int l) {
@@ -337,34 +350,34 @@ GemvArgs args_cls(flm_ctx* c) {
 
 // attention + Wo GEMV of layer l in one launch (k_attn_o); returns FLM_ERR_UNSUPPORTED when the shape does not allow it
 template <int QT>
-int launch_attn_o(flm_ctx* c, hipStream_t st, int l) {
+int launch_attn_o(flm_ctx* c, hipStream_t st, int l, int G) {
     const auto& d = c->d;
-    const int heads = c->heads_local, wgs = c->cu_count - heads;
-    if (wgs < 1 || heads > 512) return FLM_ERR_UNSUPPORTED;
+    const int parts = c->heads_local * G, wgs = c->cu_count - parts;
+    if (wgs < 1 || parts > 256) return FLM_ERR_UNSUPPORTED;
     GemvArgs a = args_o(c, l);
     if (kAblate && c->trace_class == 101 && l == 0) a.trace = c->trace;     // tools/trace_ao.py
     GemvPlan P;
     int r = plan_gemv<QT, PRO_QUANT, EPI_RESIDUAL>(c, a, wgs, P); if (r) return r;
     const int rounds = (a.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4);
     if (rounds > 3) return FLM_ERR_UNSUPPORTED;
-    size_t lds = attn_lds_bytes(d.max_seq_len, c->hs); if (P.lds > lds) lds = P.lds;
-    AttnArgs aa = args_attn(c, l);
-    unsigned* flag = c->flag_lines;                              // one 64-byte line per head, value = layer + 1; k_embed clears them at the start of the token
-    const dim3 grid(heads + P.grid), block(kGemvBlock);
-    if (c->hs % kGroup == 0) {
+    size_t lds = attn_lds_bytes(d.max_seq_len, c->hs, G > 1); if (P.lds > lds) lds = P.lds;
+    AttnArgs aa = args_attn(c, l, G);
+    unsigned* flag = c->flag_lines;                              // one 64-byte line per head part, value = layer + 1; k_embed clears them at the start of the token
+    const dim3 grid(parts + P.grid), block(kGemvBlock);
+    if (c->hs % kGroup == 0 && G == 1) {
         // a head's output is whole quant groups: the head workgroups quantize it themselves (A3 on the 64 values a wave
         // holds), the GEMV workgroups fetch 1 (2) bytes per element and skip the quantize prologue
         aa.oq = c->att_q; aa.os = c->att_qs; aa.oqt = QT;
         a.xq = c->att_q; a.xs = c->att_qs;
-        hipLaunchKernelGGL((k_attn_o<QT, 0, true>), grid, block, lds, st, aa, a, heads, flag, (unsigned)(l + 1), c->xwg_err);
+        hipLaunchKernelGGL((k_attn_o<QT, 0, true>), grid, block, lds, st, aa, a, parts, flag, (unsigned)(l + 1), c->xwg_err);
     }
-    else if (rounds <= 1) hipLaunchKernelGGL((k_attn_o<QT, 1, false>), grid, block, lds, st, aa, a, heads, flag, (unsigned)(l + 1), c->xwg_err);
-    else                  hipLaunchKernelGGL((k_attn_o<QT, 3, false>), grid, block, lds, st, aa, a, heads, flag, (unsigned)(l + 1), c->xwg_err);
+    else if (rounds <= 1) hipLaunchKernelGGL((k_attn_o<QT, 1, false>), grid, block, lds, st, aa, a, parts, flag, (unsigned)(l + 1), c->xwg_err);
+    else                  hipLaunchKernelGGL((k_attn_o<QT, 3, false>), grid, block, lds, st, aa, a, parts, flag, (unsigned)(l + 1), c->xwg_err);
     HIPC(c, hipGetLastError());
     return FLM_OK;
 }
 
-int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance) {
+int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G) {
     const auto& d = c->d;
     const int qt = d.quant_type, hs = c->hs, L = d.n_layers;
     const bool tp = c->world > 1;
@@ -383,13 +396,13 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance) {
             }
             bool fused = false;
             if (!tp && c->fuse_attn_o && !c->timing && (c->trace_class < 0 || c->trace_class == 101)) {   // attention + ATTN_O in one launch
-                const int r = qt == FLM_QT_INT8 ? launch_attn_o<QT_INT8>(c, st, l) : launch_attn_o<QT_INT16>(c, st, l);
+                const int r = qt == FLM_QT_INT8 ? launch_attn_o<QT_INT8>(c, st, l, G) : launch_attn_o<QT_INT16>(c, st, l, G);
                 if (r == FLM_OK) fused = true; else if (r != FLM_ERR_UNSUPPORTED) return r;
             }
             if (!fused) {   // ATTN task (execute_attn :441-449): local heads write their slice of the full att_out vector
                 Tick t(c, st, KC_ATTN);
-                AttnArgs aa = args_attn(c, l); if (kAblate && c->trace_class == KC_ATTN && l == 0) aa.trace = c->trace;
-                hipLaunchKernelGGL(k_attn_decode, dim3(c->heads_local), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, hs), st, aa);
+                AttnArgs aa = args_attn(c, l, G); if (kAblate && c->trace_class == KC_ATTN && l == 0) aa.trace = c->trace;
+                hipLaunchKernelGGL(k_attn_decode, dim3(c->heads_local * G), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, hs, G > 1), st, aa);
                 HIPC(c, hipGetLastError());
             }
             if (tp) {   // every rank needs all heads' outputs: the reference's threads share x2 in memory (transformer.cpp:451-454)
@@ -443,15 +456,17 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance) {
     return FLM_OK;
 }
 
-// run one token, through a cached hipGraph when enabled
-int run_token(flm_ctx* c, bool with_cls, int advance) {
-    if (!c->use_graph || c->timing || c->world > 1) return enqueue_token(c, c->stream, with_cls, advance);
-    const int key = (with_cls ? 4 : 0) + advance;
+// run one token, through a cached hipGraph when enabled.  T = positions the token's attention covers (known to the host:
+// it picks how many workgroups a head is spread over; the graphs are keyed by it)
+int run_token(flm_ctx* c, bool with_cls, int advance, int T) {
+    const int G = attn_parts(c, T);
+    if (!c->use_graph || c->timing || c->world > 1) return enqueue_token(c, c->stream, with_cls, advance, G);
+    const int key = (with_cls ? 4 : 0) + advance + 8 * G;
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
         hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
         HIPC(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        int r = enqueue_token(c, c->stream, with_cls, advance);
+        int r = enqueue_token(c, c->stream, with_cls, advance, G);
         hipError_t e = hipStreamEndCapture(c->stream, &g);
         if (r) { if (g) hipGraphDestroy(g); return r; }
         HIPC(c, e);
@@ -595,17 +610,17 @@ int feed(flm_ctx* c, const int32_t* tokens, int n, int pos, int final_advance) {
         r = c->d.quant_type == FLM_QT_INT8 ? prefill_batched<QT_INT8>(c, n - 1, pos) : prefill_batched<QT_INT16>(c, n - 1, pos);
         if (r) return r;
         r = set_state(c, pos + n - 1, tokens[n - 1], 0); if (r) return r;
-        return run_token(c, true, final_advance);
+        return run_token(c, true, final_advance, pos + n);
     }
     r = set_state(c, pos, tokens[0], 0); if (r) return r;
-    for (int i = 0; i + 1 < n; ++i) { r = run_token(c, false, 2); if (r) return r; }
+    for (int i = 0; i + 1 < n; ++i) { r = run_token(c, false, 2, pos + i + 1); if (r) return r; }
     // last token: classifier; state.step is reset so out_tokens[0] receives the argmax
     if (n > 1) {
         // step was used as the prompt cursor; zero it for the argmax slot
         hipLaunchKernelGGL(k_set_step, dim3(1), dim3(64), 0, c->stream, c->state, 0);
         HIPC(c, hipGetLastError());
     }
-    return run_token(c, true, final_advance);
+    return run_token(c, true, final_advance, pos + n);
 }
 
 } // namespace
@@ -710,6 +725,7 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
     HIPB(hipMalloc((void**)&c->flag_lines, 512 * 64)); HIPB(hipMalloc((void**)&c->xwg_err, 64));
     HIPB(hipMemsetAsync(c->flag_lines, 0, 512 * 64, c->stream)); HIPB(hipMemsetAsync(c->xwg_err, 0, 64, c->stream));
     HIPB(hipMalloc(&c->att_q, (size_t)d.dim * c->esz)); HIPB(hipMalloc((void**)&c->att_qs, (size_t)(d.dim / kGroup) * 4));
+    HIPB(hipMalloc((void**)&c->att_sc, (size_t)c->heads_local * d.max_seq_len * 4));
     HIPB(hipMalloc((void**)&c->state, sizeof(DecodeState)));
     HIPB(hipMemsetAsync(c->state, 0, sizeof(DecodeState), c->stream));
     std::vector<float> cs, sn; build_rope_table(hs, d.max_seq_len, cs, sn);
@@ -733,7 +749,7 @@ void flm_ctx_destroy(flm_ctx* c) {
     fq(c->cls);
     void* ptrs[] = {c->emb, c->emb_s, c->out_norm, c->kcache, c->vcache, c->x1, c->qbuf, c->att_out, c->hd,
                     c->logits, c->rope_cos, c->rope_sin, c->state, c->prompt_dev, c->out_tokens_dev,
-                    c->flag_lines, c->xwg_err, c->att_q, c->att_qs, c->trace,
+                    c->flag_lines, c->xwg_err, c->att_q, c->att_qs, c->att_sc, c->trace,
                     c->pf_x, c->pf_qkv, c->pf_q, c->pf_att, c->pf_gu, c->pf_hd, c->pf_xs, c->pf_xq};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->comm) ncclCommDestroy(c->comm);
@@ -750,6 +766,7 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (k == "use_mfma") c->use_mfma = value;
     else if (k == "fuse_attn_o") c->fuse_attn_o = value;
     else if (k == "use_prefill_mq") c->use_prefill_mq = value;
+    else if (k == "attn_split") c->attn_split = value;
     else if (kAblate && k == "ablate") c->ablate = value;              // FLM_ABLATE builds only: a product library cannot skip work
     else if (kAblate && k == "trace") {   // value = kernel class to trace (KC_*), -1 off
         c->trace_class = value;
@@ -898,7 +915,7 @@ static int decode_loop(flm_ctx* c, int32_t first_token, int pos, int n_steps, hi
     if (n_steps > c->out_cap) return fail(c, FLM_ERR_INVALID, "more steps than max_seq_len");
     r = set_state(c, pos, first_token, 0); if (r) return r;
     if (e0) HIPC(c, hipEventRecord(e0, c->stream));
-    for (int i = 0; i < n_steps; ++i) { r = run_token(c, true, 1); if (r) return r; }
+    for (int i = 0; i < n_steps; ++i) { r = run_token(c, true, 1, pos + i + 1); if (r) return r; }
     if (e1) HIPC(c, hipEventRecord(e1, c->stream));
     return FLM_OK;
 }
@@ -948,7 +965,7 @@ int flm_decode_timed_each(flm_ctx* c, int32_t first_token, int pos, int n_steps,
     for (auto& x : ev.e) HIPC(c, hipEventCreate(&x));
     r = set_state(c, pos, first_token, 0); if (r) return r;
     HIPC(c, hipEventRecord(ev.e[0], c->stream));
-    for (int i = 0; i < n_steps; ++i) { r = run_token(c, true, 1); if (r) return r; HIPC(c, hipEventRecord(ev.e[i + 1], c->stream)); }
+    for (int i = 0; i < n_steps; ++i) { r = run_token(c, true, 1, pos + i + 1); if (r) return r; HIPC(c, hipEventRecord(ev.e[i + 1], c->stream)); }
     HIPC(c, hipEventSynchronize(ev.e[n_steps]));
     for (int i = 0; i < n_steps; ++i) HIPC(c, hipEventElapsedTime(&ms_each[i], ev.e[i], ev.e[i + 1]));
     r = xwg_check(c);
@@ -969,7 +986,7 @@ int flm_kernel_times(flm_ctx* c, int pos, int iters, float* avg_us, int32_t* cou
         for (int it = 0; it < iters + 1; ++it) {
             r = set_state(c, pos, 1 % c->d.vocab_size, 0); if (r) return r;
             std::vector<TimedLaunch> tl; c->timing = &tl;
-            r = enqueue_token(c, c->stream, true, 1);
+            r = enqueue_token(c, c->stream, true, 1, attn_parts(c, pos + 1));
             c->timing = nullptr;
             hipStreamSynchronize(c->stream);
             for (auto& t : tl) {
@@ -992,7 +1009,7 @@ int flm_kernel_times(flm_ctx* c, int pos, int iters, float* avg_us, int32_t* cou
         switch (kc) {
         case KC_EMBED:  hipLaunchKernelGGL(k_embed, dim3((d.dim + 255) / 256), dim3(256), 0, st, c->x1, (const void*)c->emb, (const float*)c->emb_s, c->emb_qt, d.dim, (const int*)&c->state->tok, c->flag_lines); return FLM_OK;
         case KC_QKV:    return launch_gemv<PRO_RMSNORM_QUANT, EPI_ROPE_KV>(c, st, qt, args_qkv(c, l), wgs);
-        case KC_ATTN:   hipLaunchKernelGGL(k_attn_decode, dim3(c->heads_local), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, c->hs), st, args_attn(c, l)); return FLM_OK;
+        case KC_ATTN:   { const int G = attn_parts(c, pos + 1); hipLaunchKernelGGL(k_attn_decode, dim3(c->heads_local * G), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, c->hs, G > 1), st, args_attn(c, l, G)); return FLM_OK; }
         case KC_ATTN_O: return launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, args_o(c, l), wgs);
         case KC_FFN13:  return launch_gemv<PRO_RMSNORM_QUANT, EPI_SWIGLU>(c, st, qt, args_ffn13(c, l), wgs);
         case KC_FFN2:   return launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, args_ffn2(c, l), wgs);
@@ -1006,6 +1023,7 @@ int flm_kernel_times(flm_ctx* c, int pos, int iters, float* avg_us, int32_t* cou
         const bool per_layer = kc >= KC_QKV && kc <= KC_FFN2;
         const int n = per_layer ? L : 8;
         for (int it = 0; it < iters + 1 && !r; ++it) {          // first round: warm-up
+            if (kc == KC_ATTN) r = launch(KC_EMBED, 0);          // (clears the flag lines the parts of a split head wait on)
             HIPC(c, hipEventRecord(e0, st));
             for (int i = 0; i < n && !r; ++i) r = launch(kc, per_layer ? i : 0);
             HIPC(c, hipEventRecord(e1, st));
@@ -1072,7 +1090,7 @@ int flm_op_square_sum(const float* x, size_t n, float* out6) {
     hipLaunchKernelGGL(k_op_square_sum, dim3(1), dim3(256), lds, 0, dout.as<float>(), dx.as<float>(), (int)n);
     OPC(hipGetLastError()); OPC(hipDeviceSynchronize());
     OPC(hipMemcpy(out6, dout.p, 6 * 4, hipMemcpyDeviceToHost));
-    if (getenv("FLM_SQ_ITERS")) { float it[4]; hipMemcpy(it, (char*)dout.p + 24, 16, hipMemcpyDeviceToHost); fprintf(stderr, "sq_chain_spec rounds per chain (-1: plain chain): %g %g %g %g\n", it[0], it[1], it[2], it[3]); }
+    if (getenv("FLM_SQ_ITERS")) { float it[6]; hipMemcpy(it, (char*)dout.p + 24, 24, hipMemcpyDeviceToHost); fprintf(stderr, "sq_chain_spec rounds per chain (-1: plain chain): %g %g %g %g; shader-clock ticks: speculative %g, plain %g\n", it[0], it[1], it[2], it[3], it[4], it[5]); }
     return FLM_OK;
 }
 
@@ -1180,7 +1198,14 @@ int flm_op_attention(float* out, float* kc, float* vc, const float* q, const flo
     OPC(hipGetLastError());
     AttnArgs a{}; a.q = dq.as<float>(); a.kcache = dkc.as<float>(); a.vcache = dvc.as<float>(); a.pos_ptr = dpos.as<int>(); a.hs = hs; a.max_seq = max_seq;
     a.out = dout.as<float>();
-    hipLaunchKernelGGL(k_attn_decode, dim3(n_heads), dim3(kAttnBlock), attn_lds_bytes(max_seq, hs), 0, a);
+    // tests: FLM_OP_ATTN_PARTS = G spreads every head over G workgroups (the long-context path of the decode loop)
+    int G = (getenv("FLM_OP_ATTN_PARTS") && atoi(getenv("FLM_OP_ATTN_PARTS")) > 1) ? hs / kSplitDims : 1;
+    if (G < 2 || hs % kSplitDims || n_heads * G > 256 || max_seq > kSplitMaxSeq) G = 1;
+    DevBuf dsc, dfl, derr;
+    if (dsc.alloc((size_t)n_heads * max_seq * 4) || dfl.alloc(256 * 64) || derr.alloc(64)) return FLM_ERR_OOM;
+    OPC(hipMemset(dfl.p, 0, 256 * 64)); OPC(hipMemset(derr.p, 0, 64));
+    a.G = G; a.sc_global = dsc.as<float>(); a.flag_sc = dfl.as<unsigned>(); a.epoch = 1; a.err = derr.as<int>();
+    hipLaunchKernelGGL(k_attn_decode, dim3(n_heads * G), dim3(kAttnBlock), attn_lds_bytes(max_seq, hs, G > 1), 0, a);
     OPC(hipGetLastError());
     OPC(hipDeviceSynchronize());
     OPC(hipMemcpy(out, dout.p, nd * 4, hipMemcpyDeviceToHost));

@@ -89,9 +89,15 @@ __global__ void __launch_bounds__(256) k_op_square_sum(float* out, const float* 
     __shared__ float red[8];
     __syncthreads();
     int its = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     const float l = sq_chain_spec(sm + (threadIdx.x >> 6) * CS, bs, &its);
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = l; out[6 + (threadIdx.x >> 6)] = (float)its; }
+    __syncthreads();
+    const unsigned long long t2 = __builtin_amdgcn_s_memtime();
     if (threadIdx.x < 4) red[4 + threadIdx.x] = sq_chain(seq + threadIdx.x * ns, n4);
+    const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) { out[10] = (float)(t1 - t0); out[11] = (float)(t3 - t2); }      // shader-clock ticks: speculative / plain chain
     __syncthreads();
     if (threadIdx.x == 0) {
         out[0] = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, red[0]), red[1]), red[2]), red[3]);

@@ -63,7 +63,8 @@ double item_number(const Cursor& c, const Block& b) {
 bool load_flm(const std::string& path, bool tokenizer_only, bool debug, ModelFile& m, std::string& err) {
     int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) { err = "Failed to open model file:" + path; return false; }
-    struct stat st; fstat(fd, &st);
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < 8) { close(fd); err = "Cannot stat model file (or it is too short):" + path; return false; }
     m.map_size = (size_t)st.st_size;
     m.map_base = mmap(nullptr, m.map_size, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
@@ -103,7 +104,12 @@ bool load_flm(const std::string& path, bool tokenizer_only, bool debug, ModelFil
             const uint32_t n = c.at<uint32_t>(q + 40), tsz = c.at<uint32_t>(q + 44);
             const size_t items = q + 48, text = items + (size_t)16 * n;
             if (!c.ok(text, tsz)) { err = "Reading tokenizer texts error"; return false; }
-            auto str_at = [&](uint32_t off) { const char* p = reinterpret_cast<const char*>(c.base + text + off); return std::string(p, strnlen(p, tsz - off)); };
+            // every offset comes from the file: one past the text area is an error, not a read beyond the mapping
+            bool bad_off = false;
+            auto str_at = [&](uint32_t off) {
+                if (off >= tsz) { bad_off = true; return std::string(); }
+                const char* p = reinterpret_cast<const char*>(c.base + text + off); return std::string(p, strnlen(p, tsz - off));
+            };
             m.vocab.tokens.resize(n);
             for (uint32_t i = 0; i < n; ++i) {
                 const size_t it = items + (size_t)16 * i;
@@ -112,12 +118,15 @@ bool load_flm(const std::string& path, bool tokenizer_only, bool debug, ModelFil
                 t.type = (int)c.at<uint32_t>(it + 8); t.score = c.at<float>(it + 12);
             }
             m.vocab.conn_tag = str_at(conn_pos);
+            if (bad_off) { err = "Tokenizer text offset outside the text area"; return false; }
             m.vocab.bos = special[1]; m.vocab.eos = special[2]; m.vocab.pad = special[3];
             if (tokenizer_only) return true;
         } else if (b.type == BT_TENSOR) {
             // tensor header (flm_loader.cpp:165-177): shape[4] u32, tensor_type u16, layer_id u16, scales_size u32
             const size_t hp = pos + 16;
+            if (b.header_size < 40 || !c.ok(hp, 24)) { err = "Tensor block header too short:" + b.name; return false; }
             uint32_t shape[4]; memcpy(shape, c.base + hp, 16);
+            for (int i = 0; i < 4; ++i) if (shape[i] > 0x7fffffffu) { err = "Tensor dimension out of range in block:" + b.name; return false; }
             HostTensor t;
             t.kind = c.at<uint16_t>(hp + 16); t.layer = c.at<uint16_t>(hp + 18);
             const uint32_t ssz = c.at<uint32_t>(hp + 20);
@@ -126,9 +135,13 @@ bool load_flm(const std::string& path, bool tokenizer_only, bool debug, ModelFil
             else { err = "Unsupported tensor rank in block:" + b.name; return false; }
             t.qtype = b.dtype == DT_INT8 ? 2 : b.dtype == DT_INT16 ? 1 : 0;
             if (b.dtype != DT_INT8 && b.dtype != DT_INT16 && b.dtype != DT_FLOAT32) { err = "Unsupported tensor data type in block:" + b.name; return false; }
-            const size_t esz = t.qtype == 2 ? 1 : t.qtype == 1 ? 2 : 4, vbytes = (size_t)t.rows * t.cols * esz;
+            const size_t esz = t.qtype == 2 ? 1 : t.qtype == 1 ? 2 : 4;
+            const unsigned long long elems = (unsigned long long)t.rows * (unsigned long long)t.cols;       // < 2^62
+            if (elems > (1ull << 40)) { err = "Tensor too large in block:" + b.name; return false; }
+            const size_t vbytes = (size_t)elems * esz;
             const size_t d0 = pos + b.header_size;
-            if (vbytes + (size_t)ssz * 4 > b.data_size) { err = "Tensor block too small:" + b.name; return false; }
+            if (vbytes > b.data_size || (size_t)ssz * 4 > b.data_size - vbytes) { err = "Tensor block too small:" + b.name; return false; }
+            if (t.qtype && (t.cols % 64 || (size_t)ssz < elems / 64)) { err = "Quantized tensor with too few scales:" + b.name; return false; }
             t.values = c.base + d0;
             t.scales = ssz ? reinterpret_cast<const float*>(c.base + d0 + vbytes) : nullptr;
             if (t.qtype && !ssz) { err = "Quantized tensor without scales:" + b.name; return false; }
@@ -156,6 +169,7 @@ bool load_llama2c_tokenizer(const std::string& path, int vocab_size, Vocab& v, s
     }
     fclose(f);
     v.bos = 1; v.eos = 2; v.pad = 0;
+    v.conn_tag.clear();      // Tokenizer::load never sets _conn_tag (tokenizer.cpp:162-233): " " has no token of its own and falls back to the byte token
     return true;
 }
 
@@ -166,6 +180,12 @@ bool load_llama2c(const std::string& ckpt, const std::string& tok_path, bool tok
     if (fread(h, 4, 7, f) != 7) { fclose(f); err = "Reading model file error:" + ckpt; return false; }
     Config& c = m.cfg;
     c.dim = h[0]; c.hidden_dim = h[1]; c.n_layers = h[2]; c.n_heads = h[3]; c.n_kv_heads = h[4]; c.vocab_size = abs(h[5]); c.max_seq_len = h[6];
+    // the header is untrusted input (and -f llama2c skips the detector): refuse what the quantizer and the engine cannot handle
+    if (c.dim <= 0 || c.hidden_dim <= 0 || c.n_layers <= 0 || c.n_heads <= 0 || c.n_kv_heads <= 0 || c.vocab_size <= 0 || c.max_seq_len <= 0 ||
+        c.dim % 64 || c.hidden_dim % 64 || c.dim % c.n_heads || c.n_kv_heads > c.n_heads || c.n_heads % c.n_kv_heads ||
+        c.dim > (1 << 20) || c.hidden_dim > (1 << 22) || c.n_layers > 4096 || c.vocab_size > (1 << 24)) {
+        fclose(f); err = "Invalid llama2.c header (dim / hidden_dim must be positive multiples of 64, dim a multiple of n_heads, 0 < n_kv_heads <= n_heads):" + ckpt; return false;
+    }
     c.quant_type = 2; c.name = "llama2c";   // weights are quantized to INT8 below; the reference leaves NONE and only works with -q int8
     const bool shared = h[5] > 0;
     if (!load_llama2c_tokenizer(tok_path, c.vocab_size, m.vocab, err)) { fclose(f); return false; }
@@ -176,7 +196,7 @@ bool load_llama2c(const std::string& ckpt, const std::string& tok_path, bool tok
     // every 2-D tensor (the embedding table included) is quantized to INT8 / 64 at load (llama2c_loader.cpp:83,117-124)
     auto add_q = [&](int kind, int layer, int rows, int cols, const float* src) {
         HostTensor t; t.kind = kind; t.layer = layer; t.qtype = 2; t.rows = rows; t.cols = cols;
-        t.owned_values.resize((size_t)rows * cols); t.owned_scales.resize((size_t)rows * cols / 64);
+        t.owned_values.resize((size_t)rows * cols); t.owned_scales.resize(((size_t)rows * cols + 63) / 64);
         quantize_groups(src, (size_t)rows * cols, 2, t.owned_values.data(), t.owned_scales.data());
         m.tensors.push_back(std::move(t));
     };
@@ -260,7 +280,8 @@ float half_to_float(uint16_t h) {
 bool load_gguf(const std::string& path, bool tokenizer_only, bool debug, ModelFile& m, std::string& err) {
     int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) { err = "Failed to open gguf file:" + path; return false; }
-    struct stat st; fstat(fd, &st);
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < 8) { close(fd); err = "Cannot stat model file (or it is too short):" + path; return false; }
     m.map_size = (size_t)st.st_size;
     m.map_base = mmap(nullptr, m.map_size, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);

@@ -131,7 +131,8 @@ int  flm_debug_read(flm_ctx* ctx, int what, int layer, float* out, size_t n);
 /* tuning knobs: "wg_per_cu" workgroups per CU for the GEMV kernels, "use_graph" hipGraph replay on/off,
  * "fuse_attn_o" 0 = attention and the Wo GEMV as two launches (default 1: one launch, single GPU),
  * "use_prefill" 0 = feed prompts token by token (default 1: batched), "use_prefill_mq" 0 = batched attention with one query per
- * workgroup (default 1: eight), "use_mfma" 0 = int8 prefill GEMM on v_dot4 instead of the matrix cores (default 1; 2 = matrix cores, 64 x 64 tiles always).
+ * workgroup (default 1: eight), "attn_split" 0 = one workgroup per head at every context length (default 1: hs / 32 from 128 positions on; n >= 2: always n),
+ * "use_mfma" 0 = int8 prefill GEMM on v_dot4 instead of the matrix cores (default 1; 2 = matrix cores, 64 x 64 tiles always).
  * None of them changes a result bit.  (Perf-exploration switches that DO skip work -- "ablate", "trace" -- exist only in builds
  * with -DFLM_ABLATE=1; the product library answers FLM_ERR_INVALID to them.) */
 int  flm_set_option(flm_ctx* ctx, const char* key, int value);

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# before anything can load an OpenMP runtime (numpy does not, torch and the oracle do): see oracle_py._tame_openmp
+os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(8, os.cpu_count() or 1))))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -27,9 +27,19 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+def _tame_openmp():
+    """The checker's OpenMP loops are tiny; on a many-core host (the GPU box has 256 hardware threads and other tenants) the
+    default -- one spinning thread per core -- made every oracle call take seconds (a 0.05 s test took 42 s).  Cap the team and
+    make idle threads sleep; must run before libgomp starts (it reads the environment once)."""
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(8, os.cpu_count() or 1))))
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    os.environ.setdefault("OMP_DYNAMIC", "false")
+
+
 def orc():
     global _orc
     if _orc is None:
+        _tame_openmp()
         if not os.path.exists(ORACLE_SO):
             subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"], check=True)
         _orc = C.CDLL(ORACLE_SO)
@@ -46,6 +56,7 @@ def have_ref():
 def ref():
     global _ref
     if _ref is None:
+        _tame_openmp()
         _ref = C.CDLL(REF_SO)
         _ref.ref_model_load.restype = C.c_void_p
         _ref.ref_dot_f32.restype = C.c_float

@@ -175,6 +175,31 @@ def test_fused_attention_decode_over_the_whole_context_matches_two_launches(gpu)
     assert bits_equal(res[0][2], res[1][2])
 
 
+def test_long_context_decode_with_split_heads_vs_oracle(gpu):
+    """7B width, one layer: a 600-token prompt, then decode steps at positions 600.. with every head spread over 4 workgroups
+    (the default from 128 positions on) and over 1 and 2 -- logits bit-equal to the oracle's"""
+    cfg = synth.make_config("7B", ff.QT_INT8); cfg.n_layers = 1
+    tensors = synth.make_tensors(cfg, seed=19)
+    om = O.OracleModel(cfg, tensors)
+    prompt = _prompt(cfg.vocab_size, 600)
+    want = [om.forward(prompt, 0)]
+    cur, pos = int(np.argmax(want[0])), len(prompt)
+    for _ in range(3):
+        want.append(om.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(want[-1])); pos += 1
+    for opts in ({}, {"attn_split": 0}, {"attn_split": 2}, {"fuse_attn_o": 0}, {"use_graph": 0}):
+        ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        lg = ctx.forward(prompt, 0)
+        assert bits_equal(lg, want[0]), opts
+        cur, pos = int(np.argmax(lg)), len(prompt)
+        for i in range(3):
+            lg = ctx.forward(np.array([cur], np.int32), pos)
+            assert bits_equal(lg, want[i + 1]), (opts, i)
+            cur = int(np.argmax(lg)); pos += 1
+        ctx.close()
+
+
 def test_cross_workgroup_handoff_is_stable(gpu):
     """the fused attention + Wo launch hands the heads' output to the GEMV workgroups inside one kernel.  100 replays of a 5-token
     prompt fed token by token plus three more tokens (int16, 7B width: the configuration in which a hand-off that did not wait for the

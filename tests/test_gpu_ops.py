@@ -136,6 +136,35 @@ def test_attention_decode(gpu, hs, heads):
         pos += 1
 
 
+@pytest.mark.parametrize("parts", [2, 4])
+@pytest.mark.parametrize("hs,heads", [(128, 32), (64, 4), (128, 3)])
+def test_attention_decode_split_over_workgroups(gpu, hs, heads, parts, monkeypatch):
+    """long contexts spread a head over several workgroups (scores by position tile, weighted sum by output dimension, scores
+    exchanged through memory inside the launch): same bits as the oracle at short, tile-boundary and long positions"""
+    monkeypatch.setenv("FLM_OP_ATTN_PARTS", str(parts))
+    rng = np.random.default_rng(hs * heads + parts)
+    max_seq = 1024
+    kc_o = np.zeros((heads, max_seq, hs), np.float32); vc_o = np.zeros_like(kc_o)
+    pos = 0
+    for target in [0, 3, 63, 64, 200, 255, 256, 257, 700, 1023]:
+        if target > pos:
+            bs = target - pos
+            q = rng.standard_normal((heads, bs, hs)).astype(np.float32); k = rng.standard_normal((heads, bs, hs)).astype(np.float32)
+            v = rng.standard_normal((heads, bs, hs)).astype(np.float32)
+            for h in range(heads):
+                O.attention_head(kc_o[h], vc_o[h], q[h], k[h], v[h], pos)
+            pos = target
+        kc_g = kc_o.copy(); vc_g = vc_o.copy()
+        q = rng.standard_normal((heads, hs)).astype(np.float32) * 2; k = rng.standard_normal((heads, hs)).astype(np.float32)
+        v = rng.standard_normal((heads, hs)).astype(np.float32)
+        if target == 700:
+            q *= 40.0                                  # a peaked softmax: most weights fall under the 1e-15 skip threshold
+        ref = np.stack([O.attention_head(kc_o[h], vc_o[h], q[h:h + 1], k[h:h + 1], v[h:h + 1], pos)[0] for h in range(heads)])
+        out = gpu.op_attention(kc_g, vc_g, q.reshape(-1), k.reshape(-1), v.reshape(-1), heads, hs, max_seq, pos).reshape(heads, hs)
+        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), f"pos {pos}"
+        pos += 1
+
+
 def _sq_cases():
     rng = np.random.default_rng(42)
     cases = []
