@@ -283,12 +283,19 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # FLM_BENCH_FORCE_DEVICE=0: every rank on the same GPU (a 1-GPU box exercising the multi-process path: gloo bootstrap, IPC-mapped
+    # peers); the normal case is one GPU per rank and the nccl backend
+    force_dev = os.environ.get("FLM_BENCH_FORCE_DEVICE")
+    device = int(force_dev) if force_dev is not None else local_rank
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if force_dev is not None:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
 
     def barrier():
         if dist is not None:
@@ -313,7 +320,7 @@ def main():
     m = None
     if mode == "tp":
         try:
-            ctx = open_tp_ctx(capi, cfg, rank, world, local_rank, dist, torch)
+            ctx = open_tp_ctx(capi, cfg, rank, world, device, dist, torch)
             upload_synthetic(ctx, cfg)
             m = time_decode(ctx, cfg, args, prompt_for(0), barrier, gold)
             ok = 1
@@ -321,12 +328,12 @@ def main():
             log(f"rank {rank}: tensor-parallel run failed: {e}")
             tp_note = f"tensor-parallel run failed on rank {rank}: {e}"
             ok = 0
-        okt = torch.tensor([ok], device="cuda"); dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        okt = torch.tensor([ok], device="cuda" if dist.get_backend() == "nccl" else "cpu"); dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         if int(okt.item()) == 0:
             mode, m = "replicas", None
             tp_note = tp_note or "tensor-parallel run failed on another rank"
     if mode != "tp":
-        ctx = capi.Ctx(capi.desc_from_config(cfg), device=local_rank)
+        ctx = capi.Ctx(capi.desc_from_config(cfg), device=device)
         if args.wg_per_cu:
             ctx.set_option("wg_per_cu", args.wg_per_cu)
         upload_synthetic(ctx, cfg)
@@ -350,7 +357,7 @@ def main():
     replicas = None
     if mode == "tp":
         try:
-            rctx = capi.Ctx(capi.desc_from_config(cfg), device=local_rank)
+            rctx = capi.Ctx(capi.desc_from_config(cfg), device=device)
             upload_synthetic(rctx, cfg)
             rm = time_decode(rctx, cfg, args, prompt_for(rank), barrier, None)
             r_tok_s, r_elapsed = job_throughput(rm["wall_s"], args.steps, world, "replicas")
@@ -370,7 +377,7 @@ def main():
             "scaling": "strong" if mode == "tp" else "weak", "vs_baseline": None, "dtype": "int8" if qt == ff.QT_INT8 else "int16", "data": "synthetic",
             "config": {"workload": f"LLaMA2-{args.shape} {args.quant} .flm-layout synthetic weights (portable splitmix64 checkpoint, norm weights 1.0), single-stream greedy decode, "
                                    f"prompt {args.prompt_len} tokens, positions {pos}..{pos + args.steps - 1}, fp32 KV cache, max_seq 1024",
-                       "parallelism": {"single": "single-gpu", "tp": f"tp{world}: ONE sequence, every matmul split by output rows over {world} GPUs, activation slices exchanged peer to peer over xGMI",
+                       "parallelism": {"single": "single-gpu", "tp": f"tp{world}: ONE sequence, every matmul split by output rows over {world} GPUs, activation slices exchanged by " + (getattr(ctx, "exchange", "") if mode == "tp" else ""),
                                        "replicas": f"{world} replicas: one independent sequence per GPU, no data-path collective"}[mode],
                        "device_ms_per_step": round(m["ms_dev"] / args.steps, 4)},
             "p50_ms_per_step": round(m["p50_ms"], 4), "p90_ms_per_step": round(m["p90_ms"], 4),
@@ -401,13 +408,40 @@ def main():
         dist.destroy_process_group()
 
 
-def open_tp_ctx(capi, cfg, rank, world, local_rank, dist, torch):
-    """one tensor-parallel context per rank: the RCCL id travels by broadcast, the peer-to-peer handles by all_gather"""
-    idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
-    if rank == 0:
-        idt.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
-    dist.broadcast(idt, 0)
-    return capi.Ctx(capi.desc_from_config(cfg), device=local_rank, rank=rank, world=world, comm_id=bytes(idt.cpu().numpy().tobytes()))
+def open_tp_ctx(capi, cfg, rank, world, device, dist, torch):
+    """one tensor-parallel context per rank.  The ranks are connected peer to peer (every rank's exchange buffer mapped into
+    every other rank: flm_p2p_export -> all_gather of the 128-byte blobs -> flm_p2p_import); an RCCL communicator is created as
+    well when the backend is nccl, as the fallback exchange should the peer mapping fail."""
+    on_gpu = dist.get_backend() == "nccl"
+    dev = "cuda" if on_gpu else "cpu"
+    comm_id = None
+    if on_gpu:
+        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        comm_id = bytes(idt.cpu().numpy().tobytes())
+    ctx = capi.Ctx(capi.desc_from_config(cfg), device=device, rank=rank, world=world, comm_id=comm_id)
+    mine = torch.frombuffer(bytearray(ctx.p2p_export()), dtype=torch.uint8).to(dev)
+    allb = [torch.zeros(128, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(allb, mine)
+    ok = 1
+    try:
+        ctx.p2p_import([bytes(b.cpu().numpy().tobytes()) for b in allb])
+    except Exception as e:  # noqa: BLE001
+        log(f"rank {rank}: peer-to-peer mapping failed ({e}); " + ("falling back to RCCL all-gathers" if comm_id else "no fallback"))
+        ok = 0
+    okt = torch.tensor([ok], device=dev); dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+    if int(okt.item()) == 0:
+        # all ranks must agree on the exchange: rebuild without the peer mapping
+        ctx.close()
+        if not comm_id:
+            raise RuntimeError("peer-to-peer mapping failed and there is no RCCL communicator")
+        ctx = capi.Ctx(capi.desc_from_config(cfg), device=device, rank=rank, world=world, comm_id=comm_id)
+        ctx.exchange = "rccl all-gather"
+    else:
+        ctx.exchange = "peer-to-peer stores over xGMI + flag round"
+    return ctx
 
 
 if __name__ == "__main__":

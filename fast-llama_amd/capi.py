@@ -19,7 +19,7 @@ KCLASSES = ("embed", "qkv", "attn", "attn_o", "ffn13", "ffn2", "cls", "argmax", 
 
 # every symbol include/flm_gpu.h declares (tests check the library exports all of them)
 SYMBOLS = (
-    "flm_comm_unique_id", "flm_ctx_create", "flm_ctx_destroy", "flm_last_error", "flm_upload_tensor",
+    "flm_comm_unique_id", "flm_ctx_create", "flm_ctx_destroy", "flm_p2p_export", "flm_p2p_import", "flm_last_error", "flm_upload_tensor",
     "flm_forward", "flm_forward_argmax", "flm_decode_greedy", "flm_decode_timed", "flm_decode_timed_each", "flm_last_tokens", "flm_reset_kv", "flm_sync",
     "flm_kernel_times", "flm_kernel_bytes", "flm_set_option", "flm_debug_read",
     "flm_op_quantize", "flm_op_matmul_q", "flm_op_rmsnorm", "flm_op_swiglu", "flm_op_rope", "flm_op_softmax",
@@ -99,6 +99,15 @@ class Ctx:
             self.close()
         except Exception:
             pass
+
+    def p2p_export(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        _check(lib().flm_p2p_export(self._h, buf), self._h)
+        return buf.raw
+
+    def p2p_import(self, blobs):
+        raw = b"".join(blobs)
+        _check(lib().flm_p2p_import(self._h, raw, len(blobs)), self._h)
 
     def upload(self, kind, layer, value):
         if isinstance(value, tuple):

@@ -38,6 +38,8 @@ struct AttnArgs {
     // the scores between them, flag_sc one 64-byte line per (head, part) whose value reaches `epoch` when that part's scores
     // are in memory; err as in k_attn_o.
     int G; float* sc_global; unsigned* flag_sc; unsigned epoch; int* err;
+    // tensor parallel, peer-to-peer: the head's output also goes to the same place of every peer rank's buffer (as GemvArgs::out_peer)
+    float* out_peer[7]; int n_peer;
 };
 
 constexpr int kAttnBlock = 1024;      // 16 waves
@@ -362,7 +364,10 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
         }
     }
     stamp(4);
-    if (tid < nd) st_agent(orow + (size_t)h * hs + d0 + tid, o);
+    if (tid < nd) {
+        st_agent(orow + (size_t)h * hs + d0 + tid, o);
+        for (int i = 0; i < a.n_peer; ++i) __hip_atomic_store(a.out_peer[i] + (size_t)h * hs + d0 + tid, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (a.oq && G == 1) {
         // qx.quantize(x2) (transformer.cpp:138) for this head's groups: wave w holds the 64 outputs of group h * hs/64 + w;
         // the max is order-free, the element step is quant_elem.  Packed through LDS (q's place: long since consumed) so that

@@ -30,11 +30,21 @@ struct GemvArgs {
     const float* rope_cos; const float* rope_sin; // [max_seq][hs/2]
     const int* pos_ptr;                         // device-resident position
     int dim; int kv_dim; int max_seq; int hs;   // ROPE_KV geometry
+    // tensor parallel, peer-to-peer: every result is also stored into the same place of every peer rank's buffer (mapped over
+    // xGMI; system-scope stores), so that after the launch plus one flag round every rank holds the whole vector.
+    // out_peer[i] = peer i's `out` pointer (already offset like `out`); for EPI_ROPE_KV nothing is exchanged (q/k/v stay local).
+    float* out_peer[7]; int n_peer;
     // debugging taps used by the op-level exports (may be null)
     void* dbg_xq; float* dbg_xs; float* dbg_xn;
     unsigned long long* trace;                  // FLM_ABLATE builds: per-workgroup timeline [grid][8] (s_memtime), else unused
     int ablate;                                 // FLM_ABLATE builds only (every test of it sits behind kAblate; product builds ignore it): 1 no group chain, 2 no rmsnorm chain, 4 no weight loads, 8 no dots, 16 return immediately, 32 return after prologue
 };
+
+// result store: local (write-through, agent scope) + every peer (system scope)
+__device__ __forceinline__ void st_result(const GemvArgs& a, unsigned row, float v) {
+    st_agent(a.out + row, v);
+    for (int i = 0; i < a.n_peer; ++i) __hip_atomic_store(a.out_peer[i] + row, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 #ifndef FLM_ABLATE
 #define FLM_ABLATE 0          // build with -DFLM_ABLATE=1 to compile the perf-exploration switches of GemvArgs::ablate into the hot loop
@@ -270,7 +280,7 @@ __device__ __forceinline__ void gemv_preload(const GemvArgs& a, float4 (&xv)[XR 
 #else
 #define FLM_PRO_STAMP(k)
 #endif
-// COH (PRO_NONE only): the pre-quantized activation was written by other workgroups of the SAME kernel -> coherent loads
+// COH: the activation was written by other workgroups of the SAME kernel (k_attn_o) or by peer GPUs (tensor parallel) -> coherent loads
 template <int QT, int PRO, int XR, bool COH = false, class AfterStage>
 __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, float4 (&xv)[XR > 0 ? XR : 1], float4 (&wv)[XR > 0 ? XR : 1], AfterStage&& after_stage) {
     using T = QTraits<QT>;
@@ -301,6 +311,14 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
         const int rounds = (n + kGemvBlock * 4 - 1) / (kGemvBlock * 4);
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         float r = 1.0f;
+        auto ldx = [&](int e) -> float4 {                   // activation elements e..e+3 (rounds past the preloaded registers)
+            if constexpr (COH) {
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, n * 4, 0x00020000);
+                const v4f t = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rx, e * 4, 0, kAuxCoherent));
+                return make_float4(t.x, t.y, t.z, t.w);
+            } else return *reinterpret_cast<const float4*>(a.x + e);
+        };
         if constexpr (PRO == PRO_QUANT) {
             // no staging here: the hook (the weight prefetch) runs as soon as this thread's activation registers have landed
             if constexpr (XR > 0) { asm volatile("" :: "v"(xv[XR - 1].w)); }
@@ -325,7 +343,7 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
             for (int i = 0; i < XR; ++i) { if (i < srounds) stage(i, xv[i]); }
             for (int i = XR; i < srounds; ++i) {
                 const int e = tid * 4 + i * kGemvBlock * 4;
-                stage(i, e < n ? *reinterpret_cast<const float4*>(a.x + e) : z4);
+                stage(i, e < n ? ldx(e) : z4);
             }
             __syncthreads();
             FLM_PRO_STAMP(3)
@@ -388,7 +406,7 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
             const int e = tid * 4 + i * kGemvBlock * 4;
             float4 v = z4, w = z4;
             if (e < n) {
-                v = *reinterpret_cast<const float4*>(a.x + e);
+                v = ldx(e);
                 if constexpr (PRO == PRO_RMSNORM_QUANT) w = *reinterpret_cast<const float4*>(a.norm_w + e);
             }
             round(i, v, w);
@@ -666,11 +684,11 @@ struct GemvCtx {
         // ---------------- epilogues ----------------
         if constexpr (EPI == EPI_STORE || EPI == EPI_RESIDUAL) {
             if (rv) {
-                if constexpr (EPI == EPI_STORE) st_agent(a.out + row, acc);
-                else st_agent(a.out + row, __fadd_rn(resid, acc));   // o.add(tmp, offset) transformer.cpp:465,493
+                if constexpr (EPI == EPI_STORE) st_result(a, row, acc);
+                else st_result(a, row, __fadd_rn(resid, acc));       // o.add(tmp, offset) transformer.cpp:465,493
             }
         } else if constexpr (EPI == EPI_SWIGLU) {
-            if (rv) st_agent(a.out + row, swiglu_elem(acc, acc2));   // o1.swiglu(o3) transformer.cpp:481
+            if (rv) st_result(a, row, swiglu_elem(acc, acc2));       // o1.swiglu(o3) transformer.cpp:481
         } else {   // EPI_ROPE_KV: rows (2i, 2i+1) of [Wq;Wk;Wv]; RoPE on q and k, append k,v to the cache
             const float other = __shfl_xor(acc, 1, kWave);
             if (rv && (lane & 1) == 0) {
@@ -732,7 +750,8 @@ struct GemvCtx {
     }
 };
 
-template <int QT, int PRO, int EPI, int XR>
+// COH: the fp32 activation a.x was written by peer GPUs (tensor parallel) -> system-coherent loads
+template <int QT, int PRO, int EPI, int XR, bool COH = false>
 __global__ void __launch_bounds__(kGemvBlock, 4) k_gemv(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     unsigned long long rt0 = 0;
@@ -750,7 +769,7 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_gemv(const GemvArgs a) {
     // 32 MB of weight requests of the early ones: the activation came back 2.6 us later (measured), delaying the
     // whole rmsnorm chain.  Issued after the activation, the first 128 KiB per CU still arrive under the chain.
     float4 xv[XR > 0 ? XR : 1], nv[XR > 0 ? XR : 1];
-    gemv_preload<QT, PRO, XR>(a, xv, nv);
+    gemv_preload<QT, PRO, XR, COH>(a, xv, nv);
     GemvCtx<QT, EPI> g;
     g.init(a, blockIdx.x, gridDim.x, lds);
     if constexpr (PRO == PRO_NONE) g.issue(kAblate ? a.ablate : 0);
@@ -763,7 +782,7 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_gemv(const GemvArgs a) {
 #ifndef FLM_TRACE_PRO2
     stamp(1);
 #endif
-    gemv_prologue<QT, PRO, XR>(a, lds, xv, nv, [&](int) { g.issue(kAblate ? a.ablate : 0, kLatePart); });
+    gemv_prologue<QT, PRO, XR, COH>(a, lds, xv, nv, [&](int) { g.issue(kAblate ? a.ablate : 0, kLatePart); });
     stamp(2);
     if (kAblate && (a.ablate & 32)) return;
     g.run(a, lds, stamp);

@@ -73,6 +73,11 @@ struct flm_ctx {
     int fuse_attn_o = 1;                               // option "fuse_attn_o": attention + Wo GEMV in one launch (k_attn_o; single GPU)
     unsigned* flag_lines = nullptr; int* xwg_err = nullptr;   // k_attn_o: one 64-byte flag line per head; "a cross-workgroup wait timed out"
     void* att_q = nullptr; float* att_qs = nullptr;    // k_attn_o: the heads' output already quantized (head_size a multiple of 64)
+    // tensor parallel, peer-to-peer: ONE exchange buffer per rank -- [att_out | x1 | hd | logits | flag lines] -- shared with the
+    // peers (hipIpc); att_out / x1 / hd / logits point into it.  peer[r] = rank r's buffer mapped here (peer[rank] = xbuf).
+    char* xbuf = nullptr; size_t xbuf_bytes = 0, x_flags_off = 0; bool xbuf_fine = false;
+    char* peer[8] = {nullptr}; bool peer_opened[8] = {false}; int p2p = 0;
+    unsigned* xepoch = nullptr;                        // [4] exchanges done per kind (att, x1, hd, logits), device memory
     float* att_sc = nullptr;                           // [heads_local][max_seq] scores exchanged between the parts of a split head
     int attn_split = 1;                                // option "attn_split": 1 = spread a head over 4 workgroups from kSplitFrom (128) positions on, 0 = never, >= 2 = always that many
     int trace_class = -1; unsigned long long* trace = nullptr;   // FLM_ABLATE builds: GEMV timeline of one kernel class
@@ -143,24 +148,27 @@ int plan_gemv(flm_ctx* c, GemvArgs& a, int wgs, GemvPlan& P) {
     a.rows_per_pass = P.Rm; a.cb_shift = P.cb_shift; a.nbuf = P.nbuf;
     return FLM_OK;
 }
-template <int QT, int PRO, int EPI>
+template <int QT, int PRO, int EPI, bool COH>
 int launch_gemv_xr(flm_ctx* c, hipStream_t st, GemvArgs a, int wgs) {
     GemvPlan P;
     int r = plan_gemv<QT, PRO, EPI>(c, a, wgs, P); if (r) return r;
     const int rounds = (a.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4);
-    if (PRO == PRO_NONE)   hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 0>), dim3(P.grid), dim3(kGemvBlock), P.lds, st, a);
-    else if (rounds <= 1)  hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 1>), dim3(P.grid), dim3(kGemvBlock), P.lds, st, a);
-    else if (rounds <= 3)  hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 3>), dim3(P.grid), dim3(kGemvBlock), P.lds, st, a);
-    else                   hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 0>), dim3(P.grid), dim3(kGemvBlock), P.lds, st, a);
+    if (PRO == PRO_NONE)   hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 0, COH>), dim3(P.grid), dim3(kGemvBlock), P.lds, st, a);
+    else if (rounds <= 1)  hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 1, COH>), dim3(P.grid), dim3(kGemvBlock), P.lds, st, a);
+    else if (rounds <= 3)  hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 3, COH>), dim3(P.grid), dim3(kGemvBlock), P.lds, st, a);
+    else                   hipLaunchKernelGGL((k_gemv<QT, PRO, EPI, 0, COH>), dim3(P.grid), dim3(kGemvBlock), P.lds, st, a);
     HIPC(c, hipGetLastError());
     return FLM_OK;
 }
+// coh: the activation a.x holds slices written by peer GPUs (tensor parallel, peer-to-peer) -> system-coherent loads
 template <int PRO, int EPI>
-int launch_gemv(flm_ctx* c, hipStream_t st, int qt, const GemvArgs& a, int wgs) {
+int launch_gemv(flm_ctx* c, hipStream_t st, int qt, const GemvArgs& a, int wgs, bool coh = false) {
     if (a.n % kGroup != 0 || a.n <= 0) return fail(c, FLM_ERR_INVALID, "gemv: n must be a positive multiple of 64");
-    if (qt == FLM_QT_INT8)  return launch_gemv_xr<QT_INT8, PRO, EPI>(c, st, a, wgs);
-    if (qt == FLM_QT_INT16) return launch_gemv_xr<QT_INT16, PRO, EPI>(c, st, a, wgs);
-    return fail(c, FLM_ERR_UNSUPPORTED, "gemv: quant type must be INT8 or INT16");
+    if (qt != FLM_QT_INT8 && qt != FLM_QT_INT16) return fail(c, FLM_ERR_UNSUPPORTED, "gemv: quant type must be INT8 or INT16");
+    if constexpr (PRO != PRO_NONE) {
+        if (coh) return qt == FLM_QT_INT8 ? launch_gemv_xr<QT_INT8, PRO, EPI, true>(c, st, a, wgs) : launch_gemv_xr<QT_INT16, PRO, EPI, true>(c, st, a, wgs);
+    }
+    return qt == FLM_QT_INT8 ? launch_gemv_xr<QT_INT8, PRO, EPI, false>(c, st, a, wgs) : launch_gemv_xr<QT_INT16, PRO, EPI, false>(c, st, a, wgs);
 }
 // workgroups to spread a GEMV over: wg_per_cu per CU
 int gemv_grid(int cu_count, int wg_per_cu, int /*items*/, int /*rows_per_item*/) { return cu_count * wg_per_cu; }
@@ -264,11 +272,12 @@ bool model_complete(const flm_ctx* c) {
 // context's life and FLM_RETRY tells the caller (inside this library) to run the call again on one kernel per phase.
 constexpr int FLM_RETRY = 1;
 int xwg_check(flm_ctx* c) {
-    if (!c->fuse_attn_o && c->attn_split == 0) return FLM_OK;
+    if (!c->fuse_attn_o && c->attn_split == 0 && !c->p2p) return FLM_OK;
     int e = 0;
     HIPC(c, hipMemcpy(&e, c->xwg_err, 4, hipMemcpyDeviceToHost));
     if (!e) return FLM_OK;
     HIPC(c, hipMemset(c->xwg_err, 0, 4));
+    if (e == 2) return fail(c, FLM_ERR_COMM, "tensor parallel: a peer rank did not deliver its slice (20 s), or another rank gave up");
     c->fuse_attn_o = 0; c->attn_split = 0;
     for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
     c->graphs.clear();
@@ -289,6 +298,13 @@ struct Tick {
 //   with_cls  : run the final norm + classifier (+ argmax)
 //   advance   : 1 = greedy (tok <- argmax, pos++), 0 = leave state (caller copies logits), 2 = prompt feed
 // ---------------------------------------------------------------------------------------------
+// peer-to-peer tensor parallelism: where `p` (a pointer into this rank's exchange buffer) lies in every peer's buffer
+template <class A> void set_peers(flm_ctx* c, A& a, float* p) {
+    a.n_peer = 0;
+    if (!c->p2p) return;
+    const size_t off = (char*)p - c->xbuf;
+    for (int r = 0; r < c->world; ++r) if (r != c->rank) a.out_peer[a.n_peer++] = (float*)(c->peer[r] + off);
+}
 // argument blocks of the five GEMVs and the attention of layer l (shared by the per-phase launches and k_token)
 GemvArgs args_qkv(flm_ctx* c, int l) {
     const auto& d = c->d; LayerW& w = c->layers[l];
@@ -318,6 +334,7 @@ AttnArgs args_attn(flm_ctx* c, int l, int G = 1) {
     a.q = c->qbuf; a.kcache = c->kcache + (size_t)l * kv_layer; a.vcache = c->vcache + (size_t)l * kv_layer;
     a.out = c->att_out + (size_t)c->plan.head_begin * c->hs; a.pos_ptr = &c->state->pos; a.hs = c->hs; a.max_seq = d.max_seq_len;
     a.G = G; a.sc_global = c->att_sc; a.flag_sc = c->flag_lines + 256 * 16; a.epoch = (unsigned)(l + 1); a.err = c->xwg_err;
+    set_peers(c, a, a.out);
     return a;
 }
 GemvArgs args_o(flm_ctx* c, int l) {
@@ -325,6 +342,7 @@ GemvArgs args_o(flm_ctx* c, int l) {
     GemvArgs a{}; a.ablate = c->ablate;
     a.W = w.o.q; a.sW = w.o.s; a.n = c->d.dim; a.items = c->drow_count;
     a.x = c->att_out; a.out = c->x1 + c->drow_begin;
+    set_peers(c, a, a.out);
     return a;
 }
 GemvArgs args_ffn13(flm_ctx* c, int l) {
@@ -332,6 +350,7 @@ GemvArgs args_ffn13(flm_ctx* c, int l) {
     GemvArgs a{}; a.ablate = c->ablate;
     a.W = w.w13.q; a.sW = w.w13.s; a.n = c->d.dim; a.items = c->hidden_local;
     a.x = c->x1; a.norm_w = w.ffn_norm; a.out = c->hd + c->plan.hidden_begin;
+    set_peers(c, a, a.out);
     return a;
 }
 GemvArgs args_ffn2(flm_ctx* c, int l) {
@@ -339,12 +358,14 @@ GemvArgs args_ffn2(flm_ctx* c, int l) {
     GemvArgs a{}; a.ablate = c->ablate;
     a.W = w.w2.q; a.sW = w.w2.s; a.n = c->d.hidden_dim; a.items = c->drow_count;
     a.x = c->hd; a.out = c->x1 + c->drow_begin;
+    set_peers(c, a, a.out);
     return a;
 }
 GemvArgs args_cls(flm_ctx* c) {
     GemvArgs a{}; a.ablate = c->ablate;
     a.W = c->cls.q; a.sW = c->cls.s; a.n = c->d.dim; a.items = c->cls.rows;
     a.x = c->x1; a.norm_w = c->out_norm; a.out = c->logits + (c->world > 1 ? (size_t)c->rank * c->vocab_slot : 0);
+    set_peers(c, a, a.out);
     return a;
 }
 
@@ -377,73 +398,77 @@ int launch_attn_o(flm_ctx* c, hipStream_t st, int l, int G) {
     return FLM_OK;
 }
 
+// one activation exchange between the tensor-parallel ranks (the reference's threads share the vector in memory instead):
+// peer-to-peer (the producer already stored its slice everywhere: flag round only) or an RCCL all-gather
+enum XKind { XK_ATT = 0, XK_X1 = 1, XK_HD = 2, XK_LOGITS = 3 };
+int exchange(flm_ctx* c, hipStream_t st, int kind, float* full, float* mine, int count) {
+    Tick t(c, st, KC_ALLREDUCE);
+    if (c->p2p) {
+        XchgArgs x{};
+        x.local_flags = (unsigned*)(c->xbuf + c->x_flags_off);
+        for (int r = 0; r < c->world; ++r) x.peer_flags[r] = (unsigned*)(c->peer[r] + c->x_flags_off);
+        x.epoch = c->xepoch + kind; x.err = c->xwg_err; x.rank = c->rank; x.world = c->world; x.kind = kind;
+        hipLaunchKernelGGL(k_xchg, dim3(1), dim3(64), 0, st, x);
+        HIPC(c, hipGetLastError());
+        return FLM_OK;
+    }
+    if (!c->comm) return fail(c, FLM_ERR_STATE, "tensor parallel: neither flm_p2p_import was called nor an RCCL id was given");
+    NCCLC(c, ncclAllGather(mine, full, count, ncclFloat, c->comm, st));
+    return FLM_OK;
+}
+
 int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G) {
     const auto& d = c->d;
     const int qt = d.quant_type, hs = c->hs, L = d.n_layers;
-    const bool tp = c->world > 1;
+    const bool tp = c->world > 1, coh = tp && c->p2p;
     {
         Tick t(c, st, KC_EMBED);
         hipLaunchKernelGGL(k_embed, dim3((d.dim + 255) / 256), dim3(256), 0, st, c->x1, (const void*)c->emb, (const float*)c->emb_s, c->emb_qt, d.dim, (const int*)&c->state->tok, c->flag_lines);
         HIPC(c, hipGetLastError());
     }
-    {
-        const int wgs = gemv_grid(c->cu_count, c->wg_per_cu, 0, 0);
-        auto traced = [&](GemvArgs a, int kc, int l) { if (kAblate && c->trace_class == kc && l == 0) a.trace = c->trace; return a; };
-        for (int l = 0; l < L; ++l) {
-            {   // QKV task + RoPE + KV append (transformer.cpp:132-135, execute_qkv :386-395, execute_attn :431-439)
-                Tick t(c, st, KC_QKV);
-                int r = launch_gemv<PRO_RMSNORM_QUANT, EPI_ROPE_KV>(c, st, qt, traced(args_qkv(c, l), KC_QKV, l), wgs); if (r) return r;
-            }
-            bool fused = false;
-            if (!tp && c->fuse_attn_o && !c->timing && (c->trace_class < 0 || c->trace_class == 101)) {   // attention + ATTN_O in one launch
-                const int r = qt == FLM_QT_INT8 ? launch_attn_o<QT_INT8>(c, st, l, G) : launch_attn_o<QT_INT16>(c, st, l, G);
-                if (r == FLM_OK) fused = true; else if (r != FLM_ERR_UNSUPPORTED) return r;
-            }
-            if (!fused) {   // ATTN task (execute_attn :441-449): local heads write their slice of the full att_out vector
-                Tick t(c, st, KC_ATTN);
-                AttnArgs aa = args_attn(c, l, G); if (kAblate && c->trace_class == KC_ATTN && l == 0) aa.trace = c->trace;
-                hipLaunchKernelGGL(k_attn_decode, dim3(c->heads_local * G), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, hs, G > 1), st, aa);
-                HIPC(c, hipGetLastError());
-            }
-            if (tp) {   // every rank needs all heads' outputs: the reference's threads share x2 in memory (transformer.cpp:451-454)
-                Tick t(c, st, KC_ALLREDUCE);
-                NCCLC(c, ncclAllGather(c->att_out + (size_t)c->plan.head_begin * hs, c->att_out, c->dim_local, ncclFloat, c->comm, st));
-            }
-            if (!fused) {   // ATTN_O task + residual (transformer.cpp:138-139, execute_attn_o :457-466): this rank's rows of Wo
-                Tick t(c, st, KC_ATTN_O);
-                int r = launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, traced(args_o(c, l), KC_ATTN_O, l), wgs); if (r) return r;
-            }
-            if (tp) {
-                Tick t(c, st, KC_ALLREDUCE);
-                NCCLC(c, ncclAllGather(c->x1 + c->drow_begin, c->x1, c->drow_count, ncclFloat, c->comm, st));
-            }
-            {   // FFN13 task + SwiGLU (transformer.cpp:144-147, execute_ffn13 :468-483): this rank's rows of W1/W3
-                Tick t(c, st, KC_FFN13);
-                int r = launch_gemv<PRO_RMSNORM_QUANT, EPI_SWIGLU>(c, st, qt, traced(args_ffn13(c, l), KC_FFN13, l), wgs); if (r) return r;
-            }
-            if (tp) {
-                Tick t(c, st, KC_ALLREDUCE);
-                NCCLC(c, ncclAllGather(c->hd + c->plan.hidden_begin, c->hd, c->hidden_local, ncclFloat, c->comm, st));
-            }
-            {   // FFN2 task + residual (transformer.cpp:149-150, execute_ffn2 :485-494): this rank's rows of W2
-                Tick t(c, st, KC_FFN2);
-                int r = launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, traced(args_ffn2(c, l), KC_FFN2, l), wgs); if (r) return r;
-            }
-            if (tp) {
-                Tick t(c, st, KC_ALLREDUCE);
-                NCCLC(c, ncclAllGather(c->x1 + c->drow_begin, c->x1, c->drow_count, ncclFloat, c->comm, st));
-            }
+    const int wgs = gemv_grid(c->cu_count, c->wg_per_cu, 0, 0);
+    auto traced = [&](GemvArgs a, int kc, int l) { if (kAblate && c->trace_class == kc && l == 0) a.trace = c->trace; return a; };
+    int r;
+    for (int l = 0; l < L; ++l) {
+        {   // QKV task + RoPE + KV append (transformer.cpp:132-135, execute_qkv :386-395, execute_attn :431-439): this rank's heads
+            Tick t(c, st, KC_QKV);
+            r = launch_gemv<PRO_RMSNORM_QUANT, EPI_ROPE_KV>(c, st, qt, traced(args_qkv(c, l), KC_QKV, l), wgs, coh); if (r) return r;
         }
-        if (with_cls) {   // final norm + CLS task (transformer.cpp:154-160, execute_cls :496-505)
-            Tick t(c, st, KC_CLS);
-            int r = launch_gemv<PRO_RMSNORM_QUANT, EPI_STORE>(c, st, qt, traced(args_cls(c), KC_CLS, 0), wgs); if (r) return r;
+        bool fused = false;
+        if (!tp && c->fuse_attn_o && !c->timing && (c->trace_class < 0 || c->trace_class == 101)) {   // attention + ATTN_O in one launch
+            r = qt == FLM_QT_INT8 ? launch_attn_o<QT_INT8>(c, st, l, G) : launch_attn_o<QT_INT16>(c, st, l, G);
+            if (r == FLM_OK) fused = true; else if (r != FLM_ERR_UNSUPPORTED) return r;
         }
+        if (!fused) {   // ATTN task (execute_attn :441-449): local heads write their slice of the full att_out vector (on every rank, peer to peer)
+            Tick t(c, st, KC_ATTN);
+            AttnArgs aa = args_attn(c, l, G); if (kAblate && c->trace_class == KC_ATTN && l == 0) aa.trace = c->trace;
+            hipLaunchKernelGGL(k_attn_decode, dim3(c->heads_local * G), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, hs, G > 1), st, aa);
+            HIPC(c, hipGetLastError());
+        }
+        // every rank needs all heads' outputs: the reference's threads share x2 in memory (transformer.cpp:451-454)
+        if (tp) { r = exchange(c, st, XK_ATT, c->att_out, c->att_out + (size_t)c->plan.head_begin * hs, c->dim_local); if (r) return r; }
+        if (!fused) {   // ATTN_O task + residual (transformer.cpp:138-139, execute_attn_o :457-466): this rank's rows of Wo
+            Tick t(c, st, KC_ATTN_O);
+            r = launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, traced(args_o(c, l), KC_ATTN_O, l), wgs, coh); if (r) return r;
+        }
+        if (tp) { r = exchange(c, st, XK_X1, c->x1, c->x1 + c->drow_begin, c->drow_count); if (r) return r; }
+        {   // FFN13 task + SwiGLU (transformer.cpp:144-147, execute_ffn13 :468-483): this rank's rows of W1/W3
+            Tick t(c, st, KC_FFN13);
+            r = launch_gemv<PRO_RMSNORM_QUANT, EPI_SWIGLU>(c, st, qt, traced(args_ffn13(c, l), KC_FFN13, l), wgs, coh); if (r) return r;
+        }
+        if (tp) { r = exchange(c, st, XK_HD, c->hd, c->hd + c->plan.hidden_begin, c->hidden_local); if (r) return r; }
+        {   // FFN2 task + residual (transformer.cpp:149-150, execute_ffn2 :485-494): this rank's rows of W2
+            Tick t(c, st, KC_FFN2);
+            r = launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, traced(args_ffn2(c, l), KC_FFN2, l), wgs, coh); if (r) return r;
+        }
+        if (tp) { r = exchange(c, st, XK_X1, c->x1, c->x1 + c->drow_begin, c->drow_count); if (r) return r; }
     }
     if (with_cls) {
-        if (tp) {
-            Tick t(c, st, KC_ALLREDUCE);
-            NCCLC(c, ncclAllGather(c->logits + (size_t)c->rank * c->vocab_slot, c->logits, c->vocab_slot, ncclFloat, c->comm, st));
+        {   // final norm + CLS task (transformer.cpp:154-160, execute_cls :496-505): this rank's rows of the classifier
+            Tick t(c, st, KC_CLS);
+            r = launch_gemv<PRO_RMSNORM_QUANT, EPI_STORE>(c, st, qt, traced(args_cls(c), KC_CLS, 0), wgs, coh); if (r) return r;
         }
+        if (tp) { r = exchange(c, st, XK_LOGITS, c->logits, c->logits + (size_t)c->rank * c->vocab_slot, c->vocab_slot); if (r) return r; }
         if (advance != 0) {
             Tick t(c, st, KC_ARGMAX);
             hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, st, (const float*)c->logits, d.vocab_size, c->state, c->out_tokens_dev, 1);
@@ -460,7 +485,7 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
 // it picks how many workgroups a head is spread over; the graphs are keyed by it)
 int run_token(flm_ctx* c, bool with_cls, int advance, int T) {
     const int G = attn_parts(c, T);
-    if (!c->use_graph || c->timing || c->world > 1) return enqueue_token(c, c->stream, with_cls, advance, G);
+    if (!c->use_graph || c->timing || (c->world > 1 && !c->p2p)) return enqueue_token(c, c->stream, with_cls, advance, G);   // (RCCL collectives stay eager)
     const int key = (with_cls ? 4 : 0) + advance + 8 * G;
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
@@ -681,7 +706,6 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
     const int hs = d.dim / d.n_heads;
     if (hs % 8 || hs < 32 || hs > 256) return fail(nullptr, FLM_ERR_UNSUPPORTED, "head_size must be a multiple of 8 in [32, 256] (the reference's 8-lane dot_product path, x86_simd.cpp:1677-1699; 256: the attention tile staging)");
     if (world < 1 || rank < 0 || rank >= world) return fail(nullptr, FLM_ERR_INVALID, "rank/world");
-    if (world > 1 && !comm_id) return fail(nullptr, FLM_ERR_INVALID, "comm_id required when world > 1");
 
     flm_ctx* c = new flm_ctx();
     c->d = d; c->device = device_id; c->rank = rank; c->world = world; c->hs = hs; c->esz = esz_of(d.quant_type);
@@ -697,7 +721,7 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
     c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 
     HIPB(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    if (world > 1) {
+    if (world > 1 && comm_id) {   // (without an id the ranks exchange peer to peer only: flm_p2p_export / flm_p2p_import)
         ncclUniqueId id; memcpy(&id, comm_id, 128);
         ncclResult_t nr = ncclCommInitRank(&c->comm, world, id, rank);
         if (nr != ncclSuccess) { c->err = std::string("ncclCommInitRank failed: ") + ncclGetErrorString(nr); return bail(FLM_ERR_COMM); }
@@ -717,11 +741,20 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
     const size_t kvn = (size_t)L * c->heads_local * d.max_seq_len * hs;
     HIPB(hipMalloc((void**)&c->kcache, kvn * 4)); HIPB(hipMalloc((void**)&c->vcache, kvn * 4));
     HIPB(hipMemsetAsync(c->kcache, 0, kvn * 4, c->stream)); HIPB(hipMemsetAsync(c->vcache, 0, kvn * 4, c->stream));
-    HIPB(hipMalloc((void**)&c->x1, d.dim * 4)); HIPB(hipMalloc((void**)&c->qbuf, c->dim_local * 4));
-    HIPB(hipMalloc((void**)&c->att_out, d.dim * 4));                    // full vectors on every rank (all-gathered under TP)
-    HIPB(hipMalloc((void**)&c->hd, d.hidden_dim * 4));
-    HIPB(hipMalloc((void**)&c->logits, (size_t)c->vocab_slot * world * 4));
-    HIPB(hipMemsetAsync(c->logits, 0, (size_t)c->vocab_slot * world * 4, c->stream));
+    HIPB(hipMalloc((void**)&c->qbuf, c->dim_local * 4));
+    {   // the exchange buffer: att_out | x1 | hd | logits | flag lines [4 kinds][8 ranks] (full vectors on every rank under TP)
+        auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        const size_t o_att = 0, o_x1 = up(o_att + (size_t)d.dim * 4), o_hd = up(o_x1 + (size_t)d.dim * 4), o_lg = up(o_hd + (size_t)d.hidden_dim * 4);
+        const size_t o_fl = up(o_lg + (size_t)c->vocab_slot * world * 4), total = o_fl + (4 * 8 + 1) * 64;      // + the abort line
+        hipError_t ae = hipErrorUnknown;
+        if (world > 1) { ae = hipExtMallocWithFlags((void**)&c->xbuf, total, hipDeviceMallocFinegrained); c->xbuf_fine = ae == hipSuccess; }   // written by peer GPUs
+        if (ae != hipSuccess) { (void)hipGetLastError(); HIPB(hipMalloc((void**)&c->xbuf, total)); }
+        c->xbuf_bytes = total; c->x_flags_off = o_fl;
+        HIPB(hipMemsetAsync(c->xbuf, 0, total, c->stream));
+        c->att_out = (float*)(c->xbuf + o_att); c->x1 = (float*)(c->xbuf + o_x1); c->hd = (float*)(c->xbuf + o_hd); c->logits = (float*)(c->xbuf + o_lg);
+        c->peer[rank] = c->xbuf;
+        HIPB(hipMalloc((void**)&c->xepoch, 64)); HIPB(hipMemsetAsync(c->xepoch, 0, 64, c->stream));
+    }
     HIPB(hipMalloc((void**)&c->flag_lines, 512 * 64)); HIPB(hipMalloc((void**)&c->xwg_err, 64));
     HIPB(hipMemsetAsync(c->flag_lines, 0, 512 * 64, c->stream)); HIPB(hipMemsetAsync(c->xwg_err, 0, 64, c->stream));
     HIPB(hipMalloc(&c->att_q, (size_t)d.dim * c->esz)); HIPB(hipMalloc((void**)&c->att_qs, (size_t)(d.dim / kGroup) * 4));
@@ -747,14 +780,61 @@ void flm_ctx_destroy(flm_ctx* c) {
     auto fq = [](QMat& m) { if (m.q) hipFree(m.q); if (m.s) hipFree(m.s); };
     for (auto& l : c->layers) { fq(l.qkv); fq(l.o); fq(l.w13); fq(l.w2); if (l.att_norm) hipFree(l.att_norm); if (l.ffn_norm) hipFree(l.ffn_norm); }
     fq(c->cls);
-    void* ptrs[] = {c->emb, c->emb_s, c->out_norm, c->kcache, c->vcache, c->x1, c->qbuf, c->att_out, c->hd,
-                    c->logits, c->rope_cos, c->rope_sin, c->state, c->prompt_dev, c->out_tokens_dev,
+    for (int r = 0; r < c->world; ++r) if (c->peer_opened[r] && c->peer[r]) hipIpcCloseMemHandle(c->peer[r]);
+    void* ptrs[] = {c->emb, c->emb_s, c->out_norm, c->kcache, c->vcache, c->xbuf, c->xepoch, c->qbuf,
+                    c->rope_cos, c->rope_sin, c->state, c->prompt_dev, c->out_tokens_dev,
                     c->flag_lines, c->xwg_err, c->att_q, c->att_qs, c->att_sc, c->trace,
                     c->pf_x, c->pf_qkv, c->pf_q, c->pf_att, c->pf_gu, c->pf_hd, c->pf_xs, c->pf_xq};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->comm) ncclCommDestroy(c->comm);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
+}
+
+// ---- tensor parallel, peer-to-peer bootstrap ---------------------------------------------------
+// Each rank exports a 128-byte blob (IPC handle of its exchange buffer, its process and device); the caller gathers the blobs
+// of all ranks in rank order by whatever transport it has (bench.py: torch.distributed.all_gather; a C++ host: MPI, a file, a
+// socket) and hands them to flm_p2p_import, which maps every peer's buffer (hipIpcOpenMemHandle; ranks living in the SAME
+// process share the pointer directly).  From then on activation slices travel by direct stores over xGMI plus one flag
+// round (k_xchg) instead of an RCCL all-gather, and the token is replayed from a hipGraph like the single-GPU one.
+namespace {
+struct P2pBlob { unsigned long long magic; int pid, device, rank, world; unsigned long long bytes; void* raw; hipIpcMemHandle_t h; char pad[128 - 8 - 16 - 8 - 8 - sizeof(hipIpcMemHandle_t)]; };
+static_assert(sizeof(P2pBlob) == FLM_P2P_BLOB_BYTES, "blob size");
+constexpr unsigned long long kP2pMagic = 0x464C4D5032503031ull;   // "FLMP2P01"
+}
+#include <unistd.h>
+int flm_p2p_export(flm_ctx* c, void* blob128) {
+    if (!c || !blob128) return FLM_ERR_INVALID;
+    HIPC(c, hipSetDevice(c->device));
+    P2pBlob b{}; b.magic = kP2pMagic; b.pid = (int)getpid(); b.device = c->device; b.rank = c->rank; b.world = c->world; b.bytes = c->xbuf_bytes; b.raw = c->xbuf;
+    HIPC(c, hipIpcGetMemHandle(&b.h, c->xbuf));
+    memcpy(blob128, &b, sizeof b);
+    return FLM_OK;
+}
+int flm_p2p_import(flm_ctx* c, const void* blobs, int n) {
+    if (!c || !blobs || n != c->world) return FLM_ERR_INVALID;
+    HIPC(c, hipSetDevice(c->device));
+    const P2pBlob* b = (const P2pBlob*)blobs;
+    for (int r = 0; r < n; ++r) {
+        if (b[r].magic != kP2pMagic || b[r].rank != r || b[r].world != c->world || b[r].bytes != c->xbuf_bytes) return fail(c, FLM_ERR_INVALID, "p2p_import: blobs are not those of this tensor-parallel group, in rank order");
+        if (r == c->rank) continue;
+        if (c->peer[r]) continue;                                         // already mapped
+        if (b[r].pid == (int)getpid()) { c->peer[r] = (char*)b[r].raw; continue; }   // same process: the pointer is valid here
+        if (b[r].device != c->device) {
+            int can = 0; HIPC(c, hipDeviceCanAccessPeer(&can, c->device, b[r].device));
+            if (!can) return fail(c, FLM_ERR_UNSUPPORTED, "p2p_import: no peer access between the two devices");
+            hipError_t e = hipDeviceEnablePeerAccess(b[r].device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIPC(c, e);
+            (void)hipGetLastError();
+        }
+        void* p = nullptr;
+        HIPC(c, hipIpcOpenMemHandle(&p, b[r].h, hipIpcMemLazyEnablePeerAccess));
+        c->peer[r] = (char*)p; c->peer_opened[r] = true;
+    }
+    c->p2p = 1;
+    for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
+    c->graphs.clear();
+    return FLM_OK;
 }
 
 int flm_set_option(flm_ctx* c, const char* key, int value) {

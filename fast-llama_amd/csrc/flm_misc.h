@@ -70,6 +70,36 @@ __global__ void k_advance_prompt(DecodeState* st, const int* prompt) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { st->step += 1; st->pos += 1; st->tok = prompt[st->step]; }
 }
 __global__ void k_set_step(DecodeState* st, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) st->step = v; }
+// ------------------------------------------------------------------------------------------
+// Tensor parallel, one-shot peer-to-peer exchange (instead of an RCCL all-gather per activation vector: ~3 us against ~12).
+// The producing kernel has stored its slice of the vector into EVERY rank's buffer (GemvArgs::out_peer).  This one-workgroup
+// kernel runs right behind it in the stream: the kernel boundary has completed those stores, so thread r tells rank r
+// "my slice of exchange number e is in your memory" by writing e into its line of rank r's flag array (system scope), and
+// then waits until all ranks' lines in the LOCAL flag array have reached e.  e counts this kind's exchanges in device memory, so
+// a captured graph replays correctly.  flags: [kind][rank] lines of 64 bytes.
+// ------------------------------------------------------------------------------------------
+struct XchgArgs { unsigned* local_flags; unsigned* peer_flags[8]; unsigned* epoch; int* err; int rank, world, kind; };
+constexpr int kXchgAbortLine = 4 * 8;      // flag line behind the [4 kinds][8 ranks] lines: non-zero = some rank gave up, nobody waits any more
+__global__ void __launch_bounds__(64) k_xchg(const XchgArgs x) {
+    const int r = threadIdx.x;
+    const unsigned e = *x.epoch + 1;
+    if (r < x.world) __hip_atomic_store(x.peer_flags[r] + (x.kind * 8 + x.rank) * 16, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (true) {
+        const unsigned f = r < x.world ? __hip_atomic_load(x.local_flags + (x.kind * 8 + r) * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : e;
+        if (__all((int)(f - e) >= 0)) break;
+        // ranks start seconds apart (graph capture, module loading): be patient; but once ANY rank has given up, everybody leaves at once
+        const bool aborted = __hip_atomic_load(x.local_flags + kXchgAbortLine * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+        if (aborted || __builtin_amdgcn_s_memrealtime() - t0 > 2000000000ull) {                                   // 20 s of the 100 MHz clock
+            __hip_atomic_store(x.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (r < x.world) __hip_atomic_store(x.peer_flags[r] + kXchgAbortLine * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (r == 0) *x.epoch = e;
+}
+
 // ---- op-level test kernels: thin launchers over the same __device__ functions ----
 // square_sum both ways: out[0] the speculative wave evaluation (sq_chain_spec), out[1] the plain sequential chains (sq_chain);
 // out[2..5] the 4 strided lanes from sq_chain_spec, out[6..9] its round counts (-1: it fell back to the plain chain)

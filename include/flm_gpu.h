@@ -73,12 +73,19 @@ typedef struct flm_model_desc {
 
 /* ---- lifecycle: replaces ParallelTransformer::load (transformer.cpp:23-42) + parallel_*_init
  *      (transformer.cpp:209-384).  device_id = HIP ordinal.  rank/world/comm_id: tensor-parallel
- *      group (world == 1: comm_id may be NULL).  comm_id = 128 bytes from flm_comm_unique_id()
- *      on rank 0, distributed by the caller (bench.py uses torch.distributed for that). */
+ *      group.  comm_id = 128 bytes from flm_comm_unique_id() on rank 0, distributed by the caller (RCCL all-gathers, the
+ *      fallback exchange), or NULL: then the ranks must be connected peer to peer (flm_p2p_export / flm_p2p_import). */
 int  flm_comm_unique_id(void* out128);
 int  flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int world,
                     const void* comm_id, flm_ctx** out);
 void flm_ctx_destroy(flm_ctx* ctx);
+/* Tensor parallel, peer to peer (world > 1): every rank exports a blob describing its exchange buffer, the caller gathers all
+ * ranks' blobs in rank order (any transport) and imports them on every rank; activation slices then travel as direct stores
+ * over xGMI plus a flag round instead of RCCL all-gathers, and comm_id may be NULL at create.  The reference's threads share
+ * these vectors in memory (transformer.cpp:394,465,482,493,504); this is the same picture across GPUs. */
+#define FLM_P2P_BLOB_BYTES 128
+int  flm_p2p_export(flm_ctx* ctx, void* blob128);
+int  flm_p2p_import(flm_ctx* ctx, const void* blobs /* [world][128] */, int world);
 const char* flm_last_error(const flm_ctx* ctx);   /* ctx may be NULL: last create error */
 
 /* Hand one tensor (one layer of it) to the device: what load_tensor (flm_loader.cpp:493-559) +

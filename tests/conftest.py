@@ -6,6 +6,10 @@ import pytest
 # before anything can load an OpenMP runtime (numpy does not, torch and the oracle do): see oracle_py._tame_openmp
 os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(8, os.cpu_count() or 1))))
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+# tests/test_gpu_tp.py runs up to 8 tensor-parallel ranks as 8 streams of ONE process on ONE GPU; their flag waits need one hardware
+# queue per stream (HIP's default is 4 per process: two streams sharing a queue would put a waiting kernel in front of the kernel
+# it waits for).  Read once, when the HIP runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,0 +1,103 @@
+"""Tensor parallelism with the one-shot peer-to-peer exchange, on ONE GPU: `world` ranks = `world` contexts on device 0, one host
+thread each (the C ABI releases the GIL), their exchange buffers shared by pointer (same process; separate processes use the IPC
+handles of the same blobs).  Every rank streams its row shard of every matmul, stores its slice of each activation vector into
+all ranks' buffers and meets the others in k_xchg -- the data flow of BASELINE.json's config 4 -- and every rank's logits must be
+the single-GPU / reference bits.  (Real multi-GPU runs are the driver's; tests/test_tp_gloo.py covers the same flow on the CPU.)"""
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_py as O
+from fast_llama_amd import flmfile as ff, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def bits_equal(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+def _prompt(V, n):
+    return np.array([1] + [int(x) for x in (np.arange(1, n) * 7919) % V], dtype=np.int32)
+
+
+def _run_ranks(ctxs, fn):
+    out, err = [None] * len(ctxs), [None] * len(ctxs)
+
+    def work(r):
+        try:
+            out[r] = fn(ctxs[r])
+        except Exception as e:  # noqa: BLE001
+            err[r] = e
+    th = [threading.Thread(target=work, args=(r,)) for r in range(len(ctxs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    assert not any(t.is_alive() for t in th), "a rank hung"
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+@pytest.mark.parametrize("shape,qt,layers,world", [("small", ff.QT_INT8, None, 2), ("small", ff.QT_INT16, None, 2), ("small", ff.QT_INT8, None, 4), ("small", ff.QT_INT16, None, 4), ("7B", ff.QT_INT8, 1, 2), ("7B", ff.QT_INT8, 1, 8)])
+def test_tensor_parallel_p2p_is_bit_identical(gpu, shape, qt, layers, world):
+    cfg = synth.make_config(shape, qt)
+    if layers:
+        cfg.n_layers = layers
+    tensors = synth.make_tensors(cfg, seed=41)
+    om = O.OracleModel(cfg, tensors)
+    prompt = _prompt(cfg.vocab_size, 7)
+    want = [om.forward(prompt, 0)]
+    cur, pos = int(np.argmax(want[0])), len(prompt)
+    for _ in range(5):
+        want.append(om.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(want[-1])); pos += 1
+    ids_want = [int(np.argmax(w)) for w in want]
+    desc = gpu.desc_from_config(cfg)
+    ctxs = [gpu.Ctx(desc, device=0, rank=r, world=world, comm_id=None) for r in range(world)]
+    for c in ctxs:
+        c.upload_all(tensors)                       # the FULL tensors: each context keeps its row shard
+    blobs = [c.p2p_export() for c in ctxs]
+    for c in ctxs:
+        c.p2p_import(blobs)
+
+    def rank_main(c):
+        got = [c.forward(prompt, 0)]
+        cur, pos = int(np.argmax(got[0])), len(prompt)
+        for _ in range(5):
+            got.append(c.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(got[-1])); pos += 1
+        c.reset_kv()
+        first = c.forward_argmax(prompt, 0)
+        ids = [first] + [int(x) for x in c.decode_greedy(first, len(prompt), 5)]      # hipGraph replay of the sharded token
+        return got, ids
+
+    for r, (got, ids) in enumerate(_run_ranks(ctxs, rank_main)):
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert bits_equal(a, b), f"rank {r}, forward {i}"
+        assert ids == ids_want, f"rank {r}"
+    for c in ctxs:
+        c.close()
+
+
+def test_tensor_parallel_long_context_split_heads(gpu):
+    """under TP the attention runs as its own launch: long contexts spread the LOCAL heads over hs/32 workgroups each"""
+    cfg = synth.make_config("small", ff.QT_INT8)
+    tensors = synth.make_tensors(cfg, seed=43)
+    om = O.OracleModel(cfg, tensors)
+    prompt = _prompt(cfg.vocab_size, 300)
+    want = om.forward(prompt, 0)
+    t = np.array([int(np.argmax(want))], np.int32)
+    want2 = om.forward(t, 300)
+    world = 2
+    ctxs = [gpu.Ctx(gpu.desc_from_config(cfg), device=0, rank=r, world=world, comm_id=None) for r in range(world)]
+    for c in ctxs:
+        c.upload_all(tensors)
+    blobs = [c.p2p_export() for c in ctxs]
+    for c in ctxs:
+        c.p2p_import(blobs)
+    for got, got2 in _run_ranks(ctxs, lambda c: (c.forward(prompt, 0), c.forward(t, 300))):
+        assert bits_equal(got, want) and bits_equal(got2, want2)
+    for c in ctxs:
+        c.close()
