@@ -412,8 +412,9 @@ constexpr int kMqQueries = 8;
 __host__ inline size_t attn_mq_lds_bytes(int max_seq, int hs) {
     return (size_t)(kMqQueries * hs + kMqQueries * (((max_seq + 3) & ~3) + 8) + 2 * kAttnTile * attn_row_stride(hs)) * 4;
 }
-template <int NF>
-__device__ __forceinline__ void attn_prefill_mq(const AttnArgs& a, const int h, char* lds, const int pos0, const int i0, const int nq, const int row_stride) {
+// PRE: the scores come from k_qk_mfma (a.sc_global: [heads][B][max_seq], already scaled): the scores pass is a copy
+template <int NF, bool PRE = false>
+__device__ __forceinline__ void attn_prefill_mq(const AttnArgs& a, const int h, char* lds, const int pos0, const int i0, const int nq, const int row_stride, const int B = 0) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     constexpr int NQ = kMqQueries, rs = NF * 64 + 8;
     const int hs = a.hs, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -453,6 +454,15 @@ __device__ __forceinline__ void attn_prefill_mq(const AttnArgs& a, const int h, 
             if (prow[j] < kAttnTile) *reinterpret_cast<float4*>(buf + loff[j]) = make_float4(reg[j].x, reg[j].y, reg[j].z, reg[j].w);
     };
     v4f ring[NF];
+    if constexpr (PRE) {
+        // wave pair (2j, 2j+1) copies query j's row of scores
+        const int j = wave >> 1;
+        if (j < nq) {
+            const int T = pos0 + i0 + j + 1;
+            const float* src = a.sc_global + ((size_t)h * B + (i0 + j)) * a.max_seq;
+            for (int t = (tid & 127); t < T; t += 128) sc[j * scs + t] = src[t];
+        }
+    } else {
     request(rK, 0, ring);
     for (int e = tid; e < NQ * hs; e += kAttnBlock) {
         const int j = e / hs, d = e - j * hs;
@@ -490,6 +500,7 @@ __device__ __forceinline__ void attn_prefill_mq(const AttnArgs& a, const int h, 
             };
             fold(l0, jh + 0); fold(l1, jh + 1); fold(l2, jh + 2); fold(l3, jh + 3);
         }
+    }
     }
     request(rV, 0, ring);                                                       // the first V tile travels under the softmax
     __syncthreads();
@@ -560,10 +571,102 @@ __device__ __forceinline__ void attn_prefill_mq(const AttnArgs& a, const int h, 
     }
     if (mine) a.out[(size_t)(i0 + j) * row_stride + (size_t)h * hs + d] = o;
 }
+template <bool PRE>
 __global__ void __launch_bounds__(kAttnBlock) k_attn_prefill_mq(const AttnArgs a, int pos0, int row_stride, int B) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int i0 = blockIdx.y * kMqQueries, nq = B - i0 < kMqQueries ? B - i0 : kMqQueries;
-    if (a.hs <= 64) attn_prefill_mq<1>(a, blockIdx.x, lds, pos0, i0, nq, row_stride); else attn_prefill_mq<2>(a, blockIdx.x, lds, pos0, i0, nq, row_stride);
+    if (a.hs <= 64) attn_prefill_mq<1, PRE>(a, blockIdx.x, lds, pos0, i0, nq, row_stride, B); else attn_prefill_mq<2, PRE>(a, blockIdx.x, lds, pos0, i0, nq, row_stride, B);
+}
+
+// ------------------------------------------------------------------------------------------
+// Prefill QK^T on the matrix cores, fp32 in / fp32 accumulate (v_mfma_f32_16x16x4_f32), BIT-IDENTICAL to the reference's score:
+//     att[q][t] = ( sum over the 8 strided lanes k of dot_product_avx256, added 0..7 ) * 1/sqrt(hs)      (x86_simd.cpp:1447-1467,
+//                                                                                  quant_operators.cpp:340-348, 425-428)
+// where lane k's partial is the sequential chain  l_k = fma(K[t][k + 8 s], q[k + 8 s], l_k),  s = 0, 1, ...  On gfx950 an f32 MFMA
+// is bit for bit a k-ordered fmaf chain into its accumulator (D = fma(a3, b3, fma(a2, b2, fma(a1, b1, fma(a0, b0, C))))), so lane k's
+// chain is ONE accumulator fed with the head dimension permuted: the MFMA of step s' takes elements k + 8 (4 s' + c), c = 0..3, in
+// its four k-slots.  Eight accumulators (one per strided lane) x hs / 32 MFMAs each = the whole contraction with no wasted flop;
+// then the eight are added in order 0..7 and scaled on the VALU, exactly as the scalar code does.
+// Workgroup (256 threads) = one head x 16 queries; its 4 waves take 16 positions each of a 64-position tile; Q^T and K^T tiles lie in
+// LDS element-major (rows of 16 / 64 floats padded to 18 / 66: operand reads and the per-k-slot stride of 8 rows are conflict-free).
+// Output: sc_global[h][query][t] for t <= pos0 + query (causal), consumed by k_attn_prefill_mq<true>.
+// ------------------------------------------------------------------------------------------
+constexpr int kQkQ = 16, kQkT = 64, kQkQS = 18, kQkKS = 66;
+__host__ inline size_t qk_mfma_lds_bytes(int hs) { return (size_t)hs * (kQkQS + 2 * kQkKS) * 4; }
+__global__ void __launch_bounds__(256) k_qk_mfma(const AttnArgs a, int pos0, int row_stride, int B) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int hs = a.hs, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, q0 = blockIdx.y * kQkQ;
+    float* Qt = reinterpret_cast<float*>(lds);                   // [hs][kQkQS]
+    float* Kt0 = Qt + hs * kQkQS;                                // [hs][kQkKS] x 2
+    float* Kt1 = Kt0 + hs * kQkKS;
+    const int Tmax = pos0 + (q0 + kQkQ < B ? q0 + kQkQ : B);     // positions the last query of the tile sees
+    const int nt = (Tmax + kQkT - 1) / kQkT;
+    const float* K = a.kcache + (size_t)h * a.max_seq * hs;
+    const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(K), 0, a.max_seq * hs * 4, 0x00020000);
+    const float scale = (float)(1.0 / (double)__builtin_sqrtf((float)hs));
+    // Q tile, transposed: thread -> (query, 16-byte piece)
+    const int f4r = hs >> 2;
+    for (int f = tid; f < kQkQ * f4r; f += 256) {
+        const int q = f / f4r, c4 = f - q * f4r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q0 + q < B) v = *reinterpret_cast<const float4*>(a.q + (size_t)(q0 + q) * row_stride + (size_t)h * hs + c4 * 4);
+        Qt[(c4 * 4 + 0) * kQkQS + q] = v.x; Qt[(c4 * 4 + 1) * kQkQS + q] = v.y; Qt[(c4 * 4 + 2) * kQkQS + q] = v.z; Qt[(c4 * 4 + 3) * kQkQS + q] = v.w;
+    }
+    // K tiles: 64 positions x hs floats = 16 hs pieces of 16 bytes; NP per thread
+    constexpr int NPMAX = 8;                                      // hs <= 128: 64 * 32 / 256
+    const int np = kQkT * f4r / 256;
+    v4f ring[NPMAX];
+    auto request = [&](int tile) {
+#pragma unroll
+        for (int j = 0; j < NPMAX; ++j) {
+            const int f = tid + j * 256, row = f / f4r, c4 = f - row * f4r, t = tile * kQkT + row;
+            const unsigned off = (j < np && tile < nt && t < Tmax) ? (unsigned)((t * hs + c4 * 4) * 4) : 0x80000000u;
+            ring[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rK, (int)off, 0, 0));
+        }
+    };
+    auto park = [&](float* Kt) {
+#pragma unroll
+        for (int j = 0; j < NPMAX; ++j) {
+            if (j < np) {
+                const int f = tid + j * 256, row = f / f4r, c4 = f - row * f4r;
+                Kt[(c4 * 4 + 0) * kQkKS + row] = ring[j].x; Kt[(c4 * 4 + 1) * kQkKS + row] = ring[j].y;
+                Kt[(c4 * 4 + 2) * kQkKS + row] = ring[j].z; Kt[(c4 * 4 + 3) * kQkKS + row] = ring[j].w;
+            }
+        }
+    };
+    request(0);
+    const int li = lane & 15, c = lane >> 4;                      // operand lane: row / column li, k-slot c
+    const int nstep = hs >> 5;                                    // MFMAs per accumulator: (hs / 8) chain elements / 4
+    for (int s = 0; s < nt; ++s) {
+        float* Kt = (s & 1) ? Kt1 : Kt0;
+        park(Kt);
+        __syncthreads();                                          // (the first one also orders Qt)
+        request(s + 1);
+        v4f acc[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[r] = v4f{0.f, 0.f, 0.f, 0.f};
+        const float* qp = Qt + li;                                // A[i = query li][k-slot c]
+        const float* kp = Kt + wave * 16 + li;                    // B[k-slot c][j = position 16 wave + li]
+        for (int sp = 0; sp < nstep; ++sp) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int e = r + 8 * (4 * sp + c);
+                acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(qp[e * kQkQS], kp[e * kQkKS], acc[r], 0, 0, 0);
+            }
+        }
+        // D layout: column (position) = lane & 15, row (query) = 4 (lane >> 4) + reg
+        const int t = s * kQkT + wave * 16 + li;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int q = q0 + 4 * c + reg;
+            float tot = __fadd_rn(0.f, acc[0][reg]);
+#pragma unroll
+            for (int r = 1; r < 8; ++r) tot = __fadd_rn(tot, acc[r][reg]);
+            if (q < B && t < pos0 + q + 1) a.sc_global[((size_t)h * B + q) * a.max_seq + t] = __fmul_rn(tot, scale);
+        }
+    }
 }
 // grid = heads * G (G = a.G >= 1 parts per head; all of them resident: the parts wait for each other's scores)
 __global__ void __launch_bounds__(kAttnBlock) k_attn_decode(const AttnArgs a) {

@@ -70,6 +70,8 @@ struct flm_ctx {
     int pf_cap = 0;                                    // token capacity of the batched-prefill buffers below
     float *pf_x = nullptr, *pf_qkv = nullptr, *pf_q = nullptr, *pf_att = nullptr, *pf_gu = nullptr, *pf_hd = nullptr, *pf_xs = nullptr; void* pf_xq = nullptr;
     int use_prefill_mq = 1;                            // option "use_prefill_mq": batched prefill attention with 8 queries per workgroup (0: one query per workgroup)
+    int use_qk_mfma = 1;                               // option "use_qk_mfma": prefill scores on the matrix cores (fp32 MFMA, bit-identical), 0: VALU chains inside the attention kernel
+    float* pf_scores = nullptr;                        // [heads][max_seq][max_seq] prefill scores (k_qk_mfma -> k_attn_prefill_mq<true>)
     int fuse_attn_o = 1;                               // option "fuse_attn_o": attention + Wo GEMV in one launch (k_attn_o; single GPU)
     unsigned* flag_lines = nullptr; int* xwg_err = nullptr;   // k_attn_o: one 64-byte flag line per head; "a cross-workgroup wait timed out"
     void* att_q = nullptr; float* att_qs = nullptr;    // k_attn_o: the heads' output already quantized (head_size a multiple of 64)
@@ -520,6 +522,7 @@ int alloc_run_bufs(flm_ctx* c) {
     HIPC(c, hipMalloc((void**)&c->pf_hd, cap * d.hidden_dim * 4));
     HIPC(c, hipMalloc((void**)&c->pf_xs, cap * (nmax / kGroup) * 4));
     HIPC(c, hipMalloc(&c->pf_xq, cap * nmax * c->esz));
+    if (c->hs % 32 == 0 && c->hs <= 128) HIPC(c, hipMalloc((void**)&c->pf_scores, (size_t)c->heads_local * cap * d.max_seq_len * 4));
     c->pf_cap = (int)cap;
     return FLM_OK;
 }
@@ -569,6 +572,7 @@ int launch_gemm(flm_ctx* c, hipStream_t st, const GemmArgs& g, int use_mfma) {
             hipLaunchKernelGGL((k_gemm_q8_mfma<EPI, 4>), dim3(tiles128), dim3(1024), 0, st, g);
         } else hipLaunchKernelGGL((k_gemm_q8_mfma<EPI, 2>), dim3(tiles), dim3(256), 0, st, g);
     }
+    else if (QT == QT_INT16 && use_mfma) hipLaunchKernelGGL((k_gemm_q16_mfma<EPI>), dim3(tiles), dim3(256), 0, st, g);   // hi / lo byte planes on the int8 matrix cores
     else hipLaunchKernelGGL((k_gemm_q<QT, EPI>), dim3(tiles), dim3(256), 0, st, g);
     HIPC(c, hipGetLastError());
     return FLM_OK;
@@ -597,8 +601,15 @@ int prefill_batched(flm_ctx* c, int B, int pos) {
         // attention of every query over the cache rows 0 .. its own position   (execute_attn :441-449)
         AttnArgs aa{}; aa.q = c->pf_q; aa.kcache = c->kcache + (size_t)l * kv_layer; aa.vcache = c->vcache + (size_t)l * kv_layer;
         aa.out = c->pf_att; aa.pos_ptr = &c->state->pos; aa.hs = hs; aa.max_seq = d.max_seq_len;
-        if (hs <= 128 && c->use_prefill_mq)      // kMqQueries queries per workgroup share every K/V tile
-            hipLaunchKernelGGL(k_attn_prefill_mq, dim3(c->heads_local, (B + kMqQueries - 1) / kMqQueries), dim3(kAttnBlock), attn_mq_lds_bytes(d.max_seq_len, hs), st, aa, pos, dim, B);
+        if (hs <= 128 && c->use_prefill_mq && c->use_qk_mfma && c->pf_scores) {
+            // scores on the matrix cores (fp32 MFMA = the reference's chains, bit for bit), then softmax + weighted sum per 8 queries
+            aa.sc_global = c->pf_scores;
+            hipLaunchKernelGGL(k_qk_mfma, dim3(c->heads_local, (B + kQkQ - 1) / kQkQ), dim3(256), qk_mfma_lds_bytes(hs), st, aa, pos, dim, B);
+            HIPC(c, hipGetLastError());
+            hipLaunchKernelGGL(k_attn_prefill_mq<true>, dim3(c->heads_local, (B + kMqQueries - 1) / kMqQueries), dim3(kAttnBlock), attn_mq_lds_bytes(d.max_seq_len, hs), st, aa, pos, dim, B);
+        }
+        else if (hs <= 128 && c->use_prefill_mq)      // kMqQueries queries per workgroup share every K/V tile
+            hipLaunchKernelGGL(k_attn_prefill_mq<false>, dim3(c->heads_local, (B + kMqQueries - 1) / kMqQueries), dim3(kAttnBlock), attn_mq_lds_bytes(d.max_seq_len, hs), st, aa, pos, dim, B);
         else
             hipLaunchKernelGGL(k_attn_prefill, dim3(c->heads_local, B), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, hs), st, aa, pos, dim);
         HIPC(c, hipGetLastError());
@@ -784,7 +795,7 @@ void flm_ctx_destroy(flm_ctx* c) {
     void* ptrs[] = {c->emb, c->emb_s, c->out_norm, c->kcache, c->vcache, c->xbuf, c->xepoch, c->qbuf,
                     c->rope_cos, c->rope_sin, c->state, c->prompt_dev, c->out_tokens_dev,
                     c->flag_lines, c->xwg_err, c->att_q, c->att_qs, c->att_sc, c->trace,
-                    c->pf_x, c->pf_qkv, c->pf_q, c->pf_att, c->pf_gu, c->pf_hd, c->pf_xs, c->pf_xq};
+                    c->pf_x, c->pf_qkv, c->pf_q, c->pf_att, c->pf_gu, c->pf_hd, c->pf_xs, c->pf_xq, c->pf_scores};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->comm) ncclCommDestroy(c->comm);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -847,6 +858,7 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (k == "fuse_attn_o") c->fuse_attn_o = value;
     else if (k == "use_prefill_mq") c->use_prefill_mq = value;
     else if (k == "attn_split") c->attn_split = value;
+    else if (k == "use_qk_mfma") c->use_qk_mfma = value;
     else if (kAblate && k == "ablate") c->ablate = value;              // FLM_ABLATE builds only: a product library cannot skip work
     else if (kAblate && k == "trace") {   // value = kernel class to trace (KC_*), -1 off
         c->trace_class = value;

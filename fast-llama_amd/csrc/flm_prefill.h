@@ -302,6 +302,129 @@ __global__ void __launch_bounds__(64 * NW * NW) k_gemm_q8_mfma(const GemmArgs a)
     }
 }
 
+// The int16 GEMM on the matrix cores.  gfx950 has no int16 MFMA; an int16 value is split EXACTLY into two signed bytes,
+//     w = 256 * wh + wl,   wl = (int8)(w & 0xff),   wh = (w - wl) >> 8   (|w| <= 5792: wh in [-23, 23])
+// so a quant group's dot product is  65536 * S(wh, xh) + 256 * (S(wh, xl) + S(wl, xh)) + S(wl, xl)  with four int8 MFMA
+// accumulations S (each exact in int32; the combination wraps mod 2^32 on the way and lands on the true value, which the reference
+// also holds in an int32: 64 * 5792^2 < 2^31, x86_simd.cpp:1524-1552).  Eight v_mfma_i32_32x32x32_i8 per group and wave replace 1024
+// v_dot2 per lane-quadrant of k_gemm_q; the fp32 chain step per group is unchanged (quant_operators.cpp:274).  The split happens
+// once per 16-byte piece when it is parked in LDS (byte planes lo / hi per row), 64 x 64 tile, four waves x 32 x 32.
+__device__ __forceinline__ void split16(const v4i& v, unsigned (&lo)[2], unsigned (&hi)[2]) {
+    const unsigned w0 = (unsigned)v.x, w1 = (unsigned)v.y, w2 = (unsigned)v.z, w3 = (unsigned)v.w;
+    lo[0] = __builtin_amdgcn_perm(w1, w0, 0x06040200u); lo[1] = __builtin_amdgcn_perm(w3, w2, 0x06040200u);      // bytes 0, 2 of w0 then of w1
+    const unsigned h0 = __builtin_amdgcn_perm(w1, w0, 0x07050301u), h1 = __builtin_amdgcn_perm(w3, w2, 0x07050301u);
+    // wh = high byte + (low byte negative as int8 ? 1 : 0), bytewise without carries between bytes
+    const unsigned c0 = (lo[0] >> 7) & 0x01010101u, c1 = (lo[1] >> 7) & 0x01010101u;
+    hi[0] = ((h0 & 0x7f7f7f7fu) + c0) ^ (h0 & 0x80808080u);
+    hi[1] = ((h1 & 0x7f7f7f7fu) + c1) ^ (h1 & 0x80808080u);
+}
+template <int EPI>
+__global__ void __launch_bounds__(256) k_gemm_q16_mfma(const GemmArgs a) {
+    constexpr int GB = kGroup * 2;                // bytes of a group in one row (int16)
+    constexpr int LS = kGroup + 16;               // LDS row stride of a byte plane
+    constexpr int TS = 64;
+    __shared__ __attribute__((aligned(16))) char WL[2][TS * LS], WH[2][TS * LS], XL[2][TS * LS], XH[2][TS * LS];
+    __shared__ __attribute__((aligned(16))) float sWt[2][TS];
+    __shared__ float sXt[2][TS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntt = (a.B + TS - 1) / TS;
+    const int nb = gridDim.x, per = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7;              // tiles dealt to the XCDs in contiguous runs (as k_gemm_q8_mfma)
+    const int tile = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
+    const int r0 = (tile / ntt) * TS, b0 = (tile % ntt) * TS;
+    const int wr0 = (wave / 2) * 32, wc0 = (wave % 2) * 32;
+    const int sn = a.n / kGroup;
+    const size_t rowbytes = (size_t)a.n * 2;
+    constexpr int kPF = 2;                        // groups in flight through the register ring (2 x 4 pieces of 16 bytes per thread)
+    // loader: 64 rows x 8 pieces of 16 B per matrix and group; thread -> pieces tid and tid + 256 of each
+    constexpr unsigned kOOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, (int)((unsigned)a.rows * (unsigned)rowbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.Xq), 0, (int)((unsigned)a.B * (unsigned)rowbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rSW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.sW), 0, (int)((unsigned)a.rows * sn * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rSX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Xs), 0, (int)((unsigned)a.B * sn * 4), 0x00020000);
+    int prow[2], pch[2]; unsigned woff[2], xoff[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int idx = tid + k * 256; prow[k] = idx >> 3; pch[k] = idx & 7;
+        woff[k] = (r0 + prow[k] < a.rows) ? (unsigned)(r0 + prow[k]) * (unsigned)rowbytes + pch[k] * 16 : kOOB;
+        xoff[k] = (b0 + prow[k] < a.B)    ? (unsigned)(b0 + prow[k]) * (unsigned)rowbytes + pch[k] * 16 : kOOB;
+    }
+    const unsigned swoff = (tid < TS && r0 + tid < a.rows) ? (unsigned)(r0 + tid) * sn * 4 : kOOB;
+    const unsigned sxoff = (tid >= TS && tid < 2 * TS && b0 + tid - TS < a.B) ? (unsigned)(b0 + tid - TS) * sn * 4 : kOOB;
+    v4i wr[kPF][2], xr[kPF][2]; float sr[kPF];
+    auto fetch = [&](int g, int slot) {
+        const bool in = g < sn;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            wr[slot][k] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rW, (int)((in && woff[k] != kOOB) ? woff[k] + (unsigned)g * GB : kOOB), 0, 0));
+            xr[slot][k] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rX, (int)((in && xoff[k] != kOOB) ? xoff[k] + (unsigned)g * GB : kOOB), 0, 0));
+        }
+        sr[slot] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rSW, (int)((in && swoff != kOOB) ? swoff + (unsigned)g * 4 : kOOB), 0, 0)
+                                 | __builtin_amdgcn_raw_buffer_load_b32(rSX, (int)((in && sxoff != kOOB) ? sxoff + (unsigned)g * 4 : kOOB), 0, 0));
+    };
+    auto park = [&](int buf, int slot) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            unsigned lo[2], hi[2];
+            const int o = prow[k] * LS + pch[k] * 8;                       // piece -> 8 consecutive elements of the row's planes
+            split16(wr[slot][k], lo, hi);
+            *reinterpret_cast<uint2*>(&WL[buf][o]) = make_uint2(lo[0], lo[1]); *reinterpret_cast<uint2*>(&WH[buf][o]) = make_uint2(hi[0], hi[1]);
+            split16(xr[slot][k], lo, hi);
+            *reinterpret_cast<uint2*>(&XL[buf][o]) = make_uint2(lo[0], lo[1]); *reinterpret_cast<uint2*>(&XH[buf][o]) = make_uint2(hi[0], hi[1]);
+        }
+        if (tid < TS) sWt[buf][tid] = sr[slot]; else if (tid < 2 * TS) sXt[buf][tid - TS] = sr[slot];
+    };
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int am = wr0 + (lane & 31), bn = wc0 + (lane & 31), kh = (lane >> 5) * 16;
+#pragma unroll
+    for (int u = 0; u < kPF; ++u) fetch(u, u);
+    park(0, 0);
+    fetch(kPF, 0);
+    __syncthreads();
+    auto step = [&](int g, int next_slot) {
+        const int buf = g & 1;
+#define FLM_LD(P, r, off) (*reinterpret_cast<const v4i*>(&P[buf][(r) * LS + (off) + kh]))
+        const v4i al0 = FLM_LD(WL, am, 0), al1 = FLM_LD(WL, am, 32), ah0 = FLM_LD(WH, am, 0), ah1 = FLM_LD(WH, am, 32);
+        const v4i xl0 = FLM_LD(XL, bn, 0), xl1 = FLM_LD(XL, bn, 32), xh0 = FLM_LD(XH, bn, 0), xh1 = FLM_LD(XH, bn, 32);
+#undef FLM_LD
+        const v16i z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        v16i dhh = __builtin_amdgcn_mfma_i32_32x32x32_i8(ah0, xh0, z, 0, 0, 0);
+        dhh = __builtin_amdgcn_mfma_i32_32x32x32_i8(ah1, xh1, dhh, 0, 0, 0);
+        v16i dm = __builtin_amdgcn_mfma_i32_32x32x32_i8(ah0, xl0, z, 0, 0, 0);
+        dm = __builtin_amdgcn_mfma_i32_32x32x32_i8(ah1, xl1, dm, 0, 0, 0);
+        dm = __builtin_amdgcn_mfma_i32_32x32x32_i8(al0, xh0, dm, 0, 0, 0);
+        dm = __builtin_amdgcn_mfma_i32_32x32x32_i8(al1, xh1, dm, 0, 0, 0);
+        v16i dll = __builtin_amdgcn_mfma_i32_32x32x32_i8(al0, xl0, z, 0, 0, 0);
+        dll = __builtin_amdgcn_mfma_i32_32x32x32_i8(al1, xl1, dll, 0, 0, 0);
+        const float sx = sXt[buf][bn];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 sw = *reinterpret_cast<const float4*>(&sWt[buf][wr0 + 8 * q + 4 * (lane >> 5)]);
+            const float swv[4] = {sw.x, sw.y, sw.z, sw.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = 4 * q + e;
+                const int dot = (int)(((unsigned)dhh[i] << 16) + ((unsigned)dm[i] << 8) + (unsigned)dll[i]);      // wraps mod 2^32 onto the exact int32 dot
+                acc[i] = __fmaf_rn(__fmul_rn(swv[e], sx), (float)dot, acc[i]);                                   // quant_operators.cpp:274
+            }
+        }
+        park(buf ^ 1, next_slot); fetch(g + 1 + kPF, next_slot);
+        __syncthreads();
+    };
+    for (int g = 0; g < sn; g += 2) { step(g, 1); step(g + 1, 0); }          // (a group past the end contributes fma(0, 0, acc) = acc)
+    const int b = b0 + bn;
+    if (b < a.B) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = r0 + wr0 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+            if (row >= a.rows) continue;
+            float* o = a.out + (size_t)b * a.ldo + row;
+            if constexpr (EPI == EPI_RESIDUAL) *o = __fadd_rn(*o, acc[i]); else *o = acc[i];
+        }
+    }
+}
+
 // qkv[b] = [q ; k ; v] (dim each) of token b at position pos0 + b: RoPE on q and k (rope_v2 pairs), q -> qout[b], k / v -> cache rows
 __global__ void k_rope_kv_rows(const float* qkv, float* qout, float* kcache, float* vcache, const float* rope_cos, const float* rope_sin,
                                int dim, int hs, int max_seq, int pos0) {

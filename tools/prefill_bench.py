@@ -11,9 +11,10 @@ cfg = synth.make_config("7B", qt); cfg.n_layers = L
 ctx = capi.Ctx(capi.desc_from_config(cfg))
 ctx.upload_all(synth.make_tensors(cfg, seed=1, share_layers=True))
 if os.environ.get("FLM_MFMA") is not None: ctx.set_option("use_mfma", int(os.environ["FLM_MFMA"]))   # 2: 64 x 64 tiles always
+if os.environ.get("FLM_QKMFMA") is not None: ctx.set_option("use_qk_mfma", int(os.environ["FLM_QKMFMA"]))   # 0: scores on VALU chains
 if os.environ.get("FLM_MQ") is not None: ctx.set_option("use_prefill_mq", int(os.environ["FLM_MQ"]))   # 0: one query per workgroup
 prompt = (np.arange(1, n + 1, dtype=np.int64) * 7919 % cfg.vocab_size).astype(np.int32)
-for mode in (1, 0, 1):
+for mode in ((1, 1) if os.environ.get("FLM_PF_ONLY") else (1, 0, 1)):
     ctx.set_option("use_prefill", mode); ctx.reset_kv()
     ctx.sync(); t0 = time.perf_counter()
     tok = ctx.forward_argmax(prompt, 0)
