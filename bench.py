@@ -254,8 +254,49 @@ def time_decode(ctx, cfg, args, prompt, barrier, gold):
             "p50_ms": float(np.median(each)), "p90_ms": float(np.percentile(each, 90)), "each_mean_ms": float(np.mean(each))}
 
 
+def prefill_main(args):
+    """--config prefill<N>-<quant>: BASELINE.json's config 5 (LLaMA2-7B int16 + a 512-token prompt): the batched prompt path --
+    int8 / int16 GEMM tiles on the matrix cores, QK^T on fp32 MFMA, causal softmax + weighted sum -- timed as whole forwards of
+    the prompt (K repetitions on a cleared cache), reported as prompt tokens/s with the linear layers' MAC rate beside it."""
+    import re as _re
+    import torch
+    graft.load_package()
+    from fast_llama_amd import capi, flmfile as ff, synth
+    m = _re.fullmatch(r"prefill(\d+)-(int8|int16)", args.config)
+    if not m:
+        sys.exit("bench.py --config: expected prefill<N>-int8|int16, e.g. prefill512-int16")
+    n, qt = int(m.group(1)), (ff.QT_INT8 if m.group(2) == "int8" else ff.QT_INT16)
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    cfg = synth.make_config(args.shape, qt)
+    ctx = capi.Ctx(capi.desc_from_config(cfg), device=0)
+    upload_synthetic(ctx, cfg)
+    V = cfg.vocab_size
+    prompt = np.array([1] + [int(x) for x in (np.arange(1, n) * 7919) % V], dtype=np.int32)
+    for _ in range(max(1, args.warmup)):
+        ctx.reset_kv(); tok = ctx.forward_argmax(prompt, 0)
+    times = []
+    for _ in range(max(1, args.steps)):
+        ctx.reset_kv(); ctx.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter(); tok = ctx.forward_argmax(prompt, 0); times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
+    L, dim, hid = cfg.n_layers, cfg.dim, cfg.hidden_dim
+    macs = (n - 1) * ((L - 1) * (4 * dim * dim + 3 * dim * hid) + 3 * dim * dim)      # the batch: every layer but the last in full, the last one's q/k/v only
+    flops_qk = 2.0 * (L - 1) * cfg.n_heads * cfg.head_size * sum(range(1, n))              # causal QK^T (the fp32-MFMA kernel)
+    line = {"metric": f"prefill tokens/s LLaMA2-{args.shape} {m.group(2)}, {n}-token prompt", "value": round(n / dt, 1), "unit": "tokens/s", "n_gpus": 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": m.group(2), "data": "synthetic",
+            "config": {"workload": f"LLaMA2-{args.shape} {m.group(2)}, {n}-token prompt through the batched path (GEMM tiles on v_mfma_i32_32x32x32_i8, int16 as hi/lo byte planes; "
+                                   f"QK^T on v_mfma_f32_16x16x4_f32; last token through the decode kernels), next token {int(tok)}"},
+            "linear_layers": {"int_macs": int(macs), "TMAC_per_s_over_whole_forward": round(macs / dt / 1e12, 1), "note": "lower bound: the forward's whole wall time is charged to the GEMMs"},
+            "qk_flops": int(flops_qk)}
+    print(json.dumps(line), flush=True)
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default=None, help="prefill<N>-int8|int16: time the batched prompt path instead of decode (BASELINE config 5: prefill512-int16)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=8)
@@ -270,6 +311,8 @@ def main():
                     help="N > 1: 'tp' (default) = ONE sequence, every matmul split by output rows over the GPUs (strong scaling, the headline value; "
                          "the replicas figure is reported beside it); 'replicas' = one independent sequence per GPU only")
     args = ap.parse_args()
+    if args.config:
+        return prefill_main(args)
 
     import torch
     graft.load_package()
