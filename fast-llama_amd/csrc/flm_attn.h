@@ -134,9 +134,11 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
 #pragma unroll
     for (int u = 0; u < D; ++u) request(rK, sb + u, se, prow, goff, ringK[u]);
     if constexpr (SPLIT) {
-        // piece f = tid + j * 1024 of the slice: row f / 8, 16-byte column f % 8
+        // piece f = tid + j * 1024 of the slice: row f / 8, 16-byte column f % 8.  The first half of the slice (rows < 512) now, the
+        // second half when the K ring's registers are free (behind the scores; it lands under the exchange and the softmax): all of
+        // it at once is 4 registers more than a 1024-thread workgroup has
 #pragma unroll
-        for (int j = 0; j < kSplitVRegs; ++j) {
+        for (int j = 0; j < kSplitVRegs / 2; ++j) {
             const int row = (tid >> 3) + j * (kAttnBlock >> 3);
             const unsigned off = row < T ? (unsigned)((row * hs + d0 + (tid & 7) * 4) * 4) : 0x80000000u;
             vall[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rV, (int)off, 0, COH ? kAuxCoherent : 0));
@@ -158,7 +160,7 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
         const int t = s * kAttnTile + p;
         const float* kp = cur + p * rs + k;
         float l = 0.f;
-#pragma unroll 16
+#pragma unroll 8
         for (int j = 0; j < hs; j += 8) l = __fmaf_rn(kp[j], qs[j + k], l);
         const int li = __float_as_int(l);
         float tot = __fadd_rn(0.f, l);
@@ -201,6 +203,14 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
                 request(rK, s + D, se, prow, goff, ringK[u]);
                 if (s < se && tid < kAttnTile * 8) score_lane(cur, s, tid >> 3, tid & 7);
             }
+        }
+    }
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int j = kSplitVRegs / 2; j < kSplitVRegs; ++j) {
+            const int row = (tid >> 3) + j * (kAttnBlock >> 3);
+            const unsigned off = row < T ? (unsigned)((row * hs + d0 + (tid & 7) * 4) * 4) : 0x80000000u;
+            vall[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rV, (int)off, 0, COH ? kAuxCoherent : 0));
         }
     }
     stamp(1);
@@ -386,19 +396,21 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
     }
     __syncthreads();                                                // the LDS is free for whoever runs next on it
 }
-template <bool COH>
+// SPLIT is a template argument of the kernels (not a run-time branch inside one kernel): the two forms keep different things in
+// registers, and compiled into one function they spilled a 16-byte register -- behind an s_waitcnt vmcnt(0) on the whole prefetch
+template <bool COH, bool SPLIT>
 __device__ __forceinline__ void attn_head_any(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow, const int g = 0, const int G = 1) {
-    if (G > 1) {      // the host picks G = hs / kSplitDims (attn_parts): every part owns 32 output dimensions
-        if (a.hs <= 64) attn_head<1, COH, true>(a, h, lds, T, qrow, orow, g, G); else if (a.hs <= 128) attn_head<2, COH, true>(a, h, lds, T, qrow, orow, g, G); else attn_head<4, COH, true>(a, h, lds, T, qrow, orow, g, G);
-        return;
+    if constexpr (SPLIT) {      // the host picks G = hs / kSplitDims (attn_parts): every part owns 32 output dimensions; hs <= 128
+        if (a.hs <= 64) attn_head<1, COH, true>(a, h, lds, T, qrow, orow, g, G); else attn_head<2, COH, true>(a, h, lds, T, qrow, orow, g, G);
+    } else {
+        if (a.hs <= 64) attn_head<1, COH>(a, h, lds, T, qrow, orow); else if (a.hs <= 128) attn_head<2, COH>(a, h, lds, T, qrow, orow); else attn_head<4, COH>(a, h, lds, T, qrow, orow);
     }
-    if (a.hs <= 64) attn_head<1, COH>(a, h, lds, T, qrow, orow); else if (a.hs <= 128) attn_head<2, COH>(a, h, lds, T, qrow, orow); else attn_head<4, COH>(a, h, lds, T, qrow, orow);
 }
 // batched prefill: workgroup (h, i) is query i of the batch, at position pos0 + i, over the cache rows 0 .. pos0 + i
 __global__ void __launch_bounds__(kAttnBlock) k_attn_prefill(const AttnArgs a, int pos0, int row_stride) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int i = blockIdx.y;
-    attn_head_any<false>(a, blockIdx.x, lds, pos0 + i + 1, a.q + (size_t)i * row_stride, a.out + (size_t)i * row_stride);
+    attn_head_any<false, false>(a, blockIdx.x, lds, pos0 + i + 1, a.q + (size_t)i * row_stride, a.out + (size_t)i * row_stride);
 }
 // ------------------------------------------------------------------------------------------
 // Batched prefill, several queries per workgroup (hs <= 128).  Workgroup (h, g) takes the kMqQueries consecutive queries
@@ -669,10 +681,11 @@ __global__ void __launch_bounds__(256) k_qk_mfma(const AttnArgs a, int pos0, int
     }
 }
 // grid = heads * G (G = a.G >= 1 parts per head; all of them resident: the parts wait for each other's scores)
+template <bool SPLIT>
 __global__ void __launch_bounds__(kAttnBlock) k_attn_decode(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int G = a.G > 1 ? a.G : 1;
-    attn_head_any<false>(a, blockIdx.x / G, lds, *a.pos_ptr + 1, a.q, a.out, blockIdx.x % G, G);
+    const int G = SPLIT ? a.G : 1;
+    attn_head_any<false, SPLIT>(a, blockIdx.x / G, lds, *a.pos_ptr + 1, a.q, a.out, blockIdx.x % G, G);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -688,14 +701,14 @@ __global__ void __launch_bounds__(kAttnBlock) k_attn_decode(const AttnArgs a) {
 constexpr int kFlagStride = 16;      // dwords
 // PREQ: the heads hand over their output already quantized (AttnArgs::oq/os == GemvArgs::xq/xs): the GEMV workgroups
 // copy 1 (2) bytes per element into LDS with coherent loads and skip the quantize prologue (~1.8 us of a 12.9 us launch).
-template <int QT, int XR, bool PREQ>
+template <int QT, int XR, bool PREQ, bool SPLIT = false>
 __global__ void __launch_bounds__(kGemvBlock, 4) k_attn_o(const AttnArgs aa, const GemvArgs a, const int n_heads, unsigned* flag, const unsigned target, int* err) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     auto stamp = [&](int k) { if (kAblate && a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime(); };   // tools/trace_ao.py
     stamp(0);
     if ((int)blockIdx.x < n_heads) {                                           // n_heads counts head PARTS: heads * G
-        const int G = aa.G > 1 ? aa.G : 1;
-        attn_head_any<false>(aa, blockIdx.x / G, lds, *aa.pos_ptr + 1, aa.q, aa.out, blockIdx.x % G, G);
+        const int G = SPLIT ? aa.G : 1;
+        attn_head_any<false, SPLIT>(aa, blockIdx.x / G, lds, *aa.pos_ptr + 1, aa.q, aa.out, blockIdx.x % G, G);
         stamp(1);
         wait_stores_done();                                                     // every wave: its part of the head's output is where the others will read it
         __syncthreads();

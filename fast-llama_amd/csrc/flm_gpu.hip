@@ -325,7 +325,7 @@ constexpr int kSplitFrom = 128;
 int attn_parts(const flm_ctx* c, int T) {
     // every part owns kSplitDims = 32 output dimensions (its whole V slice then fits the registers / LDS of one workgroup)
     const int Gfull = c->hs / kSplitDims;
-    const bool can = c->hs % kSplitDims == 0 && Gfull >= 2 && c->d.max_seq_len <= kSplitMaxSeq && c->heads_local * Gfull + 8 <= c->cu_count && c->heads_local * Gfull <= 256;
+    const bool can = c->hs % kSplitDims == 0 && Gfull >= 2 && c->hs <= 128 && c->d.max_seq_len <= kSplitMaxSeq && c->heads_local * Gfull + 8 <= c->cu_count && c->heads_local * Gfull <= 256;
     if (!can || c->attn_split == 0) return 1;
     return (c->attn_split >= 2 || T >= kSplitFrom) ? Gfull : 1;
 }
@@ -394,6 +394,10 @@ int launch_attn_o(flm_ctx* c, hipStream_t st, int l, int G) {
         a.xq = c->att_q; a.xs = c->att_qs;
         hipLaunchKernelGGL((k_attn_o<QT, 0, true>), grid, block, lds, st, aa, a, parts, flag, (unsigned)(l + 1), c->xwg_err);
     }
+    else if (G > 1) {
+        if (rounds <= 1) hipLaunchKernelGGL((k_attn_o<QT, 1, false, true>), grid, block, lds, st, aa, a, parts, flag, (unsigned)(l + 1), c->xwg_err);
+        else             hipLaunchKernelGGL((k_attn_o<QT, 3, false, true>), grid, block, lds, st, aa, a, parts, flag, (unsigned)(l + 1), c->xwg_err);
+    }
     else if (rounds <= 1) hipLaunchKernelGGL((k_attn_o<QT, 1, false>), grid, block, lds, st, aa, a, parts, flag, (unsigned)(l + 1), c->xwg_err);
     else                  hipLaunchKernelGGL((k_attn_o<QT, 3, false>), grid, block, lds, st, aa, a, parts, flag, (unsigned)(l + 1), c->xwg_err);
     HIPC(c, hipGetLastError());
@@ -444,7 +448,8 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
         if (!fused) {   // ATTN task (execute_attn :441-449): local heads write their slice of the full att_out vector (on every rank, peer to peer)
             Tick t(c, st, KC_ATTN);
             AttnArgs aa = args_attn(c, l, G); if (kAblate && c->trace_class == KC_ATTN && l == 0) aa.trace = c->trace;
-            hipLaunchKernelGGL(k_attn_decode, dim3(c->heads_local * G), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, hs, G > 1), st, aa);
+            if (G > 1) hipLaunchKernelGGL(k_attn_decode<true>, dim3(c->heads_local * G), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, hs, true), st, aa);
+            else       hipLaunchKernelGGL(k_attn_decode<false>, dim3(c->heads_local), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, hs, false), st, aa);
             HIPC(c, hipGetLastError());
         }
         // every rank needs all heads' outputs: the reference's threads share x2 in memory (transformer.cpp:451-454)
@@ -1101,7 +1106,10 @@ int flm_kernel_times(flm_ctx* c, int pos, int iters, float* avg_us, int32_t* cou
         switch (kc) {
         case KC_EMBED:  hipLaunchKernelGGL(k_embed, dim3((d.dim + 255) / 256), dim3(256), 0, st, c->x1, (const void*)c->emb, (const float*)c->emb_s, c->emb_qt, d.dim, (const int*)&c->state->tok, c->flag_lines); return FLM_OK;
         case KC_QKV:    return launch_gemv<PRO_RMSNORM_QUANT, EPI_ROPE_KV>(c, st, qt, args_qkv(c, l), wgs);
-        case KC_ATTN:   { const int G = attn_parts(c, pos + 1); hipLaunchKernelGGL(k_attn_decode, dim3(c->heads_local * G), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, c->hs, G > 1), st, args_attn(c, l, G)); return FLM_OK; }
+        case KC_ATTN:   { const int G = attn_parts(c, pos + 1);
+                          if (G > 1) hipLaunchKernelGGL(k_attn_decode<true>, dim3(c->heads_local * G), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, c->hs, true), st, args_attn(c, l, G));
+                          else       hipLaunchKernelGGL(k_attn_decode<false>, dim3(c->heads_local), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, c->hs, false), st, args_attn(c, l, 1));
+                          return FLM_OK; }
         case KC_ATTN_O: return launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, args_o(c, l), wgs);
         case KC_FFN13:  return launch_gemv<PRO_RMSNORM_QUANT, EPI_SWIGLU>(c, st, qt, args_ffn13(c, l), wgs);
         case KC_FFN2:   return launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, args_ffn2(c, l), wgs);
@@ -1292,12 +1300,13 @@ int flm_op_attention(float* out, float* kc, float* vc, const float* q, const flo
     a.out = dout.as<float>();
     // tests: FLM_OP_ATTN_PARTS = G spreads every head over G workgroups (the long-context path of the decode loop)
     int G = (getenv("FLM_OP_ATTN_PARTS") && atoi(getenv("FLM_OP_ATTN_PARTS")) > 1) ? hs / kSplitDims : 1;
-    if (G < 2 || hs % kSplitDims || n_heads * G > 256 || max_seq > kSplitMaxSeq) G = 1;
+    if (G < 2 || hs % kSplitDims || hs > 128 || n_heads * G > 256 || max_seq > kSplitMaxSeq) G = 1;
     DevBuf dsc, dfl, derr;
     if (dsc.alloc((size_t)n_heads * max_seq * 4) || dfl.alloc(256 * 64) || derr.alloc(64)) return FLM_ERR_OOM;
     OPC(hipMemset(dfl.p, 0, 256 * 64)); OPC(hipMemset(derr.p, 0, 64));
     a.G = G; a.sc_global = dsc.as<float>(); a.flag_sc = dfl.as<unsigned>(); a.epoch = 1; a.err = derr.as<int>();
-    hipLaunchKernelGGL(k_attn_decode, dim3(n_heads * G), dim3(kAttnBlock), attn_lds_bytes(max_seq, hs, G > 1), 0, a);
+    if (G > 1) hipLaunchKernelGGL(k_attn_decode<true>, dim3(n_heads * G), dim3(kAttnBlock), attn_lds_bytes(max_seq, hs, true), 0, a);
+    else       hipLaunchKernelGGL(k_attn_decode<false>, dim3(n_heads), dim3(kAttnBlock), attn_lds_bytes(max_seq, hs, false), 0, a);
     OPC(hipGetLastError());
     OPC(hipDeviceSynchronize());
     OPC(hipMemcpy(out, dout.p, nd * 4, hipMemcpyDeviceToHost));
