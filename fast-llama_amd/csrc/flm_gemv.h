@@ -350,13 +350,8 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
             // the hook issues the weight prefetch.  The chain waves (0..3, one strided lane each) go first (the others give
             // them ~128 cycles): their loads enter an empty memory pipeline at once and they are free for the chains;
             // queued behind the other waves' loads they would stall for ~1 us before (or after) the chain.
-#ifdef FLM_CHAIN_LATE_ISSUE
-            // the chain waves request their weights only AFTER the chain: 1.35 us of issue (measured) leaves the critical path
-            if (tid >= 4 * kWave) after_stage(0);
-#else
             if (tid >= 4 * kWave) __builtin_amdgcn_s_sleep(2);
             after_stage(0);
-#endif
 #ifdef FLM_TRACE_PRO2
             FLM_PRO_STAMP(1)
 #endif
@@ -364,9 +359,6 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
                 const float l = sq_chain_spec(scratch + (tid >> 6) * CS, bs);
                 if ((tid & 63) == 0) red[8 + (tid >> 6)] = l;
             }
-#ifdef FLM_CHAIN_LATE_ISSUE
-            if (tid < 4 * kWave) after_stage(0);
-#endif
             FLM_PRO_STAMP(4)
             __syncthreads();
             const float ss = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, red[8]), red[9]), red[10]), red[11]);
@@ -773,16 +765,10 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_gemv(const GemvArgs a) {
     GemvCtx<QT, EPI> g;
     g.init(a, blockIdx.x, gridDim.x, lds);
     if constexpr (PRO == PRO_NONE) g.issue(kAblate ? a.ablate : 0);
-#ifdef FLM_EARLY_ISSUE
-    constexpr int kLatePart = 2;                       // experiment: the first register set is requested right behind the activation loads
-    if constexpr (PRO != PRO_NONE) g.issue(kAblate ? a.ablate : 0, 1);
-#else
-    constexpr int kLatePart = 0;
-#endif
 #ifndef FLM_TRACE_PRO2
     stamp(1);
 #endif
-    gemv_prologue<QT, PRO, XR, COH>(a, lds, xv, nv, [&](int) { g.issue(kAblate ? a.ablate : 0, kLatePart); });
+    gemv_prologue<QT, PRO, XR, COH>(a, lds, xv, nv, [&](int part) { g.issue(kAblate ? a.ablate : 0, part); });
     stamp(2);
     if (kAblate && (a.ablate & 32)) return;
     g.run(a, lds, stamp);

@@ -191,16 +191,21 @@ __global__ void __launch_bounds__(256) k_gemm_q(const GemmArgs a) {
 // tokens: a workgroup iteration then loads 16 KB for four times the products (the 64 x 64 tile pulls 8 KB per iteration through a
 // CU's ~30 KB/us memory pipeline, which -- not the VALU -- bounded it at 35 % of the VALU rate).
 typedef int v16i __attribute__((ext_vector_type(16)));
+// A STAGE is kGPS = 2 consecutive quant groups (128 bytes of every row): one barrier, one pair of LDS buffers and one ring slot per
+// stage instead of per group -- the loop was bound by the barrier + LDS round trip per group, not by the MFMAs or the chain
+// (round 1: 10 % of the i8 MFMA peak).  Inside a stage the groups are consumed in ascending order: the chain is unchanged.
+constexpr int kGPS = 2;
 template <int EPI, int NW>
 __global__ void __launch_bounds__(64 * NW * NW) k_gemm_q8_mfma(const GemmArgs a) {
     constexpr int GB = kGroup;                    // bytes of a group in one row (int8)
-    constexpr int LS = GB + 16;                   // LDS row stride
+    constexpr int SB = kGPS * GB;                 // bytes of a stage in one row
+    constexpr int LS = SB + 16;                   // LDS row stride
     constexpr int TS = 32 * NW;                   // tile side
     constexpr int NT = 64 * NW * NW;              // threads
     __shared__ __attribute__((aligned(16))) char Wt[2][TS * LS];
     __shared__ __attribute__((aligned(16))) char Xt[2][TS * LS];
-    __shared__ __attribute__((aligned(16))) float sWt[2][TS];
-    __shared__ float sXt[2][TS];
+    __shared__ __attribute__((aligned(16))) float sWt[2][kGPS][TS];
+    __shared__ float sXt[2][kGPS][TS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntt = (a.B + TS - 1) / TS;
     // token tile fastest: the ntt tiles that share the weight rows are neighbours in the LOGICAL order -- and workgroup b runs on XCD
@@ -210,20 +215,22 @@ __global__ void __launch_bounds__(64 * NW * NW) k_gemm_q8_mfma(const GemmArgs a)
     const int tile = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
     const int r0 = (tile / ntt) * TS, b0 = (tile % ntt) * TS;
     const int wr0 = (wave / NW) * 32, wc0 = (wave % NW) * 32;               // this wave's 32 x 32 inside the tile
-    const int sn = a.n / kGroup;
+    const int sn = a.n / kGroup, nst = (sn + kGPS - 1) / kGPS;               // groups, stages
     const size_t rowbytes = (size_t)a.n;
     const char* Wb = reinterpret_cast<const char*>(a.W);
     const char* Xb = reinterpret_cast<const char*>(a.Xq);
-    // An iteration (one quant group: 2 MFMAs + 16 chain steps per lane) takes ~0.1 us, a global load ~1-2 us: the loads run
-    // kPF groups ahead through a register ring
-    constexpr int kPF = NW == 4 ? 2 : 4;          // (the 16-wave tile has 128 registers per lane: a 4-deep ring spills)
-    // loader: TS rows x 4 chunks of 16 B for the weights and as many for the activations.  NW == 2: every thread loads one piece of
-    // each; NW == 4: threads 0..511 load weights, 512..1023 activations
+    // A stage takes ~0.2 us, a global load ~1-2 us: the loads run kPF stages ahead through a register ring
+    constexpr int kPF = NW == 4 ? 1 : 2;          // (the 16-wave tile has 128 registers per lane: a second slot spills)
+    // loader: TS rows x 8 pieces of 16 B per matrix and stage.  NW == 2: every thread loads two pieces of each matrix;
+    // NW == 4: threads 0..511 load two weight pieces, 512..1023 two activation pieces
     constexpr bool kSplit = NW == 4;
     const bool ldw = !kSplit || tid < NT / 2, ldx = !kSplit || tid >= NT / 2;
     const int lt = kSplit ? (tid & (NT / 2 - 1)) : tid;
-    const int lrow = lt >> 2, lch = lt & 3;
-    v4i wr[kPF], xr[kSplit ? 1 : kPF]; float sr[kPF];
+    constexpr int NL = kSplit ? NT / 2 : NT;      // loader threads per matrix; TS * 8 pieces / NL = 2 pieces per thread
+    int lrow[2], lch[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { const int idx = lt + k * NL; lrow[k] = idx >> 3; lch[k] = idx & 7; }
+    v4i wr[kPF][2], xr[kPF][kSplit ? 1 : 2]; float sr[kPF][kGPS];
     // branch-free raw buffer loads (pieces outside the matrix / past the last group get an out-of-range offset and read as zero):
     // with the loads under control flow the compiler waited for vmcnt(0) in every iteration, i.e. for the load it had just issued
     constexpr unsigned kOOB = 0x80000000u;
@@ -232,31 +239,46 @@ __global__ void __launch_bounds__(64 * NW * NW) k_gemm_q8_mfma(const GemmArgs a)
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Xb), 0, (int)nX, 0x00020000);
     const __amdgpu_buffer_rsrc_t rSW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.sW), 0, (int)((unsigned)a.rows * sn * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rSX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Xs), 0, (int)((unsigned)a.B * sn * 4), 0x00020000);
-    const bool wok = ldw && r0 + lrow < a.rows, xok = ldx && b0 + lrow < a.B;
-    const unsigned woff = wok ? (unsigned)(r0 + lrow) * (unsigned)rowbytes + lch * 16 : kOOB;
-    const unsigned xoff = xok ? (unsigned)(b0 + lrow) * (unsigned)rowbytes + lch * 16 : kOOB;
+    unsigned woff[2], xoff[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        woff[k] = (ldw && r0 + lrow[k] < a.rows) ? (unsigned)(r0 + lrow[k]) * (unsigned)rowbytes + lch[k] * 16 : kOOB;
+        xoff[k] = (ldx && b0 + lrow[k] < a.B)    ? (unsigned)(b0 + lrow[k]) * (unsigned)rowbytes + lch[k] * 16 : kOOB;
+    }
     const bool s_w = tid < TS, s_x = tid >= TS && tid < 2 * TS;
     const unsigned swoff = (s_w && r0 + tid < a.rows) ? (unsigned)(r0 + tid) * sn * 4 : kOOB;
     const unsigned sxoff = (s_x && b0 + tid - TS < a.B) ? (unsigned)(b0 + tid - TS) * sn * 4 : kOOB;
-    auto fetch = [&](int g, int slot) {
-        const bool in = g < sn;
-        const unsigned wo = (in && woff != kOOB) ? woff + (unsigned)g * GB : kOOB, xo = (in && xoff != kOOB) ? xoff + (unsigned)g * GB : kOOB;
-        const unsigned so = (in && swoff != kOOB) ? swoff + (unsigned)g * 4 : kOOB, sxo = (in && sxoff != kOOB) ? sxoff + (unsigned)g * 4 : kOOB;
-        const v4u w = __builtin_amdgcn_raw_buffer_load_b128(rW, (int)wo, 0, 0);
-        const v4u x = __builtin_amdgcn_raw_buffer_load_b128(rX, (int)xo, 0, 0);
-        if constexpr (kSplit) wr[slot] = __builtin_bit_cast(v4i, ldw ? w : x);       // one register per slot: a weight piece or an activation piece (the other load is out of range)
-        else { wr[slot] = __builtin_bit_cast(v4i, w); xr[slot] = __builtin_bit_cast(v4i, x); }
-        sr[slot] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rSW, (int)so, 0, 0) | __builtin_amdgcn_raw_buffer_load_b32(rSX, (int)sxo, 0, 0));
+    auto fetch = [&](int st, int slot) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            // a piece's group: st * kGPS + (lch >> 2); bytes past the row's end (an odd group count's last half stage) read as zero
+            const bool in = st * kGPS + (lch[k] >> 2) < sn;
+            const unsigned wo = (in && woff[k] != kOOB) ? woff[k] + (unsigned)st * SB : kOOB, xo = (in && xoff[k] != kOOB) ? xoff[k] + (unsigned)st * SB : kOOB;
+            const v4u w = __builtin_amdgcn_raw_buffer_load_b128(rW, (int)wo, 0, 0);
+            const v4u x = __builtin_amdgcn_raw_buffer_load_b128(rX, (int)xo, 0, 0);
+            if constexpr (kSplit) wr[slot][k] = __builtin_bit_cast(v4i, ldw ? w : x);       // one register per piece: a weight piece or an activation piece (the other load is out of range)
+            else { wr[slot][k] = __builtin_bit_cast(v4i, w); xr[slot][k] = __builtin_bit_cast(v4i, x); }
+        }
+#pragma unroll
+        for (int gi = 0; gi < kGPS; ++gi) {
+            const int g = st * kGPS + gi;
+            const unsigned so = (g < sn && swoff != kOOB) ? swoff + (unsigned)g * 4 : kOOB, sxo = (g < sn && sxoff != kOOB) ? sxoff + (unsigned)g * 4 : kOOB;
+            sr[slot][gi] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rSW, (int)so, 0, 0) | __builtin_amdgcn_raw_buffer_load_b32(rSX, (int)sxo, 0, 0));
+        }
     };
     auto park = [&](int buf, int slot) {
-        if constexpr (kSplit) {
-            char* dst = ldw ? &Wt[buf][lrow * LS + lch * 16] : &Xt[buf][lrow * LS + lch * 16];
-            *reinterpret_cast<v4i*>(dst) = wr[slot];
-        } else {
-            *reinterpret_cast<v4i*>(&Wt[buf][lrow * LS + lch * 16]) = wr[slot];
-            *reinterpret_cast<v4i*>(&Xt[buf][lrow * LS + lch * 16]) = xr[slot];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if constexpr (kSplit) {
+                char* dst = ldw ? &Wt[buf][lrow[k] * LS + lch[k] * 16] : &Xt[buf][lrow[k] * LS + lch[k] * 16];
+                *reinterpret_cast<v4i*>(dst) = wr[slot][k];
+            } else {
+                *reinterpret_cast<v4i*>(&Wt[buf][lrow[k] * LS + lch[k] * 16]) = wr[slot][k];
+                *reinterpret_cast<v4i*>(&Xt[buf][lrow[k] * LS + lch[k] * 16]) = xr[slot][k];
+            }
         }
-        if (tid < TS) sWt[buf][tid] = sr[slot]; else if (tid < 2 * TS) sXt[buf][tid - TS] = sr[slot];
+#pragma unroll
+        for (int gi = 0; gi < kGPS; ++gi) { if (tid < TS) sWt[buf][gi][tid] = sr[slot][gi]; else if (tid < 2 * TS) sXt[buf][gi][tid - TS] = sr[slot][gi]; }
     };
     float acc[16];
 #pragma unroll
@@ -267,29 +289,32 @@ __global__ void __launch_bounds__(64 * NW * NW) k_gemm_q8_mfma(const GemmArgs a)
     park(0, 0);
     fetch(kPF, 0);
     __syncthreads();
-    auto step = [&](int g, int next_slot) {                                 // group g is in LDS buffer g & 1; group g + 1 waits in ring slot next_slot
-        const int buf = g & 1;
-        const v4i a0 = *reinterpret_cast<const v4i*>(&Wt[buf][am * LS + kh]), a1 = *reinterpret_cast<const v4i*>(&Wt[buf][am * LS + 32 + kh]);
-        const v4i x0 = *reinterpret_cast<const v4i*>(&Xt[buf][bn * LS + kh]), x1 = *reinterpret_cast<const v4i*>(&Xt[buf][bn * LS + 32 + kh]);
-        v16i d = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        d = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, x0, d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, x1, d, 0, 0, 0);
-        const float sx = sXt[buf][bn];
+    auto step = [&](int st, int next_slot) {                                // stage st is in LDS buffer st & 1; stage st + 1 waits in ring slot next_slot
+        const int buf = st & 1;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 sw = *reinterpret_cast<const float4*>(&sWt[buf][wr0 + 8 * q + 4 * (lane >> 5)]);
-            acc[4 * q + 0] = __fmaf_rn(__fmul_rn(sw.x, sx), (float)d[4 * q + 0], acc[4 * q + 0]);   // quant_operators.cpp:274
-            acc[4 * q + 1] = __fmaf_rn(__fmul_rn(sw.y, sx), (float)d[4 * q + 1], acc[4 * q + 1]);
-            acc[4 * q + 2] = __fmaf_rn(__fmul_rn(sw.z, sx), (float)d[4 * q + 2], acc[4 * q + 2]);
-            acc[4 * q + 3] = __fmaf_rn(__fmul_rn(sw.w, sx), (float)d[4 * q + 3], acc[4 * q + 3]);
+        for (int gi = 0; gi < kGPS; ++gi) {
+            const v4i a0 = *reinterpret_cast<const v4i*>(&Wt[buf][am * LS + gi * GB + kh]), a1 = *reinterpret_cast<const v4i*>(&Wt[buf][am * LS + gi * GB + 32 + kh]);
+            const v4i x0 = *reinterpret_cast<const v4i*>(&Xt[buf][bn * LS + gi * GB + kh]), x1 = *reinterpret_cast<const v4i*>(&Xt[buf][bn * LS + gi * GB + 32 + kh]);
+            v16i d = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            d = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, x0, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, x1, d, 0, 0, 0);
+            const float sx = sXt[buf][gi][bn];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 sw = *reinterpret_cast<const float4*>(&sWt[buf][gi][wr0 + 8 * q + 4 * (lane >> 5)]);
+                acc[4 * q + 0] = __fmaf_rn(__fmul_rn(sw.x, sx), (float)d[4 * q + 0], acc[4 * q + 0]);   // quant_operators.cpp:274
+                acc[4 * q + 1] = __fmaf_rn(__fmul_rn(sw.y, sx), (float)d[4 * q + 1], acc[4 * q + 1]);
+                acc[4 * q + 2] = __fmaf_rn(__fmul_rn(sw.z, sx), (float)d[4 * q + 2], acc[4 * q + 2]);
+                acc[4 * q + 3] = __fmaf_rn(__fmul_rn(sw.w, sx), (float)d[4 * q + 3], acc[4 * q + 3]);
+            }
         }
-        park(buf ^ 1, next_slot); fetch(g + 1 + kPF, next_slot);           // unconditional (groups past the end are zeros): under a branch the
+        park(buf ^ 1, next_slot); fetch(st + 1 + kPF, next_slot);          // unconditional (stages past the end are zeros): under a branch the
         __syncthreads();                                                    // compiler loses count of the loads in flight and waits for all of them
     };
-    // ring slots are compile-time indices; the group count is rounded up to a multiple of kPF -- a group past the end contributes
+    // ring slots are compile-time indices; the stage count is rounded up to a multiple of kPF -- a group past the end contributes
     // fma(0, 0, acc) = acc (acc is never -0: it starts at +0 and every product s * float(dot) with dot == 0 is +0)
-    if constexpr (kPF == 4) { for (int g = 0; g < sn; g += 4) { step(g, 1); step(g + 1, 2); step(g + 2, 3); step(g + 3, 0); } }
-    else                    { for (int g = 0; g < sn; g += 2) { step(g, 1); step(g + 1, 0); } }
+    if constexpr (kPF == 2) { for (int st = 0; st < nst; st += 2) { step(st, 1); step(st + 1, 0); } }
+    else                    { for (int st = 0; st < nst; ++st) step(st, 0); }
     const int b = b0 + bn;
     if (b < a.B) {
 #pragma unroll
