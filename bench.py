@@ -1,23 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- decode tokens/s of the fast-llama per-token hot path on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W [--pos P]      (N > 1: launched by torch.distributed.run, one process per GPU)
+  python bench.py --config prefill512-int16                     (BASELINE config 5: the batched prompt path)
 
-One step = one greedy decode token of LLaMA2-7B int8 (synthetic weights, configs[2] of BASELINE.json)
-through the HIP path (fast-llama_amd/lib/libflm_gpu.so, C ABI include/flm_gpu.h).  All weights, the
-KV cache and the decode state are resident in HBM before the timed region; the K timed tokens run
-back to back from a hipGraph with no host round trip.
-N > 1 (one process per GPU): by default N REPLICAS, each GPU decoding its own sequence -- single-stream
-decode is a chain of dependent ~20 us kernels, so splitting one sequence over GPUs buys capacity, not speed
-(DESIGN.md section 8); whole-job tokens/s = N*K / max over ranks of the wall time, "scaling": "weak", no
-data-path collective.  --parallel tp runs ONE sequence tensor-parallel instead (every matmul split by
-output rows + RCCL all-gather of the activations, bit-identical to the single-GPU result; "strong").
+One step = one greedy decode token of LLaMA2-7B int8 (synthetic weights, configs[2] of BASELINE.json) through the HIP path
+(fast-llama_amd/lib/libflm_gpu.so, C ABI include/flm_gpu.h).  All weights, the KV cache and the decode state are resident in HBM
+before the timed region; the K timed tokens run back to back from a hipGraph with no host round trip.  The checkpoint is the
+portable splitmix64 one of fast_llama_amd/synth.py (norm weights 1.0), the same tensors the reference decoded when
+tests/golden/model_7B_int8_L32.npz was made -- the line's `parity` field says whether the ids decoded here equal the reference's.
+
+N > 1: the headline `value` is ONE sequence sharded over the N GPUs ("scaling": "strong"): every matmul split by output rows
+(bit-identical to one GPU), activation slices exchanged peer to peer over xGMI (RCCL all-gathers if the peer mapping fails); the
+replicas figure (N independent sequences, no data-path collective, "weak") is reported beside it in `replicas`.  If the sharded
+run fails or decodes other ids than the reference on any rank, the line falls back to replicas and says so in `tp_note`.
+--parallel replicas measures the replicas only.
 
 Rank 0 prints ONE JSON line; besides the contract's keys it carries
-  roofline     : dominant kernel (ffn13 GEMV) algorithmic bytes / its mean launch time measured live
-                 with HIP events on the ctx stream, against the 8 TB/s HBM3E peak
-  cpu_baseline : the reference's own CPU path (oracle/_ref/main, built from /root/reference by
-                 oracle/Makefile) timed on this host's cores on a bounded sample (N = 1 only)
+  roofline       : dominant kernel (ffn13 GEMV) algorithmic bytes / its mean launch time measured live with HIP events on the ctx
+                   stream, against the 8 TB/s HBM3E peak; traffic from the committed PMC summary under profiles/
+  token_roofline : algorithmic bytes per token (weights + scales + norms + KV rows at the measured positions) x tokens/s vs 8 TB/s
+  parity         : ids decoded in this run vs the reference CPU path's (golden fixture), and whether a replay gave the same ids
+  p50/p90        : per-token times of a second pass with one event per token
+  cpu_baseline   : the reference's own CPU path (oracle/_ref/main, built from /root/reference by oracle/Makefile) timed on this
+                   host's cores on a bounded sample (N = 1 only)
 """
 from __future__ import annotations
 
@@ -366,6 +372,8 @@ def main():
             ctx = open_tp_ctx(capi, cfg, rank, world, device, dist, torch)
             upload_synthetic(ctx, cfg)
             m = time_decode(ctx, cfg, args, prompt_for(0), barrier, gold)
+            if m["parity"]["match"] is False:      # a sharded run that decodes other ids than the reference is not a result: fall back, say so
+                raise RuntimeError(f"sharded decode differs from the reference's ids at generated token {m['parity'].get('first_mismatch')}")
             ok = 1
         except Exception as e:  # noqa: BLE001
             log(f"rank {rank}: tensor-parallel run failed: {e}")
