@@ -484,11 +484,12 @@ def open_tp_ctx(capi, cfg, rank, world, device, dist, torch):
         ok = 0
     okt = torch.tensor([ok], device=dev); dist.all_reduce(okt, op=dist.ReduceOp.MIN)
     if int(okt.item()) == 0:
-        # all ranks must agree on the exchange: rebuild without the peer mapping
-        ctx.close()
+        # all ranks must agree on the exchange: everybody stays on the RCCL all-gathers
         if not comm_id:
+            ctx.close()
             raise RuntimeError("peer-to-peer mapping failed and there is no RCCL communicator")
-        ctx = capi.Ctx(capi.desc_from_config(cfg), device=device, rank=rank, world=world, comm_id=comm_id)
+        if ok:
+            ctx.set_option("use_p2p", 0)
         ctx.exchange = "rccl all-gather"
     else:
         ctx.exchange = "peer-to-peer stores over xGMI + flag round"

@@ -864,6 +864,11 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (k == "use_prefill_mq") c->use_prefill_mq = value;
     else if (k == "attn_split") c->attn_split = value;
     else if (k == "use_qk_mfma") c->use_qk_mfma = value;
+    else if (k == "use_p2p") {     // 0: exchange by RCCL all-gathers although the peers are mapped (needs the communicator); 1: back to peer-to-peer
+        if (value) { for (int r = 0; r < c->world; ++r) if (!c->peer[r]) return fail(c, FLM_ERR_STATE, "use_p2p: flm_p2p_import has not mapped every peer"); }
+        else if (c->world > 1 && !c->comm) return fail(c, FLM_ERR_STATE, "use_p2p 0: no RCCL communicator (comm_id was NULL at create)");
+        c->p2p = value ? 1 : 0;
+    }
     else if (kAblate && k == "ablate") c->ablate = value;              // FLM_ABLATE builds only: a product library cannot skip work
     else if (kAblate && k == "trace") {   // value = kernel class to trace (KC_*), -1 off
         c->trace_class = value;

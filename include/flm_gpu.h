@@ -139,6 +139,7 @@ int  flm_debug_read(flm_ctx* ctx, int what, int layer, float* out, size_t n);
  * "fuse_attn_o" 0 = attention and the Wo GEMV as two launches (default 1: one launch, single GPU),
  * "use_prefill" 0 = feed prompts token by token (default 1: batched), "use_prefill_mq" 0 = batched attention with one query per
  * workgroup (default 1: eight), "attn_split" 0 = one workgroup per head at every context length (default 1: hs / 32 from 128 positions on; n >= 2: always n),
+ * "use_p2p" 0 = tensor-parallel exchanges by RCCL all-gathers even though the peers are mapped (1: peer to peer again),
  * "use_qk_mfma" 0 = prefill attention scores on VALU chains (default 1: v_mfma_f32_16x16x4_f32, the same bits),
  * "use_mfma" 0 = int8 prefill GEMM on v_dot4 instead of the matrix cores (default 1; 2 = matrix cores, 64 x 64 tiles always).
  * None of them changes a result bit.  (Perf-exploration switches that DO skip work -- "ablate", "trace" -- exist only in builds
