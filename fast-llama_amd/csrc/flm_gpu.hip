@@ -566,16 +566,23 @@ int launch_rows(flm_ctx* c, hipStream_t st, const RowsArgs& r, int B) {
     HIPC(c, hipGetLastError());
     return FLM_OK;
 }
-// use_mfma: 0 the v_dot tile kernel, 1 matrix cores (128 x 128 tiles from 768 tokens on), 2 matrix cores, 64 x 64 tiles always
+// use_mfma: 0 the v_dot tile kernel, otherwise the matrix cores (int8: 1 tile shape by size, 2 always 64 x 64, 3 always 128 x 128)
 template <int QT, int EPI>
 int launch_gemm(flm_ctx* c, hipStream_t st, const GemmArgs& g, int use_mfma) {
     const int tiles = ((g.rows + 63) / 64) * ((g.B + 63) / 64);
-    if (QT == QT_INT8 && use_mfma) {   // matrix cores: exact int32 group dots
-        if (g.B >= 768 && use_mfma != 2) {   // 128 x 128 tiles: half the bytes per product through the CU's memory pipeline; pays for long prompts only
-                                              // (measured, 4 layers of 7B width: 1000 tokens 5.99 vs 6.49 ms, 512 tokens 3.33 vs 3.05 ms)
-            const int tiles128 = ((g.rows + 127) / 128) * ((g.B + 127) / 128);
-            hipLaunchKernelGGL((k_gemm_q8_mfma<EPI, 4>), dim3(tiles128), dim3(1024), 0, st, g);
-        } else hipLaunchKernelGGL((k_gemm_q8_mfma<EPI, 2>), dim3(tiles), dim3(256), 0, st, g);
+    if (QT == QT_INT8 && use_mfma) {   // exact int32 group dots on v_mfma_i32_32x32x32_i8
+        using Big = GemmTile<4, 2, 2>; using Small = GemmTile<2, 2, 1>;
+        static bool once = false;
+        if (!once) {   // 128 x 128 tiles stage 76 KiB
+            once = true;
+            HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_q8_mfma<EPI_STORE, 4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Big::kLds));
+            HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_q8_mfma<EPI_RESIDUAL, 4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Big::kLds));
+        }
+        const int tiles128 = ((g.rows + Big::TR - 1) / Big::TR) * ((g.B + Big::TT - 1) / Big::TT);
+        // 128 x 128 tiles move 0.6x the LDS cycles and half the bytes per product; they pay once every CU has one (measured, 7B width:
+        // 512 tokens qkv / ffn13 100.8 vs 115.3 us, Wo / ffn2 (128 tiles) 95.4 vs 65.4; 1000 tokens 171 vs 221 and 110 vs 117)
+        if (use_mfma == 3 || (use_mfma == 1 && tiles128 >= 256)) hipLaunchKernelGGL((k_gemm_q8_mfma<EPI, 4, 2, 2>), dim3(tiles128), dim3(Big::NT), Big::kLds, st, g);
+        else hipLaunchKernelGGL((k_gemm_q8_mfma<EPI, 2, 2, 1>), dim3(tiles), dim3(Small::NT), Small::kLds, st, g);
     }
     else if (QT == QT_INT16 && use_mfma) hipLaunchKernelGGL((k_gemm_q16_mfma<EPI>), dim3(tiles), dim3(256), 0, st, g);   // hi / lo byte planes on the int8 matrix cores
     else hipLaunchKernelGGL((k_gemm_q<QT, EPI>), dim3(tiles), dim3(256), 0, st, g);

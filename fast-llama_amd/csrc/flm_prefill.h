@@ -182,147 +182,140 @@ __global__ void __launch_bounds__(256) k_gemm_q(const GemmArgs a) {
     }
 }
 
-// The int8 GEMM on the matrix cores (gfx950 v_mfma_i32_32x32x32_i8): same 64 x 64 workgroup tile, four waves each owning a
-// 32 x 32 (rows x tokens) quadrant.  Per quant group two MFMAs (K = 2 x 32) accumulate the group's 1024 int32 dots exactly
-// (integer sums are order-free; A and B use the same byte -> k assignment: lane half h takes bytes 32kk + 16h .. +15 of the
-// group); then every lane applies the reference's fp32 chain step to its 16 results -- that VALU work, not the MFMA, is what
-// bounds the kernel.  C/D layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
-// NW = waves per tile side: 2 -> the 64 x 64 tile (256 threads), 4 -> a 128 x 128 tile (1024 threads) for batches of more than 64
-// tokens: a workgroup iteration then loads 16 KB for four times the products (the 64 x 64 tile pulls 8 KB per iteration through a
-// CU's ~30 KB/us memory pipeline, which -- not the VALU -- bounded it at 35 % of the VALU rate).
+// The int8 GEMM on the matrix cores (gfx950 v_mfma_i32_32x32x32_i8): the 64 x 64 workgroup tile of k_gemm_q, four waves each owning
+// 32 tokens x 32 weight rows.  Per quant group two MFMAs (K = 2 x 32) accumulate the group's 1024 int32 dots exactly (integer sums
+// are order-free; A and B use the same byte -> k assignment: lane half h takes bytes 32kk + 16h .. +15 of the group); then every
+// lane applies the reference's fp32 chain step to its 16 results: v_cvt, v_mul, v_fma per output -- 48 VALU instructions per group
+// against 2 MFMAs, so the VALU (and the LDS that feeds it), not the matrix pipe, bounds the kernel.
+// A STAGE is kGPS = 2 consecutive quant groups (128 bytes of every row): one barrier and one pair of LDS buffers per stage.  Inside a
+// stage the groups are consumed in ascending order: the chain is the reference's.
+// Shaped by the counters (profiles/r02_prefill_gemm_pmc.txt): a first version held 190 registers (124 + 64 accumulation registers
+// the compiler parked the MFMA results in, one v_accvgpr_read per element to get them back), so two waves shared a SIMD -- and a
+// wave issues a VALU instruction every ~6.5 cycles at best (tools/ubench/valu_rate.hip: 1.4-1.9 cycles per instruction need four
+// waves per SIMD; scalar fp32 forms overlap the MFMAs completely, packed forms do not): the SIMDs idled 2/3 of the time.
+// Here: <= 128 registers (four waves per SIMD, MFMA results in plain VGPRs), one register slot of prefetch, tokens as the MFMA's
+// A operand so that a lane owns ONE weight row (one weight scale per lane and group, coalesced stores: 32 lanes = 128 contiguous
+// bytes of an output row), one scale load per thread and stage, five adds of address arithmetic per stage.
+// C/D layout: col = lane & 31 (weight row), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (token).
 typedef int v16i __attribute__((ext_vector_type(16)));
-// A STAGE is kGPS = 2 consecutive quant groups (128 bytes of every row): one barrier, one pair of LDS buffers and one ring slot per
-// stage instead of per group -- the loop was bound by the barrier + LDS round trip per group, not by the MFMAs or the chain
-// (round 1: 10 % of the i8 MFMA peak).  Inside a stage the groups are consumed in ascending order: the chain is unchanged.
 constexpr int kGPS = 2;
-template <int EPI, int NW>
-__global__ void __launch_bounds__(64 * NW * NW) k_gemm_q8_mfma(const GemmArgs a) {
-    constexpr int GB = kGroup;                    // bytes of a group in one row (int8)
-    constexpr int SB = kGPS * GB;                 // bytes of a stage in one row
-    constexpr int LS = SB + 16;                   // LDS row stride
-    constexpr int TS = 32 * NW;                   // tile side
-    constexpr int NT = 64 * NW * NW;              // threads
-    __shared__ __attribute__((aligned(16))) char Wt[2][TS * LS];
-    __shared__ __attribute__((aligned(16))) char Xt[2][TS * LS];
-    __shared__ __attribute__((aligned(16))) float sWt[2][kGPS][TS];
-    __shared__ float sXt[2][kGPS][TS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ntt = (a.B + TS - 1) / TS;
-    // token tile fastest: the ntt tiles that share the weight rows are neighbours in the LOGICAL order -- and workgroup b runs on XCD
-    // b mod 8 with its own L2, so the logical order is dealt to the XCDs in contiguous runs: the weight rows are then fetched from HBM
-    // once per XCD that needs them instead of once per token tile
-    const int nb = gridDim.x, per = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7;
+// Tile shapes: WT x WR waves, a wave = 32 tokens x (NB x 32) weight rows (NB fragments of the B operand share one A fragment and
+// one set of activation scales).  <2, 2, 1>: 64 tokens x 64 rows, 256 threads, four workgroups per CU.  <4, 2, 2>: 128 x 128, 512
+// threads, two per CU: per 32 x 32 x 64 products the LDS moves 36 instead of 62 cycles' worth (operand reads 12 / 16, scale reads
+// 10 / 18, stores of the staged tiles 13 / 28) and half the bytes come through the CU's memory pipeline -- and the LDS is what
+// bounds the kernel (removing the chain altogether changed nothing, removing the staging stores and loads halved the time:
+// profiles/r02_prefill_gemm_pmc.txt).
+template <int WT, int WR, int NB>
+struct GemmTile {
+    static constexpr int TT = 32 * WT, TR = 32 * NB * WR, NT = 64 * WT * WR;
+    static constexpr int SB = kGPS * kGroup;      // bytes of a stage in one row
+    static constexpr int LS = SB + 16;            // LDS row stride (conflict-free 16-byte reads of 16 consecutive rows)
+    static constexpr int kOffX = TR * LS, kOffS = (TR + TT) * LS, kBuf = kOffS + kGPS * (TR + TT) * 4;   // W rows | X rows | scales [W g0][W g1][X g0][X g1]
+    static constexpr int NPW = TR * 8 / NT, NPX = TT * 8 / NT;      // 16-byte pieces per thread and stage
+    static constexpr int kLds = 2 * kBuf;
+    static_assert(kGPS == 2 && NT == kGPS * (TR + TT) && TR % 64 == 0 && TT % 64 == 0, "one scale per thread and stage, wave-uniform (matrix, group)");
+    static_assert(TR * 8 % NT == 0 && TT * 8 % NT == 0, "whole pieces per thread");
+};
+template <int EPI, int WT, int WR, int NB>
+__global__ void __launch_bounds__(64 * WT * WR, 4) k_gemm_q8_mfma(const GemmArgs a) {
+    using G = GemmTile<WT, WR, NB>;
+    constexpr int SB = G::SB, LS = G::LS, TT = G::TT, TR = G::TR, NT = G::NT, kOffX = G::kOffX, kOffS = G::kOffS, kBuf = G::kBuf, NPW = G::NPW, NPX = G::NPX;
+    extern __shared__ __attribute__((aligned(16))) char lds[]; char* const sm = lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntt = (a.B + TT - 1) / TT;
+    const int nb = gridDim.x, per = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7;              // tiles dealt to the XCDs in contiguous runs (see k_gemm_q)
     const int tile = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
-    const int r0 = (tile / ntt) * TS, b0 = (tile % ntt) * TS;
-    const int wr0 = (wave / NW) * 32, wc0 = (wave % NW) * 32;               // this wave's 32 x 32 inside the tile
-    const int sn = a.n / kGroup, nst = (sn + kGPS - 1) / kGPS;               // groups, stages
-    const size_t rowbytes = (size_t)a.n;
-    const char* Wb = reinterpret_cast<const char*>(a.W);
-    const char* Xb = reinterpret_cast<const char*>(a.Xq);
-    // A stage takes ~0.2 us, a global load ~1-2 us: the loads run kPF stages ahead through a register ring
-    constexpr int kPF = NW == 4 ? 1 : 2;          // (the 16-wave tile has 128 registers per lane: a second slot spills)
-    // loader: TS rows x 8 pieces of 16 B per matrix and stage.  NW == 2: every thread loads two pieces of each matrix;
-    // NW == 4: threads 0..511 load two weight pieces, 512..1023 two activation pieces
-    constexpr bool kSplit = NW == 4;
-    const bool ldw = !kSplit || tid < NT / 2, ldx = !kSplit || tid >= NT / 2;
-    const int lt = kSplit ? (tid & (NT / 2 - 1)) : tid;
-    constexpr int NL = kSplit ? NT / 2 : NT;      // loader threads per matrix; TS * 8 pieces / NL = 2 pieces per thread
-    int lrow[2], lch[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) { const int idx = lt + k * NL; lrow[k] = idx >> 3; lch[k] = idx & 7; }
-    v4i wr[kPF][2], xr[kPF][kSplit ? 1 : 2]; float sr[kPF][kGPS];
-    // branch-free raw buffer loads (pieces outside the matrix / past the last group get an out-of-range offset and read as zero):
-    // with the loads under control flow the compiler waited for vmcnt(0) in every iteration, i.e. for the load it had just issued
+    const int r0 = (tile / ntt) * TR, b0 = (tile % ntt) * TT;
+    const int sn = a.n / kGroup, nst = (sn + kGPS - 1) / kGPS;
+    const unsigned rowbytes = (unsigned)a.n;
     constexpr unsigned kOOB = 0x80000000u;
-    const unsigned nW = (unsigned)a.rows * (unsigned)rowbytes, nX = (unsigned)a.B * (unsigned)rowbytes;
-    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Wb), 0, (int)nW, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Xb), 0, (int)nX, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rSW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.sW), 0, (int)((unsigned)a.rows * sn * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rSX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Xs), 0, (int)((unsigned)a.B * sn * 4), 0x00020000);
-    unsigned woff[2], xoff[2];
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, (int)((unsigned)a.rows * rowbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.Xq), 0, (int)((unsigned)a.B * rowbytes), 0x00020000);
+    // loader: piece k of a thread = 16 bytes at (row (tid >> 3) + (NT / 8) k, chunk tid & 7); rows outside a matrix read as zero
+    const int prow = tid >> 3, pch = tid & 7;
+    unsigned woff[NPW], xoff[NPX];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        woff[k] = (ldw && r0 + lrow[k] < a.rows) ? (unsigned)(r0 + lrow[k]) * (unsigned)rowbytes + lch[k] * 16 : kOOB;
-        xoff[k] = (ldx && b0 + lrow[k] < a.B)    ? (unsigned)(b0 + lrow[k]) * (unsigned)rowbytes + lch[k] * 16 : kOOB;
-    }
-    const bool s_w = tid < TS, s_x = tid >= TS && tid < 2 * TS;
-    const unsigned swoff = (s_w && r0 + tid < a.rows) ? (unsigned)(r0 + tid) * sn * 4 : kOOB;
-    const unsigned sxoff = (s_x && b0 + tid - TS < a.B) ? (unsigned)(b0 + tid - TS) * sn * 4 : kOOB;
-    auto fetch = [&](int st, int slot) {
+    for (int k = 0; k < NPW; ++k) woff[k] = (r0 + prow + (NT / 8) * k < a.rows) ? (unsigned)(r0 + prow + (NT / 8) * k) * rowbytes + pch * 16 : kOOB;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            // a piece's group: st * kGPS + (lch >> 2); bytes past the row's end (an odd group count's last half stage) read as zero
-            const bool in = st * kGPS + (lch[k] >> 2) < sn;
-            const unsigned wo = (in && woff[k] != kOOB) ? woff[k] + (unsigned)st * SB : kOOB, xo = (in && xoff[k] != kOOB) ? xoff[k] + (unsigned)st * SB : kOOB;
-            const v4u w = __builtin_amdgcn_raw_buffer_load_b128(rW, (int)wo, 0, 0);
-            const v4u x = __builtin_amdgcn_raw_buffer_load_b128(rX, (int)xo, 0, 0);
-            if constexpr (kSplit) wr[slot][k] = __builtin_bit_cast(v4i, ldw ? w : x);       // one register per piece: a weight piece or an activation piece (the other load is out of range)
-            else { wr[slot][k] = __builtin_bit_cast(v4i, w); xr[slot][k] = __builtin_bit_cast(v4i, x); }
-        }
+    for (int k = 0; k < NPX; ++k) xoff[k] = (b0 + prow + (NT / 8) * k < a.B) ? (unsigned)(b0 + prow + (NT / 8) * k) * rowbytes + pch * 16 : kOOB;
+    const unsigned poff = (unsigned)(prow * LS + pch * 16);
+    // scales: thread -> one slot of [W g0 (TR)][W g1 (TR)][X g0 (TT)][X g1 (TT)]; (matrix, group) is the same for a whole wave.
+    // A group past the end (odd group count) gets scale zero: fma(0 * sx, float(d), acc) = acc (acc is never -0).
+    const int s_slot = wave * 64;
+    const bool s_x = s_slot >= kGPS * TR;
+    const int s_gi = s_x ? (s_slot - kGPS * TR) / TT : s_slot / TR;
+    const int s_row = (s_x ? b0 + (s_slot - kGPS * TR) % TT : r0 + s_slot % TR) + lane, s_rows = s_x ? a.B : a.rows;
+    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s_x ? a.Xs : a.sW), 0, (int)((unsigned)s_rows * sn * 4), 0x00020000);
+    unsigned soff = s_row < s_rows ? ((unsigned)s_row * sn + s_gi) * 4 : kOOB;
+    const unsigned spoff = (unsigned)(kOffS + tid * 4);
+    v4u wr[NPW], xr[NPX]; unsigned sr;
+    auto fetch = [&](int st) {                    // stage st -> the register slot (stages past the end: the offsets have run past the rows; never consumed with a non-zero scale)
 #pragma unroll
-        for (int gi = 0; gi < kGPS; ++gi) {
-            const int g = st * kGPS + gi;
-            const unsigned so = (g < sn && swoff != kOOB) ? swoff + (unsigned)g * 4 : kOOB, sxo = (g < sn && sxoff != kOOB) ? sxoff + (unsigned)g * 4 : kOOB;
-            sr[slot][gi] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rSW, (int)so, 0, 0) | __builtin_amdgcn_raw_buffer_load_b32(rSX, (int)sxo, 0, 0));
-        }
+        for (int k = 0; k < NPW; ++k) { wr[k] = __builtin_amdgcn_raw_buffer_load_b128(rW, (int)woff[k], 0, 0); woff[k] += SB; }
+#pragma unroll
+        for (int k = 0; k < NPX; ++k) { xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rX, (int)xoff[k], 0, 0); xoff[k] += SB; }
+        sr = __builtin_amdgcn_raw_buffer_load_b32(rS, (int)(st * kGPS + s_gi < sn ? soff : kOOB), 0, 0); soff += kGPS * 4;
     };
-    auto park = [&](int buf, int slot) {
+    auto park = [&](int buf) {
+        char* base = sm + buf * kBuf;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if constexpr (kSplit) {
-                char* dst = ldw ? &Wt[buf][lrow[k] * LS + lch[k] * 16] : &Xt[buf][lrow[k] * LS + lch[k] * 16];
-                *reinterpret_cast<v4i*>(dst) = wr[slot][k];
-            } else {
-                *reinterpret_cast<v4i*>(&Wt[buf][lrow[k] * LS + lch[k] * 16]) = wr[slot][k];
-                *reinterpret_cast<v4i*>(&Xt[buf][lrow[k] * LS + lch[k] * 16]) = xr[slot][k];
-            }
-        }
+        for (int k = 0; k < NPW; ++k) *reinterpret_cast<v4u*>(base + poff + k * (NT / 8) * LS) = wr[k];
 #pragma unroll
-        for (int gi = 0; gi < kGPS; ++gi) { if (tid < TS) sWt[buf][gi][tid] = sr[slot][gi]; else if (tid < 2 * TS) sXt[buf][gi][tid - TS] = sr[slot][gi]; }
+        for (int k = 0; k < NPX; ++k) *reinterpret_cast<v4u*>(base + kOffX + poff + k * (NT / 8) * LS) = xr[k];
+        *reinterpret_cast<unsigned*>(base + spoff) = sr;
     };
-    float acc[16];
+    // this wave's 32 tokens x (NB x 32) weight rows
+    const int wt0 = (wave % WT) * 32, wr0 = (wave / WT) * 32 * NB, l31 = lane & 31, h = lane >> 5;
+    const unsigned offA = (unsigned)(kOffX + (wt0 + l31) * LS + h * 16), offB = (unsigned)((wr0 + l31) * LS + h * 16);
+    const unsigned offsw = (unsigned)(kOffS + (wr0 + l31) * 4), offsx = (unsigned)(kOffS + (kGPS * TR + wt0 + 4 * h) * 4);
+    float acc[NB][16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const int am = wr0 + (lane & 31), bn = wc0 + (lane & 31), kh = (lane >> 5) * 16;
+    for (int j = 0; j < NB; ++j)
 #pragma unroll
-    for (int u = 0; u < kPF; ++u) fetch(u, u);
-    park(0, 0);
-    fetch(kPF, 0);
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    fetch(0); park(0); fetch(1);
     __syncthreads();
-    auto step = [&](int st, int next_slot) {                                // stage st is in LDS buffer st & 1; stage st + 1 waits in ring slot next_slot
-        const int buf = st & 1;
+    for (int st = 0; st < nst; ++st) {
+        const char* base = sm + (st & 1) * kBuf;
 #pragma unroll
         for (int gi = 0; gi < kGPS; ++gi) {
-            const v4i a0 = *reinterpret_cast<const v4i*>(&Wt[buf][am * LS + gi * GB + kh]), a1 = *reinterpret_cast<const v4i*>(&Wt[buf][am * LS + gi * GB + 32 + kh]);
-            const v4i x0 = *reinterpret_cast<const v4i*>(&Xt[buf][bn * LS + gi * GB + kh]), x1 = *reinterpret_cast<const v4i*>(&Xt[buf][bn * LS + gi * GB + 32 + kh]);
-            v16i d = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            d = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, x0, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, x1, d, 0, 0, 0);
-            const float sx = sXt[buf][gi][bn];
+            const v4i a0 = *reinterpret_cast<const v4i*>(base + offA + gi * kGroup), a1 = *reinterpret_cast<const v4i*>(base + offA + gi * kGroup + 32);
+            float4 sx[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 sw = *reinterpret_cast<const float4*>(&sWt[buf][gi][wr0 + 8 * q + 4 * (lane >> 5)]);
-                acc[4 * q + 0] = __fmaf_rn(__fmul_rn(sw.x, sx), (float)d[4 * q + 0], acc[4 * q + 0]);   // quant_operators.cpp:274
-                acc[4 * q + 1] = __fmaf_rn(__fmul_rn(sw.y, sx), (float)d[4 * q + 1], acc[4 * q + 1]);
-                acc[4 * q + 2] = __fmaf_rn(__fmul_rn(sw.z, sx), (float)d[4 * q + 2], acc[4 * q + 2]);
-                acc[4 * q + 3] = __fmaf_rn(__fmul_rn(sw.w, sx), (float)d[4 * q + 3], acc[4 * q + 3]);
+            for (int q = 0; q < 4; ++q) sx[q] = *reinterpret_cast<const float4*>(base + offsx + gi * TT * 4 + q * 32);
+            v16i d[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const v4i b0v = *reinterpret_cast<const v4i*>(base + offB + j * 32 * LS + gi * kGroup), b1v = *reinterpret_cast<const v4i*>(base + offB + j * 32 * LS + gi * kGroup + 32);
+                const v16i z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                d[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0v, z, 0, 0, 0);
+                d[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1v, d[j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const float sw = *reinterpret_cast<const float*>(base + offsw + (gi * TR + j * 32) * 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[j][4 * q + 0] = __fmaf_rn(__fmul_rn(sw, sx[q].x), (float)d[j][4 * q + 0], acc[j][4 * q + 0]);   // quant_operators.cpp:274
+                    acc[j][4 * q + 1] = __fmaf_rn(__fmul_rn(sw, sx[q].y), (float)d[j][4 * q + 1], acc[j][4 * q + 1]);
+                    acc[j][4 * q + 2] = __fmaf_rn(__fmul_rn(sw, sx[q].z), (float)d[j][4 * q + 2], acc[j][4 * q + 2]);
+                    acc[j][4 * q + 3] = __fmaf_rn(__fmul_rn(sw, sx[q].w), (float)d[j][4 * q + 3], acc[j][4 * q + 3]);
+                }
             }
         }
-        park(buf ^ 1, next_slot); fetch(st + 1 + kPF, next_slot);          // unconditional (stages past the end are zeros): under a branch the
-        __syncthreads();                                                    // compiler loses count of the loads in flight and waits for all of them
-    };
-    // ring slots are compile-time indices; the stage count is rounded up to a multiple of kPF -- a group past the end contributes
-    // fma(0, 0, acc) = acc (acc is never -0: it starts at +0 and every product s * float(dot) with dot == 0 is +0)
-    if constexpr (kPF == 2) { for (int st = 0; st < nst; st += 2) { step(st, 1); step(st + 1, 0); } }
-    else                    { for (int st = 0; st < nst; ++st) step(st, 0); }
-    const int b = b0 + bn;
-    if (b < a.B) {
+        park((st & 1) ^ 1); fetch(st + 2);        // unconditional: a stage past the end is parked and never read with a non-zero scale
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int row = r0 + wr0 + j * 32 + l31;
+        if (row >= a.rows) continue;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int row = r0 + wr0 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-            if (row >= a.rows) continue;
+            const int b = b0 + wt0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (b >= a.B) continue;
             float* o = a.out + (size_t)b * a.ldo + row;
-            if constexpr (EPI == EPI_RESIDUAL) *o = __fadd_rn(*o, acc[i]); else *o = acc[i];
+            if constexpr (EPI == EPI_RESIDUAL) *o = __fadd_rn(*o, acc[j][i]); else *o = acc[j][i];
         }
     }
 }
