@@ -680,6 +680,127 @@ __global__ void __launch_bounds__(256) k_qk_mfma(const AttnArgs a, int pos0, int
         }
     }
 }
+// ------------------------------------------------------------------------------------------
+// Prefill softmax + weighted sum with the weighted sum on the matrix cores (v_mfma_f32_16x16x4_f32), BIT-IDENTICAL to attn_head:
+//     o[q][d] = V[0][d] * w[q][0], then o = fma(V[t][d], w[q][t], o) for t = 1, 2, ... ascending, rows with |w| <= 1e-15 skipped
+//                                                                                  (tf_operators.cpp:325-350, transformer.cpp:449)
+// An f32 MFMA is a k-ordered fmaf chain into its accumulator, so with A = the weights (row = query, k-slot = position) and B = V
+// (k-slot = position, column = output dimension) one accumulator element IS the reference's chain of one (query, dimension):
+//   * the first row by multiplication:  the accumulator starts at -0.0f, and fma(w, v, -0) == w * v for every w, v (signed zeros
+//     included);
+//   * a skipped row, and a row the query does not see (causal; the 16 queries of a tile end at 16 different positions), has weight
+//     +0: fma(0, v, o) == o for finite v, unless o == -0 (possible only while every earlier product was a zero: the sign of an exact
+//     zero output can differ from the reference's; no value downstream can see it -- the quantizer maps both zeros to 0);
+//   * V rows past the tile's last position are never loaded (out-of-range buffer offsets read as zero), so no stale cache content
+//     meets a zero weight.
+// Workgroup (256 threads) = one head x 16 queries.  Scores come from k_qk_mfma (sc_global).  Softmax on the VALU as in
+// attn_prefill_mq (max order-free; expf_ref; the sum t ascending: lane q of wave 0 = query q, rows the query does not see add +0;
+// divide; skip rule), the weights land in LDS permuted inside blocks of 16 positions so that the A operand of four consecutive
+// MFMAs is one 16-byte read.  Weighted sum: wave w owns 32 output dimensions = 2 accumulators (column li <-> dimensions
+// 32 w + 2 li and + 1: ONE 8-byte load per lane and 4 positions, 128 contiguous bytes per V row and wave); V never touches LDS,
+// it is prefetched kPvRing blocks (16 positions each) ahead into registers.
+// ------------------------------------------------------------------------------------------
+constexpr int kPvQ = 16, kPvRing = 4;
+__host__ __device__ inline int pv_row_stride(int tmax) { return ((((tmax + 15) & ~15) + 63) & ~63) + 4; }     // floats; = 4 mod 64: conflict-free 16-byte reads of 16 rows
+__host__ inline size_t pv_mfma_lds_bytes(int tmax) { return ((size_t)kPvQ * pv_row_stride(tmax) + 16) * 4; }
+__global__ void __launch_bounds__(256) k_attn_pv_mfma(const AttnArgs a, int pos0, int row_stride, int B) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int hs = a.hs, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, q0 = blockIdx.y * kPvQ, nq = B - q0 < kPvQ ? B - q0 : kPvQ;
+    const int S = pv_row_stride(pos0 + B);
+    float* E = reinterpret_cast<float*>(lds);                    // [16][S]
+    float* sums = E + kPvQ * S;                                  // [16]
+    const int Tmax = pos0 + q0 + nq, Tp = (Tmax + 15) & ~15, nblk = Tp >> 4;
+    // ---- scores -> LDS, max, exp: 16 lanes per query (wave w: queries 4w .. 4w+3), 4 consecutive positions per lane and round
+    {
+        const int q = 4 * wave + (lane >> 4), l16 = lane & 15;
+        const int Tq = q < nq ? pos0 + q0 + q + 1 : 0;
+        const float* src = a.sc_global + ((size_t)h * B + (q0 + (q < nq ? q : 0))) * a.max_seq;
+        float* row = E + q * S;
+        float m = -INFINITY;
+        for (int t = l16 * 4; t < Tp; t += 64) {
+            float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            if (t + 3 < Tq) v = *reinterpret_cast<const float4*>(src + t);
+            else { if (t < Tq) v.x = src[t]; if (t + 1 < Tq) v.y = src[t + 1]; if (t + 2 < Tq) v.z = src[t + 2]; }
+            *reinterpret_cast<float4*>(row + t) = v;
+            m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+        }
+        m = row16_max(m);
+        for (int t = l16 * 4; t < Tp; t += 64) {                 // (each lane re-reads what it wrote)
+            float4 v = *reinterpret_cast<const float4*>(row + t);
+            v.x = t < Tq ? expf_ref(__fsub_rn(v.x, m)) : 0.f; v.y = t + 1 < Tq ? expf_ref(__fsub_rn(v.y, m)) : 0.f;
+            v.z = t + 2 < Tq ? expf_ref(__fsub_rn(v.z, m)) : 0.f; v.w = t + 3 < Tq ? expf_ref(__fsub_rn(v.w, m)) : 0.f;
+            *reinterpret_cast<float4*>(row + t) = v;
+        }
+    }
+    __syncthreads();
+    // ---- the sums: lane q of wave 0, t ascending (tf_operators.cpp:180-183); positions past a query's own add +0
+    if (tid < kPvQ) {
+        const float4* r4 = reinterpret_cast<const float4*>(E + tid * S);
+        float sum = 0.f;
+#pragma unroll 4
+        for (int i = 0; i < Tp / 4; ++i) { const float4 v = r4[i]; sum = __fadd_rn(sum, v.x); sum = __fadd_rn(sum, v.y); sum = __fadd_rn(sum, v.z); sum = __fadd_rn(sum, v.w); }
+        sums[tid] = sum;
+    }
+    __syncthreads();
+    // ---- weights: divide, skip rule, permute inside the block of 16 positions: float4 c of a block = positions c, 4 + c, 8 + c, 12 + c
+    for (int bidx = tid; bidx < kPvQ * nblk; bidx += 256) {
+        const int q = bidx / nblk, bi = bidx - q * nblk;
+        float* blk = E + q * S + bi * 16;
+        const float sum = sums[q];
+        float w[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float4 v = *reinterpret_cast<const float4*>(blk + 4 * i); w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float x = q < nq ? __fdiv_rn(w[i], sum) : 0.f;
+            w[i] = (bi * 16 + i > 0 && fabsf(x) <= 1e-15f) ? 0.f : x;           // rows t >= 1 with |att| <= 1e-15 are skipped (transformer.cpp:449)
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *reinterpret_cast<float4*>(blk + 4 * c) = make_float4(w[c], w[4 + c], w[8 + c], w[12 + c]);
+    }
+    __syncthreads();
+    // ---- weighted sum on the matrix cores
+    const int li = lane & 15, c = lane >> 4, d0 = 32 * wave + 2 * li;
+    if (32 * wave >= hs) return;                                  // (hs <= 96: the last waves have no dimensions)
+    const float* V = a.vcache + (size_t)h * a.max_seq * hs;
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V), 0, Tmax * hs * 4, 0x00020000);
+    unsigned voff = d0 < hs ? (unsigned)((c * hs + d0) * 4) : 0x80000000u;      // position c of block 0; + 16 hs bytes per step
+    const unsigned vstep = (unsigned)(4 * hs * 4);
+    v2f ring[kPvRing][4];
+    auto request = [&](v2f (&r)[4]) {
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) { r[sp] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rV, (int)voff, 0, 0)); voff += vstep; }
+    };
+#pragma unroll
+    for (int r = 0; r < kPvRing; ++r) request(ring[r]);
+    v4f acc0 = {-0.f, -0.f, -0.f, -0.f}, acc1 = {-0.f, -0.f, -0.f, -0.f};
+    const float* ap = E + li * S + 4 * c;
+    for (int b0 = 0; b0 < nblk; b0 += kPvRing) {
+#pragma unroll
+        for (int r = 0; r < kPvRing; ++r) {
+            if (b0 + r < nblk) {                                  // (wave-uniform)
+                const float4 av = *reinterpret_cast<const float4*>(ap + (b0 + r) * 16);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, ring[r][0].x, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, ring[r][0].y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, ring[r][1].x, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, ring[r][1].y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, ring[r][2].x, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, ring[r][2].y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, ring[r][3].x, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, ring[r][3].y, acc1, 0, 0, 0);
+            }
+            request(ring[r]);                                     // block b0 + r + kPvRing (past the tile's last position: zeros)
+        }
+    }
+    // D layout: column li (dimensions d0, d0 + 1), row (query) = 4 c + reg
+    if (d0 < hs) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int q = 4 * c + reg;
+            if (q < nq) *reinterpret_cast<float2*>(a.out + (size_t)(q0 + q) * row_stride + (size_t)h * hs + d0) = make_float2(acc0[reg], acc1[reg]);
+        }
+    }
+}
+
 // grid = heads * G (G = a.G >= 1 parts per head; all of them resident: the parts wait for each other's scores)
 template <bool SPLIT>
 __global__ void __launch_bounds__(kAttnBlock) k_attn_decode(const AttnArgs a) {

@@ -70,6 +70,7 @@ struct flm_ctx {
     int pf_cap = 0;                                    // token capacity of the batched-prefill buffers below
     float *pf_x = nullptr, *pf_qkv = nullptr, *pf_q = nullptr, *pf_att = nullptr, *pf_gu = nullptr, *pf_hd = nullptr, *pf_xs = nullptr; void* pf_xq = nullptr;
     int use_prefill_mq = 1;                            // option "use_prefill_mq": batched prefill attention with 8 queries per workgroup (0: one query per workgroup)
+    int use_pv_mfma = 1;                               // option "use_pv_mfma": prefill weighted sum (softmax x V) on the matrix cores as well (needs use_qk_mfma), 0: VALU chains
     int use_qk_mfma = 1;                               // option "use_qk_mfma": prefill scores on the matrix cores (fp32 MFMA, bit-identical), 0: VALU chains inside the attention kernel
     float* pf_scores = nullptr;                        // [heads][max_seq][max_seq] prefill scores (k_qk_mfma -> k_attn_prefill_mq<true>)
     int fuse_attn_o = 1;                               // option "fuse_attn_o": attention + Wo GEMV in one launch (k_attn_o; single GPU)
@@ -618,7 +619,10 @@ int prefill_batched(flm_ctx* c, int B, int pos) {
             aa.sc_global = c->pf_scores;
             hipLaunchKernelGGL(k_qk_mfma, dim3(c->heads_local, (B + kQkQ - 1) / kQkQ), dim3(256), qk_mfma_lds_bytes(hs), st, aa, pos, dim, B);
             HIPC(c, hipGetLastError());
-            hipLaunchKernelGGL(k_attn_prefill_mq<true>, dim3(c->heads_local, (B + kMqQueries - 1) / kMqQueries), dim3(kAttnBlock), attn_mq_lds_bytes(d.max_seq_len, hs), st, aa, pos, dim, B);
+            if (c->use_pv_mfma && (hs & 1) == 0)   // ... and the weighted sum too (an accumulator element = the reference's chain of one (query, dimension))
+                hipLaunchKernelGGL(k_attn_pv_mfma, dim3(c->heads_local, (B + kPvQ - 1) / kPvQ), dim3(256), pv_mfma_lds_bytes(pos + B), st, aa, pos, dim, B);
+            else
+                hipLaunchKernelGGL(k_attn_prefill_mq<true>, dim3(c->heads_local, (B + kMqQueries - 1) / kMqQueries), dim3(kAttnBlock), attn_mq_lds_bytes(d.max_seq_len, hs), st, aa, pos, dim, B);
         }
         else if (hs <= 128 && c->use_prefill_mq)      // kMqQueries queries per workgroup share every K/V tile
             hipLaunchKernelGGL(k_attn_prefill_mq<false>, dim3(c->heads_local, (B + kMqQueries - 1) / kMqQueries), dim3(kAttnBlock), attn_mq_lds_bytes(d.max_seq_len, hs), st, aa, pos, dim, B);
@@ -867,6 +871,7 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (k == "use_graph") c->use_graph = value;
     else if (k == "use_prefill") c->use_prefill = value;
     else if (k == "use_mfma") c->use_mfma = value;
+    else if (k == "use_pv_mfma") c->use_pv_mfma = value;
     else if (k == "fuse_attn_o") c->fuse_attn_o = value;
     else if (k == "use_prefill_mq") c->use_prefill_mq = value;
     else if (k == "attn_split") c->attn_split = value;

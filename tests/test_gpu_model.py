@@ -137,24 +137,28 @@ def test_batched_prefill_is_bit_identical_to_token_by_token(gpu, shape, qt, laye
     assert bits_equal(outs[1][0], om.forward(prompt, 0))
 
 
-@pytest.mark.parametrize("shape,qt,n", [("small", ff.QT_INT8, 200), ("tiny128", ff.QT_INT8, 90), ("tiny", ff.QT_INT16, 333)])
-def test_prefill_scores_on_fp32_mfma_are_the_valu_bits(gpu, shape, qt, n):
+@pytest.mark.parametrize("shape,qt,n", [("small", ff.QT_INT8, 200), ("tiny128", ff.QT_INT8, 90), ("tiny", ff.QT_INT16, 333),
+                                        ((256, 512, 2, 8, 320), ff.QT_INT8, 130), ((384, 768, 2, 4, 320), ff.QT_INT8, 77), ("tiny128", ff.QT_INT8, 1000)])
+def test_prefill_attention_on_fp32_mfma_is_the_valu_bits(gpu, shape, qt, n):
     """QK^T of the batched prefill on v_mfma_f32_16x16x4_f32 (eight accumulators = the reference's eight strided lanes, head dimension
-    permuted into the k-slots) against the VALU chains: same cache rows, same logits, and both equal to the oracle.  If an f32 MFMA
-    were not a k-ordered fmaf chain on this GPU (MI355X_MICROARCH / cdna_hip_programming say it is) this is the test that fails."""
+    permuted into the k-slots) and the weighted sum on the same instruction (an accumulator element = the chain of one (query,
+    dimension), first row by multiplication = an accumulator that starts at -0) against the VALU chains: same cache rows, same logits,
+    all equal to the oracle.  Head sizes 32, 64, 96, 128.  If an f32 MFMA were not a k-ordered fmaf chain on this GPU
+    (MI355X_MICROARCH / cdna_hip_programming say it is) this is the test that fails."""
     cfg = synth.make_config(shape, qt)
     tensors = synth.make_tensors(cfg, seed=17)
     prompt = _prompt(cfg.vocab_size, n)
     res = []
-    for mfma in (1, 0):
+    for qk, pv in ((1, 1), (1, 0), (0, 0)):
         ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
-        ctx.set_option("use_qk_mfma", mfma)
+        ctx.set_option("use_qk_mfma", qk); ctx.set_option("use_pv_mfma", pv)
         lg = ctx.forward(prompt[:7], 0)
         lg = ctx.forward(prompt[7:], 7)                       # a batch that starts at a non-zero position
-        att = ctx.debug_read("vcache", cfg.n_layers - 1, cfg.n_heads * cfg.max_length * cfg.head_size)
-        res.append((lg.copy(), att.copy()))
+        kv = [ctx.debug_read(w, cfg.n_layers - 1, cfg.n_heads * cfg.max_length * cfg.head_size).copy() for w in ("kcache", "vcache")]
+        res.append((lg.copy(), kv))
         ctx.close()
-    assert bits_equal(res[0][0], res[1][0]) and bits_equal(res[0][1], res[1][1])
+    for r in res[1:]:
+        assert bits_equal(res[0][0], r[0]) and bits_equal(res[0][1][0], r[1][0]) and bits_equal(res[0][1][1], r[1][1])
     assert bits_equal(res[0][0], O.OracleModel(cfg, tensors).forward(prompt, 0))
 
 
