@@ -585,7 +585,7 @@ int launch_gemm(flm_ctx* c, hipStream_t st, const GemmArgs& g, int use_mfma) {
         if (use_mfma == 3 || (use_mfma == 1 && tiles128 >= 256)) hipLaunchKernelGGL((k_gemm_q8_mfma<EPI, 4, 2, 2>), dim3(tiles128), dim3(Big::NT), Big::kLds, st, g);
         else hipLaunchKernelGGL((k_gemm_q8_mfma<EPI, 2, 2, 1>), dim3(tiles), dim3(Small::NT), Small::kLds, st, g);
     }
-    else if (QT == QT_INT16 && use_mfma) hipLaunchKernelGGL((k_gemm_q16_mfma<EPI>), dim3(tiles), dim3(256), 0, st, g);   // hi / lo byte planes on the int8 matrix cores
+    else if (QT == QT_INT16 && use_mfma) hipLaunchKernelGGL((k_gemm_q16_mfma<EPI>), dim3(tiles), dim3(256), Gemm16Tile::kLds, st, g);   // hi / lo byte planes on the int8 matrix cores
     else hipLaunchKernelGGL((k_gemm_q<QT, EPI>), dim3(tiles), dim3(256), 0, st, g);
     HIPC(c, hipGetLastError());
     return FLM_OK;

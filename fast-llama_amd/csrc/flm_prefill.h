@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(64 * WT * WR, 4) k_gemm_q8_mfma(const GemmArgs
 // accumulations S (each exact in int32; the combination wraps mod 2^32 on the way and lands on the true value, which the reference
 // also holds in an int32: 64 * 5792^2 < 2^31, x86_simd.cpp:1524-1552).  Eight v_mfma_i32_32x32x32_i8 per group and wave replace 1024
 // v_dot2 per lane-quadrant of k_gemm_q; the fp32 chain step per group is unchanged (quant_operators.cpp:274).  The split happens
-// once per 16-byte piece when it is parked in LDS (byte planes lo / hi per row), 64 x 64 tile, four waves x 32 x 32.
+// once per 16-byte piece when it is parked in LDS (byte planes lo / hi per row).
 __device__ __forceinline__ void split16(const v4i& v, unsigned (&lo)[2], unsigned (&hi)[2]) {
     const unsigned w0 = (unsigned)v.x, w1 = (unsigned)v.y, w2 = (unsigned)v.z, w3 = (unsigned)v.w;
     lo[0] = __builtin_amdgcn_perm(w1, w0, 0x06040200u); lo[1] = __builtin_amdgcn_perm(w3, w2, 0x06040200u);      // bytes 0, 2 of w0 then of w1
@@ -336,107 +336,111 @@ __device__ __forceinline__ void split16(const v4i& v, unsigned (&lo)[2], unsigne
     hi[0] = ((h0 & 0x7f7f7f7fu) + c0) ^ (h0 & 0x80808080u);
     hi[1] = ((h1 & 0x7f7f7f7fu) + c1) ^ (h1 & 0x80808080u);
 }
+// Built like k_gemm_q8_mfma (64 tokens x 64 rows, four waves of 32 x 32, tokens as the A operand, results in VGPRs, one register
+// slot of prefetch, one scale per thread) with a stage of ONE group (128 bytes of a row = two byte planes of 64): 42 KB of LDS,
+// three workgroups per CU.  The four partial sums share ONE accumulator: d = S(hh); d <<= 8; d += S(hl) + S(lh); d <<= 8; d += S(ll)
+// (the shifts between the MFMAs; everything mod 2^32) -- 16 registers instead of 48.
+struct Gemm16Tile {
+    static constexpr int TS = 64, LS = kGroup + 16;                           // tile side; LDS row stride of a byte plane
+    static constexpr int kPlane = TS * LS, kOffS = 4 * kPlane, kBuf = kOffS + 2 * TS * 4;   // W lo | W hi | X lo | X hi | scales [W][X]
+    static constexpr int kLds = 2 * kBuf;
+};
 template <int EPI>
-__global__ void __launch_bounds__(256) k_gemm_q16_mfma(const GemmArgs a) {
-    constexpr int GB = kGroup * 2;                // bytes of a group in one row (int16)
-    constexpr int LS = kGroup + 16;               // LDS row stride of a byte plane
-    constexpr int TS = 64;
-    __shared__ __attribute__((aligned(16))) char WL[2][TS * LS], WH[2][TS * LS], XL[2][TS * LS], XH[2][TS * LS];
-    __shared__ __attribute__((aligned(16))) float sWt[2][TS];
-    __shared__ float sXt[2][TS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ void __launch_bounds__(256, 3) k_gemm_q16_mfma(const GemmArgs a) {
+    using G = Gemm16Tile;
+    constexpr int GB = kGroup * 2, LS = G::LS, TS = G::TS, kPlane = G::kPlane, kOffS = G::kOffS, kBuf = G::kBuf;
+    extern __shared__ __attribute__((aligned(16))) char lds[]; char* const sm = lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntt = (a.B + TS - 1) / TS;
-    const int nb = gridDim.x, per = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7;              // tiles dealt to the XCDs in contiguous runs (as k_gemm_q8_mfma)
+    const int nb = gridDim.x, per = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7;              // tiles dealt to the XCDs in contiguous runs (see k_gemm_q)
     const int tile = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
     const int r0 = (tile / ntt) * TS, b0 = (tile % ntt) * TS;
-    const int wr0 = (wave / 2) * 32, wc0 = (wave % 2) * 32;
     const int sn = a.n / kGroup;
-    const size_t rowbytes = (size_t)a.n * 2;
-    constexpr int kPF = 2;                        // groups in flight through the register ring (2 x 4 pieces of 16 bytes per thread)
-    // loader: 64 rows x 8 pieces of 16 B per matrix and group; thread -> pieces tid and tid + 256 of each
+    const unsigned rowbytes = (unsigned)a.n * 2;
     constexpr unsigned kOOB = 0x80000000u;
-    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, (int)((unsigned)a.rows * (unsigned)rowbytes), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.Xq), 0, (int)((unsigned)a.B * (unsigned)rowbytes), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rSW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.sW), 0, (int)((unsigned)a.rows * sn * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rSX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Xs), 0, (int)((unsigned)a.B * sn * 4), 0x00020000);
-    int prow[2], pch[2]; unsigned woff[2], xoff[2];
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, (int)((unsigned)a.rows * rowbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.Xq), 0, (int)((unsigned)a.B * rowbytes), 0x00020000);
+    // loader: piece k of a thread = 16 bytes (8 elements) at (row (tid >> 3) + 32 k, chunk tid & 7) of both matrices
+    const int prow = tid >> 3, pch = tid & 7;
+    unsigned woff[2], xoff[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        const int idx = tid + k * 256; prow[k] = idx >> 3; pch[k] = idx & 7;
-        woff[k] = (r0 + prow[k] < a.rows) ? (unsigned)(r0 + prow[k]) * (unsigned)rowbytes + pch[k] * 16 : kOOB;
-        xoff[k] = (b0 + prow[k] < a.B)    ? (unsigned)(b0 + prow[k]) * (unsigned)rowbytes + pch[k] * 16 : kOOB;
+        woff[k] = (r0 + prow + 32 * k < a.rows) ? (unsigned)(r0 + prow + 32 * k) * rowbytes + pch * 16 : kOOB;
+        xoff[k] = (b0 + prow + 32 * k < a.B)    ? (unsigned)(b0 + prow + 32 * k) * rowbytes + pch * 16 : kOOB;
     }
-    const unsigned swoff = (tid < TS && r0 + tid < a.rows) ? (unsigned)(r0 + tid) * sn * 4 : kOOB;
-    const unsigned sxoff = (tid >= TS && tid < 2 * TS && b0 + tid - TS < a.B) ? (unsigned)(b0 + tid - TS) * sn * 4 : kOOB;
-    v4i wr[kPF][2], xr[kPF][2]; float sr[kPF];
-    auto fetch = [&](int g, int slot) {
-        const bool in = g < sn;
+    const unsigned poff = (unsigned)(prow * LS + pch * 8);
+    // scales: wave 0 = the weight rows', wave 1 = the tokens' (lane = row of the tile); waves 2, 3 load nothing
+    const bool s_x = wave == 1;
+    const int s_row = (s_x ? b0 : r0) + lane, s_rows = wave < 2 ? (s_x ? a.B : a.rows) : 0;
+    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s_x ? a.Xs : a.sW), 0, (int)((unsigned)s_rows * sn * 4), 0x00020000);
+    unsigned soff = s_row < s_rows ? (unsigned)s_row * sn * 4 : kOOB;
+    const unsigned spoff = (unsigned)(kOffS + (tid & 127) * 4);
+    v4u wr[2], xr[2]; unsigned sr;
+    auto fetch = [&](int g) {                     // group g -> the register slot (groups past the end: zero scale, never consumed otherwise)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            wr[slot][k] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rW, (int)((in && woff[k] != kOOB) ? woff[k] + (unsigned)g * GB : kOOB), 0, 0));
-            xr[slot][k] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rX, (int)((in && xoff[k] != kOOB) ? xoff[k] + (unsigned)g * GB : kOOB), 0, 0));
+            wr[k] = __builtin_amdgcn_raw_buffer_load_b128(rW, (int)woff[k], 0, 0); woff[k] += GB;
+            xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rX, (int)xoff[k], 0, 0); xoff[k] += GB;
         }
-        sr[slot] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rSW, (int)((in && swoff != kOOB) ? swoff + (unsigned)g * 4 : kOOB), 0, 0)
-                                 | __builtin_amdgcn_raw_buffer_load_b32(rSX, (int)((in && sxoff != kOOB) ? sxoff + (unsigned)g * 4 : kOOB), 0, 0));
+        sr = __builtin_amdgcn_raw_buffer_load_b32(rS, (int)(g < sn ? soff : kOOB), 0, 0); soff += 4;
     };
-    auto park = [&](int buf, int slot) {
+    auto park = [&](int buf) {
+        char* base = sm + buf * kBuf;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             unsigned lo[2], hi[2];
-            const int o = prow[k] * LS + pch[k] * 8;                       // piece -> 8 consecutive elements of the row's planes
-            split16(wr[slot][k], lo, hi);
-            *reinterpret_cast<uint2*>(&WL[buf][o]) = make_uint2(lo[0], lo[1]); *reinterpret_cast<uint2*>(&WH[buf][o]) = make_uint2(hi[0], hi[1]);
-            split16(xr[slot][k], lo, hi);
-            *reinterpret_cast<uint2*>(&XL[buf][o]) = make_uint2(lo[0], lo[1]); *reinterpret_cast<uint2*>(&XH[buf][o]) = make_uint2(hi[0], hi[1]);
+            split16(__builtin_bit_cast(v4i, wr[k]), lo, hi);
+            *reinterpret_cast<uint2*>(base + poff + k * 32 * LS) = make_uint2(lo[0], lo[1]); *reinterpret_cast<uint2*>(base + kPlane + poff + k * 32 * LS) = make_uint2(hi[0], hi[1]);
+            split16(__builtin_bit_cast(v4i, xr[k]), lo, hi);
+            *reinterpret_cast<uint2*>(base + 2 * kPlane + poff + k * 32 * LS) = make_uint2(lo[0], lo[1]); *reinterpret_cast<uint2*>(base + 3 * kPlane + poff + k * 32 * LS) = make_uint2(hi[0], hi[1]);
         }
-        if (tid < TS) sWt[buf][tid] = sr[slot]; else if (tid < 2 * TS) sXt[buf][tid - TS] = sr[slot];
+        if (wave < 2) *reinterpret_cast<unsigned*>(base + spoff) = sr;
     };
+    const int wt0 = (wave & 1) * 32, wr0 = (wave >> 1) * 32, l31 = lane & 31, h = lane >> 5;
+    const unsigned offX = (unsigned)(2 * kPlane + (wt0 + l31) * LS + h * 16), offW = (unsigned)((wr0 + l31) * LS + h * 16);
+    const unsigned offsw = (unsigned)(kOffS + (wr0 + l31) * 4), offsx = (unsigned)(kOffS + (TS + wt0 + 4 * h) * 4);
     float acc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const int am = wr0 + (lane & 31), bn = wc0 + (lane & 31), kh = (lane >> 5) * 16;
-#pragma unroll
-    for (int u = 0; u < kPF; ++u) fetch(u, u);
-    park(0, 0);
-    fetch(kPF, 0);
+    fetch(0); park(0); fetch(1);
     __syncthreads();
-    auto step = [&](int g, int next_slot) {
-        const int buf = g & 1;
-#define FLM_LD(P, r, off) (*reinterpret_cast<const v4i*>(&P[buf][(r) * LS + (off) + kh]))
-        const v4i al0 = FLM_LD(WL, am, 0), al1 = FLM_LD(WL, am, 32), ah0 = FLM_LD(WH, am, 0), ah1 = FLM_LD(WH, am, 32);
-        const v4i xl0 = FLM_LD(XL, bn, 0), xl1 = FLM_LD(XL, bn, 32), xh0 = FLM_LD(XH, bn, 0), xh1 = FLM_LD(XH, bn, 32);
-#undef FLM_LD
+    for (int g = 0; g < sn; ++g) {
+        const char* base = sm + (g & 1) * kBuf;
+        const v4i xl0 = *reinterpret_cast<const v4i*>(base + offX), xl1 = *reinterpret_cast<const v4i*>(base + offX + 32);
+        const v4i xh0 = *reinterpret_cast<const v4i*>(base + offX + kPlane), xh1 = *reinterpret_cast<const v4i*>(base + offX + kPlane + 32);
+        const v4i wl0 = *reinterpret_cast<const v4i*>(base + offW), wl1 = *reinterpret_cast<const v4i*>(base + offW + 32);
+        const v4i wh0 = *reinterpret_cast<const v4i*>(base + offW + kPlane), wh1 = *reinterpret_cast<const v4i*>(base + offW + kPlane + 32);
         const v16i z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        v16i dhh = __builtin_amdgcn_mfma_i32_32x32x32_i8(ah0, xh0, z, 0, 0, 0);
-        dhh = __builtin_amdgcn_mfma_i32_32x32x32_i8(ah1, xh1, dhh, 0, 0, 0);
-        v16i dm = __builtin_amdgcn_mfma_i32_32x32x32_i8(ah0, xl0, z, 0, 0, 0);
-        dm = __builtin_amdgcn_mfma_i32_32x32x32_i8(ah1, xl1, dm, 0, 0, 0);
-        dm = __builtin_amdgcn_mfma_i32_32x32x32_i8(al0, xh0, dm, 0, 0, 0);
-        dm = __builtin_amdgcn_mfma_i32_32x32x32_i8(al1, xh1, dm, 0, 0, 0);
-        v16i dll = __builtin_amdgcn_mfma_i32_32x32x32_i8(al0, xl0, z, 0, 0, 0);
-        dll = __builtin_amdgcn_mfma_i32_32x32x32_i8(al1, xl1, dll, 0, 0, 0);
-        const float sx = sXt[buf][bn];
+        v16i d = __builtin_amdgcn_mfma_i32_32x32x32_i8(xh0, wh0, z, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_i32_32x32x32_i8(xh1, wh1, d, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d[i] = (int)((unsigned)d[i] << 8);
+        d = __builtin_amdgcn_mfma_i32_32x32x32_i8(xh0, wl0, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_i32_32x32x32_i8(xh1, wl1, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_i32_32x32x32_i8(xl0, wh0, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_i32_32x32x32_i8(xl1, wh1, d, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d[i] = (int)((unsigned)d[i] << 8);
+        d = __builtin_amdgcn_mfma_i32_32x32x32_i8(xl0, wl0, d, 0, 0, 0);                  // wraps mod 2^32 onto the exact int32 dot
+        d = __builtin_amdgcn_mfma_i32_32x32x32_i8(xl1, wl1, d, 0, 0, 0);
+        const float sw = *reinterpret_cast<const float*>(base + offsw);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 sw = *reinterpret_cast<const float4*>(&sWt[buf][wr0 + 8 * q + 4 * (lane >> 5)]);
-            const float swv[4] = {sw.x, sw.y, sw.z, sw.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int i = 4 * q + e;
-                const int dot = (int)(((unsigned)dhh[i] << 16) + ((unsigned)dm[i] << 8) + (unsigned)dll[i]);      // wraps mod 2^32 onto the exact int32 dot
-                acc[i] = __fmaf_rn(__fmul_rn(swv[e], sx), (float)dot, acc[i]);                                   // quant_operators.cpp:274
-            }
+            const float4 sx = *reinterpret_cast<const float4*>(base + offsx + q * 32);
+            acc[4 * q + 0] = __fmaf_rn(__fmul_rn(sw, sx.x), (float)d[4 * q + 0], acc[4 * q + 0]);   // quant_operators.cpp:274
+            acc[4 * q + 1] = __fmaf_rn(__fmul_rn(sw, sx.y), (float)d[4 * q + 1], acc[4 * q + 1]);
+            acc[4 * q + 2] = __fmaf_rn(__fmul_rn(sw, sx.z), (float)d[4 * q + 2], acc[4 * q + 2]);
+            acc[4 * q + 3] = __fmaf_rn(__fmul_rn(sw, sx.w), (float)d[4 * q + 3], acc[4 * q + 3]);
         }
-        park(buf ^ 1, next_slot); fetch(g + 1 + kPF, next_slot);
+        park((g & 1) ^ 1); fetch(g + 2);          // unconditional: a group past the end is parked and never read with a non-zero scale
         __syncthreads();
-    };
-    for (int g = 0; g < sn; g += 2) { step(g, 1); step(g + 1, 0); }          // (a group past the end contributes fma(0, 0, acc) = acc)
-    const int b = b0 + bn;
-    if (b < a.B) {
+    }
+    const int row = r0 + wr0 + l31;
+    if (row < a.rows) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int row = r0 + wr0 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-            if (row >= a.rows) continue;
+            const int b = b0 + wt0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (b >= a.B) continue;
             float* o = a.out + (size_t)b * a.ldo + row;
             if constexpr (EPI == EPI_RESIDUAL) *o = __fadd_rn(*o, acc[i]); else *o = acc[i];
         }
