@@ -617,7 +617,13 @@ int prefill_batched(flm_ctx* c, int B, int pos) {
         if (hs <= 128 && c->use_prefill_mq && c->use_qk_mfma && c->pf_scores) {
             // scores on the matrix cores (fp32 MFMA = the reference's chains, bit for bit), then softmax + weighted sum per 8 queries
             aa.sc_global = c->pf_scores;
-            hipLaunchKernelGGL(k_qk_mfma, dim3(c->heads_local, (B + kQkQ - 1) / kQkQ), dim3(256), qk_mfma_lds_bytes(hs), st, aa, pos, dim, B);
+            const dim3 gq(c->heads_local, (B + kQkQ - 1) / kQkQ);
+            switch (hs >> 5) {
+            case 1: hipLaunchKernelGGL(k_qk_mfma<1>, gq, dim3(256), 0, st, aa, pos, dim, B); break;
+            case 2: hipLaunchKernelGGL(k_qk_mfma<2>, gq, dim3(256), 0, st, aa, pos, dim, B); break;
+            case 3: hipLaunchKernelGGL(k_qk_mfma<3>, gq, dim3(256), 0, st, aa, pos, dim, B); break;
+            default: hipLaunchKernelGGL(k_qk_mfma<4>, gq, dim3(256), 0, st, aa, pos, dim, B); break;
+            }
             HIPC(c, hipGetLastError());
             if (c->use_pv_mfma && (hs & 1) == 0)   // ... and the weighted sum too (an accumulator element = the reference's chain of one (query, dimension))
                 hipLaunchKernelGGL(k_attn_pv_mfma, dim3(c->heads_local, (B + kPvQ - 1) / kPvQ), dim3(256), pv_mfma_lds_bytes(pos + B), st, aa, pos, dim, B);
