@@ -578,13 +578,22 @@ int launch_gemm(flm_ctx* c, hipStream_t st, const GemmArgs& g, int use_mfma) {
             once = true;
             HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_q8_mfma<EPI_STORE, 4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Big::kLds));
             HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_q8_mfma<EPI_RESIDUAL, 4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Big::kLds));
+            HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_q8_mfma<EPI_SWIGLU, 4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Big::kLds));
         }
+        if constexpr (EPI == EPI_SWIGLU) {   // g.rows = hidden: a tile = 64 rows of W1 and of W3 (gemm_fuses_swiglu decides)
+            const int tiles = ((g.rows + Big::TR / 2 - 1) / (Big::TR / 2)) * ((g.B + Big::TT - 1) / Big::TT);
+            hipLaunchKernelGGL((k_gemm_q8_mfma<EPI_SWIGLU, 4, 2, 2>), dim3(tiles), dim3(Big::NT), Big::kLds, st, g);
+            HIPC(c, hipGetLastError());
+            return FLM_OK;
+        } else {
         const int tiles128 = ((g.rows + Big::TR - 1) / Big::TR) * ((g.B + Big::TT - 1) / Big::TT);
         // 128 x 128 tiles move 0.6x the LDS cycles and half the bytes per product; they pay once every CU has one (measured, 7B width:
         // 512 tokens qkv / ffn13 100.8 vs 115.3 us, Wo / ffn2 (128 tiles) 95.4 vs 65.4; 1000 tokens 171 vs 221 and 110 vs 117)
         if (use_mfma == 3 || (use_mfma == 1 && tiles128 >= 256)) hipLaunchKernelGGL((k_gemm_q8_mfma<EPI, 4, 2, 2>), dim3(tiles128), dim3(Big::NT), Big::kLds, st, g);
         else hipLaunchKernelGGL((k_gemm_q8_mfma<EPI, 2, 2, 1>), dim3(tiles), dim3(Small::NT), Small::kLds, st, g);
+        }
     }
+    else if constexpr (EPI == EPI_SWIGLU) return fail(c, FLM_ERR_INVALID, "launch_gemm: the SwiGLU epilogue exists for the int8 matrix-core tiles only");
     else if (QT == QT_INT16 && use_mfma) hipLaunchKernelGGL((k_gemm_q16_mfma<EPI>), dim3(tiles), dim3(256), Gemm16Tile::kLds, st, g);   // hi / lo byte planes on the int8 matrix cores
     else hipLaunchKernelGGL((k_gemm_q<QT, EPI>), dim3(tiles), dim3(256), 0, st, g);
     HIPC(c, hipGetLastError());
@@ -643,10 +652,16 @@ int prefill_batched(flm_ctx* c, int B, int pos) {
         // hd = swiglu(W1 qx, W3 qx) with qx = quantize(rmsnorm(x1))   (transformer.cpp:144-147, 468-483)
         RowsArgs rf{c->pf_x, w.ffn_norm, c->pf_xq, c->pf_xs, dim};
         r = launch_rows<QT, PRO_RMSNORM_QUANT>(c, st, rf, B); if (r) return r;
-        GemmArgs g13{w.w13.q, w.w13.s, c->pf_xq, c->pf_xs, c->pf_gu, 2 * hid, dim, 2 * hid, B};
-        r = launch_gemm<QT, EPI_STORE>(c, st, g13, c->use_mfma); if (r) return r;
-        hipLaunchKernelGGL(k_swiglu_rows, dim3(B), dim3(256), 0, st, c->pf_hd, (const float*)c->pf_gu, hid);
-        HIPC(c, hipGetLastError());
+        if (QT == QT_INT8 && (c->use_mfma == 3 || (c->use_mfma == 1 && ((hid + 63) / 64) * ((B + 127) / 128) >= 256))) {
+            // 128 x 128 tiles of 64 gate + 64 up rows: the GEMM's epilogue is the SwiGLU
+            GemmArgs g13{w.w13.q, w.w13.s, c->pf_xq, c->pf_xs, c->pf_hd, hid, dim, hid, B};
+            r = launch_gemm<QT, EPI_SWIGLU>(c, st, g13, c->use_mfma); if (r) return r;
+        } else {
+            GemmArgs g13{w.w13.q, w.w13.s, c->pf_xq, c->pf_xs, c->pf_gu, 2 * hid, dim, 2 * hid, B};
+            r = launch_gemm<QT, EPI_STORE>(c, st, g13, c->use_mfma); if (r) return r;
+            hipLaunchKernelGGL(k_swiglu_rows, dim3(B), dim3(256), 0, st, c->pf_hd, (const float*)c->pf_gu, hid);
+            HIPC(c, hipGetLastError());
+        }
         // x1 += W2 quantize(hd)   (transformer.cpp:149-150, 485-494)
         RowsArgs rh{c->pf_hd, nullptr, c->pf_xq, c->pf_xs, hid};
         r = launch_rows<QT, PRO_QUANT>(c, st, rh, B); if (r) return r;

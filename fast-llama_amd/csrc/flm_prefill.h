@@ -216,26 +216,34 @@ struct GemmTile {
     static_assert(kGPS == 2 && NT == kGPS * (TR + TT) && TR % 64 == 0 && TT % 64 == 0, "one scale per thread and stage, wave-uniform (matrix, group)");
     static_assert(TR * 8 % NT == 0 && TT * 8 % NT == 0, "whole pieces per thread");
 };
+// EPI_SWIGLU (NB == 2): W = [W1 (gate) ; W3 (up)], a.rows rows each; a tile's rows are TR / 2 rows of W1 and the same rows of W3, a
+// wave's two B fragments the same 32 rows of both -- gate and up of one (token, row) meet in one lane, and the epilogue stores
+// swiglu(gate, up) (o1.swiglu(o3), transformer.cpp:481) instead of both: no [tokens][2 hidden] round trip, no k_swiglu_rows.
 template <int EPI, int WT, int WR, int NB>
 __global__ void __launch_bounds__(64 * WT * WR, 4) k_gemm_q8_mfma(const GemmArgs a) {
     using G = GemmTile<WT, WR, NB>;
+    constexpr bool TWO = EPI == EPI_SWIGLU;
+    static_assert(!TWO || NB == 2, "gate and up are the two B fragments of a wave");
+    constexpr int TRH = TWO ? G::TR / 2 : G::TR;              // rows of a.rows one tile advances
     constexpr int SB = G::SB, LS = G::LS, TT = G::TT, TR = G::TR, NT = G::NT, kOffX = G::kOffX, kOffS = G::kOffS, kBuf = G::kBuf, NPW = G::NPW, NPX = G::NPX;
     extern __shared__ __attribute__((aligned(16))) char lds[]; char* const sm = lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntt = (a.B + TT - 1) / TT;
     const int nb = gridDim.x, per = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7;              // tiles dealt to the XCDs in contiguous runs (see k_gemm_q)
     const int tile = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
-    const int r0 = (tile / ntt) * TR, b0 = (tile % ntt) * TT;
+    const int r0 = (tile / ntt) * TRH, b0 = (tile % ntt) * TT;
     const int sn = a.n / kGroup, nst = (sn + kGPS - 1) / kGPS;
     const unsigned rowbytes = (unsigned)a.n;
     constexpr unsigned kOOB = 0x80000000u;
-    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, (int)((unsigned)a.rows * rowbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, (int)((TWO ? 2u : 1u) * (unsigned)a.rows * rowbytes), 0x00020000);
+    // tile row -> row of W (or kOOB-marker -1): SWIGLU tiles hold TRH rows of W1, then the same TRH rows of W3
+    auto wrow = [&](int tr) -> int { const int within = TWO ? tr % TRH : tr, r = r0 + within; return r < a.rows ? (TWO ? (tr / TRH) * a.rows + r : r) : -1; };
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.Xq), 0, (int)((unsigned)a.B * rowbytes), 0x00020000);
     // loader: piece k of a thread = 16 bytes at (row (tid >> 3) + (NT / 8) k, chunk tid & 7); rows outside a matrix read as zero
     const int prow = tid >> 3, pch = tid & 7;
     unsigned woff[NPW], xoff[NPX];
 #pragma unroll
-    for (int k = 0; k < NPW; ++k) woff[k] = (r0 + prow + (NT / 8) * k < a.rows) ? (unsigned)(r0 + prow + (NT / 8) * k) * rowbytes + pch * 16 : kOOB;
+    for (int k = 0; k < NPW; ++k) { const int r = wrow(prow + (NT / 8) * k); woff[k] = r >= 0 ? (unsigned)r * rowbytes + pch * 16 : kOOB; }
 #pragma unroll
     for (int k = 0; k < NPX; ++k) xoff[k] = (b0 + prow + (NT / 8) * k < a.B) ? (unsigned)(b0 + prow + (NT / 8) * k) * rowbytes + pch * 16 : kOOB;
     const unsigned poff = (unsigned)(prow * LS + pch * 16);
@@ -244,9 +252,10 @@ __global__ void __launch_bounds__(64 * WT * WR, 4) k_gemm_q8_mfma(const GemmArgs
     const int s_slot = wave * 64;
     const bool s_x = s_slot >= kGPS * TR;
     const int s_gi = s_x ? (s_slot - kGPS * TR) / TT : s_slot / TR;
-    const int s_row = (s_x ? b0 + (s_slot - kGPS * TR) % TT : r0 + s_slot % TR) + lane, s_rows = s_x ? a.B : a.rows;
-    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s_x ? a.Xs : a.sW), 0, (int)((unsigned)s_rows * sn * 4), 0x00020000);
-    unsigned soff = s_row < s_rows ? ((unsigned)s_row * sn + s_gi) * 4 : kOOB;
+    const int s_row = s_x ? (b0 + (s_slot - kGPS * TR) % TT + lane < a.B ? b0 + (s_slot - kGPS * TR) % TT + lane : -1) : wrow(s_slot % TR + lane);
+    const unsigned s_rows = s_x ? (unsigned)a.B : (TWO ? 2u : 1u) * (unsigned)a.rows;
+    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s_x ? a.Xs : a.sW), 0, (int)(s_rows * sn * 4), 0x00020000);
+    unsigned soff = s_row >= 0 ? ((unsigned)s_row * sn + s_gi) * 4 : kOOB;
     const unsigned spoff = (unsigned)(kOffS + tid * 4);
     v4u wr[NPW], xr[NPX]; unsigned sr;
     auto fetch = [&](int st) {                    // stage st -> the register slot (stages past the end: the offsets have run past the rows; never consumed with a non-zero scale)
@@ -265,7 +274,9 @@ __global__ void __launch_bounds__(64 * WT * WR, 4) k_gemm_q8_mfma(const GemmArgs
         *reinterpret_cast<unsigned*>(base + spoff) = sr;
     };
     // this wave's 32 tokens x (NB x 32) weight rows
-    const int wt0 = (wave % WT) * 32, wr0 = (wave / WT) * 32 * NB, l31 = lane & 31, h = lane >> 5;
+    // (SWIGLU: fragment j = rows wr0 .. wr0 + 31 of half j, i.e. tile rows j TRH + wr0 ..; otherwise fragment j = tile rows wr0 + 32 j ..)
+    const int wt0 = (wave % WT) * 32, wr0 = (wave / WT) * 32 * (TWO ? 1 : NB), l31 = lane & 31, h = lane >> 5;
+    constexpr int FS = TWO ? TRH : 32;                            // tile rows between a wave's fragments
     const unsigned offA = (unsigned)(kOffX + (wt0 + l31) * LS + h * 16), offB = (unsigned)((wr0 + l31) * LS + h * 16);
     const unsigned offsw = (unsigned)(kOffS + (wr0 + l31) * 4), offsx = (unsigned)(kOffS + (kGPS * TR + wt0 + 4 * h) * 4);
     float acc[NB][16];
@@ -286,14 +297,14 @@ __global__ void __launch_bounds__(64 * WT * WR, 4) k_gemm_q8_mfma(const GemmArgs
             v16i d[NB];
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                const v4i b0v = *reinterpret_cast<const v4i*>(base + offB + j * 32 * LS + gi * kGroup), b1v = *reinterpret_cast<const v4i*>(base + offB + j * 32 * LS + gi * kGroup + 32);
+                const v4i b0v = *reinterpret_cast<const v4i*>(base + offB + j * FS * LS + gi * kGroup), b1v = *reinterpret_cast<const v4i*>(base + offB + j * FS * LS + gi * kGroup + 32);
                 const v16i z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                 d[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0v, z, 0, 0, 0);
                 d[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1v, d[j], 0, 0, 0);
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                const float sw = *reinterpret_cast<const float*>(base + offsw + (gi * TR + j * 32) * 4);
+                const float sw = *reinterpret_cast<const float*>(base + offsw + (gi * TR + j * FS) * 4);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     acc[j][4 * q + 0] = __fmaf_rn(__fmul_rn(sw, sx[q].x), (float)d[j][4 * q + 0], acc[j][4 * q + 0]);   // quant_operators.cpp:274
@@ -306,16 +317,27 @@ __global__ void __launch_bounds__(64 * WT * WR, 4) k_gemm_q8_mfma(const GemmArgs
         park((st & 1) ^ 1); fetch(st + 2);        // unconditional: a stage past the end is parked and never read with a non-zero scale
         __syncthreads();
     }
+    if constexpr (TWO) {
+        const int row = r0 + wr0 + l31;
+        if (row < a.rows) {
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int row = r0 + wr0 + j * 32 + l31;
-        if (row >= a.rows) continue;
+            for (int i = 0; i < 16; ++i) {
+                const int b = b0 + wt0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (b < a.B) a.out[(size_t)b * a.ldo + row] = swiglu_elem(acc[0][i], acc[NB - 1][i]);
+            }
+        }
+    } else {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int b = b0 + wt0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (b >= a.B) continue;
-            float* o = a.out + (size_t)b * a.ldo + row;
-            if constexpr (EPI == EPI_RESIDUAL) *o = __fadd_rn(*o, acc[j][i]); else *o = acc[j][i];
+        for (int j = 0; j < NB; ++j) {
+            const int row = r0 + wr0 + j * 32 + l31;
+            if (row >= a.rows) continue;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int b = b0 + wt0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (b >= a.B) continue;
+                float* o = a.out + (size_t)b * a.ldo + row;
+                if constexpr (EPI == EPI_RESIDUAL) *o = __fadd_rn(*o, acc[j][i]); else *o = acc[j][i];
+            }
         }
     }
 }

@@ -105,7 +105,8 @@ def test_7b_width_layer_every_code_path_vs_oracle(gpu, qt):
 
 
 @pytest.mark.parametrize("shape,qt,layers,n", [("tiny", ff.QT_INT8, None, 70), ("tiny128", ff.QT_INT16, None, 33), ("small", ff.QT_INT8, None, 129),
-                                               ("small", ff.QT_INT16, None, 65), ("7B", ff.QT_INT8, 2, 67), ("small", ff.QT_INT8, None, 800)])
+                                               ("small", ff.QT_INT16, None, 65), ("7B", ff.QT_INT8, 2, 67), ("small", ff.QT_INT8, None, 800),
+                                               ("7B", ff.QT_INT8, 1, 200)])
 def test_batched_prefill_is_bit_identical_to_token_by_token(gpu, shape, qt, layers, n):
     """prompts go through the batched kernels (GEMM tiles, per-row prologues, causal attention); the cache rows they leave and
     the logits of the last token must be the bits of the token-by-token path (and of the oracle)"""
@@ -115,9 +116,9 @@ def test_batched_prefill_is_bit_identical_to_token_by_token(gpu, shape, qt, laye
     tensors = synth.make_tensors(cfg, seed=8)
     prompt = _prompt(cfg.vocab_size, n)
     outs = {}
-    for mode in (0, 1, 2):                                      # 0 token by token, 1 batched (int8 GEMM on MFMA), 2 batched with v_dot4
+    for mode in (0, 1, 2, 3):                                   # 0 token by token, 1 batched (GEMMs on MFMA), 2 batched with v_dot, 3 batched, 128 x 128 tiles + fused SwiGLU forced
         ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
-        ctx.set_option("use_prefill", 1 if mode else 0); ctx.set_option("use_mfma", 1 if mode == 1 else 0)
+        ctx.set_option("use_prefill", 1 if mode else 0); ctx.set_option("use_mfma", {0: 1, 1: 1, 2: 0, 3: 3}[mode])
         lg = ctx.forward(prompt[:5], 0)                       # short prompts stay on the token-by-token path
         lg = ctx.forward(prompt[5:], 5)                       # the batch starts at a non-zero position
         kv = [ctx.debug_read("kcache", l, cfg.n_heads * cfg.max_length * cfg.head_size).reshape(cfg.n_heads, cfg.max_length, -1)[:, :n].copy()
@@ -127,7 +128,7 @@ def test_batched_prefill_is_bit_identical_to_token_by_token(gpu, shape, qt, laye
         nxt = ctx.forward(np.array([int(np.argmax(lg))], np.int32), n)
         outs[mode] = (lg, kv, vv, nxt)
         ctx.close()
-    for m in (1, 2):
+    for m in (1, 2, 3):
         assert bits_equal(outs[0][0], outs[m][0]), m
         for l in range(cfg.n_layers):
             assert bits_equal(outs[0][1][l], outs[m][1][l]), f"mode {m}: K cache layer {l}"
