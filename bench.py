@@ -262,8 +262,9 @@ def time_decode(ctx, cfg, args, prompt, barrier, gold):
 
 def prefill_main(args):
     """--config prefill<N>-<quant>: BASELINE.json's config 5 (LLaMA2-7B int16 + a 512-token prompt): the batched prompt path --
-    int8 / int16 GEMM tiles on the matrix cores, QK^T on fp32 MFMA, causal softmax + weighted sum -- timed as whole forwards of
-    the prompt (K repetitions on a cleared cache), reported as prompt tokens/s with the linear layers' MAC rate beside it."""
+    int8 / int16 GEMM tiles on the matrix cores, QK^T and softmax x V on fp32 MFMA -- timed as whole forwards of the prompt (K
+    repetitions on a cleared cache), reported as prompt tokens/s with the linear layers' MAC rate beside it; the next token is
+    checked against the token-by-token decode path over the same prompt (the path the golden-logit tests pin to the reference)."""
     import re as _re
     import torch
     graft.load_package()
@@ -286,6 +287,9 @@ def prefill_main(args):
         ctx.reset_kv(); ctx.sync(); torch.cuda.synchronize()
         t0 = time.perf_counter(); tok = ctx.forward_argmax(prompt, 0); times.append(time.perf_counter() - t0)
     dt = float(np.median(times))
+    ctx.set_option("use_prefill", 0); ctx.reset_kv()
+    tok_ref = ctx.forward_argmax(prompt, 0)                       # the same prompt, one token at a time through the decode kernels
+    ctx.set_option("use_prefill", 1)
     L, dim, hid = cfg.n_layers, cfg.dim, cfg.hidden_dim
     macs = (n - 1) * ((L - 1) * (4 * dim * dim + 3 * dim * hid) + 3 * dim * dim)      # the batch: every layer but the last in full, the last one's q/k/v only
     flops_qk = 2.0 * (L - 1) * cfg.n_heads * cfg.head_size * sum(range(1, n))              # causal QK^T (the fp32-MFMA kernel)
@@ -293,7 +297,10 @@ def prefill_main(args):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": m.group(2), "data": "synthetic",
             "config": {"workload": f"LLaMA2-{args.shape} {m.group(2)}, {n}-token prompt through the batched path (GEMM tiles on v_mfma_i32_32x32x32_i8, int16 as hi/lo byte planes; "
-                                   f"QK^T on v_mfma_f32_16x16x4_f32; last token through the decode kernels), next token {int(tok)}"},
+                                   f"QK^T and softmax x V on v_mfma_f32_16x16x4_f32; last token through the decode kernels), next token {int(tok)}"},
+            "parity": {"against": "next token of the token-by-token decode path over the same prompt in the same session (that path's logits are pinned to the "
+                                  "reference by tests/golden/model_7B_int8_L32.npz; batched vs token-by-token cache rows and logits bit for bit: tests/test_gpu_model.py)",
+                       "match": bool(int(tok) == int(tok_ref))},
             "linear_layers": {"int_macs": int(macs), "TMAC_per_s_over_whole_forward": round(macs / dt / 1e12, 1), "note": "lower bound: the forward's whole wall time is charged to the GEMMs"},
             "qk_flops": int(flops_qk)}
     print(json.dumps(line), flush=True)

@@ -141,6 +141,7 @@ int  flm_debug_read(flm_ctx* ctx, int what, int layer, float* out, size_t n);
  * workgroup (default 1: eight), "attn_split" 0 = one workgroup per head at every context length (default 1: hs / 32 from 128 positions on; n >= 2: always n),
  * "use_p2p" 0 = tensor-parallel exchanges by RCCL all-gathers even though the peers are mapped (1: peer to peer again),
  * "use_qk_mfma" 0 = prefill attention scores on VALU chains (default 1: v_mfma_f32_16x16x4_f32, the same bits),
+ * "use_pv_mfma" 0 = prefill softmax x V on VALU chains (default 1: the weighted sum on v_mfma_f32_16x16x4_f32 too; needs use_qk_mfma),
  * "use_mfma" 0 = prefill GEMMs on v_dot4 / v_dot2 instead of the matrix cores (default 1: int8 tile shape by problem size; 2 / 3 = always 64 x 64 / 128 x 128 tiles).
  * None of them changes a result bit.  (Perf-exploration switches that DO skip work -- "ablate", "trace" -- exist only in builds
  * with -DFLM_ABLATE=1; the product library answers FLM_ERR_INVALID to them.) */
