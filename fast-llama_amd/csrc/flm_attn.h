@@ -875,4 +875,48 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_attn_o(const AttnArgs aa, con
     stamp(4);
 }
 
+// ------------------------------------------------------------------------------------------
+// FFN13 (+ SwiGLU) and FFN2 (+ residual) in ONE launch (single GPU): every workgroup runs its rows of [W1; W3], publishes its slice
+// of hd (write-through stores, then its 64-byte flag line = layer + 1), requests its first two steps of W2 -- 128 KiB per CU, two
+// thirds of the matrix chip-wide, none of it depending on hd -- and only then waits for the other workgroups' lines (lane i of
+// waves 0..3 polls workgroup 64 w + i's).  The tail of FFN13, the hand-off and FFN2's quantize prologue pass while those weights
+// stream; as two launches the same interval is a kernel boundary, a ramp and a wait with an empty memory pipeline
+// (DESIGN.md section 7).  The two phases are k_gemv<RMSNORM_QUANT, SWIGLU> and k_gemv<QUANT, RESIDUAL> verbatim (hd is read
+// with coherent loads).  All workgroups are resident (grid <= CUs, one 1024-thread workgroup per CU); a poll that never succeeds
+// gives up after ~20 ms and raises *err (the host then re-runs the call on one kernel per phase).
+template <int QT, int XR2>
+__global__ void __launch_bounds__(kGemvBlock, 4) k_ffn(const GemvArgs a13, const GemvArgs a2, const int grid13, const int grid2, unsigned* flag, const unsigned target, int* err) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    auto nostamp = [](int) {};
+    if ((int)blockIdx.x < grid13) {
+        float4 xv[1], nv[1];
+        gemv_preload<QT, PRO_RMSNORM_QUANT, 1>(a13, xv, nv);
+        GemvCtx<QT, EPI_SWIGLU> g;
+        g.init(a13, blockIdx.x, grid13, lds);
+        gemv_prologue<QT, PRO_RMSNORM_QUANT, 1>(a13, lds, xv, nv, [&](int part) { g.issue(kAblate ? a13.ablate : 0, part); });
+        g.run(a13, lds, nostamp);
+    }
+    wait_stores_done();                                                         // every wave: its rows of hd are where the others will read them
+    __syncthreads();                                                            // (and the LDS is free for the second phase)
+    if (threadIdx.x == 0) __hip_atomic_store(flag + blockIdx.x * kFlagStride, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int)blockIdx.x >= grid2) return;
+    GemvCtx<QT, EPI_RESIDUAL> g2;
+    g2.init(a2, blockIdx.x, grid2, lds);
+    g2.issue(kAblate ? a2.ablate : 0, 1);                                       // ONE set now (64 KiB per CU: taken by the memory pipeline before the flags come in); hd
+    if (threadIdx.x < 256) {                                                    // requested behind two sets would wait for 128 KiB per CU to drain (measured: no gain at all)
+        const bool mine = threadIdx.x < gridDim.x;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (true) {
+            const unsigned f = mine ? __hip_atomic_load(flag + threadIdx.x * kFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
+            if (__all(f >= target)) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+    }
+    __syncthreads();
+    float4 xv2[XR2 > 0 ? XR2 : 1], nv2[XR2 > 0 ? XR2 : 1];
+    gemv_preload<QT, PRO_QUANT, XR2, true>(a2, xv2, nv2);
+    gemv_prologue<QT, PRO_QUANT, XR2, true>(a2, lds, xv2, nv2, [&](int) { g2.issue(kAblate ? a2.ablate : 0, 2); });   // the second set once hd has arrived
+    g2.run(a2, lds, nostamp);
+}
+
 } // namespace flm

@@ -74,6 +74,7 @@ struct flm_ctx {
     int use_qk_mfma = 1;                               // option "use_qk_mfma": prefill scores on the matrix cores (fp32 MFMA, bit-identical), 0: VALU chains inside the attention kernel
     float* pf_scores = nullptr;                        // [heads][max_seq][max_seq] prefill scores (k_qk_mfma -> k_attn_prefill_mq<true>)
     int fuse_attn_o = 1;                               // option "fuse_attn_o": attention + Wo GEMV in one launch (k_attn_o; single GPU)
+    int fuse_ffn = 1;                                  // option "fuse_ffn": FFN13 + FFN2 in one launch (k_ffn; single GPU)
     unsigned* flag_lines = nullptr; int* xwg_err = nullptr;   // k_attn_o: one 64-byte flag line per head; "a cross-workgroup wait timed out"
     void* att_q = nullptr; float* att_qs = nullptr;    // k_attn_o: the heads' output already quantized (head_size a multiple of 64)
     // tensor parallel, peer-to-peer: ONE exchange buffer per rank -- [att_out | x1 | hd | logits | flag lines] -- shared with the
@@ -275,13 +276,13 @@ bool model_complete(const flm_ctx* c) {
 // context's life and FLM_RETRY tells the caller (inside this library) to run the call again on one kernel per phase.
 constexpr int FLM_RETRY = 1;
 int xwg_check(flm_ctx* c) {
-    if (!c->fuse_attn_o && c->attn_split == 0 && !c->p2p) return FLM_OK;
+    if (!c->fuse_attn_o && !c->fuse_ffn && c->attn_split == 0 && !c->p2p) return FLM_OK;
     int e = 0;
     HIPC(c, hipMemcpy(&e, c->xwg_err, 4, hipMemcpyDeviceToHost));
     if (!e) return FLM_OK;
     HIPC(c, hipMemset(c->xwg_err, 0, 4));
     if (e == 2) return fail(c, FLM_ERR_COMM, "tensor parallel: a peer rank did not deliver its slice (20 s), or another rank gave up");
-    c->fuse_attn_o = 0; c->attn_split = 0;
+    c->fuse_attn_o = 0; c->fuse_ffn = 0; c->attn_split = 0;
     for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
     c->graphs.clear();
     return FLM_RETRY;
@@ -405,6 +406,25 @@ int launch_attn_o(flm_ctx* c, hipStream_t st, int l, int G) {
     return FLM_OK;
 }
 
+// FFN13 + FFN2 of layer l in one launch (k_ffn); returns FLM_ERR_UNSUPPORTED when the shape does not allow it
+template <int QT>
+int launch_ffn(flm_ctx* c, hipStream_t st, int l) {
+    GemvArgs a13 = args_ffn13(c, l), a2 = args_ffn2(c, l);
+    const int wgs = c->cu_count < 256 ? c->cu_count : 256;       // every workgroup resident, one flag line each
+    GemvPlan P13, P2;
+    int r = plan_gemv<QT, PRO_RMSNORM_QUANT, EPI_SWIGLU>(c, a13, wgs, P13); if (r) return r;
+    r = plan_gemv<QT, PRO_QUANT, EPI_RESIDUAL>(c, a2, wgs, P2); if (r) return r;
+    const int r13 = (a13.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4), r2 = (a2.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4);
+    if (r13 > 1 || r2 > 3) return FLM_ERR_UNSUPPORTED;
+    const size_t lds = P13.lds > P2.lds ? P13.lds : P2.lds;
+    const int grid = P13.grid > P2.grid ? P13.grid : P2.grid;
+    unsigned* flag = c->flag_lines + 512 * 16;                    // value = layer + 1; k_embed clears the lines at the start of the token
+    if (r2 <= 1) hipLaunchKernelGGL((k_ffn<QT, 1>), dim3(grid), dim3(kGemvBlock), lds, st, a13, a2, P13.grid, P2.grid, flag, (unsigned)(l + 1), c->xwg_err);
+    else         hipLaunchKernelGGL((k_ffn<QT, 3>), dim3(grid), dim3(kGemvBlock), lds, st, a13, a2, P13.grid, P2.grid, flag, (unsigned)(l + 1), c->xwg_err);
+    HIPC(c, hipGetLastError());
+    return FLM_OK;
+}
+
 // one activation exchange between the tensor-parallel ranks (the reference's threads share the vector in memory instead):
 // peer-to-peer (the producer already stored its slice everywhere: flag round only) or an RCCL all-gather
 enum XKind { XK_ATT = 0, XK_X1 = 1, XK_HD = 2, XK_LOGITS = 3 };
@@ -460,6 +480,10 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
             r = launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, traced(args_o(c, l), KC_ATTN_O, l), wgs, coh); if (r) return r;
         }
         if (tp) { r = exchange(c, st, XK_X1, c->x1, c->x1 + c->drow_begin, c->drow_count); if (r) return r; }
+        if (!tp && c->fuse_ffn && !c->timing && c->trace_class < 0) {   // FFN13 + FFN2 in one launch
+            r = qt == FLM_QT_INT8 ? launch_ffn<QT_INT8>(c, st, l) : launch_ffn<QT_INT16>(c, st, l);
+            if (r == FLM_OK) continue; else if (r != FLM_ERR_UNSUPPORTED) return r;
+        }
         {   // FFN13 task + SwiGLU (transformer.cpp:144-147, execute_ffn13 :468-483): this rank's rows of W1/W3
             Tick t(c, st, KC_FFN13);
             r = launch_gemv<PRO_RMSNORM_QUANT, EPI_SWIGLU>(c, st, qt, traced(args_ffn13(c, l), KC_FFN13, l), wgs, coh); if (r) return r;
@@ -803,8 +827,8 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
         c->peer[rank] = c->xbuf;
         HIPB(hipMalloc((void**)&c->xepoch, 64)); HIPB(hipMemsetAsync(c->xepoch, 0, 64, c->stream));
     }
-    HIPB(hipMalloc((void**)&c->flag_lines, 512 * 64)); HIPB(hipMalloc((void**)&c->xwg_err, 64));
-    HIPB(hipMemsetAsync(c->flag_lines, 0, 512 * 64, c->stream)); HIPB(hipMemsetAsync(c->xwg_err, 0, 64, c->stream));
+    HIPB(hipMalloc((void**)&c->flag_lines, 768 * 64)); HIPB(hipMalloc((void**)&c->xwg_err, 64));   // lines 0..255: k_attn_o's heads, 256..511: split heads' scores, 512..767: k_ffn
+    HIPB(hipMemsetAsync(c->flag_lines, 0, 768 * 64, c->stream)); HIPB(hipMemsetAsync(c->xwg_err, 0, 64, c->stream));
     HIPB(hipMalloc(&c->att_q, (size_t)d.dim * c->esz)); HIPB(hipMalloc((void**)&c->att_qs, (size_t)(d.dim / kGroup) * 4));
     HIPB(hipMalloc((void**)&c->att_sc, (size_t)c->heads_local * d.max_seq_len * 4));
     HIPB(hipMalloc((void**)&c->state, sizeof(DecodeState)));
@@ -894,6 +918,7 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (k == "use_mfma") c->use_mfma = value;
     else if (k == "use_pv_mfma") c->use_pv_mfma = value;
     else if (k == "fuse_attn_o") c->fuse_attn_o = value;
+    else if (k == "fuse_ffn") c->fuse_ffn = value;
     else if (k == "use_prefill_mq") c->use_prefill_mq = value;
     else if (k == "attn_split") c->attn_split = value;
     else if (k == "use_qk_mfma") c->use_qk_mfma = value;

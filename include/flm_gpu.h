@@ -137,6 +137,7 @@ int  flm_debug_read(flm_ctx* ctx, int what, int layer, float* out, size_t n);
 
 /* tuning knobs: "wg_per_cu" workgroups per CU for the GEMV kernels, "use_graph" hipGraph replay on/off,
  * "fuse_attn_o" 0 = attention and the Wo GEMV as two launches (default 1: one launch, single GPU),
+ * "fuse_ffn" 0 = FFN13 and FFN2 as two launches (default 1: one launch, single GPU),
  * "use_prefill" 0 = feed prompts token by token (default 1: batched), "use_prefill_mq" 0 = batched attention with one query per
  * workgroup (default 1: eight), "attn_split" 0 = one workgroup per head at every context length (default 1: hs / 32 from 128 positions on; n >= 2: always n),
  * "use_p2p" 0 = tensor-parallel exchanges by RCCL all-gathers even though the peers are mapped (1: peer to peer again),

@@ -71,7 +71,7 @@ def test_device_greedy_loop_matches_stepwise(gpu):
     assert list(ids) == step_ids
     assert list(ids) == orc_ids
     # graph on/off and attention split counts give identical tokens
-    for key, val in (("use_graph", 0), ("wg_per_cu", 1), ("wg_per_cu", 4), ("use_graph", 1), ("fuse_attn_o", 0), ("fuse_attn_o", 1)):
+    for key, val in (("use_graph", 0), ("wg_per_cu", 1), ("wg_per_cu", 4), ("use_graph", 1), ("fuse_attn_o", 0), ("fuse_ffn", 0), ("fuse_attn_o", 1), ("fuse_ffn", 1)):
         ctx.set_option(key, val); ctx.reset_kv()
         assert ctx.forward_argmax(prompt, 0) == first
         assert list(ctx.decode_greedy(first, len(prompt), n)) == list(ids)
@@ -81,7 +81,7 @@ def test_device_greedy_loop_matches_stepwise(gpu):
 @pytest.mark.parametrize("qt", [ff.QT_INT8, ff.QT_INT16])
 def test_7b_width_layer_every_code_path_vs_oracle(gpu, qt):
     """one LLaMA2-7B-width layer + the 32000-row classifier: the production pass geometry, step numbering and LDS layouts
-    (the tiny shapes use other ones), with attention + Wo fused into one launch and as two launches."""
+    (the tiny shapes use other ones), with attention + Wo and FFN13 + FFN2 fused into one launch each and as two launches."""
     cfg = synth.make_config("7B", qt); cfg.n_layers = 1
     tensors = synth.make_tensors(cfg, seed=31)
     om = O.OracleModel(cfg, tensors)
@@ -90,7 +90,7 @@ def test_7b_width_layer_every_code_path_vs_oracle(gpu, qt):
     cur, pos = int(np.argmax(want[0])), len(prompt)
     for _ in range(3):
         want.append(om.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(want[-1])); pos += 1
-    for opts in ({}, {"fuse_attn_o": 0}):
+    for opts in ({}, {"fuse_attn_o": 0}, {"fuse_ffn": 0}, {"fuse_attn_o": 0, "fuse_ffn": 0}):
         ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
         for k, v in opts.items():
             ctx.set_option(k, v)
