@@ -403,7 +403,8 @@ def main():
 
     # per-kernel times, live, HIP events on the ctx stream (eager launches, same kernels as the graph)
     kt = ctx.kernel_times(mid_pos, iters=3)
-    dom = "ffn13"
+    # the dominant launch of the token: the fused FFN13 + FFN2 kernel where the token path runs it (single GPU), else FFN13
+    dom = "ffn" if kt.get("ffn", (0.0, 0))[1] > 0 else "ffn13"
     dom_us, dom_cnt = kt[dom]
     dom_bytes = ctx.kernel_bytes(dom, mid_pos)
     achieved = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
@@ -425,7 +426,10 @@ def main():
         except Exception as e:  # noqa: BLE001
             replicas = {"value": None, "note": f"failed: {e}"}
 
-    traffic, traffic_src = pmc_traffic(r"k_gemv<2, 2, 2," if qt == ff.QT_INT8 else r"k_gemv<1, 2, 2,")
+    qn = 2 if qt == ff.QT_INT8 else 1
+    traffic, traffic_src = pmc_traffic(rf"k_ffn<{qn}," if dom == "ffn" else rf"k_gemv<{qn}, 2, 2,")
+    dom_name = (f"k_ffn<{args.quant}> (ffn13 + SwiGLU and ffn2 + residual in one launch)" if dom == "ffn"
+                else f"k_gemv<{args.quant},rmsnorm+quantize,swiglu> (ffn13)")
     if rank == 0:
         tb = token_bytes(cfg, mid_pos, esz)
         line = {
@@ -444,12 +448,13 @@ def main():
             "token_roofline": {"bytes_per_token": int(tb / tp), "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU", "pos": mid_pos,
                                "achieved": round(tb / tp * (tok_s / (world / tp)) / 1e9, 1),
                                "frac": round(tb / tp * (tok_s / (world / tp)) / 1e9 / HBM_PEAK_GBS, 4)},
-            "roofline": {"kernel": "k_gemv<int8,rmsnorm+quantize,swiglu> (ffn13)" if qt == ff.QT_INT8 else "k_gemv<int16,...> (ffn13)",
+            "roofline": {"kernel": dom_name,
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_launch": int(dom_bytes), "avg_launch_us": round(dom_us, 2), "launches_per_token": dom_cnt},
             "kernels": kernels,
-            "kernels_note": "per-class times of the stand-alone kernels (back-to-back launches); the decode loop runs attention + attn_o as one launch (k_attn_o) on a single GPU",
+            "kernels_note": "us per launch, back-to-back launches of one class between one pair of HIP events; on a single GPU the token path runs attn_wo (k_attn_o) "
+                            "instead of attn + attn_o and ffn (k_ffn) instead of ffn13 + ffn2: per token = embed + L * (qkv + attn_wo + ffn) + cls + argmax",
         }
         if replicas is not None:
             line["replicas"] = replicas

@@ -32,7 +32,7 @@ struct LayerW {
     unsigned got = 0;     // bitmask of uploaded kinds
 };
 
-enum KClass { KC_EMBED = 0, KC_QKV, KC_ATTN, KC_ATTN_O, KC_FFN13, KC_FFN2, KC_CLS, KC_ARGMAX, KC_ALLREDUCE };
+enum KClass { KC_EMBED = 0, KC_QKV, KC_ATTN, KC_ATTN_O, KC_FFN13, KC_FFN2, KC_CLS, KC_ARGMAX, KC_ALLREDUCE, KC_ATTN_WO /* k_attn_o: attention + Wo */, KC_FFN /* k_ffn: FFN13 + FFN2 */ };
 
 struct TimedLaunch { int kclass; hipEvent_t e0, e1; };
 // owners that release on every exit path (the error macros return from the middle of a function)
@@ -1178,26 +1178,35 @@ int flm_kernel_times(flm_ctx* c, int pos, int iters, float* avg_us, int32_t* cou
         case KC_FFN2:   return launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, args_ffn2(c, l), wgs);
         case KC_CLS:    return launch_gemv<PRO_RMSNORM_QUANT, EPI_STORE>(c, st, qt, args_cls(c), wgs);
         case KC_ARGMAX: hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, st, (const float*)c->logits, d.vocab_size, c->state, (int*)nullptr, 0); return FLM_OK;   // (no id is recorded: the step counter runs on)
+        // the fused launches the token path uses on a single GPU (FLM_ERR_UNSUPPORTED: this shape / option setting runs the phases separately)
+        case KC_ATTN_WO: if (!c->fuse_attn_o) return FLM_ERR_UNSUPPORTED;
+                         return qt == FLM_QT_INT8 ? launch_attn_o<QT_INT8>(c, st, l, attn_parts(c, pos + 1)) : launch_attn_o<QT_INT16>(c, st, l, attn_parts(c, pos + 1));
+        case KC_FFN:     if (!c->fuse_ffn) return FLM_ERR_UNSUPPORTED;
+                         return qt == FLM_QT_INT8 ? launch_ffn<QT_INT8>(c, st, l) : launch_ffn<QT_INT16>(c, st, l);
         default: return FLM_OK;
         }
     };
-    const int classes[] = {KC_EMBED, KC_QKV, KC_ATTN, KC_ATTN_O, KC_FFN13, KC_FFN2, KC_CLS, KC_ARGMAX};
+    const int classes[] = {KC_EMBED, KC_QKV, KC_ATTN, KC_ATTN_O, KC_FFN13, KC_FFN2, KC_CLS, KC_ARGMAX, KC_ATTN_WO, KC_FFN};
     for (int kc : classes) {
-        const bool per_layer = kc >= KC_QKV && kc <= KC_FFN2;
+        const bool fused = kc == KC_ATTN_WO || kc == KC_FFN;
+        const bool per_layer = (kc >= KC_QKV && kc <= KC_FFN2) || fused;
         const int n = per_layer ? L : 8;
         for (int it = 0; it < iters + 1 && !r; ++it) {          // first round: warm-up
-            if (kc == KC_ATTN) r = launch(KC_EMBED, 0);          // (clears the flag lines the parts of a split head wait on)
+            if (kc == KC_ATTN || fused) r = launch(KC_EMBED, 0);   // (clears the flag lines the workgroups of a fused launch / the parts of a split head wait on)
             HIPC(c, hipEventRecord(e0, st));
             for (int i = 0; i < n && !r; ++i) r = launch(kc, per_layer ? i : 0);
+            if (fused && r == FLM_ERR_UNSUPPORTED) { r = FLM_OK; cnt[kc] = 0; break; }
             HIPC(c, hipEventRecord(e1, st));
             HIPC(c, hipEventSynchronize(e1));
             float ms = 0.f; HIPC(c, hipEventElapsedTime(&ms, e0, e1));
             if (it > 0) { tot[kc] += ms * 1000.0 / n; cnt[kc] += 1; }
         }
         avg_us[kc] = cnt[kc] ? (float)(tot[kc] / cnt[kc]) : 0.f;
-        count[kc] = per_layer ? L : 1;
+        count[kc] = cnt[kc] ? (per_layer ? L : 1) : 0;
     }
-    for (int k = 0; k < FLM_KCLASSES; ++k) if (k != KC_EMBED && (k < KC_QKV || k > KC_ARGMAX)) { avg_us[k] = 0.f; count[k] = 0; }
+    avg_us[KC_ALLREDUCE] = 0.f; count[KC_ALLREDUCE] = 0;
+    if (r) return r;
+    r = xwg_check(c); if (r == FLM_RETRY) return fail(c, FLM_ERR_HIP, "cross-workgroup wait timed out while timing");
     if (r) return r;
     return flm_reset_kv(c);
 }
@@ -1213,6 +1222,8 @@ int flm_kernel_bytes(flm_ctx* c, int kclass, int pos, double* bytes) {
     case KC_ATTN_O: *bytes = mat(c->drow_count, d.dim); break;
     case KC_FFN13:  *bytes = 2.0 * mat(c->hidden_local, d.dim) + d.dim * 4.0; break;
     case KC_FFN2:   *bytes = mat(c->drow_count, d.hidden_dim); break;
+    case KC_ATTN_WO: *bytes = 2.0 * c->heads_local * c->hs * 4.0 * (pos + 1) + mat(c->drow_count, d.dim); break;
+    case KC_FFN:    *bytes = 2.0 * mat(c->hidden_local, d.dim) + d.dim * 4.0 + mat(c->drow_count, d.hidden_dim); break;
     case KC_CLS:    *bytes = mat(c->cls.rows, d.dim) + d.dim * 4.0; break;
     default:        *bytes = 0; break;
     }
