@@ -1290,7 +1290,7 @@ int flm_op_matmul_q(int qt, float* out, const void* W, const float* sW, const vo
     OPC(hipMemcpy(dW.p, W, (size_t)m * n * e, hipMemcpyHostToDevice)); OPC(hipMemcpy(dsW.p, sW, (size_t)m * sn * 4, hipMemcpyHostToDevice));
     OPC(hipMemcpy(dX.p, X, (size_t)w * n * e, hipMemcpyHostToDevice)); OPC(hipMemcpy(dsX.p, sX, (size_t)w * sn * 4, hipMemcpyHostToDevice));
     int dev = 0, cus = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const char* gv = getenv("FLM_OP_GEMM");                     // tests: 0 / 1 / 2 = launch_gemm's use_mfma, "gemv" = a GEMV per batch row
+    const char* gv = getenv("FLM_OP_GEMM");                     // tests: 0 .. 3 = launch_gemm's use_mfma, "gemv" = a GEMV per batch row
     if (w >= 16 && !(gv && !strcmp(gv, "gemv"))) {
         // the batched path the prompt takes (quant::matmul with w > 1, quant_operators.cpp:252-284): one tile kernel
         GemmArgs g{dW.p, dsW.as<float>(), dX.p, dsX.as<float>(), dO.as<float>(), m, n, m, w};
