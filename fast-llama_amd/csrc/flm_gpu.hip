@@ -25,7 +25,7 @@ namespace {
 
 thread_local std::string g_last_error;
 
-struct QMat { void* q = nullptr; float* s = nullptr; int rows = 0, cols = 0; };
+struct QMat { void* q = nullptr; float* s = nullptr; int rows = 0, cols = 0; float* st = nullptr; /* s group-major [cols / 64][rows]: the prompt path's GEMM tiles */ };
 struct LayerW {
     QMat qkv, o, w13, w2;     // w13 = [W1 (gate) ; W3 (up)] back to back: the SwiGLU GEMV walks them as one matrix
     float* att_norm = nullptr; float* ffn_norm = nullptr;
@@ -68,12 +68,13 @@ struct flm_ctx {
     int use_mfma = 1;                                  // option "use_mfma": int8 prefill GEMM on v_mfma_i32_32x32x32_i8 (0: v_dot4)
     int use_prefill = 1;                               // option "use_prefill": prompts of >= kPrefillMin+1 tokens go through the batched kernels
     int pf_cap = 0;                                    // token capacity of the batched-prefill buffers below
-    float *pf_x = nullptr, *pf_qkv = nullptr, *pf_q = nullptr, *pf_att = nullptr, *pf_gu = nullptr, *pf_hd = nullptr, *pf_xs = nullptr; void* pf_xq = nullptr;
+    float *pf_x = nullptr, *pf_qkv = nullptr, *pf_q = nullptr, *pf_att = nullptr, *pf_gu = nullptr, *pf_hd = nullptr, *pf_xs = nullptr, *pf_xst = nullptr; void* pf_xq = nullptr;
     int use_prefill_mq = 1;                            // option "use_prefill_mq": batched prefill attention with 8 queries per workgroup (0: one query per workgroup)
     int use_pv_mfma = 1;                               // option "use_pv_mfma": prefill weighted sum (softmax x V) on the matrix cores as well (needs use_qk_mfma), 0: VALU chains
     int use_qk_mfma = 1;                               // option "use_qk_mfma": prefill scores on the matrix cores (fp32 MFMA, bit-identical), 0: VALU chains inside the attention kernel
     float* pf_scores = nullptr;                        // [heads][max_seq][max_seq] prefill scores (k_qk_mfma -> k_attn_prefill_mq<true>)
     int fuse_attn_o = 1;                               // option "fuse_attn_o": attention + Wo GEMV in one launch (k_attn_o; single GPU)
+    bool st_ready = false;                             // the layer matrices' group-major scale copies (QMat::st) are up to date
     int fuse_ffn = 1;                                  // option "fuse_ffn": FFN13 + FFN2 in one launch (k_ffn; single GPU)
     unsigned* flag_lines = nullptr; int* xwg_err = nullptr;   // k_attn_o: one 64-byte flag line per head; "a cross-workgroup wait timed out"
     void* att_q = nullptr; float* att_qs = nullptr;    // k_attn_o: the heads' output already quantized (head_size a multiple of 64)
@@ -228,10 +229,11 @@ void build_rope_table(int hs, int max_seq, std::vector<float>& cs, std::vector<f
     }
 }
 
-int alloc_qmat(flm_ctx* c, QMat& m, int rows, int cols, int qt) {
+int alloc_qmat(flm_ctx* c, QMat& m, int rows, int cols, int qt, bool with_st = false) {
     m.rows = rows; m.cols = cols;
     HIPC(c, hipMalloc(&m.q, (size_t)rows * cols * esz_of(qt)));
     HIPC(c, hipMalloc((void**)&m.s, (size_t)rows * (cols / kGroup) * sizeof(float)));
+    if (with_st) HIPC(c, hipMalloc((void**)&m.st, (size_t)rows * (cols / kGroup) * sizeof(float)));
     return FLM_OK;
 }
 
@@ -550,7 +552,8 @@ int alloc_run_bufs(flm_ctx* c) {
     HIPC(c, hipMalloc((void**)&c->pf_att, cap * d.dim * 4));
     HIPC(c, hipMalloc((void**)&c->pf_gu, cap * 2 * d.hidden_dim * 4));
     HIPC(c, hipMalloc((void**)&c->pf_hd, cap * d.hidden_dim * 4));
-    HIPC(c, hipMalloc((void**)&c->pf_xs, cap * (nmax / kGroup) * 4));
+    HIPC(c, hipMalloc((void**)&c->pf_xs, 2 * cap * (nmax / kGroup) * 4 + 64));       // row-major [tokens][groups], then group-major [groups][tokens] (+ slack: the GEMM tiles read token pairs)
+    c->pf_xst = c->pf_xs + cap * (nmax / kGroup);
     HIPC(c, hipMalloc(&c->pf_xq, cap * nmax * c->esz));
     if (c->hs % 32 == 0 && c->hs <= 128) HIPC(c, hipMalloc((void**)&c->pf_scores, (size_t)c->heads_local * cap * d.max_seq_len * 4));
     c->pf_cap = (int)cap;
@@ -631,14 +634,23 @@ int prefill_batched(flm_ctx* c, int B, int pos) {
     hipStream_t st = c->stream;
     int r = B <= c->pf_cap ? FLM_OK : fail(c, FLM_ERR_INVALID, "prefill: more tokens than max_seq_len"); if (r) return r;
     const size_t kv_layer = (size_t)c->heads_local * d.max_seq_len * hs;
+    if (!c->st_ready) {   // once per set of weights: the scales group-major (no allocation: the copies' memory came with the matrices)
+        for (auto& w : c->layers)
+            for (QMat* m : {&w.qkv, &w.o, &w.w13, &w.w2}) {
+                const size_t n = (size_t)m->rows * (m->cols / kGroup);
+                hipLaunchKernelGGL(k_transpose_scales, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)m->s, m->st, m->rows, m->cols / kGroup);
+            }
+        HIPC(c, hipGetLastError());
+        c->st_ready = true;
+    }
     hipLaunchKernelGGL(k_embed_rows, dim3(B), dim3(256), 0, st, c->pf_x, (const void*)c->emb, (const float*)c->emb_s, c->emb_qt, dim, (const int*)c->prompt_dev);
     HIPC(c, hipGetLastError());
     for (int l = 0; l < L; ++l) {
         LayerW& w = c->layers[l];
         // x2 = rmsnorm(x1); qx = quantize(x2); q,k,v = W x; RoPE; cache rows   (transformer.cpp:132-135, 386-395, 431-439)
-        RowsArgs ra{c->pf_x, w.att_norm, c->pf_xq, c->pf_xs, dim};
+        RowsArgs ra{c->pf_x, w.att_norm, c->pf_xq, c->pf_xs, dim, c->pf_xst};
         r = launch_rows<QT, PRO_RMSNORM_QUANT>(c, st, ra, B); if (r) return r;
-        GemmArgs g{w.qkv.q, w.qkv.s, c->pf_xq, c->pf_xs, c->pf_qkv, 3 * dim, dim, 3 * dim, B};
+        GemmArgs g{w.qkv.q, w.qkv.s, c->pf_xq, c->pf_xs, c->pf_qkv, 3 * dim, dim, 3 * dim, B, c->pf_xst, w.qkv.st};
         r = launch_gemm<QT, EPI_STORE>(c, st, g, c->use_mfma); if (r) return r;
         hipLaunchKernelGGL(k_rope_kv_rows, dim3(B), dim3(256), 0, st, (const float*)c->pf_qkv, c->pf_q, c->kcache + (size_t)l * kv_layer, c->vcache + (size_t)l * kv_layer,
                            (const float*)c->rope_cos, (const float*)c->rope_sin, dim, hs, d.max_seq_len, pos);
@@ -669,27 +681,27 @@ int prefill_batched(flm_ctx* c, int B, int pos) {
             hipLaunchKernelGGL(k_attn_prefill, dim3(c->heads_local, B), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, hs), st, aa, pos, dim);
         HIPC(c, hipGetLastError());
         // x1 += Wo quantize(att)   (transformer.cpp:138-139, 457-466)
-        RowsArgs rq{c->pf_att, nullptr, c->pf_xq, c->pf_xs, dim};
+        RowsArgs rq{c->pf_att, nullptr, c->pf_xq, c->pf_xs, dim, c->pf_xst};
         r = launch_rows<QT, PRO_QUANT>(c, st, rq, B); if (r) return r;
-        GemmArgs go{w.o.q, w.o.s, c->pf_xq, c->pf_xs, c->pf_x, dim, dim, dim, B};
+        GemmArgs go{w.o.q, w.o.s, c->pf_xq, c->pf_xs, c->pf_x, dim, dim, dim, B, c->pf_xst, w.o.st};
         r = launch_gemm<QT, EPI_RESIDUAL>(c, st, go, c->use_mfma); if (r) return r;
         // hd = swiglu(W1 qx, W3 qx) with qx = quantize(rmsnorm(x1))   (transformer.cpp:144-147, 468-483)
-        RowsArgs rf{c->pf_x, w.ffn_norm, c->pf_xq, c->pf_xs, dim};
+        RowsArgs rf{c->pf_x, w.ffn_norm, c->pf_xq, c->pf_xs, dim, c->pf_xst};
         r = launch_rows<QT, PRO_RMSNORM_QUANT>(c, st, rf, B); if (r) return r;
         if (QT == QT_INT8 && (c->use_mfma == 3 || (c->use_mfma == 1 && ((hid + 63) / 64) * ((B + 127) / 128) >= 256))) {
             // 128 x 128 tiles of 64 gate + 64 up rows: the GEMM's epilogue is the SwiGLU
-            GemmArgs g13{w.w13.q, w.w13.s, c->pf_xq, c->pf_xs, c->pf_hd, hid, dim, hid, B};
+            GemmArgs g13{w.w13.q, w.w13.s, c->pf_xq, c->pf_xs, c->pf_hd, hid, dim, hid, B, c->pf_xst, w.w13.st};
             r = launch_gemm<QT, EPI_SWIGLU>(c, st, g13, c->use_mfma); if (r) return r;
         } else {
-            GemmArgs g13{w.w13.q, w.w13.s, c->pf_xq, c->pf_xs, c->pf_gu, 2 * hid, dim, 2 * hid, B};
+            GemmArgs g13{w.w13.q, w.w13.s, c->pf_xq, c->pf_xs, c->pf_gu, 2 * hid, dim, 2 * hid, B, c->pf_xst, w.w13.st};
             r = launch_gemm<QT, EPI_STORE>(c, st, g13, c->use_mfma); if (r) return r;
             hipLaunchKernelGGL(k_swiglu_rows, dim3(B), dim3(256), 0, st, c->pf_hd, (const float*)c->pf_gu, hid);
             HIPC(c, hipGetLastError());
         }
         // x1 += W2 quantize(hd)   (transformer.cpp:149-150, 485-494)
-        RowsArgs rh{c->pf_hd, nullptr, c->pf_xq, c->pf_xs, hid};
+        RowsArgs rh{c->pf_hd, nullptr, c->pf_xq, c->pf_xs, hid, c->pf_xst};
         r = launch_rows<QT, PRO_QUANT>(c, st, rh, B); if (r) return r;
-        GemmArgs g2{w.w2.q, w.w2.s, c->pf_xq, c->pf_xs, c->pf_x, dim, hid, dim, B};
+        GemmArgs g2{w.w2.q, w.w2.s, c->pf_xq, c->pf_xs, c->pf_x, dim, hid, dim, B, c->pf_xst, w.w2.st};
         r = launch_gemm<QT, EPI_RESIDUAL>(c, st, g2, c->use_mfma); if (r) return r;
     }
     return FLM_OK;
@@ -802,9 +814,9 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
     c->layers.resize(L);
     for (int l = 0; l < L; ++l) {
         LayerW& w = c->layers[l];
-        if (alloc_qmat(c, w.qkv, 3 * c->dim_local, d.dim, qt) || alloc_qmat(c, w.o, c->drow_count, d.dim, qt) ||
-            alloc_qmat(c, w.w13, 2 * c->hidden_local, d.dim, qt) ||
-            alloc_qmat(c, w.w2, c->drow_count, d.hidden_dim, qt)) return bail(FLM_ERR_OOM);
+        if (alloc_qmat(c, w.qkv, 3 * c->dim_local, d.dim, qt, true) || alloc_qmat(c, w.o, c->drow_count, d.dim, qt, true) ||
+            alloc_qmat(c, w.w13, 2 * c->hidden_local, d.dim, qt, true) ||
+            alloc_qmat(c, w.w2, c->drow_count, d.hidden_dim, qt, true)) return bail(FLM_ERR_OOM);
         HIPB(hipMalloc((void**)&w.att_norm, d.dim * 4)); HIPB(hipMalloc((void**)&w.ffn_norm, d.dim * 4));
     }
     if (alloc_qmat(c, c->cls, c->plan.vocab_count > 0 ? c->plan.vocab_count : 1, d.dim, qt)) return bail(FLM_ERR_OOM);
@@ -849,7 +861,7 @@ void flm_ctx_destroy(flm_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
-    auto fq = [](QMat& m) { if (m.q) hipFree(m.q); if (m.s) hipFree(m.s); };
+    auto fq = [](QMat& m) { if (m.q) hipFree(m.q); if (m.s) hipFree(m.s); if (m.st) hipFree(m.st); };
     for (auto& l : c->layers) { fq(l.qkv); fq(l.o); fq(l.w13); fq(l.w2); if (l.att_norm) hipFree(l.att_norm); if (l.ffn_norm) hipFree(l.ffn_norm); }
     fq(c->cls);
     for (int r = 0; r < c->world; ++r) if (c->peer_opened[r] && c->peer[r]) hipIpcCloseMemHandle(c->peer[r]);
@@ -940,6 +952,7 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
 }
 
 int flm_upload_tensor(flm_ctx* c, int kind, int layer, int src_qt, const void* values, const float* scales, int rows, int cols) {
+    if (c) c->st_ready = false;
     if (!c || !values) return FLM_ERR_INVALID;
     HIPC(c, hipSetDevice(c->device));
     const auto& d = c->d;
@@ -1285,15 +1298,23 @@ int flm_op_matmul_q(int qt, float* out, const void* W, const float* sW, const vo
     if (!out || !W || !sW || !X || !sX || m < 1 || n < 1 || w < 1 || gs != kGroup || n % kGroup) return FLM_ERR_INVALID;
     if (qt != FLM_QT_INT8 && qt != FLM_QT_INT16) return FLM_ERR_UNSUPPORTED;
     const size_t e = esz_of(qt), sn = n / kGroup;
-    DevBuf dW, dsW, dX, dsX, dO;
-    if (dW.alloc((size_t)m * n * e) || dsW.alloc((size_t)m * sn * 4) || dX.alloc((size_t)w * n * e) || dsX.alloc((size_t)w * sn * 4) || dO.alloc((size_t)w * m * 4)) return FLM_ERR_OOM;
+    DevBuf dW, dsW, dX, dsX, dsXT, dsWT, dO;
+    if (dW.alloc((size_t)m * n * e) || dsW.alloc((size_t)m * sn * 4) || dX.alloc((size_t)w * n * e) || dsX.alloc((size_t)w * sn * 4) || dsXT.alloc((size_t)w * sn * 4 + 64) || dsWT.alloc((size_t)m * sn * 4) || dO.alloc((size_t)w * m * 4)) return FLM_ERR_OOM;
+    {   // the activation scales once more, group-major (k_rows_prologue writes both layouts on the prompt path)
+        std::vector<float> t((size_t)w * sn);
+        for (int b = 0; b < w; ++b) for (size_t g = 0; g < sn; ++g) t[g * w + b] = sX[(size_t)b * sn + g];
+        OPC(hipMemcpy(dsXT.p, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+        std::vector<float> tw((size_t)m * sn);
+        for (int r = 0; r < m; ++r) for (size_t g = 0; g < sn; ++g) tw[g * m + r] = sW[(size_t)r * sn + g];
+        OPC(hipMemcpy(dsWT.p, tw.data(), tw.size() * 4, hipMemcpyHostToDevice));
+    }
     OPC(hipMemcpy(dW.p, W, (size_t)m * n * e, hipMemcpyHostToDevice)); OPC(hipMemcpy(dsW.p, sW, (size_t)m * sn * 4, hipMemcpyHostToDevice));
     OPC(hipMemcpy(dX.p, X, (size_t)w * n * e, hipMemcpyHostToDevice)); OPC(hipMemcpy(dsX.p, sX, (size_t)w * sn * 4, hipMemcpyHostToDevice));
     int dev = 0, cus = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const char* gv = getenv("FLM_OP_GEMM");                     // tests: 0 .. 3 = launch_gemm's use_mfma, "gemv" = a GEMV per batch row
     if (w >= 16 && !(gv && !strcmp(gv, "gemv"))) {
         // the batched path the prompt takes (quant::matmul with w > 1, quant_operators.cpp:252-284): one tile kernel
-        GemmArgs g{dW.p, dsW.as<float>(), dX.p, dsX.as<float>(), dO.as<float>(), m, n, m, w};
+        GemmArgs g{dW.p, dsW.as<float>(), dX.p, dsX.as<float>(), dO.as<float>(), m, n, m, w, dsXT.as<float>(), dsWT.as<float>()};
         const int um = gv ? atoi(gv) : 1;
         int r = qt == FLM_QT_INT8 ? launch_gemm<QT_INT8, EPI_STORE>(nullptr, 0, g, um) : launch_gemm<QT_INT16, EPI_STORE>(nullptr, 0, g, um);
         if (r) return r;

@@ -43,6 +43,7 @@ struct RowsArgs {
     const float* norm_w;     // [n] (RMSNORM_QUANT)
     void* xq; float* xs;     // [B][n] quantized, [B][n/64] scales
     int n;
+    float* xst;              // the scales once more, group-major [n/64][B] (the matrix-core GEMM tiles read 64 tokens' scales of a group as one 256-byte run); may be null
 };
 template <int QT, int PRO, int XR>
 __global__ void __launch_bounds__(kGemvBlock) k_rows_prologue(const RowsArgs r) {
@@ -59,7 +60,7 @@ __global__ void __launch_bounds__(kGemvBlock) k_rows_prologue(const RowsArgs r) 
     int4* qo = reinterpret_cast<int4*>(reinterpret_cast<char*>(r.xq) + (size_t)blockIdx.x * r.n * T::kEsz);
     for (int c = threadIdx.x; c < nb16; c += kGemvBlock) qo[c] = reinterpret_cast<const int4*>(lds)[c];
     const float* xs = reinterpret_cast<const float*>(lds + L.off_xs);
-    for (int g = threadIdx.x; g < sn; g += kGemvBlock) r.xs[(size_t)blockIdx.x * sn + g] = xs[g];
+    for (int g = threadIdx.x; g < sn; g += kGemvBlock) { r.xs[(size_t)blockIdx.x * sn + g] = xs[g]; if (r.xst) r.xst[(size_t)g * gridDim.x + blockIdx.x] = xs[g]; }
 }
 
 struct GemmArgs {
@@ -67,7 +68,14 @@ struct GemmArgs {
     const void* Xq; const float* Xs;     // [B][n], [B][n/64]
     float* out; int ldo;                 // out[b * ldo + row]
     int n, rows, B;
+    const float* XsT;                    // Xs group-major, [n/64][B] (k_gemm_q8_mfma)
+    const float* sWT;                    // sW group-major, [n/64][rows] (k_gemm_q8_mfma; SWIGLU: [n/64][2 rows])
 };
+// the group-major copy of a weight matrix's scales (made once, when the first prompt is batched)
+__global__ void k_transpose_scales(const float* s, float* st, int rows, int sn) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)rows * sn) { const int r = (int)(i / sn), g = (int)(i - (size_t)r * sn); st[(size_t)g * rows + r] = s[i]; }
+}
 // One workgroup: 64 rows x 64 tokens, thread (ty, tx) owns rows 4ty..4ty+3 x tokens 4tx..4tx+3.  Per quant group the
 // 64-row and 64-token slices (64 or 128 bytes each) go through LDS (double buffered; rows padded by 16 B: conflict-free
 // 16-byte reads), int32 dots with v_dot4 / v_dot2, then the reference's fp32 chain step for the 16 outputs of the thread.
@@ -247,15 +255,19 @@ __global__ void __launch_bounds__(64 * WT * WR, 4) k_gemm_q8_mfma(const GemmArgs
 #pragma unroll
     for (int k = 0; k < NPX; ++k) xoff[k] = (b0 + prow + (NT / 8) * k < a.B) ? (unsigned)(b0 + prow + (NT / 8) * k) * rowbytes + pch * 16 : kOOB;
     const unsigned poff = (unsigned)(prow * LS + pch * 16);
-    // scales: thread -> one slot of [W g0 (TR)][W g1 (TR)][X g0 (TT)][X g1 (TT)]; (matrix, group) is the same for a whole wave.
-    // A group past the end (odd group count) gets scale zero: fma(0 * sx, float(d), acc) = acc (acc is never -0).
+    // scales: one per thread and stage, LDS slots [W g0 (TR)][W g1 (TR)][X g0 (TT)][X g1 (TT)]; (matrix, group) is the same for a whole
+    // wave.  They come from GROUP-MAJOR copies of both scale arrays (64 rows' or tokens' scales of a group = one 256-byte run): gathered
+    // from the row-major arrays -- a cache line per lane -- these loads made twice the line requests of the tile's data and 19 % of
+    // the kernel (profiles/r02_prefill_gemm_pmc.txt, section 7).  A group past the end (odd group count) gets scale zero:
+    // fma(0 * sx, float(d), acc) = acc (acc is never -0).
     const int s_slot = wave * 64;
     const bool s_x = s_slot >= kGPS * TR;
     const int s_gi = s_x ? (s_slot - kGPS * TR) / TT : s_slot / TR;
     const int s_row = s_x ? (b0 + (s_slot - kGPS * TR) % TT + lane < a.B ? b0 + (s_slot - kGPS * TR) % TT + lane : -1) : wrow(s_slot % TR + lane);
     const unsigned s_rows = s_x ? (unsigned)a.B : (TWO ? 2u : 1u) * (unsigned)a.rows;
-    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s_x ? a.Xs : a.sW), 0, (int)(s_rows * sn * 4), 0x00020000);
-    unsigned soff = s_row >= 0 ? ((unsigned)s_row * sn + s_gi) * 4 : kOOB;
+    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s_x ? a.XsT : a.sWT), 0, (int)(s_rows * sn * 4), 0x00020000);
+    unsigned soff = s_row >= 0 ? ((unsigned)s_gi * s_rows + s_row) * 4 : kOOB;
+    const unsigned sstep = kGPS * s_rows * 4;
     const unsigned spoff = (unsigned)(kOffS + tid * 4);
     v4u wr[NPW], xr[NPX]; unsigned sr;
     auto fetch = [&](int st) {                    // stage st -> the register slot (stages past the end: the offsets have run past the rows; never consumed with a non-zero scale)
@@ -263,7 +275,7 @@ __global__ void __launch_bounds__(64 * WT * WR, 4) k_gemm_q8_mfma(const GemmArgs
         for (int k = 0; k < NPW; ++k) { wr[k] = __builtin_amdgcn_raw_buffer_load_b128(rW, (int)woff[k], 0, 0); woff[k] += SB; }
 #pragma unroll
         for (int k = 0; k < NPX; ++k) { xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rX, (int)xoff[k], 0, 0); xoff[k] += SB; }
-        sr = __builtin_amdgcn_raw_buffer_load_b32(rS, (int)(st * kGPS + s_gi < sn ? soff : kOOB), 0, 0); soff += kGPS * 4;
+        sr = __builtin_amdgcn_raw_buffer_load_b32(rS, (int)(st * kGPS + s_gi < sn ? soff : kOOB), 0, 0); soff += sstep;
     };
     auto park = [&](int buf) {
         char* base = sm + buf * kBuf;
