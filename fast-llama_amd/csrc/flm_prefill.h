@@ -68,8 +68,8 @@ struct GemmArgs {
     const void* Xq; const float* Xs;     // [B][n], [B][n/64]
     float* out; int ldo;                 // out[b * ldo + row]
     int n, rows, B;
-    const float* XsT;                    // Xs group-major, [n/64][B] (k_gemm_q8_mfma)
-    const float* sWT;                    // sW group-major, [n/64][rows] (k_gemm_q8_mfma; SWIGLU: [n/64][2 rows])
+    const float* XsT;                    // Xs group-major, [n/64][B] (the matrix-core kernels)
+    const float* sWT;                    // sW group-major, [n/64][rows] (the matrix-core kernels; SWIGLU: [n/64][2 rows])
 };
 // the group-major copy of a weight matrix's scales (made once, when the first prompt is batched)
 __global__ void k_transpose_scales(const float* s, float* st, int rows, int sn) {
@@ -403,11 +403,12 @@ __global__ void __launch_bounds__(256, 3) k_gemm_q16_mfma(const GemmArgs a) {
         xoff[k] = (b0 + prow + 32 * k < a.B)    ? (unsigned)(b0 + prow + 32 * k) * rowbytes + pch * 16 : kOOB;
     }
     const unsigned poff = (unsigned)(prow * LS + pch * 8);
-    // scales: wave 0 = the weight rows', wave 1 = the tokens' (lane = row of the tile); waves 2, 3 load nothing
+    // scales: wave 0 = the weight rows', wave 1 = the tokens' (lane = row of the tile), from the group-major copies (see k_gemm_q8_mfma);
+    // waves 2, 3 load nothing
     const bool s_x = wave == 1;
     const int s_row = (s_x ? b0 : r0) + lane, s_rows = wave < 2 ? (s_x ? a.B : a.rows) : 0;
-    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s_x ? a.Xs : a.sW), 0, (int)((unsigned)s_rows * sn * 4), 0x00020000);
-    unsigned soff = s_row < s_rows ? (unsigned)s_row * sn * 4 : kOOB;
+    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s_x ? a.XsT : a.sWT), 0, (int)((unsigned)s_rows * sn * 4), 0x00020000);
+    unsigned soff = s_row < s_rows ? (unsigned)s_row * 4 : kOOB;
     const unsigned spoff = (unsigned)(kOffS + (tid & 127) * 4);
     v4u wr[2], xr[2]; unsigned sr;
     auto fetch = [&](int g) {                     // group g -> the register slot (groups past the end: zero scale, never consumed otherwise)
@@ -416,7 +417,7 @@ __global__ void __launch_bounds__(256, 3) k_gemm_q16_mfma(const GemmArgs a) {
             wr[k] = __builtin_amdgcn_raw_buffer_load_b128(rW, (int)woff[k], 0, 0); woff[k] += GB;
             xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rX, (int)xoff[k], 0, 0); xoff[k] += GB;
         }
-        sr = __builtin_amdgcn_raw_buffer_load_b32(rS, (int)(g < sn ? soff : kOOB), 0, 0); soff += 4;
+        sr = __builtin_amdgcn_raw_buffer_load_b32(rS, (int)(g < sn ? soff : kOOB), 0, 0); soff += (unsigned)s_rows * 4;
     };
     auto park = [&](int buf) {
         char* base = sm + buf * kBuf;
