@@ -606,6 +606,7 @@ int launch_gemm(flm_ctx* c, hipStream_t st, const GemmArgs& g, int use_mfma) {
             HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_q8_mfma<EPI_STORE, 4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Big::kLds));
             HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_q8_mfma<EPI_RESIDUAL, 4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Big::kLds));
             HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_q8_mfma<EPI_SWIGLU, 4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Big::kLds));
+            HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_q8_mfma<EPI_ROPE_KV, 4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Big::kLds));
         }
         if constexpr (EPI == EPI_SWIGLU) {   // g.rows = hidden: a tile = 64 rows of W1 and of W3 (gemm_fuses_swiglu decides)
             const int tiles = ((g.rows + Big::TR / 2 - 1) / (Big::TR / 2)) * ((g.B + Big::TT - 1) / Big::TT);
@@ -620,7 +621,7 @@ int launch_gemm(flm_ctx* c, hipStream_t st, const GemmArgs& g, int use_mfma) {
         else hipLaunchKernelGGL((k_gemm_q8_mfma<EPI, 2, 2, 1>), dim3(tiles), dim3(Small::NT), Small::kLds, st, g);
         }
     }
-    else if constexpr (EPI == EPI_SWIGLU) return fail(c, FLM_ERR_INVALID, "launch_gemm: the SwiGLU epilogue exists for the int8 matrix-core tiles only");
+    else if constexpr (EPI == EPI_SWIGLU || EPI == EPI_ROPE_KV) return fail(c, FLM_ERR_INVALID, "launch_gemm: the SwiGLU / RoPE epilogues exist for the int8 matrix-core tiles only");
     else if (QT == QT_INT16 && use_mfma) hipLaunchKernelGGL((k_gemm_q16_mfma<EPI>), dim3(tiles), dim3(256), Gemm16Tile::kLds, st, g);   // hi / lo byte planes on the int8 matrix cores
     else hipLaunchKernelGGL((k_gemm_q<QT, EPI>), dim3(tiles), dim3(256), 0, st, g);
     HIPC(c, hipGetLastError());
@@ -651,10 +652,17 @@ int prefill_batched(flm_ctx* c, int B, int pos) {
         RowsArgs ra{c->pf_x, w.att_norm, c->pf_xq, c->pf_xs, dim, c->pf_xst};
         r = launch_rows<QT, PRO_RMSNORM_QUANT>(c, st, ra, B); if (r) return r;
         GemmArgs g{w.qkv.q, w.qkv.s, c->pf_xq, c->pf_xs, c->pf_qkv, 3 * dim, dim, 3 * dim, B, c->pf_xst, w.qkv.st};
-        r = launch_gemm<QT, EPI_STORE>(c, st, g, c->use_mfma); if (r) return r;
-        hipLaunchKernelGGL(k_rope_kv_rows, dim3(B), dim3(256), 0, st, (const float*)c->pf_qkv, c->pf_q, c->kcache + (size_t)l * kv_layer, c->vcache + (size_t)l * kv_layer,
-                           (const float*)c->rope_cos, (const float*)c->rope_sin, dim, hs, d.max_seq_len, pos);
-        HIPC(c, hipGetLastError());
+        if (QT == QT_INT8 && c->use_mfma && dim % 32 == 0 && hs % 2 == 0) {
+            // RoPE and the cache rows as the epilogue of the matrix-core tiles: no [tokens][3 dim] round trip, no k_rope_kv_rows
+            g.qout = c->pf_q; g.kcache = c->kcache + (size_t)l * kv_layer; g.vcache = c->vcache + (size_t)l * kv_layer;
+            g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.dim = dim; g.hs = hs; g.max_seq = d.max_seq_len; g.pos0 = pos;
+            r = launch_gemm<QT, EPI_ROPE_KV>(c, st, g, c->use_mfma); if (r) return r;
+        } else {
+            r = launch_gemm<QT, EPI_STORE>(c, st, g, c->use_mfma); if (r) return r;
+            hipLaunchKernelGGL(k_rope_kv_rows, dim3(B), dim3(256), 0, st, (const float*)c->pf_qkv, c->pf_q, c->kcache + (size_t)l * kv_layer, c->vcache + (size_t)l * kv_layer,
+                               (const float*)c->rope_cos, (const float*)c->rope_sin, dim, hs, d.max_seq_len, pos);
+            HIPC(c, hipGetLastError());
+        }
         if (l == L - 1) break;                            // the batch only has to fill the cache: nothing downstream of the last layer's K/V is needed
         // attention of every query over the cache rows 0 .. its own position   (execute_attn :441-449)
         AttnArgs aa{}; aa.q = c->pf_q; aa.kcache = c->kcache + (size_t)l * kv_layer; aa.vcache = c->vcache + (size_t)l * kv_layer;

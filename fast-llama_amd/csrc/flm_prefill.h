@@ -70,6 +70,9 @@ struct GemmArgs {
     int n, rows, B;
     const float* XsT;                    // Xs group-major, [n/64][B] (the matrix-core kernels)
     const float* sWT;                    // sW group-major, [n/64][rows] (the matrix-core kernels; SWIGLU: [n/64][2 rows])
+    // EPI_ROPE_KV (the qkv GEMM of k_gemm_q8_mfma): rows [0, dim) = q, [dim, 2 dim) = k, [2 dim, 3 dim) = v of token b at position pos0 + b;
+    // RoPE on q and k (rope_v2 pairs), q -> qout[b][dim], k / v -> the layer's cache rows (what k_rope_kv_rows does after a plain store)
+    float* qout; float* kcache; float* vcache; const float* rope_cos; const float* rope_sin; int dim, hs, max_seq, pos0;
 };
 // the group-major copy of a weight matrix's scales (made once, when the first prompt is batched)
 __global__ void k_transpose_scales(const float* s, float* st, int rows, int sn) {
@@ -329,7 +332,28 @@ __global__ void __launch_bounds__(64 * WT * WR, 4) k_gemm_q8_mfma(const GemmArgs
         park((st & 1) ^ 1); fetch(st + 2);        // unconditional: a stage past the end is parked and never read with a non-zero scale
         __syncthreads();
     }
-    if constexpr (TWO) {
+    if constexpr (EPI == EPI_ROPE_KV) {
+        // a fragment's 32 rows lie inside one of q / k / v (dim is a multiple of 32) and a RoPE pair (rows 2i, 2i + 1) in neighbouring lanes
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int row = r0 + wr0 + j * 32 + l31, which = row / a.dim, within = row - which * a.dim, hh = within / a.hs, dd = within - hh * a.hs;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int b = b0 + wt0 + (i & 3) + 8 * (i >> 2) + 4 * h, pos = a.pos0 + b;
+                const float mine = acc[j][i], other = __shfl_xor(mine, 1, 64);
+                if (row >= a.rows || b >= a.B) continue;
+                float v = mine;
+                if (which < 2) {
+                    const float c = a.rope_cos[(size_t)pos * (a.hs / 2) + dd / 2], sn_ = a.rope_sin[(size_t)pos * (a.hs / 2) + dd / 2];
+                    float o0, o1;
+                    rope_pair((lane & 1) ? other : mine, (lane & 1) ? mine : other, c, sn_, o0, o1);
+                    v = (lane & 1) ? o1 : o0;
+                }
+                if (which == 0) a.qout[(size_t)b * a.dim + within] = v;
+                else (which == 1 ? a.kcache : a.vcache)[((size_t)hh * a.max_seq + pos) * a.hs + dd] = v;
+            }
+        }
+    } else if constexpr (TWO) {
         const int row = r0 + wr0 + l31;
         if (row < a.rows) {
 #pragma unroll
