@@ -17,6 +17,7 @@
 
 #include <map>
 #include <string>
+#include <mutex>
 #include <vector>
 
 using namespace flm;
@@ -600,13 +601,17 @@ int launch_gemm(flm_ctx* c, hipStream_t st, const GemmArgs& g, int use_mfma) {
     const int tiles = ((g.rows + 63) / 64) * ((g.B + 63) / 64);
     if (QT == QT_INT8 && use_mfma) {   // exact int32 group dots on v_mfma_i32_32x32x32_i8
         using Big = GemmTile<4, 2, 2>; using Small = GemmTile<2, 2, 1>;
-        static bool once = false;
-        if (!once) {   // 128 x 128 tiles stage 76 KiB
-            once = true;
-            HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_q8_mfma<EPI_STORE, 4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Big::kLds));
-            HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_q8_mfma<EPI_RESIDUAL, 4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Big::kLds));
-            HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_q8_mfma<EPI_SWIGLU, 4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Big::kLds));
-            HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_q8_mfma<EPI_ROPE_KV, 4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Big::kLds));
+        {   // the 128 x 128 tiles stage 76 KiB of LDS: raise the kernels' dynamic-LDS limit, once per device
+            static std::mutex mu; static bool done[64] = {false};
+            int dev = 0; HIPC(c, hipGetDevice(&dev));
+            std::lock_guard<std::mutex> lk(mu);
+            if (dev >= 0 && dev < 64 && !done[dev]) {
+                HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_q8_mfma<EPI_STORE, 4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Big::kLds));
+                HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_q8_mfma<EPI_RESIDUAL, 4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Big::kLds));
+                HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_q8_mfma<EPI_SWIGLU, 4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Big::kLds));
+                HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_q8_mfma<EPI_ROPE_KV, 4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Big::kLds));
+                done[dev] = true;
+            }
         }
         if constexpr (EPI == EPI_SWIGLU) {   // g.rows = hidden: a tile = 64 rows of W1 and of W3 (gemm_fuses_swiglu decides)
             const int tiles = ((g.rows + Big::TR / 2 - 1) / (Big::TR / 2)) * ((g.B + Big::TT - 1) / Big::TT);
