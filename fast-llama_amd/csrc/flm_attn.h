@@ -134,12 +134,13 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
 #pragma unroll
     for (int u = 0; u < D; ++u) request(rK, sb + u, se, prow, goff, ringK[u]);
     if constexpr (SPLIT) {
-        // piece f = tid + j * 1024 of the slice: row f / 8, 16-byte column f % 8.  The first half of the slice (rows < 512) now, the
-        // second half when the K ring's registers are free (behind the scores; it lands under the exchange and the softmax): all of
-        // it at once is 4 registers more than a 1024-thread workgroup has
+        // a thread's pieces: the 16-byte column tid % 8 of the rows 4 (tid / 8) + (j % 4) + 512 (j / 4) -- four CONSECUTIVE rows per half, so
+        // that the transposed parking below writes four positions of a dimension with one 16-byte store.  The first half of the slice
+        // (rows < 512) now, the second half when the K ring's registers are free (behind the scores; it lands under the exchange and
+        // the softmax): all of it at once is 4 registers more than a 1024-thread workgroup has
 #pragma unroll
         for (int j = 0; j < kSplitVRegs / 2; ++j) {
-            const int row = (tid >> 3) + j * (kAttnBlock >> 3);
+            const int row = 4 * (tid >> 3) + (j & 3) + (kSplitMaxSeq / 2) * (j >> 2);
             const unsigned off = row < T ? (unsigned)((row * hs + d0 + (tid & 7) * 4) * 4) : 0x80000000u;
             vall[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rV, (int)off, 0, COH ? kAuxCoherent : 0));
         }
@@ -208,7 +209,7 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
     if constexpr (SPLIT) {
 #pragma unroll
         for (int j = kSplitVRegs / 2; j < kSplitVRegs; ++j) {
-            const int row = (tid >> 3) + j * (kAttnBlock >> 3);
+            const int row = 4 * (tid >> 3) + (j & 3) + (kSplitMaxSeq / 2) * (j >> 2);
             const unsigned off = row < T ? (unsigned)((row * hs + d0 + (tid & 7) * 4) * 4) : 0x80000000u;
             vall[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rV, (int)off, 0, COH ? kAuxCoherent : 0));
         }
@@ -318,12 +319,17 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
             for (int t = tid; t < T; t += kAttnBlock) zero_w = zero_w || (t > 0 && sc[t] == 0.f);
             if (zero_w) red[20] = 0.f;                              // some row is skipped: the chain takes the careful path
         }
+        static_assert(kSplitVRegs == 8, "two halves of four consecutive rows per thread");
 #pragma unroll
-        for (int j = 0; j < kSplitVRegs; ++j) {
-            const int row = (tid >> 3) + j * (kAttnBlock >> 3);
-            if (row < T) {
-                float* dst = tile0 + (tid & 7) * 4 * VS + row;
-                dst[0] = vall[j].x; dst[VS] = vall[j].y; dst[2 * VS] = vall[j].z; dst[3 * VS] = vall[j].w;
+        for (int hh = 0; hh < 2; ++hh) {                            // 4 rows x 4 dimensions in registers -> 4 dimensions x 4 positions: four 16-byte stores
+            const int p0 = 4 * (tid >> 3) + (kSplitMaxSeq / 2) * hh;     // (rows past T were never loaded: zeros)
+            if (p0 < T) {
+                float* dst = tile0 + (tid & 7) * 4 * VS + p0;
+                const v4f r0 = vall[4 * hh], r1 = vall[4 * hh + 1], r2 = vall[4 * hh + 2], r3 = vall[4 * hh + 3];
+                *reinterpret_cast<float4*>(dst)          = make_float4(r0.x, r1.x, r2.x, r3.x);
+                *reinterpret_cast<float4*>(dst + VS)     = make_float4(r0.y, r1.y, r2.y, r3.y);
+                *reinterpret_cast<float4*>(dst + 2 * VS) = make_float4(r0.z, r1.z, r2.z, r3.z);
+                *reinterpret_cast<float4*>(dst + 3 * VS) = make_float4(r0.w, r1.w, r2.w, r3.w);
             }
         }
         __syncthreads();
