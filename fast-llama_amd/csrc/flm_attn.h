@@ -1,4 +1,5 @@
-// flm_attn.h -- single-query attention (attn_head, k_attn_decode, k_attn_prefill) and the fused attention + Wo launch (k_attn_o).
+// flm_attn.h -- single-query attention (attn_head, k_attn_decode, k_attn_prefill), prompt attention on the fp32 matrix cores (k_qk_mfma,
+// k_attn_pv_mfma) and on VALU chains (k_attn_prefill_mq), and the fused launches of the decode path (k_attn_o: attention + Wo; k_ffn: FFN13 + FFN2).
 // Part of flm_kernels.h (hand-written gfx950 / CDNA4 kernels of the fast-llama per-token hot path); include that header.
 #pragma once
 #include "flm_math.h"

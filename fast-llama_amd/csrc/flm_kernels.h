@@ -15,13 +15,16 @@
 //   * attention : q.k as 8 strided lanes + sequential lane sum; glibc-exact expf; sequential softmax
 //                 sum; weighted V sum sequential over positions
 //
-// Kernel inventory (one decode token = embed + L x {qkv, attention + attn_o, ffn13, ffn2} + cls + argmax):
+// Kernel inventory (one decode token on a single GPU = embed + L x {qkv, attention + attn_o, ffn13 + ffn2} + cls + argmax):
 //   k_gemv<QT,PRO,EPI,XR> group-quantized GEMV, HBM-bound; fused prologue (rmsnorm+quantize | quantize)
 //                         and epilogue (store | residual add | SwiGLU | RoPE + KV-cache append)
-//   k_attn_decode         fp32 single-query attention over the fp32 KV cache
+//   k_attn_decode         fp32 single-query attention over the fp32 KV cache (heads split over workgroups at long contexts)
 //   k_attn_o<QT,XR,PREQ>  attention heads and the Wo GEMV in one launch (single GPU)
-//   k_rows_prologue, k_gemm_q8_mfma / k_gemm_q, k_rope_kv_rows, k_attn_prefill, k_swiglu_rows: batched prompt processing
-//   k_embed, k_argmax_advance
+//   k_ffn<QT,XR2>         FFN13 (+ SwiGLU) and FFN2 (+ residual) in one launch (single GPU)
+//   batched prompt processing: k_rows_prologue, k_gemm_q8_mfma<EPI,WT,WR,NB> / k_gemm_q16_mfma (int8 matrix cores; epilogues store |
+//                         residual | SwiGLU | RoPE + KV rows) / k_gemm_q (v_dot), k_qk_mfma + k_attn_pv_mfma (fp32 matrix cores) /
+//                         k_attn_prefill_mq (VALU), k_rope_kv_rows, k_swiglu_rows
+//   k_embed, k_argmax_advance, k_xchg (tensor-parallel exchange)
 // plus small op-level kernels that expose the same __device__ functions to the parity tests.
 //
 // The code lives in: flm_math.h (exact scalar / wave building blocks), flm_gemv.h, flm_attn.h, flm_prefill.h, flm_misc.h.
