@@ -814,7 +814,17 @@ __global__ void __launch_bounds__(256) k_attn_pv_mfma(const AttnArgs a, int pos0
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int q = 4 * c + reg;
-            if (q < nq) *reinterpret_cast<float2*>(a.out + (size_t)(q0 + q) * row_stride + (size_t)h * hs + d0) = make_float2(acc0[reg], acc1[reg]);
+            if (q < nq) {
+                const size_t idx = (size_t)(q0 + q) * row_stride + (size_t)h * hs + d0;
+                if (a.n_peer == 0) *reinterpret_cast<float2*>(a.out + idx) = make_float2(acc0[reg], acc1[reg]);
+                else {   // tensor parallel: the local heads' columns of every rank's exchange region
+                    st_agent(a.out + idx, acc0[reg]); st_agent(a.out + idx + 1, acc1[reg]);
+                    for (int i = 0; i < a.n_peer; ++i) {
+                        __hip_atomic_store(a.out_peer[i] + idx, acc0[reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_store(a.out_peer[i] + idx + 1, acc1[reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
+            }
         }
     }
 }

@@ -69,6 +69,7 @@ struct flm_ctx {
     int use_mfma = 1;                                  // option "use_mfma": int8 prefill GEMM on v_mfma_i32_32x32x32_i8 (0: v_dot4)
     int use_prefill = 1;                               // option "use_prefill": prompts of >= kPrefillMin+1 tokens go through the batched kernels
     int pf_cap = 0;                                    // token capacity of the batched-prefill buffers below
+    bool pf_in_xbuf = false;                           // tensor parallel: pf_x / pf_att / pf_hd are regions of the exchange buffer (peers store into them)
     float *pf_x = nullptr, *pf_qkv = nullptr, *pf_q = nullptr, *pf_att = nullptr, *pf_gu = nullptr, *pf_hd = nullptr, *pf_xs = nullptr, *pf_xst = nullptr; void* pf_xq = nullptr;
     int use_prefill_mq = 1;                            // option "use_prefill_mq": batched prefill attention with 8 queries per workgroup (0: one query per workgroup)
     int use_pv_mfma = 1;                               // option "use_pv_mfma": prefill weighted sum (softmax x V) on the matrix cores as well (needs use_qk_mfma), 0: VALU chains
@@ -545,14 +546,16 @@ int alloc_run_bufs(flm_ctx* c) {
     c->prompt_cap = d.max_seq_len; c->out_cap = d.max_seq_len;
     HIPC(c, hipMalloc((void**)&c->prompt_dev, sizeof(int) * c->prompt_cap));
     HIPC(c, hipMalloc((void**)&c->out_tokens_dev, sizeof(int) * c->out_cap));
-    if (c->world != 1) return FLM_OK;                                    // batched prefill is single-GPU
+    // (tensor parallel: the full-width activations are regions of the exchange buffer, the rest is this rank's shard)
     const size_t cap = d.max_seq_len < 64 ? 64 : (size_t)d.max_seq_len, nmax = d.hidden_dim > d.dim ? d.hidden_dim : d.dim;
-    HIPC(c, hipMalloc((void**)&c->pf_x, cap * d.dim * 4));
-    HIPC(c, hipMalloc((void**)&c->pf_qkv, cap * 3 * d.dim * 4));
-    HIPC(c, hipMalloc((void**)&c->pf_q, cap * d.dim * 4));
-    HIPC(c, hipMalloc((void**)&c->pf_att, cap * d.dim * 4));
-    HIPC(c, hipMalloc((void**)&c->pf_gu, cap * 2 * d.hidden_dim * 4));
-    HIPC(c, hipMalloc((void**)&c->pf_hd, cap * d.hidden_dim * 4));
+    if (!c->pf_in_xbuf) {
+        HIPC(c, hipMalloc((void**)&c->pf_x, cap * d.dim * 4));
+        HIPC(c, hipMalloc((void**)&c->pf_att, cap * d.dim * 4));
+        HIPC(c, hipMalloc((void**)&c->pf_hd, cap * d.hidden_dim * 4));
+    }
+    HIPC(c, hipMalloc((void**)&c->pf_qkv, cap * 3 * c->dim_local * 4));
+    HIPC(c, hipMalloc((void**)&c->pf_q, cap * c->dim_local * 4));
+    HIPC(c, hipMalloc((void**)&c->pf_gu, cap * 2 * c->hidden_local * 4));
     HIPC(c, hipMalloc((void**)&c->pf_xs, 2 * cap * (nmax / kGroup) * 4 + 64));       // row-major [tokens][groups], then group-major [groups][tokens] (+ slack: the GEMM tiles read token pairs)
     c->pf_xst = c->pf_xs + cap * (nmax / kGroup);
     HIPC(c, hipMalloc(&c->pf_xq, cap * nmax * c->esz));
@@ -586,10 +589,15 @@ int check_ready(flm_ctx* c, int n, int pos) {
 constexpr int kPrefillMin = 4;
 
 template <int QT, int PRO>
-int launch_rows(flm_ctx* c, hipStream_t st, const RowsArgs& r, int B) {
+int launch_rows(flm_ctx* c, hipStream_t st, const RowsArgs& r, int B, bool coh = false) {
     const size_t lds = (size_t)gemv_lds_layout(r.n, QTraits<QT>::kEsz, true, 4, 4, false).total;
     const int rounds = (r.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4);
-    if (rounds <= 1)      hipLaunchKernelGGL((k_rows_prologue<QT, PRO, 1>), dim3(B), dim3(kGemvBlock), lds, st, r);
+    if (coh) {   // the rows lie in the exchange buffer and were partly written by peer GPUs
+        if (rounds <= 1)      hipLaunchKernelGGL((k_rows_prologue<QT, PRO, 1, true>), dim3(B), dim3(kGemvBlock), lds, st, r);
+        else if (rounds <= 3) hipLaunchKernelGGL((k_rows_prologue<QT, PRO, 3, true>), dim3(B), dim3(kGemvBlock), lds, st, r);
+        else                  hipLaunchKernelGGL((k_rows_prologue<QT, PRO, 0, true>), dim3(B), dim3(kGemvBlock), lds, st, r);
+    }
+    else if (rounds <= 1) hipLaunchKernelGGL((k_rows_prologue<QT, PRO, 1>), dim3(B), dim3(kGemvBlock), lds, st, r);
     else if (rounds <= 3) hipLaunchKernelGGL((k_rows_prologue<QT, PRO, 3>), dim3(B), dim3(kGemvBlock), lds, st, r);
     else                  hipLaunchKernelGGL((k_rows_prologue<QT, PRO, 0>), dim3(B), dim3(kGemvBlock), lds, st, r);
     HIPC(c, hipGetLastError());
@@ -649,38 +657,46 @@ int prefill_batched(flm_ctx* c, int B, int pos) {
         HIPC(c, hipGetLastError());
         c->st_ready = true;
     }
+    // Tensor parallel (peer-to-peer; int8 matrix-core kernels): this rank's heads / rows / hidden slice of every step, as in the decode path
+    // (split_rows, transformer.cpp:264-287); the attention output, the residual stream and hd are full-width in every rank's exchange
+    // region: the kernel that produces a column slice stores it into all of them, a flag round (k_xchg) closes the step, the row
+    // prologues read with coherent loads.  Single GPU: dimL == dim, slices = everything, no peers.
+    const bool tp = c->world > 1;
+    const int dimL = c->dim_local, hidL = c->hidden_local, col_o = c->drow_begin, rows_o = c->drow_count, col_h = c->plan.hidden_begin, col_a = c->plan.head_begin * hs;
+    auto peers = [&](GemmArgs& g, float* p) { g.n_peer = 0; if (tp) { const size_t off = (char*)p - c->xbuf; for (int r2 = 0; r2 < c->world; ++r2) if (r2 != c->rank) g.out_peer[g.n_peer++] = (float*)(c->peer[r2] + off); } };
     hipLaunchKernelGGL(k_embed_rows, dim3(B), dim3(256), 0, st, c->pf_x, (const void*)c->emb, (const float*)c->emb_s, c->emb_qt, dim, (const int*)c->prompt_dev);
     HIPC(c, hipGetLastError());
     for (int l = 0; l < L; ++l) {
         LayerW& w = c->layers[l];
         // x2 = rmsnorm(x1); qx = quantize(x2); q,k,v = W x; RoPE; cache rows   (transformer.cpp:132-135, 386-395, 431-439)
         RowsArgs ra{c->pf_x, w.att_norm, c->pf_xq, c->pf_xs, dim, c->pf_xst};
-        r = launch_rows<QT, PRO_RMSNORM_QUANT>(c, st, ra, B); if (r) return r;
-        GemmArgs g{w.qkv.q, w.qkv.s, c->pf_xq, c->pf_xs, c->pf_qkv, 3 * dim, dim, 3 * dim, B, c->pf_xst, w.qkv.st};
-        if (QT == QT_INT8 && c->use_mfma && dim % 32 == 0 && hs % 2 == 0) {
+        r = launch_rows<QT, PRO_RMSNORM_QUANT>(c, st, ra, B, tp); if (r) return r;
+        GemmArgs g{w.qkv.q, w.qkv.s, c->pf_xq, c->pf_xs, c->pf_qkv, 3 * dimL, dim, 3 * dimL, B, c->pf_xst, w.qkv.st};
+        if (QT == QT_INT8 && c->use_mfma && dimL % 32 == 0 && hs % 2 == 0) {
             // RoPE and the cache rows as the epilogue of the matrix-core tiles: no [tokens][3 dim] round trip, no k_rope_kv_rows
             g.qout = c->pf_q; g.kcache = c->kcache + (size_t)l * kv_layer; g.vcache = c->vcache + (size_t)l * kv_layer;
-            g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.dim = dim; g.hs = hs; g.max_seq = d.max_seq_len; g.pos0 = pos;
+            g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.dim = dimL; g.hs = hs; g.max_seq = d.max_seq_len; g.pos0 = pos;
             r = launch_gemm<QT, EPI_ROPE_KV>(c, st, g, c->use_mfma); if (r) return r;
         } else {
             r = launch_gemm<QT, EPI_STORE>(c, st, g, c->use_mfma); if (r) return r;
             hipLaunchKernelGGL(k_rope_kv_rows, dim3(B), dim3(256), 0, st, (const float*)c->pf_qkv, c->pf_q, c->kcache + (size_t)l * kv_layer, c->vcache + (size_t)l * kv_layer,
-                               (const float*)c->rope_cos, (const float*)c->rope_sin, dim, hs, d.max_seq_len, pos);
+                               (const float*)c->rope_cos, (const float*)c->rope_sin, dimL, hs, d.max_seq_len, pos);
             HIPC(c, hipGetLastError());
         }
         if (l == L - 1) break;                            // the batch only has to fill the cache: nothing downstream of the last layer's K/V is needed
-        // attention of every query over the cache rows 0 .. its own position   (execute_attn :441-449)
+        // attention of every query over the cache rows 0 .. its own position   (execute_attn :441-449): the local heads' columns of att
         AttnArgs aa{}; aa.q = c->pf_q; aa.kcache = c->kcache + (size_t)l * kv_layer; aa.vcache = c->vcache + (size_t)l * kv_layer;
-        aa.out = c->pf_att; aa.pos_ptr = &c->state->pos; aa.hs = hs; aa.max_seq = d.max_seq_len;
+        aa.out = c->pf_att + col_a; aa.pos_ptr = &c->state->pos; aa.hs = hs; aa.max_seq = d.max_seq_len;
+        if (tp) { const size_t off = (char*)aa.out - c->xbuf; for (int r2 = 0; r2 < c->world; ++r2) if (r2 != c->rank) aa.out_peer[aa.n_peer++] = (float*)(c->peer[r2] + off); }
         if (hs <= 128 && c->use_prefill_mq && c->use_qk_mfma && c->pf_scores) {
             // scores on the matrix cores (fp32 MFMA = the reference's chains, bit for bit), then softmax + weighted sum per 8 queries
             aa.sc_global = c->pf_scores;
             const dim3 gq(c->heads_local, (B + kQkQ - 1) / kQkQ);
             switch (hs >> 5) {
-            case 1: hipLaunchKernelGGL(k_qk_mfma<1>, gq, dim3(256), 0, st, aa, pos, dim, B); break;
-            case 2: hipLaunchKernelGGL(k_qk_mfma<2>, gq, dim3(256), 0, st, aa, pos, dim, B); break;
-            case 3: hipLaunchKernelGGL(k_qk_mfma<3>, gq, dim3(256), 0, st, aa, pos, dim, B); break;
-            default: hipLaunchKernelGGL(k_qk_mfma<4>, gq, dim3(256), 0, st, aa, pos, dim, B); break;
+            case 1: hipLaunchKernelGGL(k_qk_mfma<1>, gq, dim3(256), 0, st, aa, pos, dimL, B); break;
+            case 2: hipLaunchKernelGGL(k_qk_mfma<2>, gq, dim3(256), 0, st, aa, pos, dimL, B); break;
+            case 3: hipLaunchKernelGGL(k_qk_mfma<3>, gq, dim3(256), 0, st, aa, pos, dimL, B); break;
+            default: hipLaunchKernelGGL(k_qk_mfma<4>, gq, dim3(256), 0, st, aa, pos, dimL, B); break;
             }
             HIPC(c, hipGetLastError());
             if (c->use_pv_mfma && (hs & 1) == 0)   // ... and the weighted sum too (an accumulator element = the reference's chain of one (query, dimension))
@@ -693,17 +709,21 @@ int prefill_batched(flm_ctx* c, int B, int pos) {
         else
             hipLaunchKernelGGL(k_attn_prefill, dim3(c->heads_local, B), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, hs), st, aa, pos, dim);
         HIPC(c, hipGetLastError());
-        // x1 += Wo quantize(att)   (transformer.cpp:138-139, 457-466)
+        if (tp) { r = exchange(c, st, XK_ATT, nullptr, nullptr, 0); if (r) return r; }
+        // x1 += Wo quantize(att)   (transformer.cpp:138-139, 457-466): this rank's rows of Wo = its columns of x1
         RowsArgs rq{c->pf_att, nullptr, c->pf_xq, c->pf_xs, dim, c->pf_xst};
-        r = launch_rows<QT, PRO_QUANT>(c, st, rq, B); if (r) return r;
-        GemmArgs go{w.o.q, w.o.s, c->pf_xq, c->pf_xs, c->pf_x, dim, dim, dim, B, c->pf_xst, w.o.st};
+        r = launch_rows<QT, PRO_QUANT>(c, st, rq, B, tp); if (r) return r;
+        GemmArgs go{w.o.q, w.o.s, c->pf_xq, c->pf_xs, c->pf_x + col_o, dim, dim, rows_o, B, c->pf_xst, w.o.st};
+        peers(go, go.out);
         r = launch_gemm<QT, EPI_RESIDUAL>(c, st, go, c->use_mfma); if (r) return r;
-        // hd = swiglu(W1 qx, W3 qx) with qx = quantize(rmsnorm(x1))   (transformer.cpp:144-147, 468-483)
+        if (tp) { r = exchange(c, st, XK_X1, nullptr, nullptr, 0); if (r) return r; }
+        // hd = swiglu(W1 qx, W3 qx) with qx = quantize(rmsnorm(x1))   (transformer.cpp:144-147, 468-483): this rank's slice of hd
         RowsArgs rf{c->pf_x, w.ffn_norm, c->pf_xq, c->pf_xs, dim, c->pf_xst};
-        r = launch_rows<QT, PRO_RMSNORM_QUANT>(c, st, rf, B); if (r) return r;
-        if (QT == QT_INT8 && (c->use_mfma == 3 || (c->use_mfma == 1 && ((hid + 63) / 64) * ((B + 127) / 128) >= 256))) {
+        r = launch_rows<QT, PRO_RMSNORM_QUANT>(c, st, rf, B, tp); if (r) return r;
+        if (QT == QT_INT8 && (tp || c->use_mfma == 3 || (c->use_mfma == 1 && ((hidL + 63) / 64) * ((B + 127) / 128) >= 256))) {
             // 128 x 128 tiles of 64 gate + 64 up rows: the GEMM's epilogue is the SwiGLU
-            GemmArgs g13{w.w13.q, w.w13.s, c->pf_xq, c->pf_xs, c->pf_hd, hid, dim, hid, B, c->pf_xst, w.w13.st};
+            GemmArgs g13{w.w13.q, w.w13.s, c->pf_xq, c->pf_xs, c->pf_hd + col_h, hid, dim, hidL, B, c->pf_xst, w.w13.st};
+            peers(g13, g13.out);
             r = launch_gemm<QT, EPI_SWIGLU>(c, st, g13, c->use_mfma); if (r) return r;
         } else {
             GemmArgs g13{w.w13.q, w.w13.s, c->pf_xq, c->pf_xs, c->pf_gu, 2 * hid, dim, 2 * hid, B, c->pf_xst, w.w13.st};
@@ -711,11 +731,14 @@ int prefill_batched(flm_ctx* c, int B, int pos) {
             hipLaunchKernelGGL(k_swiglu_rows, dim3(B), dim3(256), 0, st, c->pf_hd, (const float*)c->pf_gu, hid);
             HIPC(c, hipGetLastError());
         }
+        if (tp) { r = exchange(c, st, XK_HD, nullptr, nullptr, 0); if (r) return r; }
         // x1 += W2 quantize(hd)   (transformer.cpp:149-150, 485-494)
         RowsArgs rh{c->pf_hd, nullptr, c->pf_xq, c->pf_xs, hid, c->pf_xst};
-        r = launch_rows<QT, PRO_QUANT>(c, st, rh, B); if (r) return r;
-        GemmArgs g2{w.w2.q, w.w2.s, c->pf_xq, c->pf_xs, c->pf_x, dim, hid, dim, B, c->pf_xst, w.w2.st};
+        r = launch_rows<QT, PRO_QUANT>(c, st, rh, B, tp); if (r) return r;
+        GemmArgs g2{w.w2.q, w.w2.s, c->pf_xq, c->pf_xs, c->pf_x + col_o, dim, hid, rows_o, B, c->pf_xst, w.w2.st};
+        peers(g2, g2.out);
         r = launch_gemm<QT, EPI_RESIDUAL>(c, st, g2, c->use_mfma); if (r) return r;
+        if (tp) { r = exchange(c, st, XK_X1, nullptr, nullptr, 0); if (r) return r; }
     }
     return FLM_OK;
 }
@@ -727,7 +750,11 @@ int feed(flm_ctx* c, const int32_t* tokens, int n, int pos, int final_advance) {
     if (n > c->prompt_cap) return fail(c, FLM_ERR_INVALID, "more tokens than max_seq_len");
     for (int i = 0; i < n; ++i) if (tokens[i] < 0 || tokens[i] >= c->d.vocab_size) return fail(c, FLM_ERR_INVALID, "token id out of range");
     HIPC(c, hipMemcpyAsync(c->prompt_dev, tokens, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));   // (the caller's buffer outlives the call: every entry point synchronises)
-    if (c->use_prefill && c->world == 1 && n - 1 >= kPrefillMin && c->hidden_local == c->d.hidden_dim) {
+    // batched: single GPU always; tensor parallel over the peer-to-peer exchange with the int8 matrix-core kernels (the kernels that store
+    // their column slices into the peers' buffers)
+    const bool tp_ok = c->world > 1 && c->p2p && c->pf_in_xbuf && c->d.quant_type == FLM_QT_INT8 && c->use_mfma && c->use_qk_mfma && c->use_pv_mfma && c->use_prefill_mq &&
+                       c->pf_scores && c->hs <= 128 && c->hs % 2 == 0 && c->dim_local % 32 == 0;
+    if (c->use_prefill && (c->world == 1 || tp_ok) && n - 1 >= kPrefillMin) {
         // all tokens but the last in one batch (cache rows only), then the last one through the decode kernels
         r = c->d.quant_type == FLM_QT_INT8 ? prefill_batched<QT_INT8>(c, n - 1, pos) : prefill_batched<QT_INT16>(c, n - 1, pos);
         if (r) return r;
@@ -842,7 +869,12 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
     {   // the exchange buffer: att_out | x1 | hd | logits | flag lines [4 kinds][8 ranks] (full vectors on every rank under TP)
         auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
         const size_t o_att = 0, o_x1 = up(o_att + (size_t)d.dim * 4), o_hd = up(o_x1 + (size_t)d.dim * 4), o_lg = up(o_hd + (size_t)d.hidden_dim * 4);
-        const size_t o_fl = up(o_lg + (size_t)c->vocab_slot * world * 4), total = o_fl + (4 * 8 + 1) * 64;      // + the abort line
+        const size_t o_fl = up(o_lg + (size_t)c->vocab_slot * world * 4);
+        // tensor parallel: the batched prompt path's full-width activations [tokens][dim | dim | hidden] live here too (every rank stores its
+        // column slices into every rank's copy)
+        const size_t pcap = d.max_seq_len < 64 ? 64 : (size_t)d.max_seq_len;
+        const size_t o_px = up(o_fl + (4 * 8 + 1) * 64), o_pa = up(o_px + (world > 1 ? pcap * d.dim * 4 : 0)), o_ph = up(o_pa + (world > 1 ? pcap * d.dim * 4 : 0));
+        const size_t total = world > 1 ? up(o_ph + pcap * d.hidden_dim * 4) : o_fl + (4 * 8 + 1) * 64;      // (flags: + the abort line)
         hipError_t ae = hipErrorUnknown;
         if (world > 1) { ae = hipExtMallocWithFlags((void**)&c->xbuf, total, hipDeviceMallocFinegrained); c->xbuf_fine = ae == hipSuccess; }   // written by peer GPUs
         if (ae != hipSuccess) { (void)hipGetLastError(); HIPB(hipMalloc((void**)&c->xbuf, total)); }
@@ -850,6 +882,7 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
         HIPB(hipMemsetAsync(c->xbuf, 0, total, c->stream));
         c->att_out = (float*)(c->xbuf + o_att); c->x1 = (float*)(c->xbuf + o_x1); c->hd = (float*)(c->xbuf + o_hd); c->logits = (float*)(c->xbuf + o_lg);
         c->peer[rank] = c->xbuf;
+        if (world > 1) { c->pf_x = (float*)(c->xbuf + o_px); c->pf_att = (float*)(c->xbuf + o_pa); c->pf_hd = (float*)(c->xbuf + o_ph); c->pf_in_xbuf = true; }
         HIPB(hipMalloc((void**)&c->xepoch, 64)); HIPB(hipMemsetAsync(c->xepoch, 0, 64, c->stream));
     }
     HIPB(hipMalloc((void**)&c->flag_lines, 768 * 64)); HIPB(hipMalloc((void**)&c->xwg_err, 64));   // lines 0..255: k_attn_o's heads, 256..511: split heads' scores, 512..767: k_ffn
@@ -881,7 +914,7 @@ void flm_ctx_destroy(flm_ctx* c) {
     void* ptrs[] = {c->emb, c->emb_s, c->out_norm, c->kcache, c->vcache, c->xbuf, c->xepoch, c->qbuf,
                     c->rope_cos, c->rope_sin, c->state, c->prompt_dev, c->out_tokens_dev,
                     c->flag_lines, c->xwg_err, c->att_q, c->att_qs, c->att_sc, c->trace,
-                    c->pf_x, c->pf_qkv, c->pf_q, c->pf_att, c->pf_gu, c->pf_hd, c->pf_xs, c->pf_xq, c->pf_scores};
+                    c->pf_in_xbuf ? nullptr : c->pf_x, c->pf_qkv, c->pf_q, c->pf_in_xbuf ? nullptr : c->pf_att, c->pf_gu, c->pf_in_xbuf ? nullptr : c->pf_hd, c->pf_xs, c->pf_xq, c->pf_scores};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->comm) ncclCommDestroy(c->comm);
     if (c->stream) hipStreamDestroy(c->stream);

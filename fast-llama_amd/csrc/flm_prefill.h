@@ -45,7 +45,8 @@ struct RowsArgs {
     int n;
     float* xst;              // the scales once more, group-major [n/64][B] (the matrix-core GEMM tiles read 64 tokens' scales of a group as one 256-byte run); may be null
 };
-template <int QT, int PRO, int XR>
+// COH: the rows were (partly) written by peer GPUs (tensor parallel: the exchange regions) -> system-coherent loads
+template <int QT, int PRO, int XR, bool COH = false>
 __global__ void __launch_bounds__(kGemvBlock) k_rows_prologue(const RowsArgs r) {
     using T = QTraits<QT>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -53,8 +54,8 @@ __global__ void __launch_bounds__(kGemvBlock) k_rows_prologue(const RowsArgs r) 
     a.n = r.n; a.x = r.x + (size_t)blockIdx.x * r.n; a.norm_w = r.norm_w;
     a.rows_per_pass = 4; a.cb_shift = 4;                                     // (only the fixed LDS offsets are used)
     float4 xv[XR > 0 ? XR : 1], nv[XR > 0 ? XR : 1];
-    gemv_preload<QT, PRO, XR>(a, xv, nv);
-    gemv_prologue<QT, PRO, XR>(a, lds, xv, nv, [](int) {});
+    gemv_preload<QT, PRO, XR, COH>(a, xv, nv);
+    gemv_prologue<QT, PRO, XR, COH>(a, lds, xv, nv, [](int) {});
     const GemvLds L = gemv_lds_layout(r.n, T::kEsz, true, 4, 4, false);
     const int nb16 = r.n * T::kEsz / 16, sn = r.n / kGroup;
     int4* qo = reinterpret_cast<int4*>(reinterpret_cast<char*>(r.xq) + (size_t)blockIdx.x * r.n * T::kEsz);
@@ -73,7 +74,16 @@ struct GemmArgs {
     // EPI_ROPE_KV (the qkv GEMM of k_gemm_q8_mfma): rows [0, dim) = q, [dim, 2 dim) = k, [2 dim, 3 dim) = v of token b at position pos0 + b;
     // RoPE on q and k (rope_v2 pairs), q -> qout[b][dim], k / v -> the layer's cache rows (what k_rope_kv_rows does after a plain store)
     float* qout; float* kcache; float* vcache; const float* rope_cos; const float* rope_sin; int dim, hs, max_seq, pos0;
+    // tensor parallel, peer-to-peer (EPI_RESIDUAL / EPI_SWIGLU of k_gemm_q8_mfma): `out` lies in this rank's exchange region (its old value
+    // is read coherently) and every result also goes to the same place of every peer's region (system-scope stores), as GemvArgs::out_peer
+    float* out_peer[7]; int n_peer;
 };
+// a result of a batched kernel that the other ranks need: local write-through store + one system-scope store per peer
+__device__ __forceinline__ void st_result_tp(float* o, const size_t idx, const float v, float* const (&peer)[7], const int n_peer) {
+    if (n_peer == 0) { o[idx] = v; return; }
+    st_agent(o + idx, v);
+    for (int i = 0; i < n_peer; ++i) __hip_atomic_store(peer[i] + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // the group-major copy of a weight matrix's scales (made once, when the first prompt is batched)
 __global__ void k_transpose_scales(const float* s, float* st, int rows, int sn) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -359,7 +369,7 @@ __global__ void __launch_bounds__(64 * WT * WR, 4) k_gemm_q8_mfma(const GemmArgs
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int b = b0 + wt0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (b < a.B) a.out[(size_t)b * a.ldo + row] = swiglu_elem(acc[0][i], acc[NB - 1][i]);
+                if (b < a.B) st_result_tp(a.out, (size_t)b * a.ldo + row, swiglu_elem(acc[0][i], acc[NB - 1][i]), a.out_peer, a.n_peer);
             }
         }
     } else {
@@ -371,8 +381,9 @@ __global__ void __launch_bounds__(64 * WT * WR, 4) k_gemm_q8_mfma(const GemmArgs
             for (int i = 0; i < 16; ++i) {
                 const int b = b0 + wt0 + (i & 3) + 8 * (i >> 2) + 4 * h;
                 if (b >= a.B) continue;
-                float* o = a.out + (size_t)b * a.ldo + row;
-                if constexpr (EPI == EPI_RESIDUAL) *o = __fadd_rn(*o, acc[j][i]); else *o = acc[j][i];
+                const size_t idx = (size_t)b * a.ldo + row;
+                if constexpr (EPI == EPI_RESIDUAL) st_result_tp(a.out, idx, __fadd_rn(a.n_peer ? ld_agent(a.out + idx) : a.out[idx], acc[j][i]), a.out_peer, a.n_peer);
+                else a.out[idx] = acc[j][i];
             }
         }
     }

@@ -101,3 +101,39 @@ def test_tensor_parallel_long_context_split_heads(gpu):
         assert bits_equal(got, want) and bits_equal(got2, want2)
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("shape,layers,world,n", [("small", None, 2, 140), ("small", None, 4, 33), ("7B", 2, 2, 150), ("7B", 2, 8, 70)])
+def test_tensor_parallel_batched_prompt(gpu, shape, layers, world, n):
+    """prompts under tensor parallelism go through the batched kernels too (int8, peer to peer): every rank runs its heads / rows / hidden
+    slice of every step, the kernels store their column slices of the attention output, the residual stream and hd into every rank's
+    exchange region, a flag round closes each step.  Logits of the prompt and of the next token = the oracle's bits on every rank, and
+    the same as with the prompt fed token by token."""
+    cfg = synth.make_config(shape, ff.QT_INT8)
+    if layers:
+        cfg.n_layers = layers
+    tensors = synth.make_tensors(cfg, seed=47)
+    om = O.OracleModel(cfg, tensors)
+    prompt = _prompt(cfg.vocab_size, n)
+    want = om.forward(prompt, 0)
+    t = np.array([int(np.argmax(want))], np.int32)
+    want2 = om.forward(t, n)
+    ctxs = [gpu.Ctx(gpu.desc_from_config(cfg), device=0, rank=r, world=world, comm_id=None) for r in range(world)]
+    for c in ctxs:
+        c.upload_all(tensors)
+    blobs = [c.p2p_export() for c in ctxs]
+    for c in ctxs:
+        c.p2p_import(blobs)
+
+    def rank_main(c):
+        a = c.forward(prompt, 0); b = c.forward(t, n)
+        c.set_option("use_prefill", 0); c.reset_kv()
+        a0 = c.forward(prompt, 0)
+        return a, b, a0
+
+    for r, (a, b, a0) in enumerate(_run_ranks(ctxs, rank_main)):
+        assert bits_equal(a, want), f"rank {r}: prompt logits"
+        assert bits_equal(b, want2), f"rank {r}: next token"
+        assert bits_equal(a0, want), f"rank {r}: token by token"
+    for c in ctxs:
+        c.close()
