@@ -281,10 +281,14 @@ bool model_complete(const flm_ctx* c) {
 constexpr int FLM_RETRY = 1;
 int xwg_check(flm_ctx* c) {
     if (!c->fuse_attn_o && !c->fuse_ffn && c->attn_split == 0 && !c->p2p) return FLM_OK;
+    // (on the context's own stream: a copy on the legacy stream synchronises with every blocking stream of the process -- and fails
+    //  outright while another context's thread is capturing its token graph; seen once in ~10 runs of the threaded tensor-parallel tests)
     int e = 0;
-    HIPC(c, hipMemcpy(&e, c->xwg_err, 4, hipMemcpyDeviceToHost));
+    HIPC(c, hipMemcpyAsync(&e, c->xwg_err, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
     if (!e) return FLM_OK;
-    HIPC(c, hipMemset(c->xwg_err, 0, 4));
+    HIPC(c, hipMemsetAsync(c->xwg_err, 0, 4, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
     if (e == 2) return fail(c, FLM_ERR_COMM, "tensor parallel: a peer rank did not deliver its slice (20 s), or another rank gave up");
     c->fuse_attn_o = 0; c->fuse_ffn = 0; c->attn_split = 0;
     for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
@@ -893,8 +897,10 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
     HIPB(hipMemsetAsync(c->state, 0, sizeof(DecodeState), c->stream));
     std::vector<float> cs, sn; build_rope_table(hs, d.max_seq_len, cs, sn);
     HIPB(hipMalloc((void**)&c->rope_cos, cs.size() * 4)); HIPB(hipMalloc((void**)&c->rope_sin, sn.size() * 4));
-    HIPB(hipMemcpy(c->rope_cos, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
-    HIPB(hipMemcpy(c->rope_sin, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+    // (copies on the context's stream, never on the legacy stream: another context's thread may be capturing its token graph)
+    HIPB(hipMemcpyAsync(c->rope_cos, cs.data(), cs.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPB(hipMemcpyAsync(c->rope_sin, sn.data(), sn.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPB(hipStreamSynchronize(c->stream));                                    // (cs / sn go out of scope)
     if (alloc_run_bufs(c)) return bail(FLM_ERR_OOM);
     HIPB(hipStreamSynchronize(c->stream));
 #undef HIPB
@@ -1007,7 +1013,8 @@ int flm_upload_tensor(flm_ctx* c, int kind, int layer, int src_qt, const void* v
     if (kind >= 16 && (layer < 0 || layer >= d.n_layers)) return fail(c, FLM_ERR_INVALID, "layer out of range");
     auto vec = [&](float* dst, int n) -> int {
         if (src_qt != FLM_QT_NONE || (size_t)rows * cols != (size_t)n) return fail(c, FLM_ERR_INVALID, "norm tensor must be fp32 [dim]");
-        HIPC(c, hipMemcpy(dst, values, (size_t)n * 4, hipMemcpyHostToDevice));
+        HIPC(c, hipMemcpyAsync(dst, values, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
         return FLM_OK;
     };
     const int hb = c->plan.head_begin * hs, hn = c->dim_local;
@@ -1017,8 +1024,9 @@ int flm_upload_tensor(flm_ctx* c, int kind, int layer, int src_qt, const void* v
         const size_t n = (size_t)rows * cols;
         if (c->emb) { hipFree(c->emb); c->emb = nullptr; } if (c->emb_s) { hipFree(c->emb_s); c->emb_s = nullptr; }
         HIPC(c, hipMalloc(&c->emb, n * esz_of(src_qt)));
-        HIPC(c, hipMemcpy(c->emb, values, n * esz_of(src_qt), hipMemcpyHostToDevice));
-        if (src_qt != FLM_QT_NONE) { HIPC(c, hipMalloc((void**)&c->emb_s, n / kGroup * 4)); HIPC(c, hipMemcpy(c->emb_s, scales, n / kGroup * 4, hipMemcpyHostToDevice)); }
+        HIPC(c, hipMemcpyAsync(c->emb, values, n * esz_of(src_qt), hipMemcpyHostToDevice, c->stream));
+        if (src_qt != FLM_QT_NONE) { HIPC(c, hipMalloc((void**)&c->emb_s, n / kGroup * 4)); HIPC(c, hipMemcpyAsync(c->emb_s, scales, n / kGroup * 4, hipMemcpyHostToDevice, c->stream)); }
+        HIPC(c, hipStreamSynchronize(c->stream));
         c->emb_qt = src_qt; c->got_emb = true;
         for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
         c->graphs.clear();
@@ -1094,8 +1102,8 @@ int flm_debug_read(flm_ctx* c, int what, int layer, float* out, size_t n) {
     default: return fail(c, FLM_ERR_INVALID, "debug_read: unknown buffer");
     }
     if (n > cap || layer < 0 || layer >= c->d.n_layers) return fail(c, FLM_ERR_INVALID, "debug_read: size/layer");
+    HIPC(c, hipMemcpyAsync(out, src, n * 4, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
-    HIPC(c, hipMemcpy(out, src, n * 4, hipMemcpyDeviceToHost));
     return FLM_OK;
 }
 
