@@ -661,7 +661,7 @@ int prefill_batched(flm_ctx* c, int B, int pos) {
         HIPC(c, hipGetLastError());
         c->st_ready = true;
     }
-    // Tensor parallel (peer-to-peer; int8 matrix-core kernels): this rank's heads / rows / hidden slice of every step, as in the decode path
+    // Tensor parallel (peer-to-peer; the matrix-core kernels): this rank's heads / rows / hidden slice of every step, as in the decode path
     // (split_rows, transformer.cpp:264-287); the attention output, the residual stream and hd are full-width in every rank's exchange
     // region: the kernel that produces a column slice stores it into all of them, a flag round (k_xchg) closes the step, the row
     // prologues read with coherent loads.  Single GPU: dimL == dim, slices = everything, no peers.
@@ -724,15 +724,16 @@ int prefill_batched(flm_ctx* c, int B, int pos) {
         // hd = swiglu(W1 qx, W3 qx) with qx = quantize(rmsnorm(x1))   (transformer.cpp:144-147, 468-483): this rank's slice of hd
         RowsArgs rf{c->pf_x, w.ffn_norm, c->pf_xq, c->pf_xs, dim, c->pf_xst};
         r = launch_rows<QT, PRO_RMSNORM_QUANT>(c, st, rf, B, tp); if (r) return r;
-        if (QT == QT_INT8 && (tp || c->use_mfma == 3 || (c->use_mfma == 1 && ((hidL + 63) / 64) * ((B + 127) / 128) >= 256))) {
+        if (QT == QT_INT8 && c->use_mfma && (tp || c->use_mfma == 3 || (c->use_mfma == 1 && ((hidL + 63) / 64) * ((B + 127) / 128) >= 256))) {
             // 128 x 128 tiles of 64 gate + 64 up rows: the GEMM's epilogue is the SwiGLU
             GemmArgs g13{w.w13.q, w.w13.s, c->pf_xq, c->pf_xs, c->pf_hd + col_h, hid, dim, hidL, B, c->pf_xst, w.w13.st};
             peers(g13, g13.out);
             r = launch_gemm<QT, EPI_SWIGLU>(c, st, g13, c->use_mfma); if (r) return r;
         } else {
-            GemmArgs g13{w.w13.q, w.w13.s, c->pf_xq, c->pf_xs, c->pf_gu, 2 * hid, dim, 2 * hid, B, c->pf_xst, w.w13.st};
+            GemmArgs g13{w.w13.q, w.w13.s, c->pf_xq, c->pf_xs, c->pf_gu, 2 * hidL, dim, 2 * hidL, B, c->pf_xst, w.w13.st};
             r = launch_gemm<QT, EPI_STORE>(c, st, g13, c->use_mfma); if (r) return r;
-            hipLaunchKernelGGL(k_swiglu_rows, dim3(B), dim3(256), 0, st, c->pf_hd, (const float*)c->pf_gu, hid);
+            SwigluPeers sp{}; { GemmArgs t{}; peers(t, c->pf_hd + col_h); sp.n = t.n_peer; for (int i = 0; i < t.n_peer; ++i) sp.p[i] = t.out_peer[i]; }
+            hipLaunchKernelGGL(k_swiglu_rows, dim3(B), dim3(256), 0, st, c->pf_hd + col_h, (const float*)c->pf_gu, hidL, hid, sp);
             HIPC(c, hipGetLastError());
         }
         if (tp) { r = exchange(c, st, XK_HD, nullptr, nullptr, 0); if (r) return r; }
@@ -754,9 +755,9 @@ int feed(flm_ctx* c, const int32_t* tokens, int n, int pos, int final_advance) {
     if (n > c->prompt_cap) return fail(c, FLM_ERR_INVALID, "more tokens than max_seq_len");
     for (int i = 0; i < n; ++i) if (tokens[i] < 0 || tokens[i] >= c->d.vocab_size) return fail(c, FLM_ERR_INVALID, "token id out of range");
     HIPC(c, hipMemcpyAsync(c->prompt_dev, tokens, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));   // (the caller's buffer outlives the call: every entry point synchronises)
-    // batched: single GPU always; tensor parallel over the peer-to-peer exchange with the int8 matrix-core kernels (the kernels that store
-    // their column slices into the peers' buffers)
-    const bool tp_ok = c->world > 1 && c->p2p && c->pf_in_xbuf && c->d.quant_type == FLM_QT_INT8 && c->use_mfma && c->use_qk_mfma && c->use_pv_mfma && c->use_prefill_mq &&
+    // batched: single GPU always; tensor parallel over the peer-to-peer exchange with the matrix-core kernels (the kernels that store their
+    // column slices into the peers' buffers)
+    const bool tp_ok = c->world > 1 && c->p2p && c->pf_in_xbuf && c->use_mfma && c->use_qk_mfma && c->use_pv_mfma && c->use_prefill_mq &&
                        c->pf_scores && c->hs <= 128 && c->hs % 2 == 0 && c->dim_local % 32 == 0;
     if (c->use_prefill && (c->world == 1 || tp_ok) && n - 1 >= kPrefillMin) {
         // all tokens but the last in one batch (cache rows only), then the last one through the decode kernels

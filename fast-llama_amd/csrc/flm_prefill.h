@@ -511,8 +511,9 @@ __global__ void __launch_bounds__(256, 3) k_gemm_q16_mfma(const GemmArgs a) {
         for (int i = 0; i < 16; ++i) {
             const int b = b0 + wt0 + (i & 3) + 8 * (i >> 2) + 4 * h;
             if (b >= a.B) continue;
-            float* o = a.out + (size_t)b * a.ldo + row;
-            if constexpr (EPI == EPI_RESIDUAL) *o = __fadd_rn(*o, acc[i]); else *o = acc[i];
+            const size_t idx = (size_t)b * a.ldo + row;
+            if constexpr (EPI == EPI_RESIDUAL) st_result_tp(a.out, idx, __fadd_rn(a.n_peer ? ld_agent(a.out + idx) : a.out[idx], acc[i]), a.out_peer, a.n_peer);   // (peers: tensor parallel, see GemmArgs)
+            else a.out[idx] = acc[i];
         }
     }
 }
@@ -534,10 +535,11 @@ __global__ void k_rope_kv_rows(const float* qkv, float* qout, float* kcache, flo
     }
 }
 
-__global__ void k_swiglu_rows(float* hd, const float* gu, int hidden) {
+// gu[b] = [gate ; up] (hidden each, this rank's slice) -> hd[b * ldo + i]; tensor parallel: hd = this rank's columns of every rank's [tokens][hidden_dim]
+struct SwigluPeers { float* p[7]; int n; };
+__global__ void k_swiglu_rows(float* hd, const float* gu, int hidden, int ldo, const SwigluPeers peers) {
     const float* g = gu + (size_t)blockIdx.x * 2 * hidden;
-    float* o = hd + (size_t)blockIdx.x * hidden;
-    for (int i = threadIdx.x; i < hidden; i += blockDim.x) o[i] = swiglu_elem(g[i], g[hidden + i]);   // o1.swiglu(o3) transformer.cpp:481
+    for (int i = threadIdx.x; i < hidden; i += blockDim.x) st_result_tp(hd, (size_t)blockIdx.x * ldo + i, swiglu_elem(g[i], g[hidden + i]), peers.p, peers.n);   // o1.swiglu(o3) transformer.cpp:481
 }
 
 } // namespace flm

@@ -139,8 +139,8 @@ int  flm_debug_read(flm_ctx* ctx, int what, int layer, float* out, size_t n);
 /* tuning knobs: "wg_per_cu" workgroups per CU for the GEMV kernels, "use_graph" hipGraph replay on/off,
  * "fuse_attn_o" 0 = attention and the Wo GEMV as two launches (default 1: one launch, single GPU),
  * "fuse_ffn" 0 = FFN13 and FFN2 as two launches (default 1: one launch, single GPU),
- * "use_prefill" 0 = feed prompts token by token (default 1: batched; under tensor parallelism batched for int8 models once the peers are
- * mapped with flm_p2p_import, token by token otherwise), "use_prefill_mq" 0 = batched attention with one query per
+ * "use_prefill" 0 = feed prompts token by token (default 1: batched; under tensor parallelism batched once the peers are mapped with
+ * flm_p2p_import, token by token otherwise), "use_prefill_mq" 0 = batched attention with one query per
  * workgroup (default 1: eight), "attn_split" 0 = one workgroup per head at every context length (default 1: hs / 32 from 128 positions on; n >= 2: always n),
  * "use_p2p" 0 = tensor-parallel exchanges by RCCL all-gathers even though the peers are mapped (1: peer to peer again),
  * "use_qk_mfma" 0 = prefill attention scores on VALU chains (default 1: v_mfma_f32_16x16x4_f32, the same bits),

@@ -103,13 +103,14 @@ def test_tensor_parallel_long_context_split_heads(gpu):
         c.close()
 
 
-@pytest.mark.parametrize("shape,layers,world,n", [("small", None, 2, 140), ("small", None, 4, 33), ("7B", 2, 2, 150), ("7B", 2, 8, 70)])
-def test_tensor_parallel_batched_prompt(gpu, shape, layers, world, n):
-    """prompts under tensor parallelism go through the batched kernels too (int8, peer to peer): every rank runs its heads / rows / hidden
+@pytest.mark.parametrize("shape,qt,layers,world,n", [("small", ff.QT_INT8, None, 2, 140), ("small", ff.QT_INT8, None, 4, 33), ("7B", ff.QT_INT8, 2, 2, 150),
+                                                     ("7B", ff.QT_INT8, 2, 8, 70), ("small", ff.QT_INT16, None, 2, 75), ("7B", ff.QT_INT16, 2, 4, 90)])
+def test_tensor_parallel_batched_prompt(gpu, shape, qt, layers, world, n):
+    """prompts under tensor parallelism go through the batched kernels too (peer to peer): every rank runs its heads / rows / hidden
     slice of every step, the kernels store their column slices of the attention output, the residual stream and hd into every rank's
     exchange region, a flag round closes each step.  Logits of the prompt and of the next token = the oracle's bits on every rank, and
     the same as with the prompt fed token by token."""
-    cfg = synth.make_config(shape, ff.QT_INT8)
+    cfg = synth.make_config(shape, qt)
     if layers:
         cfg.n_layers = layers
     tensors = synth.make_tensors(cfg, seed=47)
