@@ -720,16 +720,19 @@ __global__ void __launch_bounds__(256) k_qk_mfma(const AttnArgs a, int pos0, int
 // ------------------------------------------------------------------------------------------
 constexpr int kPvQ = 16, kPvRing = 4;
 __host__ __device__ inline int pv_row_stride(int tmax) { return ((((tmax + 15) & ~15) + 63) & ~63) + 4; }     // floats; = 4 mod 64: conflict-free 16-byte reads of 16 rows
-__host__ inline size_t pv_mfma_lds_bytes(int tmax) { return ((size_t)kPvQ * pv_row_stride(tmax) + 16) * 4; }
-__global__ void __launch_bounds__(256) k_attn_pv_mfma(const AttnArgs a, int pos0, int row_stride, int B) {
+__host__ inline size_t pv_mfma_lds_bytes(int tmax, int qw = kPvQ) { return ((size_t)qw * pv_row_stride(tmax) + 16) * 4; }
+// queries per workgroup: 16 while their exps fit the LDS (64 bytes per position: up to ~2500 positions), then 8, 4, 2, 1 -- the rows
+// of the A operand past qw are fed zeros; the bits of a (query, dimension) chain do not depend on its row
+__host__ inline int pv_mfma_queries(int tmax, size_t lds_max) { int qw = kPvQ; while (qw > 1 && pv_mfma_lds_bytes(tmax, qw) > lds_max) qw >>= 1; return qw; }
+__global__ void __launch_bounds__(256) k_attn_pv_mfma(const AttnArgs a, int pos0, int row_stride, int B, int qw) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     typedef float v2f __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int hs = a.hs, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = blockIdx.x, q0 = blockIdx.y * kPvQ, nq = B - q0 < kPvQ ? B - q0 : kPvQ;
+    const int h = blockIdx.x, q0 = blockIdx.y * qw, nq = B - q0 < qw ? B - q0 : qw;
     const int S = pv_row_stride(pos0 + B);
-    float* E = reinterpret_cast<float*>(lds);                    // [16][S]
-    float* sums = E + kPvQ * S;                                  // [16]
+    float* E = reinterpret_cast<float*>(lds);                    // [qw][S]
+    float* sums = E + qw * S;                                    // [qw]
     const int Tmax = pos0 + q0 + nq, Tp = (Tmax + 15) & ~15, nblk = Tp >> 4;
     // ---- scores -> LDS, max, exp: 16 lanes per query (wave w: queries 4w .. 4w+3), 4 consecutive positions per lane and round
     {
@@ -737,8 +740,9 @@ __global__ void __launch_bounds__(256) k_attn_pv_mfma(const AttnArgs a, int pos0
         const int Tq = q < nq ? pos0 + q0 + q + 1 : 0;
         const float* src = a.sc_global + ((size_t)h * B + (q0 + (q < nq ? q : 0))) * a.max_seq;
         float* row = E + q * S;
+        const int Tr = q < qw ? Tp : 0;                          // (rows past qw do not exist)
         float m = -INFINITY;
-        for (int t = l16 * 4; t < Tp; t += 64) {
+        for (int t = l16 * 4; t < Tr; t += 64) {
             float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
             if (t + 3 < Tq) v = *reinterpret_cast<const float4*>(src + t);
             else { if (t < Tq) v.x = src[t]; if (t + 1 < Tq) v.y = src[t + 1]; if (t + 2 < Tq) v.z = src[t + 2]; }
@@ -746,7 +750,7 @@ __global__ void __launch_bounds__(256) k_attn_pv_mfma(const AttnArgs a, int pos0
             m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
         }
         m = row16_max(m);
-        for (int t = l16 * 4; t < Tp; t += 64) {                 // (each lane re-reads what it wrote)
+        for (int t = l16 * 4; t < Tr; t += 64) {                 // (each lane re-reads what it wrote)
             float4 v = *reinterpret_cast<const float4*>(row + t);
             v.x = t < Tq ? expf_ref(__fsub_rn(v.x, m)) : 0.f; v.y = t + 1 < Tq ? expf_ref(__fsub_rn(v.y, m)) : 0.f;
             v.z = t + 2 < Tq ? expf_ref(__fsub_rn(v.z, m)) : 0.f; v.w = t + 3 < Tq ? expf_ref(__fsub_rn(v.w, m)) : 0.f;
@@ -755,7 +759,7 @@ __global__ void __launch_bounds__(256) k_attn_pv_mfma(const AttnArgs a, int pos0
     }
     __syncthreads();
     // ---- the sums: lane q of wave 0, t ascending (tf_operators.cpp:180-183); positions past a query's own add +0
-    if (tid < kPvQ) {
+    if (tid < qw) {
         const float4* r4 = reinterpret_cast<const float4*>(E + tid * S);
         float sum = 0.f;
 #pragma unroll 4
@@ -764,7 +768,7 @@ __global__ void __launch_bounds__(256) k_attn_pv_mfma(const AttnArgs a, int pos0
     }
     __syncthreads();
     // ---- weights: divide, skip rule, permute inside the block of 16 positions: float4 c of a block = positions c, 4 + c, 8 + c, 12 + c
-    for (int bidx = tid; bidx < kPvQ * nblk; bidx += 256) {
+    for (int bidx = tid; bidx < qw * nblk; bidx += 256) {
         const int q = bidx / nblk, bi = bidx - q * nblk;
         float* blk = E + q * S + bi * 16;
         const float sum = sums[q];
@@ -795,12 +799,13 @@ __global__ void __launch_bounds__(256) k_attn_pv_mfma(const AttnArgs a, int pos0
 #pragma unroll
     for (int r = 0; r < kPvRing; ++r) request(ring[r]);
     v4f acc0 = {-0.f, -0.f, -0.f, -0.f}, acc1 = {-0.f, -0.f, -0.f, -0.f};
-    const float* ap = E + li * S + 4 * c;
+    const float* ap = E + (li < qw ? li : 0) * S + 4 * c;
     for (int b0 = 0; b0 < nblk; b0 += kPvRing) {
 #pragma unroll
         for (int r = 0; r < kPvRing; ++r) {
             if (b0 + r < nblk) {                                  // (wave-uniform)
-                const float4 av = *reinterpret_cast<const float4*>(ap + (b0 + r) * 16);
+                float4 av = *reinterpret_cast<const float4*>(ap + (b0 + r) * 16);
+                if (li >= qw) av = make_float4(0.f, 0.f, 0.f, 0.f);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, ring[r][0].x, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, ring[r][0].y, acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, ring[r][1].x, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, ring[r][1].y, acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, ring[r][2].x, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, ring[r][2].y, acc1, 0, 0, 0);

@@ -42,6 +42,7 @@ struct EvPair { hipEvent_t e0 = nullptr, e1 = nullptr; ~EvPair() { if (e0) hipEv
 
 } // namespace
 
+constexpr size_t kLdsMax = 160 * 1024;                            // LDS of a gfx950 CU = the most one workgroup can have
 struct flm_ctx {
     flm_model_desc d{};
     int device = 0, rank = 0, world = 1;
@@ -151,7 +152,7 @@ int plan_gemv(flm_ctx* c, GemvArgs& a, int wgs, GemvPlan& P) {
     const int rows = a.items * (PAIRS ? 2 : 1);
     if ((double)rows * a.n * QTraits<QT>::kEsz * (TWO ? 2 : 1) >= 2147483648.0) return fail(c, FLM_ERR_UNSUPPORTED, "gemv: matrix of 2 GiB or more");
     P = gemv_plan(a.n, QTraits<QT>::kEsz, rows, TWO, PAIRS, true, wgs);
-    if (P.lds > 160 * 1024) return fail(c, FLM_ERR_UNSUPPORTED, "gemv: activation vector does not fit LDS");
+    if (P.lds > kLdsMax) return fail(c, FLM_ERR_UNSUPPORTED, "gemv: activation vector does not fit LDS");
     a.rows_per_pass = P.Rm; a.cb_shift = P.cb_shift; a.nbuf = P.nbuf;
     return FLM_OK;
 }
@@ -563,7 +564,9 @@ int alloc_run_bufs(flm_ctx* c) {
     HIPC(c, hipMalloc((void**)&c->pf_xs, 2 * cap * (nmax / kGroup) * 4 + 64));       // row-major [tokens][groups], then group-major [groups][tokens] (+ slack: the GEMM tiles read token pairs)
     c->pf_xst = c->pf_xs + cap * (nmax / kGroup);
     HIPC(c, hipMalloc(&c->pf_xq, cap * nmax * c->esz));
-    if (c->hs % 32 == 0 && c->hs <= 128) HIPC(c, hipMalloc((void**)&c->pf_scores, (size_t)c->heads_local * cap * d.max_seq_len * 4));
+    if (c->hs % 32 == 0 && c->hs <= 128 && hipMalloc((void**)&c->pf_scores, (size_t)c->heads_local * cap * d.max_seq_len * 4) != hipSuccess) {
+        c->pf_scores = nullptr; (void)hipGetLastError();        // (quadratic in max_seq_len: without it prompts take the kernels that compute their own scores)
+    }
     c->pf_cap = (int)cap;
     return FLM_OK;
 }
@@ -692,8 +695,12 @@ int prefill_batched(flm_ctx* c, int B, int pos) {
         AttnArgs aa{}; aa.q = c->pf_q; aa.kcache = c->kcache + (size_t)l * kv_layer; aa.vcache = c->vcache + (size_t)l * kv_layer;
         aa.out = c->pf_att + col_a; aa.pos_ptr = &c->state->pos; aa.hs = hs; aa.max_seq = d.max_seq_len;
         if (tp) { const size_t off = (char*)aa.out - c->xbuf; for (int r2 = 0; r2 < c->world; ++r2) if (r2 != c->rank) aa.out_peer[aa.n_peer++] = (float*)(c->peer[r2] + off); }
-        if (hs <= 128 && c->use_prefill_mq && c->use_qk_mfma && c->pf_scores) {
-            // scores on the matrix cores (fp32 MFMA = the reference's chains, bit for bit), then softmax + weighted sum per 8 queries
+        // which kernels: the exps of a tile of queries (weighted sum on the matrix cores) or the scores of 8 queries (VALU) must fit the LDS;
+        // one query per workgroup needs 4 bytes per position and always fits (flm_ctx_create checked max_seq_len against it)
+        const bool mq_fits = attn_mq_lds_bytes(d.max_seq_len, hs) <= kLdsMax;
+        const bool pv_mfma = c->use_pv_mfma && (hs & 1) == 0;
+        if (hs <= 128 && c->use_prefill_mq && c->use_qk_mfma && c->pf_scores && (pv_mfma || mq_fits)) {
+            // scores on the matrix cores (fp32 MFMA = the reference's chains, bit for bit), then softmax + weighted sum per tile of queries
             aa.sc_global = c->pf_scores;
             const dim3 gq(c->heads_local, (B + kQkQ - 1) / kQkQ);
             switch (hs >> 5) {
@@ -703,12 +710,13 @@ int prefill_batched(flm_ctx* c, int B, int pos) {
             default: hipLaunchKernelGGL(k_qk_mfma<4>, gq, dim3(256), 0, st, aa, pos, dimL, B); break;
             }
             HIPC(c, hipGetLastError());
-            if (c->use_pv_mfma && (hs & 1) == 0)   // ... and the weighted sum too (an accumulator element = the reference's chain of one (query, dimension))
-                hipLaunchKernelGGL(k_attn_pv_mfma, dim3(c->heads_local, (B + kPvQ - 1) / kPvQ), dim3(256), pv_mfma_lds_bytes(pos + B), st, aa, pos, dim, B);
-            else
+            if (pv_mfma) {   // ... and the weighted sum too (an accumulator element = the reference's chain of one (query, dimension))
+                const int qw = pv_mfma_queries(pos + B, kLdsMax);     // 16 queries per workgroup up to ~2500 positions, fewer beyond
+                hipLaunchKernelGGL(k_attn_pv_mfma, dim3(c->heads_local, (B + qw - 1) / qw), dim3(256), pv_mfma_lds_bytes(pos + B, qw), st, aa, pos, dim, B, qw);
+            } else
                 hipLaunchKernelGGL(k_attn_prefill_mq<true>, dim3(c->heads_local, (B + kMqQueries - 1) / kMqQueries), dim3(kAttnBlock), attn_mq_lds_bytes(d.max_seq_len, hs), st, aa, pos, dim, B);
         }
-        else if (hs <= 128 && c->use_prefill_mq)      // kMqQueries queries per workgroup share every K/V tile
+        else if (hs <= 128 && c->use_prefill_mq && mq_fits)      // kMqQueries queries per workgroup share every K/V tile
             hipLaunchKernelGGL(k_attn_prefill_mq<false>, dim3(c->heads_local, (B + kMqQueries - 1) / kMqQueries), dim3(kAttnBlock), attn_mq_lds_bytes(d.max_seq_len, hs), st, aa, pos, dim, B);
         else
             hipLaunchKernelGGL(k_attn_prefill, dim3(c->heads_local, B), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, hs), st, aa, pos, dim);
@@ -835,6 +843,8 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
     const int hs = d.dim / d.n_heads;
     if (hs % 8 || hs < 32 || hs > 256) return fail(nullptr, FLM_ERR_UNSUPPORTED, "head_size must be a multiple of 8 in [32, 256] (the reference's 8-lane dot_product path, x86_simd.cpp:1677-1699; 256: the attention tile staging)");
     if (world < 1 || rank < 0 || rank >= world) return fail(nullptr, FLM_ERR_INVALID, "rank/world");
+    if (attn_lds_bytes(d.max_seq_len, hs) > kLdsMax)
+        return fail(nullptr, FLM_ERR_UNSUPPORTED, "max_seq_len: a head's scores (4 bytes per position) and its K/V tiles must fit the 160 KiB of LDS of one CU");
 
     flm_ctx* c = new flm_ctx();
     c->d = d; c->device = device_id; c->rank = rank; c->world = world; c->hs = hs; c->esz = esz_of(d.quant_type);

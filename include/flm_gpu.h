@@ -66,7 +66,8 @@ typedef struct flm_model_desc {
     int32_t n_heads;
     int32_t n_kv_heads;       /* must equal n_heads (see FLM_ERR_UNSUPPORTED) */
     int32_t vocab_size;
-    int32_t max_seq_len;      /* reference clamps to 1024 (transformer.cpp:32) */
+    int32_t max_seq_len;      /* reference clamps to 1024 (transformer.cpp:32); here any length whose scores (4 bytes per position) fit the
+                               * LDS beside a head's K/V tiles: ~22 000 positions at head size 128 (FLM_ERR_UNSUPPORTED beyond) */
     int32_t quant_type;       /* FLM_QT_INT8 | FLM_QT_INT16: type of the linear layers and activations */
     int32_t quant_group_size; /* 64 */
 } flm_model_desc;

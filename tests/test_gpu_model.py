@@ -163,6 +163,35 @@ def test_prefill_attention_on_fp32_mfma_is_the_valu_bits(gpu, shape, qt, n):
     assert bits_equal(res[0][0], O.OracleModel(cfg, tensors).forward(prompt, 0))
 
 
+@pytest.mark.parametrize("n", [3000, 5500])
+def test_prompts_longer_than_one_tile_of_exps_fits_the_lds(gpu, n):
+    """a prompt of more than ~2500 tokens: 16 queries' exps (64 bytes per position) no longer fit the 160 KiB of LDS, the weighted-sum
+    kernel takes 8 (4) queries per workgroup; with the matrix-core weighted sum switched off the 8-query VALU kernel does not fit
+    either (max_seq_len 6000) and the one-query-per-workgroup kernel runs.  Same cache rows and logits on every path, equal to the
+    token-by-token path's and to the oracle's."""
+    cfg = synth.make_config("tiny128", ff.QT_INT8, max_length=6000)
+    tensors = synth.make_tensors(cfg, seed=23)
+    prompt = _prompt(cfg.vocab_size, n)
+    res = []
+    for prefill, pv in ((1, 1), (1, 0), (0, 1)) if n == 3000 else ((1, 1), (0, 1)):
+        ctx = gpu.Ctx(gpu.desc_from_config(cfg, max_seq_len=cfg.max_length)); ctx.upload_all(tensors)
+        ctx.set_option("use_prefill", prefill); ctx.set_option("use_pv_mfma", pv)
+        lg = ctx.forward(prompt, 0)
+        kv = [ctx.debug_read(w, cfg.n_layers - 1, cfg.n_heads * cfg.max_length * cfg.head_size).copy() for w in ("kcache", "vcache")]
+        nxt = ctx.forward(np.array([int(np.argmax(lg))], np.int32), n)
+        res.append((lg.copy(), kv, nxt.copy()))
+        ctx.close()
+    for r in res[1:]:
+        assert bits_equal(res[0][0], r[0]) and bits_equal(res[0][1][0], r[1][0]) and bits_equal(res[0][1][1], r[1][1]) and bits_equal(res[0][2], r[2])
+    assert bits_equal(res[0][0], O.OracleModel(cfg, tensors, max_seq=cfg.max_length).forward(prompt, 0))
+
+
+def test_max_seq_len_beyond_the_lds_is_refused_at_create(gpu):
+    cfg = synth.make_config("tiny128", ff.QT_INT8, max_length=40000)
+    with pytest.raises(Exception, match="max_seq_len"):
+        gpu.Ctx(gpu.desc_from_config(cfg, max_seq_len=cfg.max_length))
+
+
 def test_long_context_positions(gpu):
     """positions up to max_seq_len-1 (1024 clamp, transformer.cpp:32): prefill 1000 tokens on the GPU and the oracle."""
     cfg = synth.make_config("tiny", ff.QT_INT8)
