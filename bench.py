@@ -454,7 +454,8 @@ def main():
                          "bytes_per_launch": int(dom_bytes), "avg_launch_us": round(dom_us, 2), "launches_per_token": dom_cnt},
             "kernels": kernels,
             "kernels_note": "us per launch, back-to-back launches of one class between one pair of HIP events; on a single GPU the token path runs attn_wo (k_attn_o) "
-                            "instead of attn + attn_o and ffn (k_ffn) instead of ffn13 + ffn2: per token = embed + L * (qkv + attn_wo + ffn) + cls + argmax",
+                            "instead of attn + attn_o and ffn (k_ffn) instead of ffn13 + ffn2: per token = embed + L * (qkv + attn_wo + ffn) + cls + argmax; where qkv_attn_wo "
+                            "(k_qkv_attn_o: contexts from 128 positions on) is listed, the token runs it instead of qkv + attn_wo",
         }
         if replicas is not None:
             line["replicas"] = replicas

@@ -898,6 +898,80 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_attn_o(const AttnArgs aa, con
 }
 
 // ------------------------------------------------------------------------------------------
+// QKV (+ RoPE + cache append), attention and the output projection in ONE launch (single GPU): k_attn_o with the QKV GEMV in front.
+// Every workgroup runs its rows of [Wq; Wk; Wv] (k_gemv<RMSNORM_QUANT, ROPE_KV> verbatim), publishes them (write-through stores,
+// then `target` in its line of flagq).  This hand-off is NOT all-to-all: a head needs its own hs rows of q, k and v only, i.e. the
+// lines of the <= 3 * ceil(hs / Rm + 1) workgroups that reduced them -- no wait for the slowest of 256, no 16 KB vector to gather.
+// The other workgroups go on as in k_attn_o (Wo prefetch, wait for the heads' lines, GEMV).
+template <int QT, int XR, bool PREQ, bool SPLIT = false>
+__global__ void __launch_bounds__(kGemvBlock, 4) k_qkv_attn_o(const GemvArgs aq, const AttnArgs aa, const GemvArgs a, const int gridq, const int n_heads, const int grido,
+                                                              unsigned* flagq, unsigned* flag, const unsigned target, int* err) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    auto nostamp = [](int) {};
+    if ((int)blockIdx.x < gridq) {
+        float4 xq[1], nq[1];
+        gemv_preload<QT, PRO_RMSNORM_QUANT, 1>(aq, xq, nq);
+        GemvCtx<QT, EPI_ROPE_KV> gq;
+        gq.init(aq, blockIdx.x, gridq, lds);
+        gemv_prologue<QT, PRO_RMSNORM_QUANT, 1>(aq, lds, xq, nq, [&](int part) { gq.issue(kAblate ? aq.ablate : 0, part); });
+        gq.run(aq, lds, nostamp);
+        wait_stores_done();                                                     // every wave: its q / cache rows are where the heads will read them
+        __syncthreads();                                                        // (and the LDS is free for the next phase)
+        if (threadIdx.x == 0) __hip_atomic_store(flagq + blockIdx.x * kFlagStride, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if ((int)blockIdx.x < n_heads) {                                            // n_heads counts head PARTS: heads * G
+        const int G = SPLIT ? aa.G : 1, h = blockIdx.x / G;
+        if (threadIdx.x < 256) {
+            // lane i: does workgroup i reduce a row of this head's q, k or v?  (pass p = rows [p Rm, (p + 1) Rm) of [Wq; Wk; Wv], workgroup p mod gridq)
+            bool need = false;
+            if ((int)threadIdx.x < gridq) {
+                const unsigned Rm = aq.rows_per_pass, hs = aa.hs, nq = gridq;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const unsigned r0 = (m == 0 ? 0u : m == 1 ? (unsigned)aq.dim : (unsigned)(aq.dim + aq.kv_dim)) + h * hs;
+                    const unsigned pa = r0 / Rm, pb = (r0 + hs - 1) / Rm;
+                    need |= (threadIdx.x + nq - pa % nq) % nq <= pb - pa;
+                }
+            }
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (true) {
+                const unsigned f = need ? __hip_atomic_load(flagq + threadIdx.x * kFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
+                if (__all(f >= target)) break;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+        __syncthreads();
+        attn_head_any<true, SPLIT>(aa, h, lds, *aa.pos_ptr + 1, aa.q, aa.out, blockIdx.x % G, G);
+        wait_stores_done();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(flag + blockIdx.x * kFlagStride, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if ((int)blockIdx.x >= n_heads + grido) return;
+    GemvCtx<QT, EPI_RESIDUAL> g;
+    g.init(a, blockIdx.x - n_heads, grido, lds);
+    g.issue(kAblate ? a.ablate : 0);
+    if ((int)(threadIdx.x & ~63u) < n_heads) {                              // the waves that own at least one head's flag: lane i polls head i's line
+        const bool mine = (int)threadIdx.x < n_heads;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (true) {
+            const unsigned f = mine ? __hip_atomic_load(flag + threadIdx.x * kFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
+            if (__all(f >= target)) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+    }
+    __syncthreads();
+    float4 xv[XR > 0 ? XR : 1], nv[XR > 0 ? XR : 1];
+    if constexpr (PREQ) {
+        gemv_prologue<QT, PRO_NONE, 0, true>(a, lds, xv, nv, [](int) {});
+    } else {
+        gemv_preload<QT, PRO_QUANT, XR, true>(a, xv, nv);
+        gemv_prologue<QT, PRO_QUANT, XR>(a, lds, xv, nv, [](int) {});
+    }
+    g.run(a, lds, [](int) {});
+}
+
+// ------------------------------------------------------------------------------------------
 // FFN13 (+ SwiGLU) and FFN2 (+ residual) in ONE launch (single GPU): every workgroup runs its rows of [W1; W3], publishes its slice
 // of hd (write-through stores, then its 64-byte flag line = layer + 1), requests its first two steps of W2 -- 128 KiB per CU, two
 // thirds of the matrix chip-wide, none of it depending on hd -- and only then waits for the other workgroups' lines (lane i of

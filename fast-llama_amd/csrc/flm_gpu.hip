@@ -33,7 +33,7 @@ struct LayerW {
     unsigned got = 0;     // bitmask of uploaded kinds
 };
 
-enum KClass { KC_EMBED = 0, KC_QKV, KC_ATTN, KC_ATTN_O, KC_FFN13, KC_FFN2, KC_CLS, KC_ARGMAX, KC_ALLREDUCE, KC_ATTN_WO /* k_attn_o: attention + Wo */, KC_FFN /* k_ffn: FFN13 + FFN2 */ };
+enum KClass { KC_EMBED = 0, KC_QKV, KC_ATTN, KC_ATTN_O, KC_FFN13, KC_FFN2, KC_CLS, KC_ARGMAX, KC_ALLREDUCE, KC_ATTN_WO /* k_attn_o: attention + Wo */, KC_FFN /* k_ffn: FFN13 + FFN2 */, KC_QKV_ATTN_WO /* k_qkv_attn_o */ };
 
 struct TimedLaunch { int kclass; hipEvent_t e0, e1; };
 // owners that release on every exit path (the error macros return from the middle of a function)
@@ -79,6 +79,8 @@ struct flm_ctx {
     int fuse_attn_o = 1;                               // option "fuse_attn_o": attention + Wo GEMV in one launch (k_attn_o; single GPU)
     bool st_ready = false;                             // the layer matrices' group-major scale copies (QMat::st) are up to date
     int fuse_ffn = 1;                                  // option "fuse_ffn": FFN13 + FFN2 in one launch (k_ffn; single GPU)
+    int fuse_qkv = 1;                                  // option "fuse_qkv": QKV in front of attention + Wo in the same launch (k_qkv_attn_o; single GPU): 0 never,
+                                                       // 1 when a head is spread over several workgroups (long contexts: where it pays), 2 always
     unsigned* flag_lines = nullptr; int* xwg_err = nullptr;   // k_attn_o: one 64-byte flag line per head; "a cross-workgroup wait timed out"
     void* att_q = nullptr; float* att_qs = nullptr;    // k_attn_o: the heads' output already quantized (head_size a multiple of 64)
     // tensor parallel, peer-to-peer: ONE exchange buffer per rank -- [att_out | x1 | hd | logits | flag lines] -- shared with the
@@ -291,7 +293,7 @@ int xwg_check(flm_ctx* c) {
     HIPC(c, hipMemsetAsync(c->xwg_err, 0, 4, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     if (e == 2) return fail(c, FLM_ERR_COMM, "tensor parallel: a peer rank did not deliver its slice (20 s), or another rank gave up");
-    c->fuse_attn_o = 0; c->fuse_ffn = 0; c->attn_split = 0;
+    c->fuse_attn_o = 0; c->fuse_ffn = 0; c->fuse_qkv = 0; c->attn_split = 0;
     for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
     c->graphs.clear();
     return FLM_RETRY;
@@ -415,6 +417,40 @@ int launch_attn_o(flm_ctx* c, hipStream_t st, int l, int G) {
     return FLM_OK;
 }
 
+// QKV + attention + Wo GEMV of layer l in one launch (k_qkv_attn_o); returns FLM_ERR_UNSUPPORTED when the shape does not allow it
+template <int QT>
+int launch_qkv_attn_o(flm_ctx* c, hipStream_t st, int l, int G) {
+    const auto& d = c->d;
+    const int parts = c->heads_local * G, all = c->cu_count < 256 ? c->cu_count : 256, wgs = all - parts;
+    if (wgs < 1 || parts > 256) return FLM_ERR_UNSUPPORTED;
+    GemvArgs aq = args_qkv(c, l), a = args_o(c, l);
+    GemvPlan Pq, P;
+    int r = plan_gemv<QT, PRO_RMSNORM_QUANT, EPI_ROPE_KV>(c, aq, all, Pq); if (r) return r;
+    r = plan_gemv<QT, PRO_QUANT, EPI_RESIDUAL>(c, a, wgs, P); if (r) return r;
+    const int rq = (aq.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4), rounds = (a.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4);
+    if (rq > 1 || rounds > 3) return FLM_ERR_UNSUPPORTED;
+    size_t lds = attn_lds_bytes(d.max_seq_len, c->hs, G > 1); if (P.lds > lds) lds = P.lds; if (Pq.lds > lds) lds = Pq.lds;
+    AttnArgs aa = args_attn(c, l, G);
+    unsigned* flag = c->flag_lines;                              // heads' lines (as k_attn_o)
+    unsigned* flagq = c->flag_lines + 768 * 16;                  // the QKV workgroups' lines; value = layer + 1, cleared by k_embed
+    const int gridx = parts + P.grid > Pq.grid ? parts + P.grid : Pq.grid;
+    const dim3 grid(gridx), block(kGemvBlock);
+    const unsigned tgt = (unsigned)(l + 1);
+    if (c->hs % kGroup == 0 && G == 1) {
+        aa.oq = c->att_q; aa.os = c->att_qs; aa.oqt = QT;
+        a.xq = c->att_q; a.xs = c->att_qs;
+        hipLaunchKernelGGL((k_qkv_attn_o<QT, 0, true>), grid, block, lds, st, aq, aa, a, Pq.grid, parts, P.grid, flagq, flag, tgt, c->xwg_err);
+    }
+    else if (G > 1) {
+        if (rounds <= 1) hipLaunchKernelGGL((k_qkv_attn_o<QT, 1, false, true>), grid, block, lds, st, aq, aa, a, Pq.grid, parts, P.grid, flagq, flag, tgt, c->xwg_err);
+        else             hipLaunchKernelGGL((k_qkv_attn_o<QT, 3, false, true>), grid, block, lds, st, aq, aa, a, Pq.grid, parts, P.grid, flagq, flag, tgt, c->xwg_err);
+    }
+    else if (rounds <= 1) hipLaunchKernelGGL((k_qkv_attn_o<QT, 1, false>), grid, block, lds, st, aq, aa, a, Pq.grid, parts, P.grid, flagq, flag, tgt, c->xwg_err);
+    else                  hipLaunchKernelGGL((k_qkv_attn_o<QT, 3, false>), grid, block, lds, st, aq, aa, a, Pq.grid, parts, P.grid, flagq, flag, tgt, c->xwg_err);
+    HIPC(c, hipGetLastError());
+    return FLM_OK;
+}
+
 // FFN13 + FFN2 of layer l in one launch (k_ffn); returns FLM_ERR_UNSUPPORTED when the shape does not allow it
 template <int QT>
 int launch_ffn(flm_ctx* c, hipStream_t st, int l) {
@@ -466,12 +502,16 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
     auto traced = [&](GemvArgs a, int kc, int l) { if (kAblate && c->trace_class == kc && l == 0) a.trace = c->trace; return a; };
     int r;
     for (int l = 0; l < L; ++l) {
-        {   // QKV task + RoPE + KV append (transformer.cpp:132-135, execute_qkv :386-395, execute_attn :431-439): this rank's heads
+        bool fused = false;
+        if (!tp && c->fuse_attn_o && (c->fuse_qkv >= 2 || (c->fuse_qkv && G > 1)) && !c->timing && c->trace_class < 0) {   // QKV + attention + ATTN_O in one launch
+            r = qt == FLM_QT_INT8 ? launch_qkv_attn_o<QT_INT8>(c, st, l, G) : launch_qkv_attn_o<QT_INT16>(c, st, l, G);
+            if (r == FLM_OK) fused = true; else if (r != FLM_ERR_UNSUPPORTED) return r;
+        }
+        if (!fused) {   // QKV task + RoPE + KV append (transformer.cpp:132-135, execute_qkv :386-395, execute_attn :431-439): this rank's heads
             Tick t(c, st, KC_QKV);
             r = launch_gemv<PRO_RMSNORM_QUANT, EPI_ROPE_KV>(c, st, qt, traced(args_qkv(c, l), KC_QKV, l), wgs, coh); if (r) return r;
         }
-        bool fused = false;
-        if (!tp && c->fuse_attn_o && !c->timing && (c->trace_class < 0 || c->trace_class == 101)) {   // attention + ATTN_O in one launch
+        if (!fused && !tp && c->fuse_attn_o && !c->timing && (c->trace_class < 0 || c->trace_class == 101)) {   // attention + ATTN_O in one launch
             r = qt == FLM_QT_INT8 ? launch_attn_o<QT_INT8>(c, st, l, G) : launch_attn_o<QT_INT16>(c, st, l, G);
             if (r == FLM_OK) fused = true; else if (r != FLM_ERR_UNSUPPORTED) return r;
         }
@@ -900,8 +940,8 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
         if (world > 1) { c->pf_x = (float*)(c->xbuf + o_px); c->pf_att = (float*)(c->xbuf + o_pa); c->pf_hd = (float*)(c->xbuf + o_ph); c->pf_in_xbuf = true; }
         HIPB(hipMalloc((void**)&c->xepoch, 64)); HIPB(hipMemsetAsync(c->xepoch, 0, 64, c->stream));
     }
-    HIPB(hipMalloc((void**)&c->flag_lines, 768 * 64)); HIPB(hipMalloc((void**)&c->xwg_err, 64));   // lines 0..255: k_attn_o's heads, 256..511: split heads' scores, 512..767: k_ffn
-    HIPB(hipMemsetAsync(c->flag_lines, 0, 768 * 64, c->stream)); HIPB(hipMemsetAsync(c->xwg_err, 0, 64, c->stream));
+    HIPB(hipMalloc((void**)&c->flag_lines, 1024 * 64)); HIPB(hipMalloc((void**)&c->xwg_err, 64));   // lines 0..255: k_attn_o's heads, 256..511: split heads' scores, 512..767: k_ffn, 768..1023: k_qkv_attn_o's QKV rows
+    HIPB(hipMemsetAsync(c->flag_lines, 0, 1024 * 64, c->stream)); HIPB(hipMemsetAsync(c->xwg_err, 0, 64, c->stream));
     HIPB(hipMalloc(&c->att_q, (size_t)d.dim * c->esz)); HIPB(hipMalloc((void**)&c->att_qs, (size_t)(d.dim / kGroup) * 4));
     HIPB(hipMalloc((void**)&c->att_sc, (size_t)c->heads_local * d.max_seq_len * 4));
     HIPB(hipMalloc((void**)&c->state, sizeof(DecodeState)));
@@ -994,6 +1034,7 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (k == "use_pv_mfma") c->use_pv_mfma = value;
     else if (k == "fuse_attn_o") c->fuse_attn_o = value;
     else if (k == "fuse_ffn") c->fuse_ffn = value;
+    else if (k == "fuse_qkv") c->fuse_qkv = value;
     else if (k == "use_prefill_mq") c->use_prefill_mq = value;
     else if (k == "attn_split") c->attn_split = value;
     else if (k == "use_qk_mfma") c->use_qk_mfma = value;
@@ -1261,12 +1302,15 @@ int flm_kernel_times(flm_ctx* c, int pos, int iters, float* avg_us, int32_t* cou
                          return qt == FLM_QT_INT8 ? launch_attn_o<QT_INT8>(c, st, l, attn_parts(c, pos + 1)) : launch_attn_o<QT_INT16>(c, st, l, attn_parts(c, pos + 1));
         case KC_FFN:     if (!c->fuse_ffn) return FLM_ERR_UNSUPPORTED;
                          return qt == FLM_QT_INT8 ? launch_ffn<QT_INT8>(c, st, l) : launch_ffn<QT_INT16>(c, st, l);
+        case KC_QKV_ATTN_WO: { const int G = attn_parts(c, pos + 1);
+                         if (!c->fuse_attn_o || !(c->fuse_qkv >= 2 || (c->fuse_qkv && G > 1))) return FLM_ERR_UNSUPPORTED;
+                         return qt == FLM_QT_INT8 ? launch_qkv_attn_o<QT_INT8>(c, st, l, G) : launch_qkv_attn_o<QT_INT16>(c, st, l, G); }
         default: return FLM_OK;
         }
     };
-    const int classes[] = {KC_EMBED, KC_QKV, KC_ATTN, KC_ATTN_O, KC_FFN13, KC_FFN2, KC_CLS, KC_ARGMAX, KC_ATTN_WO, KC_FFN};
+    const int classes[] = {KC_EMBED, KC_QKV, KC_ATTN, KC_ATTN_O, KC_FFN13, KC_FFN2, KC_CLS, KC_ARGMAX, KC_ATTN_WO, KC_FFN, KC_QKV_ATTN_WO};
     for (int kc : classes) {
-        const bool fused = kc == KC_ATTN_WO || kc == KC_FFN;
+        const bool fused = kc == KC_ATTN_WO || kc == KC_FFN || kc == KC_QKV_ATTN_WO;
         const bool per_layer = (kc >= KC_QKV && kc <= KC_FFN2) || fused;
         const int n = per_layer ? L : 8;
         for (int it = 0; it < iters + 1 && !r; ++it) {          // first round: warm-up
@@ -1302,6 +1346,7 @@ int flm_kernel_bytes(flm_ctx* c, int kclass, int pos, double* bytes) {
     case KC_FFN2:   *bytes = mat(c->drow_count, d.hidden_dim); break;
     case KC_ATTN_WO: *bytes = 2.0 * c->heads_local * c->hs * 4.0 * (pos + 1) + mat(c->drow_count, d.dim); break;
     case KC_FFN:    *bytes = 2.0 * mat(c->hidden_local, d.dim) + d.dim * 4.0 + mat(c->drow_count, d.hidden_dim); break;
+    case KC_QKV_ATTN_WO: *bytes = mat(3.0 * c->dim_local, d.dim) + d.dim * 4.0 + 2.0 * c->heads_local * c->hs * 4.0 * (pos + 1) + mat(c->drow_count, d.dim); break;
     case KC_CLS:    *bytes = mat(c->cls.rows, d.dim) + d.dim * 4.0; break;
     default:        *bytes = 0; break;
     }

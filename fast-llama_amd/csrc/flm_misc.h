@@ -14,7 +14,10 @@ namespace flm {
 // x1 = embedding[token] (copy or dequantize; transformer.cpp:115-122)
 __global__ void k_embed(float* x, const void* emb, const float* emb_s, int emb_qt, int dim, const int* tok_ptr, unsigned* bar) {
     const int tok = *tok_ptr;
-    if (bar && blockIdx.x == 0) { bar[threadIdx.x * 16] = 0; bar[(threadIdx.x + blockDim.x) * 16] = 0; bar[(threadIdx.x + 2 * blockDim.x) * 16] = 0; }   // the flag lines (768, 64 B apart) of the fused launches that follow
+    if (bar && blockIdx.x == 0) {   // the flag lines (1024, 64 B apart) the workgroups of the token's fused launches wait on
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bar[(threadIdx.x + k * blockDim.x) * 16] = 0;
+    }
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < dim; e += gridDim.x * blockDim.x) {
         float v;
         if (emb_qt == 0) v = reinterpret_cast<const float*>(emb)[(size_t)tok * dim + e];

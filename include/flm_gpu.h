@@ -123,11 +123,12 @@ int  flm_sync(flm_ctx* ctx);
 /* Per-kernel timing at position pos with HIP events on the ctx's stream, averaged over `iters` rounds.
  * Classes: 0 embed, 1 qkv, 2 attn, 3 attn_o, 4 ffn13, 5 ffn2, 6 cls, 7 argmax, 8 allreduce (tensor parallel), and the two fused launches
  * the single-GPU token path runs instead of (2, 3) and (4, 5): 9 attn_wo (attention + Wo), 10 ffn (FFN13 + FFN2); count 0 = not in use.
+ * 11 qkv_attn_wo: QKV + attention + Wo in one launch, what the token path runs instead of (1, 9) at long contexts ("fuse_qkv").
  * avg_us[c] = mean duration of ONE launch of class c (single GPU: the class's launches of one token are
  * enqueued back to back between one pair of events, so the figure is launch duration + dispatch gap and
  * agrees with a rocprofv3 kernel trace), count[c] = launches of that class per token.
  * Side effect: the KV cache is cleared and the decode state is undefined afterwards. */
-#define FLM_KCLASSES 11
+#define FLM_KCLASSES 12
 int  flm_kernel_times(flm_ctx* ctx, int pos, int iters, float* avg_us, int32_t* count);
 /* weight + scale bytes one launch of class c streams (the algorithmic bytes of DESIGN.md) */
 int  flm_kernel_bytes(flm_ctx* ctx, int kclass, int pos, double* bytes);
@@ -140,6 +141,8 @@ int  flm_debug_read(flm_ctx* ctx, int what, int layer, float* out, size_t n);
 /* tuning knobs: "wg_per_cu" workgroups per CU for the GEMV kernels, "use_graph" hipGraph replay on/off,
  * "fuse_attn_o" 0 = attention and the Wo GEMV as two launches (default 1: one launch, single GPU),
  * "fuse_ffn" 0 = FFN13 and FFN2 as two launches (default 1: one launch, single GPU),
+ * "fuse_qkv" QKV in the same launch as attention + Wo: 0 never, 1 (default) when a head is spread over several workgroups (contexts
+ *            from 128 positions on, where it pays), 2 always (single GPU),
  * "use_prefill" 0 = feed prompts token by token (default 1: batched; under tensor parallelism batched once the peers are mapped with
  * flm_p2p_import, token by token otherwise), "use_prefill_mq" 0 = batched attention with one query per
  * workgroup (default 1: eight), "attn_split" 0 = one workgroup per head at every context length (default 1: hs / 32 from 128 positions on; n >= 2: always n),

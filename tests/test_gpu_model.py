@@ -81,7 +81,8 @@ def test_device_greedy_loop_matches_stepwise(gpu):
 @pytest.mark.parametrize("qt", [ff.QT_INT8, ff.QT_INT16])
 def test_7b_width_layer_every_code_path_vs_oracle(gpu, qt):
     """one LLaMA2-7B-width layer + the 32000-row classifier: the production pass geometry, step numbering and LDS layouts
-    (the tiny shapes use other ones), with attention + Wo and FFN13 + FFN2 fused into one launch each and as two launches."""
+    (the tiny shapes use other ones), with attention + Wo and FFN13 + FFN2 fused into one launch each and as two launches, and with
+    QKV in the attention's launch as well (the default only at long contexts)."""
     cfg = synth.make_config("7B", qt); cfg.n_layers = 1
     tensors = synth.make_tensors(cfg, seed=31)
     om = O.OracleModel(cfg, tensors)
@@ -90,7 +91,7 @@ def test_7b_width_layer_every_code_path_vs_oracle(gpu, qt):
     cur, pos = int(np.argmax(want[0])), len(prompt)
     for _ in range(3):
         want.append(om.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(want[-1])); pos += 1
-    for opts in ({}, {"fuse_attn_o": 0}, {"fuse_ffn": 0}, {"fuse_attn_o": 0, "fuse_ffn": 0}):
+    for opts in ({}, {"fuse_attn_o": 0}, {"fuse_ffn": 0}, {"fuse_attn_o": 0, "fuse_ffn": 0}, {"fuse_qkv": 2}, {"fuse_qkv": 2, "use_prefill": 0}):
         ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
         for k, v in opts.items():
             ctx.set_option(k, v)
@@ -213,21 +214,23 @@ def test_long_context_positions(gpu):
 
 def test_fused_attention_decode_over_the_whole_context_matches_two_launches(gpu):
     """7B width, one layer: 1000 greedy tokens (positions 8..1007: 1 to 16 K/V tiles per head) with attention + Wo as one launch
-    and as two -- the same ids and, at the end, the same logits bits; no cross-workgroup wait may time out on the way."""
+    and as two, and with QKV in the same launch at every length / never -- the same ids and, at the end, the same logits bits; no
+    cross-workgroup wait may time out on the way."""
     cfg = synth.make_config("7B", ff.QT_INT8); cfg.n_layers = 1
     tensors = synth.make_tensors(cfg, seed=77)
     prompt = _prompt(cfg.vocab_size, 8)
     res = []
-    for fuse in (1, 0):
+    for fuse, fq in ((1, 1), (0, 1), (1, 2), (1, 0)):
         ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
-        ctx.set_option("fuse_attn_o", fuse)
+        ctx.set_option("fuse_attn_o", fuse); ctx.set_option("fuse_qkv", fq)
         first = ctx.forward_argmax(prompt, 0)
         ids = list(ctx.decode_greedy(first, len(prompt), 1000))
         lg = ctx.forward(np.array([ids[-1]], np.int32), len(prompt) + 1000)
         res.append((first, ids, lg.copy()))
         ctx.close()
-    assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
-    assert bits_equal(res[0][2], res[1][2])
+    for r in res[1:]:
+        assert res[0][0] == r[0] and res[0][1] == r[1]
+        assert bits_equal(res[0][2], r[2])
 
 
 def test_long_context_decode_with_split_heads_vs_oracle(gpu):
@@ -241,7 +244,7 @@ def test_long_context_decode_with_split_heads_vs_oracle(gpu):
     cur, pos = int(np.argmax(want[0])), len(prompt)
     for _ in range(3):
         want.append(om.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(want[-1])); pos += 1
-    for opts in ({}, {"attn_split": 0}, {"attn_split": 2}, {"fuse_attn_o": 0}, {"use_graph": 0}):
+    for opts in ({}, {"attn_split": 0}, {"attn_split": 2}, {"fuse_attn_o": 0}, {"use_graph": 0}, {"fuse_qkv": 0}, {"fuse_qkv": 2, "attn_split": 0}):
         ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
         for k, v in opts.items():
             ctx.set_option(k, v)
