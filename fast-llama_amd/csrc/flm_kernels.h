@@ -20,6 +20,7 @@
 //                         and epilogue (store | residual add | SwiGLU | RoPE + KV-cache append)
 //   k_attn_decode         fp32 single-query attention over the fp32 KV cache (heads split over workgroups at long contexts)
 //   k_attn_o<QT,XR,PREQ>  attention heads and the Wo GEMV in one launch (single GPU)
+//   k_qkv_attn_o<...>     the same with the QKV GEMV in front (long contexts: a head waits for the workgroups that reduced its rows only)
 //   k_ffn<QT,XR2>         FFN13 (+ SwiGLU) and FFN2 (+ residual) in one launch (single GPU)
 //   batched prompt processing: k_rows_prologue, k_gemm_q8_mfma<EPI,WT,WR,NB> / k_gemm_q16_mfma (int8 matrix cores; epilogues store |
 //                         residual | SwiGLU | RoPE + KV rows) / k_gemm_q (v_dot), k_qk_mfma + k_attn_pv_mfma (fp32 matrix cores) /
