@@ -773,7 +773,11 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_gemv(const GemvArgs a) {
     if (kAblate && (a.ablate & 32)) return;
     g.run(a, lds, stamp);
     stamp(6);
-    if (kAblate && a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime() - rt0;
+    if (kAblate && a.trace && threadIdx.x == 0) {
+        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+        a.trace[blockIdx.x * 8 + 7] = rt1 - rt0;
+        if (a.ablate & 64) { a.trace[blockIdx.x * 8 + 1] = rt0; a.trace[blockIdx.x * 8 + 2] = rt1; }   // tools/trace_skew.py: absolute 100 MHz stamps (one clock for all XCDs)
+    }
 }
 
 } // namespace flm

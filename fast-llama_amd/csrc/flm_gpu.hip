@@ -1151,6 +1151,15 @@ int flm_debug_read(flm_ctx* c, int what, int layer, float* out, size_t n) {
             out[i] = (i % 8 == 7 && rpw == 1) ? (float)t[i] : ((t[i] && t[base]) ? (float)(long long)(t[i] - t[base]) : -1.f);
         }
         return FLM_OK; }
+    case 8: {   // tools/trace_skew.py (FLM_ABLATE builds, ablate & 64): columns 1 and 2 = 100 MHz real-time ticks of a workgroup's start / end, relative to the earliest start
+        if (!c->trace || n > 4096 * 8) return fail(c, FLM_ERR_INVALID, "debug_read: no trace");
+        HIPC(c, hipStreamSynchronize(c->stream));
+        std::vector<unsigned long long> t(4096 * 8);
+        HIPC(c, hipMemcpy(t.data(), c->trace, t.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull;
+        for (size_t i = 1; i < n; i += 8) if (t[i] && t[i] < t0) t0 = t[i];
+        for (size_t i = 0; i < n; ++i) out[i] = ((i % 8 == 1 || i % 8 == 2) && t[i]) ? (float)(long long)(t[i] - t0) : -1.f;
+        return FLM_OK; }
     default: return fail(c, FLM_ERR_INVALID, "debug_read: unknown buffer");
     }
     if (n > cap || layer < 0 || layer >= c->d.n_layers) return fail(c, FLM_ERR_INVALID, "debug_read: size/layer");
