@@ -401,6 +401,21 @@ def main():
     mid_pos = pos + args.steps // 2
     tp = world if mode == "tp" else 1
 
+    # a second operating point, outside the timed region of `value`: the same decode from position 512 ("also report at
+    # pos ~ 512"): a 512-token prompt through the batched kernels, 4 untimed steps (graph capture), then K timed steps
+    long_ctx = None
+    if mode == "single" and args.pos is None and rank == 0:
+        try:
+            lp = np.array([1] + [int(x) for x in (np.arange(1, 512) * 7919) % V], dtype=np.int32)
+            lf = ctx.forward_argmax(lp, 0)
+            lw = ctx.decode_greedy(lf, 512, 4)
+            lms = ctx.decode_timed(int(lw[-1]), 516, args.steps)
+            lb = token_bytes(cfg, 516 + args.steps // 2, esz)
+            long_ctx = {"positions": f"516..{515 + args.steps}", "ms_per_step": round(lms / args.steps, 4), "tokens_per_s": round(args.steps / (lms / 1e3), 2),
+                        "bytes_per_token": int(lb), "token_roofline_frac": round(lb * (args.steps / (lms / 1e3)) / 1e9 / HBM_PEAK_GBS, 4),
+                        "note": "device time of K steps between HIP events on the ctx stream; not part of `value`"}
+        except Exception as e:  # noqa: BLE001
+            long_ctx = {"error": str(e)}
     # per-kernel times, live, HIP events on the ctx stream (eager launches, same kernels as the graph)
     kt = ctx.kernel_times(mid_pos, iters=3)
     # the dominant launch of the token: the fused FFN13 + FFN2 kernel where the token path runs it (single GPU), else FFN13
@@ -457,6 +472,8 @@ def main():
                             "instead of attn + attn_o and ffn (k_ffn) instead of ffn13 + ffn2: per token = embed + L * (qkv + attn_wo + ffn) + cls + argmax; where qkv_attn_wo "
                             "(k_qkv_attn_o: contexts from 128 positions on) is listed, the token runs it instead of qkv + attn_wo",
         }
+        if long_ctx is not None:
+            line["long_context"] = long_ctx
         if replicas is not None:
             line["replicas"] = replicas
         if tp_note:
