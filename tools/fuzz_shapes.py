@@ -1,4 +1,6 @@
-"""random small model shapes (odd group counts, hs 32/64/128, int8/int16) against the CPU oracle, logits bit for bit: python tools/fuzz_shapes.py [n] [seed]"""
+"""random small model shapes (odd group counts, hs 32/64/128, int8/int16) against the CPU oracle, logits bit for bit: python tools/fuzz_shapes.py [n] [seed] [long]
+(long = 1: prompts of 100..700 tokens -- the batched prompt kernels, then decode steps with the heads split over workgroups and QKV in the
+attention's launch where the shape allows it)"""
 import sys, os
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np
@@ -7,6 +9,7 @@ from fast_llama_amd import capi, synth, flmfile as ff
 import oracle_py as O
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+long_ctx = len(sys.argv) > 3 and int(sys.argv[3]) != 0
 bad = 0
 for it in range(n):
     hs = int(rng.choice([32, 64, 128])); heads = int(rng.integers(1, 9))
@@ -19,7 +22,7 @@ for it in range(n):
     tensors = synth.make_tensors(cfg, seed=100 + it)
     om = O.OracleModel(cfg, tensors)
     ctx = capi.Ctx(capi.desc_from_config(cfg)); ctx.upload_all(tensors)
-    npr = int(rng.integers(1, 40))
+    npr = int(rng.integers(100, 700)) if long_ctx else int(rng.integers(1, 40))
     prompt = np.array([1] + [int(x) for x in rng.integers(2, vocab, npr - 1)], dtype=np.int32) if npr > 1 else np.array([1], np.int32)
     lg = ctx.forward(prompt, 0); lo = om.forward(prompt, 0)
     ok = np.array_equal(lg.view(np.uint32), lo.view(np.uint32))
