@@ -33,7 +33,7 @@ struct LayerW {
     unsigned got = 0;     // bitmask of uploaded kinds
 };
 
-enum KClass { KC_EMBED = 0, KC_QKV, KC_ATTN, KC_ATTN_O, KC_FFN13, KC_FFN2, KC_CLS, KC_ARGMAX, KC_ALLREDUCE, KC_ATTN_WO /* k_attn_o: attention + Wo */, KC_FFN /* k_ffn: FFN13 + FFN2 */, KC_QKV_ATTN_WO /* k_qkv_attn_o */ };
+enum KClass { KC_EMBED = 0, KC_QKV, KC_ATTN, KC_ATTN_O, KC_FFN13, KC_FFN2, KC_CLS, KC_ARGMAX, KC_ALLREDUCE, KC_ATTN_WO /* k_attn_o: attention + Wo */, KC_FFN /* k_ffn: FFN13 + FFN2 */, KC_QKV_ATTN_WO /* k_qkv_attn_o */, KC_ENG_FFN /* k_engine: FFN13 + FFN2 */, KC_ENG_LAYER /* k_engine: Wo + FFN13 + FFN2 + the next layer's QKV (or the classifier) */ };
 
 struct TimedLaunch { int kclass; hipEvent_t e0, e1; };
 // owners that release on every exit path (the error macros return from the middle of a function)
@@ -90,6 +90,10 @@ struct flm_ctx {
     unsigned* xepoch = nullptr;                        // [4] exchanges done per kind (att, x1, hd, logits), device memory
     float* att_sc = nullptr;                           // [heads_local][max_seq] scores exchanged between the parts of a split head
     int attn_split = 1;                                // option "attn_split": 1 = spread a head over 4 workgroups from kSplitFrom (128) positions on, 0 = never, >= 2 = always that many
+    // the weight-streaming engine (flm_engine.h; single GPU, int8): option "engine": 0 off, 1 FFN13 + FFN2 per launch, 2 Wo .. next QKV per launch
+    int engine = 1; bool eng_built = false; int eng_nslot = 0; size_t eng_lds = 0; int eng_trace = 0;
+    EngPhase* eng_prog[3] = {nullptr, nullptr, nullptr};   // device programs: [0] FFN pairs, [1] layer chains with pre-quantized head outputs, [2] with fp32 head outputs
+    unsigned long long *gx1 = nullptr, *ghd = nullptr, *ghq = nullptr; unsigned* eng_base = nullptr;
     int trace_class = -1; unsigned long long* trace = nullptr;   // FLM_ABLATE builds: GEMV timeline of one kernel class
     std::map<int, hipGraphExec_t> graphs;             // key = with_cls*4 + advance
     std::vector<TimedLaunch>* timing = nullptr;
@@ -283,7 +287,7 @@ bool model_complete(const flm_ctx* c) {
 // context's life and FLM_RETRY tells the caller (inside this library) to run the call again on one kernel per phase.
 constexpr int FLM_RETRY = 1;
 int xwg_check(flm_ctx* c) {
-    if (!c->fuse_attn_o && !c->fuse_ffn && c->attn_split == 0 && !c->p2p) return FLM_OK;
+    if (!c->fuse_attn_o && !c->fuse_ffn && c->attn_split == 0 && !c->p2p && !c->engine) return FLM_OK;
     // (on the context's own stream: a copy on the legacy stream synchronises with every blocking stream of the process -- and fails
     //  outright while another context's thread is capturing its token graph; seen once in ~10 runs of the threaded tensor-parallel tests)
     int e = 0;
@@ -293,7 +297,7 @@ int xwg_check(flm_ctx* c) {
     HIPC(c, hipMemsetAsync(c->xwg_err, 0, 4, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     if (e == 2) return fail(c, FLM_ERR_COMM, "tensor parallel: a peer rank did not deliver its slice (20 s), or another rank gave up");
-    c->fuse_attn_o = 0; c->fuse_ffn = 0; c->fuse_qkv = 0; c->attn_split = 0;
+    c->fuse_attn_o = 0; c->fuse_ffn = 0; c->fuse_qkv = 0; c->attn_split = 0; c->engine = 0;
     for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
     c->graphs.clear();
     return FLM_RETRY;
@@ -470,6 +474,75 @@ int launch_ffn(flm_ctx* c, hipStream_t st, int l) {
     return FLM_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The weight-streaming engine (flm_engine.h): device programs and launches.  Program index of a phase: 4 l + {0 QKV, 1 Wo, 2 FFN13, 3 FFN2},
+// the classifier at 4 L.  Three variants (what differs is where a phase's activation comes from and whether its results leave as granules):
+//   [0] "engine" 1: launches of {FFN13, FFN2} -- FFN13 reads x1 from memory, FFN2 takes hd through the granule hand-off
+//   [1] "engine" 2: launches of {QKV(0)}, {Wo(l), FFN13(l), FFN2(l), QKV(l+1) | classifier}; Wo reads the heads' output already quantized
+//   [2] the same with fp32 head outputs (split heads at long contexts do not quantize their slices)
+// ---------------------------------------------------------------------------------------------
+bool eng_supported(const flm_ctx* c) {
+    const auto& d = c->d;
+    if (c->world != 1 || d.quant_type != FLM_QT_INT8) return false;
+    if (d.dim % 256 || d.hidden_dim % 256 || (c->hs & 1)) return false;
+    if (d.dim / 4 > kEngConsumers * kEngMaxOwn * c->cu_count) return false;           // residual rows per consumer lane
+    if (4 * d.n_layers + 2 >= kEngEpochStride) return false;
+    return true;
+}
+int eng_build(flm_ctx* c) {
+    if (c->eng_built) return FLM_OK;
+    const auto& d = c->d; const int L = d.n_layers;
+    const int kmax = d.hidden_dim > d.dim ? d.hidden_dim : d.dim;
+    int ns = 14; while (ns > 4 && (size_t)eng_lds_layout(ns, kmax, 1, d.dim).total > kLdsMax) --ns;
+    if ((size_t)eng_lds_layout(ns, kmax, 1, d.dim).total > kLdsMax) return FLM_ERR_UNSUPPORTED;
+    c->eng_nslot = ns; c->eng_lds = (size_t)eng_lds_layout(ns, kmax, 1, d.dim).total;
+    {   // the ring takes most of the CU's 160 KiB: raise the kernel's dynamic-LDS limit, once per device
+        static std::mutex mu; static bool done[64] = {false};
+        std::lock_guard<std::mutex> lk(mu);
+        if (c->device >= 0 && c->device < 64 && !done[c->device]) {
+            HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_engine<QT_INT8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
+            done[c->device] = true;
+        }
+    }
+    const size_t kv_layer = (size_t)c->heads_local * d.max_seq_len * c->hs;
+    for (int v = 0; v < 3; ++v) {
+        std::vector<EngPhase> pr((size_t)4 * L + 1);
+        for (int l = 0; l < L; ++l) {
+            LayerW& w = c->layers[l];
+            EngPhase q{}; q.W = w.qkv.q; q.sW = w.qkv.s; q.K = d.dim; q.rows = w.qkv.rows; q.epi = EPI_ROPE_KV;
+            q.pro = (v == 0 || l == 0) ? EPRO_X_RMS : EPRO_GRAN_RMS; q.x = c->x1; q.norm_w = w.att_norm; q.out = c->qbuf;
+            q.kcache = c->kcache + (size_t)l * kv_layer; q.vcache = c->vcache + (size_t)l * kv_layer;
+            q.dim = c->dim_local; q.kv_dim = c->dim_local; q.hs = c->hs; q.max_seq = d.max_seq_len;
+            EngPhase o{}; o.W = w.o.q; o.sW = w.o.s; o.K = d.dim; o.rows = c->drow_count; o.epi = EPI_RESIDUAL;
+            o.pro = v == 1 ? EPRO_XQ : EPRO_X_Q; o.x = c->att_out; o.xq = c->att_q; o.xs = c->att_qs; o.out = c->x1 + c->drow_begin; o.gran_out = 1;
+            EngPhase f{}; f.W = w.w13.q; f.sW = w.w13.s; f.K = d.dim; f.rows = c->hidden_local; f.epi = EPI_SWIGLU;
+            f.pro = v == 0 ? EPRO_X_RMS : EPRO_GRAN_RMS; f.x = c->x1; f.norm_w = w.ffn_norm; f.out = c->hd + c->plan.hidden_begin; f.gran_out = 1;
+            EngPhase g{}; g.W = w.w2.q; g.sW = w.w2.s; g.K = d.hidden_dim; g.rows = c->drow_count; g.epi = EPI_RESIDUAL;
+            g.pro = EPRO_GRAN_HD; g.out = c->x1 + c->drow_begin; g.gran_out = v == 0 ? 0 : 1;
+            pr[4 * l] = q; pr[4 * l + 1] = o; pr[4 * l + 2] = f; pr[4 * l + 3] = g;
+        }
+        EngPhase k{}; k.W = c->cls.q; k.sW = c->cls.s; k.K = d.dim; k.rows = c->cls.rows; k.epi = EPI_STORE;
+        k.pro = EPRO_GRAN_RMS; k.norm_w = c->out_norm; k.out = c->logits;
+        pr[4 * L] = k;
+        if (!c->eng_prog[v]) HIPC(c, hipMalloc((void**)&c->eng_prog[v], pr.size() * sizeof(EngPhase)));
+        HIPC(c, hipMemcpyAsync(c->eng_prog[v], pr.data(), pr.size() * sizeof(EngPhase), hipMemcpyHostToDevice, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));                                      // (pr goes out of scope)
+    }
+    c->eng_built = true;
+    return FLM_OK;
+}
+int launch_engine(flm_ctx* c, hipStream_t st, int variant, int ph0, int ph1) {
+    EngArgs a{};
+    a.prog = c->eng_prog[variant]; a.ph0 = ph0; a.ph1 = ph1;
+    a.gx1 = c->gx1; a.ghd = c->ghd; a.ghq = c->ghq; a.base_ptr = c->eng_base; a.x1 = c->x1;
+    a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.pos_ptr = &c->state->pos; a.err = c->xwg_err; a.nslot = c->eng_nslot;
+    if (c->eng_trace && ph0 == c->eng_trace) a.trace = c->trace;                     // tools/trace_eng.py: the stamps of the launch that starts at this phase
+    hipLaunchKernelGGL(k_engine<QT_INT8>, dim3(c->cu_count), dim3(kEngBlock), c->eng_lds, st, a);
+    HIPC(c, hipGetLastError());
+    return FLM_OK;
+}
+
 // one activation exchange between the tensor-parallel ranks (the reference's threads share the vector in memory instead):
 // peer-to-peer (the producer already stored its slice everywhere: flag round only) or an RCCL all-gather
 enum XKind { XK_ATT = 0, XK_X1 = 1, XK_HD = 2, XK_LOGITS = 3 };
@@ -495,13 +568,32 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
     const bool tp = c->world > 1, coh = tp && c->p2p;
     {
         Tick t(c, st, KC_EMBED);
-        hipLaunchKernelGGL(k_embed, dim3((d.dim + 255) / 256), dim3(256), 0, st, c->x1, (const void*)c->emb, (const float*)c->emb_s, c->emb_qt, d.dim, (const int*)&c->state->tok, c->flag_lines);
+        hipLaunchKernelGGL(k_embed, dim3((d.dim + 255) / 256), dim3(256), 0, st, c->x1, (const void*)c->emb, (const float*)c->emb_s, c->emb_qt, d.dim, (const int*)&c->state->tok, c->flag_lines, c->eng_base);
         HIPC(c, hipGetLastError());
     }
     const int wgs = gemv_grid(c->cu_count, c->wg_per_cu, 0, 0);
     auto traced = [&](GemvArgs a, int kc, int l) { if (kAblate && c->trace_class == kc && l == 0) a.trace = c->trace; return a; };
     int r;
-    for (int l = 0; l < L; ++l) {
+    // the weight-streaming engine (single GPU, int8): 1 = FFN13 + FFN2 per launch, 2 = {Wo, FFN13, FFN2, next QKV | classifier} per launch
+    int eng = 0;
+    if (!tp && c->engine && !c->timing && c->trace_class < 0 && c->eng_built) eng = c->engine;   // (programs are built before any capture: eng_prepare)
+    bool cls_done = false;
+    if (eng >= 2) {
+        const bool preq = hs % kGroup == 0 && G == 1;                 // the heads hand their output over quantized
+        const int v = preq ? 1 : 2;
+        r = launch_engine(c, st, v, 0, 1); if (r) return r;           // QKV of layer 0 (x1 from memory)
+        for (int l = 0; l < L; ++l) {
+            AttnArgs aa = args_attn(c, l, G);
+            if (preq) { aa.oq = c->att_q; aa.os = c->att_qs; aa.oqt = QT_INT8; }
+            if (G > 1) hipLaunchKernelGGL(k_attn_decode<true>, dim3(c->heads_local * G), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, hs, true), st, aa);
+            else       hipLaunchKernelGGL(k_attn_decode<false>, dim3(c->heads_local), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, hs, false), st, aa);
+            HIPC(c, hipGetLastError());
+            const int ph1 = l + 1 < L ? 4 * l + 5 : (with_cls ? 4 * L + 1 : 4 * L);
+            r = launch_engine(c, st, v, 4 * l + 1, ph1); if (r) return r;
+        }
+        cls_done = with_cls;
+    }
+    for (int l = 0; l < (eng >= 2 ? 0 : L); ++l) {
         bool fused = false;
         if (!tp && c->fuse_attn_o && (c->fuse_qkv >= 2 || (c->fuse_qkv && G > 1)) && !c->timing && c->trace_class < 0) {   // QKV + attention + ATTN_O in one launch
             r = qt == FLM_QT_INT8 ? launch_qkv_attn_o<QT_INT8>(c, st, l, G) : launch_qkv_attn_o<QT_INT16>(c, st, l, G);
@@ -529,6 +621,7 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
             r = launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, traced(args_o(c, l), KC_ATTN_O, l), wgs, coh); if (r) return r;
         }
         if (tp) { r = exchange(c, st, XK_X1, c->x1, c->x1 + c->drow_begin, c->drow_count); if (r) return r; }
+        if (eng == 1) { r = launch_engine(c, st, 0, 4 * l + 2, 4 * l + 4); if (r) return r; continue; }   // FFN13 + FFN2 on the engine
         if (!tp && c->fuse_ffn && !c->timing && c->trace_class < 0) {   // FFN13 + FFN2 in one launch
             r = qt == FLM_QT_INT8 ? launch_ffn<QT_INT8>(c, st, l) : launch_ffn<QT_INT16>(c, st, l);
             if (r == FLM_OK) continue; else if (r != FLM_ERR_UNSUPPORTED) return r;
@@ -545,7 +638,7 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
         if (tp) { r = exchange(c, st, XK_X1, c->x1, c->x1 + c->drow_begin, c->drow_count); if (r) return r; }
     }
     if (with_cls) {
-        {   // final norm + CLS task (transformer.cpp:154-160, execute_cls :496-505): this rank's rows of the classifier
+        if (!cls_done) {   // final norm + CLS task (transformer.cpp:154-160, execute_cls :496-505): this rank's rows of the classifier
             Tick t(c, st, KC_CLS);
             r = launch_gemv<PRO_RMSNORM_QUANT, EPI_STORE>(c, st, qt, traced(args_cls(c), KC_CLS, 0), wgs, coh); if (r) return r;
         }
@@ -564,8 +657,17 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
 
 // run one token, through a cached hipGraph when enabled.  T = positions the token's attention covers (known to the host:
 // it picks how many workgroups a head is spread over; the graphs are keyed by it)
+// build the engine's device programs (allocations and copies: never inside a stream capture); an unsupported shape leaves the engine off
+int eng_prepare(flm_ctx* c) {
+    if (!c->engine || c->eng_built) return FLM_OK;
+    if (!eng_supported(c)) { c->engine = 0; return FLM_OK; }
+    const int r = eng_build(c);
+    if (r == FLM_ERR_UNSUPPORTED) { c->engine = 0; return FLM_OK; }
+    return r;
+}
 int run_token(flm_ctx* c, bool with_cls, int advance, int T) {
     const int G = attn_parts(c, T);
+    { const int r = eng_prepare(c); if (r) return r; }
     if (!c->use_graph || c->timing || (c->world > 1 && !c->p2p)) return enqueue_token(c, c->stream, with_cls, advance, G);   // (RCCL collectives stay eager)
     const int key = (with_cls ? 4 : 0) + advance + 8 * G;
     auto it = c->graphs.find(key);
@@ -942,6 +1044,13 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
     }
     HIPB(hipMalloc((void**)&c->flag_lines, 1024 * 64)); HIPB(hipMalloc((void**)&c->xwg_err, 64));   // lines 0..255: k_attn_o's heads, 256..511: split heads' scores, 512..767: k_ffn, 768..1023: k_qkv_attn_o's QKV rows
     HIPB(hipMemsetAsync(c->flag_lines, 0, 1024 * 64, c->stream)); HIPB(hipMemsetAsync(c->xwg_err, 0, 64, c->stream));
+    {   // the engine's granule buffers (8 bytes per value: {value, tag}) and the token's epoch base
+        const size_t nq = (size_t)(d.hidden_dim / kGroup) * (16 * c->esz + 1);
+        HIPB(hipMalloc((void**)&c->gx1, (size_t)d.dim * 8)); HIPB(hipMalloc((void**)&c->ghd, (size_t)d.hidden_dim * 8)); HIPB(hipMalloc((void**)&c->ghq, nq * 8));
+        HIPB(hipMalloc((void**)&c->eng_base, 64));
+        HIPB(hipMemsetAsync(c->gx1, 0, (size_t)d.dim * 8, c->stream)); HIPB(hipMemsetAsync(c->ghd, 0, (size_t)d.hidden_dim * 8, c->stream));
+        HIPB(hipMemsetAsync(c->ghq, 0, nq * 8, c->stream)); HIPB(hipMemsetAsync(c->eng_base, 0, 64, c->stream));
+    }
     HIPB(hipMalloc(&c->att_q, (size_t)d.dim * c->esz)); HIPB(hipMalloc((void**)&c->att_qs, (size_t)(d.dim / kGroup) * 4));
     HIPB(hipMalloc((void**)&c->att_sc, (size_t)c->heads_local * d.max_seq_len * 4));
     HIPB(hipMalloc((void**)&c->state, sizeof(DecodeState)));
@@ -970,7 +1079,7 @@ void flm_ctx_destroy(flm_ctx* c) {
     for (int r = 0; r < c->world; ++r) if (c->peer_opened[r] && c->peer[r]) hipIpcCloseMemHandle(c->peer[r]);
     void* ptrs[] = {c->emb, c->emb_s, c->out_norm, c->kcache, c->vcache, c->xbuf, c->xepoch, c->qbuf,
                     c->rope_cos, c->rope_sin, c->state, c->prompt_dev, c->out_tokens_dev,
-                    c->flag_lines, c->xwg_err, c->att_q, c->att_qs, c->att_sc, c->trace,
+                    c->flag_lines, c->xwg_err, c->att_q, c->att_qs, c->att_sc, c->trace, c->gx1, c->ghd, c->ghq, c->eng_base, c->eng_prog[0], c->eng_prog[1], c->eng_prog[2],
                     c->pf_in_xbuf ? nullptr : c->pf_x, c->pf_qkv, c->pf_q, c->pf_in_xbuf ? nullptr : c->pf_att, c->pf_gu, c->pf_in_xbuf ? nullptr : c->pf_hd, c->pf_xs, c->pf_xq, c->pf_scores};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->comm) ncclCommDestroy(c->comm);
@@ -1037,6 +1146,12 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (k == "fuse_qkv") c->fuse_qkv = value;
     else if (k == "use_prefill_mq") c->use_prefill_mq = value;
     else if (k == "attn_split") c->attn_split = value;
+    else if (k == "engine") c->engine = value;
+    else if (k == "eng_trace") {   // value = first phase of the engine launch whose in-kernel stamps are recorded (0 off); read them with flm_debug_read(9)
+        c->eng_trace = value;
+        if (!c->trace) { HIPC(c, hipMalloc((void**)&c->trace, 4096 * 8 * 8)); }
+        HIPC(c, hipMemset(c->trace, 0, 4096 * 8 * 8));
+    }
     else if (k == "use_qk_mfma") c->use_qk_mfma = value;
     else if (k == "use_p2p") {     // 0: exchange by RCCL all-gathers although the peers are mapped (needs the communicator); 1: back to peer-to-peer
         if (value) { for (int r = 0; r < c->world; ++r) if (!c->peer[r]) return fail(c, FLM_ERR_STATE, "use_p2p: flm_p2p_import has not mapped every peer"); }
@@ -1159,6 +1274,15 @@ int flm_debug_read(flm_ctx* c, int what, int layer, float* out, size_t n) {
         unsigned long long t0 = ~0ull;
         for (size_t i = 1; i < n; i += 8) if (t[i] && t[i] < t0) t0 = t[i];
         for (size_t i = 0; i < n; ++i) out[i] = ((i % 8 == 1 || i % 8 == 2) && t[i]) ? (float)(long long)(t[i] - t0) : -1.f;
+        return FLM_OK; }
+    case 9: {   // tools/trace_eng.py: the engine launch's stamps [workgroup][64] (100 MHz clock), microseconds after the earliest one; 0 = not stamped -> -1
+        if (!c->trace || n > 4096 * 8) return fail(c, FLM_ERR_INVALID, "debug_read: no trace");
+        HIPC(c, hipStreamSynchronize(c->stream));
+        std::vector<unsigned long long> t(4096 * 8);
+        HIPC(c, hipMemcpy(t.data(), c->trace, t.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull;
+        for (size_t i = 0; i < n; ++i) if (i % 8 != 7 && !(i % 8 == 6 && i % 128 < 64) && t[i] && t[i] < t0) t0 = t[i];          // (column 7 of every wave: accumulated waiting time, not a stamp)
+        for (size_t i = 0; i < n; ++i) out[i] = i % 8 == 6 && i % 128 < 64 ? ((t[i] & 0xffff) ? (float)((double)(t[i] >> 16) * 10.0 / (double)(t[i] & 0xffff)) : -1.f) /* ns per piece inside the dot loops */ : i % 8 == 7 ? (float)((double)t[i] * 0.01) : (t[i] ? (float)((double)(long long)(t[i] - t0) * 0.01) : -1.f);
         return FLM_OK; }
     default: return fail(c, FLM_ERR_INVALID, "debug_read: unknown buffer");
     }
@@ -1290,12 +1414,13 @@ int flm_kernel_times(flm_ctx* c, int pos, int iters, float* avg_us, int32_t* cou
     const auto& d = c->d;
     const int qt = d.quant_type, L = d.n_layers, wgs = gemv_grid(c->cu_count, c->wg_per_cu, 0, 0);
     hipStream_t st = c->stream;
+    r = eng_prepare(c); if (r) return r;
     r = set_state(c, pos, 1 % d.vocab_size, 0); if (r) return r;
     EvPair ev; HIPC(c, hipEventCreate(&ev.e0)); HIPC(c, hipEventCreate(&ev.e1));
     const hipEvent_t e0 = ev.e0, e1 = ev.e1;
     auto launch = [&](int kc, int l) -> int {
         switch (kc) {
-        case KC_EMBED:  hipLaunchKernelGGL(k_embed, dim3((d.dim + 255) / 256), dim3(256), 0, st, c->x1, (const void*)c->emb, (const float*)c->emb_s, c->emb_qt, d.dim, (const int*)&c->state->tok, c->flag_lines); return FLM_OK;
+        case KC_EMBED:  hipLaunchKernelGGL(k_embed, dim3((d.dim + 255) / 256), dim3(256), 0, st, c->x1, (const void*)c->emb, (const float*)c->emb_s, c->emb_qt, d.dim, (const int*)&c->state->tok, c->flag_lines, c->eng_base); return FLM_OK;
         case KC_QKV:    return launch_gemv<PRO_RMSNORM_QUANT, EPI_ROPE_KV>(c, st, qt, args_qkv(c, l), wgs);
         case KC_ATTN:   { const int G = attn_parts(c, pos + 1);
                           if (G > 1) hipLaunchKernelGGL(k_attn_decode<true>, dim3(c->heads_local * G), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, c->hs, true), st, args_attn(c, l, G));
@@ -1311,15 +1436,19 @@ int flm_kernel_times(flm_ctx* c, int pos, int iters, float* avg_us, int32_t* cou
                          return qt == FLM_QT_INT8 ? launch_attn_o<QT_INT8>(c, st, l, attn_parts(c, pos + 1)) : launch_attn_o<QT_INT16>(c, st, l, attn_parts(c, pos + 1));
         case KC_FFN:     if (!c->fuse_ffn) return FLM_ERR_UNSUPPORTED;
                          return qt == FLM_QT_INT8 ? launch_ffn<QT_INT8>(c, st, l) : launch_ffn<QT_INT16>(c, st, l);
+        case KC_ENG_FFN:   if (!c->engine || !c->eng_built) return FLM_ERR_UNSUPPORTED;
+                           return launch_engine(c, st, 0, 4 * l + 2, 4 * l + 4);
+        case KC_ENG_LAYER: if (c->engine < 2 || !c->eng_built) return FLM_ERR_UNSUPPORTED;
+                           return launch_engine(c, st, 1, 4 * l + 1, l + 1 < L ? 4 * l + 5 : 4 * L + 1);
         case KC_QKV_ATTN_WO: { const int G = attn_parts(c, pos + 1);
                          if (!c->fuse_attn_o || !(c->fuse_qkv >= 2 || (c->fuse_qkv && G > 1))) return FLM_ERR_UNSUPPORTED;
                          return qt == FLM_QT_INT8 ? launch_qkv_attn_o<QT_INT8>(c, st, l, G) : launch_qkv_attn_o<QT_INT16>(c, st, l, G); }
         default: return FLM_OK;
         }
     };
-    const int classes[] = {KC_EMBED, KC_QKV, KC_ATTN, KC_ATTN_O, KC_FFN13, KC_FFN2, KC_CLS, KC_ARGMAX, KC_ATTN_WO, KC_FFN, KC_QKV_ATTN_WO};
+    const int classes[] = {KC_EMBED, KC_QKV, KC_ATTN, KC_ATTN_O, KC_FFN13, KC_FFN2, KC_CLS, KC_ARGMAX, KC_ATTN_WO, KC_FFN, KC_QKV_ATTN_WO, KC_ENG_FFN, KC_ENG_LAYER};
     for (int kc : classes) {
-        const bool fused = kc == KC_ATTN_WO || kc == KC_FFN || kc == KC_QKV_ATTN_WO;
+        const bool fused = kc == KC_ATTN_WO || kc == KC_FFN || kc == KC_QKV_ATTN_WO || kc == KC_ENG_FFN || kc == KC_ENG_LAYER;
         const bool per_layer = (kc >= KC_QKV && kc <= KC_FFN2) || fused;
         const int n = per_layer ? L : 8;
         for (int it = 0; it < iters + 1 && !r; ++it) {          // first round: warm-up
@@ -1356,6 +1485,8 @@ int flm_kernel_bytes(flm_ctx* c, int kclass, int pos, double* bytes) {
     case KC_ATTN_WO: *bytes = 2.0 * c->heads_local * c->hs * 4.0 * (pos + 1) + mat(c->drow_count, d.dim); break;
     case KC_FFN:    *bytes = 2.0 * mat(c->hidden_local, d.dim) + d.dim * 4.0 + mat(c->drow_count, d.hidden_dim); break;
     case KC_QKV_ATTN_WO: *bytes = mat(3.0 * c->dim_local, d.dim) + d.dim * 4.0 + 2.0 * c->heads_local * c->hs * 4.0 * (pos + 1) + mat(c->drow_count, d.dim); break;
+    case KC_ENG_FFN: *bytes = 2.0 * mat(c->hidden_local, d.dim) + d.dim * 4.0 + mat(c->drow_count, d.hidden_dim); break;
+    case KC_ENG_LAYER: *bytes = mat(c->drow_count, d.dim) + 2.0 * mat(c->hidden_local, d.dim) + mat(c->drow_count, d.hidden_dim) + mat(3.0 * c->dim_local, d.dim) + 2 * d.dim * 4.0; break;   // (the last layer's launch ends with the classifier instead of a QKV)
     case KC_CLS:    *bytes = mat(c->cls.rows, d.dim) + d.dim * 4.0; break;
     default:        *bytes = 0; break;
     }

@@ -124,11 +124,13 @@ int  flm_sync(flm_ctx* ctx);
  * Classes: 0 embed, 1 qkv, 2 attn, 3 attn_o, 4 ffn13, 5 ffn2, 6 cls, 7 argmax, 8 allreduce (tensor parallel), and the two fused launches
  * the single-GPU token path runs instead of (2, 3) and (4, 5): 9 attn_wo (attention + Wo), 10 ffn (FFN13 + FFN2); count 0 = not in use.
  * 11 qkv_attn_wo: QKV + attention + Wo in one launch, what the token path runs instead of (1, 9) at long contexts ("fuse_qkv").
+ * 12 eng_ffn, 13 eng_layer: launches of the weight-streaming engine (option "engine" 1: FFN13 + FFN2 instead of 10; 2: Wo + FFN13 + FFN2 +
+ * the next layer's QKV, or the classifier after the last layer).
  * avg_us[c] = mean duration of ONE launch of class c (single GPU: the class's launches of one token are
  * enqueued back to back between one pair of events, so the figure is launch duration + dispatch gap and
  * agrees with a rocprofv3 kernel trace), count[c] = launches of that class per token.
  * Side effect: the KV cache is cleared and the decode state is undefined afterwards. */
-#define FLM_KCLASSES 12
+#define FLM_KCLASSES 14
 int  flm_kernel_times(flm_ctx* ctx, int pos, int iters, float* avg_us, int32_t* count);
 /* weight + scale bytes one launch of class c streams (the algorithmic bytes of DESIGN.md) */
 int  flm_kernel_bytes(flm_ctx* ctx, int kclass, int pos, double* bytes);
