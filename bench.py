@@ -231,21 +231,34 @@ def time_decode(ctx, cfg, args, prompt, barrier, gold):
     hipGraphs) -> EXACTLY K timed steps between barriers -> the ids for the parity field, and a second pass with an event
     per token for the median.  Returns a dict of measurements."""
     import torch
-    first = ctx.forward_argmax(prompt, 0)
-    ids = [int(first)]
-    pos = len(prompt)
-    n_pre = max(args.warmup, (args.pos - pos) if args.pos is not None else 0)
-    if n_pre > 0:
-        pre = ctx.decode_greedy(first, pos, n_pre)
-        ids += [int(x) for x in pre]; first = int(pre[-1]); pos += n_pre
-    if pos + args.steps > 1024:
-        sys.exit(f"bench.py: positions {pos}..{pos + args.steps - 1} exceed max_seq_len 1024")
+    # Every rank runs BOTH barriers whatever happens on it (a rank that raised before its barriers would leave the others in theirs while
+    # it goes on to the caller's all-reduce: mismatched collectives, a hang instead of the fall-back to replicas); the error is re-raised
+    # behind the second barrier.
+    err = None
+    first, ids, pos, ms_dev, wall = 0, [], len(prompt), 0.0, 0.0
+    try:
+        first = ctx.forward_argmax(prompt, 0)
+        ids = [int(first)]
+        n_pre = max(args.warmup, (args.pos - pos) if args.pos is not None else 0)
+        if n_pre > 0:
+            pre = ctx.decode_greedy(first, pos, n_pre)
+            ids += [int(x) for x in pre]; first = int(pre[-1]); pos += n_pre
+        if pos + args.steps > 1024:
+            raise RuntimeError(f"bench.py: positions {pos}..{pos + args.steps - 1} exceed max_seq_len 1024")
+    except Exception as e:  # noqa: BLE001
+        err = e
     barrier()
     t0 = time.perf_counter()
-    ms_dev = ctx.decode_timed(first, pos, args.steps)      # enqueues EXACTLY K tokens and waits for the last one
+    if err is None:
+        try:
+            ms_dev = ctx.decode_timed(first, pos, args.steps)      # enqueues EXACTLY K tokens and waits for the last one
+        except Exception as e:  # noqa: BLE001
+            err = e
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     barrier()
+    if err is not None:
+        raise err
     ids += [int(x) for x in ctx.last_tokens(args.steps)]
     each = ctx.decode_timed_each(first, pos, args.steps)    # same tokens again (same cache rows), one event per token
     again = [int(x) for x in ctx.last_tokens(args.steps)]

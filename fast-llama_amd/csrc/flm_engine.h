@@ -42,11 +42,13 @@
 
 namespace flm {
 
-constexpr int kEngLoaders = 4, kEngConsumers = 8, kEngBlock = 64 * (kEngLoaders + kEngConsumers);
+constexpr int kEngLoaders = 4, kEngConsumers = 12, kEngBlock = 64 * (kEngLoaders + kEngConsumers);
 constexpr int kEngPieces = 8, kEngSlotW = kEngPieces * 1024, kEngSlotBytes = kEngSlotW + kEngPieces * 64;   // 8 KiB of weights + their 128 scales
-constexpr int kEngMaxSlots = 16;
+constexpr int kEngSlots = 14;                 // ring slots: a compile-time constant (slot = F % 14 and the sequence number F / 14 are computed per fill by lone
+                                              // waves that issue an instruction every ~6 cycles: a division by a run-time value per fill made the loaders the bound)
 constexpr int kEngCL = 64 * kEngConsumers;    // consumer lanes of a workgroup
-constexpr int kEngMaxOwn = 2;                 // residual rows a consumer lane can own: dim <= 4 * 4 * kEngMaxOwn * nCU
+constexpr int kEngMaxOwn = 2;                 // residual rows a consumer lane can own: dim <= 4 * kEngConsumers * kEngMaxOwn * nCU
+constexpr int kEngTrace = 256;                // trace words per workgroup (tools/trace_eng.py): consumer w at 8 w, loader L at 96 + 8 L, consumer accumulators at 128 + 4 w
 constexpr int kEngEpochStride = 1024;         // the token's epoch base advances by this (k_embed): phases per token < 1024
 
 enum EngPro { EPRO_X_RMS = 0,     // x (plain fp32 array, complete when the launch starts) -> rmsnorm -> quantize
@@ -62,17 +64,22 @@ struct EngPhase {
     float* out;                               // plain results (x1 / hd / q / logits)
     float* kcache; float* vcache;             // ROPE_KV: this layer's caches [heads][max_seq][hs]
     int dim, kv_dim, hs, max_seq;             // ROPE_KV geometry
-    int gran_out, pad;                        // results also leave as granules (RESIDUAL -> gx1, SWIGLU -> ghd)
+    int gran_out, index;                      // results also leave as granules (RESIDUAL -> gx1, SWIGLU -> ghd); index of the phase in the token's program (epochs)
+    // geometry the host works out for the launch's grid (eng_fill_geom): the first `umod` workgroups have ucu_hi units, the others one fewer;
+    // reciprocals for the quotients the loaders and consumers need per fill ([0]: workgroups with ucu_hi units, [1]: the others)
+    int ucu_hi, umod;
+    unsigned inv_ppuv, inv2SA[2], inv2SB[2];
 };
+constexpr int kEngMaxPhases = 5;
 struct EngArgs {
-    const EngPhase* prog; int ph0, ph1;       // phases [ph0, ph1) of the token's program
+    EngPhase ph[kEngMaxPhases]; int nph;      // the launch's phases, by value: scalar loads from the kernel-argument segment
     unsigned long long* gx1; unsigned long long* ghd; unsigned long long* ghq;
     const unsigned* base_ptr;                 // the token's epoch base (device memory; advanced once per token)
     const float* x1;                          // the residual stream when the launch starts (owners read their rows)
     const float* rope_cos; const float* rope_sin; const int* pos_ptr;
     int* err;
-    int nslot;
-    unsigned long long* trace;                // FLM_ABLATE builds: per-workgroup stamps
+    unsigned long long* trace;                // tools/trace_eng.py: per-workgroup stamps
+    int ablate;                               // FLM_ABLATE builds only: 1 consumers skip the dots, 2 no scale loads, 4 one fill in flight per loader, 16 no prologues / epilogues
 };
 
 // LDS: [ring: nslot x 17 KiB] [ctl: 256 B] [xq: kmax * esz] [xs: kmax / 64 floats] [chain staging: 4 strips (rmsnorm phases)]
@@ -90,29 +97,66 @@ __host__ __device__ inline EngLds eng_lds_layout(int nslot, int kmax, int esz, i
 enum { ECTL_FILL = 0, ECTL_FREE = 16, ECTL_SYNC = 32, ECTL_ABORT = 33, ECTL_XREQ = 34 /* consumer waves that have fetched the launch's first activation */,
        ECTL_GATHER = 35 /* consumer waves sweeping granules right now */, ECTL_RED = 36 };
 
-// how the rows of a phase fall on (CU, consumer), and the numbering of the phase's ring fills.  Consumers w < rr have `ua` units, the others
-// ua - 1; round s of the stream holds one fill of every consumer that still has pieces: all 8 while s < SB, the first rr while SB <= s < SA.
-// Only those fills are numbered -- a consumer that has run out takes no ring slot (numbering empty fills too left the busy consumers
-// a fraction of the ring: the loaders could not run ahead of them).
+// how the rows of a phase fall on (CU, consumer), and the numbering of the phase's ring fills.  Consumers w < rr ("long") have ua units =
+// SA slots, the others ("short") ua - 1 units = SB slots.  Only fills that exist are numbered -- a consumer that has run out takes no ring
+// slot -- and the two classes are MERGED BY PROGRESS: long round s (one fill of every long consumer) has key (2 s + 1) / SA, short round
+// s' key (2 s' + 1) / SB, smaller keys first, long first on ties.  So a consumer with twice the rows is fed at twice the rate from the
+// start, and everybody ends together (in plain round-robin order the long streams were starved during the first half of a phase and
+// alone, at their own dot rate, during the second: FFN13 took 19 us instead of 13).
 struct EngGeom {
-    int U, PPU, PPUV, NM;        // units, pieces per unit and matrix, per unit (x 2: SWIGLU), matrices
+    int PPUV;                    // pieces per unit (x 2: SWIGLU)
     int ucu;                     // units of this CU
     int ua, rr, SA, SB;          // see above
     int nfill;                   // fills of the phase on this CU
+    unsigned inv2SA, inv2SB;     // ceil(2^32 / (2 SA)), ceil(2^32 / (2 SB)): exact quotients for the numerators that occur (< 2^16)
+    static __host__ __device__ unsigned quo(unsigned x, unsigned d, unsigned inv) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return d > 1 ? __umulhi(x, inv) : x;
+#else
+        (void)inv; return x / d;
+#endif
+    }
     __host__ __device__ int units_of(int w) const { return w < rr ? ua : ua - 1; }
     __host__ __device__ int slots_of(int w) const { return w < rr ? SA : SB; }
-    __host__ __device__ int fill_of(int s, int w) const { return s < SB ? kEngConsumers * s + w : kEngConsumers * SB + rr * (s - SB) + w; }   // (s < slots_of(w))
+    // short rounds in front of long round s: key' < key  <=>  (2 s' + 1) SA < (2 s + 1) SB
+    __host__ __device__ int short_before(int s) const { const int num = (2 * s + 1) * SB - SA; if (num <= 0) return 0; const int q = (int)quo((unsigned)(num + 2 * SA - 1), (unsigned)(2 * SA), inv2SA); return q < SB ? q : SB; }
+    // long rounds in front of short round s': key <= key'  <=>  (2 s + 1) SB <= (2 s' + 1) SA
+    __host__ __device__ int long_before(int s) const { const int num = (2 * s + 1) * SA - SB; if (num < 0) return 0; const int q = (int)quo((unsigned)num, (unsigned)(2 * SB), inv2SB) + 1; return q < SA ? q : SA; }
+    __host__ __device__ int fill_of(int s, int w) const {              // (s < slots_of(w))
+        return w < rr ? rr * s + (kEngConsumers - rr) * short_before(s) + w : (kEngConsumers - rr) * s + rr * long_before(s) + (w - rr);
+    }
 };
-__host__ __device__ inline EngGeom eng_geom(int K, int rows, int esz, bool two, int c, int ncu) {
+// the part of the geometry that needs no division: from the units of the workgroup
+__host__ __device__ inline EngGeom eng_geom_units(int ucu, int ppuv) {
     EngGeom g;
-    g.U = (rows + 3) / 4; g.PPU = K * esz / 256; g.NM = two ? 2 : 1; g.PPUV = g.PPU * g.NM;
-    g.ucu = c < g.U ? (g.U - c + ncu - 1) / ncu : 0;
-    g.ua = (g.ucu + kEngConsumers - 1) / kEngConsumers; g.rr = g.ucu - (g.ua - 1) * kEngConsumers;      // rr in 1..8 when ucu > 0
-    if (g.ucu == 0) { g.ua = 0; g.rr = kEngConsumers; }
-    g.SA = (g.ua * g.PPUV + kEngPieces - 1) / kEngPieces;
-    g.SB = g.ua > 0 ? ((g.ua - 1) * g.PPUV + kEngPieces - 1) / kEngPieces : 0;
+    g.PPUV = ppuv; g.ucu = ucu;
+    g.ua = (ucu + kEngConsumers - 1) / kEngConsumers; g.rr = ucu - (g.ua - 1) * kEngConsumers;      // rr in 1..8 when ucu > 0   (kEngConsumers: a power of two)
+    if (ucu == 0) { g.ua = 0; g.rr = kEngConsumers; }
+    g.SA = (g.ua * ppuv + kEngPieces - 1) / kEngPieces;
+    g.SB = g.ua > 0 ? ((g.ua - 1) * ppuv + kEngPieces - 1) / kEngPieces : 0;
     if (g.rr == kEngConsumers) g.SB = g.SA;                            // every consumer has ua units
     g.nfill = kEngConsumers * g.SB + g.rr * (g.SA - g.SB);
+    g.inv2SA = 0; g.inv2SB = 0;
+    return g;
+}
+__host__ __device__ inline int eng_ppuv(const EngPhase& P, int esz) { return (P.K * esz / 256) * (P.epi == EPI_SWIGLU ? 2 : 1); }
+// host: the phase's per-grid numbers
+inline void eng_fill_geom(EngPhase& P, int esz, int ncu) {
+    const int U = (P.rows + 3) / 4, ppuv = eng_ppuv(P, esz);
+    P.ucu_hi = (U + ncu - 1) / ncu; P.umod = U - (P.ucu_hi - 1) * ncu;                       // workgroups c < umod have ucu_hi units (umod in 1..ncu when U > 0)
+    if (U == 0) { P.ucu_hi = 0; P.umod = ncu; }
+    P.inv_ppuv = ppuv > 1 ? 0xFFFFFFFFu / (unsigned)ppuv + 1u : 0u;
+    for (int v = 0; v < 2; ++v) {
+        const int ucu = P.ucu_hi - v; const EngGeom g = eng_geom_units(ucu > 0 ? ucu : 0, ppuv);
+        P.inv2SA[v] = g.SA > 0 ? 0xFFFFFFFFu / (unsigned)(2 * g.SA) + 1u : 0u; P.inv2SB[v] = g.SB > 0 ? 0xFFFFFFFFu / (unsigned)(2 * g.SB) + 1u : 0u;
+    }
+}
+// device: workgroup c's geometry of phase P
+__device__ __forceinline__ EngGeom eng_geom(const EngPhase& P, int esz, int c) {
+    const int v = c < P.umod ? 0 : 1;
+    int ucu = P.ucu_hi - v; if (ucu < 0) ucu = 0;
+    EngGeom g = eng_geom_units(ucu, eng_ppuv(P, esz));
+    g.inv2SA = P.inv2SA[v]; g.inv2SB = P.inv2SB[v];
     return g;
 }
 
@@ -134,9 +178,6 @@ template <class P> __device__ __forceinline__ P* eng_uni(P* p) {
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
     return reinterpret_cast<P*>((uintptr_t)(((u64)hi << 32) | lo));
 }
-// the loop-invariant part of a phase in scalar registers
-struct EngPh { const void* W; const float* sW; int K, rows, epi, pro; };
-__device__ __forceinline__ EngPh eng_phase(const EngPhase& P) { EngPh q; q.W = eng_uni(P.W); q.sW = eng_uni(P.sW); q.K = eng_uni(P.K); q.rows = eng_uni(P.rows); q.epi = eng_uni(P.epi); q.pro = eng_uni(P.pro); return q; }
 __device__ __forceinline__ void gran_st(u64* p, unsigned epoch, unsigned bits) { __hip_atomic_store(p, ((u64)epoch << 32) | bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // a bounded wait on an LDS word; false = gave up (this wave timed out, or another wave of the workgroup did)
@@ -165,81 +206,129 @@ struct EngWait {
 __device__ __forceinline__ void eng_dma4(const __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned dst) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %0, %1, 0 offen nt lds" :: "v"(voff), "s"(r), "s"(dst) : "memory");
 }
+// the same piece load with the column offset in the instruction's 12-bit immediate: the pieces of a fill that lie in one unit differ by
+// multiples of 256 bytes, so one VGPR address serves the fill
+// (the hardware adds the instruction offset to the LDS address as well -- LDS address = M0 + offset + 16 * lane --: M0 is set OFF bytes low)
+template <int OFF>
+__device__ __forceinline__ void eng_dma16i(const __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen offset:%3 nt lds" :: "v"(voff), "s"(r), "s"(dst - OFF), "i"(OFF) : "memory");
+}
 template <int QT>
 __device__ __forceinline__ void eng_loader(const EngArgs& a, char* lds, const int L) {
     using T = QTraits<QT>;
-    const int lane = threadIdx.x & 63, c = blockIdx.x, ncu = gridDim.x, nslot = a.nslot;
+    const int lane = threadIdx.x & 63, c = blockIdx.x, ncu = gridDim.x;
+    constexpr int nslot = kEngSlots;
     unsigned* ctl = reinterpret_cast<unsigned*>(lds + nslot * kEngSlotBytes);
-    const EngWait wt{ctl, a.err, a.trace ? a.trace + c * 128 + 64 + 8 * L + 7 : nullptr};
+    const EngWait wt{ctl, a.err, a.trace ? a.trace + c * kEngTrace + 96 + 8 * L + 7 : nullptr};
     int F0 = 0;
-    // A fill = 8 weight pieces + 2 scale dword loads = 10 vector-memory instructions; 2 fills of this loader are in flight (8 per CU, ~68 KiB:
-    // what the stream needs, tools/ubench/ldsdma.hip).  A lone wave issues an instruction every ~6 cycles, and a fill every 0.3 us per CU means
-    // ~1 us per fill and loader: everything per fill is incremental scalar arithmetic (the first version, two loaders with divisions per fill,
-    // was the bound at 15 KB/us per CU).  pend: the fill issued before the newest one, not yet published.
-    int pend = -1;
-    auto drain = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (pend >= 0 && lane == 0) eng_lds_st(ctl + ECTL_FILL + pend % nslot, (unsigned)(pend / nslot + 1)); pend = -1; };
-    if (a.trace && lane == 0) a.trace[c * 128 + 64 + 8 * L] = __builtin_amdgcn_s_memrealtime();
+    // A fill = 8 weight pieces + 2 scale dword loads = 10 vector-memory instructions, kEngDepth fills of this loader in flight (12 per CU, ~100 KiB).
+    // The loader is a lone wave that issues an instruction every ~6 cycles and must turn a fill around in ~1 us: everything per fill is
+    // incremental scalar arithmetic, the phase descriptors come from the kernel-argument segment (scalar loads), and a fill that lies inside
+    // one unit (the rule) needs ONE vector address per matrix -- the column offsets are instruction immediates.  (The first versions spent
+    // 1.7 us of instructions per fill: divisions by run-time values, per-piece address arithmetic, per-lane scale decodes.)
+    constexpr int kDepth = 2;
+    int ps0 = 0, ps1 = 0, ps2 = 0; unsigned pv0 = 0, pv1 = 0, pv2 = 0; int npend = 0;   // fills issued and not yet published, oldest first: (slot, sequence to publish)
+    auto publish_oldest = [&]() { if (lane == 0) eng_lds_st(ctl + ECTL_FILL + ps0, pv0); ps0 = ps1; pv0 = pv1; ps1 = ps2; pv1 = pv2; --npend; };
+    auto drain = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); while (npend > 0) publish_oldest(); };
+    // this loader's fills are F = L, L + 4, ...: their slot F % 14 and sequence F / 14 advance incrementally
+    int ownF = L, slot = L % nslot; unsigned seq = (unsigned)(L / nslot);
+    if (a.trace && lane == 0) a.trace[c * kEngTrace + 96 + 8 * L] = __builtin_amdgcn_s_memrealtime();
     // The CU's memory pipeline is a FIFO: an activation requested behind a ring of weight fills returns behind them (+4 us on the first
     // prologue, measured).  The first fill waits until the consumers hold the launch's first activation.
-    if (eng_uni(a.prog[a.ph0].pro) <= EPRO_XQ && !wt.until_ge(ctl + ECTL_XREQ, kEngConsumers)) return;
-    for (int ph = a.ph0; ph < a.ph1; ++ph) {
-        const EngPh P = eng_phase(a.prog[ph]);
+    if (a.ph[0].pro <= EPRO_XQ && !wt.until_ge(ctl + ECTL_XREQ, kEngConsumers)) return;
+    for (int ph = 0; ph < a.nph; ++ph) {
+        const EngPhase& P = a.ph[ph];
         const bool two = P.epi == EPI_SWIGLU;
-        const EngGeom G = eng_geom(P.K, P.rows, T::kEsz, two, c, ncu);
-        const int rowbytes = P.K * T::kEsz, sn = P.K / kGroup;
-        const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(P.W), 0, G.NM * P.rows * rowbytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.sW), 0, G.NM * P.rows * sn * 4, 0x00020000);
+        const EngGeom G = eng_geom(P, T::kEsz, c);
+        const int rowbytes = P.K * T::kEsz, sn = P.K / kGroup, NM = two ? 2 : 1;
+        const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(P.W), 0, NM * P.rows * rowbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.sW), 0, NM * P.rows * sn * 4, 0x00020000);
         const unsigned lane_w = (unsigned)((lane >> 4) * rowbytes + (lane & 15) * 16);
         // scale loads: lane (p = lane >> 4, r = (lane >> 2) & 3, g = lane & 3) of half h -> group g of row r of piece 4 h + p
         const unsigned lane_s = (unsigned)((((lane >> 2) & 3) * sn + (lane & 3)) * 4);
         const unsigned mat_w = two ? (unsigned)(P.rows * rowbytes) : 0u, mat_s = two ? (unsigned)(P.rows * sn * 4) : 0u;
         const unsigned ustep_w = (unsigned)(4 * ncu * kEngConsumers * rowbytes), ustep_s = (unsigned)(4 * ncu * kEngConsumers * sn * 4);
-        const unsigned inv_ppuv = G.PPUV > 1 ? 0xFFFFFFFFu / (unsigned)G.PPUV + 1u : 0u;      // exact quotients for the piece numbers that occur (< 2^16)
-        for (int s = 0; s < G.SA; ++s) {
-            const int nw = s < G.SB ? kEngConsumers : G.rr;            // consumers with a fill in this round
+        int sL = 0, sS = 0, Fi = F0;                                     // next long / short round, next fill number
+        while (sL < G.SA || sS < G.SB) {
+            const bool lng = sS >= G.SB || (sL < G.SA && (2 * sL + 1) * G.SB <= (2 * sS + 1) * G.SA);   // the merge of EngGeom::fill_of
+            const int s = lng ? sL : sS, w0 = lng ? 0 : G.rr, w1 = lng ? G.rr : kEngConsumers;
+            if (lng) ++sL; else ++sS;
+            // does this loader have a fill in the round?  (its fills are ownF, ownF + 4, ...; the round holds Fi .. Fi + (w1 - w0) - 1)
+            const int nround = w1 - w0;
+            if (ownF >= Fi + nround) { Fi += nround; continue; }
             const int j0 = s * kEngPieces;
-            const int m0 = G.PPUV > 1 ? (int)__umulhi((unsigned)j0, inv_ppuv) : j0, rem0 = j0 - m0 * G.PPUV;   // the round's first piece: unit m0 of its stream, piece rem0 of the unit
-            for (int w = 0; w < nw; ++w) {
-                const int F = F0 + G.fill_of(s, w);
-                if (F % kEngLoaders != L) continue;
-                const int slot = F % nslot;
-                const unsigned seq = (unsigned)(F / nslot);
+            const int m0 = G.PPUV > 1 ? (int)__umulhi((unsigned)j0, P.inv_ppuv) : j0, rem0 = j0 - m0 * G.PPUV;   // the round's first piece: unit m0 of its stream, piece rem0 of the unit
+            const int nu_round = lng ? G.ua : G.ua - 1;                   // units of the round's streams
+            // a fill inside one unit that exists: the fast path (rows past the end of a matrix read as zero or as the next matrix's rows: the
+            // epilogue drops their results)
+            const bool fast = rem0 + kEngPieces <= G.PPUV && m0 < nu_round && !(kAblate && (a.ablate & 32));
+            // per-lane scale offsets relative to the stream's unit m0 (fast path): piece 4 h + (lane >> 4)
+            unsigned so_rel0 = 0, so_rel1 = 0;
+            if (fast) {
+                const int r0 = rem0 + (lane >> 4), r1 = r0 + 4;
+                so_rel0 = (two ? (unsigned)((r0 & 1) ? mat_s : 0u) + (unsigned)((r0 >> 1) * 16) : (unsigned)(r0 * 16)) + lane_s;
+                so_rel1 = (two ? (unsigned)((r1 & 1) ? mat_s : 0u) + (unsigned)((r1 >> 1) * 16) : (unsigned)(r1 * 16)) + lane_s;
+            }
+            const unsigned cbo = (unsigned)((two ? rem0 >> 1 : rem0) * 256);   // fast path: byte offset of the fill's first column block in a row
+            while (ownF < Fi + nround) {
+                const int w = w0 + (ownF - Fi), F = ownF;
                 if (eng_lds_ld(ctl + ECTL_FREE + slot) < seq) {
                     drain();                                          // nothing to issue anyway: what has landed becomes visible now
                     if (!wt.until_ge(ctl + ECTL_FREE + slot, seq)) return;
                 }
-                const int nu = G.units_of(w);
                 const unsigned dst = (unsigned)(uintptr_t)(lds + slot * kEngSlotBytes);
                 // while this CU's consumers sweep granules, one fill in flight per loader: their polls queue behind whatever is requested here
                 if (eng_lds_ld(ctl + ECTL_GATHER) != 0) drain();
-                int m = m0, rem = rem0;
-                unsigned ub_w = (unsigned)(4 * (c + ncu * w) * rowbytes) + (unsigned)m0 * ustep_w, ub_s = (unsigned)(4 * (c + ncu * w) * sn * 4) + (unsigned)m0 * ustep_s;
-                // lane-side decode of the scale loads' pieces (p + 4 h pieces behind the cursor): one wrap at most when a unit has >= 8 pieces
+                const unsigned ub_w = (unsigned)(4 * (c + ncu * w) * rowbytes) + (unsigned)m0 * ustep_w, ub_s = (unsigned)(4 * (c + ncu * w) * sn * 4) + (unsigned)m0 * ustep_s;
+                if (fast) {
+                    if (!(kAblate && (a.ablate & 2))) { eng_dma4(rS, so_rel0 + ub_s, dst + kEngSlotW); eng_dma4(rS, so_rel1 + ub_s, dst + kEngSlotW + 256); }
+                    const unsigned v1 = lane_w + ub_w + cbo;
+                    if (two) {
+                        const unsigned v3 = v1 + mat_w;
+                        eng_dma16i<0>(rW, v1, dst); eng_dma16i<0>(rW, v3, dst + 1024); eng_dma16i<256>(rW, v1, dst + 2048); eng_dma16i<256>(rW, v3, dst + 3072);
+                        eng_dma16i<512>(rW, v1, dst + 4096); eng_dma16i<512>(rW, v3, dst + 5120); eng_dma16i<768>(rW, v1, dst + 6144); eng_dma16i<768>(rW, v3, dst + 7168);
+                    } else {
+                        eng_dma16i<0>(rW, v1, dst); eng_dma16i<256>(rW, v1, dst + 1024); eng_dma16i<512>(rW, v1, dst + 2048); eng_dma16i<768>(rW, v1, dst + 3072);
+                        eng_dma16i<1024>(rW, v1, dst + 4096); eng_dma16i<1280>(rW, v1, dst + 5120); eng_dma16i<1536>(rW, v1, dst + 6144); eng_dma16i<1792>(rW, v1, dst + 7168);
+                    }
+                } else {
+                    // the general path: the fill crosses a unit end, runs past the stream's last unit, or units are shorter than a fill
+                    const int nu = G.units_of(w);
+                    int m = m0, rem = rem0; unsigned ubw = ub_w;
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int off = 4 * h + (lane >> 4);
-                    int mm, rr;
-                    if (G.PPUV >= kEngPieces) { const int t = rem + off; const bool wr = t >= G.PPUV; mm = m + (wr ? 1 : 0); rr = wr ? t - G.PPUV : t; }
-                    else { const int t = rem + off; const int q = t / G.PPUV; mm = m + q; rr = t - q * G.PPUV; }
-                    const int cb = two ? rr >> 1 : rr;
-                    const int row = 4 * (c + ncu * (w + kEngConsumers * mm)) + ((lane >> 2) & 3);
-                    const unsigned so = (mm < nu && row < P.rows) ? ub_s + (unsigned)(mm - m) * ustep_s + ((two && (rr & 1)) ? mat_s : 0u) + (unsigned)(cb * 16) + lane_s : 0x80000000u;
-                    eng_dma4(rS, so, dst + kEngSlotW + h * 256);
-                }
+                    for (int h = 0; h < 2; ++h) {
+                        const int off = 4 * h + (lane >> 4);
+                        int mm, rr;
+                        if (G.PPUV >= kEngPieces) { const int t = rem + off; const bool wr = t >= G.PPUV; mm = m + (wr ? 1 : 0); rr = wr ? t - G.PPUV : t; }
+                        else { const int t = rem + off; const int q = t / G.PPUV; mm = m + q; rr = t - q * G.PPUV; }
+                        const int cb = two ? rr >> 1 : rr;
+                        const int row = 4 * (c + ncu * (w + kEngConsumers * mm)) + ((lane >> 2) & 3);
+                        const unsigned so = (mm < nu && row < P.rows) ? ub_s + (unsigned)(mm - m) * ustep_s + ((two && (rr & 1)) ? mat_s : 0u) + (unsigned)(cb * 16) + lane_s : 0x80000000u;
+                        if (!(kAblate && (a.ablate & 2))) eng_dma4(rS, so, dst + kEngSlotW + h * 256);
+                    }
 #pragma unroll
-                for (int p = 0; p < kEngPieces; ++p) {
-                    const int cb = two ? rem >> 1 : rem;
-                    const unsigned base = m < nu ? ub_w + ((two && (rem & 1)) ? mat_w : 0u) + (unsigned)(cb * 256) : 0x80000000u;
-                    eng_dma16(rW, lane_w + base, dst + p * 1024);
-                    if (++rem == G.PPUV) { rem = 0; ++m; ub_w += ustep_w; }
+                    for (int p = 0; p < kEngPieces; ++p) {
+                        const int cb = two ? rem >> 1 : rem;
+                        const unsigned base = m < nu ? ubw + ((two && (rem & 1)) ? mat_w : 0u) + (unsigned)(cb * 256) : 0x80000000u;
+                        eng_dma16(rW, lane_w + base, dst + p * 1024);
+                        if (++rem == G.PPUV) { rem = 0; ++m; ubw += ustep_w; }
+                    }
                 }
-                asm volatile("s_waitcnt vmcnt(10)" ::: "memory");       // at most the newest fill is outstanding: the one before has landed
-                if (pend >= 0 && lane == 0) eng_lds_st(ctl + ECTL_FILL + pend % nslot, (unsigned)(pend / nslot + 1));
-                pend = F;
+                // kDepth fills in flight: with kDepth - 1 older ones pending, the oldest has landed once at most (kDepth - 1) * 10 loads are outstanding
+                if (kAblate && (a.ablate & 4)) drain();
+                if (npend == kDepth - 1) {
+                    if constexpr (kDepth == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");   // (kDepth - 1) * 10
+                    publish_oldest();
+                }
+                static_assert(kDepth == 2 || kDepth == 3, "the vmcnt immediates above");
+                if (npend == 0) { ps0 = slot; pv0 = seq + 1; } else if (npend == 1) { ps1 = slot; pv1 = seq + 1; } else { ps2 = slot; pv2 = seq + 1; }
+                ++npend;
+                ownF += kEngLoaders; slot += kEngLoaders; if (slot >= nslot) { slot -= nslot; ++seq; }
             }
+            Fi += nround;
         }
         F0 += G.nfill;
-        if (a.trace && lane == 0 && ph - a.ph0 < 7) a.trace[c * 128 + 64 + 8 * L + 1 + (ph - a.ph0)] = __builtin_amdgcn_s_memrealtime();   // the phase's last fill is issued
+        if (a.trace && lane == 0 && ph < 7) a.trace[c * kEngTrace + 96 + 8 * L + 1 + ph] = __builtin_amdgcn_s_memrealtime();   // the phase's last fill is issued
     }
     drain();
 }
@@ -251,8 +340,8 @@ struct EngCons {
     char* lds; unsigned* ctl; EngWait wt; EngLds LY;
     int lane, w, c, ncu, nsync;
     bool ok;
-    unsigned long long* trace;                // [workgroup][128]: consumer w's stamps at 8 w + k, loader L's at 64 + 8 L + k (100 MHz clock)
-    __device__ __forceinline__ void stamp(int k) const { if (trace && lane == 0 && k < 8) trace[c * 128 + 8 * w + k] = __builtin_amdgcn_s_memrealtime(); }
+    unsigned long long* trace;                // [workgroup][kEngTrace] (100 MHz clock)
+    __device__ __forceinline__ void stamp(int k) const { if (trace && lane == 0 && k < 6) trace[c * kEngTrace + 8 * w + k] = __builtin_amdgcn_s_memrealtime(); }
     // meet the other consumer waves (LDS counter; the loaders never take part)
     __device__ __forceinline__ void sync4() {   // ("4": the first version had 4 consumer waves)
         ++nsync;
@@ -281,7 +370,7 @@ struct EngSpin {
 // rmsnorm + quantize of the n values staged in the chain strips (gemv_prologue's PRO_RMSNORM_QUANT, on the consumer waves): wave c < 4 runs the
 // reference's strided lane c (sq_chain_spec), then every lane scales and quantizes its 4-element pieces.
 template <int QT>
-__device__ __forceinline__ void eng_norm_quant(EngCons& E, const int n, const float* norm_w, const bool with_norm) {
+__device__ __forceinline__ void eng_norm_quant(EngCons& E, const int n, const float* norm_w, const bool with_norm, const float4 (&nwp)[4]) {
     using T = QTraits<QT>;
     float* stage = reinterpret_cast<float*>(E.lds + E.LY.off_stage);
     float* red = reinterpret_cast<float*>(E.ctl + ECTL_RED);
@@ -299,6 +388,7 @@ __device__ __forceinline__ void eng_norm_quant(EngCons& E, const int n, const fl
         r = rms_scale(ss, n);
     }
     const int rounds = (n + 4 * kEngCL - 1) / (4 * kEngCL);
+#pragma unroll 4
     for (int i = 0; i < rounds; ++i) {
         const int e = 4 * T4 + 4 * kEngCL * i, k = T4 + kEngCL * i;             // chain element k of every strip = x[4 k + c]
         const bool act = e < n;
@@ -307,7 +397,7 @@ __device__ __forceinline__ void eng_norm_quant(EngCons& E, const int n, const fl
             const int o = (k >> bs) * LS + (k & (B - 1));
             v = make_float4(stage[o], stage[CS + o], stage[2 * CS + o], stage[3 * CS + o]);
             if (with_norm) {   // multiply_avx256 (x86_simd.cpp:1360-1372): (x*w)*r
-                const float4 wv = *reinterpret_cast<const float4*>(norm_w + e);
+                const float4 wv = i < 4 ? nwp[i < 4 ? i : 0] : *reinterpret_cast<const float4*>(norm_w + e);   // (the first 4 rounds were fetched before the vector arrived)
                 v.x = __fmul_rn(__fmul_rn(v.x, wv.x), r); v.y = __fmul_rn(__fmul_rn(v.y, wv.y), r);
                 v.z = __fmul_rn(__fmul_rn(v.z, wv.z), r); v.w = __fmul_rn(__fmul_rn(v.w, wv.w), r);
             }
@@ -389,6 +479,10 @@ __device__ __forceinline__ void eng_prologue(EngCons& E, const EngArgs& a, const
         return;
     }
     // fp32 sources: stage the vector in the chain strips (zero-padded), then (rmsnorm,) quantize
+    // the norm weights first: requested behind the loaders' fills they would come back microseconds later, on the critical path
+    float4 nwp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int e = 4 * T4 + 4 * kEngCL * i; nwp[i] = (P.pro != EPRO_X_Q && e < n) ? *reinterpret_cast<const float4*>(P.norm_w + e) : make_float4(0.f, 0.f, 0.f, 0.f); }
     const int bs = chain_bshift(n), slots = 64 << bs;                  // chain elements per strip incl. padding
     const int rounds = (slots + kEngCL - 1) / kEngCL;
     if (P.pro == EPRO_GRAN_RMS) {
@@ -432,7 +526,7 @@ __device__ __forceinline__ void eng_prologue(EngCons& E, const EngArgs& a, const
         }
     }
     E.sync4();
-    eng_norm_quant<QT>(E, n, P.norm_w, P.pro != EPRO_X_Q);
+    eng_norm_quant<QT>(E, n, P.norm_w, P.pro != EPRO_X_Q, nwp);
 }
 
 // the reference's chain over a piece's 4 groups: acc = fma(sW[g] * sX[g], float(dot_g), acc), g ascending (quant_operators.cpp:274-276).  fd: this
@@ -501,12 +595,13 @@ __device__ __forceinline__ void eng_consumer(const EngArgs& a, char* lds, const 
     EngCons E;
     E.lds = lds; E.lane = threadIdx.x & 63; E.w = w; E.c = blockIdx.x; E.ncu = gridDim.x; E.nsync = 0; E.ok = true; E.trace = a.trace;
     E.stamp(0);
-    const int nslot = a.nslot, lane = E.lane, c = E.c, ncu = E.ncu;
+    constexpr int nslot = kEngSlots;
+    const int lane = E.lane, c = E.c, ncu = E.ncu;
     E.ctl = reinterpret_cast<unsigned*>(lds + nslot * kEngSlotBytes);
-    E.wt = EngWait{E.ctl, a.err, a.trace ? a.trace + E.c * 128 + 8 * w + 7 : nullptr};
+    E.wt = EngWait{E.ctl, a.err, a.trace ? a.trace + E.c * kEngTrace + 8 * w + 7 : nullptr};
     {   // the LDS layout depends on the largest K / the largest normalised vector of the launch
         int kmax = 0, nnorm = 0;
-        for (int ph = a.ph0; ph < a.ph1; ++ph) { const EngPhase& P = a.prog[ph]; if (P.K > kmax) kmax = P.K; if (P.pro != EPRO_XQ && P.pro != EPRO_GRAN_HD && P.K > nnorm) nnorm = P.K; }
+        for (int ph = 0; ph < a.nph; ++ph) { const EngPhase& P = a.ph[ph]; if (P.K > kmax) kmax = P.K; if (P.pro != EPRO_XQ && P.pro != EPRO_GRAN_HD && P.K > nnorm) nnorm = P.K; }
         E.LY = eng_lds_layout(nslot, kmax, T::kEsz, nnorm);
     }
     const unsigned base = (unsigned)eng_uni((int)*a.base_ptr);
@@ -515,8 +610,8 @@ __device__ __forceinline__ void eng_consumer(const EngArgs& a, char* lds, const 
     float x1own[kEngMaxOwn];
 #pragma unroll
     for (int m = 0; m < kEngMaxOwn; ++m) x1own[m] = 0.f;
-    for (int ph = a.ph0; ph < a.ph1; ++ph) {
-        const EngPhase& P = a.prog[ph];
+    for (int ph = 0; ph < a.nph; ++ph) {
+        const EngPhase& P = a.ph[ph];
         if (P.epi == EPI_RESIDUAL) {
 #pragma unroll
             for (int m = 0; m < kEngMaxOwn; ++m) { const int row = 4 * (c + ncu * (w + kEngConsumers * m)) + lane; if (lane < 4 && row < P.rows) x1own[m] = a.x1[row]; }
@@ -525,22 +620,25 @@ __device__ __forceinline__ void eng_consumer(const EngArgs& a, char* lds, const 
     }
     const char* xq = lds + E.LY.off_xq; const float* xs = reinterpret_cast<const float*>(lds + E.LY.off_xs);
     int F0 = 0;
-    for (int ph = a.ph0; ph < a.ph1 && E.ok; ++ph) {
-        EngPhase P = a.prog[ph];
-        P.K = eng_uni(P.K); P.rows = eng_uni(P.rows); P.epi = eng_uni(P.epi); P.pro = eng_uni(P.pro); P.gran_out = eng_uni(P.gran_out);
-        const unsigned epoch = base + (unsigned)ph + 1u;                // of this phase's results; the previous phase's: epoch - 1
+    unsigned long long tacc_fill = 0, tacc_run = 0, tacc_epi = 0, tacc_slots = 0;   // (tracing) 100 MHz ticks waiting for fills / in the dots / in epilogues; slots
+    for (int ph = 0; ph < a.nph && E.ok; ++ph) {
+        const EngPhase& P = a.ph[ph];
+        const unsigned epoch = base + (unsigned)P.index + 1u;           // of this phase's results; the previous phase's: epoch - 1
         const bool two = P.epi == EPI_SWIGLU;
-        const EngGeom G = eng_geom(P.K, P.rows, T::kEsz, two, c, ncu);
+        const EngGeom G = eng_geom(P, T::kEsz, c);
         const int nu = G.units_of(w), ns = G.slots_of(w);
-        eng_prologue<QT>(E, a, P, epoch - 1u);
+        if (kAblate && (a.ablate & 16)) { if (ph == 0 && lane == 0) __hip_atomic_fetch_add(E.ctl + ECTL_XREQ, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // (pure streaming: no prologue)
+        else eng_prologue<QT>(E, a, P, epoch - 1u);
         if (!E.ok) break;
-        E.stamp(1 + 3 * (ph - a.ph0));
+        E.stamp(1 + 3 * ph);
         float acc = 0.f, acc3 = 0.f;
         int m = 0, rem = 0;
         for (int s = 0; s < ns; ++s) {
             const int F = F0 + G.fill_of(s, w), slot = F % nslot;
             const unsigned seq = (unsigned)(F / nslot) + 1u;
+            const unsigned long long tf0 = E.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
             if (!E.wt.until_ge(E.ctl + ECTL_FILL + slot, seq)) { E.ok = false; break; }
+            if (E.trace) { tacc_fill += __builtin_amdgcn_s_memrealtime() - tf0; ++tacc_slots; }
             {
                 const char* sl = lds + slot * kEngSlotBytes;
                 const char* wp = sl + lane * 16;
@@ -552,11 +650,14 @@ __device__ __forceinline__ void eng_consumer(const EngArgs& a, char* lds, const 
                     const char* xa = xq + cb0 * 256 + (lane & 15) * 16;
                     const char* xsa = reinterpret_cast<const char*>(xs) + cb0 * 16;
                     const unsigned long long tr0 = E.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
-                    if (two) eng_run<true>(wp + p * 1024, sp + p * 64, xa, xsa, run >> 1, acc, acc3);
+                    if (kAblate && (a.ablate & 1)) {}
+                    else if (two) eng_run<true>(wp + p * 1024, sp + p * 64, xa, xsa, run >> 1, acc, acc3);
                     else eng_run<false>(wp + p * 1024, sp + p * 64, xa, xsa, run, acc, acc3);
-                    if (E.trace && lane == 0) E.trace[c * 128 + 8 * w + 6] += ((__builtin_amdgcn_s_memrealtime() - tr0) << 16) + (unsigned)run;   // (tracing) time in the dots, pieces done
+                    if (E.trace) tacc_run += ((__builtin_amdgcn_s_memrealtime() - tr0) << 16) + (unsigned)run;   // (tracing) time in the dots, pieces done
                     p += run; rem += run;
-                    if (rem == G.PPUV) {
+                    const unsigned long long te0 = E.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+                    if (rem == G.PPUV && kAblate && (a.ablate & 16)) { acc = 0.f; acc3 = 0.f; rem = 0; ++m; }
+                    else if (rem == G.PPUV) {
                             // ---- the unit's 4 rows are complete: row r's value sits in all lanes of DPP row r
                             const int u = c + ncu * (w + kEngConsumers * m), row0 = 4 * u;
                             const float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 0)), a1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 16));
@@ -575,7 +676,9 @@ __device__ __forceinline__ void eng_consumer(const EngArgs& a, char* lds, const 
                                 const float b0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc3), 0)), b1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc3), 16));
                                 const float b2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc3), 32)), b3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc3), 48));
                                 const float v3 = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
-                                if (rv) { const float h = swiglu_elem(v, v3); P.out[row] = h; if (P.gran_out) gran_st(a.ghd + row, epoch, __float_as_uint(h)); }   // o1.swiglu(o3) transformer.cpp:481
+                                // o1.swiglu(o3) (transformer.cpp:481): here only when the results stay in memory; inside a launch the owner of the row's quant group
+                                // evaluates it for 64 rows at once (4 lanes of a lone wave in double precision cost ~1 us per unit on this wave's critical path)
+                                if (rv) { if (P.gran_out) { gran_st(a.ghd + 2 * row, epoch, __float_as_uint(v)); gran_st(a.ghd + 2 * row + 1, epoch, __float_as_uint(v3)); } else P.out[row] = swiglu_elem(v, v3); }
                             } else {   // EPI_ROPE_KV: rows (2i, 2i+1) of [Wq; Wk; Wv]: RoPE on q and k, k and v appended to the cache
                                 const float x0 = lane == 0 ? a0 : a2, x1 = lane == 0 ? a1 : a3;
                                 const int prow = row0 + lane;                                  // lanes 0 and 2: the pair's first row
@@ -597,6 +700,7 @@ __device__ __forceinline__ void eng_consumer(const EngArgs& a, char* lds, const 
                                 }
                             }
                             acc = 0.f; acc3 = 0.f; rem = 0; ++m;
+                            if (E.trace) tacc_epi += __builtin_amdgcn_s_memrealtime() - te0;
                     }
                 }
             }
@@ -605,21 +709,24 @@ __device__ __forceinline__ void eng_consumer(const EngArgs& a, char* lds, const 
         }
         F0 += G.nfill;
         if (!E.ok) break;
-        E.stamp(2 + 3 * (ph - a.ph0));
-        if (P.epi == EPI_SWIGLU && P.gran_out && w == kEngConsumers - 1) {
-            // hop 1 of the hd hand-off: this CU owns the quant groups g = c, c + nCU, ...: gather the group's 64 values (lane = element),
-            // qh.quantize(hd) (transformer.cpp:149; quant_operators.cpp:26-47: max order-free, then the element step), publish 16 dwords + scale
+        E.stamp(2 + 3 * ph);
+        if (P.epi == EPI_SWIGLU && P.gran_out && w == kEngConsumers - 1 && !(kAblate && (a.ablate & 16))) {
+            // hop 1 of the hd hand-off: this CU owns the quant groups g = c, c + nCU, ...: gather the group's 64 pairs of chain values (lane = row),
+            // SwiGLU, qh.quantize(hd) (transformer.cpp:149; quant_operators.cpp:26-47: max order-free, then the element step), publish 16 dwords + scale
             constexpr int DPG = 16 * T::kEsz, GPG = DPG + 1;
+            typedef unsigned v4u __attribute__((ext_vector_type(4)));
+            const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(a.ghd, 0, P.rows * 16, 0x00020000);
             for (int g = c; g < P.rows / kGroup; g += ncu) {
-                u64 x;
+                v4u x;                                                  // {W1 dot chain, tag, W3 dot chain, tag} of row 64 g + lane
                 EngSpin sp;
                 while (true) {
-                    x = __hip_atomic_load(a.ghd + g * kGroup + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__all((unsigned)(x >> 32) == epoch)) break;
+                    x = __builtin_bit_cast(v4u, __builtin_amdgcn_raw_buffer_load_b128(rh, (g * kGroup + lane) * 16, 0, kAuxCoherent));
+                    if (__all(x.y == epoch && x.w == epoch)) break;
                     if (sp.fail(E.wt)) { E.ok = false; break; }
                 }
                 if (!E.ok) break;
-                const float hv = __uint_as_float((unsigned)x);
+                const float hv = swiglu_elem(__uint_as_float(x.x), __uint_as_float(x.z));      // o1.swiglu(o3) transformer.cpp:481
+                P.out[g * kGroup + lane] = hv;
                 const float mx = wave_max(fabsf(hv));
                 const float sc = __fdiv_rn(mx, T::kF);
                 const int q = quant_elem(hv, sc);
@@ -627,16 +734,17 @@ __device__ __forceinline__ void eng_consumer(const EngArgs& a, char* lds, const 
                 if ((lane & 3) == 0) gran_st(a.ghq + g * GPG + (lane >> 2), epoch, pk);
                 if (lane == 0) gran_st(a.ghq + g * GPG + DPG, epoch, __float_as_uint(sc));
             }
-            E.stamp(3 + 3 * (ph - a.ph0));
+            E.stamp(3 + 3 * ph);
         }
     }
+    if (E.trace && lane == 0) { unsigned long long* t = E.trace + c * kEngTrace; t[8 * w + 6] = tacc_run; t[128 + 4 * w] = tacc_fill; t[128 + 4 * w + 1] = tacc_run >> 16; t[128 + 4 * w + 2] = tacc_epi; t[128 + 4 * w + 3] = tacc_slots; }
 }
 
 // grid = CUs (every workgroup resident: the consumers of all CUs wait for each other's granules), block = kEngBlock
 template <int QT>
 __global__ void __launch_bounds__(kEngBlock) k_engine(const EngArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    unsigned* ctl = reinterpret_cast<unsigned*>(lds + a.nslot * kEngSlotBytes);
+    unsigned* ctl = reinterpret_cast<unsigned*>(lds + kEngSlots * kEngSlotBytes);
     if (threadIdx.x < 64) ctl[threadIdx.x] = 0;
     __syncthreads();                                                     // the only workgroup barrier of the kernel
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

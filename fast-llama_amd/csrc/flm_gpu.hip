@@ -76,6 +76,7 @@ struct flm_ctx {
     int use_pv_mfma = 1;                               // option "use_pv_mfma": prefill weighted sum (softmax x V) on the matrix cores as well (needs use_qk_mfma), 0: VALU chains
     int use_qk_mfma = 1;                               // option "use_qk_mfma": prefill scores on the matrix cores (fp32 MFMA, bit-identical), 0: VALU chains inside the attention kernel
     float* pf_scores = nullptr;                        // [heads][max_seq][max_seq] prefill scores (k_qk_mfma -> k_attn_prefill_mq<true>)
+    bool tp_prefill = false;                           // tensor parallel: every rank of the group can (and will) feed prompts through the batched kernels
     int fuse_attn_o = 1;                               // option "fuse_attn_o": attention + Wo GEMV in one launch (k_attn_o; single GPU)
     bool st_ready = false;                             // the layer matrices' group-major scale copies (QMat::st) are up to date
     int fuse_ffn = 1;                                  // option "fuse_ffn": FFN13 + FFN2 in one launch (k_ffn; single GPU)
@@ -92,7 +93,7 @@ struct flm_ctx {
     int attn_split = 1;                                // option "attn_split": 1 = spread a head over 4 workgroups from kSplitFrom (128) positions on, 0 = never, >= 2 = always that many
     // the weight-streaming engine (flm_engine.h; single GPU, int8): option "engine": 0 off, 1 FFN13 + FFN2 per launch, 2 Wo .. next QKV per launch
     int engine = 1; bool eng_built = false; int eng_nslot = 0; size_t eng_lds = 0; int eng_trace = 0;
-    EngPhase* eng_prog[3] = {nullptr, nullptr, nullptr};   // device programs: [0] FFN pairs, [1] layer chains with pre-quantized head outputs, [2] with fp32 head outputs
+    std::vector<EngPhase> eng_prog[3];                     // the token's programs (host; a launch's phases travel as kernel arguments): [0] FFN pairs, [1] layer chains with pre-quantized head outputs, [2] with fp32 head outputs
     unsigned long long *gx1 = nullptr, *ghd = nullptr, *ghq = nullptr; unsigned* eng_base = nullptr;
     int trace_class = -1; unsigned long long* trace = nullptr;   // FLM_ABLATE builds: GEMV timeline of one kernel class
     std::map<int, hipGraphExec_t> graphs;             // key = with_cls*4 + advance
@@ -296,7 +297,17 @@ int xwg_check(flm_ctx* c) {
     if (!e) return FLM_OK;
     HIPC(c, hipMemsetAsync(c->xwg_err, 0, 4, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
-    if (e == 2) return fail(c, FLM_ERR_COMM, "tensor parallel: a peer rank did not deliver its slice (20 s), or another rank gave up");
+    if (e == 2) return fail(c, FLM_ERR_COMM, "tensor parallel: a peer rank did not deliver its slice (20 s), or another rank gave up; the context group cannot be used any more");
+    if (c->world > 1) {
+        // A cross-workgroup wait inside this rank timed out (a split head's scores).  The other ranks cannot re-run the call with it -- they
+        // have gone on with this rank's bad slices -- so this is a GROUP error: tell them (abort line) and say so; no silent retry.
+        if (c->p2p) {
+            for (int r = 0; r < c->world; ++r) if (c->peer[r]) { unsigned one = 1; (void)hipMemcpyAsync(c->peer[r] + c->x_flags_off + kXchgAbortLine * 64, &one, 4, hipMemcpyHostToDevice, c->stream); }
+            (void)hipStreamSynchronize(c->stream);
+        }
+        c->attn_split = 0;
+        return fail(c, FLM_ERR_COMM, "tensor parallel: a cross-workgroup wait on this rank timed out; the group's results are invalid and the context group cannot be used any more");
+    }
     c->fuse_attn_o = 0; c->fuse_ffn = 0; c->fuse_qkv = 0; c->attn_split = 0; c->engine = 0;
     for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
     c->graphs.clear();
@@ -494,9 +505,8 @@ int eng_build(flm_ctx* c) {
     if (c->eng_built) return FLM_OK;
     const auto& d = c->d; const int L = d.n_layers;
     const int kmax = d.hidden_dim > d.dim ? d.hidden_dim : d.dim;
-    int ns = 14; while (ns > 4 && (size_t)eng_lds_layout(ns, kmax, 1, d.dim).total > kLdsMax) --ns;
-    if ((size_t)eng_lds_layout(ns, kmax, 1, d.dim).total > kLdsMax) return FLM_ERR_UNSUPPORTED;
-    c->eng_nslot = ns; c->eng_lds = (size_t)eng_lds_layout(ns, kmax, 1, d.dim).total;
+    if ((size_t)eng_lds_layout(kEngSlots, kmax, 1, d.dim).total > kLdsMax) return FLM_ERR_UNSUPPORTED;   // (the ring's size is a compile-time constant)
+    c->eng_nslot = kEngSlots; c->eng_lds = (size_t)eng_lds_layout(kEngSlots, kmax, 1, d.dim).total;
     {   // the ring takes most of the CU's 160 KiB: raise the kernel's dynamic-LDS limit, once per device
         static std::mutex mu; static bool done[64] = {false};
         std::lock_guard<std::mutex> lk(mu);
@@ -525,18 +535,20 @@ int eng_build(flm_ctx* c) {
         EngPhase k{}; k.W = c->cls.q; k.sW = c->cls.s; k.K = d.dim; k.rows = c->cls.rows; k.epi = EPI_STORE;
         k.pro = EPRO_GRAN_RMS; k.norm_w = c->out_norm; k.out = c->logits;
         pr[4 * L] = k;
-        if (!c->eng_prog[v]) HIPC(c, hipMalloc((void**)&c->eng_prog[v], pr.size() * sizeof(EngPhase)));
-        HIPC(c, hipMemcpyAsync(c->eng_prog[v], pr.data(), pr.size() * sizeof(EngPhase), hipMemcpyHostToDevice, c->stream));
-        HIPC(c, hipStreamSynchronize(c->stream));                                      // (pr goes out of scope)
+        for (size_t i = 0; i < pr.size(); ++i) { pr[i].index = (int)i; eng_fill_geom(pr[i], 1, c->cu_count); }
+        c->eng_prog[v] = std::move(pr);
     }
     c->eng_built = true;
     return FLM_OK;
 }
 int launch_engine(flm_ctx* c, hipStream_t st, int variant, int ph0, int ph1) {
     EngArgs a{};
-    a.prog = c->eng_prog[variant]; a.ph0 = ph0; a.ph1 = ph1;
+    if (ph1 - ph0 < 1 || ph1 - ph0 > kEngMaxPhases || ph1 > (int)c->eng_prog[variant].size()) return fail(c, FLM_ERR_INVALID, "engine: phase range");
+    a.nph = ph1 - ph0;
+    for (int i = 0; i < a.nph; ++i) a.ph[i] = c->eng_prog[variant][ph0 + i];
     a.gx1 = c->gx1; a.ghd = c->ghd; a.ghq = c->ghq; a.base_ptr = c->eng_base; a.x1 = c->x1;
-    a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.pos_ptr = &c->state->pos; a.err = c->xwg_err; a.nslot = c->eng_nslot;
+    a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.pos_ptr = &c->state->pos; a.err = c->xwg_err;
+    a.ablate = c->ablate;
     if (c->eng_trace && ph0 == c->eng_trace) a.trace = c->trace;                     // tools/trace_eng.py: the stamps of the launch that starts at this phase
     hipLaunchKernelGGL(k_engine<QT_INT8>, dim3(c->cu_count), dim3(kEngBlock), c->eng_lds, st, a);
     HIPC(c, hipGetLastError());
@@ -645,7 +657,7 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
         if (tp) { r = exchange(c, st, XK_LOGITS, c->logits, c->logits + (size_t)c->rank * c->vocab_slot, c->vocab_slot); if (r) return r; }
         if (advance != 0) {
             Tick t(c, st, KC_ARGMAX);
-            hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, st, (const float*)c->logits, d.vocab_size, c->state, c->out_tokens_dev, 1);
+            hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, st, (const float*)c->logits, d.vocab_size, c->state, c->out_tokens_dev, 1, c->out_cap);
             HIPC(c, hipGetLastError());
         }
     } else if (advance == 2) {
@@ -898,6 +910,11 @@ int prefill_batched(flm_ctx* c, int B, int pos) {
     return FLM_OK;
 }
 
+// can this rank run the batched prompt path under tensor parallelism?  (rank-local: a failed score-buffer allocation, options)
+bool tp_prefill_capable(const flm_ctx* c) {
+    return c->pf_in_xbuf && c->use_mfma && c->use_qk_mfma && c->use_pv_mfma && c->use_prefill_mq &&
+           c->pf_scores && c->hs <= 128 && c->hs % 2 == 0 && c->dim_local % 32 == 0;
+}
 // feed tokens[0..n) sequentially (row i of the reference's batched prefill depends only on rows
 // <= i through the KV cache, so token-by-token evaluation performs the same per-row arithmetic).
 int feed(flm_ctx* c, const int32_t* tokens, int n, int pos, int final_advance) {
@@ -907,8 +924,7 @@ int feed(flm_ctx* c, const int32_t* tokens, int n, int pos, int final_advance) {
     HIPC(c, hipMemcpyAsync(c->prompt_dev, tokens, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));   // (the caller's buffer outlives the call: every entry point synchronises)
     // batched: single GPU always; tensor parallel over the peer-to-peer exchange with the matrix-core kernels (the kernels that store their
     // column slices into the peers' buffers)
-    const bool tp_ok = c->world > 1 && c->p2p && c->pf_in_xbuf && c->use_mfma && c->use_qk_mfma && c->use_pv_mfma && c->use_prefill_mq &&
-                       c->pf_scores && c->hs <= 128 && c->hs % 2 == 0 && c->dim_local % 32 == 0;
+    const bool tp_ok = c->world > 1 && c->p2p && c->tp_prefill;          // agreed by all ranks at flm_p2p_import
     if (c->use_prefill && (c->world == 1 || tp_ok) && n - 1 >= kPrefillMin) {
         // all tokens but the last in one batch (cache rows only), then the last one through the decode kernels
         r = c->d.quant_type == FLM_QT_INT8 ? prefill_batched<QT_INT8>(c, n - 1, pos) : prefill_batched<QT_INT16>(c, n - 1, pos);
@@ -1046,9 +1062,9 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
     HIPB(hipMemsetAsync(c->flag_lines, 0, 1024 * 64, c->stream)); HIPB(hipMemsetAsync(c->xwg_err, 0, 64, c->stream));
     {   // the engine's granule buffers (8 bytes per value: {value, tag}) and the token's epoch base
         const size_t nq = (size_t)(d.hidden_dim / kGroup) * (16 * c->esz + 1);
-        HIPB(hipMalloc((void**)&c->gx1, (size_t)d.dim * 8)); HIPB(hipMalloc((void**)&c->ghd, (size_t)d.hidden_dim * 8)); HIPB(hipMalloc((void**)&c->ghq, nq * 8));
+        HIPB(hipMalloc((void**)&c->gx1, (size_t)d.dim * 8)); HIPB(hipMalloc((void**)&c->ghd, (size_t)d.hidden_dim * 16)); HIPB(hipMalloc((void**)&c->ghq, nq * 8));
         HIPB(hipMalloc((void**)&c->eng_base, 64));
-        HIPB(hipMemsetAsync(c->gx1, 0, (size_t)d.dim * 8, c->stream)); HIPB(hipMemsetAsync(c->ghd, 0, (size_t)d.hidden_dim * 8, c->stream));
+        HIPB(hipMemsetAsync(c->gx1, 0, (size_t)d.dim * 8, c->stream)); HIPB(hipMemsetAsync(c->ghd, 0, (size_t)d.hidden_dim * 16, c->stream));
         HIPB(hipMemsetAsync(c->ghq, 0, nq * 8, c->stream)); HIPB(hipMemsetAsync(c->eng_base, 0, 64, c->stream));
     }
     HIPB(hipMalloc(&c->att_q, (size_t)d.dim * c->esz)); HIPB(hipMalloc((void**)&c->att_qs, (size_t)(d.dim / kGroup) * 4));
@@ -1079,7 +1095,7 @@ void flm_ctx_destroy(flm_ctx* c) {
     for (int r = 0; r < c->world; ++r) if (c->peer_opened[r] && c->peer[r]) hipIpcCloseMemHandle(c->peer[r]);
     void* ptrs[] = {c->emb, c->emb_s, c->out_norm, c->kcache, c->vcache, c->xbuf, c->xepoch, c->qbuf,
                     c->rope_cos, c->rope_sin, c->state, c->prompt_dev, c->out_tokens_dev,
-                    c->flag_lines, c->xwg_err, c->att_q, c->att_qs, c->att_sc, c->trace, c->gx1, c->ghd, c->ghq, c->eng_base, c->eng_prog[0], c->eng_prog[1], c->eng_prog[2],
+                    c->flag_lines, c->xwg_err, c->att_q, c->att_qs, c->att_sc, c->trace, c->gx1, c->ghd, c->ghq, c->eng_base,
                     c->pf_in_xbuf ? nullptr : c->pf_x, c->pf_qkv, c->pf_q, c->pf_in_xbuf ? nullptr : c->pf_att, c->pf_gu, c->pf_in_xbuf ? nullptr : c->pf_hd, c->pf_xs, c->pf_xq, c->pf_scores};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->comm) ncclCommDestroy(c->comm);
@@ -1094,7 +1110,7 @@ void flm_ctx_destroy(flm_ctx* c) {
 // process share the pointer directly).  From then on activation slices travel by direct stores over xGMI plus one flag
 // round (k_xchg) instead of an RCCL all-gather, and the token is replayed from a hipGraph like the single-GPU one.
 namespace {
-struct P2pBlob { unsigned long long magic; int pid, device, rank, world; unsigned long long bytes; void* raw; hipIpcMemHandle_t h; char pad[128 - 8 - 16 - 8 - 8 - sizeof(hipIpcMemHandle_t)]; };
+struct P2pBlob { unsigned long long magic; int pid, device, rank, world; unsigned long long bytes; void* raw; hipIpcMemHandle_t h; int caps; /* bit 0: this rank can run the batched prompt path */ char pad[128 - 8 - 16 - 8 - 8 - sizeof(hipIpcMemHandle_t) - 4]; };
 static_assert(sizeof(P2pBlob) == FLM_P2P_BLOB_BYTES, "blob size");
 constexpr unsigned long long kP2pMagic = 0x464C4D5032503031ull;   // "FLMP2P01"
 }
@@ -1103,6 +1119,7 @@ int flm_p2p_export(flm_ctx* c, void* blob128) {
     if (!c || !blob128) return FLM_ERR_INVALID;
     HIPC(c, hipSetDevice(c->device));
     P2pBlob b{}; b.magic = kP2pMagic; b.pid = (int)getpid(); b.device = c->device; b.rank = c->rank; b.world = c->world; b.bytes = c->xbuf_bytes; b.raw = c->xbuf;
+    b.caps = tp_prefill_capable(c) ? 1 : 0;
     HIPC(c, hipIpcGetMemHandle(&b.h, c->xbuf));
     memcpy(blob128, &b, sizeof b);
     return FLM_OK;
@@ -1111,18 +1128,23 @@ int flm_p2p_import(flm_ctx* c, const void* blobs, int n) {
     if (!c || !blobs || n != c->world) return FLM_ERR_INVALID;
     HIPC(c, hipSetDevice(c->device));
     const P2pBlob* b = (const P2pBlob*)blobs;
+    // the batched prompt path runs 4 exchanges per layer, token-by-token feeding 4 per layer and TOKEN: every rank must take the same one
+    // (decided once, from what all ranks can do; options that would change it afterwards are refused)
+    c->tp_prefill = true;
+    for (int r = 0; r < n; ++r) if (!(b[r].caps & 1)) c->tp_prefill = false;
+    if (!tp_prefill_capable(c)) c->tp_prefill = false;
     for (int r = 0; r < n; ++r) {
         if (b[r].magic != kP2pMagic || b[r].rank != r || b[r].world != c->world || b[r].bytes != c->xbuf_bytes) return fail(c, FLM_ERR_INVALID, "p2p_import: blobs are not those of this tensor-parallel group, in rank order");
         if (r == c->rank) continue;
         if (c->peer[r]) continue;                                         // already mapped
-        if (b[r].pid == (int)getpid()) { c->peer[r] = (char*)b[r].raw; continue; }   // same process: the pointer is valid here
-        if (b[r].device != c->device) {
+        if (b[r].device != c->device) {                                   // (also for a peer of the same process on another GPU: one host thread per GPU)
             int can = 0; HIPC(c, hipDeviceCanAccessPeer(&can, c->device, b[r].device));
             if (!can) return fail(c, FLM_ERR_UNSUPPORTED, "p2p_import: no peer access between the two devices");
             hipError_t e = hipDeviceEnablePeerAccess(b[r].device, 0);
             if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIPC(c, e);
             (void)hipGetLastError();
         }
+        if (b[r].pid == (int)getpid()) { c->peer[r] = (char*)b[r].raw; continue; }   // same process: the pointer is valid here, only the IPC mapping is skipped
         void* p = nullptr;
         HIPC(c, hipIpcOpenMemHandle(&p, b[r].h, hipIpcMemLazyEnablePeerAccess));
         c->peer[r] = (char*)p; c->peer_opened[r] = true;
@@ -1136,6 +1158,8 @@ int flm_p2p_import(flm_ctx* c, const void* blobs, int n) {
 int flm_set_option(flm_ctx* c, const char* key, int value) {
     if (!c || !key) return FLM_ERR_INVALID;
     std::string k(key);
+    if (c->world > 1 && c->p2p && (k == "use_mfma" || k == "use_pv_mfma" || k == "use_prefill_mq" || k == "use_qk_mfma"))
+        return fail(c, FLM_ERR_STATE, "set_option: which prompt kernels a tensor-parallel group runs is agreed at flm_p2p_import; set this option on every rank before importing (\"use_prefill\" may be switched later, on every rank alike)");
     if (k == "wg_per_cu") { c->wg_per_cu = value > 0 ? value : 1; }
     else if (k == "use_graph") c->use_graph = value;
     else if (k == "use_prefill") c->use_prefill = value;
@@ -1149,8 +1173,8 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (k == "engine") c->engine = value;
     else if (k == "eng_trace") {   // value = first phase of the engine launch whose in-kernel stamps are recorded (0 off); read them with flm_debug_read(9)
         c->eng_trace = value;
-        if (!c->trace) { HIPC(c, hipMalloc((void**)&c->trace, 4096 * 8 * 8)); }
-        HIPC(c, hipMemset(c->trace, 0, 4096 * 8 * 8));
+        if (!c->trace) { HIPC(c, hipMalloc((void**)&c->trace, 65536 * 8)); }
+        HIPC(c, hipMemset(c->trace, 0, 65536 * 8));
     }
     else if (k == "use_qk_mfma") c->use_qk_mfma = value;
     else if (k == "use_p2p") {     // 0: exchange by RCCL all-gathers although the peers are mapped (needs the communicator); 1: back to peer-to-peer
@@ -1161,8 +1185,8 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (kAblate && k == "ablate") c->ablate = value;              // FLM_ABLATE builds only: a product library cannot skip work
     else if (kAblate && k == "trace") {   // value = kernel class to trace (KC_*), -1 off
         c->trace_class = value;
-        if (!c->trace) { HIPC(c, hipMalloc((void**)&c->trace, 4096 * 8 * 8)); }
-        HIPC(c, hipMemset(c->trace, 0, 4096 * 8 * 8));
+        if (!c->trace) { HIPC(c, hipMalloc((void**)&c->trace, 65536 * 8)); }
+        HIPC(c, hipMemset(c->trace, 0, 65536 * 8));
     }
     else return fail(c, FLM_ERR_INVALID, "unknown option");
     for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
@@ -1275,14 +1299,20 @@ int flm_debug_read(flm_ctx* c, int what, int layer, float* out, size_t n) {
         for (size_t i = 1; i < n; i += 8) if (t[i] && t[i] < t0) t0 = t[i];
         for (size_t i = 0; i < n; ++i) out[i] = ((i % 8 == 1 || i % 8 == 2) && t[i]) ? (float)(long long)(t[i] - t0) : -1.f;
         return FLM_OK; }
-    case 9: {   // tools/trace_eng.py: the engine launch's stamps [workgroup][64] (100 MHz clock), microseconds after the earliest one; 0 = not stamped -> -1
-        if (!c->trace || n > 4096 * 8) return fail(c, FLM_ERR_INVALID, "debug_read: no trace");
+    case 9: {   // tools/trace_eng.py: the engine launch's words [workgroup][kEngTrace] (100 MHz clock): stamps as microseconds after the earliest one (0 = not
+                // stamped -> -1), accumulated times as microseconds, counts as they are
+        if (!c->trace || n > 65536) return fail(c, FLM_ERR_INVALID, "debug_read: no trace");
         HIPC(c, hipStreamSynchronize(c->stream));
-        std::vector<unsigned long long> t(4096 * 8);
+        std::vector<unsigned long long> t(65536);
         HIPC(c, hipMemcpy(t.data(), c->trace, t.size() * 8, hipMemcpyDeviceToHost));
+        auto kind = [](size_t i) { const size_t j = i % kEngTrace; if (j >= 128) return j % 4 == 3 ? 3 : 2; if (j < 96 && j % 8 == 6) return 4; if (j % 8 == 7) return 2; return 1; };   // 1 stamp, 2 time, 3 count, 4 {ticks << 16 | pieces}
         unsigned long long t0 = ~0ull;
-        for (size_t i = 0; i < n; ++i) if (i % 8 != 7 && !(i % 8 == 6 && i % 128 < 64) && t[i] && t[i] < t0) t0 = t[i];          // (column 7 of every wave: accumulated waiting time, not a stamp)
-        for (size_t i = 0; i < n; ++i) out[i] = i % 8 == 6 && i % 128 < 64 ? ((t[i] & 0xffff) ? (float)((double)(t[i] >> 16) * 10.0 / (double)(t[i] & 0xffff)) : -1.f) /* ns per piece inside the dot loops */ : i % 8 == 7 ? (float)((double)t[i] * 0.01) : (t[i] ? (float)((double)(long long)(t[i] - t0) * 0.01) : -1.f);
+        for (size_t i = 0; i < n; ++i) if (kind(i) == 1 && t[i] && t[i] < t0) t0 = t[i];
+        for (size_t i = 0; i < n; ++i) {
+            const int k = kind(i);
+            out[i] = k == 1 ? (t[i] ? (float)((double)(long long)(t[i] - t0) * 0.01) : -1.f) : k == 2 ? (float)((double)t[i] * 0.01) : k == 3 ? (float)t[i]
+                   : ((t[i] & 0xffff) ? (float)((double)(t[i] >> 16) * 10.0 / (double)(t[i] & 0xffff)) : -1.f);   // ns per piece inside the dot loops
+        }
         return FLM_OK; }
     default: return fail(c, FLM_ERR_INVALID, "debug_read: unknown buffer");
     }
@@ -1430,7 +1460,7 @@ int flm_kernel_times(flm_ctx* c, int pos, int iters, float* avg_us, int32_t* cou
         case KC_FFN13:  return launch_gemv<PRO_RMSNORM_QUANT, EPI_SWIGLU>(c, st, qt, args_ffn13(c, l), wgs);
         case KC_FFN2:   return launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, args_ffn2(c, l), wgs);
         case KC_CLS:    return launch_gemv<PRO_RMSNORM_QUANT, EPI_STORE>(c, st, qt, args_cls(c), wgs);
-        case KC_ARGMAX: hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, st, (const float*)c->logits, d.vocab_size, c->state, (int*)nullptr, 0); return FLM_OK;   // (no id is recorded: the step counter runs on)
+        case KC_ARGMAX: hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, st, (const float*)c->logits, d.vocab_size, c->state, (int*)nullptr, 0, 0); return FLM_OK;   // (no id is recorded: the step counter runs on)
         // the fused launches the token path uses on a single GPU (FLM_ERR_UNSUPPORTED: this shape / option setting runs the phases separately)
         case KC_ATTN_WO: if (!c->fuse_attn_o) return FLM_ERR_UNSUPPORTED;
                          return qt == FLM_QT_INT8 ? launch_attn_o<QT_INT8>(c, st, l, attn_parts(c, pos + 1)) : launch_attn_o<QT_INT16>(c, st, l, attn_parts(c, pos + 1));
@@ -1587,7 +1617,7 @@ int flm_op_argmax(const float* logits, int n, int32_t* idx) {
     if (dl.alloc((size_t)n * 4) || dst.alloc(sizeof(DecodeState)) || dout.alloc(16)) return FLM_ERR_OOM;
     OPC(hipMemcpy(dl.p, logits, (size_t)n * 4, hipMemcpyHostToDevice));
     OPC(hipMemset(dst.p, 0, sizeof(DecodeState)));
-    hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, 0, (const float*)dl.as<float>(), n, dst.as<DecodeState>(), dout.as<int>(), 0);
+    hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, 0, (const float*)dl.as<float>(), n, dst.as<DecodeState>(), dout.as<int>(), 0, 4);
     OPC(hipGetLastError()); OPC(hipDeviceSynchronize());
     OPC(hipMemcpy(idx, dout.p, 4, hipMemcpyDeviceToHost));
     return FLM_OK;

@@ -36,7 +36,7 @@ __global__ void k_embed(float* x, const void* emb, const float* emb_s, int emb_q
 // sample_argmax (src/transformer/sampler.cpp:36-47): first maximum wins.  One workgroup.
 // Also advances the device-resident decode state: tok <- argmax, pos <- pos+1, out[step++] <- argmax.
 struct DecodeState { int pos; int tok; int step; int pad; };
-__global__ void __launch_bounds__(1024) k_argmax_advance(const float* logits, int n, DecodeState* st, int* out_tokens, int advance) {
+__global__ void __launch_bounds__(1024) k_argmax_advance(const float* logits, int n, DecodeState* st, int* out_tokens, int advance, int out_cap) {
     __shared__ float bv[16]; __shared__ int bi[16];
     float best = -INFINITY; int idx = 0x7fffffff;
     // ascending index order within a thread and strict '>' keep the FIRST maximum
@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(1024) k_argmax_advance(const float* logits, in
     if (threadIdx.x == 0) {
         for (int w = 1; w < (int)(blockDim.x >> 6); ++w) if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
         if (idx == 0x7fffffff) idx = 0;      // all -inf / NaN: reference returns index 0
-        if (out_tokens) out_tokens[st->step] = idx;
+        if (out_tokens && st->step >= 0 && st->step < out_cap) out_tokens[st->step] = idx;      // (out_cap: the buffer's size; a caller that forgot to reset `step` must not write past it)
         if (advance) { st->tok = idx; st->pos += 1; }
         st->step += 1;
     }

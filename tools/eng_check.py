@@ -14,6 +14,7 @@ for eng in (0, mode):
     ctx = capi.Ctx(capi.desc_from_config(cfg)); ctx.upload_all(tensors)
     ctx.set_option("engine", eng)
     ctx.set_option("use_graph", 0)
+    if os.environ.get("FLM_ABL") and eng: ctx.set_option("ablate", int(os.environ["FLM_ABL"]))
     prompt = np.array([5, 9, 100], dtype=np.int32)
     lg = ctx.forward(prompt, 0)
     res[eng] = dict(logits=lg.copy(), hd=ctx.debug_read("hd", 0, cfg.hidden_dim), x1=ctx.debug_read("x1", 0, cfg.dim), q=ctx.debug_read("q", 0, cfg.dim), att=ctx.debug_read("att_out", 0, cfg.dim))

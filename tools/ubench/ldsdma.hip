@@ -91,6 +91,82 @@ __global__ void __launch_bounds__(64 * (4 + NLOAD)) k_ring(const char* W, const 
     }
 }
 
+
+// the engine's stream shape: the CU's fills go round robin over NSTREAM consumer streams (stream w: units c + ncu (w + NSTREAM m)), PIECES pieces
+// per fill (+ PIECES / 8 scale KiB-eighths), TWO: a unit's pieces alternate between two matrices `rows` apart
+template <int NSLOT, int DEPTH, int NLOAD, int NSTREAM, int PIECES, bool TWO>
+__global__ void __launch_bounds__(64 * (4 + NLOAD)) k_ring2(const char* W, const float* S, int K, int rows, int mode, unsigned* sums, unsigned long long* ticks) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int SLOTB = PIECES * 1024 + PIECES * 64;
+    unsigned* fill_seq = reinterpret_cast<unsigned*>(lds + NSLOT * SLOTB);
+    unsigned* free_seq = fill_seq + NSLOT;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x < 2 * NSLOT) fill_seq[threadIdx.x] = 0;
+    __syncthreads();
+    const int R = TWO ? rows / 2 : rows;                                          // rows per matrix
+    const int PPU = K / 256, PPUV = TWO ? 2 * PPU : PPU, U = R / 4, c = blockIdx.x, ncu = gridDim.x;
+    const int upc = c < U % ncu ? U / ncu + 1 : U / ncu;                          // units of this CU
+    const int ups = upc / NSTREAM;                                                // units per stream (remainder dropped: a benchmark)
+    const int fps = ups * PPUV / PIECES, NF = fps * NSTREAM;                      // fills per stream, fills of the CU
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    if (wave < NLOAD) {
+        const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(W), 0, rows * K, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S), 0, rows * (K / 64) * 4, 0x00020000);
+        const unsigned voff = (lane >> 4) * K + (lane & 15) * 16;
+        int nissued = 0;
+        for (int F = wave; F < NF; F += NLOAD) {
+            const int slot = F % NSLOT; const unsigned need = F / NSLOT;
+            while (lds_ld(free_seq + slot) < need) __builtin_amdgcn_s_sleep(1);
+            const unsigned dst = (unsigned)(uintptr_t)(lds + slot * SLOTB);
+            const int w = F % NSTREAM, sidx = F / NSTREAM;                        // stream, its fill number
+            int j = sidx * PIECES, m = j / PPUV, rem = j - m * PPUV;
+            {   // scale bytes: PIECES * 64 bytes per fill
+                const size_t so = ((size_t)c * NF + F) * (PIECES * 64) + lane * 16;
+                if (lane * 16 < PIECES * 64) dma16<true>(rS, so < (size_t)rows * (K / 64) * 4 ? (unsigned)so : 0x80000000u, 0, dst + PIECES * 1024);
+            }
+#pragma unroll
+            for (int p = 0; p < PIECES; ++p) {
+                const int cb = TWO ? rem >> 1 : rem, mat = TWO ? rem & 1 : 0;
+                const unsigned base = (unsigned)((mat * R + 4 * (c + ncu * (w + NSTREAM * m))) * K + cb * 256);
+                dma16<true>(rW, voff + base, 0, dst + p * 1024);
+                if (++rem == PPUV) { rem = 0; ++m; }
+            }
+            ++nissued;
+            if (nissued >= DEPTH) {
+                constexpr int IPF = PIECES + 1;
+                if constexpr (DEPTH == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if constexpr ((DEPTH - 1) * IPF == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                else if constexpr ((DEPTH - 1) * IPF == 17) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+                else if constexpr ((DEPTH - 1) * IPF == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+                else if constexpr ((DEPTH - 1) * IPF == 27) asm volatile("s_waitcnt vmcnt(27)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
+                const int Fd = F - (DEPTH - 1) * NLOAD;
+                if (lane == 0) lds_st(fill_seq + Fd % NSLOT, (unsigned)(Fd / NSLOT + 1));
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int F = wave; F < NF; F += NLOAD) if (F + (DEPTH - 1) * NLOAD >= NF && lane == 0) lds_st(fill_seq + F % NSLOT, (unsigned)(F / NSLOT + 1));
+        if (lane == 0 && ticks && wave == 0) ticks[c * 2] = __builtin_amdgcn_s_memrealtime() - t0;
+    } else {
+        const int w = wave - NLOAD;
+        unsigned acc = 0;
+        for (int F = w; F < NF; F += 4) {
+            const int slot = F % NSLOT;
+            while (lds_ld(fill_seq + slot) < (unsigned)(F / NSLOT + 1)) __builtin_amdgcn_s_sleep(1);
+            if (mode == 0) {
+                const v4u* s = reinterpret_cast<const v4u*>(lds + slot * SLOTB);
+#pragma unroll
+                for (int p = 0; p < PIECES; ++p) { const v4u v = s[p * 64 + lane]; acc += v.x + v.y + v.z + v.w; }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) lds_st(free_seq + slot, (unsigned)(F / NSLOT + 1));
+        }
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) sums[c * 4 + w] = acc;
+        if (lane == 0 && ticks && w == 0) ticks[c * 2 + 1] = __builtin_amdgcn_s_memrealtime() - t0;
+    }
+}
+
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 20;
     const int K = argc > 2 ? atoi(argv[2]) : 4096;
@@ -108,8 +184,8 @@ int main(int argc, char** argv) {
     hipStream_t st; hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     printf("matrix [%d][%d] int8 + scales: %.1f MB per launch, %d copies\n", rows, K, (wbytes + sbytes) * 1e-6, nbuf);
-    auto run = [&](const char* name, int mode, auto kern, int nslot, int nload) {
-        const size_t ldsb = (size_t)nslot * kSlotBytes + 64;
+    auto run = [&](const char* name, int mode, auto kern, int nslot, int nload, int slotb = kSlotBytes) {
+        const size_t ldsb = (size_t)nslot * slotb + 128;
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
         int b = 0;
         auto launch = [&] { hipLaunchKernelGGL(kern, dim3(256), dim3(64 * (4 + nload)), ldsb, st, W + wbytes * (b % nbuf), (const float*)((char*)S + sbytes * (b % nbuf)), K, rows, mode, sums, ticks); ++b; };
@@ -128,13 +204,14 @@ int main(int argc, char** argv) {
         printf("%-44s %8.2f us/launch  %5.2f TB/s   in-kernel: loader %.2f us, consumers %.2f us (100 MHz ticks x 10 ns)%s\n", name, us, (wbytes + sbytes) / us * 1e-6,
                lmax * 0.01, cmax * 0.01, mode == 0 ? (tot == ref ? "   sum OK" : "   SUM MISMATCH") : "");
     };
-    run("1 loader, 4x256B pieces, nt, 7 slots, 3 deep", 0, k_ring<7, 3, 1, 4, true>, 7, 1);
-    run("2 loaders, 4x256B pieces, nt, 7 slots, 2 deep each", 0, k_ring<7, 2, 2, 4, true>, 7, 2);
-    run("2 loaders, 4x256B pieces, nt, 7 slots, 1 deep each", 0, k_ring<7, 1, 2, 4, true>, 7, 2);
-    run("2 loaders, 4x256B pieces, default policy, 2 deep", 0, k_ring<7, 2, 2, 4, false>, 7, 2);
-    run("2 loaders, 4x256B pieces, nt, 5 slots, 2 deep each", 0, k_ring<5, 2, 2, 4, true>, 5, 2);
-    run("3 loaders, 4x256B pieces, nt, 7 slots, 2 deep each", 0, k_ring<7, 2, 3, 4, true>, 7, 3);
-    run("4 loaders, 4x256B pieces, nt, 8 slots, 2 deep each", 0, k_ring<8, 2, 4, 4, true>, 8, 4);
-    run("4 loaders, 4x256B pieces, nt, 8 slots, 1 deep each", 0, k_ring<8, 1, 4, 4, true>, 8, 4);
+    run("2 loaders x 2 deep, 1 stream, 16-piece fills (round 3's first ubench)", 1, k_ring<7, 2, 2, 4, true>, 7, 2);
+    run("2 loaders x 2 deep, 1 stream, 16-piece fills", 1, k_ring2<7, 2, 2, 1, 16, false>, 7, 2, 17408);
+    run("2 loaders x 2 deep, 8 streams, 16-piece fills", 1, k_ring2<7, 2, 2, 8, 16, false>, 7, 2, 17408);
+    run("4 loaders x 2 deep, 1 stream, 8-piece fills", 1, k_ring2<14, 2, 4, 1, 8, false>, 14, 4, 8704);
+    run("4 loaders x 2 deep, 8 streams, 8-piece fills", 1, k_ring2<14, 2, 4, 8, 8, false>, 14, 4, 8704);
+    run("4 loaders x 2 deep, 8 streams, 8-piece fills, two matrices", 1, k_ring2<14, 2, 4, 8, 8, true>, 14, 4, 8704);
+    run("4 loaders x 3 deep, 8 streams, 8-piece fills, two matrices", 1, k_ring2<14, 3, 4, 8, 8, true>, 14, 4, 8704);
+    run("4 loaders x 2 deep, 2 streams, 8-piece fills", 1, k_ring2<14, 2, 4, 2, 8, false>, 14, 4, 8704);
+    run("4 loaders x 2 deep, 4 streams, 8-piece fills", 1, k_ring2<14, 2, 4, 4, 8, false>, 14, 4, 8704);
     return 0;
 }
