@@ -48,7 +48,7 @@ constexpr int kEngSlots = 14;                 // ring slots: a compile-time cons
                                               // waves that issue an instruction every ~6 cycles: a division by a run-time value per fill made the loaders the bound)
 constexpr int kEngCL = 64 * kEngConsumers;    // consumer lanes of a workgroup
 constexpr int kEngMaxOwn = 2;                 // residual rows a consumer lane can own: dim <= 4 * kEngConsumers * kEngMaxOwn * nCU
-constexpr int kEngTrace = 256;                // trace words per workgroup (tools/trace_eng.py): consumer w at 8 w, loader L at 96 + 8 L, consumer accumulators at 128 + 4 w
+constexpr int kEngTrace = 512;                // trace words per workgroup (tools/trace_eng.py): consumer w at 16 w, loader L at 256 + 8 L, consumer accumulators at 320 + 4 w
 constexpr int kEngEpochStride = 1024;         // the token's epoch base advances by this (k_embed): phases per token < 1024
 
 enum EngPro { EPRO_X_RMS = 0,     // x (plain fp32 array, complete when the launch starts) -> rmsnorm -> quantize
@@ -189,7 +189,7 @@ struct EngWait {
         if (eng_lds_ld(word) >= v) return true;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         for (unsigned n = 1;; ++n) {
-            __builtin_amdgcn_s_sleep(1);
+            if (n < 8) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(6);     // (a poller shares its SIMD with waves that work: after ~0.3 us it backs off)
             if (eng_lds_ld(word) >= v) { if (wacc && (threadIdx.x & 63) == 0) *wacc += __builtin_amdgcn_s_memrealtime() - t0; return true; }
             if ((n & 63) == 0) {
                 if (aborted()) return false;
@@ -219,7 +219,7 @@ __device__ __forceinline__ void eng_loader(const EngArgs& a, char* lds, const in
     const int lane = threadIdx.x & 63, c = blockIdx.x, ncu = gridDim.x;
     constexpr int nslot = kEngSlots;
     unsigned* ctl = reinterpret_cast<unsigned*>(lds + nslot * kEngSlotBytes);
-    const EngWait wt{ctl, a.err, a.trace ? a.trace + c * kEngTrace + 96 + 8 * L + 7 : nullptr};
+    const EngWait wt{ctl, a.err, a.trace ? a.trace + c * kEngTrace + 256 + 8 * L + 7 : nullptr};
     int F0 = 0;
     // A fill = 8 weight pieces + 2 scale dword loads = 10 vector-memory instructions, kEngDepth fills of this loader in flight (12 per CU, ~100 KiB).
     // The loader is a lone wave that issues an instruction every ~6 cycles and must turn a fill around in ~1 us: everything per fill is
@@ -232,10 +232,10 @@ __device__ __forceinline__ void eng_loader(const EngArgs& a, char* lds, const in
     auto drain = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); while (npend > 0) publish_oldest(); };
     // this loader's fills are F = L, L + 4, ...: their slot F % 14 and sequence F / 14 advance incrementally
     int ownF = L, slot = L % nslot; unsigned seq = (unsigned)(L / nslot);
-    if (a.trace && lane == 0) a.trace[c * kEngTrace + 96 + 8 * L] = __builtin_amdgcn_s_memrealtime();
+    if (a.trace && lane == 0) a.trace[c * kEngTrace + 256 + 8 * L] = __builtin_amdgcn_s_memrealtime();
     // The CU's memory pipeline is a FIFO: an activation requested behind a ring of weight fills returns behind them (+4 us on the first
     // prologue, measured).  The first fill waits until the consumers hold the launch's first activation.
-    if (a.ph[0].pro <= EPRO_XQ && !wt.until_ge(ctl + ECTL_XREQ, kEngConsumers)) return;
+    if (a.ph[0].pro < EPRO_XQ && !wt.until_ge(ctl + ECTL_XREQ, kEngConsumers)) return;      // (a pre-quantized activation is a few KB: not worth the wait)
     for (int ph = 0; ph < a.nph; ++ph) {
         const EngPhase& P = a.ph[ph];
         const bool two = P.epi == EPI_SWIGLU;
@@ -328,7 +328,7 @@ __device__ __forceinline__ void eng_loader(const EngArgs& a, char* lds, const in
             Fi += nround;
         }
         F0 += G.nfill;
-        if (a.trace && lane == 0 && ph < 7) a.trace[c * kEngTrace + 96 + 8 * L + 1 + ph] = __builtin_amdgcn_s_memrealtime();   // the phase's last fill is issued
+        if (a.trace && lane == 0 && ph < 6) a.trace[c * kEngTrace + 256 + 8 * L + 1 + ph] = __builtin_amdgcn_s_memrealtime();   // the phase's last fill is issued
     }
     drain();
 }
@@ -338,10 +338,10 @@ __device__ __forceinline__ void eng_loader(const EngArgs& a, char* lds, const in
 // ------------------------------------------------------------------------------------------
 struct EngCons {
     char* lds; unsigned* ctl; EngWait wt; EngLds LY;
-    int lane, w, c, ncu, nsync;
+    int lane, w, c, ncu, nsync, ph;
     bool ok;
     unsigned long long* trace;                // [workgroup][kEngTrace] (100 MHz clock)
-    __device__ __forceinline__ void stamp(int k) const { if (trace && lane == 0 && k < 6) trace[c * kEngTrace + 8 * w + k] = __builtin_amdgcn_s_memrealtime(); }
+    __device__ __forceinline__ void stamp(int k) const { if (trace && lane == 0 && k < 14) trace[c * kEngTrace + 16 * w + k] = __builtin_amdgcn_s_memrealtime(); }
     // meet the other consumer waves (LDS counter; the loaders never take part)
     __device__ __forceinline__ void sync4() {   // ("4": the first version had 4 consumer waves)
         ++nsync;
@@ -380,10 +380,13 @@ __device__ __forceinline__ void eng_norm_quant(EngCons& E, const int n, const fl
     float r = 1.0f;
     if (with_norm) {
         if (E.w < 4) {
+            __builtin_amdgcn_s_setprio(3);                             // the whole CU waits for these four waves
             const float l = sq_chain_spec(stage + E.w * CS, bs);       // simd::square_sum's lane w (x86_simd.cpp:942-960)
+            __builtin_amdgcn_s_setprio(0);
             if (E.lane == 0) red[E.w] = l;
         }
         E.sync4();
+        if (E.w == 1) E.stamp(3 + 3 * E.ph);                          // (tracing) consumer 1: the chains are done
         const float ss = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, red[0]), red[1]), red[2]), red[3]);
         r = rms_scale(ss, n);
     }
@@ -525,7 +528,9 @@ __device__ __forceinline__ void eng_prologue(EngCons& E, const EngArgs& a, const
             for (int i = 0; i < 4; ++i) { const int k = T4 + kEngCL * (i0 + i); if (k < slots) eng_stage4(stage, k, bs, xv[i]); }
         }
     }
+    if (E.w == 0) E.stamp(3 + 3 * E.ph);                              // (tracing) consumer 0: its part of the vector is staged
     E.sync4();
+    if (E.w == 2) E.stamp(3 + 3 * E.ph);                              // (tracing) consumer 2: everybody's part is staged
     eng_norm_quant<QT>(E, n, P.norm_w, P.pro != EPRO_X_Q, nwp);
 }
 
@@ -598,7 +603,7 @@ __device__ __forceinline__ void eng_consumer(const EngArgs& a, char* lds, const 
     constexpr int nslot = kEngSlots;
     const int lane = E.lane, c = E.c, ncu = E.ncu;
     E.ctl = reinterpret_cast<unsigned*>(lds + nslot * kEngSlotBytes);
-    E.wt = EngWait{E.ctl, a.err, a.trace ? a.trace + E.c * kEngTrace + 8 * w + 7 : nullptr};
+    E.wt = EngWait{E.ctl, a.err, a.trace ? a.trace + E.c * kEngTrace + 16 * w + 15 : nullptr};
     {   // the LDS layout depends on the largest K / the largest normalised vector of the launch
         int kmax = 0, nnorm = 0;
         for (int ph = 0; ph < a.nph; ++ph) { const EngPhase& P = a.ph[ph]; if (P.K > kmax) kmax = P.K; if (P.pro != EPRO_XQ && P.pro != EPRO_GRAN_HD && P.K > nnorm) nnorm = P.K; }
@@ -628,7 +633,7 @@ __device__ __forceinline__ void eng_consumer(const EngArgs& a, char* lds, const 
         const EngGeom G = eng_geom(P, T::kEsz, c);
         const int nu = G.units_of(w), ns = G.slots_of(w);
         if (kAblate && (a.ablate & 16)) { if (ph == 0 && lane == 0) __hip_atomic_fetch_add(E.ctl + ECTL_XREQ, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // (pure streaming: no prologue)
-        else eng_prologue<QT>(E, a, P, epoch - 1u);
+        else { E.ph = ph; eng_prologue<QT>(E, a, P, epoch - 1u); }
         if (!E.ok) break;
         E.stamp(1 + 3 * ph);
         float acc = 0.f, acc3 = 0.f;
@@ -737,7 +742,7 @@ __device__ __forceinline__ void eng_consumer(const EngArgs& a, char* lds, const 
             E.stamp(3 + 3 * ph);
         }
     }
-    if (E.trace && lane == 0) { unsigned long long* t = E.trace + c * kEngTrace; t[8 * w + 6] = tacc_run; t[128 + 4 * w] = tacc_fill; t[128 + 4 * w + 1] = tacc_run >> 16; t[128 + 4 * w + 2] = tacc_epi; t[128 + 4 * w + 3] = tacc_slots; }
+    if (E.trace && lane == 0) { unsigned long long* t = E.trace + c * kEngTrace; t[16 * w + 14] = tacc_run; t[320 + 4 * w] = tacc_fill; t[320 + 4 * w + 1] = tacc_run >> 16; t[320 + 4 * w + 2] = tacc_epi; t[320 + 4 * w + 3] = tacc_slots; }
 }
 
 // grid = CUs (every workgroup resident: the consumers of all CUs wait for each other's granules), block = kEngBlock

@@ -91,8 +91,9 @@ struct flm_ctx {
     unsigned* xepoch = nullptr;                        // [4] exchanges done per kind (att, x1, hd, logits), device memory
     float* att_sc = nullptr;                           // [heads_local][max_seq] scores exchanged between the parts of a split head
     int attn_split = 1;                                // option "attn_split": 1 = spread a head over 4 workgroups from kSplitFrom (128) positions on, 0 = never, >= 2 = always that many
-    // the weight-streaming engine (flm_engine.h; single GPU, int8): option "engine": 0 off, 1 FFN13 + FFN2 per launch, 2 Wo .. next QKV per launch
-    int engine = 1; bool eng_built = false; int eng_nslot = 0; size_t eng_lds = 0; int eng_trace = 0;
+    // the weight-streaming engine (flm_engine.h; single GPU, int8): option "engine": 0 off (the default: bit-identical but, as measured in round 3, not yet
+    // faster than the fused per-phase launches -- DESIGN.md section 7b), 1 FFN13 + FFN2 per launch, 2 Wo .. next QKV per launch
+    int engine = 0; bool eng_built = false; int eng_nslot = 0; size_t eng_lds = 0; int eng_trace = 0;
     std::vector<EngPhase> eng_prog[3];                     // the token's programs (host; a launch's phases travel as kernel arguments): [0] FFN pairs, [1] layer chains with pre-quantized head outputs, [2] with fp32 head outputs
     unsigned long long *gx1 = nullptr, *ghd = nullptr, *ghq = nullptr; unsigned* eng_base = nullptr;
     int trace_class = -1; unsigned long long* trace = nullptr;   // FLM_ABLATE builds: GEMV timeline of one kernel class
@@ -1173,8 +1174,8 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (k == "engine") c->engine = value;
     else if (k == "eng_trace") {   // value = first phase of the engine launch whose in-kernel stamps are recorded (0 off); read them with flm_debug_read(9)
         c->eng_trace = value;
-        if (!c->trace) { HIPC(c, hipMalloc((void**)&c->trace, 65536 * 8)); }
-        HIPC(c, hipMemset(c->trace, 0, 65536 * 8));
+        if (!c->trace) { HIPC(c, hipMalloc((void**)&c->trace, 131072 * 8)); }
+        HIPC(c, hipMemset(c->trace, 0, 131072 * 8));
     }
     else if (k == "use_qk_mfma") c->use_qk_mfma = value;
     else if (k == "use_p2p") {     // 0: exchange by RCCL all-gathers although the peers are mapped (needs the communicator); 1: back to peer-to-peer
@@ -1185,8 +1186,8 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (kAblate && k == "ablate") c->ablate = value;              // FLM_ABLATE builds only: a product library cannot skip work
     else if (kAblate && k == "trace") {   // value = kernel class to trace (KC_*), -1 off
         c->trace_class = value;
-        if (!c->trace) { HIPC(c, hipMalloc((void**)&c->trace, 65536 * 8)); }
-        HIPC(c, hipMemset(c->trace, 0, 65536 * 8));
+        if (!c->trace) { HIPC(c, hipMalloc((void**)&c->trace, 131072 * 8)); }
+        HIPC(c, hipMemset(c->trace, 0, 131072 * 8));
     }
     else return fail(c, FLM_ERR_INVALID, "unknown option");
     for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
@@ -1301,11 +1302,11 @@ int flm_debug_read(flm_ctx* c, int what, int layer, float* out, size_t n) {
         return FLM_OK; }
     case 9: {   // tools/trace_eng.py: the engine launch's words [workgroup][kEngTrace] (100 MHz clock): stamps as microseconds after the earliest one (0 = not
                 // stamped -> -1), accumulated times as microseconds, counts as they are
-        if (!c->trace || n > 65536) return fail(c, FLM_ERR_INVALID, "debug_read: no trace");
+        if (!c->trace || n > 131072) return fail(c, FLM_ERR_INVALID, "debug_read: no trace");
         HIPC(c, hipStreamSynchronize(c->stream));
-        std::vector<unsigned long long> t(65536);
+        std::vector<unsigned long long> t(131072);
         HIPC(c, hipMemcpy(t.data(), c->trace, t.size() * 8, hipMemcpyDeviceToHost));
-        auto kind = [](size_t i) { const size_t j = i % kEngTrace; if (j >= 128) return j % 4 == 3 ? 3 : 2; if (j < 96 && j % 8 == 6) return 4; if (j % 8 == 7) return 2; return 1; };   // 1 stamp, 2 time, 3 count, 4 {ticks << 16 | pieces}
+        auto kind = [](size_t i) { const size_t j = i % kEngTrace; if (j >= 320) return j % 4 == 3 ? 3 : 2; if (j < 256) return j % 16 == 14 ? 4 : j % 16 == 15 ? 2 : 1; return j % 8 == 7 ? 2 : 1; };   // 1 stamp, 2 time, 3 count, 4 {ticks << 16 | pieces}
         unsigned long long t0 = ~0ull;
         for (size_t i = 0; i < n; ++i) if (kind(i) == 1 && t[i] && t[i] < t0) t0 = t[i];
         for (size_t i = 0; i < n; ++i) {

@@ -8,6 +8,7 @@ L = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 mode = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ph0 = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 pos = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+NPH = 4 if mode == 2 else 2
 cfg = synth.make_config("7B", ff.QT_INT8); cfg.n_layers = L
 ctx = capi.Ctx(capi.desc_from_config(cfg)); ctx.upload_all(synth.make_tensors(cfg, seed=1))
 ctx.set_option("engine", mode)
@@ -17,14 +18,14 @@ first = ctx.forward_argmax(prompt, 0)
 ctx.decode_greedy(first, pos, 8)
 ctx.set_option("eng_trace", ph0)
 ctx.decode_greedy(first, pos, 1)
-t = ctx.debug_read("eng_trace", 0, 256 * 256).reshape(256, 256)
-def col(i):
+t = ctx.debug_read("eng_trace", 0, 256 * 512).reshape(256, 512)
+def col(i, short=False):
     v = t[:, i]; v = v[v >= 0]
-    return f"{np.median(v):6.2f} [{v.min():6.2f} {v.max():6.2f}]" if v.size else "   -"
-print("us after the launch's earliest stamp: median [min max] over the workgroups; wait = total time in slow waits on LDS sequence words")
+    if not v.size: return "  -"
+    return f"{np.median(v):5.1f}" if short else f"{np.median(v):6.2f} [{v.min():6.2f} {v.max():6.2f}]"
+print("us after the launch's earliest stamp, median over the workgroups (first line: median [min max]); per phase: prologue done / stream done (/ consumer 0: own part staged, 2: all staged, 1: chains done, 11: group owner's duty done)")
 for w in range(12):
-    print(f"consumer {w}: start {col(8*w)} | " + " | ".join(f"ph{k} pro {col(8*w+1+3*k)} stream {col(8*w+2+3*k)}" + (f" hop1 {col(8*w+3+3*k)}" if w == 11 else "") for k in range(2)) + f" | wait {col(8*w+7)} | ns/piece {col(8*w+6)}")
+    print(f"consumer {w:2d}: start {col(16*w, True)} | " + " | ".join(f"ph{k} {col(16*w+1+3*k, True)} / {col(16*w+2+3*k, True)}" + (f" / {col(16*w+3+3*k, True)}" if w in (0, 1, 2, 11) else "") for k in range(NPH))
+          + f" | slow waits {col(16*w+15, True)} | ns/piece {col(16*w+14, True)} | waiting for fills {col(320+4*w, True)} dots {col(320+4*w+1, True)} epilogues {col(320+4*w+2, True)} slots {col(320+4*w+3, True)}")
 for l in range(4):
-    print(f"loader {l}: start {col(96+8*l)} | " + " | ".join(f"ph{k} issued {col(96+8*l+1+k)}" for k in range(2)) + f" | wait for slots {col(96+8*l+7)}")
-for w in range(12):
-    print(f"consumer {w}: us waiting for fills {col(128+4*w)} | in the dot loops {col(128+4*w+1)} | in epilogues {col(128+4*w+2)} | slots {col(128+4*w+3)}")
+    print(f"loader {l}: start {col(256+8*l, True)} | issued: " + " ".join(f"ph{k} {col(256+8*l+1+k)}" for k in range(NPH)) + f" | waiting for slots {col(256+8*l+7)}")
