@@ -110,12 +110,31 @@ def host_cores():
         return os.cpu_count() or 1, "unknown"
 
 
-def pmc_traffic(kernel_regex):
+def _mangled_fragment(kernel_regex):
+    """'k_ffn<2,' -> b'5k_ffnILi2E', 'k_gemv<2, 2, 2,' -> b'6k_gemvILi2ELi2ELi2E': the Itanium-mangled head of a kernel template instantiation
+    whose first arguments are small integers (all that the PMC summaries' names are matched by)"""
+    m = re.match(r"(\w+)<([\d, ]*)", kernel_regex.replace("\\", ""))
+    if not m:
+        return None
+    name, args = m.group(1), [a for a in m.group(2).replace(" ", "").split(",") if a]
+    return (f"{len(name)}{name}I" + "".join(f"Li{a}E" for a in args)).encode()
+
+
+def pmc_traffic(kernel_regex, lib_path=None):
     """HBM bytes per launch of the dominant kernel from the newest committed PMC summary under profiles/
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 is the gfx950 correction of
-    MI355X_MICROARCH.md; counters are in KiB).  None when no summary is there."""
+    MI355X_MICROARCH.md; counters are in KiB).  None when no summary is there -- or when the kernel the summary names is no longer in the
+    library this run loaded (a stale summary must not be reported as current): returns (bytes, file, note)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json")))
+    frag = _mangled_fragment(kernel_regex)
+    if lib_path and frag:
+        try:
+            with open(lib_path, "rb") as f:
+                if frag not in f.read():
+                    return None, None, f"no kernel matching {kernel_regex!r} ({frag.decode()}) in {os.path.basename(lib_path)}: PMC summaries under profiles/ are stale"
+        except OSError as e:
+            return None, None, f"cannot read {lib_path}: {e}"
     for f in reversed(files):
         try:
             d = json.load(open(f))
@@ -123,8 +142,8 @@ def pmc_traffic(kernel_regex):
             continue
         for name, c in d.items():
             if re.search(kernel_regex, name) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                return int((2 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024), os.path.basename(f)
-    return None, None
+                return int((2 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024), os.path.basename(f), "kernel symbol found in the loaded library"
+    return None, None, "no PMC summary for this kernel under profiles/"
 
 
 def cpu_baseline(cfg, budget_s=40.0):
@@ -139,19 +158,24 @@ def cpu_baseline(cfg, budget_s=40.0):
     ref_main = os.path.join(ROOT, "oracle", "_ref", "main")
     res = {"unit": "tokens/s", "cores": threads, "host": model}
 
-    def run_ref(L, n_tokens):
+    def run_ref(L, n_tokens, nthreads=None, keep=False, reuse=False):
+        nthreads = nthreads or threads
         c = copy.copy(cfg); c.n_layers = L; c.name = f"synthetic-7Bwidth-L{L}"
         path = f"/tmp/flm-bench-L{L}.flm"
-        tensors = synth.make_tensors(c, seed=7, share_layers=True)
-        ff.write_flm(path, c, synth.make_tokenizer(c.vocab_size), tensors)
-        del tensors
-        cmd = ["timeout", "300", ref_main, "-c", path, "-j", str(threads), "-q", "int8", "-n", str(n_tokens), "-t", "0",
+        if not (reuse and os.path.exists(path)):
+            tensors = synth.make_tensors(c, seed=7, share_layers=True)
+            ff.write_flm(path, c, synth.make_tokenizer(c.vocab_size), tensors)
+            del tensors
+        cmd = ["timeout", "300", ref_main, "-c", path, "-j", str(nthreads), "-q", "int8", "-n", str(n_tokens), "-t", "0",
                "--mode", "bm", "--rounds", "1", "--uma", "-i", "the shape of it"]
         t0 = time.time()
         out = subprocess.run(cmd, capture_output=True, text=True)
-        os.remove(path)
+        if not keep:
+            os.remove(path)
         m = re.search(r"output_token_latancy:(?:\x1b\[[0-9;]*m)?\s*([0-9.]+)", out.stdout)
         if out.returncode != 0 or not m:
+            if os.path.exists(path):
+                os.remove(path)
             raise RuntimeError(f"reference binary failed rc={out.returncode}: {out.stdout[-300:]} {out.stderr[-300:]}")
         return float(m.group(1)), time.time() - t0
 
@@ -163,7 +187,14 @@ def cpu_baseline(cfg, budget_s=40.0):
             if free_gb > need_gb + 2:
                 # the whole model: the reference binary decodes the same 32-layer shape, no extrapolation
                 ntok = 160
-                t_tok, wall = run_ref(cfg.n_layers, ntok)
+                t_tok, wall = run_ref(cfg.n_layers, ntok, keep=True)
+                try:   # the reference's own README quotes -j 8 (/root/reference README.md:96-100): the same file once more on 8 threads, fewer tokens
+                    t8, wall8 = run_ref(cfg.n_layers, 24, nthreads=8, reuse=True)
+                    res["j8"] = {"value": round(1000.0 / t8, 2), "unit": "tokens/s", "cores": 8, "sample": f"the same file, -j 8, 24 decode tokens: {t8:.1f} ms per output token (wall {wall8:.0f}s)"}
+                except Exception as e:  # noqa: BLE001
+                    res["j8"] = {"value": None, "sample": f"failed: {e}"}
+                    if os.path.exists(f"/tmp/flm-bench-L{cfg.n_layers}.flm"):
+                        os.remove(f"/tmp/flm-bench-L{cfg.n_layers}.flm")
                 res.update(value=1000.0 / t_tok, kind="reference",
                            sample=(f"reference binary (oracle/_ref/main, -O3 -march=x86-64-v3 -mfma, AVX2 kernels) -j {threads} -t 0 --mode bm --uma, the full "
                                    f"{cfg.n_layers}-layer LLaMA2-7B-shaped int8 .flm (synthetic weights, identical tensors in every layer), prompt 13 tokens + {ntok} "
@@ -429,6 +460,26 @@ def main():
                         "note": "device time of K steps between HIP events on the ctx stream; not part of `value`"}
         except Exception as e:  # noqa: BLE001
             long_ctx = {"error": str(e)}
+    # a third operating point, outside the timed region of `value`: BASELINE config 5's prompt path at this run's quant type -- a 512-token prompt through
+    # the batched kernels (int8 GEMM tiles on the matrix cores, fp32-MFMA QK^T / PV), median of 3 forwards on a cleared cache
+    prefill = None
+    if mode == "single" and args.pos is None and rank == 0:
+        try:
+            lp = np.array([1] + [int(x) for x in (np.arange(1, 512) * 7919) % V], dtype=np.int32)
+            ctx.reset_kv(); ctx.forward_argmax(lp, 0)                       # warm-up (group-major scale copies, first launches)
+            pts = []
+            for _ in range(3):
+                ctx.reset_kv(); ctx.sync(); torch.cuda.synchronize()
+                t0 = time.perf_counter(); ctx.forward_argmax(lp, 0); pts.append(time.perf_counter() - t0)
+            pdt = float(np.median(pts))
+            L_, dim_, hid_ = cfg.n_layers, cfg.dim, cfg.hidden_dim
+            macs = (len(lp) - 1) * ((L_ - 1) * (4 * dim_ * dim_ + 3 * dim_ * hid_) + 3 * dim_ * dim_) + L_ * (4 * dim_ * dim_ + 3 * dim_ * hid_) + V * dim_
+            prefill = {"prompt_tokens": int(len(lp)), "ms": round(pdt * 1e3, 3), "prompt_tokens_per_s": round(len(lp) / pdt, 1), "linear_TMACs_per_s": round(macs / pdt / 1e12, 1),
+                       "i8_mfma_peak_TMACs_per_s": 1972.0, "frac_of_i8_mfma_peak": round(macs / pdt / 1e12 / 1972.0, 4),
+                       "note": "wall time of flm_forward_argmax (one host call, prompt ids in, next id out); MACs of the linear layers as the kernels run them (the batch skips "
+                               "the last layer's attention and FFN); peak = 3944 TOPS int8 MFMA (MI355X_MICROARCH.md) / 2; not part of `value`"}
+        except Exception as e:  # noqa: BLE001
+            prefill = {"error": str(e)}
     # per-kernel times, live, HIP events on the ctx stream (eager launches, same kernels as the graph)
     kt = ctx.kernel_times(mid_pos, iters=3)
     # the dominant launch of the token: the fused FFN13 + FFN2 kernel where the token path runs it (single GPU), else FFN13
@@ -436,6 +487,13 @@ def main():
     dom_us, dom_cnt = kt[dom]
     dom_bytes = ctx.kernel_bytes(dom, mid_pos)
     achieved = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
+    try:
+        tpath = ctx.query("token_path")
+        token_path = {"resident": bool(ctx.query("resident")), "fell_back_after_timeout": bool(ctx.query("fallback")),
+                      "attn_wo_fused": bool(tpath & 1), "ffn_fused": bool(tpath & 2), "qkv_joins_at_long_contexts": bool(tpath & 4), "engine": (tpath >> 4) & 3,
+                      "heads_split_at_long_contexts": bool(tpath & 64)}
+    except Exception as e:  # noqa: BLE001
+        token_path = {"error": str(e)}
     kernels = {k: {"us": round(v[0], 2), "per_token": v[1], "GBps": round(ctx.kernel_bytes(k, mid_pos) / (v[0] * 1e-6) / 1e9, 1) if v[0] > 0 else 0.0}
                for k, v in kt.items() if v[1] > 0}
     ctx.close()
@@ -455,7 +513,7 @@ def main():
             replicas = {"value": None, "note": f"failed: {e}"}
 
     qn = 2 if qt == ff.QT_INT8 else 1
-    traffic, traffic_src = pmc_traffic(rf"k_ffn<{qn}," if dom == "ffn" else rf"k_gemv<{qn}, 2, 2,")
+    traffic, traffic_src, traffic_note = pmc_traffic(rf"k_ffn<{qn}," if dom == "ffn" else rf"k_gemv<{qn}, 2, 2,", capi.LIB_PATH)
     dom_name = (f"k_ffn<{args.quant}> (ffn13 + SwiGLU and ffn2 + residual in one launch)" if dom == "ffn"
                 else f"k_gemv<{args.quant},rmsnorm+quantize,swiglu> (ffn13)")
     if rank == 0:
@@ -478,8 +536,9 @@ def main():
                                "frac": round(tb / tp * (tok_s / (world / tp)) / 1e9 / HBM_PEAK_GBS, 4)},
             "roofline": {"kernel": dom_name,
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
                          "bytes_per_launch": int(dom_bytes), "avg_launch_us": round(dom_us, 2), "launches_per_token": dom_cnt},
+            "token_path": token_path,
             "kernels": kernels,
             "kernels_note": "us per launch, back-to-back launches of one class between one pair of HIP events; on a single GPU the token path runs attn_wo (k_attn_o) "
                             "instead of attn + attn_o and ffn (k_ffn) instead of ffn13 + ffn2: per token = embed + L * (qkv + attn_wo + ffn) + cls + argmax; where qkv_attn_wo "
@@ -487,6 +546,8 @@ def main():
         }
         if long_ctx is not None:
             line["long_context"] = long_ctx
+        if prefill is not None:
+            line["prefill"] = prefill
         if replicas is not None:
             line["replicas"] = replicas
         if tp_note:

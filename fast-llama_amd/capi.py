@@ -21,7 +21,7 @@ KCLASSES = ("embed", "qkv", "attn", "attn_o", "ffn13", "ffn2", "cls", "argmax", 
 SYMBOLS = (
     "flm_comm_unique_id", "flm_ctx_create", "flm_ctx_destroy", "flm_p2p_export", "flm_p2p_import", "flm_last_error", "flm_upload_tensor",
     "flm_forward", "flm_forward_argmax", "flm_decode_greedy", "flm_decode_timed", "flm_decode_timed_each", "flm_last_tokens", "flm_reset_kv", "flm_sync",
-    "flm_kernel_times", "flm_kernel_bytes", "flm_set_option", "flm_debug_read",
+    "flm_kernel_times", "flm_kernel_bytes", "flm_set_option", "flm_query", "flm_debug_read",
     "flm_op_quantize", "flm_op_matmul_q", "flm_op_rmsnorm", "flm_op_swiglu", "flm_op_rope", "flm_op_softmax",
     "flm_op_attention", "flm_op_expf", "flm_op_math", "flm_op_square_sum", "flm_op_argmax", "flm_plan_shards",
 )
@@ -164,6 +164,11 @@ class Ctx:
 
     def set_option(self, key, value):
         _check(lib().flm_set_option(self._h, key.encode(), int(value)), self._h)
+
+    def query(self, key) -> int:
+        v = C.c_int(0)
+        _check(lib().flm_query(self._h, key.encode(), C.byref(v)), self._h)
+        return int(v.value)
 
     def debug_read(self, what, layer, n):
         names = {"x1": 0, "q": 1, "att_out": 2, "hd": 3, "kcache": 4, "vcache": 5, "logits": 6, "trace": 7, "trace_abs": 8, "eng_trace": 9}

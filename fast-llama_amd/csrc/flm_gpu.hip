@@ -96,6 +96,8 @@ struct flm_ctx {
     int engine = 0; bool eng_built = false; int eng_nslot = 0; size_t eng_lds = 0; int eng_trace = 0;
     std::vector<EngPhase> eng_prog[3];                     // the token's programs (host; a launch's phases travel as kernel arguments): [0] FFN pairs, [1] layer chains with pre-quantized head outputs, [2] with fp32 head outputs
     unsigned long long *gx1 = nullptr, *ghd = nullptr, *ghq = nullptr; unsigned* eng_base = nullptr;
+    int resident = 1;                                  // the census at create saw every workgroup of a cu_count-wide launch co-resident
+    int fell_back = 0;                                 // a cross-workgroup wait timed out once: fused launches off for good
     int trace_class = -1; unsigned long long* trace = nullptr;   // FLM_ABLATE builds: GEMV timeline of one kernel class
     std::map<int, hipGraphExec_t> graphs;             // key = with_cls*4 + advance
     std::vector<TimedLaunch>* timing = nullptr;
@@ -309,10 +311,29 @@ int xwg_check(flm_ctx* c) {
         c->attn_split = 0;
         return fail(c, FLM_ERR_COMM, "tensor parallel: a cross-workgroup wait on this rank timed out; the group's results are invalid and the context group cannot be used any more");
     }
-    c->fuse_attn_o = 0; c->fuse_ffn = 0; c->fuse_qkv = 0; c->attn_split = 0; c->engine = 0;
+    c->fuse_attn_o = 0; c->fuse_ffn = 0; c->fuse_qkv = 0; c->attn_split = 0; c->engine = 0; c->fell_back = 1;
     for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
     c->graphs.clear();
     return FLM_RETRY;
+}
+
+
+// Census: the fused launches (k_attn_o, k_ffn, k_qkv_attn_o, k_engine, split heads) wait for each other's flags, so every workgroup of a
+// cu_count-wide launch of 1024-thread workgroups with most of the CU's LDS must be RESIDENT at once.  The occupancy API cannot see a masked or
+// partitioned device (MI355X_MICROARCH.md: verify with a census kernel): every workgroup checks in and waits (bounded) until all have.
+__global__ void __launch_bounds__(1024) k_census(unsigned* counter, unsigned n, int* ok) {
+    extern __shared__ char census_lds[];
+    if (threadIdx.x == 0) {
+        census_lds[0] = 1;
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        bool all = false;
+        while (!all && __builtin_amdgcn_s_memrealtime() - t0 < 200000ull) {                       // 2 ms of the 100 MHz clock
+            all = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n;
+            if (!all) __builtin_amdgcn_s_sleep(8);
+        }
+        if (!all) __hip_atomic_store(ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 struct Tick {
@@ -1080,6 +1101,24 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
     HIPB(hipStreamSynchronize(c->stream));                                    // (cs / sn go out of scope)
     if (alloc_run_bufs(c)) return bail(FLM_ERR_OOM);
     HIPB(hipStreamSynchronize(c->stream));
+    {   // can the fused launches run here?  Decided once, up front -- not after a 20 ms stall in the first token
+        static std::mutex mu; static bool attr_done[64] = {false};
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (device_id >= 0 && device_id < 64 && !attr_done[device_id]) {
+                HIPB(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_census), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
+                attr_done[device_id] = true;
+            }
+        }
+        unsigned* cnt = (unsigned*)((char*)c->xwg_err + 32); int* okp = c->xwg_err + 4;
+        int one = 1;
+        HIPB(hipMemsetAsync(cnt, 0, 4, c->stream)); HIPB(hipMemcpyAsync(okp, &one, 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_census, dim3(c->cu_count), dim3(1024), 150 * 1024, c->stream, cnt, (unsigned)c->cu_count, okp);
+        int ok = 0;
+        if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&ok, okp, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess) c->resident = ok ? 1 : 0;
+        else { (void)hipGetLastError(); c->resident = 0; }
+        if (!c->resident) { c->fuse_attn_o = 0; c->fuse_ffn = 0; c->fuse_qkv = 0; c->attn_split = 0; c->engine = 0; }
+    }
 #undef HIPB
     *out = c;
     return FLM_OK;
@@ -1161,6 +1200,8 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     std::string k(key);
     if (c->world > 1 && c->p2p && (k == "use_mfma" || k == "use_pv_mfma" || k == "use_prefill_mq" || k == "use_qk_mfma"))
         return fail(c, FLM_ERR_STATE, "set_option: which prompt kernels a tensor-parallel group runs is agreed at flm_p2p_import; set this option on every rank before importing (\"use_prefill\" may be switched later, on every rank alike)");
+    if (!c->resident && value != 0 && (k == "fuse_attn_o" || k == "fuse_ffn" || k == "fuse_qkv" || k == "attn_split" || k == "engine"))
+        return fail(c, FLM_ERR_UNSUPPORTED, "set_option: this device does not keep one workgroup per CU resident (census at flm_ctx_create); the fused launches stay off");
     if (k == "wg_per_cu") { c->wg_per_cu = value > 0 ? value : 1; }
     else if (k == "use_graph") c->use_graph = value;
     else if (k == "use_prefill") c->use_prefill = value;
@@ -1193,6 +1234,20 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
     c->graphs.clear();
     return FLM_OK;
+}
+
+
+int flm_query(flm_ctx* c, const char* key, int* value) {
+    if (!c || !key || !value) return FLM_ERR_INVALID;
+    const std::string k(key);
+    const struct { const char* k; int v; } tab[] = {
+        {"wg_per_cu", c->wg_per_cu}, {"use_graph", c->use_graph}, {"use_prefill", c->use_prefill}, {"use_mfma", c->use_mfma}, {"use_pv_mfma", c->use_pv_mfma},
+        {"fuse_attn_o", c->fuse_attn_o}, {"fuse_ffn", c->fuse_ffn}, {"fuse_qkv", c->fuse_qkv}, {"use_prefill_mq", c->use_prefill_mq}, {"attn_split", c->attn_split},
+        {"use_qk_mfma", c->use_qk_mfma}, {"use_p2p", c->p2p}, {"engine", c->engine}, {"resident", c->resident}, {"fallback", c->fell_back},
+        {"token_path", (c->world == 1 ? ((c->fuse_attn_o ? 1 : 0) | (c->fuse_ffn && c->engine != 1 && c->engine != 2 ? 2 : 0) | (c->fuse_attn_o && c->fuse_qkv == 1 ? 4 : 0) | (c->fuse_attn_o && c->fuse_qkv >= 2 ? 8 : 0) | ((c->engine & 3) << 4)) : 0) | (c->attn_split ? 64 : 0)},
+    };
+    for (const auto& t : tab) if (k == t.k) { *value = t.v; return FLM_OK; }
+    return fail(c, FLM_ERR_INVALID, "query: unknown key");
 }
 
 int flm_upload_tensor(flm_ctx* c, int kind, int layer, int src_qt, const void* values, const float* scales, int rows, int cols) {

@@ -152,9 +152,21 @@ int  flm_debug_read(flm_ctx* ctx, int what, int layer, float* out, size_t n);
  * "use_qk_mfma" 0 = prefill attention scores on VALU chains (default 1: v_mfma_f32_16x16x4_f32, the same bits),
  * "use_pv_mfma" 0 = prefill softmax x V on VALU chains (default 1: the weighted sum on v_mfma_f32_16x16x4_f32 too; needs use_qk_mfma),
  * "use_mfma" 0 = prefill GEMMs on v_dot4 / v_dot2 instead of the matrix cores (default 1: int8 tile shape by problem size; 2 / 3 = always 64 x 64 / 128 x 128 tiles).
+ * "engine" the weight-streaming engine (fast-llama_amd/csrc/flm_engine.h; single GPU, int8): 0 (default) off, 1 = FFN13 + FFN2 per launch, 2 = Wo + FFN13 +
+ *          FFN2 + the next layer's QKV (or the classifier) per launch; bit-identical, measured slower than the fused launches.
  * None of them changes a result bit.  (Perf-exploration switches that DO skip work -- "ablate", "trace" -- exist only in builds
  * with -DFLM_ABLATE=1; the product library answers FLM_ERR_INVALID to them.) */
 int  flm_set_option(flm_ctx* ctx, const char* key, int value);
+/* What the context actually runs (bench.py reports it; a caller can see that a fused launch was given up).  Keys: every flm_set_option key
+ * (its current value), and
+ *   "resident"  1 = the census at flm_ctx_create saw one 1024-thread workgroup per CU co-resident (the fused launches wait across workgroups;
+ *               0 = they were switched off up front: a masked / partitioned device),
+ *   "fallback"  1 = a cross-workgroup wait timed out during some call and the context fell back to one kernel per phase for good (flm_gpu.hip
+ *               xwg_check; the call itself was re-run and returned correct results),
+ *   "token_path" bit 0 attention + Wo fused, bit 1 FFN13 + FFN2 fused, bit 2 QKV joins the attention's launch at long contexts, bit 3 the same
+ *               at every context, bits 4-5 the engine mode, bit 6 heads split over workgroups at long contexts.
+ * Unknown key: FLM_ERR_INVALID. */
+int  flm_query(flm_ctx* ctx, const char* key, int* value);
 
 /* ---- op level: 1:1 mirrors of the reference operator seam, host pointers in / out, running the
  *      same device code as the fused path.  Used by the parity tests. ----------------------- */
