@@ -599,7 +599,7 @@ int exchange(flm_ctx* c, hipStream_t st, int kind, float* full, float* mine, int
 int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G) {
     const auto& d = c->d;
     const int qt = d.quant_type, hs = c->hs, L = d.n_layers;
-    const bool tp = c->world > 1, coh = tp && c->p2p;
+    const bool tp = c->world > 1 || c->comm != nullptr, coh = tp && c->p2p;
     {
         Tick t(c, st, KC_EMBED);
         hipLaunchKernelGGL(k_embed, dim3((d.dim + 255) / 256), dim3(256), 0, st, c->x1, (const void*)c->emb, (const float*)c->emb_s, c->emb_qt, d.dim, (const int*)&c->state->tok, c->flag_lines, c->eng_base);
@@ -702,7 +702,7 @@ int eng_prepare(flm_ctx* c) {
 int run_token(flm_ctx* c, bool with_cls, int advance, int T) {
     const int G = attn_parts(c, T);
     { const int r = eng_prepare(c); if (r) return r; }
-    if (!c->use_graph || c->timing || (c->world > 1 && !c->p2p)) return enqueue_token(c, c->stream, with_cls, advance, G);   // (RCCL collectives stay eager)
+    if (!c->use_graph || c->timing || ((c->world > 1 || c->comm) && !c->p2p)) return enqueue_token(c, c->stream, with_cls, advance, G);   // (RCCL collectives stay eager)
     const int key = (with_cls ? 4 : 0) + advance + 8 * G;
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
@@ -1040,7 +1040,8 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
     c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 
     HIPB(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    if (world > 1 && comm_id) {   // (without an id the ranks exchange peer to peer only: flm_p2p_export / flm_p2p_import)
+    if (comm_id) {   // (without an id the ranks exchange peer to peer only: flm_p2p_export / flm_p2p_import; world 1 with an id: the sharded token path
+                     //  with RCCL exchanges over a 1-rank communicator -- how the tests run the RCCL branch on a 1-GPU box)
         ncclUniqueId id; memcpy(&id, comm_id, 128);
         ncclResult_t nr = ncclCommInitRank(&c->comm, world, id, rank);
         if (nr != ncclSuccess) { c->err = std::string("ncclCommInitRank failed: ") + ncclGetErrorString(nr); return bail(FLM_ERR_COMM); }

@@ -88,6 +88,9 @@ constexpr int kXchgAbortLine = 4 * 8;      // flag line behind the [4 kinds][8 r
 __global__ void __launch_bounds__(64) k_xchg(const XchgArgs x) {
     const int r = threadIdx.x;
     const unsigned e = *x.epoch + 1;
+    // release: the slices this rank's producing kernel stored into the peers' buffers (system-scope stores, completed by the kernel boundary in front of
+    // this launch) are ordered before the flag for ANY observer -- on one device that cannot fail, across xGMI links it is what the flag promises
+    __atomic_thread_fence(__ATOMIC_RELEASE);
     if (r < x.world) __hip_atomic_store(x.peer_flags[r] + (x.kind * 8 + x.rank) * 16, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (true) {
@@ -102,6 +105,8 @@ __global__ void __launch_bounds__(64) k_xchg(const XchgArgs x) {
         }
         __builtin_amdgcn_s_sleep(8);
     }
+    // acquire: nothing this rank reads after the wait (the consumers' system-coherent loads in the next launch) is served from before the peers' flags
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
     if (r == 0) *x.epoch = e;
 }
 

@@ -4,12 +4,25 @@
 
 #include <iomanip>
 #include <iostream>
+#include <thread>
 
 namespace flmhost {
 
-GpuTransformer::~GpuTransformer() { if (_ctx) flm_ctx_destroy(_ctx); }
+GpuTransformer::~GpuTransformer() { for (flm_ctx* c : _ctxs) if (c) flm_ctx_destroy(c); }
 
-bool GpuTransformer::load(const std::string& ckpt, const std::string& tknr, FileType ft, int qtype, int device, uint64_t seed) {
+int GpuTransformer::on_all(const std::function<int(int)>& f) {
+    const int n = (int)_ctxs.size();
+    if (n == 1) return f(0);
+    std::vector<int> rc(n, 0);
+    std::vector<std::thread> th;
+    for (int r = 1; r < n; ++r) th.emplace_back([&, r] { rc[r] = f(r); });
+    rc[0] = f(0);
+    for (auto& t : th) t.join();
+    for (int r = 0; r < n; ++r) if (rc[r] != FLM_OK) { _err = std::string("rank ") + std::to_string(r) + ": " + flm_last_error(_ctxs[r]); return rc[r]; }
+    return FLM_OK;
+}
+
+bool GpuTransformer::load(const std::string& ckpt, const std::string& tknr, FileType ft, int qtype, const std::vector<int>& devices, uint64_t seed) {
     ModelFile mf;
     if (!load_model_file(ckpt, tknr, ft, false, _debug, mf, _err)) return false;
     _cfg = mf.cfg;
@@ -20,12 +33,26 @@ bool GpuTransformer::load(const std::string& ckpt, const std::string& tknr, File
     flm_model_desc d{};
     d.dim = _cfg.dim; d.hidden_dim = _cfg.hidden_dim; d.n_layers = _cfg.n_layers; d.n_heads = _cfg.n_heads; d.n_kv_heads = _cfg.n_kv_heads;
     d.vocab_size = _cfg.vocab_size; d.max_seq_len = _cfg.max_seq_len; d.quant_type = _cfg.quant_type; d.quant_group_size = _cfg.quant_group_size;
-    int rc = flm_ctx_create(&d, device, 0, 1, nullptr, &_ctx);
-    if (rc != FLM_OK) { _err = std::string("GPU context: ") + flm_last_error(nullptr); return false; }
+    const int world = (int)devices.size();
+    if (world < 1 || world > 8) { _err = "1 to 8 devices"; return false; }
+    _ctxs.assign(world, nullptr);
+    for (int r = 0; r < world; ++r) {
+        const int rc = flm_ctx_create(&d, devices[r], r, world, nullptr, &_ctxs[r]);
+        if (rc != FLM_OK) { _err = std::string("GPU context (rank ") + std::to_string(r) + ", device " + std::to_string(devices[r]) + "): " + flm_last_error(nullptr); return false; }
+    }
     for (const HostTensor& t : mf.tensors) {
-        // a quantized tensor of another type than the model's cannot be multiplied (tensor.cpp:557-561)
-        rc = flm_upload_tensor(_ctx, t.kind, t.layer, t.qtype, t.values, t.scales, t.rows, t.cols);
-        if (rc != FLM_OK) { _err = std::string("upload: ") + flm_last_error(_ctx); return false; }
+        // a quantized tensor of another type than the model's cannot be multiplied (tensor.cpp:557-561); every rank is handed the full tensor and keeps its rows
+        for (int r = 0; r < world; ++r) {
+            const int rc = flm_upload_tensor(_ctxs[r], t.kind, t.layer, t.qtype, t.values, t.scales, t.rows, t.cols);
+            if (rc != FLM_OK) { _err = std::string("upload: ") + flm_last_error(_ctxs[r]); return false; }
+        }
+    }
+    if (world > 1) {   // connect the ranks peer to peer: every rank's exchange buffer mapped into every other (ranks of one process share pointers)
+        std::vector<unsigned char> blobs((size_t)world * FLM_P2P_BLOB_BYTES);
+        for (int r = 0; r < world; ++r)
+            if (flm_p2p_export(_ctxs[r], blobs.data() + (size_t)r * FLM_P2P_BLOB_BYTES) != FLM_OK) { _err = std::string("p2p export: ") + flm_last_error(_ctxs[r]); return false; }
+        for (int r = 0; r < world; ++r)
+            if (flm_p2p_import(_ctxs[r], blobs.data(), world) != FLM_OK) { _err = std::string("p2p import: ") + flm_last_error(_ctxs[r]); return false; }
     }
     return true;
 }
@@ -77,7 +104,9 @@ bool GpuTransformer::generate(const char* prompt, const std::function<bool(const
             // temperature 0: run a chunk of tokens in the device-resident greedy loop (no per-token host round trip)
             int chunk = max_tokens - i; if (chunk > 8) chunk = 8;
             std::vector<int32_t> out(chunk);
-            if (flm_decode_greedy(_ctx, cur[0], i, chunk, out.data()) != FLM_OK) { _err = flm_last_error(_ctx); return false; }
+            std::vector<std::vector<int32_t>> outs(_ctxs.size(), std::vector<int32_t>(chunk));
+            if (on_all([&](int r) { return flm_decode_greedy(_ctxs[r], cur[0], i, chunk, outs[r].data()); }) != FLM_OK) return false;
+            out = outs[0];
             bool stop = false;
             for (int k = 0; k < chunk && !stop; ++k) {
                 next = out[k];
@@ -89,9 +118,16 @@ bool GpuTransformer::generate(const char* prompt, const std::function<bool(const
             continue;
         }
         int rc;
-        if (greedy) { int32_t t; rc = flm_forward_argmax(_ctx, cur.data(), (int)cur.size(), i, &t); next = t; }
-        else { rc = flm_forward(_ctx, cur.data(), (int)cur.size(), i, logits.data()); if (rc == FLM_OK) next = _sampler.sample(logits.data(), temperature, topp); }
-        if (rc != FLM_OK) { _err = flm_last_error(_ctx); return false; }
+        if (greedy) {
+            std::vector<int32_t> ts(_ctxs.size(), 0);
+            rc = on_all([&](int r) { return flm_forward_argmax(_ctxs[r], cur.data(), (int)cur.size(), i, &ts[r]); }); next = ts[0];
+        } else {
+            std::vector<std::vector<float>> lgs(_ctxs.size());
+            for (size_t r = 1; r < lgs.size(); ++r) lgs[r].resize(_cfg.vocab_size);
+            rc = on_all([&](int r) { return flm_forward(_ctxs[r], cur.data(), (int)cur.size(), i, r == 0 ? logits.data() : lgs[r].data()); });
+            if (rc == FLM_OK) next = _sampler.sample(logits.data(), temperature, topp);
+        }
+        if (rc != FLM_OK) return false;
         if (!emit(next, i, (int)cur.size())) break;
         i += (int)cur.size();
         cur = {next};

@@ -20,8 +20,12 @@ class GpuTransformer {
 public:
     explicit GpuTransformer(bool debug) : _debug(debug) {}
     ~GpuTransformer();
-    // load(ckpt, tokenizer, file type, -q quant type, device): transformer.cpp:23-42
-    bool load(const std::string& ckpt, const std::string& tknr, FileType ft, int qtype, int device, uint64_t seed = 0);
+    // load(ckpt, tokenizer, file type, -q quant type, devices): transformer.cpp:23-42.  More than one device = the reference's parallel width
+    // (main.cpp:30,78 `-j`, split_rows transformer.cpp:264-287) on GPUs: ONE sequence, every matmul split by output rows over the devices, one host
+    // thread per device (a tensor-parallel rank of the C ABI), activation slices exchanged peer to peer.  A device may be named more than once
+    // (ranks sharing a GPU: how the 1-GPU test box exercises the path).
+    bool load(const std::string& ckpt, const std::string& tknr, FileType ft, int qtype, const std::vector<int>& devices, uint64_t seed = 0);
+    bool load(const std::string& ckpt, const std::string& tknr, FileType ft, int qtype, int device, uint64_t seed = 0) { return load(ckpt, tknr, ft, qtype, std::vector<int>{device}, seed); }
     std::vector<int> encode(const char* prompt) const;
     std::string decode(const std::vector<int>& tokens) const { return _tok.decode(tokens); }
     // generate(prompt, cb(text, n_input, n_output, ended), max_new_tokens, temperature, topp): transformer.cpp:54-103
@@ -33,7 +37,9 @@ private:
     Config _cfg;
     Tokenizer _tok;
     Sampler _sampler;
-    flm_ctx* _ctx = nullptr;
+    std::vector<flm_ctx*> _ctxs;                    // rank r's context (rank 0's results are the ones reported)
+    // run f(rank) on every rank at once (the ranks wait for each other's slices inside the launches); first non-zero status wins
+    int on_all(const std::function<int(int)>& f);
     std::string _err;
 };
 

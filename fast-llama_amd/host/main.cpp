@@ -1,7 +1,8 @@
 // main.cpp -- drop-in for the reference CLI (src/main.cpp): the same flags, the same prompt/output/summary
 // lines, the per-token transformer running on an MI355X through include/flm_gpu.h.
 //   ./main -c model.flm -q int8 -i "prompt" [-n 512] [-t 1.0] [-p 0.9] [-j N] [--mode gen|chat|bm] [--rounds R]
-// Extra flag of this build: --device <hip ordinal>.
+// Extra flags of this build: --device <hip ordinal>; --devices a,b,... = the reference's parallel width (-j, main.cpp:30,78) on GPUs: one
+// sequence sharded over the named devices (split_rows, transformer.cpp:264-287), one host thread per device.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -10,6 +11,7 @@
 #include <chrono>
 #include <iostream>
 #include <string>
+#include <vector>
 
 #include "engine.h"
 
@@ -24,6 +26,7 @@ struct Args {
     int num_threads = -1, max_tokens = 512, qtype = 2, rounds = 0, device = 0, seed = 128391297;
     float topp = 0.9f, temp = 1.0f;
     bool use_numa = false, detail = false, debug = false;
+    std::vector<int> devices;
     Mode mode = Mode::GEN;
 };
 const char* Y = "\x1b[33m"; const char* G = "\x1b[32m"; const char* E = "\x1b[0m";
@@ -41,6 +44,7 @@ void usage(const char* bin) {
     fprintf(stderr, "   --quant,-q        <string>    quantization type, can be INT8, INT16\n");
     fprintf(stderr, "   --threads,-j      <number>    accepted for compatibility (the GPU build has no worker threads)\n");
     fprintf(stderr, "   --device          <number>    HIP device ordinal (this build only)\n");
+    fprintf(stderr, "   --devices         <a,b,...>   shard ONE sequence over these HIP devices, 1 to 8 of them (this build only)\n");
     fprintf(stderr, "   --encode,-e       <string>    encode the input string into tokens\n");
     fprintf(stderr, "   --decode,-d       <string>    decode the input tokens to text\n");
     fprintf(stderr, "   --help,-h                     print this message\n");
@@ -67,6 +71,7 @@ void parse(Args& a, int argc, const char** argv) {      // Arguments::parse (mai
         else if (arg == "--seed") a.seed = atoi(val());
         else if (arg == "--rounds") a.rounds = atoi(val());
         else if (arg == "--device") a.device = atoi(val());
+        else if (arg == "--devices") { const char* v = val(); a.devices.clear(); while (*v) { char* e; a.devices.push_back((int)strtol(v, &e, 10)); v = *e ? e + 1 : e; } }
         else if (arg == "-m" || arg == "--mode") { const char* s = val(); if (!strcasecmp(s, "gen") || !strcasecmp(s, "generate")) a.mode = Mode::GEN; else if (!strcasecmp(s, "chat")) a.mode = Mode::CHAT; else if (!strcasecmp(s, "benchmark") || !strcasecmp(s, "bm")) a.mode = Mode::TEST; }
         else if (arg == "--debug") { a.debug = true; a.detail = true; }
         else if (arg == "-h" || arg == "--help") { usage(argv[0]); exit(0); }
@@ -104,8 +109,11 @@ int main(int argc, const char** argv) {
         fprintf(stderr, "num_threads:%s%d%s\n   use_numa:%s%d%s\n  ckpt_path:%s%s%s\n  tknr_path:%s%s%s\n      top_p:%s%g%s\ntemperature:%s%g%s\n\n",
                 Y, args.num_threads, E, Y, (int)args.use_numa, E, Y, args.ckpt.c_str(), E, Y, args.tknr.c_str(), E, Y, args.topp, E, Y, args.temp, E);
     }
+    if (args.devices.empty()) args.devices.push_back(args.device);
+    // ranks sharing a GPU wait for each other inside their launches: each needs a hardware queue of its own (HIP's default is 4 per process)
+    if (args.devices.size() > 1) setenv("GPU_MAX_HW_QUEUES", "16", 0);
     GpuTransformer tf(args.detail || args.debug);
-    if (!tf.load(args.ckpt, args.tknr, args.ft, args.qtype, args.device)) { fprintf(stderr, "Failed to load model\n%s\n", tf.error().c_str()); return 1; }
+    if (!tf.load(args.ckpt, args.tknr, args.ft, args.qtype, args.devices)) { fprintf(stderr, "Failed to load model\n%s\n", tf.error().c_str()); return 1; }
     args.qtype = tf.get_quant_type();
     if (args.detail) fprintf(stderr, "Model loaded\n\n");
 

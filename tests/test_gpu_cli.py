@@ -85,3 +85,13 @@ def test_cli_on_gguf_matches_reference_transcript(gpu, name, tmp_path):
     assert r2.returncode == 0, r2.stderr.decode(errors="replace")
     strip_name = lambda b: re.sub(rb"model:[^\t]*", b"model:<m>", _strip_timing(b))
     assert strip_name(r2.stdout) == strip_name(r.stdout)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,devices", [("greedy_int8", "0,0"), ("sample_int16", "0,0,0,0")])
+def test_cli_devices_shards_one_sequence_over_ranks(gpu, name, devices, tmp_path):
+    """--devices a,b,...: the reference's parallel width (`-j`, main.cpp:30,78; split_rows transformer.cpp:264-287) as tensor-parallel ranks, one host thread
+    per device, peers mapped inside the process.  On the 1-GPU box the ranks share device 0; the transcript must be the reference's (the sharded run is
+    bit-identical to the single-GPU one), greedy and sampled."""
+    got, want = _run(name, tmp_path, ["--devices", devices])
+    assert _strip_timing(got) == _strip_timing(want)

@@ -138,3 +138,31 @@ def test_tensor_parallel_batched_prompt(gpu, shape, qt, layers, world, n):
         assert bits_equal(a0, want), f"rank {r}: token by token"
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("qt", [ff.QT_INT8, ff.QT_INT16])
+def test_rccl_exchange_branch_on_a_one_rank_communicator(gpu, qt):
+    """The RCCL fallback of the exchange (flm_gpu.hip `exchange`: ncclAllGather on the ctx stream; ncclCommInitRank at create) had never executed anywhere:
+    a context created with a real ncclUniqueId -- world 1 is enough on a 1-GPU box -- runs the SHARDED token path (one kernel per phase, an all-gather
+    behind each of the four activation vectors and the logits, eager launches) over a 1-rank communicator.  Init, the in-place all-gathers and the
+    results (the oracle's bits) are what is checked; the collective's cost on xGMI is the driver's to measure."""
+    cfg = synth.make_config("small", qt)
+    tensors = synth.make_tensors(cfg, seed=43)
+    om = O.OracleModel(cfg, tensors)
+    prompt = _prompt(cfg.vocab_size, 3)                    # (short: fed token by token, every token through the exchanges)
+    ctx = gpu.Ctx(gpu.desc_from_config(cfg), device=0, rank=0, world=1, comm_id=gpu.comm_unique_id())
+    ctx.upload_all(tensors)
+    lg = ctx.forward(prompt, 0)
+    assert bits_equal(lg, om.forward(prompt, 0))
+    cur, pos = int(np.argmax(lg)), len(prompt)
+    for _ in range(4):
+        t = np.array([cur], np.int32)
+        lg = ctx.forward(t, pos)
+        assert bits_equal(lg, om.forward(t, pos))
+        cur = int(np.argmax(lg)); pos += 1
+    ids = ctx.decode_greedy(cur, pos, 5)
+    ref, c2, p2 = [], cur, pos
+    for _ in range(5):
+        c2 = int(np.argmax(om.forward(np.array([c2], np.int32), p2))); p2 += 1; ref.append(c2)
+    assert list(ids) == ref
+    ctx.close()
