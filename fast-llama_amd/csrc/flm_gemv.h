@@ -34,6 +34,12 @@ struct GemvArgs {
     // xGMI; system-scope stores), so that after the launch plus one flag round every rank holds the whole vector.
     // out_peer[i] = peer i's `out` pointer (already offset like `out`); for EPI_ROPE_KV nothing is exchanged (q/k/v stay local).
     float* out_peer[7]; int n_peer;
+    // ... and the flag round of that exchange folded into the CONSUMING launch (XchgFold below; world == 0: not used)
+    struct XchgFold {
+        unsigned* local_flags; unsigned* peer_flags[8];         // flag lines [slot][rank], 64 bytes each, in every rank's exchange buffer
+        const unsigned* base; unsigned add;                     // epoch of the exchange this launch consumes = *base (the token's, advanced by k_embed) + add
+        int rank, world, slot; int* err;
+    } xf;
     // debugging taps used by the op-level exports (may be null)
     void* dbg_xq; float* dbg_xs; float* dbg_xn;
     unsigned long long* trace;                  // FLM_ABLATE builds: per-workgroup timeline [grid][8] (s_memtime), else unused
@@ -742,6 +748,38 @@ struct GemvCtx {
     }
 };
 
+// Tensor parallel, peer to peer: the flag round of an exchange inside the launch that CONSUMES the exchanged vector (instead of a one-workgroup
+// kernel, k_xchg, between producer and consumer: 4 of a sharded layer's 9 launches).  The producing launch of this rank has completed (kernel boundary:
+// its system-scope stores into every peer's buffer are done), so workgroup 0 tells every peer "my slice of exchange e is in your memory" (release fence,
+// one flag line per (slot, rank)); every workgroup then waits until all ranks' lines in the LOCAL buffer have reached e and acquires.  e comes from the
+// token's epoch base in device memory (the same on every rank: all ranks run the same tokens), so a captured graph replays correctly.
+constexpr int kXchgSlots = 8;                  // flag slots: 0..3 k_xchg's kinds (att, x1, hd, logits), 4..6 the folded exchanges (att, x1, hd)
+constexpr int kXchgAbortLine = kXchgSlots * 8; // flag line behind the [slot][8 ranks] lines: non-zero = some rank gave up, nobody waits any more
+__device__ __forceinline__ void xchg_fold(const GemvArgs::XchgFold& x) {
+    const unsigned e = *x.base + x.add;
+    const int r = threadIdx.x;
+    if (threadIdx.x < 64) {
+        if (blockIdx.x == 0) {
+            __atomic_thread_fence(__ATOMIC_RELEASE);
+            if (r < x.world) __hip_atomic_store(x.peer_flags[r] + (x.slot * 8 + x.rank) * 16, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (true) {
+            const unsigned f = r < x.world ? __hip_atomic_load(x.local_flags + (x.slot * 8 + r) * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : e;
+            if (__all((int)(f - e) >= 0)) break;
+            const bool aborted = __hip_atomic_load(x.local_flags + kXchgAbortLine * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+            if (aborted || __builtin_amdgcn_s_memrealtime() - t0 > 2000000000ull) {                               // 20 s: ranks start seconds apart
+                __hip_atomic_store(x.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (r < x.world) __hip_atomic_store(x.peer_flags[r] + kXchgAbortLine * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    __syncthreads();
+}
+
 // COH: the fp32 activation a.x was written by peer GPUs (tensor parallel) -> system-coherent loads
 template <int QT, int PRO, int EPI, int XR, bool COH = false>
 __global__ void __launch_bounds__(kGemvBlock, 4) k_gemv(const GemvArgs a) {
@@ -760,6 +798,7 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_gemv(const GemvArgs a) {
     // front -- but workgroups start ~1 us apart, and the activation loads of the late ones then queued in HBM behind
     // 32 MB of weight requests of the early ones: the activation came back 2.6 us later (measured), delaying the
     // whole rmsnorm chain.  Issued after the activation, the first 128 KiB per CU still arrive under the chain.
+    if constexpr (COH) { if (a.xf.world) xchg_fold(a.xf); }           // tensor parallel: the exchange's flag round, here instead of in a launch of its own
     float4 xv[XR > 0 ? XR : 1], nv[XR > 0 ? XR : 1];
     gemv_preload<QT, PRO, XR, COH>(a, xv, nv);
     GemvCtx<QT, EPI> g;

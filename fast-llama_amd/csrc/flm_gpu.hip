@@ -47,7 +47,7 @@ struct flm_ctx {
     flm_model_desc d{};
     int device = 0, rank = 0, world = 1;
     flm_shard_plan plan{};
-    int hs = 0, esz = 1, cu_count = 256, n_xcd = 8;
+    int hs = 0, esz = 1, cu_count = 256, cu_total = 256, n_xcd = 8;   // cu_count: CUs this context's launches are sized for (cu_total / cu_parts)
     int dim_local = 0, hidden_local = 0, heads_local = 0, vocab_slot = 0;    // dim_local = heads_local*hs: q/k/v rows and attention outputs owned
     int drow_begin = 0, drow_count = 0;                                       // rows of Wo / W2 (= slice of the residual stream) owned
     hipStream_t stream = nullptr;
@@ -76,6 +76,9 @@ struct flm_ctx {
     int use_pv_mfma = 1;                               // option "use_pv_mfma": prefill weighted sum (softmax x V) on the matrix cores as well (needs use_qk_mfma), 0: VALU chains
     int use_qk_mfma = 1;                               // option "use_qk_mfma": prefill scores on the matrix cores (fp32 MFMA, bit-identical), 0: VALU chains inside the attention kernel
     float* pf_scores = nullptr;                        // [heads][max_seq][max_seq] prefill scores (k_qk_mfma -> k_attn_prefill_mq<true>)
+    int fold_xchg = 1;                                 // option "fold_xchg": tensor parallel, peer to peer: the exchanges' flag rounds inside the consuming GEMV launches
+    int ranks_on_device = 1;                           // ranks of the group that live on this context's device (flm_p2p_import): folding needs a CU partition each
+    int cu_parts = 1;                                  // option "cu_parts": the ctx's stream is confined to 1 / cu_parts of the device's CUs (rank % cu_parts picks which)
     bool tp_prefill = false;                           // tensor parallel: every rank of the group can (and will) feed prompts through the batched kernels
     int fuse_attn_o = 1;                               // option "fuse_attn_o": attention + Wo GEMV in one launch (k_attn_o; single GPU)
     bool st_ready = false;                             // the layer matrices' group-major scale copies (QMat::st) are up to date
@@ -421,6 +424,17 @@ GemvArgs args_cls(flm_ctx* c) {
     return a;
 }
 
+
+// tensor parallel, peer to peer: the consuming GEMV of exchange (layer l, kind) does the flag round itself (xchg_fold)
+void set_fold(flm_ctx* c, GemvArgs& a, int l, int kind) {
+    a.xf.world = 0;
+    if (!(c->world > 1 && c->p2p && c->fold_xchg)) return;
+    a.xf.local_flags = (unsigned*)(c->xbuf + c->x_flags_off);
+    for (int r = 0; r < c->world; ++r) a.xf.peer_flags[r] = (unsigned*)(c->peer[r] + c->x_flags_off);
+    a.xf.base = c->eng_base; a.xf.add = (unsigned)(4 * l + kind + 1);
+    a.xf.rank = c->rank; a.xf.world = c->world; a.xf.slot = 4 + (kind == 3 ? 1 : kind); a.xf.err = c->xwg_err;      // kinds: 0 att, 1 x1 behind Wo, 2 hd, 3 x1 behind FFN2 (the x1 slot again)
+}
+
 // attention + Wo GEMV of layer l in one launch (k_attn_o); returns FLM_ERR_UNSUPPORTED when the shape does not allow it
 template <int QT>
 int launch_attn_o(flm_ctx* c, hipStream_t st, int l, int G) {
@@ -627,6 +641,12 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
         }
         cls_done = with_cls;
     }
+    // tensor parallel, peer to peer: the flag rounds of the att / x1 / hd exchanges happen inside the launches that consume them (xchg_fold), not in
+    // launches of their own; what stays a k_xchg is the logits' exchange and, for a token without classifier, the last x1 exchange (the next token's
+    // k_embed rewrites x1: every peer's stores into it must have landed first)
+    // (ranks sharing a device need a CU partition each -- "cu_parts" -- or a consumer that fills the device while it polls keeps its peers' producers out)
+    const bool fold = tp && c->p2p && c->fold_xchg && c->world > 1 && c->cu_parts >= c->ranks_on_device;
+    auto folded = [&](GemvArgs a, int l, int kind) { if (fold && l >= 0) set_fold(c, a, l, kind); return a; };
     for (int l = 0; l < (eng >= 2 ? 0 : L); ++l) {
         bool fused = false;
         if (!tp && c->fuse_attn_o && (c->fuse_qkv >= 2 || (c->fuse_qkv && G > 1)) && !c->timing && c->trace_class < 0) {   // QKV + attention + ATTN_O in one launch
@@ -635,7 +655,7 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
         }
         if (!fused) {   // QKV task + RoPE + KV append (transformer.cpp:132-135, execute_qkv :386-395, execute_attn :431-439): this rank's heads
             Tick t(c, st, KC_QKV);
-            r = launch_gemv<PRO_RMSNORM_QUANT, EPI_ROPE_KV>(c, st, qt, traced(args_qkv(c, l), KC_QKV, l), wgs, coh); if (r) return r;
+            r = launch_gemv<PRO_RMSNORM_QUANT, EPI_ROPE_KV>(c, st, qt, folded(traced(args_qkv(c, l), KC_QKV, l), l - 1, 3), wgs, coh); if (r) return r;
         }
         if (!fused && !tp && c->fuse_attn_o && !c->timing && (c->trace_class < 0 || c->trace_class == 101)) {   // attention + ATTN_O in one launch
             r = qt == FLM_QT_INT8 ? launch_attn_o<QT_INT8>(c, st, l, G) : launch_attn_o<QT_INT16>(c, st, l, G);
@@ -649,12 +669,12 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
             HIPC(c, hipGetLastError());
         }
         // every rank needs all heads' outputs: the reference's threads share x2 in memory (transformer.cpp:451-454)
-        if (tp) { r = exchange(c, st, XK_ATT, c->att_out, c->att_out + (size_t)c->plan.head_begin * hs, c->dim_local); if (r) return r; }
+        if (tp && !fold) { r = exchange(c, st, XK_ATT, c->att_out, c->att_out + (size_t)c->plan.head_begin * hs, c->dim_local); if (r) return r; }
         if (!fused) {   // ATTN_O task + residual (transformer.cpp:138-139, execute_attn_o :457-466): this rank's rows of Wo
             Tick t(c, st, KC_ATTN_O);
-            r = launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, traced(args_o(c, l), KC_ATTN_O, l), wgs, coh); if (r) return r;
+            r = launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, folded(traced(args_o(c, l), KC_ATTN_O, l), l, 0), wgs, coh); if (r) return r;
         }
-        if (tp) { r = exchange(c, st, XK_X1, c->x1, c->x1 + c->drow_begin, c->drow_count); if (r) return r; }
+        if (tp && !fold) { r = exchange(c, st, XK_X1, c->x1, c->x1 + c->drow_begin, c->drow_count); if (r) return r; }
         if (eng == 1) { r = launch_engine(c, st, 0, 4 * l + 2, 4 * l + 4); if (r) return r; continue; }   // FFN13 + FFN2 on the engine
         if (!tp && c->fuse_ffn && !c->timing && c->trace_class < 0) {   // FFN13 + FFN2 in one launch
             r = qt == FLM_QT_INT8 ? launch_ffn<QT_INT8>(c, st, l) : launch_ffn<QT_INT16>(c, st, l);
@@ -662,19 +682,19 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
         }
         {   // FFN13 task + SwiGLU (transformer.cpp:144-147, execute_ffn13 :468-483): this rank's rows of W1/W3
             Tick t(c, st, KC_FFN13);
-            r = launch_gemv<PRO_RMSNORM_QUANT, EPI_SWIGLU>(c, st, qt, traced(args_ffn13(c, l), KC_FFN13, l), wgs, coh); if (r) return r;
+            r = launch_gemv<PRO_RMSNORM_QUANT, EPI_SWIGLU>(c, st, qt, folded(traced(args_ffn13(c, l), KC_FFN13, l), l, 1), wgs, coh); if (r) return r;
         }
-        if (tp) { r = exchange(c, st, XK_HD, c->hd, c->hd + c->plan.hidden_begin, c->hidden_local); if (r) return r; }
+        if (tp && !fold) { r = exchange(c, st, XK_HD, c->hd, c->hd + c->plan.hidden_begin, c->hidden_local); if (r) return r; }
         {   // FFN2 task + residual (transformer.cpp:149-150, execute_ffn2 :485-494): this rank's rows of W2
             Tick t(c, st, KC_FFN2);
-            r = launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, traced(args_ffn2(c, l), KC_FFN2, l), wgs, coh); if (r) return r;
+            r = launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, folded(traced(args_ffn2(c, l), KC_FFN2, l), l, 2), wgs, coh); if (r) return r;
         }
-        if (tp) { r = exchange(c, st, XK_X1, c->x1, c->x1 + c->drow_begin, c->drow_count); if (r) return r; }
+        if (tp && (!fold || (l == L - 1 && !with_cls))) { r = exchange(c, st, XK_X1, c->x1, c->x1 + c->drow_begin, c->drow_count); if (r) return r; }
     }
     if (with_cls) {
         if (!cls_done) {   // final norm + CLS task (transformer.cpp:154-160, execute_cls :496-505): this rank's rows of the classifier
             Tick t(c, st, KC_CLS);
-            r = launch_gemv<PRO_RMSNORM_QUANT, EPI_STORE>(c, st, qt, traced(args_cls(c), KC_CLS, 0), wgs, coh); if (r) return r;
+            r = launch_gemv<PRO_RMSNORM_QUANT, EPI_STORE>(c, st, qt, folded(traced(args_cls(c), KC_CLS, 0), L - 1, 3), wgs, coh); if (r) return r;
         }
         if (tp) { r = exchange(c, st, XK_LOGITS, c->logits, c->logits + (size_t)c->rank * c->vocab_slot, c->vocab_slot); if (r) return r; }
         if (advance != 0) {
@@ -1037,7 +1057,7 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
 #define HIPB(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { c->err = std::string(#expr " failed: ") + hipGetErrorString(e_); return bail(FLM_ERR_HIP); } } while (0)
     HIPB(hipSetDevice(device_id));
     hipDeviceProp_t prop; HIPB(hipGetDeviceProperties(&prop, device_id));
-    c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; c->cu_total = c->cu_count;
 
     HIPB(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     if (comm_id) {   // (without an id the ranks exchange peer to peer only: flm_p2p_export / flm_p2p_import; world 1 with an id: the sharded token path
@@ -1069,8 +1089,8 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
         // tensor parallel: the batched prompt path's full-width activations [tokens][dim | dim | hidden] live here too (every rank stores its
         // column slices into every rank's copy)
         const size_t pcap = d.max_seq_len < 64 ? 64 : (size_t)d.max_seq_len;
-        const size_t o_px = up(o_fl + (4 * 8 + 1) * 64), o_pa = up(o_px + (world > 1 ? pcap * d.dim * 4 : 0)), o_ph = up(o_pa + (world > 1 ? pcap * d.dim * 4 : 0));
-        const size_t total = world > 1 ? up(o_ph + pcap * d.hidden_dim * 4) : o_fl + (4 * 8 + 1) * 64;      // (flags: + the abort line)
+        const size_t o_px = up(o_fl + (kXchgSlots * 8 + 1) * 64), o_pa = up(o_px + (world > 1 ? pcap * d.dim * 4 : 0)), o_ph = up(o_pa + (world > 1 ? pcap * d.dim * 4 : 0));
+        const size_t total = world > 1 ? up(o_ph + pcap * d.hidden_dim * 4) : o_fl + (kXchgSlots * 8 + 1) * 64;      // (flags: + the abort line)
         hipError_t ae = hipErrorUnknown;
         if (world > 1) { ae = hipExtMallocWithFlags((void**)&c->xbuf, total, hipDeviceMallocFinegrained); c->xbuf_fine = ae == hipSuccess; }   // written by peer GPUs
         if (ae != hipSuccess) { (void)hipGetLastError(); HIPB(hipMalloc((void**)&c->xbuf, total)); }
@@ -1173,6 +1193,8 @@ int flm_p2p_import(flm_ctx* c, const void* blobs, int n) {
     // (decided once, from what all ranks can do; options that would change it afterwards are refused)
     c->tp_prefill = true;
     for (int r = 0; r < n; ++r) if (!(b[r].caps & 1)) c->tp_prefill = false;
+    c->ranks_on_device = 0;
+    for (int r = 0; r < n; ++r) if (b[r].device == c->device) ++c->ranks_on_device;
     if (!tp_prefill_capable(c)) c->tp_prefill = false;
     for (int r = 0; r < n; ++r) {
         if (b[r].magic != kP2pMagic || b[r].rank != r || b[r].world != c->world || b[r].bytes != c->xbuf_bytes) return fail(c, FLM_ERR_INVALID, "p2p_import: blobs are not those of this tensor-parallel group, in rank order");
@@ -1214,6 +1236,25 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (k == "use_prefill_mq") c->use_prefill_mq = value;
     else if (k == "attn_split") c->attn_split = value;
     else if (k == "engine") c->engine = value;
+    else if (k == "fold_xchg") c->fold_xchg = value;
+    else if (k == "cu_parts") {
+        // confine this context's stream to 1 / value of the device's CUs (part rank % value) and size its launches for them: how several tensor-parallel
+        // ranks share ONE GPU without a waiting consumer launch taking the CUs its peers' producers need (tests; a real rank owns a device: value 1)
+        if (value < 1 || value > 8 || c->cu_total % value) return fail(c, FLM_ERR_INVALID, "cu_parts: 1, 2, 4 or 8");
+        HIPC(c, hipStreamSynchronize(c->stream));
+        hipStream_t ns = nullptr;
+        if (value == 1) HIPC(c, hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+        else {
+            const int per = c->cu_total / value, first = (c->rank % value) * per;
+            std::vector<uint32_t> mask((c->cu_total + 31) / 32, 0u);
+            for (int i = first; i < first + per; ++i) mask[i / 32] |= 1u << (i % 32);
+            HIPC(c, hipExtStreamCreateWithCUMask(&ns, (uint32_t)mask.size(), mask.data()));
+        }
+        HIPC(c, hipStreamDestroy(c->stream));
+        c->stream = ns; c->cu_parts = value; c->cu_count = c->cu_total / value;
+        if (value > 1) { c->fuse_attn_o = 0; c->fuse_ffn = 0; c->fuse_qkv = 0; c->engine = 0; }
+        c->eng_built = false;
+    }
     else if (k == "eng_trace") {   // value = first phase of the engine launch whose in-kernel stamps are recorded (0 off); read them with flm_debug_read(9)
         c->eng_trace = value;
         if (!c->trace) { HIPC(c, hipMalloc((void**)&c->trace, 131072 * 8)); }
@@ -1244,7 +1285,7 @@ int flm_query(flm_ctx* c, const char* key, int* value) {
     const struct { const char* k; int v; } tab[] = {
         {"wg_per_cu", c->wg_per_cu}, {"use_graph", c->use_graph}, {"use_prefill", c->use_prefill}, {"use_mfma", c->use_mfma}, {"use_pv_mfma", c->use_pv_mfma},
         {"fuse_attn_o", c->fuse_attn_o}, {"fuse_ffn", c->fuse_ffn}, {"fuse_qkv", c->fuse_qkv}, {"use_prefill_mq", c->use_prefill_mq}, {"attn_split", c->attn_split},
-        {"use_qk_mfma", c->use_qk_mfma}, {"use_p2p", c->p2p}, {"engine", c->engine}, {"resident", c->resident}, {"fallback", c->fell_back},
+        {"use_qk_mfma", c->use_qk_mfma}, {"use_p2p", c->p2p}, {"engine", c->engine}, {"fold_xchg", c->fold_xchg}, {"cu_parts", c->cu_parts}, {"fold_active", (c->world > 1 && c->p2p && c->fold_xchg && c->cu_parts >= c->ranks_on_device) ? 1 : 0}, {"resident", c->resident}, {"fallback", c->fell_back},
         {"token_path", (c->world == 1 ? ((c->fuse_attn_o ? 1 : 0) | (c->fuse_ffn && c->engine != 1 && c->engine != 2 ? 2 : 0) | (c->fuse_attn_o && c->fuse_qkv == 1 ? 4 : 0) | (c->fuse_attn_o && c->fuse_qkv >= 2 ? 8 : 0) | ((c->engine & 3) << 4)) : 0) | (c->attn_split ? 64 : 0)},
     };
     for (const auto& t : tab) if (k == t.k) { *value = t.v; return FLM_OK; }

@@ -84,7 +84,6 @@ __global__ void k_set_step(DecodeState* st, int v) { if (threadIdx.x == 0 && blo
 // a captured graph replays correctly.  flags: [kind][rank] lines of 64 bytes.
 // ------------------------------------------------------------------------------------------
 struct XchgArgs { unsigned* local_flags; unsigned* peer_flags[8]; unsigned* epoch; int* err; int rank, world, kind; };
-constexpr int kXchgAbortLine = 4 * 8;      // flag line behind the [4 kinds][8 ranks] lines: non-zero = some rank gave up, nobody waits any more
 __global__ void __launch_bounds__(64) k_xchg(const XchgArgs x) {
     const int r = threadIdx.x;
     const unsigned e = *x.epoch + 1;

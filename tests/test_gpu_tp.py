@@ -166,3 +166,46 @@ def test_rccl_exchange_branch_on_a_one_rank_communicator(gpu, qt):
         c2 = int(np.argmax(om.forward(np.array([c2], np.int32), p2))); p2 += 1; ref.append(c2)
     assert list(ids) == ref
     ctx.close()
+
+
+@pytest.mark.parametrize("shape,qt,layers,world", [("small", ff.QT_INT8, None, 2), ("small", ff.QT_INT16, None, 4), ("7B", ff.QT_INT8, 2, 2), ("7B", ff.QT_INT8, 1, 4)])
+def test_folded_exchange_under_cu_masks(gpu, shape, qt, layers, world):
+    """The latency path of the sharded token: every exchange's flag round inside the GEMV launch that consumes the vector ("fold_xchg", the default when
+    every rank has CUs of its own) -- 5 launches per layer instead of 9.  On one GPU the ranks get disjoint CU masks ("cu_parts": 2 x 128 or 4 x 64 CUs,
+    launches sized to the mask), so a consumer that polls cannot keep its peers' producers off the device.  Logits and graph-replayed greedy ids of
+    every rank = the oracle's bits; without the partition the contexts fall back to k_xchg launches by themselves (fold_active 0)."""
+    cfg = synth.make_config(shape, qt)
+    if layers:
+        cfg.n_layers = layers
+    tensors = synth.make_tensors(cfg, seed=53)
+    om = O.OracleModel(cfg, tensors)
+    prompt = _prompt(cfg.vocab_size, 4)
+    want = [om.forward(prompt, 0)]
+    cur, pos = int(np.argmax(want[0])), len(prompt)
+    for _ in range(6):
+        want.append(om.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(want[-1])); pos += 1
+    ids_want = [int(np.argmax(w)) for w in want]
+    ctxs = [gpu.Ctx(gpu.desc_from_config(cfg), device=0, rank=r, world=world, comm_id=None) for r in range(world)]
+    for c in ctxs:
+        c.upload_all(tensors)
+    blobs = [c.p2p_export() for c in ctxs]
+    for c in ctxs:
+        c.p2p_import(blobs)
+        assert c.query("fold_active") == 0          # ranks share the device and have no partition yet
+        c.set_option("cu_parts", world)
+        assert c.query("fold_active") == 1
+
+    def rank_main(c):
+        lg = [c.forward(prompt, 0)]
+        cur, pos = int(np.argmax(lg[0])), len(prompt)
+        for _ in range(2):
+            lg.append(c.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(lg[-1])); pos += 1
+        ids = c.decode_greedy(cur, pos, 4)
+        return lg, [int(x) for x in ids]
+
+    for r, (lg, ids) in enumerate(_run_ranks(ctxs, rank_main)):
+        for i, l in enumerate(lg):
+            assert bits_equal(l, want[i]), f"rank {r}: logits of step {i}"
+        assert ids == ids_want[3:7], f"rank {r}: greedy ids"
+    for c in ctxs:
+        c.close()
