@@ -67,7 +67,7 @@ struct flm_ctx {
 
     // options
     int wg_per_cu = 1; int use_graph = 1; int ablate = 0;
-    int use_mfma = 1;                                  // option "use_mfma": int8 prefill GEMM on v_mfma_i32_32x32x32_i8 (0: v_dot4)
+    int use_mfma = 1;                                  // option "use_mfma": int8 prefill GEMM tile shape on v_mfma_i32_32x32x32_i8: 1 by size, 2 (0) 64 x 64, 3 128 x 128
     int use_prefill = 1;                               // option "use_prefill": prompts of >= kPrefillMin+1 tokens go through the batched kernels
     int pf_cap = 0;                                    // token capacity of the batched-prefill buffers below
     bool pf_in_xbuf = false;                           // tensor parallel: pf_x / pf_att / pf_hd are regions of the exchange buffer (peers store into them)
@@ -806,11 +806,12 @@ int launch_rows(flm_ctx* c, hipStream_t st, const RowsArgs& r, int B, bool coh =
     HIPC(c, hipGetLastError());
     return FLM_OK;
 }
-// use_mfma: 0 the v_dot tile kernel, otherwise the matrix cores (int8: 1 tile shape by size, 2 always 64 x 64, 3 always 128 x 128)
+// use_mfma (int8): 1 tile shape by size, 2 (and 0) always 64 x 64, 3 always 128 x 128 matrix-core tiles; int16: always the hi / lo byte planes on the int8 matrix cores
 template <int QT, int EPI>
 int launch_gemm(flm_ctx* c, hipStream_t st, const GemmArgs& g, int use_mfma) {
     const int tiles = ((g.rows + 63) / 64) * ((g.B + 63) / 64);
-    if (QT == QT_INT8 && use_mfma) {   // exact int32 group dots on v_mfma_i32_32x32x32_i8
+    if (use_mfma == 0) use_mfma = 2;
+    if (QT == QT_INT8) {   // exact int32 group dots on v_mfma_i32_32x32x32_i8
         using Big = GemmTile<4, 2, 2>; using Small = GemmTile<2, 2, 1>;
         {   // the 128 x 128 tiles stage 76 KiB of LDS: raise the kernels' dynamic-LDS limit, once per device
             static std::mutex mu; static bool done[64] = {false};
@@ -838,8 +839,7 @@ int launch_gemm(flm_ctx* c, hipStream_t st, const GemmArgs& g, int use_mfma) {
         }
     }
     else if constexpr (EPI == EPI_SWIGLU || EPI == EPI_ROPE_KV) return fail(c, FLM_ERR_INVALID, "launch_gemm: the SwiGLU / RoPE epilogues exist for the int8 matrix-core tiles only");
-    else if (QT == QT_INT16 && use_mfma) hipLaunchKernelGGL((k_gemm_q16_mfma<EPI>), dim3(tiles), dim3(256), Gemm16Tile::kLds, st, g);   // hi / lo byte planes on the int8 matrix cores
-    else hipLaunchKernelGGL((k_gemm_q<QT, EPI>), dim3(tiles), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((k_gemm_q16_mfma<EPI>), dim3(tiles), dim3(256), Gemm16Tile::kLds, st, g);   // hi / lo byte planes on the int8 matrix cores
     HIPC(c, hipGetLastError());
     return FLM_OK;
 }

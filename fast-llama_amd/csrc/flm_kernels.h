@@ -18,14 +18,15 @@
 // Kernel inventory (one decode token on a single GPU = embed + L x {qkv, attention + attn_o, ffn13 + ffn2} + cls + argmax):
 //   k_gemv<QT,PRO,EPI,XR> group-quantized GEMV, HBM-bound; fused prologue (rmsnorm+quantize | quantize)
 //                         and epilogue (store | residual add | SwiGLU | RoPE + KV-cache append)
-//   k_attn_decode         fp32 single-query attention over the fp32 KV cache (heads split over workgroups at long contexts)
+//   k_attn_decode         fp32 single-query attention over the fp32 KV cache (heads split over workgroups at long contexts): the stand-alone launch
+//                         of the tensor-parallel token path, of "engine" 2 and of "fuse_attn_o" 0; the single-GPU default runs it inside k_attn_o
 //   k_attn_o<QT,XR,PREQ>  attention heads and the Wo GEMV in one launch (single GPU)
 //   k_qkv_attn_o<...>     the same with the QKV GEMV in front (long contexts: a head waits for the workgroups that reduced its rows only)
 //   k_ffn<QT,XR2>         FFN13 (+ SwiGLU) and FFN2 (+ residual) in one launch (single GPU)
 //   k_engine<QT>          the weight-streaming engine (flm_engine.h): several dependent GEMVs in one launch, loader waves feeding an LDS ring
 //                         with LDS-DMA across the phase edges, consumer waves doing prologues / dots / chains / hand-offs (single GPU, int8)
 //   batched prompt processing: k_rows_prologue, k_gemm_q8_mfma<EPI,WT,WR,NB> / k_gemm_q16_mfma (int8 matrix cores; epilogues store |
-//                         residual | SwiGLU | RoPE + KV rows) / k_gemm_q (v_dot), k_qk_mfma + k_attn_pv_mfma (fp32 matrix cores) /
+//                         residual | SwiGLU | RoPE + KV rows), k_qk_mfma + k_attn_pv_mfma (fp32 matrix cores) /
 //                         k_attn_prefill_mq (VALU), k_rope_kv_rows, k_swiglu_rows
 //   k_embed, k_argmax_advance, k_xchg (tensor-parallel exchange)
 // plus small op-level kernels that expose the same __device__ functions to the parity tests.

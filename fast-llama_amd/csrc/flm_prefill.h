@@ -17,7 +17,8 @@ namespace flm {
 // streamed once per 64 tokens instead of once per token.
 //   k_embed_rows        x[b] = embedding[token b]
 //   k_rows_prologue     per token row: (rmsnorm,) quantize -> xq[b], xs[b]   (the decode prologue, one workgroup per row)
-//   k_gemm_q            out[b][r] (+)= W[r] . xq[b] for a 64 x 64 (rows x tokens) tile per workgroup
+//   (k_gemm_q, the v_dot4 / v_dot2 tile kernel of round 1, is gone: 256 VGPRs, reachable only through "use_mfma" 0, 3-6x slower than the matrix-core
+//    tiles that replaced it; "use_mfma" 0 now selects the 64 x 64 matrix-core tiles)
 //   k_rope_kv_rows      RoPE on q and k of every token, K/V rows appended to the cache
 //   k_attn_prefill      causal attention: one workgroup per (head, query), the decode attention with T = pos + i + 1
 //   k_swiglu_rows       hd[b] = swiglu(gate[b], up[b])
@@ -89,121 +90,7 @@ __global__ void k_transpose_scales(const float* s, float* st, int rows, int sn) 
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < (size_t)rows * sn) { const int r = (int)(i / sn), g = (int)(i - (size_t)r * sn); st[(size_t)g * rows + r] = s[i]; }
 }
-// One workgroup: 64 rows x 64 tokens, thread (ty, tx) owns rows 4ty..4ty+3 x tokens 4tx..4tx+3.  Per quant group the
-// 64-row and 64-token slices (64 or 128 bytes each) go through LDS (double buffered; rows padded by 16 B: conflict-free
-// 16-byte reads), int32 dots with v_dot4 / v_dot2, then the reference's fp32 chain step for the 16 outputs of the thread.
-template <int QT, int EPI>
-__global__ void __launch_bounds__(256) k_gemm_q(const GemmArgs a) {
-    using T = QTraits<QT>;
-    constexpr int GB = kGroup * T::kEsz;          // bytes of a group in one row
-    constexpr int NCH = GB / 16;                  // 16-byte chunks per group
-    constexpr int LS = GB + 16;                   // LDS row stride
-    constexpr int NLD = 64 * NCH / 256;           // 16-byte pieces per thread and tile
-    __shared__ __attribute__((aligned(16))) char Wt[2][64 * LS];
-    __shared__ __attribute__((aligned(16))) char Xt[2][64 * LS];
-    __shared__ float sWt[2][64], sXt[2][64];
-    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    const int ntt = (a.B + 63) / 64;
-    // token tile fastest: the ntt tiles that share 64 weight rows are neighbours in the LOGICAL order -- and workgroup b runs on XCD
-    // b mod 8 with its own L2, so the logical order is dealt to the XCDs in contiguous runs: the weight rows are then fetched from HBM
-    // once per XCD that needs them instead of once per token tile (8x the traffic at 512 tokens)
-    const int nb = gridDim.x, per = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7;
-    const int tile = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
-    const int r0 = (tile / ntt) * 64, b0 = (tile % ntt) * 64;
-    const int sn = a.n / kGroup;
-    const size_t rowbytes = (size_t)a.n * T::kEsz;
-    const char* Wb = reinterpret_cast<const char*>(a.W);
-    const char* Xb = reinterpret_cast<const char*>(a.Xq);
-    v4i wr[NLD], xr[NLD]; float sr = 0.f;
-    // branch-free raw buffer loads (rows outside the matrix / groups past the end: out-of-range offset, zeros): under control flow the
-    // compiler waits for vmcnt(0) in every iteration
-    constexpr unsigned kOOB = 0x80000000u;
-    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Wb), 0, (int)((unsigned)a.rows * (unsigned)rowbytes), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Xb), 0, (int)((unsigned)a.B * (unsigned)rowbytes), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rSW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.sW), 0, (int)((unsigned)a.rows * sn * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rSX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Xs), 0, (int)((unsigned)a.B * sn * 4), 0x00020000);
-    unsigned woff[NLD], xoff[NLD];
-#pragma unroll
-    for (int k = 0; k < NLD; ++k) {
-        const int idx = tid + k * 256, row = idx / NCH, ch = idx % NCH;
-        woff[k] = (r0 + row < a.rows) ? (unsigned)(r0 + row) * (unsigned)rowbytes + ch * 16 : kOOB;
-        xoff[k] = (b0 + row < a.B)    ? (unsigned)(b0 + row) * (unsigned)rowbytes + ch * 16 : kOOB;
-    }
-    const unsigned swoff = (tid < 64 && r0 + tid < a.rows) ? (unsigned)(r0 + tid) * sn * 4 : kOOB;
-    const unsigned sxoff = (tid >= 64 && tid < 128 && b0 + tid - 64 < a.B) ? (unsigned)(b0 + tid - 64) * sn * 4 : kOOB;
-    auto fetch = [&](int g) {
-        const bool in = g < sn;
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            wr[k] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rW, (int)((in && woff[k] != kOOB) ? woff[k] + (unsigned)g * GB : kOOB), 0, 0));
-            xr[k] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rX, (int)((in && xoff[k] != kOOB) ? xoff[k] + (unsigned)g * GB : kOOB), 0, 0));
-        }
-        sr = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rSW, (int)((in && swoff != kOOB) ? swoff + (unsigned)g * 4 : kOOB), 0, 0)
-                           | __builtin_amdgcn_raw_buffer_load_b32(rSX, (int)((in && sxoff != kOOB) ? sxoff + (unsigned)g * 4 : kOOB), 0, 0));
-    };
-    auto park = [&](int buf) {
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int idx = tid + k * 256, row = idx / NCH, ch = idx % NCH;
-            *reinterpret_cast<v4i*>(&Wt[buf][row * LS + ch * 16]) = wr[k];
-            *reinterpret_cast<v4i*>(&Xt[buf][row * LS + ch * 16]) = xr[k];
-        }
-        if (tid < 64) sWt[buf][tid] = sr; else if (tid < 128) sXt[buf][tid - 64] = sr;
-    };
-    float acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-    fetch(0); park(0);
-    __syncthreads();
-    for (int g = 0; g < sn; ++g) {
-        const int buf = g & 1;
-        fetch(g + 1);                                                         // (past the end: zeros, never parked)
-        int d[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) d[i][j] = 0;
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-            v4i w[4], x[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) w[i] = *reinterpret_cast<const v4i*>(&Wt[buf][(ty * 4 + i) * LS + ch * 16]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) x[j] = *reinterpret_cast<const v4i*>(&Xt[buf][(tx * 4 + j) * LS + ch * 16]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if constexpr (QT == QT_INT8) d[i][j] = dot16_i8(w[i], x[j], d[i][j]); else d[i][j] = dot8_i16(w[i], x[j], d[i][j]);
-                }
-        }
-        float sw[4], sx[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { sw[i] = sWt[buf][ty * 4 + i]; sx[i] = sXt[buf][tx * 4 + i]; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __fmaf_rn(__fmul_rn(sw[i], sx[j]), (float)d[i][j], acc[i][j]);   // quant_operators.cpp:274
-        park(buf ^ 1);                                                        // (unconditional: the last one parks zeros)
-        __syncthreads();
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int b = b0 + tx * 4 + j;
-        if (b >= a.B) continue;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = r0 + ty * 4 + i;
-            if (row >= a.rows) continue;
-            float* o = a.out + (size_t)b * a.ldo + row;
-            if constexpr (EPI == EPI_RESIDUAL) *o = __fadd_rn(*o, acc[i][j]); else *o = acc[i][j];
-        }
-    }
-}
-
-// The int8 GEMM on the matrix cores (gfx950 v_mfma_i32_32x32x32_i8): the 64 x 64 workgroup tile of k_gemm_q, four waves each owning
+// The int8 GEMM on the matrix cores (gfx950 v_mfma_i32_32x32x32_i8): a 64 x 64 (rows x tokens) workgroup tile, four waves each owning
 // 32 tokens x 32 weight rows.  Per quant group two MFMAs (K = 2 x 32) accumulate the group's 1024 int32 dots exactly (integer sums
 // are order-free; A and B use the same byte -> k assignment: lane half h takes bytes 32kk + 16h .. +15 of the group); then every
 // lane applies the reference's fp32 chain step to its 16 results: v_cvt, v_mul, v_fma per output -- 48 VALU instructions per group
@@ -250,7 +137,7 @@ __global__ void __launch_bounds__(64 * WT * WR, 4) k_gemm_q8_mfma(const GemmArgs
     extern __shared__ __attribute__((aligned(16))) char lds[]; char* const sm = lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntt = (a.B + TT - 1) / TT;
-    const int nb = gridDim.x, per = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7;              // tiles dealt to the XCDs in contiguous runs (see k_gemm_q)
+    const int nb = gridDim.x, per = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7;              // tiles dealt to the XCDs in contiguous runs (token tile fastest: the tiles that share 64 weight rows are neighbours in the LOGICAL order, and workgroup b runs on XCD b mod 8 with its own L2: weight rows are fetched from HBM once per XCD instead of once per token tile)
     const int tile = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
     const int r0 = (tile / ntt) * TRH, b0 = (tile % ntt) * TT;
     const int sn = a.n / kGroup, nst = (sn + kGPS - 1) / kGPS;
@@ -394,7 +281,7 @@ __global__ void __launch_bounds__(64 * WT * WR, 4) k_gemm_q8_mfma(const GemmArgs
 // so a quant group's dot product is  65536 * S(wh, xh) + 256 * (S(wh, xl) + S(wl, xh)) + S(wl, xl)  with four int8 MFMA
 // accumulations S (each exact in int32; the combination wraps mod 2^32 on the way and lands on the true value, which the reference
 // also holds in an int32: 64 * 5792^2 < 2^31, x86_simd.cpp:1524-1552).  Eight v_mfma_i32_32x32x32_i8 per group and wave replace 1024
-// v_dot2 per lane-quadrant of k_gemm_q; the fp32 chain step per group is unchanged (quant_operators.cpp:274).  The split happens
+// the fp32 chain step per group is unchanged (quant_operators.cpp:274).  The split happens
 // once per 16-byte piece when it is parked in LDS (byte planes lo / hi per row).
 __device__ __forceinline__ void split16(const v4i& v, unsigned (&lo)[2], unsigned (&hi)[2]) {
     const unsigned w0 = (unsigned)v.x, w1 = (unsigned)v.y, w2 = (unsigned)v.z, w3 = (unsigned)v.w;
@@ -421,7 +308,7 @@ __global__ void __launch_bounds__(256, 3) k_gemm_q16_mfma(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[]; char* const sm = lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntt = (a.B + TS - 1) / TS;
-    const int nb = gridDim.x, per = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7;              // tiles dealt to the XCDs in contiguous runs (see k_gemm_q)
+    const int nb = gridDim.x, per = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7;              // tiles dealt to the XCDs in contiguous runs (token tile fastest: the tiles that share 64 weight rows are neighbours in the LOGICAL order, and workgroup b runs on XCD b mod 8 with its own L2: weight rows are fetched from HBM once per XCD instead of once per token tile)
     const int tile = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
     const int r0 = (tile / ntt) * TS, b0 = (tile % ntt) * TS;
     const int sn = a.n / kGroup;

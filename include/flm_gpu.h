@@ -154,7 +154,7 @@ int  flm_debug_read(flm_ctx* ctx, int what, int layer, float* out, size_t n);
  * "cu_parts" n = confine the context's stream to 1/n of the device's CUs (part rank % n) and size its launches for them: several ranks on ONE GPU (tests),
  * "use_qk_mfma" 0 = prefill attention scores on VALU chains (default 1: v_mfma_f32_16x16x4_f32, the same bits),
  * "use_pv_mfma" 0 = prefill softmax x V on VALU chains (default 1: the weighted sum on v_mfma_f32_16x16x4_f32 too; needs use_qk_mfma),
- * "use_mfma" 0 = prefill GEMMs on v_dot4 / v_dot2 instead of the matrix cores (default 1: int8 tile shape by problem size; 2 / 3 = always 64 x 64 / 128 x 128 tiles).
+ * "use_mfma" int8 prefill GEMM tile shape on the matrix cores: 1 (default) by problem size, 2 (or 0) always 64 x 64, 3 always 128 x 128 tiles.
  * "engine" the weight-streaming engine (fast-llama_amd/csrc/flm_engine.h; single GPU, int8): 0 (default) off, 1 = FFN13 + FFN2 per launch, 2 = Wo + FFN13 +
  *          FFN2 + the next layer's QKV (or the classifier) per launch; bit-identical, measured slower than the fused launches.
  * None of them changes a result bit.  (Perf-exploration switches that DO skip work -- "ablate", "trace" -- exist only in builds
@@ -176,7 +176,7 @@ int  flm_query(flm_ctx* ctx, const char* key, int* value);
 /* quant::quantize (quant_operators.cpp:78-97) */
 int  flm_op_quantize(int qt, void* qx, float* qs, const float* x, size_t n, int gs);
 /* quant::matmul (quant_operators.cpp:571-591), same argument order: out[w][m].  w < 16: one GEMV per batch row (the decode
- * kernel); w >= 16: the tile kernels of the batched prompt path (int8 and int16 on the int8 matrix cores; FLM_OP_GEMM=0: v_dot) */
+ * kernel); w >= 16: the tile kernels of the batched prompt path (int8 and int16 on the int8 matrix cores; FLM_OP_GEMM=1|2|3: the tile shape) */
 int  flm_op_matmul_q(int qt, float* out, const void* mat1, const float* scales1,
                      const void* mat2, const float* scales2, int m, int n, int w, int gs);
 /* simd::rmsnorm(o,x,w,n) (x86_simd.cpp:1754-1764) */

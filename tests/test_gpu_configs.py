@@ -118,7 +118,7 @@ def test_config5_7B_width_int16_512_token_prefill_vs_oracle(gpu):
 @pytest.mark.parametrize("m,n,w", [(200, 256, 16), (64, 11008, 17), (1000, 4096, 64), (130, 512, 100), (4100, 1024, 200), (96, 256, 800),
                                    (70, 320, 33), (129, 64, 65), (33, 704, 130)])
 def test_op_matmul_batched_runs_the_tile_kernels(gpu, qt, dt, lim, m, n, w, monkeypatch):
-    """flm_op_matmul_q with w >= 16 goes through k_gemm_q8_mfma / k_gemm_q16_mfma / k_gemm_q -- the kernels the batched prompt path
+    """flm_op_matmul_q with w >= 16 goes through k_gemm_q8_mfma / k_gemm_q16_mfma -- the kernels the batched prompt path
     uses -- and must equal quant::matmul's chain bit for bit, as the per-row GEMV does (odd group counts: the MFMA kernels' half
     stage; ragged row / token tiles)"""
     rng = np.random.default_rng(m * 7 + n + w + qt)
@@ -126,7 +126,7 @@ def test_op_matmul_batched_runs_the_tile_kernels(gpu, qt, dt, lim, m, n, w, monk
     sW = rng.uniform(1e-4, 1e-3, (m, n // 64)).astype(np.float32); sX = rng.uniform(1e-3, 1e-2, (w, n // 64)).astype(np.float32)
     if n >= 128: X[:, 64:128] = 0; sX[:, 1] = 0.0
     ref = O.matmul_q(qt, W, sW, X, sX)
-    for variant in ("0", "1", "2", "3", "gemv"):          # v_dot tiles, matrix cores (tile shape by size / 64 x 64 / 128 x 128), a GEMV per row
+    for variant in ("1", "2", "3", "gemv"):          # matrix cores (tile shape by size / 64 x 64 / 128 x 128), a GEMV per row
         monkeypatch.setenv("FLM_OP_GEMM", variant)
         out = gpu.op_matmul_q(qt, W, sW, X, sX)
         assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), variant

@@ -117,9 +117,9 @@ def test_batched_prefill_is_bit_identical_to_token_by_token(gpu, shape, qt, laye
     tensors = synth.make_tensors(cfg, seed=8)
     prompt = _prompt(cfg.vocab_size, n)
     outs = {}
-    for mode in (0, 1, 2, 3):                                   # 0 token by token, 1 batched (GEMMs on MFMA), 2 batched with v_dot, 3 batched, 128 x 128 tiles + fused SwiGLU forced
+    for mode in (0, 1, 2, 3):                                   # 0 token by token, 1 batched (tile shape by size), 2 batched, 64 x 64 tiles forced, 3 batched, 128 x 128 tiles + fused SwiGLU forced
         ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
-        ctx.set_option("use_prefill", 1 if mode else 0); ctx.set_option("use_mfma", {0: 1, 1: 1, 2: 0, 3: 3}[mode])
+        ctx.set_option("use_prefill", 1 if mode else 0); ctx.set_option("use_mfma", {0: 1, 1: 1, 2: 2, 3: 3}[mode])
         lg = ctx.forward(prompt[:5], 0)                       # short prompts stay on the token-by-token path
         lg = ctx.forward(prompt[5:], 5)                       # the batch starts at a non-zero position
         kv = [ctx.debug_read("kcache", l, cfg.n_heads * cfg.max_length * cfg.head_size).reshape(cfg.n_heads, cfg.max_length, -1)[:, :n].copy()

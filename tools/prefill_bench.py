@@ -10,7 +10,7 @@ qt = ff.QT_INT16 if len(sys.argv) > 3 and sys.argv[3] == "int16" else ff.QT_INT8
 cfg = synth.make_config("7B", qt); cfg.n_layers = L
 ctx = capi.Ctx(capi.desc_from_config(cfg))
 ctx.upload_all(synth.make_tensors(cfg, seed=1, share_layers=True))
-if os.environ.get("FLM_MFMA") is not None: ctx.set_option("use_mfma", int(os.environ["FLM_MFMA"]))   # 0: v_dot tile kernel
+if os.environ.get("FLM_MFMA") is not None: ctx.set_option("use_mfma", int(os.environ["FLM_MFMA"]))   # 2 / 3: 64 x 64 / 128 x 128 tiles
 if os.environ.get("FLM_QKMFMA") is not None: ctx.set_option("use_qk_mfma", int(os.environ["FLM_QKMFMA"]))   # 0: scores on VALU chains
 if os.environ.get("FLM_MQ") is not None: ctx.set_option("use_prefill_mq", int(os.environ["FLM_MQ"]))   # 0: one query per workgroup
 prompt = (np.arange(1, n + 1, dtype=np.int64) * 7919 % cfg.vocab_size).astype(np.int32)
