@@ -90,6 +90,59 @@ __global__ void k_transpose_scales(const float* s, float* st, int rows, int sn) 
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < (size_t)rows * sn) { const int r = (int)(i / sn), g = (int)(i - (size_t)r * sn); st[(size_t)g * rows + r] = s[i]; }
 }
+// The epilogue of the int8 matrix-core GEMMs (k_gemm_q8_mfma, k_gemm_q8_ring): a wave holds acc[j][i] = the finished chain of
+// (token tb + (i & 3) + 8 (i >> 2) + 4 (lane >> 5), row rbase + 32 j) -- SWIGLU: j = 0 gate, j = 1 up of the SAME row rbase -- with rbase = the
+// lane's row (lane & 31 inside a 32-row fragment).  Store | residual add | SwiGLU | RoPE + KV rows.
+template <int EPI, int NB>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, const float (&acc)[NB][16], const int rbase, const int tb, const int lane) {
+    constexpr bool TWO = EPI == EPI_SWIGLU;
+    const int h = lane >> 5;
+    if constexpr (EPI == EPI_ROPE_KV) {
+        // a fragment's 32 rows lie inside one of q / k / v (dim is a multiple of 32) and a RoPE pair (rows 2i, 2i + 1) in neighbouring lanes
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int row = rbase + j * 32, which = row / a.dim, within = row - which * a.dim, hh = within / a.hs, dd = within - hh * a.hs;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int b = tb + (i & 3) + 8 * (i >> 2) + 4 * h, pos = a.pos0 + b;
+                const float mine = acc[j][i], other = __shfl_xor(mine, 1, 64);
+                if (row >= a.rows || b >= a.B) continue;
+                float v = mine;
+                if (which < 2) {
+                    const float c = a.rope_cos[(size_t)pos * (a.hs / 2) + dd / 2], sn_ = a.rope_sin[(size_t)pos * (a.hs / 2) + dd / 2];
+                    float o0, o1;
+                    rope_pair((lane & 1) ? other : mine, (lane & 1) ? mine : other, c, sn_, o0, o1);
+                    v = (lane & 1) ? o1 : o0;
+                }
+                if (which == 0) a.qout[(size_t)b * a.dim + within] = v;
+                else (which == 1 ? a.kcache : a.vcache)[((size_t)hh * a.max_seq + pos) * a.hs + dd] = v;
+            }
+        }
+    } else if constexpr (TWO) {
+        const int row = rbase;
+        if (row < a.rows) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int b = tb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (b < a.B) st_result_tp(a.out, (size_t)b * a.ldo + row, swiglu_elem(acc[0][i], acc[NB - 1][i]), a.out_peer, a.n_peer);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int row = rbase + j * 32;
+            if (row >= a.rows) continue;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int b = tb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (b >= a.B) continue;
+                const size_t idx = (size_t)b * a.ldo + row;
+                if constexpr (EPI == EPI_RESIDUAL) st_result_tp(a.out, idx, __fadd_rn(a.n_peer ? ld_agent(a.out + idx) : a.out[idx], acc[j][i]), a.out_peer, a.n_peer);
+                else a.out[idx] = acc[j][i];
+            }
+        }
+    }
+}
 // The int8 GEMM on the matrix cores (gfx950 v_mfma_i32_32x32x32_i8): a 64 x 64 (rows x tokens) workgroup tile, four waves each owning
 // 32 tokens x 32 weight rows.  Per quant group two MFMAs (K = 2 x 32) accumulate the group's 1024 int32 dots exactly (integer sums
 // are order-free; A and B use the same byte -> k assignment: lane half h takes bytes 32kk + 16h .. +15 of the group); then every
@@ -229,51 +282,7 @@ __global__ void __launch_bounds__(64 * WT * WR, 4) k_gemm_q8_mfma(const GemmArgs
         park((st & 1) ^ 1); fetch(st + 2);        // unconditional: a stage past the end is parked and never read with a non-zero scale
         __syncthreads();
     }
-    if constexpr (EPI == EPI_ROPE_KV) {
-        // a fragment's 32 rows lie inside one of q / k / v (dim is a multiple of 32) and a RoPE pair (rows 2i, 2i + 1) in neighbouring lanes
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int row = r0 + wr0 + j * 32 + l31, which = row / a.dim, within = row - which * a.dim, hh = within / a.hs, dd = within - hh * a.hs;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int b = b0 + wt0 + (i & 3) + 8 * (i >> 2) + 4 * h, pos = a.pos0 + b;
-                const float mine = acc[j][i], other = __shfl_xor(mine, 1, 64);
-                if (row >= a.rows || b >= a.B) continue;
-                float v = mine;
-                if (which < 2) {
-                    const float c = a.rope_cos[(size_t)pos * (a.hs / 2) + dd / 2], sn_ = a.rope_sin[(size_t)pos * (a.hs / 2) + dd / 2];
-                    float o0, o1;
-                    rope_pair((lane & 1) ? other : mine, (lane & 1) ? mine : other, c, sn_, o0, o1);
-                    v = (lane & 1) ? o1 : o0;
-                }
-                if (which == 0) a.qout[(size_t)b * a.dim + within] = v;
-                else (which == 1 ? a.kcache : a.vcache)[((size_t)hh * a.max_seq + pos) * a.hs + dd] = v;
-            }
-        }
-    } else if constexpr (TWO) {
-        const int row = r0 + wr0 + l31;
-        if (row < a.rows) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int b = b0 + wt0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (b < a.B) st_result_tp(a.out, (size_t)b * a.ldo + row, swiglu_elem(acc[0][i], acc[NB - 1][i]), a.out_peer, a.n_peer);
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int row = r0 + wr0 + j * 32 + l31;
-            if (row >= a.rows) continue;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int b = b0 + wt0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (b >= a.B) continue;
-                const size_t idx = (size_t)b * a.ldo + row;
-                if constexpr (EPI == EPI_RESIDUAL) st_result_tp(a.out, idx, __fadd_rn(a.n_peer ? ld_agent(a.out + idx) : a.out[idx], acc[j][i]), a.out_peer, a.n_peer);
-                else a.out[idx] = acc[j][i];
-            }
-        }
-    }
+    gemm_epilogue<EPI, NB>(a, acc, r0 + wr0 + l31, b0 + wt0, lane);
 }
 
 // The int16 GEMM on the matrix cores.  gfx950 has no int16 MFMA; an int16 value is split EXACTLY into two signed bytes,
