@@ -71,7 +71,16 @@ void parse(Args& a, int argc, const char** argv) {      // Arguments::parse (mai
         else if (arg == "--seed") a.seed = atoi(val());
         else if (arg == "--rounds") a.rounds = atoi(val());
         else if (arg == "--device") a.device = atoi(val());
-        else if (arg == "--devices") { const char* v = val(); a.devices.clear(); while (*v) { char* e; a.devices.push_back((int)strtol(v, &e, 10)); v = *e ? e + 1 : e; } }
+        else if (arg == "--devices") {                       // a comma-separated list of 1 to 8 non-negative ordinals, nothing else
+            const char* v = val(); a.devices.clear();
+            bool ok = *v != 0;
+            while (ok && *v) {
+                char* e; const long d = strtol(v, &e, 10);
+                ok = e != v && d >= 0 && d < 1024 && (*e == 0 || (*e == ',' && e[1] != 0)) && a.devices.size() < 8;
+                if (ok) { a.devices.push_back((int)d); v = *e ? e + 1 : e; }
+            }
+            if (!ok) { fprintf(stderr, "Invalid --devices list:\x1b[31m%s\x1b[0m (expected 1 to 8 HIP device ordinals, e.g. 0,1,2,3)\n", argv[i - 1]); usage(argv[0]); exit(-1); }
+        }
         else if (arg == "-m" || arg == "--mode") { const char* s = val(); if (!strcasecmp(s, "gen") || !strcasecmp(s, "generate")) a.mode = Mode::GEN; else if (!strcasecmp(s, "chat")) a.mode = Mode::CHAT; else if (!strcasecmp(s, "benchmark") || !strcasecmp(s, "bm")) a.mode = Mode::TEST; }
         else if (arg == "--debug") { a.debug = true; a.detail = true; }
         else if (arg == "-h" || arg == "--help") { usage(argv[0]); exit(0); }
