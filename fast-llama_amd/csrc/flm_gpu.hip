@@ -1235,7 +1235,7 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (k == "fuse_qkv") c->fuse_qkv = value;
     else if (k == "use_prefill_mq") c->use_prefill_mq = value;
     else if (k == "attn_split") c->attn_split = value;
-    else if (k == "engine") c->engine = value;
+    else if (k == "engine") { if (value < 0 || value > 2) return fail(c, FLM_ERR_INVALID, "engine: 0 (off), 1 (FFN13 + FFN2 per launch) or 2 (Wo + FFN13 + FFN2 + next QKV per launch)"); c->engine = value; }
     else if (k == "fold_xchg") c->fold_xchg = value;
     else if (k == "cu_parts") {
         // confine this context's stream to 1 / value of the device's CUs (part rank % value) and size its launches for them: how several tensor-parallel

@@ -77,3 +77,37 @@ def test_engine_long_context_split_heads(gpu):
         out[mode] = [first] + [int(x) for x in ctx.decode_greedy(first, len(prompt), 6)]
         ctx.close()
     assert out[2] == out[0]
+
+
+def test_option_and_query_surface_of_round_3(gpu):
+    """flm_query reads back every option and the path flags; unknown keys and out-of-range values are errors, not silent no-ops;
+    the engine is refused where it cannot run (int16 models fall back to the per-phase kernels by themselves)"""
+    cfg = synth.make_config("tiny", ff.QT_INT8)
+    ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(synth.make_tensors(cfg, seed=5))
+    assert ctx.query("resident") == 1 and ctx.query("fallback") == 0
+    tp = ctx.query("token_path")
+    assert tp & 1 and tp & 2                                   # attention + Wo and FFN13 + FFN2 fused on a whole device
+    for key in ("engine", "fold_xchg", "cu_parts", "fuse_attn_o", "fuse_ffn", "fuse_qkv", "attn_split", "use_graph", "use_mfma"):
+        ctx.query(key)
+    with pytest.raises(gpu.FlmError):
+        ctx.query("no_such_key")
+    with pytest.raises(gpu.FlmError):
+        ctx.set_option("no_such_key", 1)
+    with pytest.raises(gpu.FlmError):
+        ctx.set_option("cu_parts", 3)                          # 1, 2, 4 or 8
+    with pytest.raises(gpu.FlmError):
+        ctx.set_option("engine", 3)                            # 0, 1 or 2
+    ctx.set_option("engine", 2)
+    assert ctx.query("engine") == 2 and (ctx.query("token_path") >> 4) & 3 == 2
+    ctx.set_option("engine", 0)
+    ctx.close()
+    # an int16 model: the engine option is accepted and the token path stays on the per-phase kernels (the engine is int8 only), results unchanged
+    cfg16 = synth.make_config("tiny", ff.QT_INT16)
+    t16 = synth.make_tensors(cfg16, seed=5)
+    c16 = gpu.Ctx(gpu.desc_from_config(cfg16)); c16.upload_all(t16)
+    om = O.OracleModel(cfg16, t16)
+    prompt = np.array([1, 5, 9], np.int32)
+    ref = om.forward(prompt, 0)
+    c16.set_option("engine", 2)
+    assert np.array_equal(c16.forward(prompt, 0).view(np.uint32), ref.view(np.uint32))
+    c16.close()
