@@ -67,3 +67,22 @@ def test_single_process_is_identity():
     assert bench.max_over_ranks(1.25) == 1.25
     v, e = bench.job_throughput(2.0, 128, 1, "single")
     assert v == 64.0 and e == 2.0
+
+
+def test_pmc_traffic_refuses_a_summary_whose_kernel_is_not_in_the_library(tmp_path):
+    """roofline.traffic comes from a committed PMC summary: it is reported only while the kernel the summary names is still a symbol of the
+    library the run loaded (round-2 review: a stale file must not be presented as current)"""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    assert b._mangled_fragment("k_ffn<2,") == b"5k_ffnILi2E"
+    assert b._mangled_fragment("k_gemv<2, 2, 2,") == b"6k_gemvILi2ELi2ELi2E"
+    assert b._mangled_fragment("no template") is None
+    lib_with = tmp_path / "with.so"; lib_with.write_bytes(b"\0\0_ZN3flm5k_ffnILi2ELi3EEEvNS_8GemvArgsES1_iiPjjPi\0")
+    lib_without = tmp_path / "without.so"; lib_without.write_bytes(b"\0\0_ZN3flm6k_gemvILi2ELi2ELi2ELi0ELb0EEEvNS_8GemvArgsE\0")
+    got, src, note = b.pmc_traffic(r"k_ffn<2,", str(lib_with))
+    assert got and got > 100e6 and src.endswith(".json") and "found" in note        # the committed profiles/r*_pmc_*.json
+    got, src, note = b.pmc_traffic(r"k_ffn<2,", str(lib_without))
+    assert got is None and src is None and "stale" in note
+    got, src, note = b.pmc_traffic(r"k_ffn<2,", str(tmp_path / "missing.so"))
+    assert got is None and "cannot read" in note
