@@ -853,20 +853,30 @@ __global__ void __launch_bounds__(kAttnBlock) k_attn_decode(const AttnArgs a) {
 // is read with coherent loads.  All workgroups are resident (grid <= CUs, one 1024-thread workgroup per CU); a poll that
 // never succeeds gives up after ~20 ms and raises *err.  The flag lines are zero when the token starts (k_embed).
 constexpr int kFlagStride = 16;      // dwords
+// k_attn_o under tensor parallelism (peer to peer): this rank's head parts are lines [line0, line0 + its parts) of n_lines; a head part raises its line in EVERY
+// rank's array (system-scope store behind a release fence: its slice of att has gone to every rank's buffer before), the Wo workgroups wait for all n_lines
+// lines of the local array and acquire.  The value is the token's epoch base (device memory, advanced by k_embed) + add: the lines are never cleared.
+struct AoTp { unsigned* peer_flags[8]; const unsigned* base; unsigned add; int world, line0, n_lines; };
 // PREQ: the heads hand over their output already quantized (AttnArgs::oq/os == GemvArgs::xq/xs): the GEMV workgroups
 // copy 1 (2) bytes per element into LDS with coherent loads and skip the quantize prologue (~1.8 us of a 12.9 us launch).
 template <int QT, int XR, bool PREQ, bool SPLIT = false>
-__global__ void __launch_bounds__(kGemvBlock, 4) k_attn_o(const AttnArgs aa, const GemvArgs a, const int n_heads, unsigned* flag, const unsigned target, int* err) {
+__global__ void __launch_bounds__(kGemvBlock, 4) k_attn_o(const AttnArgs aa, const GemvArgs a, const int n_heads, unsigned* flag, const unsigned target_, int* err, const AoTp tp) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     auto stamp = [&](int k) { if (kAblate && a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime(); };   // tools/trace_ao.py
     stamp(0);
-    if ((int)blockIdx.x < n_heads) {                                           // n_heads counts head PARTS: heads * G
+    const unsigned target = tp.world ? *tp.base + tp.add : target_;
+    if ((int)blockIdx.x < n_heads) {                                           // n_heads counts (this rank's) head PARTS: heads * G
         const int G = SPLIT ? aa.G : 1;
         attn_head_any<false, SPLIT>(aa, blockIdx.x / G, lds, *aa.pos_ptr + 1, aa.q, aa.out, blockIdx.x % G, G);
         stamp(1);
         wait_stores_done();                                                     // every wave: its part of the head's output is where the others will read it
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(flag + blockIdx.x * kFlagStride, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) {
+            if (tp.world) {
+                __atomic_thread_fence(__ATOMIC_RELEASE);
+                for (int r = 0; r < tp.world; ++r) __hip_atomic_store(tp.peer_flags[r] + (tp.line0 + blockIdx.x) * kFlagStride, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else __hip_atomic_store(flag + blockIdx.x * kFlagStride, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         stamp(4);
         return;
     }
@@ -874,14 +884,18 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_attn_o(const AttnArgs aa, con
     g.init(a, blockIdx.x - n_heads, gridDim.x - n_heads, lds);
     g.issue(kAblate ? a.ablate : 0);
     stamp(1);
-    if ((int)(threadIdx.x & ~63u) < n_heads) {                              // the waves that own at least one head's flag: lane i polls head i's line
-        const bool mine = (int)threadIdx.x < n_heads;
+    const int n_poll = tp.world ? tp.n_lines : n_heads;
+    if ((int)(threadIdx.x & ~63u) < n_poll) {                               // the waves that own at least one head's flag: lane i polls head i's line
+        const bool mine = (int)threadIdx.x < n_poll;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while (true) {
-            const unsigned f = mine ? __hip_atomic_load(flag + threadIdx.x * kFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
-            if (__all(f >= target)) break;
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            unsigned f = target;
+            if (mine) f = tp.world ? __hip_atomic_load(flag + threadIdx.x * kFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(flag + threadIdx.x * kFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((int)(f - target) >= 0)) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > (tp.world ? 2000000000ull : 2000000ull)) { __hip_atomic_store(err, tp.world ? 2 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }   // (ranks start seconds apart)
+            if (tp.world) __builtin_amdgcn_s_sleep(4);
         }
+        if (tp.world) __atomic_thread_fence(__ATOMIC_ACQUIRE);
     }
     __syncthreads();
     stamp(2);

@@ -89,7 +89,8 @@ struct flm_ctx {
     void* att_q = nullptr; float* att_qs = nullptr;    // k_attn_o: the heads' output already quantized (head_size a multiple of 64)
     // tensor parallel, peer-to-peer: ONE exchange buffer per rank -- [att_out | x1 | hd | logits | flag lines] -- shared with the
     // peers (hipIpc); att_out / x1 / hd / logits point into it.  peer[r] = rank r's buffer mapped here (peer[rank] = xbuf).
-    char* xbuf = nullptr; size_t xbuf_bytes = 0, x_flags_off = 0; bool xbuf_fine = false;
+    char* xbuf = nullptr; size_t xbuf_bytes = 0, x_flags_off = 0, x_hflags_off = 0; bool xbuf_fine = false;
+    int tp_fuse_attn = 1;                              // option "tp_fuse_attn": tensor parallel with folded exchanges: attention + Wo GEMV in one launch (k_attn_o across ranks)
     char* peer[8] = {nullptr}; bool peer_opened[8] = {false}; int p2p = 0;
     unsigned* xepoch = nullptr;                        // [4] exchanges done per kind (att, x1, hd, logits), device memory
     float* att_sc = nullptr;                           // [heads_local][max_seq] scores exchanged between the parts of a split head
@@ -451,19 +452,36 @@ int launch_attn_o(flm_ctx* c, hipStream_t st, int l, int G) {
     AttnArgs aa = args_attn(c, l, G);
     unsigned* flag = c->flag_lines;                              // one 64-byte line per head part, value = layer + 1; k_embed clears them at the start of the token
     const dim3 grid(parts + P.grid), block(kGemvBlock);
+    AoTp tp{};
+    if (c->world > 1) {
+        // across ranks: every rank's head parts raise their lines in every rank's array (in the exchange buffer); the Wo workgroups read the full att vector
+        // from this rank's exchange region (the heads' stores went to every rank) with coherent loads and quantize it themselves
+        if (d.n_heads * G > 256) return FLM_ERR_UNSUPPORTED;
+        tp.world = c->world; tp.line0 = c->plan.head_begin * G; tp.n_lines = d.n_heads * G; tp.base = c->eng_base; tp.add = (unsigned)(4 * l + 1);
+        for (int r = 0; r < c->world; ++r) tp.peer_flags[r] = (unsigned*)(c->peer[r] + c->x_hflags_off);
+        flag = (unsigned*)(c->xbuf + c->x_hflags_off);
+        if (G > 1) {
+            if (rounds <= 1) hipLaunchKernelGGL((k_attn_o<QT, 1, false, true>), grid, block, lds, st, aa, a, parts, flag, 0u, c->xwg_err, tp);
+            else             hipLaunchKernelGGL((k_attn_o<QT, 3, false, true>), grid, block, lds, st, aa, a, parts, flag, 0u, c->xwg_err, tp);
+        }
+        else if (rounds <= 1) hipLaunchKernelGGL((k_attn_o<QT, 1, false>), grid, block, lds, st, aa, a, parts, flag, 0u, c->xwg_err, tp);
+        else                  hipLaunchKernelGGL((k_attn_o<QT, 3, false>), grid, block, lds, st, aa, a, parts, flag, 0u, c->xwg_err, tp);
+        HIPC(c, hipGetLastError());
+        return FLM_OK;
+    }
     if (c->hs % kGroup == 0 && G == 1) {
         // a head's output is whole quant groups: the head workgroups quantize it themselves (A3 on the 64 values a wave
         // holds), the GEMV workgroups fetch 1 (2) bytes per element and skip the quantize prologue
         aa.oq = c->att_q; aa.os = c->att_qs; aa.oqt = QT;
         a.xq = c->att_q; a.xs = c->att_qs;
-        hipLaunchKernelGGL((k_attn_o<QT, 0, true>), grid, block, lds, st, aa, a, parts, flag, (unsigned)(l + 1), c->xwg_err);
+        hipLaunchKernelGGL((k_attn_o<QT, 0, true>), grid, block, lds, st, aa, a, parts, flag, (unsigned)(l + 1), c->xwg_err, tp);
     }
     else if (G > 1) {
-        if (rounds <= 1) hipLaunchKernelGGL((k_attn_o<QT, 1, false, true>), grid, block, lds, st, aa, a, parts, flag, (unsigned)(l + 1), c->xwg_err);
-        else             hipLaunchKernelGGL((k_attn_o<QT, 3, false, true>), grid, block, lds, st, aa, a, parts, flag, (unsigned)(l + 1), c->xwg_err);
+        if (rounds <= 1) hipLaunchKernelGGL((k_attn_o<QT, 1, false, true>), grid, block, lds, st, aa, a, parts, flag, (unsigned)(l + 1), c->xwg_err, tp);
+        else             hipLaunchKernelGGL((k_attn_o<QT, 3, false, true>), grid, block, lds, st, aa, a, parts, flag, (unsigned)(l + 1), c->xwg_err, tp);
     }
-    else if (rounds <= 1) hipLaunchKernelGGL((k_attn_o<QT, 1, false>), grid, block, lds, st, aa, a, parts, flag, (unsigned)(l + 1), c->xwg_err);
-    else                  hipLaunchKernelGGL((k_attn_o<QT, 3, false>), grid, block, lds, st, aa, a, parts, flag, (unsigned)(l + 1), c->xwg_err);
+    else if (rounds <= 1) hipLaunchKernelGGL((k_attn_o<QT, 1, false>), grid, block, lds, st, aa, a, parts, flag, (unsigned)(l + 1), c->xwg_err, tp);
+    else                  hipLaunchKernelGGL((k_attn_o<QT, 3, false>), grid, block, lds, st, aa, a, parts, flag, (unsigned)(l + 1), c->xwg_err, tp);
     HIPC(c, hipGetLastError());
     return FLM_OK;
 }
@@ -657,7 +675,7 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
             Tick t(c, st, KC_QKV);
             r = launch_gemv<PRO_RMSNORM_QUANT, EPI_ROPE_KV>(c, st, qt, folded(traced(args_qkv(c, l), KC_QKV, l), l - 1, 3), wgs, coh); if (r) return r;
         }
-        if (!fused && !tp && c->fuse_attn_o && !c->timing && (c->trace_class < 0 || c->trace_class == 101)) {   // attention + ATTN_O in one launch
+        if (!fused && ((!tp && c->fuse_attn_o) || (fold && c->tp_fuse_attn)) && !c->timing && (c->trace_class < 0 || c->trace_class == 101)) {   // attention + ATTN_O in one launch (tensor parallel: across the ranks)
             r = qt == FLM_QT_INT8 ? launch_attn_o<QT_INT8>(c, st, l, G) : launch_attn_o<QT_INT16>(c, st, l, G);
             if (r == FLM_OK) fused = true; else if (r != FLM_ERR_UNSUPPORTED) return r;
         }
@@ -1089,12 +1107,13 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
         // tensor parallel: the batched prompt path's full-width activations [tokens][dim | dim | hidden] live here too (every rank stores its
         // column slices into every rank's copy)
         const size_t pcap = d.max_seq_len < 64 ? 64 : (size_t)d.max_seq_len;
-        const size_t o_px = up(o_fl + (kXchgSlots * 8 + 1) * 64), o_pa = up(o_px + (world > 1 ? pcap * d.dim * 4 : 0)), o_ph = up(o_pa + (world > 1 ? pcap * d.dim * 4 : 0));
+        const size_t o_hf = up(o_fl + (kXchgSlots * 8 + 1) * 64);                                  // tensor parallel: one line per head part of the whole model (k_attn_o's hand-off across ranks)
+        const size_t o_px = up(o_hf + (world > 1 ? 256 * 64 : 0)), o_pa = up(o_px + (world > 1 ? pcap * d.dim * 4 : 0)), o_ph = up(o_pa + (world > 1 ? pcap * d.dim * 4 : 0));
         const size_t total = world > 1 ? up(o_ph + pcap * d.hidden_dim * 4) : o_fl + (kXchgSlots * 8 + 1) * 64;      // (flags: + the abort line)
         hipError_t ae = hipErrorUnknown;
         if (world > 1) { ae = hipExtMallocWithFlags((void**)&c->xbuf, total, hipDeviceMallocFinegrained); c->xbuf_fine = ae == hipSuccess; }   // written by peer GPUs
         if (ae != hipSuccess) { (void)hipGetLastError(); HIPB(hipMalloc((void**)&c->xbuf, total)); }
-        c->xbuf_bytes = total; c->x_flags_off = o_fl;
+        c->xbuf_bytes = total; c->x_flags_off = o_fl; c->x_hflags_off = o_hf;
         HIPB(hipMemsetAsync(c->xbuf, 0, total, c->stream));
         c->att_out = (float*)(c->xbuf + o_att); c->x1 = (float*)(c->xbuf + o_x1); c->hd = (float*)(c->xbuf + o_hd); c->logits = (float*)(c->xbuf + o_lg);
         c->peer[rank] = c->xbuf;
@@ -1237,6 +1256,7 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (k == "attn_split") c->attn_split = value;
     else if (k == "engine") { if (value < 0 || value > 2) return fail(c, FLM_ERR_INVALID, "engine: 0 (off), 1 (FFN13 + FFN2 per launch) or 2 (Wo + FFN13 + FFN2 + next QKV per launch)"); c->engine = value; }
     else if (k == "fold_xchg") c->fold_xchg = value;
+    else if (k == "tp_fuse_attn") c->tp_fuse_attn = value;
     else if (k == "cu_parts") {
         // confine this context's stream to 1 / value of the device's CUs (part rank % value) and size its launches for them: how several tensor-parallel
         // ranks share ONE GPU without a waiting consumer launch taking the CUs its peers' producers need (tests; a real rank owns a device: value 1)
@@ -1285,7 +1305,7 @@ int flm_query(flm_ctx* c, const char* key, int* value) {
     const struct { const char* k; int v; } tab[] = {
         {"wg_per_cu", c->wg_per_cu}, {"use_graph", c->use_graph}, {"use_prefill", c->use_prefill}, {"use_mfma", c->use_mfma}, {"use_pv_mfma", c->use_pv_mfma},
         {"fuse_attn_o", c->fuse_attn_o}, {"fuse_ffn", c->fuse_ffn}, {"fuse_qkv", c->fuse_qkv}, {"use_prefill_mq", c->use_prefill_mq}, {"attn_split", c->attn_split},
-        {"use_qk_mfma", c->use_qk_mfma}, {"use_p2p", c->p2p}, {"engine", c->engine}, {"fold_xchg", c->fold_xchg}, {"cu_parts", c->cu_parts}, {"fold_active", (c->world > 1 && c->p2p && c->fold_xchg && c->cu_parts >= c->ranks_on_device) ? 1 : 0}, {"resident", c->resident}, {"fallback", c->fell_back},
+        {"use_qk_mfma", c->use_qk_mfma}, {"use_p2p", c->p2p}, {"engine", c->engine}, {"fold_xchg", c->fold_xchg}, {"tp_fuse_attn", c->tp_fuse_attn}, {"cu_parts", c->cu_parts}, {"fold_active", (c->world > 1 && c->p2p && c->fold_xchg && c->cu_parts >= c->ranks_on_device) ? 1 : 0}, {"resident", c->resident}, {"fallback", c->fell_back},
         {"token_path", (c->world == 1 ? ((c->fuse_attn_o ? 1 : 0) | (c->fuse_ffn && c->engine != 1 && c->engine != 2 ? 2 : 0) | (c->fuse_attn_o && c->fuse_qkv == 1 ? 4 : 0) | (c->fuse_attn_o && c->fuse_qkv >= 2 ? 8 : 0) | ((c->engine & 3) << 4)) : 0) | (c->attn_split ? 64 : 0)},
     };
     for (const auto& t : tab) if (k == t.k) { *value = t.v; return FLM_OK; }
@@ -1560,7 +1580,7 @@ int flm_kernel_times(flm_ctx* c, int pos, int iters, float* avg_us, int32_t* cou
         case KC_CLS:    return launch_gemv<PRO_RMSNORM_QUANT, EPI_STORE>(c, st, qt, args_cls(c), wgs);
         case KC_ARGMAX: hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, st, (const float*)c->logits, d.vocab_size, c->state, (int*)nullptr, 0, 0); return FLM_OK;   // (no id is recorded: the step counter runs on)
         // the fused launches the token path uses on a single GPU (FLM_ERR_UNSUPPORTED: this shape / option setting runs the phases separately)
-        case KC_ATTN_WO: if (!c->fuse_attn_o) return FLM_ERR_UNSUPPORTED;
+        case KC_ATTN_WO: if (!c->fuse_attn_o || c->world > 1) return FLM_ERR_UNSUPPORTED;      // (across ranks the launch waits for its peers' heads: not timed in isolation)
                          return qt == FLM_QT_INT8 ? launch_attn_o<QT_INT8>(c, st, l, attn_parts(c, pos + 1)) : launch_attn_o<QT_INT16>(c, st, l, attn_parts(c, pos + 1));
         case KC_FFN:     if (!c->fuse_ffn) return FLM_ERR_UNSUPPORTED;
                          return qt == FLM_QT_INT8 ? launch_ffn<QT_INT8>(c, st, l) : launch_ffn<QT_INT16>(c, st, l);

@@ -168,12 +168,15 @@ def test_rccl_exchange_branch_on_a_one_rank_communicator(gpu, qt):
     ctx.close()
 
 
-@pytest.mark.parametrize("shape,qt,layers,world", [("small", ff.QT_INT8, None, 2), ("small", ff.QT_INT16, None, 4), ("7B", ff.QT_INT8, 2, 2), ("7B", ff.QT_INT8, 1, 4)])
-def test_folded_exchange_under_cu_masks(gpu, shape, qt, layers, world):
+@pytest.mark.parametrize("shape,qt,layers,world,fuse", [("small", ff.QT_INT8, None, 2, 1), ("small", ff.QT_INT16, None, 4, 1), ("7B", ff.QT_INT8, 2, 2, 1), ("7B", ff.QT_INT8, 1, 4, 1),
+                                                        ("small", ff.QT_INT8, None, 2, 0), ("7B", ff.QT_INT8, 2, 2, 0)])
+def test_folded_exchange_under_cu_masks(gpu, shape, qt, layers, world, fuse):
     """The latency path of the sharded token: every exchange's flag round inside the GEMV launch that consumes the vector ("fold_xchg", the default when
     every rank has CUs of its own) -- 5 launches per layer instead of 9.  On one GPU the ranks get disjoint CU masks ("cu_parts": 2 x 128 or 4 x 64 CUs,
     launches sized to the mask), so a consumer that polls cannot keep its peers' producers off the device.  Logits and graph-replayed greedy ids of
-    every rank = the oracle's bits; without the partition the contexts fall back to k_xchg launches by themselves (fold_active 0)."""
+    every rank = the oracle's bits; without the partition the contexts fall back to k_xchg launches by themselves (fold_active 0).
+    fuse 1 (the default): attention and the Wo GEMV are ONE launch across the ranks ("tp_fuse_attn": every rank's heads raise their lines in every rank's
+    array, the Wo workgroups of every rank wait for all heads of the model) -- 4 launches per layer; fuse 0: two launches."""
     cfg = synth.make_config(shape, qt)
     if layers:
         cfg.n_layers = layers
@@ -194,6 +197,7 @@ def test_folded_exchange_under_cu_masks(gpu, shape, qt, layers, world):
         assert c.query("fold_active") == 0          # ranks share the device and have no partition yet
         c.set_option("cu_parts", world)
         assert c.query("fold_active") == 1
+        c.set_option("tp_fuse_attn", fuse)
 
     def rank_main(c):
         lg = [c.forward(prompt, 0)]
@@ -207,5 +211,41 @@ def test_folded_exchange_under_cu_masks(gpu, shape, qt, layers, world):
         for i, l in enumerate(lg):
             assert bits_equal(l, want[i]), f"rank {r}: logits of step {i}"
         assert ids == ids_want[3:7], f"rank {r}: greedy ids"
+    for c in ctxs:
+        c.close()
+
+
+@pytest.mark.parametrize("fuse", [1, 0])
+def test_fused_attention_across_ranks_with_split_heads(gpu, fuse):
+    """long contexts under tensor parallelism with folded exchanges: a rank's heads are spread over hs/32 workgroups each inside the attention + Wo launch that
+    spans the ranks (a part raises its own line; the Wo workgroups wait for every part of every head of the model); CU-masked ranks on one GPU, oracle bits"""
+    cfg = synth.make_config("small", ff.QT_INT8)
+    tensors = synth.make_tensors(cfg, seed=47)
+    om = O.OracleModel(cfg, tensors)
+    prompt = _prompt(cfg.vocab_size, 200)
+    want = [om.forward(prompt, 0)]
+    cur, pos = int(np.argmax(want[0])), len(prompt)
+    for _ in range(4):
+        want.append(om.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(want[-1])); pos += 1
+    ids_want = [int(np.argmax(w)) for w in want]
+    world = 2
+    ctxs = [gpu.Ctx(gpu.desc_from_config(cfg), device=0, rank=r, world=world, comm_id=None) for r in range(world)]
+    for c in ctxs:
+        c.upload_all(tensors)
+    blobs = [c.p2p_export() for c in ctxs]
+    for c in ctxs:
+        c.p2p_import(blobs)
+        c.set_option("cu_parts", world)
+        c.set_option("tp_fuse_attn", fuse)
+
+    def rank_main(c):
+        lg = [c.forward(prompt, 0)]
+        cur, pos = int(np.argmax(lg[0])), len(prompt)
+        lg.append(c.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(lg[-1])); pos += 1
+        return lg, [int(x) for x in c.decode_greedy(cur, pos, 3)]
+
+    for r, (lg, ids) in enumerate(_run_ranks(ctxs, rank_main)):
+        assert bits_equal(lg[0], want[0]) and bits_equal(lg[1], want[1]), f"rank {r}"
+        assert ids == ids_want[2:5], f"rank {r}: greedy ids"
     for c in ctxs:
         c.close()
