@@ -994,33 +994,51 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_qkv_attn_o(const GemvArgs aq,
 // (DESIGN.md section 7).  The two phases are k_gemv<RMSNORM_QUANT, SWIGLU> and k_gemv<QUANT, RESIDUAL> verbatim (hd is read
 // with coherent loads).  All workgroups are resident (grid <= CUs, one 1024-thread workgroup per CU); a poll that never succeeds
 // gives up after ~20 ms and raises *err (the host then re-runs the call on one kernel per phase).
-template <int QT, int XR2>
-__global__ void __launch_bounds__(kGemvBlock, 4) k_ffn(const GemvArgs a13, const GemvArgs a2, const int grid13, const int grid2, unsigned* flag, const unsigned target, int* err) {
+// Tensor parallel (TP): the launch spans the ranks.  FFN13 consumes the x1 exchange (its flag round folded into this launch: xchg_fold, coherent loads); a rank's
+// workgroups count themselves out on a device counter when their rows of hd have gone to every rank's buffer, the last one raises the RANK's line in every rank's
+// array (release fence before, epoch value = the token's base + add; 8 lines, never cleared) -- an all-to-all between N x 256 workgroups would be N x 256 lines per
+// workgroup to poll --, and the FFN2 workgroups of every rank wait for the N rank lines, acquire, and go on as on a single GPU.
+struct FfnTp { unsigned* peer_flags[8]; const unsigned* base; unsigned add; int world, rank; unsigned long long* counter; };
+template <int QT, int XR2, bool TP = false>
+__global__ void __launch_bounds__(kGemvBlock, 4) k_ffn(const GemvArgs a13, const GemvArgs a2, const int grid13, const int grid2, unsigned* flag, const unsigned target_, int* err, const FfnTp tp) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     auto nostamp = [](int) {};
+    const unsigned target = TP ? *tp.base + tp.add : target_;
+    if constexpr (TP) { if (a13.xf.world) xchg_fold(a13.xf); }                  // (every workgroup: the barrier inside is the workgroup's own)
     if ((int)blockIdx.x < grid13) {
         float4 xv[1], nv[1];
-        gemv_preload<QT, PRO_RMSNORM_QUANT, 1>(a13, xv, nv);
+        gemv_preload<QT, PRO_RMSNORM_QUANT, 1, TP>(a13, xv, nv);
         GemvCtx<QT, EPI_SWIGLU> g;
         g.init(a13, blockIdx.x, grid13, lds);
-        gemv_prologue<QT, PRO_RMSNORM_QUANT, 1>(a13, lds, xv, nv, [&](int part) { g.issue(kAblate ? a13.ablate : 0, part); });
+        gemv_prologue<QT, PRO_RMSNORM_QUANT, 1, TP>(a13, lds, xv, nv, [&](int part) { g.issue(kAblate ? a13.ablate : 0, part); });
         g.run(a13, lds, nostamp);
     }
     wait_stores_done();                                                         // every wave: its rows of hd are where the others will read them
     __syncthreads();                                                            // (and the LDS is free for the second phase)
-    if (threadIdx.x == 0) __hip_atomic_store(flag + blockIdx.x * kFlagStride, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+        if constexpr (TP) {
+            const unsigned long long old = __hip_atomic_fetch_add(tp.counter, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if ((old + 1) % gridDim.x == 0) {                                   // the rank's last workgroup (the counter only ever grows: gridDim.x per launch)
+                __atomic_thread_fence(__ATOMIC_RELEASE);
+                for (int r = 0; r < tp.world; ++r) __hip_atomic_store(tp.peer_flags[r] + tp.rank * kFlagStride, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        } else __hip_atomic_store(flag + blockIdx.x * kFlagStride, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if ((int)blockIdx.x >= grid2) return;
     GemvCtx<QT, EPI_RESIDUAL> g2;
     g2.init(a2, blockIdx.x, grid2, lds);
     g2.issue(kAblate ? a2.ablate : 0, 1);                                       // ONE set now (64 KiB per CU: taken by the memory pipeline before the flags come in); hd
     if (threadIdx.x < 256) {                                                    // requested behind two sets would wait for 128 KiB per CU to drain (measured: no gain at all)
-        const bool mine = threadIdx.x < gridDim.x;
+        const bool mine = (int)threadIdx.x < (TP ? tp.world : (int)gridDim.x);
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while (true) {
-            const unsigned f = mine ? __hip_atomic_load(flag + threadIdx.x * kFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
-            if (__all(f >= target)) break;
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            unsigned f = target;
+            if (mine) f = TP ? __hip_atomic_load(flag + threadIdx.x * kFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(flag + threadIdx.x * kFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((int)(f - target) >= 0)) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > (TP ? 2000000000ull : 2000000ull)) { __hip_atomic_store(err, TP ? 2 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            if constexpr (TP) __builtin_amdgcn_s_sleep(4);
         }
+        if constexpr (TP) __atomic_thread_fence(__ATOMIC_ACQUIRE);
     }
     __syncthreads();
     float4 xv2[XR2 > 0 ? XR2 : 1], nv2[XR2 > 0 ? XR2 : 1];

@@ -90,6 +90,9 @@ struct flm_ctx {
     // tensor parallel, peer-to-peer: ONE exchange buffer per rank -- [att_out | x1 | hd | logits | flag lines] -- shared with the
     // peers (hipIpc); att_out / x1 / hd / logits point into it.  peer[r] = rank r's buffer mapped here (peer[rank] = xbuf).
     char* xbuf = nullptr; size_t xbuf_bytes = 0, x_flags_off = 0, x_hflags_off = 0; bool xbuf_fine = false;
+    int tp_fuse_ffn = 0;                               // option "tp_fuse_ffn": the same for FFN13 + FFN2 (k_ffn across ranks: one line per rank, raised by the rank's last workgroup); off by
+                                                       // default: on one GPU under CU masks it is slower at 2-4 ranks and faster at 8 (profiles/r03_tp_onegpu.txt) -- a multi-GPU box has to decide
+    unsigned long long* ffn_counter = nullptr;         // (its device counter)
     int tp_fuse_attn = 1;                              // option "tp_fuse_attn": tensor parallel with folded exchanges: attention + Wo GEMV in one launch (k_attn_o across ranks)
     char* peer[8] = {nullptr}; bool peer_opened[8] = {false}; int p2p = 0;
     unsigned* xepoch = nullptr;                        // [4] exchanges done per kind (att, x1, hd, logits), device memory
@@ -533,8 +536,20 @@ int launch_ffn(flm_ctx* c, hipStream_t st, int l) {
     const size_t lds = P13.lds > P2.lds ? P13.lds : P2.lds;
     const int grid = P13.grid > P2.grid ? P13.grid : P2.grid;
     unsigned* flag = c->flag_lines + 512 * 16;                    // value = layer + 1; k_embed clears the lines at the start of the token
-    if (r2 <= 1) hipLaunchKernelGGL((k_ffn<QT, 1>), dim3(grid), dim3(kGemvBlock), lds, st, a13, a2, P13.grid, P2.grid, flag, (unsigned)(l + 1), c->xwg_err);
-    else         hipLaunchKernelGGL((k_ffn<QT, 3>), dim3(grid), dim3(kGemvBlock), lds, st, a13, a2, P13.grid, P2.grid, flag, (unsigned)(l + 1), c->xwg_err);
+    FfnTp tp{};
+    if (c->world > 1) {
+        // across ranks: FFN13 consumes the x1 exchange behind the Wo launch (folded flag round, kind 1); one line per RANK for hd (in the exchange buffer, behind the head lines)
+        set_fold(c, a13, l, 1);
+        tp.world = c->world; tp.rank = c->rank; tp.base = c->eng_base; tp.add = (unsigned)(4 * l + 3); tp.counter = c->ffn_counter;
+        for (int r = 0; r < c->world; ++r) tp.peer_flags[r] = (unsigned*)(c->peer[r] + c->x_hflags_off) + 256 * 16;
+        flag = (unsigned*)(c->xbuf + c->x_hflags_off) + 256 * 16;
+        if (r2 <= 1) hipLaunchKernelGGL((k_ffn<QT, 1, true>), dim3(grid), dim3(kGemvBlock), lds, st, a13, a2, P13.grid, P2.grid, flag, 0u, c->xwg_err, tp);
+        else         hipLaunchKernelGGL((k_ffn<QT, 3, true>), dim3(grid), dim3(kGemvBlock), lds, st, a13, a2, P13.grid, P2.grid, flag, 0u, c->xwg_err, tp);
+        HIPC(c, hipGetLastError());
+        return FLM_OK;
+    }
+    if (r2 <= 1) hipLaunchKernelGGL((k_ffn<QT, 1>), dim3(grid), dim3(kGemvBlock), lds, st, a13, a2, P13.grid, P2.grid, flag, (unsigned)(l + 1), c->xwg_err, tp);
+    else         hipLaunchKernelGGL((k_ffn<QT, 3>), dim3(grid), dim3(kGemvBlock), lds, st, a13, a2, P13.grid, P2.grid, flag, (unsigned)(l + 1), c->xwg_err, tp);
     HIPC(c, hipGetLastError());
     return FLM_OK;
 }
@@ -694,9 +709,12 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
         }
         if (tp && !fold) { r = exchange(c, st, XK_X1, c->x1, c->x1 + c->drow_begin, c->drow_count); if (r) return r; }
         if (eng == 1) { r = launch_engine(c, st, 0, 4 * l + 2, 4 * l + 4); if (r) return r; continue; }   // FFN13 + FFN2 on the engine
-        if (!tp && c->fuse_ffn && !c->timing && c->trace_class < 0) {   // FFN13 + FFN2 in one launch
+        if (((!tp && c->fuse_ffn) || (fold && c->tp_fuse_ffn)) && !c->timing && c->trace_class < 0) {   // FFN13 + FFN2 in one launch (tensor parallel: across the ranks)
             r = qt == FLM_QT_INT8 ? launch_ffn<QT_INT8>(c, st, l) : launch_ffn<QT_INT16>(c, st, l);
-            if (r == FLM_OK) continue; else if (r != FLM_ERR_UNSUPPORTED) return r;
+            if (r == FLM_OK) {
+                if (tp && l == L - 1 && !with_cls) { r = exchange(c, st, XK_X1, c->x1, c->x1 + c->drow_begin, c->drow_count); if (r) return r; }   // (see below)
+                continue;
+            } else if (r != FLM_ERR_UNSUPPORTED) return r;
         }
         {   // FFN13 task + SwiGLU (transformer.cpp:144-147, execute_ffn13 :468-483): this rank's rows of W1/W3
             Tick t(c, st, KC_FFN13);
@@ -1108,7 +1126,8 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
         // column slices into every rank's copy)
         const size_t pcap = d.max_seq_len < 64 ? 64 : (size_t)d.max_seq_len;
         const size_t o_hf = up(o_fl + (kXchgSlots * 8 + 1) * 64);                                  // tensor parallel: one line per head part of the whole model (k_attn_o's hand-off across ranks)
-        const size_t o_px = up(o_hf + (world > 1 ? 256 * 64 : 0)), o_pa = up(o_px + (world > 1 ? pcap * d.dim * 4 : 0)), o_ph = up(o_pa + (world > 1 ? pcap * d.dim * 4 : 0));
+        const size_t o_px = up(o_hf + (world > 1 ? (256 + 8) * 64 : 0));                             // (+ one line per rank: k_ffn's hand-off across ranks)
+        const size_t o_pa = up(o_px + (world > 1 ? pcap * d.dim * 4 : 0)), o_ph = up(o_pa + (world > 1 ? pcap * d.dim * 4 : 0));
         const size_t total = world > 1 ? up(o_ph + pcap * d.hidden_dim * 4) : o_fl + (kXchgSlots * 8 + 1) * 64;      // (flags: + the abort line)
         hipError_t ae = hipErrorUnknown;
         if (world > 1) { ae = hipExtMallocWithFlags((void**)&c->xbuf, total, hipDeviceMallocFinegrained); c->xbuf_fine = ae == hipSuccess; }   // written by peer GPUs
@@ -1119,6 +1138,7 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
         c->peer[rank] = c->xbuf;
         if (world > 1) { c->pf_x = (float*)(c->xbuf + o_px); c->pf_att = (float*)(c->xbuf + o_pa); c->pf_hd = (float*)(c->xbuf + o_ph); c->pf_in_xbuf = true; }
         HIPB(hipMalloc((void**)&c->xepoch, 64)); HIPB(hipMemsetAsync(c->xepoch, 0, 64, c->stream));
+        HIPB(hipMalloc((void**)&c->ffn_counter, 64)); HIPB(hipMemsetAsync(c->ffn_counter, 0, 64, c->stream));
     }
     HIPB(hipMalloc((void**)&c->flag_lines, 1024 * 64)); HIPB(hipMalloc((void**)&c->xwg_err, 64));   // lines 0..255: k_attn_o's heads, 256..511: split heads' scores, 512..767: k_ffn, 768..1023: k_qkv_attn_o's QKV rows
     HIPB(hipMemsetAsync(c->flag_lines, 0, 1024 * 64, c->stream)); HIPB(hipMemsetAsync(c->xwg_err, 0, 64, c->stream));
@@ -1175,7 +1195,7 @@ void flm_ctx_destroy(flm_ctx* c) {
     for (int r = 0; r < c->world; ++r) if (c->peer_opened[r] && c->peer[r]) hipIpcCloseMemHandle(c->peer[r]);
     void* ptrs[] = {c->emb, c->emb_s, c->out_norm, c->kcache, c->vcache, c->xbuf, c->xepoch, c->qbuf,
                     c->rope_cos, c->rope_sin, c->state, c->prompt_dev, c->out_tokens_dev,
-                    c->flag_lines, c->xwg_err, c->att_q, c->att_qs, c->att_sc, c->trace, c->gx1, c->ghd, c->ghq, c->eng_base,
+                    c->flag_lines, c->xwg_err, c->att_q, c->att_qs, c->att_sc, c->trace, c->gx1, c->ghd, c->ghq, c->eng_base, c->ffn_counter,
                     c->pf_in_xbuf ? nullptr : c->pf_x, c->pf_qkv, c->pf_q, c->pf_in_xbuf ? nullptr : c->pf_att, c->pf_gu, c->pf_in_xbuf ? nullptr : c->pf_hd, c->pf_xs, c->pf_xq, c->pf_scores};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->comm) ncclCommDestroy(c->comm);
@@ -1257,6 +1277,7 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (k == "engine") { if (value < 0 || value > 2) return fail(c, FLM_ERR_INVALID, "engine: 0 (off), 1 (FFN13 + FFN2 per launch) or 2 (Wo + FFN13 + FFN2 + next QKV per launch)"); c->engine = value; }
     else if (k == "fold_xchg") c->fold_xchg = value;
     else if (k == "tp_fuse_attn") c->tp_fuse_attn = value;
+    else if (k == "tp_fuse_ffn") c->tp_fuse_ffn = value;
     else if (k == "cu_parts") {
         // confine this context's stream to 1 / value of the device's CUs (part rank % value) and size its launches for them: how several tensor-parallel
         // ranks share ONE GPU without a waiting consumer launch taking the CUs its peers' producers need (tests; a real rank owns a device: value 1)
@@ -1305,7 +1326,7 @@ int flm_query(flm_ctx* c, const char* key, int* value) {
     const struct { const char* k; int v; } tab[] = {
         {"wg_per_cu", c->wg_per_cu}, {"use_graph", c->use_graph}, {"use_prefill", c->use_prefill}, {"use_mfma", c->use_mfma}, {"use_pv_mfma", c->use_pv_mfma},
         {"fuse_attn_o", c->fuse_attn_o}, {"fuse_ffn", c->fuse_ffn}, {"fuse_qkv", c->fuse_qkv}, {"use_prefill_mq", c->use_prefill_mq}, {"attn_split", c->attn_split},
-        {"use_qk_mfma", c->use_qk_mfma}, {"use_p2p", c->p2p}, {"engine", c->engine}, {"fold_xchg", c->fold_xchg}, {"tp_fuse_attn", c->tp_fuse_attn}, {"cu_parts", c->cu_parts}, {"fold_active", (c->world > 1 && c->p2p && c->fold_xchg && c->cu_parts >= c->ranks_on_device) ? 1 : 0}, {"resident", c->resident}, {"fallback", c->fell_back},
+        {"use_qk_mfma", c->use_qk_mfma}, {"use_p2p", c->p2p}, {"engine", c->engine}, {"fold_xchg", c->fold_xchg}, {"tp_fuse_attn", c->tp_fuse_attn}, {"tp_fuse_ffn", c->tp_fuse_ffn}, {"cu_parts", c->cu_parts}, {"fold_active", (c->world > 1 && c->p2p && c->fold_xchg && c->cu_parts >= c->ranks_on_device) ? 1 : 0}, {"resident", c->resident}, {"fallback", c->fell_back},
         {"token_path", (c->world == 1 ? ((c->fuse_attn_o ? 1 : 0) | (c->fuse_ffn && c->engine != 1 && c->engine != 2 ? 2 : 0) | (c->fuse_attn_o && c->fuse_qkv == 1 ? 4 : 0) | (c->fuse_attn_o && c->fuse_qkv >= 2 ? 8 : 0) | ((c->engine & 3) << 4)) : 0) | (c->attn_split ? 64 : 0)},
     };
     for (const auto& t : tab) if (k == t.k) { *value = t.v; return FLM_OK; }
@@ -1582,7 +1603,7 @@ int flm_kernel_times(flm_ctx* c, int pos, int iters, float* avg_us, int32_t* cou
         // the fused launches the token path uses on a single GPU (FLM_ERR_UNSUPPORTED: this shape / option setting runs the phases separately)
         case KC_ATTN_WO: if (!c->fuse_attn_o || c->world > 1) return FLM_ERR_UNSUPPORTED;      // (across ranks the launch waits for its peers' heads: not timed in isolation)
                          return qt == FLM_QT_INT8 ? launch_attn_o<QT_INT8>(c, st, l, attn_parts(c, pos + 1)) : launch_attn_o<QT_INT16>(c, st, l, attn_parts(c, pos + 1));
-        case KC_FFN:     if (!c->fuse_ffn) return FLM_ERR_UNSUPPORTED;
+        case KC_FFN:     if (!c->fuse_ffn || c->world > 1) return FLM_ERR_UNSUPPORTED;
                          return qt == FLM_QT_INT8 ? launch_ffn<QT_INT8>(c, st, l) : launch_ffn<QT_INT16>(c, st, l);
         case KC_ENG_FFN:   if (!c->engine || !c->eng_built) return FLM_ERR_UNSUPPORTED;
                            return launch_engine(c, st, 0, 4 * l + 2, 4 * l + 4);

@@ -176,7 +176,8 @@ def test_folded_exchange_under_cu_masks(gpu, shape, qt, layers, world, fuse):
     launches sized to the mask), so a consumer that polls cannot keep its peers' producers off the device.  Logits and graph-replayed greedy ids of
     every rank = the oracle's bits; without the partition the contexts fall back to k_xchg launches by themselves (fold_active 0).
     fuse 1 (the default): attention and the Wo GEMV are ONE launch across the ranks ("tp_fuse_attn": every rank's heads raise their lines in every rank's
-    array, the Wo workgroups of every rank wait for all heads of the model) -- 4 launches per layer; fuse 0: two launches."""
+    array, the Wo workgroups of every rank wait for all heads of the model), and so are FFN13 and FFN2 ("tp_fuse_ffn": a rank's last workgroup raises the
+    rank's line everywhere) -- 3 launches per layer; fuse 0: five."""
     cfg = synth.make_config(shape, qt)
     if layers:
         cfg.n_layers = layers
@@ -197,7 +198,7 @@ def test_folded_exchange_under_cu_masks(gpu, shape, qt, layers, world, fuse):
         assert c.query("fold_active") == 0          # ranks share the device and have no partition yet
         c.set_option("cu_parts", world)
         assert c.query("fold_active") == 1
-        c.set_option("tp_fuse_attn", fuse)
+        c.set_option("tp_fuse_attn", fuse); c.set_option("tp_fuse_ffn", fuse)
 
     def rank_main(c):
         lg = [c.forward(prompt, 0)]
@@ -236,7 +237,7 @@ def test_fused_attention_across_ranks_with_split_heads(gpu, fuse):
     for c in ctxs:
         c.p2p_import(blobs)
         c.set_option("cu_parts", world)
-        c.set_option("tp_fuse_attn", fuse)
+        c.set_option("tp_fuse_attn", fuse); c.set_option("tp_fuse_ffn", fuse)
 
     def rank_main(c):
         lg = [c.forward(prompt, 0)]

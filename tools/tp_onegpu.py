@@ -23,9 +23,10 @@ def run(fn):
     [t.start() for t in th]; [t.join() for t in th]
     return out
 
-for fold, fuse, name in ((0, 0, "k_xchg launches (9 per layer)"), (1, 0, "folded exchanges (5 per layer)"), (1, 1, "folded + attention and Wo in one launch (4 per layer)")):
+for fold, fa, fn, name in ((0, 0, 0, "k_xchg launches (9 per layer)"), (1, 0, 0, "folded exchanges (5 per layer)"), (1, 1, 0, "folded + attention and Wo in one launch (4 per layer)"),
+                           (1, 1, 1, "folded + attention and Wo, FFN13 and FFN2 fused (3 per layer)")):
     for c in ctxs:
-        c.set_option("fold_xchg", fold); c.set_option("tp_fuse_attn", fuse); c.reset_kv()
+        c.set_option("fold_xchg", fold); c.set_option("tp_fuse_attn", fa); c.set_option("tp_fuse_ffn", fn); c.reset_kv()
     first = run(lambda c: c.forward_argmax(prompt, 0))[0]
     run(lambda c: c.decode_greedy(first, len(prompt), 8))
     best = 1e9
@@ -34,4 +35,4 @@ for fold, fuse, name in ((0, 0, "k_xchg launches (9 per layer)"), (1, 0, "folded
         ids = run(lambda c: c.decode_greedy(first, len(prompt), ntok))
         best = min(best, time.perf_counter() - t0)
     assert all(list(i) == list(ids[0]) for i in ids)
-    print(f"tp{world} on one GPU ({256 // world} CUs per rank), {L} layers of 7B width: {name:58s} {best / ntok * 1e6:8.1f} us per token  ids {list(ids[0][:4])}")
+    print(f"tp{world} on one GPU ({256 // world} CUs per rank), {L} layers of 7B width: {name:66s} {best / ntok * 1e6:8.1f} us per token  ids {list(ids[0][:4])}")
