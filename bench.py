@@ -597,6 +597,11 @@ def open_tp_ctx(capi, cfg, rank, world, device, dist, torch):
         ctx.exchange = "rccl all-gather"
     else:
         ctx.exchange = "peer-to-peer stores over xGMI + flag round"
+        if os.environ.get("FLM_BENCH_FORCE_DEVICE") is not None and world in (2, 4, 8):
+            # the rehearsal on ONE GPU: give every rank a CU partition of its own, so that the latency path (flag rounds folded into the consuming launches,
+            # attention + Wo as one launch across the ranks) runs between PROCESSES here as it does between GPUs there
+            ctx.set_option("cu_parts", world)
+            ctx.exchange += f" (rehearsal: {world} ranks on one GPU, 1/{world} of the CUs each; fold_active {ctx.query('fold_active')})"
     return ctx
 
 
