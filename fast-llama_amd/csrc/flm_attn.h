@@ -917,17 +917,21 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_attn_o(const AttnArgs aa, con
 // then `target` in its line of flagq).  This hand-off is NOT all-to-all: a head needs its own hs rows of q, k and v only, i.e. the
 // lines of the <= 3 * ceil(hs / Rm + 1) workgroups that reduced them -- no wait for the slowest of 256, no 16 KB vector to gather.
 // The other workgroups go on as in k_attn_o (Wo prefetch, wait for the heads' lines, GEMV).
-template <int QT, int XR, bool PREQ, bool SPLIT = false>
+// TP: the launch spans the tensor-parallel ranks -- the QKV phase consumes the x1 exchange behind the previous layer's FFN2 (folded flag round, coherent loads; its
+// rows are this rank's heads, so the QKV -> heads hand-off stays inside the rank: flagq is local and cleared by k_embed); the heads -> Wo hand-off as in k_attn_o (AoTp).
+template <int QT, int XR, bool PREQ, bool SPLIT = false, bool TP = false>
 __global__ void __launch_bounds__(kGemvBlock, 4) k_qkv_attn_o(const GemvArgs aq, const AttnArgs aa, const GemvArgs a, const int gridq, const int n_heads, const int grido,
-                                                              unsigned* flagq, unsigned* flag, const unsigned target, int* err) {
+                                                              unsigned* flagq, unsigned* flag, const unsigned target, int* err, const AoTp tp) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     auto nostamp = [](int) {};
+    const unsigned htarget = TP ? *tp.base + tp.add : target;                   // the heads' lines (epoch values across ranks); flagq keeps `target`
+    if constexpr (TP) { if (aq.xf.world) xchg_fold(aq.xf); }
     if ((int)blockIdx.x < gridq) {
         float4 xq[1], nq[1];
-        gemv_preload<QT, PRO_RMSNORM_QUANT, 1>(aq, xq, nq);
+        gemv_preload<QT, PRO_RMSNORM_QUANT, 1, TP>(aq, xq, nq);
         GemvCtx<QT, EPI_ROPE_KV> gq;
         gq.init(aq, blockIdx.x, gridq, lds);
-        gemv_prologue<QT, PRO_RMSNORM_QUANT, 1>(aq, lds, xq, nq, [&](int part) { gq.issue(kAblate ? aq.ablate : 0, part); });
+        gemv_prologue<QT, PRO_RMSNORM_QUANT, 1, TP>(aq, lds, xq, nq, [&](int part) { gq.issue(kAblate ? aq.ablate : 0, part); });
         gq.run(aq, lds, nostamp);
         wait_stores_done();                                                     // every wave: its q / cache rows are where the heads will read them
         __syncthreads();                                                        // (and the LDS is free for the next phase)
@@ -958,21 +962,30 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_qkv_attn_o(const GemvArgs aq,
         attn_head_any<true, SPLIT>(aa, h, lds, *aa.pos_ptr + 1, aa.q, aa.out, blockIdx.x % G, G);
         wait_stores_done();
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(flag + blockIdx.x * kFlagStride, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) {
+            if constexpr (TP) {
+                __atomic_thread_fence(__ATOMIC_RELEASE);
+                for (int r = 0; r < tp.world; ++r) __hip_atomic_store(tp.peer_flags[r] + (tp.line0 + blockIdx.x) * kFlagStride, htarget, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else __hip_atomic_store(flag + blockIdx.x * kFlagStride, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         return;
     }
     if ((int)blockIdx.x >= n_heads + grido) return;
     GemvCtx<QT, EPI_RESIDUAL> g;
     g.init(a, blockIdx.x - n_heads, grido, lds);
     g.issue(kAblate ? a.ablate : 0);
-    if ((int)(threadIdx.x & ~63u) < n_heads) {                              // the waves that own at least one head's flag: lane i polls head i's line
-        const bool mine = (int)threadIdx.x < n_heads;
+    const int n_poll = TP ? tp.n_lines : n_heads;
+    if ((int)(threadIdx.x & ~63u) < n_poll) {                               // the waves that own at least one head's flag: lane i polls head i's line
+        const bool mine = (int)threadIdx.x < n_poll;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while (true) {
-            const unsigned f = mine ? __hip_atomic_load(flag + threadIdx.x * kFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
-            if (__all(f >= target)) break;
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            unsigned f = htarget;
+            if (mine) f = TP ? __hip_atomic_load(flag + threadIdx.x * kFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(flag + threadIdx.x * kFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((int)(f - htarget) >= 0)) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > (TP ? 2000000000ull : 2000000ull)) { __hip_atomic_store(err, TP ? 2 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            if constexpr (TP) __builtin_amdgcn_s_sleep(4);
         }
+        if constexpr (TP) __atomic_thread_fence(__ATOMIC_ACQUIRE);
     }
     __syncthreads();
     float4 xv[XR > 0 ? XR : 1], nv[XR > 0 ? XR : 1];

@@ -93,7 +93,8 @@ struct flm_ctx {
     int tp_fuse_ffn = 0;                               // option "tp_fuse_ffn": the same for FFN13 + FFN2 (k_ffn across ranks: one line per rank, raised by the rank's last workgroup); off by
                                                        // default: on one GPU under CU masks it is slower at 2-4 ranks and faster at 8 (profiles/r03_tp_onegpu.txt) -- a multi-GPU box has to decide
     unsigned long long* ffn_counter = nullptr;         // (its device counter)
-    int tp_fuse_attn = 1;                              // option "tp_fuse_attn": tensor parallel with folded exchanges: attention + Wo GEMV in one launch (k_attn_o across ranks)
+    int tp_fuse_attn = 2;                              // option "tp_fuse_attn": tensor parallel with folded exchanges: 1 = attention + Wo GEMV in one launch across the ranks (k_attn_o),
+                                                       // 2 (default) = with the QKV GEMV in front (k_qkv_attn_o: its rows are the rank's own heads), 0 = separate launches
     char* peer[8] = {nullptr}; bool peer_opened[8] = {false}; int p2p = 0;
     unsigned* xepoch = nullptr;                        // [4] exchanges done per kind (att, x1, hd, logits), device memory
     float* att_sc = nullptr;                           // [heads_local][max_seq] scores exchanged between the parts of a split head
@@ -508,17 +509,34 @@ int launch_qkv_attn_o(flm_ctx* c, hipStream_t st, int l, int G) {
     const int gridx = parts + P.grid > Pq.grid ? parts + P.grid : Pq.grid;
     const dim3 grid(gridx), block(kGemvBlock);
     const unsigned tgt = (unsigned)(l + 1);
+    AoTp tp{};
+    if (c->world > 1) {
+        // across ranks (see launch_attn_o); the QKV phase consumes the x1 exchange behind the previous layer's FFN2 (kind 3 of layer l - 1; layer 0 reads the embedding)
+        if (d.n_heads * G > 256) return FLM_ERR_UNSUPPORTED;
+        if (l > 0) set_fold(c, aq, l - 1, 3);
+        tp.world = c->world; tp.line0 = c->plan.head_begin * G; tp.n_lines = d.n_heads * G; tp.base = c->eng_base; tp.add = (unsigned)(4 * l + 1);
+        for (int r = 0; r < c->world; ++r) tp.peer_flags[r] = (unsigned*)(c->peer[r] + c->x_hflags_off);
+        flag = (unsigned*)(c->xbuf + c->x_hflags_off);
+        if (G > 1) {
+            if (rounds <= 1) hipLaunchKernelGGL((k_qkv_attn_o<QT, 1, false, true, true>), grid, block, lds, st, aq, aa, a, Pq.grid, parts, P.grid, flagq, flag, tgt, c->xwg_err, tp);
+            else             hipLaunchKernelGGL((k_qkv_attn_o<QT, 3, false, true, true>), grid, block, lds, st, aq, aa, a, Pq.grid, parts, P.grid, flagq, flag, tgt, c->xwg_err, tp);
+        }
+        else if (rounds <= 1) hipLaunchKernelGGL((k_qkv_attn_o<QT, 1, false, false, true>), grid, block, lds, st, aq, aa, a, Pq.grid, parts, P.grid, flagq, flag, tgt, c->xwg_err, tp);
+        else                  hipLaunchKernelGGL((k_qkv_attn_o<QT, 3, false, false, true>), grid, block, lds, st, aq, aa, a, Pq.grid, parts, P.grid, flagq, flag, tgt, c->xwg_err, tp);
+        HIPC(c, hipGetLastError());
+        return FLM_OK;
+    }
     if (c->hs % kGroup == 0 && G == 1) {
         aa.oq = c->att_q; aa.os = c->att_qs; aa.oqt = QT;
         a.xq = c->att_q; a.xs = c->att_qs;
-        hipLaunchKernelGGL((k_qkv_attn_o<QT, 0, true>), grid, block, lds, st, aq, aa, a, Pq.grid, parts, P.grid, flagq, flag, tgt, c->xwg_err);
+        hipLaunchKernelGGL((k_qkv_attn_o<QT, 0, true>), grid, block, lds, st, aq, aa, a, Pq.grid, parts, P.grid, flagq, flag, tgt, c->xwg_err, tp);
     }
     else if (G > 1) {
-        if (rounds <= 1) hipLaunchKernelGGL((k_qkv_attn_o<QT, 1, false, true>), grid, block, lds, st, aq, aa, a, Pq.grid, parts, P.grid, flagq, flag, tgt, c->xwg_err);
-        else             hipLaunchKernelGGL((k_qkv_attn_o<QT, 3, false, true>), grid, block, lds, st, aq, aa, a, Pq.grid, parts, P.grid, flagq, flag, tgt, c->xwg_err);
+        if (rounds <= 1) hipLaunchKernelGGL((k_qkv_attn_o<QT, 1, false, true>), grid, block, lds, st, aq, aa, a, Pq.grid, parts, P.grid, flagq, flag, tgt, c->xwg_err, tp);
+        else             hipLaunchKernelGGL((k_qkv_attn_o<QT, 3, false, true>), grid, block, lds, st, aq, aa, a, Pq.grid, parts, P.grid, flagq, flag, tgt, c->xwg_err, tp);
     }
-    else if (rounds <= 1) hipLaunchKernelGGL((k_qkv_attn_o<QT, 1, false>), grid, block, lds, st, aq, aa, a, Pq.grid, parts, P.grid, flagq, flag, tgt, c->xwg_err);
-    else                  hipLaunchKernelGGL((k_qkv_attn_o<QT, 3, false>), grid, block, lds, st, aq, aa, a, Pq.grid, parts, P.grid, flagq, flag, tgt, c->xwg_err);
+    else if (rounds <= 1) hipLaunchKernelGGL((k_qkv_attn_o<QT, 1, false>), grid, block, lds, st, aq, aa, a, Pq.grid, parts, P.grid, flagq, flag, tgt, c->xwg_err, tp);
+    else                  hipLaunchKernelGGL((k_qkv_attn_o<QT, 3, false>), grid, block, lds, st, aq, aa, a, Pq.grid, parts, P.grid, flagq, flag, tgt, c->xwg_err, tp);
     HIPC(c, hipGetLastError());
     return FLM_OK;
 }
@@ -682,7 +700,7 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
     auto folded = [&](GemvArgs a, int l, int kind) { if (fold && l >= 0) set_fold(c, a, l, kind); return a; };
     for (int l = 0; l < (eng >= 2 ? 0 : L); ++l) {
         bool fused = false;
-        if (!tp && c->fuse_attn_o && (c->fuse_qkv >= 2 || (c->fuse_qkv && G > 1)) && !c->timing && c->trace_class < 0) {   // QKV + attention + ATTN_O in one launch
+        if (((!tp && c->fuse_attn_o && (c->fuse_qkv >= 2 || (c->fuse_qkv && G > 1))) || (fold && c->tp_fuse_attn >= 2)) && !c->timing && c->trace_class < 0) {   // QKV + attention + ATTN_O in one launch (tensor parallel: "tp_fuse_attn" 2)
             r = qt == FLM_QT_INT8 ? launch_qkv_attn_o<QT_INT8>(c, st, l, G) : launch_qkv_attn_o<QT_INT16>(c, st, l, G);
             if (r == FLM_OK) fused = true; else if (r != FLM_ERR_UNSUPPORTED) return r;
         }
@@ -1610,6 +1628,7 @@ int flm_kernel_times(flm_ctx* c, int pos, int iters, float* avg_us, int32_t* cou
         case KC_ENG_LAYER: if (c->engine < 2 || !c->eng_built) return FLM_ERR_UNSUPPORTED;
                            return launch_engine(c, st, 1, 4 * l + 1, l + 1 < L ? 4 * l + 5 : 4 * L + 1);
         case KC_QKV_ATTN_WO: { const int G = attn_parts(c, pos + 1);
+                         if (c->world > 1) return FLM_ERR_UNSUPPORTED;
                          if (!c->fuse_attn_o || !(c->fuse_qkv >= 2 || (c->fuse_qkv && G > 1))) return FLM_ERR_UNSUPPORTED;
                          return qt == FLM_QT_INT8 ? launch_qkv_attn_o<QT_INT8>(c, st, l, G) : launch_qkv_attn_o<QT_INT16>(c, st, l, G); }
         default: return FLM_OK;

@@ -150,10 +150,10 @@ int  flm_debug_read(flm_ctx* ctx, int what, int layer, float* out, size_t n);
  * workgroup (default 1: eight), "attn_split" 0 = one workgroup per head at every context length (default 1: hs / 32 from 128 positions on; n >= 2: always n),
  * "use_p2p" 0 = tensor-parallel exchanges by RCCL all-gathers even though the peers are mapped (1: peer to peer again),
  * "fold_xchg" 0 = every peer-to-peer exchange's flag round as a launch of its own (k_xchg); default 1: inside the GEMV launch that consumes the vector
- *             (a sharded layer = 5 launches instead of 9; 4 with "tp_fuse_attn"),
- * "tp_fuse_attn" tensor parallel with folded exchanges: 1 (default) = attention and the Wo GEMV in ONE launch across the ranks (every rank's heads raise their flag lines
- *             in every rank's array; a sharded layer = 4 launches), 0 = two launches,
- * "tp_fuse_ffn" the same for FFN13 + FFN2 (one flag line per rank, raised by the rank's last workgroup; a sharded layer = 3 launches); default 0,
+ *             (a sharded layer = 5 launches instead of 9; 3 with "tp_fuse_attn" 2),
+ * "tp_fuse_attn" tensor parallel with folded exchanges: 1 = attention and the Wo GEMV in ONE launch across the ranks (every rank's heads raise their flag lines
+ *             in every rank's array; a sharded layer = 4 launches), 2 (default) = with the QKV GEMV in front (3 launches), 0 = separate launches,
+ * "tp_fuse_ffn" the same for FFN13 + FFN2 (one flag line per rank, raised by the rank's last workgroup; a sharded layer = 2 launches); default 0,
  * "cu_parts" n = confine the context's stream to 1/n of the device's CUs (part rank % n) and size its launches for them: several ranks on ONE GPU (tests),
  * "use_qk_mfma" 0 = prefill attention scores on VALU chains (default 1: v_mfma_f32_16x16x4_f32, the same bits),
  * "use_pv_mfma" 0 = prefill softmax x V on VALU chains (default 1: the weighted sum on v_mfma_f32_16x16x4_f32 too; needs use_qk_mfma),

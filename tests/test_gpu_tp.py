@@ -169,7 +169,8 @@ def test_rccl_exchange_branch_on_a_one_rank_communicator(gpu, qt):
 
 
 @pytest.mark.parametrize("shape,qt,layers,world,fuse", [("small", ff.QT_INT8, None, 2, 1), ("small", ff.QT_INT16, None, 4, 1), ("7B", ff.QT_INT8, 2, 2, 1), ("7B", ff.QT_INT8, 1, 4, 1),
-                                                        ("small", ff.QT_INT8, None, 2, 0), ("7B", ff.QT_INT8, 2, 2, 0)])
+                                                        ("small", ff.QT_INT8, None, 2, 0), ("7B", ff.QT_INT8, 2, 2, 0),
+                                                        ("small", ff.QT_INT8, None, 2, 2), ("small", ff.QT_INT16, None, 4, 2), ("7B", ff.QT_INT8, 2, 2, 2), ("7B", ff.QT_INT8, 1, 4, 2)])
 def test_folded_exchange_under_cu_masks(gpu, shape, qt, layers, world, fuse):
     """The latency path of the sharded token: every exchange's flag round inside the GEMV launch that consumes the vector ("fold_xchg", the default when
     every rank has CUs of its own) -- 5 launches per layer instead of 9.  On one GPU the ranks get disjoint CU masks ("cu_parts": 2 x 128 or 4 x 64 CUs,
@@ -177,7 +178,7 @@ def test_folded_exchange_under_cu_masks(gpu, shape, qt, layers, world, fuse):
     every rank = the oracle's bits; without the partition the contexts fall back to k_xchg launches by themselves (fold_active 0).
     fuse 1 (the default): attention and the Wo GEMV are ONE launch across the ranks ("tp_fuse_attn": every rank's heads raise their lines in every rank's
     array, the Wo workgroups of every rank wait for all heads of the model), and so are FFN13 and FFN2 ("tp_fuse_ffn": a rank's last workgroup raises the
-    rank's line everywhere) -- 3 launches per layer; fuse 0: five."""
+    rank's line everywhere) -- 3 launches per layer; fuse 0: five; fuse 2: the QKV GEMV joins the attention's launch too (its rows are the rank's own heads) -- 2 per layer."""
     cfg = synth.make_config(shape, qt)
     if layers:
         cfg.n_layers = layers
@@ -198,7 +199,7 @@ def test_folded_exchange_under_cu_masks(gpu, shape, qt, layers, world, fuse):
         assert c.query("fold_active") == 0          # ranks share the device and have no partition yet
         c.set_option("cu_parts", world)
         assert c.query("fold_active") == 1
-        c.set_option("tp_fuse_attn", fuse); c.set_option("tp_fuse_ffn", fuse)
+        c.set_option("tp_fuse_attn", fuse); c.set_option("tp_fuse_ffn", 1 if fuse else 0)
 
     def rank_main(c):
         lg = [c.forward(prompt, 0)]
@@ -216,7 +217,7 @@ def test_folded_exchange_under_cu_masks(gpu, shape, qt, layers, world, fuse):
         c.close()
 
 
-@pytest.mark.parametrize("fuse", [1, 0])
+@pytest.mark.parametrize("fuse", [1, 0, 2])
 def test_fused_attention_across_ranks_with_split_heads(gpu, fuse):
     """long contexts under tensor parallelism with folded exchanges: a rank's heads are spread over hs/32 workgroups each inside the attention + Wo launch that
     spans the ranks (a part raises its own line; the Wo workgroups wait for every part of every head of the model); CU-masked ranks on one GPU, oracle bits"""
@@ -237,7 +238,7 @@ def test_fused_attention_across_ranks_with_split_heads(gpu, fuse):
     for c in ctxs:
         c.p2p_import(blobs)
         c.set_option("cu_parts", world)
-        c.set_option("tp_fuse_attn", fuse); c.set_option("tp_fuse_ffn", fuse)
+        c.set_option("tp_fuse_attn", fuse); c.set_option("tp_fuse_ffn", 1 if fuse else 0)
 
     def rank_main(c):
         lg = [c.forward(prompt, 0)]

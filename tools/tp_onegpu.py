@@ -24,7 +24,8 @@ def run(fn):
     return out
 
 for fold, fa, fn, name in ((0, 0, 0, "k_xchg launches (9 per layer)"), (1, 0, 0, "folded exchanges (5 per layer)"), (1, 1, 0, "folded + attention and Wo in one launch (4 per layer)"),
-                           (1, 1, 1, "folded + attention and Wo, FFN13 and FFN2 fused (3 per layer)")):
+                           (1, 2, 0, "folded + QKV, attention and Wo in one launch (3 per layer)"), (1, 1, 1, "folded + attention and Wo, FFN13 and FFN2 fused (3 per layer)"),
+                           (1, 2, 1, "folded + QKV, attention, Wo | FFN13, FFN2 (2 per layer)")):
     for c in ctxs:
         c.set_option("fold_xchg", fold); c.set_option("tp_fuse_attn", fa); c.set_option("tp_fuse_ffn", fn); c.reset_kv()
     first = run(lambda c: c.forward_argmax(prompt, 0))[0]
