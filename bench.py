@@ -601,7 +601,12 @@ def open_tp_ctx(capi, cfg, rank, world, device, dist, torch):
             # the rehearsal on ONE GPU: give every rank a CU partition of its own, so that the latency path (flag rounds folded into the consuming launches,
             # attention + Wo as one launch across the ranks) runs between PROCESSES here as it does between GPUs there
             ctx.set_option("cu_parts", world)
-            ctx.exchange += f" (rehearsal: {world} ranks on one GPU, 1/{world} of the CUs each; fold_active {ctx.query('fold_active')})"
+            ctx.exchange += f" (rehearsal: {world} ranks on one GPU, 1/{world} of the CUs each)"
+        # which launch structure the sharded token runs (read back, not assumed): flag rounds folded into the consuming launches or k_xchg launches; QKV + attention + Wo /
+        # FFN13 + FFN2 as launches that span the ranks
+        fold, fa, fn = ctx.query("fold_active"), ctx.query("tp_fuse_attn"), ctx.query("tp_fuse_ffn")
+        per_layer = 9 if not fold else (5 - (2 if fa >= 2 else 1 if fa == 1 else 0) - (1 if fn else 0))
+        ctx.exchange += f"; {per_layer} launches per sharded layer (fold_active {fold}, tp_fuse_attn {fa}, tp_fuse_ffn {fn})"
     return ctx
 
 
