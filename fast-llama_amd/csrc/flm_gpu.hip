@@ -698,9 +698,12 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
     // (ranks sharing a device need a CU partition each -- "cu_parts" -- or a consumer that fills the device while it polls keeps its peers' producers out)
     const bool fold = tp && c->p2p && c->fold_xchg && c->world > 1 && c->cu_parts >= c->ranks_on_device;
     auto folded = [&](GemvArgs a, int l, int kind) { if (fold && l >= 0) set_fold(c, a, l, kind); return a; };
+    // launches that span the ranks wait across workgroups of one launch too: only where the census found one workgroup per CU resident (a CU partition
+    // made for the tests is sized for it: launches are cut to the partition)
+    const bool span = fold && (c->resident || c->cu_parts > 1);
     for (int l = 0; l < (eng >= 2 ? 0 : L); ++l) {
         bool fused = false;
-        if (((!tp && c->fuse_attn_o && (c->fuse_qkv >= 2 || (c->fuse_qkv && G > 1))) || (fold && c->tp_fuse_attn >= 2)) && !c->timing && c->trace_class < 0) {   // QKV + attention + ATTN_O in one launch (tensor parallel: "tp_fuse_attn" 2)
+        if (((!tp && c->fuse_attn_o && (c->fuse_qkv >= 2 || (c->fuse_qkv && G > 1))) || (span && c->tp_fuse_attn >= 2)) && !c->timing && c->trace_class < 0) {   // QKV + attention + ATTN_O in one launch (tensor parallel: "tp_fuse_attn" 2)
             r = qt == FLM_QT_INT8 ? launch_qkv_attn_o<QT_INT8>(c, st, l, G) : launch_qkv_attn_o<QT_INT16>(c, st, l, G);
             if (r == FLM_OK) fused = true; else if (r != FLM_ERR_UNSUPPORTED) return r;
         }
@@ -708,7 +711,7 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
             Tick t(c, st, KC_QKV);
             r = launch_gemv<PRO_RMSNORM_QUANT, EPI_ROPE_KV>(c, st, qt, folded(traced(args_qkv(c, l), KC_QKV, l), l - 1, 3), wgs, coh); if (r) return r;
         }
-        if (!fused && ((!tp && c->fuse_attn_o) || (fold && c->tp_fuse_attn)) && !c->timing && (c->trace_class < 0 || c->trace_class == 101)) {   // attention + ATTN_O in one launch (tensor parallel: across the ranks)
+        if (!fused && ((!tp && c->fuse_attn_o) || (span && c->tp_fuse_attn)) && !c->timing && (c->trace_class < 0 || c->trace_class == 101)) {   // attention + ATTN_O in one launch (tensor parallel: across the ranks)
             r = qt == FLM_QT_INT8 ? launch_attn_o<QT_INT8>(c, st, l, G) : launch_attn_o<QT_INT16>(c, st, l, G);
             if (r == FLM_OK) fused = true; else if (r != FLM_ERR_UNSUPPORTED) return r;
         }
@@ -727,7 +730,7 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
         }
         if (tp && !fold) { r = exchange(c, st, XK_X1, c->x1, c->x1 + c->drow_begin, c->drow_count); if (r) return r; }
         if (eng == 1) { r = launch_engine(c, st, 0, 4 * l + 2, 4 * l + 4); if (r) return r; continue; }   // FFN13 + FFN2 on the engine
-        if (((!tp && c->fuse_ffn) || (fold && c->tp_fuse_ffn)) && !c->timing && c->trace_class < 0) {   // FFN13 + FFN2 in one launch (tensor parallel: across the ranks)
+        if (((!tp && c->fuse_ffn) || (span && c->tp_fuse_ffn)) && !c->timing && c->trace_class < 0) {   // FFN13 + FFN2 in one launch (tensor parallel: across the ranks)
             r = qt == FLM_QT_INT8 ? launch_ffn<QT_INT8>(c, st, l) : launch_ffn<QT_INT16>(c, st, l);
             if (r == FLM_OK) {
                 if (tp && l == L - 1 && !with_cls) { r = exchange(c, st, XK_X1, c->x1, c->x1 + c->drow_begin, c->drow_count); if (r) return r; }   // (see below)
