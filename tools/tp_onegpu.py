@@ -23,9 +23,11 @@ def run(fn):
     [t.start() for t in th]; [t.join() for t in th]
     return out
 
+only = os.environ.get("FLM_TP_ONLY")      # e.g. "1,2,1": that structure alone (for a profile)
 for fold, fa, fn, name in ((0, 0, 0, "k_xchg launches (9 per layer)"), (1, 0, 0, "folded exchanges (5 per layer)"), (1, 1, 0, "folded + attention and Wo in one launch (4 per layer)"),
                            (1, 2, 0, "folded + QKV, attention and Wo in one launch (3 per layer)"), (1, 1, 1, "folded + attention and Wo, FFN13 and FFN2 fused (3 per layer)"),
                            (1, 2, 1, "folded + QKV, attention, Wo | FFN13, FFN2 (2 per layer)")):
+    if only and only != f"{fold},{fa},{fn}": continue
     for c in ctxs:
         c.set_option("fold_xchg", fold); c.set_option("tp_fuse_attn", fa); c.set_option("tp_fuse_ffn", fn); c.reset_kv()
     first = run(lambda c: c.forward_argmax(prompt, 0))[0]
@@ -36,4 +38,6 @@ for fold, fa, fn, name in ((0, 0, 0, "k_xchg launches (9 per layer)"), (1, 0, 0,
         ids = run(lambda c: c.decode_greedy(first, len(prompt), ntok))
         best = min(best, time.perf_counter() - t0)
     assert all(list(i) == list(ids[0]) for i in ids)
-    print(f"tp{world} on one GPU ({256 // world} CUs per rank), {L} layers of 7B width: {name:66s} {best / ntok * 1e6:8.1f} us per token  ids {list(ids[0][:4])}")
+    dev_ms = run(lambda c: c.decode_timed(first, len(prompt), ntok))          # HIP events on each rank's own stream
+    name += f" [device: {max(dev_ms) / ntok * 1e3:.1f} us]"
+    print(f"tp{world} on one GPU ({256 // world} CUs per rank), {L} layers of 7B width: {name:90s} {best / ntok * 1e6:8.1f} us per token  ids {list(ids[0][:4])}")
