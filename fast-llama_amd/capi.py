@@ -171,7 +171,7 @@ class Ctx:
         return int(v.value)
 
     def debug_read(self, what, layer, n):
-        names = {"x1": 0, "q": 1, "att_out": 2, "hd": 3, "kcache": 4, "vcache": 5, "logits": 6, "trace": 7, "trace_abs": 8, "eng_trace": 9}
+        names = {"x1": 0, "q": 1, "att_out": 2, "hd": 3, "kcache": 4, "vcache": 5, "logits": 6, "trace": 7, "trace_abs": 8, "eng_trace": 9, "back_trace": 10}
         out = np.empty(n, dtype=np.float32)
         _check(lib().flm_debug_read(self._h, names[what], int(layer), _p(out), C.c_size_t(n)), self._h)
         return out

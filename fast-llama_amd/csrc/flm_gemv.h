@@ -162,8 +162,13 @@ constexpr int kChainHead = 4;          // lanes whose elements run in order befo
 // p: one chain's strip [64 lanes][B + 4] floats, zero-padded past the data.  Returns the chain value in every lane.
 // BVR > 0: B = 4 * BVR is a compile-time constant and the lane's elements stay in registers (B <= 16: every model width up to
 // 4096); BVR == 0: any B, elements re-read from LDS in every pass.
+#ifdef FLM_TRACE_PRO_RT
+#define FLM_CHAIN_STAMP(k) if (tr && lane == 0) tr[k] = __builtin_amdgcn_s_memtime();
+#else
+#define FLM_CHAIN_STAMP(k)
+#endif
 template <int BVR>
-__device__ __forceinline__ float sq_chain_spec_t(const float* p, const int bshift, int* rounds_out) {
+__device__ __forceinline__ float sq_chain_spec_t(const float* p, const int bshift, int* rounds_out, unsigned long long* tr = nullptr) {
     const int lane = threadIdx.x & 63, B = BVR ? 4 * BVR : (1 << bshift), BV = B >> 2, LS = B + 4;
     const float4* pl = reinterpret_cast<const float4*>(p + lane * LS);
     float4 xr[BVR ? BVR : 1];
@@ -172,6 +177,7 @@ __device__ __forceinline__ float sq_chain_spec_t(const float* p, const int bshif
         for (int q = 0; q < BVR; ++q) xr[q] = pl[q];
     }
     auto elem = [&](int q) -> float4 { if constexpr (BVR > 0) return xr[q]; else return pl[q]; };
+    FLM_CHAIN_STAMP(0)
 #define FLM_SQ4(l, v) l = __fmaf_rn(v.x, v.x, l); l = __fmaf_rn(v.y, v.y, l); l = __fmaf_rn(v.z, v.z, l); l = __fmaf_rn(v.w, v.w, l);
     // 1. approximate per-lane sums, all-zero lanes (pass-through whatever l is)
     float s = 0.f, m = 0.f;
@@ -179,14 +185,30 @@ __device__ __forceinline__ float sq_chain_spec_t(const float* p, const int bshif
     for (int q = 0; q < BV; ++q) { const float4 v = elem(q); FLM_SQ4(s, v) m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))); }
     const bool allzero = (m == 0.f) && (s == 0.f);              // (s: a NaN among zeros must not count as zero)
     const float P = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(wave_scan_incl(s)), 0x138 /* wave_shr:1 */, 0xF, 0xF, true));
+    FLM_CHAIN_STAMP(1)
     // the head: lanes [0, kChainHead) in order (every lane computes it: broadcast reads)
     float hv = 0.f;
+    if constexpr (BVR > 0) {
+        // the elements are in the registers of lanes 0..3: v_readlane turns each into a scalar operand of the (wave-uniform) chain -- no LDS trip
 #pragma unroll
-    for (int L = 0; L < kChainHead; ++L) {
-        const float4* r = reinterpret_cast<const float4*>(p + L * LS);
+        for (int L = 0; L < kChainHead; ++L) {
 #pragma unroll
-        for (int q = 0; q < BV; ++q) { const float4 v = r[q]; FLM_SQ4(hv, v) }
+            for (int q = 0; q < BVR; ++q) {
+                float4 v;
+                v.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xr[q].x), L)); v.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xr[q].y), L));
+                v.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xr[q].z), L)); v.w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xr[q].w), L));
+                FLM_SQ4(hv, v)
+            }
+        }
+    } else {
+#pragma unroll
+        for (int L = 0; L < kChainHead; ++L) {
+            const float4* r = reinterpret_cast<const float4*>(p + L * LS);
+#pragma unroll
+            for (int q = 0; q < BV; ++q) { const float4 v = r[q]; FLM_SQ4(hv, v) }
+        }
     }
+    FLM_CHAIN_STAMP(2)
     // 2. increments against the expected binade
     const unsigned eb = __float_as_uint(P) & 0x7f800000u;
     bool valid = lane >= kChainHead && eb >= (27u << 23) && eb <= (250u << 23);      // P finite and normal, room for u/2 and 2A
@@ -202,6 +224,7 @@ __device__ __forceinline__ float sq_chain_spec_t(const float* p, const int bshif
     }
     if (!(T < INFINITY)) valid = false;                         // (inf / NaN never enters the prefix)
     if (!valid) T = 0.f;
+    FLM_CHAIN_STAMP(3)
     // 3. fp64 exactness of the prefix
     const unsigned long long live = __ballot(valid && !allzero);
     bool plain = false;
@@ -216,12 +239,14 @@ __device__ __forceinline__ float sq_chain_spec_t(const float* p, const int bshif
         return l;
     }
     const double Td = (double)T, Si = wave_scan_incl_f64(Td), S = __dsub_rn(Si, Td);
+    FLM_CHAIN_STAMP(4)
     // 4. rounds
     int base = kChainHead, rounds = 0;
     double bv = (double)hv, Sb = readlane_f64(S, kChainHead);
     float res;
     for (;;) {
         ++rounds;
+        if (rounds <= 9) { FLM_CHAIN_STAMP(4 + rounds) }
         const double d = __dadd_rn(bv, __dsub_rn(S, Sb));
         const float st = (float)d;
         const bool exact = (double)st == d;
@@ -239,14 +264,16 @@ __device__ __forceinline__ float sq_chain_spec_t(const float* p, const int bshif
         base = f + 1; bv = (double)res; Sb = readlane_f64(S, f + 1);
     }
 #undef FLM_SQ4
+    FLM_CHAIN_STAMP(14)
+    if (tr && lane == 0) tr[15] = (unsigned long long)rounds;
     if (rounds_out) *rounds_out = rounds;
     return res;
 }
 // (BVR > 0 keeps the lane's elements in registers; inside k_gemv that costs 16+ VGPRs next to the two prefetched weight sets and the
 //  kernel SPILLS -- scratch accesses then queue behind the weight loads in the memory pipeline and the chain took 10 us instead of 2.5:
 //  measured.  The prologue therefore runs the LDS-fed form; the register form is for callers with registers to spare.)
-__device__ __forceinline__ float sq_chain_spec(const float* p, const int bshift, int* rounds_out = nullptr) {
-    return sq_chain_spec_t<0>(p, bshift, rounds_out);
+__device__ __forceinline__ float sq_chain_spec(const float* p, const int bshift, int* rounds_out = nullptr, unsigned long long* tr = nullptr) {
+    return sq_chain_spec_t<0>(p, bshift, rounds_out, tr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -281,13 +308,18 @@ __device__ __forceinline__ void gemv_preload(const GemvArgs& a, float4 (&xv)[XR 
     }
 }
 
-#ifdef FLM_TRACE_PRO
+#ifdef FLM_TRACE_PRO_RT      // tools/trace_back.py: the prologue's stamps on the 100 MHz clock (one clock for all XCDs), wave 0 / wave 15
+#define FLM_PRO_STAMP(k) if (kAblate && a.trace && (threadIdx.x == 0 || threadIdx.x == 960)) a.trace[blockIdx.x * 16 + (threadIdx.x ? 8 : 0) + (k)] = __builtin_amdgcn_s_memrealtime();
+#elif defined(FLM_TRACE_PRO)
 #define FLM_PRO_STAMP(k) if (kAblate && a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime();
 #else
 #define FLM_PRO_STAMP(k)
 #endif
 // COH: the activation was written by other workgroups of the SAME kernel (k_attn_o) or by peer GPUs (tensor parallel) -> coherent loads
-template <int QT, int PRO, int XR, bool COH = false, class AfterStage>
+// LATE (rmsnorm prologue): the four chain waves request their weights BEHIND the prologue (at the start of run()) instead of in front of their chain.  The barrier behind the chain waits for every
+// wave's issue, and a wave's issue waits for room in the CU's memory pipeline (~30 KB/us): with all 16 waves requesting two register sets the last request is
+// accepted ~4.5 us after the first, long after the chain is done.  Only worth it where the run has something to start on while those sets are in flight (k_attn_ffn's stash).
+template <int QT, int PRO, int XR, bool COH = false, bool LATE = false, class AfterStage>
 __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, float4 (&xv)[XR > 0 ? XR : 1], float4 (&wv)[XR > 0 ? XR : 1], AfterStage&& after_stage) {
     using T = QTraits<QT>;
     const int n = a.n;
@@ -317,6 +349,9 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
         const int rounds = (n + kGemvBlock * 4 - 1) / (kGemvBlock * 4);
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         float r = 1.0f;
+#ifdef FLM_TRACE_PRO_RT
+        FLM_PRO_STAMP(0)
+#endif
         auto ldx = [&](int e) -> float4 {                   // activation elements e..e+3 (rounds past the preloaded registers)
             if constexpr (COH) {
                 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -329,7 +364,7 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
             // no staging here: the hook (the weight prefetch) runs as soon as this thread's activation registers have landed
             if constexpr (XR > 0) { asm volatile("" :: "v"(xv[XR - 1].w)); }
             FLM_PRO_STAMP(3)
-            after_stage(0);
+            if constexpr (!LATE) after_stage(0);              // (LATE: nothing is requested in front of the quantizer; run() requests what was not)
             FLM_PRO_STAMP(4)
         }
         if constexpr (PRO == PRO_RMSNORM_QUANT) {
@@ -351,20 +386,48 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
                 const int e = tid * 4 + i * kGemvBlock * 4;
                 stage(i, e < n ? ldx(e) : z4);
             }
+#ifdef FLM_TRACE_PRO_RT
+            FLM_PRO_STAMP(1)
+#endif
             __syncthreads();
             FLM_PRO_STAMP(3)
             // the hook issues the weight prefetch.  The chain waves (0..3, one strided lane each) go first (the others give
             // them ~128 cycles): their loads enter an empty memory pipeline at once and they are free for the chains;
             // queued behind the other waves' loads they would stall for ~1 us before (or after) the chain.
-            if (tid >= 4 * kWave) __builtin_amdgcn_s_sleep(2);
-            after_stage(0);
+            if constexpr (!LATE) {
+                if (tid >= 4 * kWave) __builtin_amdgcn_s_sleep(2);
+                after_stage(0);
 #ifdef FLM_TRACE_PRO2
-            FLM_PRO_STAMP(1)
+                FLM_PRO_STAMP(1)
 #endif
-            if (tid < 4 * kWave && !(kAblate && (a.ablate & 2))) {
-                const float l = sq_chain_spec(scratch + (tid >> 6) * CS, bs);
-                if ((tid & 63) == 0) red[8 + (tid >> 6)] = l;
+                if (tid < 4 * kWave && !(kAblate && (a.ablate & 2))) {
+                    const float l = sq_chain_spec(scratch + (tid >> 6) * CS, bs);
+                    if ((tid & 63) == 0) red[8 + (tid >> 6)] = l;
+                }
+            } else {
+                // A wave-uniform branch (scalar condition): the chain's code never runs in a wave whose register sets have been requested, so the
+                // allocator may give it the sets' registers -- the lane's elements stay in registers (BVR) and the head's reads run far ahead.
+                // (the chain waves' own sets are requested at the start of run() -- GemvCtx::primedA/B --, behind the barriers that wait for the chain)
+                const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+                if (wv >= 4) after_stage(0);
+                else if (!(kAblate && (a.ablate & 2))) {
+#ifdef FLM_TRACE_PRO_RT
+                    unsigned long long* tr = (kAblate && a.trace && tid < 64) ? a.trace + 2 * 4096 + blockIdx.x * 16 : nullptr;
+#else
+                    unsigned long long* tr = nullptr;
+#endif
+                    const float* cp = scratch + wv * CS;
+                    float l;
+                    if (bs == 4) l = sq_chain_spec_t<4>(cp, bs, nullptr, tr);
+                    else if (bs == 3) l = sq_chain_spec_t<2>(cp, bs, nullptr, tr);
+                    else if (bs == 2) l = sq_chain_spec_t<1>(cp, bs, nullptr, tr);
+                    else l = sq_chain_spec_t<0>(cp, bs, nullptr, tr);
+                    if ((tid & 63) == 0) red[8 + wv] = l;
+                }
             }
+#ifdef FLM_TRACE_PRO_RT
+            FLM_PRO_STAMP(2)
+#endif
             FLM_PRO_STAMP(4)
             __syncthreads();
             const float ss = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, red[8]), red[9]), red[10]), red[11]);
@@ -412,7 +475,13 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
         if constexpr (PRO == PRO_QUANT) {
             FLM_PRO_STAMP(5)
         }
+#ifdef FLM_TRACE_PRO_RT
+        FLM_PRO_STAMP(6)
+#endif
         __syncthreads();
+#ifdef FLM_TRACE_PRO_RT
+        FLM_PRO_STAMP(7)
+#endif
         if (a.dbg_xq && blockIdx.x == 0) {
             const int nb4 = n * T::kEsz / 4;
             for (int c = tid; c < nb4; c += kGemvBlock) reinterpret_cast<uint32_t*>(a.dbg_xq)[c] = reinterpret_cast<uint32_t*>(xq)[c];
@@ -449,7 +518,7 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
 typedef unsigned int u32;
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
-template <int QT, int EPI>
+template <int QT, int EPI, bool STASH = false>
 struct GemvCtx {
     using T = QTraits<QT>;
     static constexpr u32 LPGS = (T::kEPC == 16) ? 2 : 3;                      // log2(lanes per quant group): 4 | 8 lanes
@@ -478,6 +547,12 @@ struct GemvCtx {
     u32 lane_j, lane_s2off, lane_sx2off, lane_poff;                            // per lane, scale role: block of the step, its scale, the activation scale, strip entry (s)
     bool leader;                                                               // per lane
     u32 dW, dS, dT, dummy_st, wg, nwg, nbuf;
+    // LDS stash (STASH; round 4): steps [2 x 16, 2 x 16 + st_n) of the workgroup were fetched with LDS-DMA (buffer_load ... lds: no registers, no VALU)
+    // into slots of kSlotBytes at LDS byte st_base while the CU's memory pipeline had nothing else to do (another phase's hand-off, the attention).
+    // They are numbered like every other step and handed out by the same counter; load_step takes such a step from its slot instead of from memory.
+    // The caller guarantees that every wave has waited for its own DMA (s_waitcnt vmcnt(0)) before the workgroup barrier in front of run().
+    u32 st_base, st_n;
+    static constexpr u32 kSlotBytes = H * 1024 + 256;                          // H weight blocks + the step's scale dwords
     __amdgpu_buffer_rsrc_t rW, rS;
     Set setA, setB;
     bool stored;                                                               // this wave wrote results to global memory
@@ -486,8 +561,9 @@ struct GemvCtx {
     static __device__ __forceinline__ u32 udiv(u32 x, u32 d, u32 inv) { return d > 1 ? __umulhi(x, inv) : x; }
 
     // ctr_slot: which of the two step counters in LDS this GEMV uses
-    __device__ __forceinline__ void init(const GemvArgs& a, u32 wg_, u32 nwg_, char* lds, u32 ctr_slot = 0) {
-        n = a.n; wg = wg_; nwg = nwg_;
+    // write_ctr = false: a temporary context that only issues stash loads for a later phase (the LDS counter belongs to the running phase)
+    __device__ __forceinline__ void init(const GemvArgs& a, u32 wg_, u32 nwg_, char* lds, u32 ctr_slot = 0, u32 st_base_ = 0, u32 st_n_ = 0, bool write_ctr = true) {
+        n = a.n; wg = wg_; nwg = nwg_; st_base = st_base_; st_n = st_n_;
         lane = threadIdx.x & 63;
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         rowbytes = n * T::kEsz; sn = n / kGroup;
@@ -531,9 +607,12 @@ struct GemvCtx {
         rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, (int)(NM * TRm * rowbytes), kRsrcFlags);
         rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.sW), 0, (int)(NM * TRm * sn * 4), kRsrcFlags);
         stored = false; primedA = primedB = false;
-        // the first two steps of every wave are fixed (wave, wave + 16): they are requested before any barrier
-        if (threadIdx.x == 0) *reinterpret_cast<u32*>(lds + ctr_off) = 2 * kWavesPerBlock;
+        // the first two steps of every wave are fixed (wave, wave + 16): they are requested before any barrier (the stash's steps are the next numbers)
+        if (write_ctr && threadIdx.x == 0) *reinterpret_cast<u32*>(lds + ctr_off) = 2 * kWavesPerBlock;
     }
+
+    // (a context that was initialised with write_ctr = false while another GEMV was using the LDS)
+    __device__ __forceinline__ void reset_ctr(char* lds) const { if (threadIdx.x == 0) *reinterpret_cast<u32*>(lds + ctr_off) = 2 * kWavesPerBlock; }
 
     // step number -> the set's bookkeeping and the scalar offsets of its first block
     __device__ __forceinline__ void decode(u32 s, Set& S, u32& wo, u32& so) const {
@@ -548,9 +627,19 @@ struct GemvCtx {
         S.itl = itl; S.xo = cc; S.nlive = RBP - rb0 < (u32)H ? RBP - rb0 : (u32)H;
         S.st = rb0 * RB * gstride + g0 * ES + (second ? 4u : 0u);
     }
-    __device__ __forceinline__ void load_step(Set& S, u32 s, int ablate) const {
+    __device__ __forceinline__ void load_step(Set& S, u32 s, int ablate, const char* lds = nullptr) const {
         u32 wo, so;
         decode(s, S, wo, so);
+        if constexpr (STASH) {
+            const u32 si = s - 2 * kWavesPerBlock;
+            if (si < st_n) {                                                   // (wave-uniform) the step lies in the stash: lane for lane what the loads below deliver
+                const char* p = lds + st_base + si * kSlotBytes;
+#pragma unroll
+                for (int j = 0; j < H; ++j) S.w[j] = *reinterpret_cast<const v4i*>(p + j * 1024 + lane * 16);
+                S.sw = *reinterpret_cast<const float*>(p + H * 1024 + lane * 4);
+                return;
+            }
+        }
         u32 nl = S.nlive;
         if (kAblate && (ablate & 4)) { nl = 0; so = kOOB; }
 #pragma unroll
@@ -567,6 +656,29 @@ struct GemvCtx {
     __device__ __forceinline__ void issue(int ablate, int part = 0) {
         if (part != 2) { load_step(setA, wave, ablate); primedA = true; }
         if (part != 1) { load_step(setB, wave + kWavesPerBlock, ablate); primedB = true; }
+    }
+
+    // this wave's stash slots: the step's H weight blocks and its scale dwords go straight to LDS, lane for lane what load_step puts into registers
+    // (LDS address = M0 + 16 (4) x lane; blocks past the step's live ones / steps past the end get the out-of-range offset: no memory access)
+    __device__ __forceinline__ void stash_issue(const char* lds) const {
+        const u32 lds0 = (u32)(uintptr_t)(__attribute__((address_space(3))) const char*)lds;
+        for (u32 i = wave; i < st_n; i += kWavesPerBlock) {
+            Set S; u32 wo, so;
+            decode(2 * kWavesPerBlock + i, S, wo, so);
+            const u32 dst = __builtin_amdgcn_readfirstlane(lds0 + st_base + i * kSlotBytes);
+#pragma unroll
+            for (int j = 0; j < H; ++j) {
+                const u32 woj = (u32)j < S.nlive ? lane_woff + wo + j * dW : kOOB;
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen nt lds" :: "v"(woj), "s"(rW), "s"(dst + j * 1024) : "memory");
+            }
+            const u32 svo = lane_j < S.nlive ? lane_s2off + so : kOOB;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %0, %1, 0 offen nt lds" :: "v"(svo), "s"(rS), "s"(dst + H * 1024) : "memory");
+        }
+    }
+    // whichever of the two fixed sets this wave has not requested yet
+    __device__ __forceinline__ void issue_missing(int ablate) {
+        if (!primedA) { load_step(setA, wave, ablate); primedA = true; }
+        if (!primedB) { load_step(setB, wave + kWavesPerBlock, ablate); primedB = true; }
     }
 
     // reduce one step: the group dots of its H blocks (registers), then the leaders park them; the scale-role lanes park s = sW * sX
@@ -718,8 +830,8 @@ struct GemvCtx {
         u32 it = 0;                                                            // pass of this workgroup this wave is in
         bool tr3 = false;
         // a wave's step numbers only grow, so when a set belongs to a later pass every earlier pass is complete for this wave
-        auto do_set = [&](Set& S) -> bool {
-            while (it < S.itl) {
+        auto finish_upto = [&](u32 limit) {
+            while (it < limit) {
                 char* strips = lds + off_scr + (nbuf > 1 ? (it & 1) * buf_bytes : 0u);   // double buffered across passes
 #ifdef FLM_TRACE_WAVES
                 if (kAblate && a.trace && it == 0 && lane == 0 && wave % 3 == 0) a.trace[blockIdx.x * 8 + 1 + wave / 3] = __builtin_amdgcn_s_memtime();
@@ -732,11 +844,14 @@ struct GemvCtx {
 #endif
                 ++it;
             }
+        };
+        auto do_set = [&](Set& S) -> bool {
+            finish_upto(S.itl);
             if (S.itl >= np_wg) return false;                                  // no work left (every later number is past the end too)
             reduce_step(S, lds, lds + off_scr + (nbuf > 1 ? (S.itl & 1) * buf_bytes : 0u), a.ablate);
             u32 s = 0;
             if (lane == 0) s = atomicAdd(ctr, 1u);
-            load_step(S, __builtin_amdgcn_readfirstlane(s), a.ablate);         // refill this set: a full cycle ahead
+            load_step(S, __builtin_amdgcn_readfirstlane(s), a.ablate, lds);    // refill this set: a full cycle ahead
 #if !defined(FLM_TRACE_PRO) && !defined(FLM_TRACE_BAR)
             if (!tr3) { tr3 = true; stamp(3); }
 #endif

@@ -33,7 +33,7 @@ struct LayerW {
     unsigned got = 0;     // bitmask of uploaded kinds
 };
 
-enum KClass { KC_EMBED = 0, KC_QKV, KC_ATTN, KC_ATTN_O, KC_FFN13, KC_FFN2, KC_CLS, KC_ARGMAX, KC_ALLREDUCE, KC_ATTN_WO /* k_attn_o: attention + Wo */, KC_FFN /* k_ffn: FFN13 + FFN2 */, KC_QKV_ATTN_WO /* k_qkv_attn_o */, KC_ENG_FFN /* k_engine: FFN13 + FFN2 */, KC_ENG_LAYER /* k_engine: Wo + FFN13 + FFN2 + the next layer's QKV (or the classifier) */ };
+enum KClass { KC_EMBED = 0, KC_QKV, KC_ATTN, KC_ATTN_O, KC_FFN13, KC_FFN2, KC_CLS, KC_ARGMAX, KC_ALLREDUCE, KC_ATTN_WO /* k_attn_o: attention + Wo */, KC_FFN /* k_ffn: FFN13 + FFN2 */, KC_QKV_ATTN_WO /* k_qkv_attn_o */, KC_ENG_FFN /* k_engine: FFN13 + FFN2 */, KC_ENG_LAYER /* k_engine: Wo + FFN13 + FFN2 + the next layer's QKV (or the classifier) */, KC_ATTN_FFN /* k_attn_ffn: attention + Wo + FFN13 + FFN2 */ };
 
 struct TimedLaunch { int kclass; hipEvent_t e0, e1; };
 // owners that release on every exit path (the error macros return from the middle of a function)
@@ -83,6 +83,10 @@ struct flm_ctx {
     int fuse_attn_o = 1;                               // option "fuse_attn_o": attention + Wo GEMV in one launch (k_attn_o; single GPU)
     bool st_ready = false;                             // the layer matrices' group-major scale copies (QMat::st) are up to date
     int fuse_ffn = 1;                                  // option "fuse_ffn": FFN13 + FFN2 in one launch (k_ffn; single GPU)
+    int fuse_back = 1;                                 // option "fuse_back": attention + Wo + FFN13 + FFN2 in one launch with [W1; W3] stashed in LDS under the attention (k_attn_ffn; single GPU,
+                                                       // head size a multiple of 64, one workgroup per head)
+    int fuse_layer = 1;                                // option "fuse_layer": ... with the QKV GEMV in front: the whole layer in one launch
+    int back_nst13 = -1, back_nst13_head = -1, back_nst2 = 0, back_pre13 = 16;   // options "back_*": k_attn_ffn's stash slots (-1: as many as the LDS holds) and early register set (flm_layer.h)
     int fuse_qkv = 1;                                  // option "fuse_qkv": QKV in front of attention + Wo in the same launch (k_qkv_attn_o; single GPU): 0 never,
                                                        // 1 when a head is spread over several workgroups (long contexts: where it pays), 2 always
     unsigned* flag_lines = nullptr; int* xwg_err = nullptr;   // k_attn_o: one 64-byte flag line per head; "a cross-workgroup wait timed out"
@@ -299,7 +303,7 @@ bool model_complete(const flm_ctx* c) {
 // context's life and FLM_RETRY tells the caller (inside this library) to run the call again on one kernel per phase.
 constexpr int FLM_RETRY = 1;
 int xwg_check(flm_ctx* c) {
-    if (!c->fuse_attn_o && !c->fuse_ffn && c->attn_split == 0 && !c->p2p && !c->engine) return FLM_OK;
+    if (!c->fuse_attn_o && !c->fuse_ffn && !c->fuse_back && c->attn_split == 0 && !c->p2p && !c->engine) return FLM_OK;
     // (on the context's own stream: a copy on the legacy stream synchronises with every blocking stream of the process -- and fails
     //  outright while another context's thread is capturing its token graph; seen once in ~10 runs of the threaded tensor-parallel tests)
     int e = 0;
@@ -319,7 +323,7 @@ int xwg_check(flm_ctx* c) {
         c->attn_split = 0;
         return fail(c, FLM_ERR_COMM, "tensor parallel: a cross-workgroup wait on this rank timed out; the group's results are invalid and the context group cannot be used any more");
     }
-    c->fuse_attn_o = 0; c->fuse_ffn = 0; c->fuse_qkv = 0; c->attn_split = 0; c->engine = 0; c->fell_back = 1;
+    c->fuse_attn_o = 0; c->fuse_ffn = 0; c->fuse_qkv = 0; c->fuse_back = 0; c->attn_split = 0; c->engine = 0; c->fell_back = 1;
     for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
     c->graphs.clear();
     return FLM_RETRY;
@@ -573,6 +577,71 @@ int launch_ffn(flm_ctx* c, hipStream_t st, int l) {
 }
 
 
+// attention + Wo + FFN13 + FFN2 of layer l in one launch (k_attn_ffn, flm_layer.h); returns FLM_ERR_UNSUPPORTED when the shape does not allow it
+template <int QT>
+int launch_attn_ffn(flm_ctx* c, hipStream_t st, int l, bool with_qkv) {
+    const auto& d = c->d;
+    constexpr int esz = QTraits<QT>::kEsz;
+    const int all = c->cu_count < 256 ? c->cu_count : 256, parts = c->heads_local, wgs_o = all - parts;
+    if (c->world != 1 || c->hs % kGroup != 0 || wgs_o < 1 || parts > 256) return FLM_ERR_UNSUPPORTED;
+    GemvArgs aq = args_qkv(c, l), ao = args_o(c, l), a13 = args_ffn13(c, l), a2 = args_ffn2(c, l);
+    GemvPlan Pq{}, Po, P13, P2;
+    int r = plan_gemv<QT, PRO_QUANT, EPI_RESIDUAL>(c, ao, wgs_o, Po); if (r) return r;
+    if (with_qkv) {
+        r = plan_gemv<QT, PRO_RMSNORM_QUANT, EPI_ROPE_KV>(c, aq, all, Pq); if (r) return r;
+        if ((aq.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4) > 1) return FLM_ERR_UNSUPPORTED;
+    }
+    r = plan_gemv<QT, PRO_RMSNORM_QUANT, EPI_SWIGLU>(c, a13, all, P13); if (r) return r;
+    r = plan_gemv<QT, PRO_QUANT, EPI_RESIDUAL>(c, a2, all, P2); if (r) return r;
+    const int r13 = (a13.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4), r2 = (a2.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4);
+    if (r13 > 1 || r2 > 3) return FLM_ERR_UNSUPPORTED;
+    // a workgroup with a single pass needs one strip buffer: the LDS above the phases' own layouts is the stash
+    auto one_pass = [&](GemvArgs& a, GemvPlan& P, bool two, int rows_per_item = 1) {
+        const int rows = a.items * rows_per_item, npass = (rows + P.Rm - 1) / P.Rm;
+        if (npass <= P.grid) { a.nbuf = 1; P.nbuf = 1; P.lds = (size_t)gemv_lds_layout(a.n, esz, true, P.Rm, 64 >> P.cb_shift, two, 1).total; }
+    };
+    one_pass(ao, Po, false); one_pass(a13, P13, true); one_pass(a2, P2, false);
+    size_t own = Po.lds; if (P13.lds > own) own = P13.lds; if (P2.lds > own) own = P2.lds;
+    if (with_qkv) { one_pass(aq, Pq, false, 2); if (Pq.lds > kLdsMax) return FLM_ERR_UNSUPPORTED; }     // (the QKV phase is over before the first stash request: its layout may overlap the slots)
+    own = (own + 255) & ~(size_t)255;
+    const size_t lds_attn = attn_lds_bytes(d.max_seq_len, c->hs, false);
+    if (own > kLdsMax || lds_attn > kLdsMax) return FLM_ERR_UNSUPPORTED;
+    const int slot = kStepBlk * 1024 + 256, fit = (int)((kLdsMax - own) / slot);
+    auto slots = [&](int want) { int n = want < 0 ? fit : want; if (n > fit) n = fit; if (n > 32) n = 32; return n < 0 ? 0 : n; };
+    AttnArgs aa = args_attn(c, l, 1);
+    aa.oq = c->att_q; aa.os = c->att_qs; aa.oqt = QT;
+    ao.xq = c->att_q; ao.xs = c->att_qs;
+    BackArgs p{};
+    p.n_heads = parts; p.grido = Po.grid; p.grid13 = P13.grid; p.grid2 = P2.grid;
+    p.flag_h = c->flag_lines; p.flag_hd = c->flag_lines + 512 * 16; p.flag_x = c->flag_lines + 1024 * 16;
+    p.gridq = with_qkv ? Pq.grid : 0; p.flag_q = c->flag_lines + 768 * 16;
+    p.target = (unsigned)(l + 1); p.err = c->xwg_err;
+    p.st_base = (unsigned)own; p.nst13 = slots(c->back_nst13); p.nst13_head = slots(c->back_nst13_head); p.nst2 = slots(c->back_nst2); p.pre13 = c->back_pre13 < 0 ? 0 : c->back_pre13 > 16 ? 16 : c->back_pre13;
+    if (kAblate && c->trace_class == 102 && l == 0) { p.trace = c->trace; a13.trace = c->trace + 256 * 16; a2.trace = c->trace + 2 * 256 * 16; }   // tools/trace_back.py
+    int grid = parts + Po.grid; if (P13.grid > grid) grid = P13.grid; if (P2.grid > grid) grid = P2.grid; if (with_qkv && Pq.grid > grid) grid = Pq.grid;
+    if (grid > all) return FLM_ERR_UNSUPPORTED;
+    {   // the stash takes the rest of the CU's 160 KiB: raise the kernels' dynamic-LDS limit, once per device
+        static std::mutex mu; static bool done[64] = {false};
+        std::lock_guard<std::mutex> lk(mu);
+        if (c->device >= 0 && c->device < 64 && !done[c->device]) {
+            const void* fns[] = {(const void*)&k_attn_ffn<QT_INT8, 1, false>, (const void*)&k_attn_ffn<QT_INT8, 3, false>, (const void*)&k_attn_ffn<QT_INT16, 1, false>, (const void*)&k_attn_ffn<QT_INT16, 3, false>,
+                                 (const void*)&k_attn_ffn<QT_INT8, 1, true>, (const void*)&k_attn_ffn<QT_INT8, 3, true>, (const void*)&k_attn_ffn<QT_INT16, 1, true>, (const void*)&k_attn_ffn<QT_INT16, 3, true>};
+            for (const void* f : fns) HIPC(c, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
+            done[c->device] = true;
+        }
+    }
+    const dim3 g3(grid), b3(kGemvBlock);
+    if (with_qkv) {
+        if (r2 <= 1) hipLaunchKernelGGL((k_attn_ffn<QT, 1, true>), g3, b3, kLdsMax, st, aq, aa, ao, a13, a2, p);
+        else         hipLaunchKernelGGL((k_attn_ffn<QT, 3, true>), g3, b3, kLdsMax, st, aq, aa, ao, a13, a2, p);
+    }
+    else if (r2 <= 1) hipLaunchKernelGGL((k_attn_ffn<QT, 1, false>), g3, b3, kLdsMax, st, aq, aa, ao, a13, a2, p);
+    else              hipLaunchKernelGGL((k_attn_ffn<QT, 3, false>), g3, b3, kLdsMax, st, aq, aa, ao, a13, a2, p);
+    HIPC(c, hipGetLastError());
+    return FLM_OK;
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // The weight-streaming engine (flm_engine.h): device programs and launches.  Program index of a phase: 4 l + {0 QKV, 1 Wo, 2 FFN13, 3 FFN2},
 // the classifier at 4 L.  Three variants (what differs is where a phase's activation comes from and whether its results leave as granules):
@@ -703,6 +772,11 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
     const bool span = fold && (c->resident || c->cu_parts > 1);
     for (int l = 0; l < (eng >= 2 ? 0 : L); ++l) {
         bool fused = false;
+        const bool back_ok = !tp && c->fuse_back && c->fuse_attn_o && c->fuse_ffn && G == 1 && eng == 0 && !c->timing && (c->trace_class < 0 || c->trace_class == 102);
+        if (back_ok && c->fuse_layer) {   // the whole layer in one launch
+            r = qt == FLM_QT_INT8 ? launch_attn_ffn<QT_INT8>(c, st, l, true) : launch_attn_ffn<QT_INT16>(c, st, l, true);
+            if (r == FLM_OK) continue; else if (r != FLM_ERR_UNSUPPORTED) return r;
+        }
         if (((!tp && c->fuse_attn_o && (c->fuse_qkv >= 2 || (c->fuse_qkv && G > 1))) || (span && c->tp_fuse_attn >= 2)) && !c->timing && c->trace_class < 0) {   // QKV + attention + ATTN_O in one launch (tensor parallel: "tp_fuse_attn" 2)
             r = qt == FLM_QT_INT8 ? launch_qkv_attn_o<QT_INT8>(c, st, l, G) : launch_qkv_attn_o<QT_INT16>(c, st, l, G);
             if (r == FLM_OK) fused = true; else if (r != FLM_ERR_UNSUPPORTED) return r;
@@ -710,6 +784,10 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
         if (!fused) {   // QKV task + RoPE + KV append (transformer.cpp:132-135, execute_qkv :386-395, execute_attn :431-439): this rank's heads
             Tick t(c, st, KC_QKV);
             r = launch_gemv<PRO_RMSNORM_QUANT, EPI_ROPE_KV>(c, st, qt, folded(traced(args_qkv(c, l), KC_QKV, l), l - 1, 3), wgs, coh); if (r) return r;
+        }
+        if (!fused && back_ok) {   // attention + ATTN_O + FFN13 + FFN2 in one launch
+            r = qt == FLM_QT_INT8 ? launch_attn_ffn<QT_INT8>(c, st, l, false) : launch_attn_ffn<QT_INT16>(c, st, l, false);
+            if (r == FLM_OK) continue; else if (r != FLM_ERR_UNSUPPORTED) return r;
         }
         if (!fused && ((!tp && c->fuse_attn_o) || (span && c->tp_fuse_attn)) && !c->timing && (c->trace_class < 0 || c->trace_class == 101)) {   // attention + ATTN_O in one launch (tensor parallel: across the ranks)
             r = qt == FLM_QT_INT8 ? launch_attn_o<QT_INT8>(c, st, l, G) : launch_attn_o<QT_INT16>(c, st, l, G);
@@ -1161,8 +1239,8 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
         HIPB(hipMalloc((void**)&c->xepoch, 64)); HIPB(hipMemsetAsync(c->xepoch, 0, 64, c->stream));
         HIPB(hipMalloc((void**)&c->ffn_counter, 64)); HIPB(hipMemsetAsync(c->ffn_counter, 0, 64, c->stream));
     }
-    HIPB(hipMalloc((void**)&c->flag_lines, 1024 * 64)); HIPB(hipMalloc((void**)&c->xwg_err, 64));   // lines 0..255: k_attn_o's heads, 256..511: split heads' scores, 512..767: k_ffn, 768..1023: k_qkv_attn_o's QKV rows
-    HIPB(hipMemsetAsync(c->flag_lines, 0, 1024 * 64, c->stream)); HIPB(hipMemsetAsync(c->xwg_err, 0, 64, c->stream));
+    HIPB(hipMalloc((void**)&c->flag_lines, 1536 * 64)); HIPB(hipMalloc((void**)&c->xwg_err, 64));   // lines 0..255: k_attn_o's heads, 256..511: split heads' scores, 512..767: k_ffn, 768..1023: k_qkv_attn_o's QKV rows, 1024..1279: k_attn_ffn's x1 rows (k_embed clears all 1536)
+    HIPB(hipMemsetAsync(c->flag_lines, 0, 1536 * 64, c->stream)); HIPB(hipMemsetAsync(c->xwg_err, 0, 64, c->stream));
     {   // the engine's granule buffers (8 bytes per value: {value, tag}) and the token's epoch base
         const size_t nq = (size_t)(d.hidden_dim / kGroup) * (16 * c->esz + 1);
         HIPB(hipMalloc((void**)&c->gx1, (size_t)d.dim * 8)); HIPB(hipMalloc((void**)&c->ghd, (size_t)d.hidden_dim * 16)); HIPB(hipMalloc((void**)&c->ghq, nq * 8));
@@ -1198,7 +1276,7 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
         int ok = 0;
         if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&ok, okp, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess) c->resident = ok ? 1 : 0;
         else { (void)hipGetLastError(); c->resident = 0; }
-        if (!c->resident) { c->fuse_attn_o = 0; c->fuse_ffn = 0; c->fuse_qkv = 0; c->attn_split = 0; c->engine = 0; }
+        if (!c->resident) { c->fuse_attn_o = 0; c->fuse_ffn = 0; c->fuse_qkv = 0; c->fuse_back = 0; c->attn_split = 0; c->engine = 0; }
     }
 #undef HIPB
     *out = c;
@@ -1283,7 +1361,7 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     std::string k(key);
     if (c->world > 1 && c->p2p && (k == "use_mfma" || k == "use_pv_mfma" || k == "use_prefill_mq" || k == "use_qk_mfma"))
         return fail(c, FLM_ERR_STATE, "set_option: which prompt kernels a tensor-parallel group runs is agreed at flm_p2p_import; set this option on every rank before importing (\"use_prefill\" may be switched later, on every rank alike)");
-    if (!c->resident && value != 0 && (k == "fuse_attn_o" || k == "fuse_ffn" || k == "fuse_qkv" || k == "attn_split" || k == "engine"))
+    if (!c->resident && value != 0 && (k == "fuse_attn_o" || k == "fuse_ffn" || k == "fuse_qkv" || k == "fuse_back" || k == "attn_split" || k == "engine"))
         return fail(c, FLM_ERR_UNSUPPORTED, "set_option: this device does not keep one workgroup per CU resident (census at flm_ctx_create); the fused launches stay off");
     if (k == "wg_per_cu") { c->wg_per_cu = value > 0 ? value : 1; }
     else if (k == "use_graph") c->use_graph = value;
@@ -1293,6 +1371,12 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (k == "fuse_attn_o") c->fuse_attn_o = value;
     else if (k == "fuse_ffn") c->fuse_ffn = value;
     else if (k == "fuse_qkv") c->fuse_qkv = value;
+    else if (k == "fuse_back") c->fuse_back = value;
+    else if (k == "fuse_layer") c->fuse_layer = value;
+    else if (k == "back_nst13") c->back_nst13 = value;
+    else if (k == "back_nst13_head") c->back_nst13_head = value;
+    else if (k == "back_nst2") c->back_nst2 = value;
+    else if (k == "back_pre13") c->back_pre13 = value;
     else if (k == "use_prefill_mq") c->use_prefill_mq = value;
     else if (k == "attn_split") c->attn_split = value;
     else if (k == "engine") { if (value < 0 || value > 2) return fail(c, FLM_ERR_INVALID, "engine: 0 (off), 1 (FFN13 + FFN2 per launch) or 2 (Wo + FFN13 + FFN2 + next QKV per launch)"); c->engine = value; }
@@ -1314,7 +1398,7 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
         }
         HIPC(c, hipStreamDestroy(c->stream));
         c->stream = ns; c->cu_parts = value; c->cu_count = c->cu_total / value;
-        if (value > 1) { c->fuse_attn_o = 0; c->fuse_ffn = 0; c->fuse_qkv = 0; c->engine = 0; }
+        if (value > 1) { c->fuse_attn_o = 0; c->fuse_ffn = 0; c->fuse_qkv = 0; c->fuse_back = 0; c->engine = 0; }
         c->eng_built = false;
     }
     else if (k == "eng_trace") {   // value = first phase of the engine launch whose in-kernel stamps are recorded (0 off); read them with flm_debug_read(9)
@@ -1346,9 +1430,9 @@ int flm_query(flm_ctx* c, const char* key, int* value) {
     const std::string k(key);
     const struct { const char* k; int v; } tab[] = {
         {"wg_per_cu", c->wg_per_cu}, {"use_graph", c->use_graph}, {"use_prefill", c->use_prefill}, {"use_mfma", c->use_mfma}, {"use_pv_mfma", c->use_pv_mfma},
-        {"fuse_attn_o", c->fuse_attn_o}, {"fuse_ffn", c->fuse_ffn}, {"fuse_qkv", c->fuse_qkv}, {"use_prefill_mq", c->use_prefill_mq}, {"attn_split", c->attn_split},
+        {"fuse_attn_o", c->fuse_attn_o}, {"fuse_ffn", c->fuse_ffn}, {"fuse_qkv", c->fuse_qkv}, {"fuse_back", c->fuse_back}, {"fuse_layer", c->fuse_layer}, {"back_nst13", c->back_nst13}, {"back_nst13_head", c->back_nst13_head}, {"back_nst2", c->back_nst2}, {"back_pre13", c->back_pre13}, {"use_prefill_mq", c->use_prefill_mq}, {"attn_split", c->attn_split},
         {"use_qk_mfma", c->use_qk_mfma}, {"use_p2p", c->p2p}, {"engine", c->engine}, {"fold_xchg", c->fold_xchg}, {"tp_fuse_attn", c->tp_fuse_attn}, {"tp_fuse_ffn", c->tp_fuse_ffn}, {"cu_parts", c->cu_parts}, {"fold_active", (c->world > 1 && c->p2p && c->fold_xchg && c->cu_parts >= c->ranks_on_device) ? 1 : 0}, {"resident", c->resident}, {"fallback", c->fell_back},
-        {"token_path", (c->world == 1 ? ((c->fuse_attn_o ? 1 : 0) | (c->fuse_ffn && c->engine != 1 && c->engine != 2 ? 2 : 0) | (c->fuse_attn_o && c->fuse_qkv == 1 ? 4 : 0) | (c->fuse_attn_o && c->fuse_qkv >= 2 ? 8 : 0) | ((c->engine & 3) << 4)) : 0) | (c->attn_split ? 64 : 0)},
+        {"token_path", (c->world == 1 ? ((c->fuse_attn_o ? 1 : 0) | (c->fuse_ffn && c->engine != 1 && c->engine != 2 ? 2 : 0) | (c->fuse_attn_o && c->fuse_qkv == 1 ? 4 : 0) | (c->fuse_attn_o && c->fuse_qkv >= 2 ? 8 : 0) | ((c->engine & 3) << 4) | (c->fuse_back && c->fuse_attn_o && c->fuse_ffn && !c->engine ? 128 : 0)) : 0) | (c->attn_split ? 64 : 0)},
     };
     for (const auto& t : tab) if (k == t.k) { *value = t.v; return FLM_OK; }
     return fail(c, FLM_ERR_INVALID, "query: unknown key");
@@ -1473,6 +1557,18 @@ int flm_debug_read(flm_ctx* c, int what, int layer, float* out, size_t n) {
             out[i] = k == 1 ? (t[i] ? (float)((double)(long long)(t[i] - t0) * 0.01) : -1.f) : k == 2 ? (float)((double)t[i] * 0.01) : k == 3 ? (float)t[i]
                    : ((t[i] & 0xffff) ? (float)((double)(t[i] >> 16) * 10.0 / (double)(t[i] & 0xffff)) : -1.f);   // ns per piece inside the dot loops
         }
+        return FLM_OK; }
+    case 10: {  // tools/trace_back.py (FLM_ABLATE builds): k_attn_ffn's stamps [workgroup][16] on the 100 MHz clock (one clock for all XCDs) as microseconds after the earliest one; -1 = not stamped
+        if (!c->trace || n > 131072) return fail(c, FLM_ERR_INVALID, "debug_read: no trace");
+        HIPC(c, hipStreamSynchronize(c->stream));
+        std::vector<unsigned long long> t(n);
+        HIPC(c, hipMemcpy(t.data(), c->trace, n * 8, hipMemcpyDeviceToHost));
+        // words [0, 3 * 4096): 100 MHz stamps; from 3 * 4096 on: rows of 16 shader-clock stamps (the rmsnorm chain's stages), given as ticks after the row's first, [15] a raw count
+        const size_t nrt = n < 3 * 4096 ? n : 3 * 4096;
+        unsigned long long t0 = ~0ull;
+        for (size_t i = 0; i < nrt; ++i) if (t[i] && t[i] < t0) t0 = t[i];
+        for (size_t i = 0; i < nrt; ++i) out[i] = t[i] ? (float)((double)(long long)(t[i] - t0) * 0.01) : -1.f;
+        for (size_t i = nrt; i < n; ++i) { const size_t b = i - i % 16; out[i] = i % 16 == 15 ? (float)t[i] : ((t[i] && t[b]) ? (float)(long long)(t[i] - t[b]) : -1.f); }
         return FLM_OK; }
     default: return fail(c, FLM_ERR_INVALID, "debug_read: unknown buffer");
     }

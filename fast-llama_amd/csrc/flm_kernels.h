@@ -36,6 +36,7 @@
 #include "flm_math.h"
 #include "flm_gemv.h"
 #include "flm_attn.h"
+#include "flm_layer.h"
 #include "flm_engine.h"
 #include "flm_prefill.h"
 #include "flm_misc.h"

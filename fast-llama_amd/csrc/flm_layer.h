@@ -1,0 +1,199 @@
+// flm_layer.h -- the back half of a decoder layer as ONE launch (single GPU): attention, Wo + residual, FFN13 + SwiGLU, FFN2 + residual
+// (transformer.cpp:136-152: ATTN, ATTN_O, rmsnorm, quantize, FFN13, quantize, FFN2), with the weight stream running through the attention.
+// Part of flm_kernels.h (hand-written gfx950 / CDNA4 kernels of the fast-llama per-token hot path); include that header.
+#pragma once
+#include "flm_math.h"
+#include "flm_gemv.h"
+#include "flm_attn.h"
+// (bit-exactness hygiene: see flm_math.h -- no implicit FMA contraction in any of these headers)
+#pragma clang fp contract(off)
+
+namespace flm {
+
+// ------------------------------------------------------------------------------------------
+// k_attn_ffn = k_attn_o + k_ffn in one launch, phases and arithmetic verbatim (k_gemv's GemvCtx, attn_head), plus what only one launch can do:
+//   * while the 32 head workgroups run their ~6 us of dependent fp32 chains, the other 224 CUs have nothing in flight once their share of Wo (79 KiB,
+//     registers) has landed, and 160 KiB of LDS each that nothing uses: they fetch the first steps of THEIR rows of [W1; W3] into that LDS with LDS-DMA
+//     (GemvCtx::stash_issue: no registers, no VALU) -- ~100 KiB per CU, a quarter of FFN13's bytes, off the streaming phase's clock;
+//   * the x1 hand-off (Wo's rows -> every workgroup's rmsnorm) is a flag round instead of a kernel boundary + launch ramp;
+//   * the head workgroups fetch their stash when their head is done (they wait for x1 anyway), every workgroup fetches a stash of W2 behind its own
+//     rows of hd (it waits for the slowest workgroup's hd anyway).
+// A stash is bounded (<= 25 steps of 4.25 KiB): what is requested in front of a flag poll delays that poll by the time the CU's in-order memory
+// pipeline needs for it (~30 KB/us), which the median workgroup spends waiting for the slowest producer in any case.
+// Hand-offs as in k_attn_o / k_ffn: write-through stores, s_waitcnt vmcnt(0), one 64-byte flag line per producer workgroup (value layer + 1, cleared by
+// k_embed), lane i polls line i, coherent loads of the vector.  All workgroups resident (grid <= CUs: the census of flm_ctx_create); a poll that never
+// succeeds gives up after ~20 ms and raises *err (the host re-runs the call on one kernel per phase).
+// ------------------------------------------------------------------------------------------
+struct BackArgs {
+    int n_heads;                // head workgroups [0, n_heads); Wo workgroups [n_heads, n_heads + grido)
+    int grido, grid13, grid2;
+    int gridq;                  // QKV = true: the workgroups [0, gridq) of the QKV GEMV in front
+    unsigned* flag_q;           // ... and their lines
+    unsigned* flag_h;           // heads' lines
+    unsigned* flag_x;           // Wo workgroups' lines (x1)
+    unsigned* flag_hd;          // FFN13 workgroups' lines (hd)
+    unsigned target; int* err;
+    unsigned st_base;           // LDS byte offset of the stash slots (above every phase's own layout)
+    int nst13;                  // stash slots of [W1; W3] a Wo workgroup fills under the attention
+    int nst13_head;             // ... a head workgroup fills when its head is done
+    int nst2;                   // stash slots of W2 every workgroup fills behind its rows of hd
+    int pre13;                  // the first pre13 waves of a workgroup request their first register set of [W1; W3] before the x1 flag round (16: all, as k_ffn does for W2)
+    unsigned long long* trace;  // FLM_ABLATE builds: [grid][16] s_memrealtime stamps (100 MHz, one clock for all XCDs; tools/trace_back.py)
+};
+
+// lane i (of the first 256 threads) polls line i of `n` lines until all have reached `target`
+__device__ __forceinline__ void poll_lines(const unsigned* flag, int n, unsigned target, int* err) {
+    if ((int)(threadIdx.x & ~63u) < n) {
+        const bool mine = (int)threadIdx.x < n;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (true) {
+            unsigned f = target;
+            if (mine) f = __hip_atomic_load(flag + threadIdx.x * kFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((int)(f - target) >= 0)) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        }
+    }
+}
+
+#ifndef FLM_BACK_LATE
+#define FLM_BACK_LATE 1
+#endif
+#ifndef FLM_BACK_LATE2
+#define FLM_BACK_LATE2 0          // FFN2's prologue: its second register set requested BEHIND the quantizer: measured slower (the phase is bound by the stream behind hd's arrival)
+#endif
+#ifndef FLM_LAYER_LATEQ
+#define FLM_LAYER_LATEQ 1
+#endif
+// QKV = true: the whole layer -- the QKV GEMV (k_gemv<RMSNORM_QUANT, ROPE_KV> verbatim, every workgroup its rows of [Wq; Wk; Wv]) in front, as in k_qkv_attn_o: a head waits for
+// the lines of the <= 3 * ceil(hs / Rm + 1) workgroups that reduced its rows of q, k and v and reads them with coherent loads; the other workgroups go straight
+// from their last QKV row to the Wo / stash requests, so the memory pipeline has work across what used to be a kernel boundary and a launch ramp.
+template <int QT, int XR2, bool QKV = false>
+__global__ void __launch_bounds__(kGemvBlock, 4) k_attn_ffn(const GemvArgs aq, const AttnArgs aa, const GemvArgs ao, const GemvArgs a13, const GemvArgs a2, const BackArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    auto nostamp = [](int) {};
+    auto stamp = [&](int k) { if (kAblate && p.trace && threadIdx.x == 0) p.trace[blockIdx.x * 16 + k] = __builtin_amdgcn_s_memrealtime(); };
+    stamp(0);
+    const unsigned target = p.target;
+    unsigned nst13 = 0;
+    if constexpr (QKV) {
+        if ((int)blockIdx.x < p.gridq) {
+            float4 xq[1], nq[1];
+            gemv_preload<QT, PRO_RMSNORM_QUANT, 1>(aq, xq, nq);
+            GemvCtx<QT, EPI_ROPE_KV> gq;
+            gq.init(aq, blockIdx.x, p.gridq, lds);
+            gemv_prologue<QT, PRO_RMSNORM_QUANT, 1, false, FLM_LAYER_LATEQ != 0>(aq, lds, xq, nq, [&](int part) { gq.issue(kAblate ? aq.ablate : 0, part); });
+            stamp(12);
+            gq.run(aq, lds, nostamp);
+            stamp(13);
+            wait_stores_done();                                                 // every wave: its q / cache rows are where the heads will read them
+            __syncthreads();                                                    // (and the LDS is free for the next phase)
+            if (threadIdx.x == 0) __hip_atomic_store(p.flag_q + blockIdx.x * kFlagStride, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            stamp(14);
+        }
+    }
+    if ((int)blockIdx.x < p.n_heads) {
+        if constexpr (QKV) {
+            if (threadIdx.x < 256) {
+                // lane i: does workgroup i reduce a row of this head's q, k or v?  (pass p = rows [p Rm, (p + 1) Rm) of [Wq; Wk; Wv], workgroup p mod gridq)
+                bool need = false;
+                if ((int)threadIdx.x < p.gridq) {
+                    const unsigned Rm = aq.rows_per_pass, hs = aa.hs, nq = p.gridq, h = blockIdx.x;
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        const unsigned r0 = (m == 0 ? 0u : m == 1 ? (unsigned)aq.dim : (unsigned)(aq.dim + aq.kv_dim)) + h * hs;
+                        const unsigned pa = r0 / Rm, pb = (r0 + hs - 1) / Rm;
+                        need |= (threadIdx.x + nq - pa % nq) % nq <= pb - pa;
+                    }
+                }
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                while (true) {
+                    const unsigned f = need ? __hip_atomic_load(p.flag_q + threadIdx.x * kFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
+                    if (__all((int)(f - target) >= 0)) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) { __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                }
+            }
+            __syncthreads();
+        }
+        attn_head_any<QKV, false>(aa, blockIdx.x, lds, *aa.pos_ptr + 1, aa.q, aa.out);
+        stamp(1);
+        wait_stores_done();                                                     // every wave: its part of the head's output is where the others will read it
+        __syncthreads();                                                        // (and the LDS is free)
+        if (threadIdx.x == 0) __hip_atomic_store(p.flag_h + blockIdx.x * kFlagStride, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stamp(2);
+        if (p.nst13_head > 0 && (int)blockIdx.x < p.grid13) {
+            nst13 = (unsigned)p.nst13_head;
+            GemvCtx<QT, EPI_SWIGLU, true> t;
+            t.init(a13, blockIdx.x, p.grid13, lds, 0, p.st_base, nst13, false);
+            t.stash_issue(lds);
+        }
+    } else if ((int)blockIdx.x >= p.n_heads + p.grido) {                        // (Wo's passes do not reach this workgroup: the stash only)
+        if (p.nst13 > 0 && (int)blockIdx.x < p.grid13) {
+            nst13 = (unsigned)p.nst13;
+            GemvCtx<QT, EPI_SWIGLU, true> t;
+            t.init(a13, blockIdx.x, p.grid13, lds, 0, p.st_base, nst13, false);
+            t.stash_issue(lds);
+        }
+    } else {
+        GemvCtx<QT, EPI_RESIDUAL> g;
+        g.init(ao, blockIdx.x - p.n_heads, p.grido, lds);
+        g.issue(kAblate ? ao.ablate : 0);
+        if (p.nst13 > 0 && (int)blockIdx.x < p.grid13) {
+            nst13 = (unsigned)p.nst13;
+            GemvCtx<QT, EPI_SWIGLU, true> t;
+            t.init(a13, blockIdx.x, p.grid13, lds, 0, p.st_base, nst13, false);
+            t.stash_issue(lds);
+        }
+        stamp(1);
+        poll_lines(p.flag_h, p.n_heads, target, p.err);
+        __syncthreads();
+        stamp(2);
+        float4 xv[1], nv[1];
+        gemv_prologue<QT, PRO_NONE, 0, true>(ao, lds, xv, nv, [](int) {});   // the heads' output arrives quantized (PREQ)
+        g.run(ao, lds, nostamp);
+        stamp(3);
+        wait_stores_done();                                                     // every wave: its rows of x1 are where the others will read them
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(p.flag_x + (blockIdx.x - p.n_heads) * kFlagStride, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stamp(4);
+    }
+    // ---- FFN13: k_gemv<RMSNORM_QUANT, SWIGLU> behind the x1 flag round (x1 through coherent loads)
+    if ((int)blockIdx.x < p.grid13) {
+        GemvCtx<QT, EPI_SWIGLU, true> g;
+        g.init(a13, blockIdx.x, p.grid13, lds, 0, p.st_base, nst13);
+        if ((int)g.wave < p.pre13) g.issue(kAblate ? a13.ablate : 0, 1);       // the first pre13 waves: their first register set in front of the x1 flag round
+        poll_lines(p.flag_x, p.grido, target, p.err);
+        wait_stores_done();                                                     // every wave: the stash slots it requested have landed
+        __syncthreads();
+        stamp(5);
+        float4 xv[1], nv[1];
+        gemv_preload<QT, PRO_RMSNORM_QUANT, 1, true>(a13, xv, nv);
+        gemv_prologue<QT, PRO_RMSNORM_QUANT, 1, true, FLM_BACK_LATE != 0>(a13, lds, xv, nv, [&](int) { g.issue_missing(kAblate ? a13.ablate : 0); });
+        stamp(6);
+        g.run(a13, lds, nostamp);
+        stamp(7);
+    } else {
+        poll_lines(p.flag_x, p.grido, target, p.err);                           // (keeps the order x1 -> hd for a workgroup without rows)
+    }
+    wait_stores_done();                                                         // every wave: its rows of hd are where the others will read them
+    __syncthreads();                                                            // (and the LDS is free for the last phase)
+    if (threadIdx.x == 0) __hip_atomic_store(p.flag_hd + blockIdx.x * kFlagStride, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    stamp(8);
+    if ((int)blockIdx.x >= p.grid2) return;
+    // ---- FFN2: k_gemv<QUANT, RESIDUAL> behind the hd flag round
+    GemvCtx<QT, EPI_RESIDUAL, true> g2;
+    g2.init(a2, blockIdx.x, p.grid2, lds, 0, p.st_base, (unsigned)p.nst2);
+    g2.issue(kAblate ? a2.ablate : 0, 1);                                       // ONE set now, the second when hd has arrived (k_ffn)
+    g2.stash_issue(lds);
+    poll_lines(p.flag_hd, (int)gridDim.x, target, p.err);
+    wait_stores_done();                                                         // every wave: the stash slots it requested have landed
+    __syncthreads();
+    stamp(9);
+    float4 xv2[XR2 > 0 ? XR2 : 1], nv2[XR2 > 0 ? XR2 : 1];
+    gemv_preload<QT, PRO_QUANT, XR2, true>(a2, xv2, nv2);
+    gemv_prologue<QT, PRO_QUANT, XR2, true, FLM_BACK_LATE2 != 0>(a2, lds, xv2, nv2, [&](int) { g2.issue(kAblate ? a2.ablate : 0, 2); });
+    stamp(10);
+    g2.run(a2, lds, nostamp);
+    stamp(11);
+}
+
+} // namespace flm

@@ -16,9 +16,9 @@ __global__ void k_embed(float* x, const void* emb, const float* emb_s, int emb_q
     const int tok = *tok_ptr;
     // a new token: the engine launches' granule tags (flm_engine.h) move on; wrap long before a tag could become 0
     if (eng_base && blockIdx.x == 0 && threadIdx.x == 0) { const unsigned b = *eng_base; *eng_base = b >= 0xFFF00000u ? 0u : b + 1024u; }
-    if (bar && blockIdx.x == 0) {   // the flag lines (1024, 64 B apart) the workgroups of the token's fused launches wait on
+    if (bar && blockIdx.x == 0) {   // the flag lines (kFlagLines = 1536, 64 B apart) the workgroups of the token's fused launches wait on
 #pragma unroll
-        for (int k = 0; k < 4; ++k) bar[(threadIdx.x + k * blockDim.x) * 16] = 0;
+        for (int k = 0; k < 6; ++k) bar[(threadIdx.x + k * blockDim.x) * 16] = 0;
     }
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < dim; e += gridDim.x * blockDim.x) {
         float v;
@@ -129,8 +129,14 @@ __global__ void __launch_bounds__(256) k_op_square_sum(float* out, const float* 
     __syncthreads();
     int its = 0;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    const float l = sq_chain_spec(sm + (threadIdx.x >> 6) * CS, bs, &its);
+    float l = sq_chain_spec(sm + (threadIdx.x >> 6) * CS, bs, &its);
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    {   // the register-fed form (k_attn_ffn's prologue: elements in registers, the head through v_readlane) must give the same bits
+        const float* cp = sm + (threadIdx.x >> 6) * CS;
+        float lr = l;
+        if (bs == 4) lr = sq_chain_spec_t<4>(cp, bs, nullptr); else if (bs == 3) lr = sq_chain_spec_t<2>(cp, bs, nullptr); else if (bs == 2) lr = sq_chain_spec_t<1>(cp, bs, nullptr);
+        if (__float_as_uint(lr) != __float_as_uint(l)) l = __uint_as_float(0x7fc00000u);
+    }
     if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = l; out[6 + (threadIdx.x >> 6)] = (float)its; }
     __syncthreads();
     const unsigned long long t2 = __builtin_amdgcn_s_memtime();

@@ -91,7 +91,7 @@ def test_7b_width_layer_every_code_path_vs_oracle(gpu, qt):
     cur, pos = int(np.argmax(want[0])), len(prompt)
     for _ in range(3):
         want.append(om.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(want[-1])); pos += 1
-    for opts in ({}, {"fuse_attn_o": 0}, {"fuse_ffn": 0}, {"fuse_attn_o": 0, "fuse_ffn": 0}, {"fuse_qkv": 2}, {"fuse_qkv": 2, "use_prefill": 0}):
+    for opts in ({}, {"fuse_layer": 0}, {"fuse_back": 0}, {"fuse_attn_o": 0}, {"fuse_ffn": 0}, {"fuse_attn_o": 0, "fuse_ffn": 0}, {"fuse_qkv": 2}, {"fuse_qkv": 2, "use_prefill": 0}):
         ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
         for k, v in opts.items():
             ctx.set_option(k, v)
@@ -102,6 +102,41 @@ def test_7b_width_layer_every_code_path_vs_oracle(gpu, qt):
             lg = ctx.forward(np.array([cur], np.int32), pos)
             assert bits_equal(lg, want[i + 1]), (opts, i, rel_err(lg, want[i + 1]))
             cur = int(np.argmax(lg)); pos += 1
+        ctx.close()
+
+
+@pytest.mark.parametrize("shape,qt,layers", [("7B", ff.QT_INT8, 2), ("7B", ff.QT_INT16, 1), ("small", ff.QT_INT8, None), ("tiny128", ff.QT_INT16, None),
+                                             ((512, 1408, 3, 8, 320), ff.QT_INT8, None), ((1024, 2752, 2, 8, 320), ff.QT_INT16, None)])
+def test_back_half_of_a_layer_in_one_launch_vs_oracle(gpu, shape, qt, layers):
+    """k_attn_ffn: attention + Wo + FFN13 + FFN2 as one launch (head sizes that are multiples of 64; the other shapes must fall back to the two
+    launches by themselves), with every way of filling the LDS stash -- [W1; W3] under the attention, by the head workgroups behind their head, W2 behind
+    a workgroup's rows of hd, the first register set in front of the x1 flag round --: logits of a prompt (token by token) and of graph-replayed greedy
+    steps are the oracle's bits, whatever the stash holds."""
+    cfg = synth.make_config(shape, qt)
+    if layers:
+        cfg.n_layers = layers
+    tensors = synth.make_tensors(cfg, seed=41)
+    om = O.OracleModel(cfg, tensors)
+    prompt = _prompt(cfg.vocab_size, 5)
+    want = [om.forward(prompt, 0)]
+    cur, pos = int(np.argmax(want[0])), len(prompt)
+    for _ in range(4):
+        want.append(om.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(want[-1])); pos += 1
+    variants = ({}, {"fuse_layer": 0}, {"back_nst13": 0}, {"back_nst13": 3, "fuse_layer": 0}, {"back_nst13": 17, "back_nst13_head": 5}, {"back_nst13_head": -1, "back_nst2": -1},
+                {"back_nst13": 0, "back_nst2": 7, "back_pre13": 1}, {"back_nst13": -1, "back_nst13_head": -1, "back_nst2": -1, "back_pre13": 1, "use_graph": 0})
+    for opts in variants:
+        ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
+        ctx.set_option("use_prefill", 0)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        lg = ctx.forward(prompt, 0)
+        assert bits_equal(lg, want[0]), (opts, rel_err(lg, want[0]))
+        cur, pos = int(np.argmax(lg)), len(prompt)
+        for i in range(4):
+            lg = ctx.forward(np.array([cur], np.int32), pos)
+            assert bits_equal(lg, want[i + 1]), (opts, i, rel_err(lg, want[i + 1]))
+            cur = int(np.argmax(lg)); pos += 1
+        assert ctx.query("fallback") == 0
         ctx.close()
 
 
