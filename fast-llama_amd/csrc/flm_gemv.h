@@ -179,49 +179,42 @@ __device__ __forceinline__ float sq_chain_spec_t(const float* p, const int bshif
     auto elem = [&](int q) -> float4 { if constexpr (BVR > 0) return xr[q]; else return pl[q]; };
     FLM_CHAIN_STAMP(0)
 #define FLM_SQ4(l, v) l = __fmaf_rn(v.x, v.x, l); l = __fmaf_rn(v.y, v.y, l); l = __fmaf_rn(v.z, v.z, l); l = __fmaf_rn(v.w, v.w, l);
-    // 1. approximate per-lane sums, all-zero lanes (pass-through whatever l is)
-    float s = 0.f, m = 0.f;
+    // (A lone wave issues one instruction every ~8 shader clocks whatever its kind -- measured in situ: ~900 instructions took 3.3 us -- so what counts below is
+    //  the NUMBER of instructions on this wave's path, not their latencies.)
+    // 1. approximate per-lane sums; all-zero lanes (every element +-0: pass-through whatever l is)
+    float s = 0.f; unsigned orb = 0u;
 #pragma unroll
-    for (int q = 0; q < BV; ++q) { const float4 v = elem(q); FLM_SQ4(s, v) m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))); }
-    const bool allzero = (m == 0.f) && (s == 0.f);              // (s: a NaN among zeros must not count as zero)
+    for (int q = 0; q < BV; ++q) { const float4 v = elem(q); FLM_SQ4(s, v) orb |= __float_as_uint(v.x) | __float_as_uint(v.y); orb |= __float_as_uint(v.z) | __float_as_uint(v.w); }
+    const bool allzero = (orb & 0x7fffffffu) == 0u;
     const float P = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(wave_scan_incl(s)), 0x138 /* wave_shr:1 */, 0xF, 0xF, true));
     FLM_CHAIN_STAMP(1)
-    // the head: lanes [0, kChainHead) in order (every lane computes it: broadcast reads)
-    float hv = 0.f;
-    if constexpr (BVR > 0) {
-        // the elements are in the registers of lanes 0..3: v_readlane turns each into a scalar operand of the (wave-uniform) chain -- no LDS trip
+    // the head: lanes [0, kChainHead) in order.  Every lane advances ITS elements from whatever it holds, then takes its left neighbour's result
+    // (wave_shr:1): after round k lane k holds the chain through lanes 0..k -- 17 instructions per head lane, no broadcast of the elements.
+    float hv;
+    {
+        float l = 0.f;
 #pragma unroll
         for (int L = 0; L < kChainHead; ++L) {
 #pragma unroll
-            for (int q = 0; q < BVR; ++q) {
-                float4 v;
-                v.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xr[q].x), L)); v.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xr[q].y), L));
-                v.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xr[q].z), L)); v.w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xr[q].w), L));
-                FLM_SQ4(hv, v)
-            }
+            for (int q = 0; q < BV; ++q) { const float4 v = elem(q); FLM_SQ4(l, v) }
+            if (L + 1 < kChainHead) l = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(l), 0x138 /* wave_shr:1 */, 0xF, 0xF, true));
         }
-    } else {
-#pragma unroll
-        for (int L = 0; L < kChainHead; ++L) {
-            const float4* r = reinterpret_cast<const float4*>(p + L * LS);
-#pragma unroll
-            for (int q = 0; q < BV; ++q) { const float4 v = r[q]; FLM_SQ4(hv, v) }
-        }
+        hv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l), kChainHead - 1));
     }
     FLM_CHAIN_STAMP(2)
-    // 2. increments against the expected binade
+    // 2. the lane's increments against the binade it expects to start in, T = sum of RN_u(x^2), as the chain itself run from A = 2^E: while a chain stays inside
+    //    [A, 2A) every step adds RN_u(x^2) whatever multiple of u it started from (exact ties aside), so chain(A) - A is that sum; if it leaves the binade,
+    //    T >= A and the lane fails the "stays below 2A" test of the rounds anyway.  Ties: the same chain from A + u has the other parity -- without a tie
+    //    the two end exactly u apart, a tie moves them to 0 or 2u apart (and later ties keep them there).  34 instructions instead of 96.
     const unsigned eb = __float_as_uint(P) & 0x7f800000u;
-    bool valid = lane >= kChainHead && eb >= (27u << 23) && eb <= (250u << 23);      // P finite and normal, room for u/2 and 2A
+    bool valid = lane >= kChainHead && eb >= (27u << 23) && eb <= (250u << 23);      // P finite and normal, room for u and 2A
     const unsigned ebv = valid ? eb : 0x3f800000u;
-    const float A = __uint_as_float(ebv), half_u = __uint_as_float(ebv - (24u << 23)), top = __fadd_rn(A, A);
-    float T = 0.f; bool tie = false;
+    const float A = __uint_as_float(ebv), u1 = __uint_as_float(ebv - (23u << 23)), top = __fadd_rn(A, A);
+    float ca = A, cb = __fadd_rn(A, u1);
 #pragma unroll
-    for (int q = 0; q < BV; ++q) {
-        const float4 v = elem(q);
-#define FLM_INC(x) { const float t_ = __fsub_rn(__fmaf_rn(x, x, A), A); tie = tie || (fabsf(__fmaf_rn(x, x, -t_)) == half_u); T = __fadd_rn(T, t_); }
-        FLM_INC(v.x) FLM_INC(v.y) FLM_INC(v.z) FLM_INC(v.w)
-#undef FLM_INC
-    }
+    for (int q = 0; q < BV; ++q) { const float4 v = elem(q); FLM_SQ4(ca, v) FLM_SQ4(cb, v) }
+    float T = __fsub_rn(ca, A);
+    const bool tie = __fsub_rn(cb, ca) != u1;
     if (!(T < INFINITY)) valid = false;                         // (inf / NaN never enters the prefix)
     if (!valid) T = 0.f;
     FLM_CHAIN_STAMP(3)
@@ -240,20 +233,20 @@ __device__ __forceinline__ float sq_chain_spec_t(const float* p, const int bshif
     }
     const double Td = (double)T, Si = wave_scan_incl_f64(Td), S = __dsub_rn(Si, Td);
     FLM_CHAIN_STAMP(4)
-    // 4. rounds
-    int base = kChainHead, rounds = 0;
+    // 4. rounds.  The lane tests as wave masks (a v_cmp writes its mask straight into scalar registers; the rest is scalar logic): ~40 instructions per round.
+    //    (No test that the presumed start is exactly an fp32 value: the first inconsistent lane's start is exact by induction -- all lanes before it are consistent --,
+    //     and the lanes behind it are not looked at.)
+    int rounds = 0;
+    const unsigned long long zero_m = __ballot(allzero), good_m = __ballot(valid && !tie);
+    unsigned long long done_m = (1ull << kChainHead) - 1ull;     // lanes in front of the base
     double bv = (double)hv, Sb = readlane_f64(S, kChainHead);
     float res;
     for (;;) {
         ++rounds;
         if (rounds <= 9) { FLM_CHAIN_STAMP(4 + rounds) }
-        const double d = __dadd_rn(bv, __dsub_rn(S, Sb));
-        const float st = (float)d;
-        const bool exact = (double)st == d;
-        const bool okE = (__float_as_uint(st) & 0x7f800000u) == eb;
-        const bool okTop = __fadd_rn(st, T) < top;
-        const bool ok = lane < base || (exact && (allzero || (valid && !tie && okE && okTop)));
-        const unsigned long long bad = __ballot(!ok);
+        const float st = (float)__dadd_rn(bv, __dsub_rn(S, Sb));
+        const unsigned long long e_m = __ballot((__float_as_uint(st) & 0x7f800000u) == eb), t_m = __ballot(__fadd_rn(st, T) < top);
+        const unsigned long long bad = ~(zero_m | (good_m & e_m & t_m) | done_m);
         if (bad == 0) { res = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint((float)__dadd_rn(bv, __dsub_rn(Si, Sb))), 63)); break; }
         const int f = __ffsll((long long)bad) - 1;
         float l = st;                                           // every lane runs its B steps from its presumed start; lane f's start is exact
@@ -261,7 +254,7 @@ __device__ __forceinline__ float sq_chain_spec_t(const float* p, const int bshif
         for (int q = 0; q < BV; ++q) { const float4 v = elem(q); FLM_SQ4(l, v) }
         res = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(l), f));
         if (f == 63) break;
-        base = f + 1; bv = (double)res; Sb = readlane_f64(S, f + 1);
+        done_m = (2ull << f) - 1ull; bv = (double)res; Sb = readlane_f64(S, f + 1);
     }
 #undef FLM_SQ4
     FLM_CHAIN_STAMP(14)

@@ -34,8 +34,9 @@ static float chain_spec(const float* p, int n, int head_lanes) {
     // ---- per lane: approximate sum of squares, all-zero flag
     float s[NL]; int allzero[NL];
     for (int L = 0; L < NL; ++L) {
-        float a = 0.f; int z = 1;
-        for (int j = 0; j < B; ++j) { int k = L * B + j; float x = k < n ? p[k] : 0.f; a = fmaf(x, x, a); if (x != 0.f) z = 0; }
+        float a = 0.f; int z = 1; uint32_t orb = 0;
+        for (int j = 0; j < B; ++j) { int k = L * B + j; float x = k < n ? p[k] : 0.f; a = fmaf(x, x, a); orb |= f2u(x); }
+        z = (orb & 0x7fffffffu) == 0;                       // every element +-0 (the kernel: one OR over the bit patterns)
         s[L] = a; allzero[L] = z;
     }
     // inclusive scan (any order: approximate), exclusive prefix P
@@ -54,16 +55,17 @@ static float chain_spec(const float* p, int n, int head_lanes) {
         Eb[L] = eb; T[L] = 0.f; tie[L] = 0; top[L] = 0.f;
         if (!valid[L] || L < base) { valid[L] = valid[L] && L >= base; continue; }
         if (!allzero[L]) { if (eb < emin) emin = eb; if (eb > emax) emax = eb; }
-        const float A = u2f(eb), half_u = u2f(eb - (24u << 23));
+        // round 4: T = chain(A) - A (inside the binade every step adds RN_u(x^2) whatever multiple of u it started from; a chain that leaves the binade
+        // gives T >= A, which fails okTop); ties from the same chain run from A + u: without a tie the two end exactly u apart
+        const float A = u2f(eb), u1 = u2f(eb - (23u << 23));
         top[L] = A + A;
-        float acc = 0.f;
+        float ca = A, cb = A + u1;
         for (int j = 0; j < B; ++j) {
             int k = L * B + j; float x = k < n ? p[k] : 0.f;
-            const float t = fmaf(x, x, A) - A;
-            if (fabsf(fmaf(x, x, -t)) == half_u) tie[L] = 1;
-            acc += t;
+            ca = fmaf(x, x, ca); cb = fmaf(x, x, cb);
         }
-        T[L] = acc;
+        T[L] = ca - A;
+        tie[L] = (cb - ca) != u1;
     }
     // fp64 exactness of the prefix: all T multiples of 2^(emin-23), every partial sum < 2^(emax+2)
     if (emin != 0xffffffffu && ((emax - emin) >> 23) > 26) { ++g_fallback; return chain_seq(p, n); }
@@ -81,7 +83,8 @@ static float chain_spec(const float* p, int n, int head_lanes) {
             const int exact = (double)st == d;
             const int okE = (f2u(st) & 0x7f800000u) == Eb[L];
             const int okTop = (st + T[L]) < top[L];
-            const int ok = exact && (allzero[L] || (valid[L] && !tie[L] && okE && okTop));
+            (void)exact;                                    // (round 4: no exactness test -- the first inconsistent lane's start is exact by induction)
+            const int ok = allzero[L] || (valid[L] && !tie[L] && okE && okTop);
             if (!ok) { f = L; st_f = st; (void)st_f; break; }
         }
         if (f == NL) { const double d = bv + (S[NL] - Sb); return (float)d; }
@@ -102,7 +105,7 @@ static double nrand(void) { double u = urand() + 1e-300, v = urand(); return sqr
 int main(void) {
     const int sizes[] = {16, 64, 192, 256, 1024, 2752, 4096, 1028};
     long bad = 0, total = 0, rounds = 0;
-    for (int rep = 0; rep < 4000; ++rep) {
+    for (int rep = 0; rep < 40000; ++rep) {
         const int n = sizes[rep % 8];
         float* x = malloc(sizeof(float) * n);
         const int kind = (rep / 8) % 14;
