@@ -483,15 +483,16 @@ def main():
     # per-kernel times, live, HIP events on the ctx stream (eager launches, same kernels as the graph)
     kt = ctx.kernel_times(mid_pos, iters=3)
     # the dominant launch of the token: the fused FFN13 + FFN2 kernel where the token path runs it (single GPU), else FFN13
-    dom = "ffn" if kt.get("ffn", (0.0, 0))[1] > 0 else "ffn13"
+    dom = next((k for k in ("layer", "back", "ffn") if kt.get(k, (0.0, 0))[1] > 0), "ffn13")
     dom_us, dom_cnt = kt[dom]
     dom_bytes = ctx.kernel_bytes(dom, mid_pos)
     achieved = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
     try:
         tpath = ctx.query("token_path")
         token_path = {"resident": bool(ctx.query("resident")), "fell_back_after_timeout": bool(ctx.query("fallback")),
-                      "attn_wo_fused": bool(tpath & 1), "ffn_fused": bool(tpath & 2), "qkv_joins_at_long_contexts": bool(tpath & 4), "engine": (tpath >> 4) & 3,
-                      "heads_split_at_long_contexts": bool(tpath & 64)}
+                      "attn_wo_fused": bool(tpath & 1), "ffn_fused": bool(tpath & 2), "qkv_joins_at_long_contexts": bool(tpath & 4),
+                      "heads_split_at_long_contexts": bool(tpath & 64), "attention_to_ffn2_in_one_launch": bool(tpath & 128), "whole_layer_in_one_launch": bool(tpath & 256),
+                      "launches_per_token_short_context": (cfg.n_layers * (1 if tpath & 256 else 2 if tpath & 128 else 3) + 3)}
     except Exception as e:  # noqa: BLE001
         token_path = {"error": str(e)}
     kernels = {k: {"us": round(v[0], 2), "per_token": v[1], "GBps": round(ctx.kernel_bytes(k, mid_pos) / (v[0] * 1e-6) / 1e9, 1) if v[0] > 0 else 0.0}
@@ -513,9 +514,11 @@ def main():
             replicas = {"value": None, "note": f"failed: {e}"}
 
     qn = 2 if qt == ff.QT_INT8 else 1
-    traffic, traffic_src, traffic_note = pmc_traffic(rf"k_ffn<{qn}," if dom == "ffn" else rf"k_gemv<{qn}, 2, 2,", capi.LIB_PATH)
-    dom_name = (f"k_ffn<{args.quant}> (ffn13 + SwiGLU and ffn2 + residual in one launch)" if dom == "ffn"
-                else f"k_gemv<{args.quant},rmsnorm+quantize,swiglu> (ffn13)")
+    dom_regex = {"layer": rf"k_attn_ffn<{qn}, \d+, true>", "back": rf"k_attn_ffn<{qn}, \d+, false>", "ffn": rf"k_ffn<{qn},"}.get(dom, rf"k_gemv<{qn}, 2, 2,")
+    traffic, traffic_src, traffic_note = pmc_traffic(dom_regex, capi.LIB_PATH)
+    dom_name = {"layer": f"k_attn_ffn<{args.quant}, QKV> (the whole decoder layer in one launch: QKV + RoPE, attention, Wo + residual, FFN13 + SwiGLU, FFN2 + residual)",
+                "back": f"k_attn_ffn<{args.quant}> (attention, Wo + residual, FFN13 + SwiGLU, FFN2 + residual in one launch)",
+                "ffn": f"k_ffn<{args.quant}> (ffn13 + SwiGLU and ffn2 + residual in one launch)"}.get(dom, f"k_gemv<{args.quant},rmsnorm+quantize,swiglu> (ffn13)")
     if rank == 0:
         tb = token_bytes(cfg, mid_pos, esz)
         line = {
@@ -540,9 +543,10 @@ def main():
                          "bytes_per_launch": int(dom_bytes), "avg_launch_us": round(dom_us, 2), "launches_per_token": dom_cnt},
             "token_path": token_path,
             "kernels": kernels,
-            "kernels_note": "us per launch, back-to-back launches of one class between one pair of HIP events; on a single GPU the token path runs attn_wo (k_attn_o) "
-                            "instead of attn + attn_o and ffn (k_ffn) instead of ffn13 + ffn2: per token = embed + L * (qkv + attn_wo + ffn) + cls + argmax; where qkv_attn_wo "
-                            "(k_qkv_attn_o: contexts from 128 positions on) is listed, the token runs it instead of qkv + attn_wo",
+            "kernels_note": "us per launch, back-to-back launches of one class between one pair of HIP events; on a single GPU the token runs `layer` (k_attn_ffn: the whole "
+                            "decoder layer in one launch) where it is listed: per token = embed + L * layer + cls + argmax; else attn_wo (k_attn_o) instead of attn + attn_o and ffn "
+                            "(k_ffn) instead of ffn13 + ffn2, and where qkv_attn_wo (k_qkv_attn_o: contexts from 128 positions on) is listed, that instead of qkv + attn_wo; the "
+                            "per-phase classes (qkv .. ffn2) are timed beside them for reference",
         }
         if long_ctx is not None:
             line["long_context"] = long_ctx

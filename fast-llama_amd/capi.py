@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FLM_GPU_LIB") or os.path.join(_HERE, "lib", "libflm_gpu.so")   # FLM_GPU_LIB: tools/variants.sh builds
 
 QT_NONE, QT_INT16, QT_INT8 = 0, 1, 2
-KCLASSES = ("embed", "qkv", "attn", "attn_o", "ffn13", "ffn2", "cls", "argmax", "allreduce", "attn_wo", "ffn", "qkv_attn_wo", "eng_ffn", "eng_layer")   # the last three: the fused launches of the single-GPU token path
+KCLASSES = ("embed", "qkv", "attn", "attn_o", "ffn13", "ffn2", "cls", "argmax", "allreduce", "attn_wo", "ffn", "qkv_attn_wo", "layer", "back")   # from "attn_wo" on: the fused launches of the single-GPU token path ("layer": k_attn_ffn, the whole decoder layer in one launch; "back": the same without the QKV GEMV)
 
 # every symbol include/flm_gpu.h declares (tests check the library exports all of them)
 SYMBOLS = (
@@ -171,7 +171,7 @@ class Ctx:
         return int(v.value)
 
     def debug_read(self, what, layer, n):
-        names = {"x1": 0, "q": 1, "att_out": 2, "hd": 3, "kcache": 4, "vcache": 5, "logits": 6, "trace": 7, "trace_abs": 8, "eng_trace": 9, "back_trace": 10}
+        names = {"x1": 0, "q": 1, "att_out": 2, "hd": 3, "kcache": 4, "vcache": 5, "logits": 6, "trace": 7, "trace_abs": 8, "back_trace": 10}
         out = np.empty(n, dtype=np.float32)
         _check(lib().flm_debug_read(self._h, names[what], int(layer), _p(out), C.c_size_t(n)), self._h)
         return out

@@ -33,7 +33,7 @@ struct LayerW {
     unsigned got = 0;     // bitmask of uploaded kinds
 };
 
-enum KClass { KC_EMBED = 0, KC_QKV, KC_ATTN, KC_ATTN_O, KC_FFN13, KC_FFN2, KC_CLS, KC_ARGMAX, KC_ALLREDUCE, KC_ATTN_WO /* k_attn_o: attention + Wo */, KC_FFN /* k_ffn: FFN13 + FFN2 */, KC_QKV_ATTN_WO /* k_qkv_attn_o */, KC_ENG_FFN /* k_engine: FFN13 + FFN2 */, KC_ENG_LAYER /* k_engine: Wo + FFN13 + FFN2 + the next layer's QKV (or the classifier) */, KC_ATTN_FFN /* k_attn_ffn: attention + Wo + FFN13 + FFN2 */ };
+enum KClass { KC_EMBED = 0, KC_QKV, KC_ATTN, KC_ATTN_O, KC_FFN13, KC_FFN2, KC_CLS, KC_ARGMAX, KC_ALLREDUCE, KC_ATTN_WO /* k_attn_o: attention + Wo */, KC_FFN /* k_ffn: FFN13 + FFN2 */, KC_QKV_ATTN_WO /* k_qkv_attn_o */, KC_LAYER /* k_attn_ffn with the QKV GEMV in front: the whole layer */, KC_BACK /* k_attn_ffn: attention + Wo + FFN13 + FFN2 */ };
 
 struct TimedLaunch { int kclass; hipEvent_t e0, e1; };
 // owners that release on every exit path (the error macros return from the middle of a function)
@@ -103,11 +103,7 @@ struct flm_ctx {
     unsigned* xepoch = nullptr;                        // [4] exchanges done per kind (att, x1, hd, logits), device memory
     float* att_sc = nullptr;                           // [heads_local][max_seq] scores exchanged between the parts of a split head
     int attn_split = 1;                                // option "attn_split": 1 = spread a head over 4 workgroups from kSplitFrom (128) positions on, 0 = never, >= 2 = always that many
-    // the weight-streaming engine (flm_engine.h; single GPU, int8): option "engine": 0 off (the default: bit-identical but, as measured in round 3, not yet
-    // faster than the fused per-phase launches -- DESIGN.md section 7b), 1 FFN13 + FFN2 per launch, 2 Wo .. next QKV per launch
-    int engine = 0; bool eng_built = false; int eng_nslot = 0; size_t eng_lds = 0; int eng_trace = 0;
-    std::vector<EngPhase> eng_prog[3];                     // the token's programs (host; a launch's phases travel as kernel arguments): [0] FFN pairs, [1] layer chains with pre-quantized head outputs, [2] with fp32 head outputs
-    unsigned long long *gx1 = nullptr, *ghd = nullptr, *ghq = nullptr; unsigned* eng_base = nullptr;
+    unsigned* eng_base = nullptr;                      // the token's epoch base (device memory, advanced by k_embed): the tensor-parallel exchanges' flag values count from it
     int resident = 1;                                  // the census at create saw every workgroup of a cu_count-wide launch co-resident
     int fell_back = 0;                                 // a cross-workgroup wait timed out once: fused launches off for good
     int trace_class = -1; unsigned long long* trace = nullptr;   // FLM_ABLATE builds: GEMV timeline of one kernel class
@@ -303,7 +299,7 @@ bool model_complete(const flm_ctx* c) {
 // context's life and FLM_RETRY tells the caller (inside this library) to run the call again on one kernel per phase.
 constexpr int FLM_RETRY = 1;
 int xwg_check(flm_ctx* c) {
-    if (!c->fuse_attn_o && !c->fuse_ffn && !c->fuse_back && c->attn_split == 0 && !c->p2p && !c->engine) return FLM_OK;
+    if (!c->fuse_attn_o && !c->fuse_ffn && !c->fuse_back && c->attn_split == 0 && !c->p2p) return FLM_OK;
     // (on the context's own stream: a copy on the legacy stream synchronises with every blocking stream of the process -- and fails
     //  outright while another context's thread is capturing its token graph; seen once in ~10 runs of the threaded tensor-parallel tests)
     int e = 0;
@@ -323,14 +319,14 @@ int xwg_check(flm_ctx* c) {
         c->attn_split = 0;
         return fail(c, FLM_ERR_COMM, "tensor parallel: a cross-workgroup wait on this rank timed out; the group's results are invalid and the context group cannot be used any more");
     }
-    c->fuse_attn_o = 0; c->fuse_ffn = 0; c->fuse_qkv = 0; c->fuse_back = 0; c->attn_split = 0; c->engine = 0; c->fell_back = 1;
+    c->fuse_attn_o = 0; c->fuse_ffn = 0; c->fuse_qkv = 0; c->fuse_back = 0; c->attn_split = 0; c->fell_back = 1;
     for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
     c->graphs.clear();
     return FLM_RETRY;
 }
 
 
-// Census: the fused launches (k_attn_o, k_ffn, k_qkv_attn_o, k_engine, split heads) wait for each other's flags, so every workgroup of a
+// Census: the fused launches (k_attn_o, k_ffn, k_qkv_attn_o, k_attn_ffn, split heads) wait for each other's flags, so every workgroup of a
 // cu_count-wide launch of 1024-thread workgroups with most of the CU's LDS must be RESIDENT at once.  The occupancy API cannot see a masked or
 // partitioned device (MI355X_MICROARCH.md: verify with a census kernel): every workgroup checks in and waits (bounded) until all have.
 __global__ void __launch_bounds__(1024) k_census(unsigned* counter, unsigned n, int* ok) {
@@ -642,75 +638,6 @@ int launch_attn_ffn(flm_ctx* c, hipStream_t st, int l, bool with_qkv) {
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// The weight-streaming engine (flm_engine.h): device programs and launches.  Program index of a phase: 4 l + {0 QKV, 1 Wo, 2 FFN13, 3 FFN2},
-// the classifier at 4 L.  Three variants (what differs is where a phase's activation comes from and whether its results leave as granules):
-//   [0] "engine" 1: launches of {FFN13, FFN2} -- FFN13 reads x1 from memory, FFN2 takes hd through the granule hand-off
-//   [1] "engine" 2: launches of {QKV(0)}, {Wo(l), FFN13(l), FFN2(l), QKV(l+1) | classifier}; Wo reads the heads' output already quantized
-//   [2] the same with fp32 head outputs (split heads at long contexts do not quantize their slices)
-// ---------------------------------------------------------------------------------------------
-bool eng_supported(const flm_ctx* c) {
-    const auto& d = c->d;
-    if (c->world != 1 || d.quant_type != FLM_QT_INT8) return false;
-    if (d.dim % 256 || d.hidden_dim % 256 || (c->hs & 1)) return false;
-    if (d.dim / 4 > kEngConsumers * kEngMaxOwn * c->cu_count) return false;           // residual rows per consumer lane
-    if (4 * d.n_layers + 2 >= kEngEpochStride) return false;
-    return true;
-}
-int eng_build(flm_ctx* c) {
-    if (c->eng_built) return FLM_OK;
-    const auto& d = c->d; const int L = d.n_layers;
-    const int kmax = d.hidden_dim > d.dim ? d.hidden_dim : d.dim;
-    if ((size_t)eng_lds_layout(kEngSlots, kmax, 1, d.dim).total > kLdsMax) return FLM_ERR_UNSUPPORTED;   // (the ring's size is a compile-time constant)
-    c->eng_nslot = kEngSlots; c->eng_lds = (size_t)eng_lds_layout(kEngSlots, kmax, 1, d.dim).total;
-    {   // the ring takes most of the CU's 160 KiB: raise the kernel's dynamic-LDS limit, once per device
-        static std::mutex mu; static bool done[64] = {false};
-        std::lock_guard<std::mutex> lk(mu);
-        if (c->device >= 0 && c->device < 64 && !done[c->device]) {
-            HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_engine<QT_INT8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
-            done[c->device] = true;
-        }
-    }
-    const size_t kv_layer = (size_t)c->heads_local * d.max_seq_len * c->hs;
-    for (int v = 0; v < 3; ++v) {
-        std::vector<EngPhase> pr((size_t)4 * L + 1);
-        for (int l = 0; l < L; ++l) {
-            LayerW& w = c->layers[l];
-            EngPhase q{}; q.W = w.qkv.q; q.sW = w.qkv.s; q.K = d.dim; q.rows = w.qkv.rows; q.epi = EPI_ROPE_KV;
-            q.pro = (v == 0 || l == 0) ? EPRO_X_RMS : EPRO_GRAN_RMS; q.x = c->x1; q.norm_w = w.att_norm; q.out = c->qbuf;
-            q.kcache = c->kcache + (size_t)l * kv_layer; q.vcache = c->vcache + (size_t)l * kv_layer;
-            q.dim = c->dim_local; q.kv_dim = c->dim_local; q.hs = c->hs; q.max_seq = d.max_seq_len;
-            EngPhase o{}; o.W = w.o.q; o.sW = w.o.s; o.K = d.dim; o.rows = c->drow_count; o.epi = EPI_RESIDUAL;
-            o.pro = v == 1 ? EPRO_XQ : EPRO_X_Q; o.x = c->att_out; o.xq = c->att_q; o.xs = c->att_qs; o.out = c->x1 + c->drow_begin; o.gran_out = 1;
-            EngPhase f{}; f.W = w.w13.q; f.sW = w.w13.s; f.K = d.dim; f.rows = c->hidden_local; f.epi = EPI_SWIGLU;
-            f.pro = v == 0 ? EPRO_X_RMS : EPRO_GRAN_RMS; f.x = c->x1; f.norm_w = w.ffn_norm; f.out = c->hd + c->plan.hidden_begin; f.gran_out = 1;
-            EngPhase g{}; g.W = w.w2.q; g.sW = w.w2.s; g.K = d.hidden_dim; g.rows = c->drow_count; g.epi = EPI_RESIDUAL;
-            g.pro = EPRO_GRAN_HD; g.out = c->x1 + c->drow_begin; g.gran_out = v == 0 ? 0 : 1;
-            pr[4 * l] = q; pr[4 * l + 1] = o; pr[4 * l + 2] = f; pr[4 * l + 3] = g;
-        }
-        EngPhase k{}; k.W = c->cls.q; k.sW = c->cls.s; k.K = d.dim; k.rows = c->cls.rows; k.epi = EPI_STORE;
-        k.pro = EPRO_GRAN_RMS; k.norm_w = c->out_norm; k.out = c->logits;
-        pr[4 * L] = k;
-        for (size_t i = 0; i < pr.size(); ++i) { pr[i].index = (int)i; eng_fill_geom(pr[i], 1, c->cu_count); }
-        c->eng_prog[v] = std::move(pr);
-    }
-    c->eng_built = true;
-    return FLM_OK;
-}
-int launch_engine(flm_ctx* c, hipStream_t st, int variant, int ph0, int ph1) {
-    EngArgs a{};
-    if (ph1 - ph0 < 1 || ph1 - ph0 > kEngMaxPhases || ph1 > (int)c->eng_prog[variant].size()) return fail(c, FLM_ERR_INVALID, "engine: phase range");
-    a.nph = ph1 - ph0;
-    for (int i = 0; i < a.nph; ++i) a.ph[i] = c->eng_prog[variant][ph0 + i];
-    a.gx1 = c->gx1; a.ghd = c->ghd; a.ghq = c->ghq; a.base_ptr = c->eng_base; a.x1 = c->x1;
-    a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.pos_ptr = &c->state->pos; a.err = c->xwg_err;
-    a.ablate = c->ablate;
-    if (c->eng_trace && ph0 == c->eng_trace) a.trace = c->trace;                     // tools/trace_eng.py: the stamps of the launch that starts at this phase
-    hipLaunchKernelGGL(k_engine<QT_INT8>, dim3(c->cu_count), dim3(kEngBlock), c->eng_lds, st, a);
-    HIPC(c, hipGetLastError());
-    return FLM_OK;
-}
-
 // one activation exchange between the tensor-parallel ranks (the reference's threads share the vector in memory instead):
 // peer-to-peer (the producer already stored its slice everywhere: flag round only) or an RCCL all-gather
 enum XKind { XK_ATT = 0, XK_X1 = 1, XK_HD = 2, XK_LOGITS = 3 };
@@ -742,25 +669,6 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
     const int wgs = gemv_grid(c->cu_count, c->wg_per_cu, 0, 0);
     auto traced = [&](GemvArgs a, int kc, int l) { if (kAblate && c->trace_class == kc && l == 0) a.trace = c->trace; return a; };
     int r;
-    // the weight-streaming engine (single GPU, int8): 1 = FFN13 + FFN2 per launch, 2 = {Wo, FFN13, FFN2, next QKV | classifier} per launch
-    int eng = 0;
-    if (!tp && c->engine && !c->timing && c->trace_class < 0 && c->eng_built) eng = c->engine;   // (programs are built before any capture: eng_prepare)
-    bool cls_done = false;
-    if (eng >= 2) {
-        const bool preq = hs % kGroup == 0 && G == 1;                 // the heads hand their output over quantized
-        const int v = preq ? 1 : 2;
-        r = launch_engine(c, st, v, 0, 1); if (r) return r;           // QKV of layer 0 (x1 from memory)
-        for (int l = 0; l < L; ++l) {
-            AttnArgs aa = args_attn(c, l, G);
-            if (preq) { aa.oq = c->att_q; aa.os = c->att_qs; aa.oqt = QT_INT8; }
-            if (G > 1) hipLaunchKernelGGL(k_attn_decode<true>, dim3(c->heads_local * G), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, hs, true), st, aa);
-            else       hipLaunchKernelGGL(k_attn_decode<false>, dim3(c->heads_local), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, hs, false), st, aa);
-            HIPC(c, hipGetLastError());
-            const int ph1 = l + 1 < L ? 4 * l + 5 : (with_cls ? 4 * L + 1 : 4 * L);
-            r = launch_engine(c, st, v, 4 * l + 1, ph1); if (r) return r;
-        }
-        cls_done = with_cls;
-    }
     // tensor parallel, peer to peer: the flag rounds of the att / x1 / hd exchanges happen inside the launches that consume them (xchg_fold), not in
     // launches of their own; what stays a k_xchg is the logits' exchange and, for a token without classifier, the last x1 exchange (the next token's
     // k_embed rewrites x1: every peer's stores into it must have landed first)
@@ -770,9 +678,9 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
     // launches that span the ranks wait across workgroups of one launch too: only where the census found one workgroup per CU resident (a CU partition
     // made for the tests is sized for it: launches are cut to the partition)
     const bool span = fold && (c->resident || c->cu_parts > 1);
-    for (int l = 0; l < (eng >= 2 ? 0 : L); ++l) {
+    for (int l = 0; l < L; ++l) {
         bool fused = false;
-        const bool back_ok = !tp && c->fuse_back && c->fuse_attn_o && c->fuse_ffn && G == 1 && eng == 0 && !c->timing && (c->trace_class < 0 || c->trace_class == 102);
+        const bool back_ok = !tp && c->fuse_back && c->fuse_attn_o && c->fuse_ffn && G == 1 && !c->timing && (c->trace_class < 0 || c->trace_class == 102);
         if (back_ok && c->fuse_layer) {   // the whole layer in one launch
             r = qt == FLM_QT_INT8 ? launch_attn_ffn<QT_INT8>(c, st, l, true) : launch_attn_ffn<QT_INT16>(c, st, l, true);
             if (r == FLM_OK) continue; else if (r != FLM_ERR_UNSUPPORTED) return r;
@@ -807,7 +715,6 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
             r = launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, folded(traced(args_o(c, l), KC_ATTN_O, l), l, 0), wgs, coh); if (r) return r;
         }
         if (tp && !fold) { r = exchange(c, st, XK_X1, c->x1, c->x1 + c->drow_begin, c->drow_count); if (r) return r; }
-        if (eng == 1) { r = launch_engine(c, st, 0, 4 * l + 2, 4 * l + 4); if (r) return r; continue; }   // FFN13 + FFN2 on the engine
         if (((!tp && c->fuse_ffn) || (span && c->tp_fuse_ffn)) && !c->timing && c->trace_class < 0) {   // FFN13 + FFN2 in one launch (tensor parallel: across the ranks)
             r = qt == FLM_QT_INT8 ? launch_ffn<QT_INT8>(c, st, l) : launch_ffn<QT_INT16>(c, st, l);
             if (r == FLM_OK) {
@@ -827,7 +734,7 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
         if (tp && (!fold || (l == L - 1 && !with_cls))) { r = exchange(c, st, XK_X1, c->x1, c->x1 + c->drow_begin, c->drow_count); if (r) return r; }
     }
     if (with_cls) {
-        if (!cls_done) {   // final norm + CLS task (transformer.cpp:154-160, execute_cls :496-505): this rank's rows of the classifier
+        {   // final norm + CLS task (transformer.cpp:154-160, execute_cls :496-505): this rank's rows of the classifier
             Tick t(c, st, KC_CLS);
             r = launch_gemv<PRO_RMSNORM_QUANT, EPI_STORE>(c, st, qt, folded(traced(args_cls(c), KC_CLS, 0), L - 1, 3), wgs, coh); if (r) return r;
         }
@@ -846,17 +753,8 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
 
 // run one token, through a cached hipGraph when enabled.  T = positions the token's attention covers (known to the host:
 // it picks how many workgroups a head is spread over; the graphs are keyed by it)
-// build the engine's device programs (allocations and copies: never inside a stream capture); an unsupported shape leaves the engine off
-int eng_prepare(flm_ctx* c) {
-    if (!c->engine || c->eng_built) return FLM_OK;
-    if (!eng_supported(c)) { c->engine = 0; return FLM_OK; }
-    const int r = eng_build(c);
-    if (r == FLM_ERR_UNSUPPORTED) { c->engine = 0; return FLM_OK; }
-    return r;
-}
 int run_token(flm_ctx* c, bool with_cls, int advance, int T) {
     const int G = attn_parts(c, T);
-    { const int r = eng_prepare(c); if (r) return r; }
     if (!c->use_graph || c->timing || ((c->world > 1 || c->comm) && !c->p2p)) return enqueue_token(c, c->stream, with_cls, advance, G);   // (RCCL collectives stay eager)
     const int key = (with_cls ? 4 : 0) + advance + 8 * G;
     auto it = c->graphs.find(key);
@@ -1241,13 +1139,7 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
     }
     HIPB(hipMalloc((void**)&c->flag_lines, 1536 * 64)); HIPB(hipMalloc((void**)&c->xwg_err, 64));   // lines 0..255: k_attn_o's heads, 256..511: split heads' scores, 512..767: k_ffn, 768..1023: k_qkv_attn_o's QKV rows, 1024..1279: k_attn_ffn's x1 rows (k_embed clears all 1536)
     HIPB(hipMemsetAsync(c->flag_lines, 0, 1536 * 64, c->stream)); HIPB(hipMemsetAsync(c->xwg_err, 0, 64, c->stream));
-    {   // the engine's granule buffers (8 bytes per value: {value, tag}) and the token's epoch base
-        const size_t nq = (size_t)(d.hidden_dim / kGroup) * (16 * c->esz + 1);
-        HIPB(hipMalloc((void**)&c->gx1, (size_t)d.dim * 8)); HIPB(hipMalloc((void**)&c->ghd, (size_t)d.hidden_dim * 16)); HIPB(hipMalloc((void**)&c->ghq, nq * 8));
-        HIPB(hipMalloc((void**)&c->eng_base, 64));
-        HIPB(hipMemsetAsync(c->gx1, 0, (size_t)d.dim * 8, c->stream)); HIPB(hipMemsetAsync(c->ghd, 0, (size_t)d.hidden_dim * 16, c->stream));
-        HIPB(hipMemsetAsync(c->ghq, 0, nq * 8, c->stream)); HIPB(hipMemsetAsync(c->eng_base, 0, 64, c->stream));
-    }
+    HIPB(hipMalloc((void**)&c->eng_base, 64)); HIPB(hipMemsetAsync(c->eng_base, 0, 64, c->stream));   // the token's epoch base
     HIPB(hipMalloc(&c->att_q, (size_t)d.dim * c->esz)); HIPB(hipMalloc((void**)&c->att_qs, (size_t)(d.dim / kGroup) * 4));
     HIPB(hipMalloc((void**)&c->att_sc, (size_t)c->heads_local * d.max_seq_len * 4));
     HIPB(hipMalloc((void**)&c->state, sizeof(DecodeState)));
@@ -1276,7 +1168,7 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
         int ok = 0;
         if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&ok, okp, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess) c->resident = ok ? 1 : 0;
         else { (void)hipGetLastError(); c->resident = 0; }
-        if (!c->resident) { c->fuse_attn_o = 0; c->fuse_ffn = 0; c->fuse_qkv = 0; c->fuse_back = 0; c->attn_split = 0; c->engine = 0; }
+        if (!c->resident) { c->fuse_attn_o = 0; c->fuse_ffn = 0; c->fuse_qkv = 0; c->fuse_back = 0; c->attn_split = 0; }
     }
 #undef HIPB
     *out = c;
@@ -1294,7 +1186,7 @@ void flm_ctx_destroy(flm_ctx* c) {
     for (int r = 0; r < c->world; ++r) if (c->peer_opened[r] && c->peer[r]) hipIpcCloseMemHandle(c->peer[r]);
     void* ptrs[] = {c->emb, c->emb_s, c->out_norm, c->kcache, c->vcache, c->xbuf, c->xepoch, c->qbuf,
                     c->rope_cos, c->rope_sin, c->state, c->prompt_dev, c->out_tokens_dev,
-                    c->flag_lines, c->xwg_err, c->att_q, c->att_qs, c->att_sc, c->trace, c->gx1, c->ghd, c->ghq, c->eng_base, c->ffn_counter,
+                    c->flag_lines, c->xwg_err, c->att_q, c->att_qs, c->att_sc, c->trace, c->eng_base, c->ffn_counter,
                     c->pf_in_xbuf ? nullptr : c->pf_x, c->pf_qkv, c->pf_q, c->pf_in_xbuf ? nullptr : c->pf_att, c->pf_gu, c->pf_in_xbuf ? nullptr : c->pf_hd, c->pf_xs, c->pf_xq, c->pf_scores};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->comm) ncclCommDestroy(c->comm);
@@ -1361,7 +1253,7 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     std::string k(key);
     if (c->world > 1 && c->p2p && (k == "use_mfma" || k == "use_pv_mfma" || k == "use_prefill_mq" || k == "use_qk_mfma"))
         return fail(c, FLM_ERR_STATE, "set_option: which prompt kernels a tensor-parallel group runs is agreed at flm_p2p_import; set this option on every rank before importing (\"use_prefill\" may be switched later, on every rank alike)");
-    if (!c->resident && value != 0 && (k == "fuse_attn_o" || k == "fuse_ffn" || k == "fuse_qkv" || k == "fuse_back" || k == "attn_split" || k == "engine"))
+    if (!c->resident && value != 0 && (k == "fuse_attn_o" || k == "fuse_ffn" || k == "fuse_qkv" || k == "fuse_back" || k == "attn_split"))
         return fail(c, FLM_ERR_UNSUPPORTED, "set_option: this device does not keep one workgroup per CU resident (census at flm_ctx_create); the fused launches stay off");
     if (k == "wg_per_cu") { c->wg_per_cu = value > 0 ? value : 1; }
     else if (k == "use_graph") c->use_graph = value;
@@ -1379,7 +1271,6 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (k == "back_pre13") c->back_pre13 = value;
     else if (k == "use_prefill_mq") c->use_prefill_mq = value;
     else if (k == "attn_split") c->attn_split = value;
-    else if (k == "engine") { if (value < 0 || value > 2) return fail(c, FLM_ERR_INVALID, "engine: 0 (off), 1 (FFN13 + FFN2 per launch) or 2 (Wo + FFN13 + FFN2 + next QKV per launch)"); c->engine = value; }
     else if (k == "fold_xchg") c->fold_xchg = value;
     else if (k == "tp_fuse_attn") c->tp_fuse_attn = value;
     else if (k == "tp_fuse_ffn") c->tp_fuse_ffn = value;
@@ -1398,13 +1289,7 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
         }
         HIPC(c, hipStreamDestroy(c->stream));
         c->stream = ns; c->cu_parts = value; c->cu_count = c->cu_total / value;
-        if (value > 1) { c->fuse_attn_o = 0; c->fuse_ffn = 0; c->fuse_qkv = 0; c->fuse_back = 0; c->engine = 0; }
-        c->eng_built = false;
-    }
-    else if (k == "eng_trace") {   // value = first phase of the engine launch whose in-kernel stamps are recorded (0 off); read them with flm_debug_read(9)
-        c->eng_trace = value;
-        if (!c->trace) { HIPC(c, hipMalloc((void**)&c->trace, 131072 * 8)); }
-        HIPC(c, hipMemset(c->trace, 0, 131072 * 8));
+        if (value > 1) { c->fuse_attn_o = 0; c->fuse_ffn = 0; c->fuse_qkv = 0; c->fuse_back = 0; }
     }
     else if (k == "use_qk_mfma") c->use_qk_mfma = value;
     else if (k == "use_p2p") {     // 0: exchange by RCCL all-gathers although the peers are mapped (needs the communicator); 1: back to peer-to-peer
@@ -1431,8 +1316,8 @@ int flm_query(flm_ctx* c, const char* key, int* value) {
     const struct { const char* k; int v; } tab[] = {
         {"wg_per_cu", c->wg_per_cu}, {"use_graph", c->use_graph}, {"use_prefill", c->use_prefill}, {"use_mfma", c->use_mfma}, {"use_pv_mfma", c->use_pv_mfma},
         {"fuse_attn_o", c->fuse_attn_o}, {"fuse_ffn", c->fuse_ffn}, {"fuse_qkv", c->fuse_qkv}, {"fuse_back", c->fuse_back}, {"fuse_layer", c->fuse_layer}, {"back_nst13", c->back_nst13}, {"back_nst13_head", c->back_nst13_head}, {"back_nst2", c->back_nst2}, {"back_pre13", c->back_pre13}, {"use_prefill_mq", c->use_prefill_mq}, {"attn_split", c->attn_split},
-        {"use_qk_mfma", c->use_qk_mfma}, {"use_p2p", c->p2p}, {"engine", c->engine}, {"fold_xchg", c->fold_xchg}, {"tp_fuse_attn", c->tp_fuse_attn}, {"tp_fuse_ffn", c->tp_fuse_ffn}, {"cu_parts", c->cu_parts}, {"fold_active", (c->world > 1 && c->p2p && c->fold_xchg && c->cu_parts >= c->ranks_on_device) ? 1 : 0}, {"resident", c->resident}, {"fallback", c->fell_back},
-        {"token_path", (c->world == 1 ? ((c->fuse_attn_o ? 1 : 0) | (c->fuse_ffn && c->engine != 1 && c->engine != 2 ? 2 : 0) | (c->fuse_attn_o && c->fuse_qkv == 1 ? 4 : 0) | (c->fuse_attn_o && c->fuse_qkv >= 2 ? 8 : 0) | ((c->engine & 3) << 4) | (c->fuse_back && c->fuse_attn_o && c->fuse_ffn && !c->engine ? 128 : 0)) : 0) | (c->attn_split ? 64 : 0)},
+        {"use_qk_mfma", c->use_qk_mfma}, {"use_p2p", c->p2p}, {"fold_xchg", c->fold_xchg}, {"tp_fuse_attn", c->tp_fuse_attn}, {"tp_fuse_ffn", c->tp_fuse_ffn}, {"cu_parts", c->cu_parts}, {"fold_active", (c->world > 1 && c->p2p && c->fold_xchg && c->cu_parts >= c->ranks_on_device) ? 1 : 0}, {"resident", c->resident}, {"fallback", c->fell_back},
+        {"token_path", (c->world == 1 ? ((c->fuse_attn_o ? 1 : 0) | (c->fuse_ffn ? 2 : 0) | (c->fuse_attn_o && c->fuse_qkv == 1 ? 4 : 0) | (c->fuse_attn_o && c->fuse_qkv >= 2 ? 8 : 0) | (c->fuse_back && c->fuse_attn_o && c->fuse_ffn ? (c->fuse_layer ? 128 + 256 : 128) : 0)) : 0) | (c->attn_split ? 64 : 0)},
     };
     for (const auto& t : tab) if (k == t.k) { *value = t.v; return FLM_OK; }
     return fail(c, FLM_ERR_INVALID, "query: unknown key");
@@ -1542,21 +1427,6 @@ int flm_debug_read(flm_ctx* c, int what, int layer, float* out, size_t n) {
         unsigned long long t0 = ~0ull;
         for (size_t i = 1; i < n; i += 8) if (t[i] && t[i] < t0) t0 = t[i];
         for (size_t i = 0; i < n; ++i) out[i] = ((i % 8 == 1 || i % 8 == 2) && t[i]) ? (float)(long long)(t[i] - t0) : -1.f;
-        return FLM_OK; }
-    case 9: {   // tools/trace_eng.py: the engine launch's words [workgroup][kEngTrace] (100 MHz clock): stamps as microseconds after the earliest one (0 = not
-                // stamped -> -1), accumulated times as microseconds, counts as they are
-        if (!c->trace || n > 131072) return fail(c, FLM_ERR_INVALID, "debug_read: no trace");
-        HIPC(c, hipStreamSynchronize(c->stream));
-        std::vector<unsigned long long> t(131072);
-        HIPC(c, hipMemcpy(t.data(), c->trace, t.size() * 8, hipMemcpyDeviceToHost));
-        auto kind = [](size_t i) { const size_t j = i % kEngTrace; if (j >= 320) return j % 4 == 3 ? 3 : 2; if (j < 256) return j % 16 == 14 ? 4 : j % 16 == 15 ? 2 : 1; return j % 8 == 7 ? 2 : 1; };   // 1 stamp, 2 time, 3 count, 4 {ticks << 16 | pieces}
-        unsigned long long t0 = ~0ull;
-        for (size_t i = 0; i < n; ++i) if (kind(i) == 1 && t[i] && t[i] < t0) t0 = t[i];
-        for (size_t i = 0; i < n; ++i) {
-            const int k = kind(i);
-            out[i] = k == 1 ? (t[i] ? (float)((double)(long long)(t[i] - t0) * 0.01) : -1.f) : k == 2 ? (float)((double)t[i] * 0.01) : k == 3 ? (float)t[i]
-                   : ((t[i] & 0xffff) ? (float)((double)(t[i] >> 16) * 10.0 / (double)(t[i] & 0xffff)) : -1.f);   // ns per piece inside the dot loops
-        }
         return FLM_OK; }
     case 10: {  // tools/trace_back.py (FLM_ABLATE builds): k_attn_ffn's stamps [workgroup][16] on the 100 MHz clock (one clock for all XCDs) as microseconds after the earliest one; -1 = not stamped
         if (!c->trace || n > 131072) return fail(c, FLM_ERR_INVALID, "debug_read: no trace");
@@ -1700,7 +1570,6 @@ int flm_kernel_times(flm_ctx* c, int pos, int iters, float* avg_us, int32_t* cou
     const auto& d = c->d;
     const int qt = d.quant_type, L = d.n_layers, wgs = gemv_grid(c->cu_count, c->wg_per_cu, 0, 0);
     hipStream_t st = c->stream;
-    r = eng_prepare(c); if (r) return r;
     r = set_state(c, pos, 1 % d.vocab_size, 0); if (r) return r;
     EvPair ev; HIPC(c, hipEventCreate(&ev.e0)); HIPC(c, hipEventCreate(&ev.e1));
     const hipEvent_t e0 = ev.e0, e1 = ev.e1;
@@ -1722,20 +1591,19 @@ int flm_kernel_times(flm_ctx* c, int pos, int iters, float* avg_us, int32_t* cou
                          return qt == FLM_QT_INT8 ? launch_attn_o<QT_INT8>(c, st, l, attn_parts(c, pos + 1)) : launch_attn_o<QT_INT16>(c, st, l, attn_parts(c, pos + 1));
         case KC_FFN:     if (!c->fuse_ffn || c->world > 1) return FLM_ERR_UNSUPPORTED;
                          return qt == FLM_QT_INT8 ? launch_ffn<QT_INT8>(c, st, l) : launch_ffn<QT_INT16>(c, st, l);
-        case KC_ENG_FFN:   if (!c->engine || !c->eng_built) return FLM_ERR_UNSUPPORTED;
-                           return launch_engine(c, st, 0, 4 * l + 2, 4 * l + 4);
-        case KC_ENG_LAYER: if (c->engine < 2 || !c->eng_built) return FLM_ERR_UNSUPPORTED;
-                           return launch_engine(c, st, 1, 4 * l + 1, l + 1 < L ? 4 * l + 5 : 4 * L + 1);
         case KC_QKV_ATTN_WO: { const int G = attn_parts(c, pos + 1);
                          if (c->world > 1) return FLM_ERR_UNSUPPORTED;
                          if (!c->fuse_attn_o || !(c->fuse_qkv >= 2 || (c->fuse_qkv && G > 1))) return FLM_ERR_UNSUPPORTED;
                          return qt == FLM_QT_INT8 ? launch_qkv_attn_o<QT_INT8>(c, st, l, G) : launch_qkv_attn_o<QT_INT16>(c, st, l, G); }
+        case KC_LAYER: case KC_BACK: {
+                         if (c->world > 1 || !c->fuse_back || !c->fuse_attn_o || !c->fuse_ffn || attn_parts(c, pos + 1) != 1 || (kc == KC_LAYER) != (c->fuse_layer != 0)) return FLM_ERR_UNSUPPORTED;
+                         return qt == FLM_QT_INT8 ? launch_attn_ffn<QT_INT8>(c, st, l, kc == KC_LAYER) : launch_attn_ffn<QT_INT16>(c, st, l, kc == KC_LAYER); }
         default: return FLM_OK;
         }
     };
-    const int classes[] = {KC_EMBED, KC_QKV, KC_ATTN, KC_ATTN_O, KC_FFN13, KC_FFN2, KC_CLS, KC_ARGMAX, KC_ATTN_WO, KC_FFN, KC_QKV_ATTN_WO, KC_ENG_FFN, KC_ENG_LAYER};
+    const int classes[] = {KC_EMBED, KC_QKV, KC_ATTN, KC_ATTN_O, KC_FFN13, KC_FFN2, KC_CLS, KC_ARGMAX, KC_ATTN_WO, KC_FFN, KC_QKV_ATTN_WO, KC_LAYER, KC_BACK};
     for (int kc : classes) {
-        const bool fused = kc == KC_ATTN_WO || kc == KC_FFN || kc == KC_QKV_ATTN_WO || kc == KC_ENG_FFN || kc == KC_ENG_LAYER;
+        const bool fused = kc == KC_ATTN_WO || kc == KC_FFN || kc == KC_QKV_ATTN_WO || kc == KC_LAYER || kc == KC_BACK;
         const bool per_layer = (kc >= KC_QKV && kc <= KC_FFN2) || fused;
         const int n = per_layer ? L : 8;
         for (int it = 0; it < iters + 1 && !r; ++it) {          // first round: warm-up
@@ -1772,9 +1640,9 @@ int flm_kernel_bytes(flm_ctx* c, int kclass, int pos, double* bytes) {
     case KC_ATTN_WO: *bytes = 2.0 * c->heads_local * c->hs * 4.0 * (pos + 1) + mat(c->drow_count, d.dim); break;
     case KC_FFN:    *bytes = 2.0 * mat(c->hidden_local, d.dim) + d.dim * 4.0 + mat(c->drow_count, d.hidden_dim); break;
     case KC_QKV_ATTN_WO: *bytes = mat(3.0 * c->dim_local, d.dim) + d.dim * 4.0 + 2.0 * c->heads_local * c->hs * 4.0 * (pos + 1) + mat(c->drow_count, d.dim); break;
-    case KC_ENG_FFN: *bytes = 2.0 * mat(c->hidden_local, d.dim) + d.dim * 4.0 + mat(c->drow_count, d.hidden_dim); break;
-    case KC_ENG_LAYER: *bytes = mat(c->drow_count, d.dim) + 2.0 * mat(c->hidden_local, d.dim) + mat(c->drow_count, d.hidden_dim) + mat(3.0 * c->dim_local, d.dim) + 2 * d.dim * 4.0; break;   // (the last layer's launch ends with the classifier instead of a QKV)
     case KC_CLS:    *bytes = mat(c->cls.rows, d.dim) + d.dim * 4.0; break;
+    case KC_BACK:   *bytes = 2.0 * c->heads_local * c->hs * 4.0 * (pos + 1) + mat(c->drow_count, d.dim) + 2.0 * mat(c->hidden_local, d.dim) + d.dim * 4.0 + mat(c->drow_count, d.hidden_dim); break;
+    case KC_LAYER:  *bytes = mat(3.0 * c->dim_local, d.dim) + d.dim * 4.0 + 2.0 * c->heads_local * c->hs * 4.0 * (pos + 1) + mat(c->drow_count, d.dim) + 2.0 * mat(c->hidden_local, d.dim) + d.dim * 4.0 + mat(c->drow_count, d.hidden_dim); break;
     default:        *bytes = 0; break;
     }
     return FLM_OK;

@@ -15,28 +15,30 @@
 //   * attention : q.k as 8 strided lanes + sequential lane sum; glibc-exact expf; sequential softmax
 //                 sum; weighted V sum sequential over positions
 //
-// Kernel inventory (one decode token on a single GPU = embed + L x {qkv, attention + attn_o, ffn13 + ffn2} + cls + argmax):
-//   k_gemv<QT,PRO,EPI,XR> group-quantized GEMV, HBM-bound; fused prologue (rmsnorm+quantize | quantize)
-//                         and epilogue (store | residual add | SwiGLU | RoPE + KV-cache append)
+// Kernel inventory.  One decode token on a single GPU = k_embed + L x k_attn_ffn<.., QKV = true> + k_gemv(cls) + k_argmax_advance (head size a multiple of 64, contexts
+// below 128 positions); from 128 positions on (a head spread over 4 workgroups) L x {k_qkv_attn_o, k_ffn}.  What else is here runs under options, tensor parallelism or tests:
+//   k_attn_ffn<QT,XR2,QKV> THE DEFAULT DECODE LAUNCH (flm_layer.h): the whole decoder layer -- QKV GEMV, attention heads, Wo, FFN13 + SwiGLU, FFN2 -- in one launch; the
+//                         hand-offs are flag rounds, [W1; W3] is stashed in LDS by LDS-DMA under the attention ("fuse_layer" 0: without the QKV GEMV; "fuse_back" 0: off)
+//   k_gemv<QT,PRO,EPI,XR> group-quantized GEMV, HBM-bound; fused prologue (rmsnorm+quantize | quantize) and epilogue (store | residual add | SwiGLU | RoPE + KV-cache
+//                         append): the classifier of every token; every phase of a tensor-parallel rank's token; the per-phase fallback behind a timed-out hand-off
 //   k_attn_decode         fp32 single-query attention over the fp32 KV cache (heads split over workgroups at long contexts): the stand-alone launch
-//                         of the tensor-parallel token path, of "engine" 2 and of "fuse_attn_o" 0; the single-GPU default runs it inside k_attn_o
-//   k_attn_o<QT,XR,PREQ>  attention heads and the Wo GEMV in one launch (single GPU)
-//   k_qkv_attn_o<...>     the same with the QKV GEMV in front (long contexts: a head waits for the workgroups that reduced its rows only)
-//   k_ffn<QT,XR2>         FFN13 (+ SwiGLU) and FFN2 (+ residual) in one launch (single GPU)
-//   k_engine<QT>          the weight-streaming engine (flm_engine.h): several dependent GEMVs in one launch, loader waves feeding an LDS ring
-//                         with LDS-DMA across the phase edges, consumer waves doing prologues / dots / chains / hand-offs (single GPU, int8)
+//                         of the tensor-parallel token path and of "fuse_attn_o" 0
+//   k_attn_o<QT,XR,PREQ>  attention heads and the Wo GEMV in one launch ("fuse_back" 0; head sizes that are not multiples of 64; across tensor-parallel ranks)
+//   k_qkv_attn_o<...>     the same with the QKV GEMV in front (long contexts: a head waits for the workgroups that reduced its rows only; across ranks)
+//   k_ffn<QT,XR2>         FFN13 (+ SwiGLU) and FFN2 (+ residual) in one launch (beside k_attn_o / k_qkv_attn_o; across ranks as an option)
 //   batched prompt processing: k_rows_prologue, k_gemm_q8_mfma<EPI,WT,WR,NB> / k_gemm_q16_mfma (int8 matrix cores; epilogues store |
 //                         residual | SwiGLU | RoPE + KV rows), k_qk_mfma + k_attn_pv_mfma (fp32 matrix cores) /
 //                         k_attn_prefill_mq (VALU), k_rope_kv_rows, k_swiglu_rows
 //   k_embed, k_argmax_advance, k_xchg (tensor-parallel exchange)
 // plus small op-level kernels that expose the same __device__ functions to the parity tests.
+// (Round 3's weight-streaming engine -- loader / consumer waves around an LDS ring -- was measured slower than these launches and left the library in round 4:
+//  tools/experiments/engine/, numbers in profiles/r03_engine_timelines.txt.)
 //
-// The code lives in: flm_math.h (exact scalar / wave building blocks), flm_gemv.h, flm_attn.h, flm_engine.h, flm_prefill.h, flm_misc.h.
+// The code lives in: flm_math.h (exact scalar / wave building blocks), flm_gemv.h, flm_attn.h, flm_layer.h, flm_prefill.h, flm_misc.h.
 #pragma once
 #include "flm_math.h"
 #include "flm_gemv.h"
 #include "flm_attn.h"
 #include "flm_layer.h"
-#include "flm_engine.h"
 #include "flm_prefill.h"
 #include "flm_misc.h"

@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_attn_ffn(const GemvArgs aq, c
     stamp(9);
     float4 xv2[XR2 > 0 ? XR2 : 1], nv2[XR2 > 0 ? XR2 : 1];
     gemv_preload<QT, PRO_QUANT, XR2, true>(a2, xv2, nv2);
-    gemv_prologue<QT, PRO_QUANT, XR2, true, FLM_BACK_LATE2 != 0>(a2, lds, xv2, nv2, [&](int) { g2.issue(kAblate ? a2.ablate : 0, 2); });
+    gemv_prologue<QT, PRO_QUANT, XR2, true, FLM_BACK_LATE2 == 1>(a2, lds, xv2, nv2, [&](int) { if (FLM_BACK_LATE2 != 2 || (g2.wave & 1) == 0) g2.issue(kAblate ? a2.ablate : 0, 2); });
     stamp(10);
     g2.run(a2, lds, nostamp);
     stamp(11);

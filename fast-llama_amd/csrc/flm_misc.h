@@ -14,7 +14,7 @@ namespace flm {
 // x1 = embedding[token] (copy or dequantize; transformer.cpp:115-122)
 __global__ void k_embed(float* x, const void* emb, const float* emb_s, int emb_qt, int dim, const int* tok_ptr, unsigned* bar, unsigned* eng_base = nullptr) {
     const int tok = *tok_ptr;
-    // a new token: the engine launches' granule tags (flm_engine.h) move on; wrap long before a tag could become 0
+    // a new token: the epoch base of the tensor-parallel exchanges' flag values moves on; wrap long before a value could become 0
     if (eng_base && blockIdx.x == 0 && threadIdx.x == 0) { const unsigned b = *eng_base; *eng_base = b >= 0xFFF00000u ? 0u : b + 1024u; }
     if (bar && blockIdx.x == 0) {   // the flag lines (kFlagLines = 1536, 64 B apart) the workgroups of the token's fused launches wait on
 #pragma unroll

@@ -124,8 +124,8 @@ int  flm_sync(flm_ctx* ctx);
  * Classes: 0 embed, 1 qkv, 2 attn, 3 attn_o, 4 ffn13, 5 ffn2, 6 cls, 7 argmax, 8 allreduce (tensor parallel), and the two fused launches
  * the single-GPU token path runs instead of (2, 3) and (4, 5): 9 attn_wo (attention + Wo), 10 ffn (FFN13 + FFN2); count 0 = not in use.
  * 11 qkv_attn_wo: QKV + attention + Wo in one launch, what the token path runs instead of (1, 9) at long contexts ("fuse_qkv").
- * 12 eng_ffn, 13 eng_layer: launches of the weight-streaming engine (option "engine" 1: FFN13 + FFN2 instead of 10; 2: Wo + FFN13 + FFN2 +
- * the next layer's QKV, or the classifier after the last layer).
+ * 12 layer: the whole decoder layer in one launch (k_attn_ffn: QKV, attention, Wo, FFN13, FFN2 -- what the token path runs instead of (1, 9, 10) where a head is
+ * one workgroup and the head size a multiple of 64; option "fuse_layer"), 13 back: the same without the QKV GEMV ("fuse_layer" 0: instead of (9, 10)).
  * avg_us[c] = mean duration of ONE launch of class c (single GPU: the class's launches of one token are
  * enqueued back to back between one pair of events, so the figure is launch duration + dispatch gap and
  * agrees with a rocprofv3 kernel trace), count[c] = launches of that class per token.
@@ -158,8 +158,11 @@ int  flm_debug_read(flm_ctx* ctx, int what, int layer, float* out, size_t n);
  * "use_qk_mfma" 0 = prefill attention scores on VALU chains (default 1: v_mfma_f32_16x16x4_f32, the same bits),
  * "use_pv_mfma" 0 = prefill softmax x V on VALU chains (default 1: the weighted sum on v_mfma_f32_16x16x4_f32 too; needs use_qk_mfma),
  * "use_mfma" int8 prefill GEMM tile shape on the matrix cores: 1 (default) by problem size, 2 (or 0) always 64 x 64, 3 always 128 x 128 tiles.
- * "engine" the weight-streaming engine (fast-llama_amd/csrc/flm_engine.h; single GPU, int8): 0 (default) off, 1 = FFN13 + FFN2 per launch, 2 = Wo + FFN13 +
- *          FFN2 + the next layer's QKV (or the classifier) per launch; bit-identical, measured slower than the fused launches.
+ * "fuse_back" 0 = attention + Wo and FFN13 + FFN2 as two launches (k_attn_o, k_ffn) instead of one (k_attn_ffn, default 1: [W1; W3] stashed in LDS under the attention),
+ * "fuse_layer" 0 = the QKV GEMV as its own launch in front of k_attn_ffn (default 1: the whole decoder layer in one launch),
+ * "back_nst13" / "back_nst13_head" / "back_nst2" LDS stash slots (4.25 KiB each; -1 = as many as the LDS holds) a Wo workgroup fills with [W1; W3] under the attention /
+ *          a head workgroup fills behind its head / every workgroup fills with W2 behind its rows of hd; "back_pre13" how many of a workgroup's 16 waves request their
+ *          first register set of [W1; W3] in front of the x1 flag round (defaults -1, -1, 0, 16: tools/back_bench.py),
  * None of them changes a result bit.  (Perf-exploration switches that DO skip work -- "ablate", "trace" -- exist only in builds
  * with -DFLM_ABLATE=1; the product library answers FLM_ERR_INVALID to them.) */
 int  flm_set_option(flm_ctx* ctx, const char* key, int value);
@@ -170,7 +173,8 @@ int  flm_set_option(flm_ctx* ctx, const char* key, int value);
  *   "fallback"  1 = a cross-workgroup wait timed out during some call and the context fell back to one kernel per phase for good (flm_gpu.hip
  *               xwg_check; the call itself was re-run and returned correct results),
  *   "token_path" bit 0 attention + Wo fused, bit 1 FFN13 + FFN2 fused, bit 2 QKV joins the attention's launch at long contexts, bit 3 the same
- *               at every context, bits 4-5 the engine mode, bit 6 heads split over workgroups at long contexts.
+ *               at every context, bit 6 heads split over workgroups at long contexts, bit 7 attention .. FFN2 in one launch (k_attn_ffn), bit 8 with the QKV GEMV in front
+ *               (the whole layer in one launch).
  * Unknown key: FLM_ERR_INVALID. */
 int  flm_query(flm_ctx* ctx, const char* key, int* value);
 

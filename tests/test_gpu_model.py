@@ -350,3 +350,48 @@ def test_golden_logits_from_reference(gpu, name, shape, qt, f32):
         assert int(np.argmax(lg)) == int(g["ids"][i + 1])
         pos += 1
     ctx.close()
+
+
+def test_option_and_query_surface(gpu):
+    """flm_query reads back every option and the path flags; unknown keys and out-of-range values are errors, not silent no-ops; every legal on / off combination
+    of the launch-structure options on a tiny model gives the oracle's bits (the options choose launches, never arithmetic)"""
+    cfg = synth.make_config("tiny", ff.QT_INT8)
+    tensors = synth.make_tensors(cfg, seed=5)
+    ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
+    assert ctx.query("resident") == 1 and ctx.query("fallback") == 0
+    tp = ctx.query("token_path")
+    assert tp & 1 and tp & 2 and tp & 128 and tp & 256        # attention + Wo, FFN13 + FFN2, both in one launch, with the QKV GEMV in front
+    for key in ("fold_xchg", "cu_parts", "fuse_attn_o", "fuse_ffn", "fuse_qkv", "fuse_back", "fuse_layer", "back_nst13", "back_nst13_head", "back_nst2", "back_pre13",
+                "attn_split", "use_graph", "use_mfma", "use_prefill", "wg_per_cu"):
+        ctx.query(key)
+    with pytest.raises(gpu.FlmError):
+        ctx.query("no_such_key")
+    with pytest.raises(gpu.FlmError):
+        ctx.set_option("no_such_key", 1)
+    with pytest.raises(gpu.FlmError):
+        ctx.set_option("cu_parts", 3)                          # 1, 2, 4 or 8
+    with pytest.raises(gpu.FlmError):
+        ctx.set_option("engine", 1)                            # round 3's engine left the library
+    ctx.close()
+    om = O.OracleModel(cfg, tensors)
+    prompt = _prompt(cfg.vocab_size, 4)
+    want = [om.forward(prompt, 0)]
+    cur, pos = int(np.argmax(want[0])), len(prompt)
+    for _ in range(2):
+        want.append(om.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(want[-1])); pos += 1
+    import itertools
+    keys = ("fuse_layer", "fuse_back", "fuse_attn_o", "fuse_ffn", "use_graph")
+    for vals in itertools.product((0, 1), repeat=len(keys)):
+        for fq in (0, 2):
+            ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
+            for k, v in zip(keys, vals):
+                ctx.set_option(k, v)
+            ctx.set_option("fuse_qkv", fq)
+            lg = ctx.forward(prompt, 0)
+            assert bits_equal(lg, want[0]), (vals, fq)
+            cur, pos = int(np.argmax(lg)), len(prompt)
+            for i in range(2):
+                lg = ctx.forward(np.array([cur], np.int32), pos)
+                assert bits_equal(lg, want[i + 1]), (vals, fq, i)
+                cur = int(np.argmax(lg)); pos += 1
+            ctx.close()

@@ -13,7 +13,6 @@ ctx.upload_all(synth.make_tensors(cfg, seed=1))
 if wg: ctx.set_option("wg_per_cu", wg)
 abl = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 if abl: ctx.set_option("ablate", abl)
-if os.environ.get("FLM_ENGINE") is not None: ctx.set_option("engine", int(os.environ["FLM_ENGINE"]))
 if os.environ.get("FLM_SPLIT") is not None: ctx.set_option("attn_split", int(os.environ["FLM_SPLIT"]))
 if os.environ.get("FLM_FUSE") is not None: ctx.set_option("fuse_attn_o", int(os.environ["FLM_FUSE"]))
 prompt = np.arange(1, pos + 1, dtype=np.int32) % cfg.vocab_size
