@@ -437,7 +437,7 @@ __device__ __forceinline__ void attn_head_any(const AttnArgs& a, const int h, ch
     }
 }
 // batched prefill: workgroup (h, i) is query i of the batch, at position pos0 + i, over the cache rows 0 .. pos0 + i
-__global__ void __launch_bounds__(kAttnBlock) k_attn_prefill(const AttnArgs a, int pos0, int row_stride) {
+inline __global__ void __launch_bounds__(kAttnBlock) k_attn_prefill(const AttnArgs a, int pos0, int row_stride) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int i = blockIdx.y;
     attn_head_any<false, false>(a, blockIdx.x, lds, pos0 + i + 1, a.q + (size_t)i * row_stride, a.out + (size_t)i * row_stride);
@@ -724,7 +724,7 @@ __host__ inline size_t pv_mfma_lds_bytes(int tmax, int qw = kPvQ) { return ((siz
 // queries per workgroup: 16 while their exps fit the LDS (64 bytes per position: up to ~2500 positions), then 8, 4, 2, 1 -- the rows
 // of the A operand past qw are fed zeros; the bits of a (query, dimension) chain do not depend on its row
 __host__ inline int pv_mfma_queries(int tmax, size_t lds_max) { int qw = kPvQ; while (qw > 1 && pv_mfma_lds_bytes(tmax, qw) > lds_max) qw >>= 1; return qw; }
-__global__ void __launch_bounds__(256) k_attn_pv_mfma(const AttnArgs a, int pos0, int row_stride, int B, int qw) {
+inline __global__ void __launch_bounds__(256) k_attn_pv_mfma(const AttnArgs a, int pos0, int row_stride, int B, int qw) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     typedef float v2f __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) char lds[];

@@ -1,0 +1,74 @@
+// flm_layerlaunch.hip -- host side of k_attn_ffn (flm_layer.h): the whole decoder layer, or attention .. FFN2, as one launch.
+#include "flm_host.h"
+
+namespace fh {
+
+// attention + Wo + FFN13 + FFN2 of layer l in one launch (k_attn_ffn, flm_layer.h); returns FLM_ERR_UNSUPPORTED when the shape does not allow it
+template <int QT>
+int launch_attn_ffn(flm_ctx* c, hipStream_t st, int l, bool with_qkv) {
+    const auto& d = c->d;
+    constexpr int esz = QTraits<QT>::kEsz;
+    const int all = c->cu_count < 256 ? c->cu_count : 256, parts = c->heads_local, wgs_o = all - parts;
+    if (c->world != 1 || c->hs % kGroup != 0 || wgs_o < 1 || parts > 256) return FLM_ERR_UNSUPPORTED;
+    GemvArgs aq = args_qkv(c, l), ao = args_o(c, l), a13 = args_ffn13(c, l), a2 = args_ffn2(c, l);
+    GemvPlan Pq{}, Po, P13, P2;
+    int r = plan_gemv<QT, PRO_QUANT, EPI_RESIDUAL>(c, ao, wgs_o, Po); if (r) return r;
+    if (with_qkv) {
+        r = plan_gemv<QT, PRO_RMSNORM_QUANT, EPI_ROPE_KV>(c, aq, all, Pq); if (r) return r;
+        if ((aq.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4) > 1) return FLM_ERR_UNSUPPORTED;
+    }
+    r = plan_gemv<QT, PRO_RMSNORM_QUANT, EPI_SWIGLU>(c, a13, all, P13); if (r) return r;
+    r = plan_gemv<QT, PRO_QUANT, EPI_RESIDUAL>(c, a2, all, P2); if (r) return r;
+    const int r13 = (a13.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4), r2 = (a2.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4);
+    if (r13 > 1 || r2 > 3) return FLM_ERR_UNSUPPORTED;
+    // a workgroup with a single pass needs one strip buffer: the LDS above the phases' own layouts is the stash
+    auto one_pass = [&](GemvArgs& a, GemvPlan& P, bool two, int rows_per_item = 1) {
+        const int rows = a.items * rows_per_item, npass = (rows + P.Rm - 1) / P.Rm;
+        if (npass <= P.grid) { a.nbuf = 1; P.nbuf = 1; P.lds = (size_t)gemv_lds_layout(a.n, esz, true, P.Rm, 64 >> P.cb_shift, two, 1).total; }
+    };
+    one_pass(ao, Po, false); one_pass(a13, P13, true); one_pass(a2, P2, false);
+    size_t own = Po.lds; if (P13.lds > own) own = P13.lds; if (P2.lds > own) own = P2.lds;
+    if (with_qkv) { one_pass(aq, Pq, false, 2); if (Pq.lds > kLdsMax) return FLM_ERR_UNSUPPORTED; }     // (the QKV phase is over before the first stash request: its layout may overlap the slots)
+    own = (own + 255) & ~(size_t)255;
+    const size_t lds_attn = attn_lds_bytes(d.max_seq_len, c->hs, false);
+    if (own > kLdsMax || lds_attn > kLdsMax) return FLM_ERR_UNSUPPORTED;
+    const int slot = kStepBlk * 1024 + 256, fit = (int)((kLdsMax - own) / slot);
+    auto slots = [&](int want) { int n = want < 0 ? fit : want; if (n > fit) n = fit; if (n > 32) n = 32; return n < 0 ? 0 : n; };
+    AttnArgs aa = args_attn(c, l, 1);
+    aa.oq = c->att_q; aa.os = c->att_qs; aa.oqt = QT;
+    ao.xq = c->att_q; ao.xs = c->att_qs;
+    BackArgs p{};
+    p.n_heads = parts; p.grido = Po.grid; p.grid13 = P13.grid; p.grid2 = P2.grid;
+    p.flag_h = c->flag_lines; p.flag_hd = c->flag_lines + 512 * 16; p.flag_x = c->flag_lines + 1024 * 16;
+    p.gridq = with_qkv ? Pq.grid : 0; p.flag_q = c->flag_lines + 768 * 16;
+    p.target = (unsigned)(l + 1); p.err = c->xwg_err;
+    p.st_base = (unsigned)own; p.nst13 = slots(c->back_nst13); p.nst13_head = slots(c->back_nst13_head); p.nst2 = slots(c->back_nst2); p.pre13 = c->back_pre13 < 0 ? 0 : c->back_pre13 > 16 ? 16 : c->back_pre13;
+    if (kAblate && c->trace_class == 102 && l == 0) { p.trace = c->trace; a13.trace = c->trace + 256 * 16; a2.trace = c->trace + 2 * 256 * 16; }   // tools/trace_back.py
+    int grid = parts + Po.grid; if (P13.grid > grid) grid = P13.grid; if (P2.grid > grid) grid = P2.grid; if (with_qkv && Pq.grid > grid) grid = Pq.grid;
+    if (grid > all) return FLM_ERR_UNSUPPORTED;
+    {   // the stash takes the rest of the CU's 160 KiB: raise the kernels' dynamic-LDS limit, once per device
+        static std::mutex mu; static bool done[64] = {false};
+        std::lock_guard<std::mutex> lk(mu);
+        if (c->device >= 0 && c->device < 64 && !done[c->device]) {
+            const void* fns[] = {(const void*)&k_attn_ffn<QT_INT8, 1, false>, (const void*)&k_attn_ffn<QT_INT8, 3, false>, (const void*)&k_attn_ffn<QT_INT16, 1, false>, (const void*)&k_attn_ffn<QT_INT16, 3, false>,
+                                 (const void*)&k_attn_ffn<QT_INT8, 1, true>, (const void*)&k_attn_ffn<QT_INT8, 3, true>, (const void*)&k_attn_ffn<QT_INT16, 1, true>, (const void*)&k_attn_ffn<QT_INT16, 3, true>};
+            for (const void* f : fns) HIPC(c, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
+            done[c->device] = true;
+        }
+    }
+    const dim3 g3(grid), b3(kGemvBlock);
+    if (with_qkv) {
+        if (r2 <= 1) hipLaunchKernelGGL((k_attn_ffn<QT, 1, true>), g3, b3, kLdsMax, st, aq, aa, ao, a13, a2, p);
+        else         hipLaunchKernelGGL((k_attn_ffn<QT, 3, true>), g3, b3, kLdsMax, st, aq, aa, ao, a13, a2, p);
+    }
+    else if (r2 <= 1) hipLaunchKernelGGL((k_attn_ffn<QT, 1, false>), g3, b3, kLdsMax, st, aq, aa, ao, a13, a2, p);
+    else              hipLaunchKernelGGL((k_attn_ffn<QT, 3, false>), g3, b3, kLdsMax, st, aq, aa, ao, a13, a2, p);
+    HIPC(c, hipGetLastError());
+    return FLM_OK;
+}
+
+int launch_layer(flm_ctx* c, hipStream_t st, int qt, int l, bool with_qkv) {
+    return qt == FLM_QT_INT8 ? launch_attn_ffn<QT_INT8>(c, st, l, with_qkv) : launch_attn_ffn<QT_INT16>(c, st, l, with_qkv);
+}
+
+} // namespace fh

@@ -12,7 +12,7 @@ namespace flm {
 // small kernels
 // ------------------------------------------------------------------------------------------
 // x1 = embedding[token] (copy or dequantize; transformer.cpp:115-122)
-__global__ void k_embed(float* x, const void* emb, const float* emb_s, int emb_qt, int dim, const int* tok_ptr, unsigned* bar, unsigned* eng_base = nullptr) {
+inline __global__ void k_embed(float* x, const void* emb, const float* emb_s, int emb_qt, int dim, const int* tok_ptr, unsigned* bar, unsigned* eng_base = nullptr) {
     const int tok = *tok_ptr;
     // a new token: the epoch base of the tensor-parallel exchanges' flag values moves on; wrap long before a value could become 0
     if (eng_base && blockIdx.x == 0 && threadIdx.x == 0) { const unsigned b = *eng_base; *eng_base = b >= 0xFFF00000u ? 0u : b + 1024u; }
@@ -36,7 +36,7 @@ __global__ void k_embed(float* x, const void* emb, const float* emb_s, int emb_q
 // sample_argmax (src/transformer/sampler.cpp:36-47): first maximum wins.  One workgroup.
 // Also advances the device-resident decode state: tok <- argmax, pos <- pos+1, out[step++] <- argmax.
 struct DecodeState { int pos; int tok; int step; int pad; };
-__global__ void __launch_bounds__(1024) k_argmax_advance(const float* logits, int n, DecodeState* st, int* out_tokens, int advance, int out_cap) {
+inline __global__ void __launch_bounds__(1024) k_argmax_advance(const float* logits, int n, DecodeState* st, int* out_tokens, int advance, int out_cap) {
     __shared__ float bv[16]; __shared__ int bi[16];
     float best = -INFINITY; int idx = 0x7fffffff;
     // ascending index order within a thread and strict '>' keep the FIRST maximum
@@ -71,10 +71,10 @@ __global__ void __launch_bounds__(1024) k_argmax_advance(const float* logits, in
     }
 }
 // prompt feeding: pos <- pos+1, tok <- prompt[++step]
-__global__ void k_advance_prompt(DecodeState* st, const int* prompt) {
+inline __global__ void k_advance_prompt(DecodeState* st, const int* prompt) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { st->step += 1; st->pos += 1; st->tok = prompt[st->step]; }
 }
-__global__ void k_set_step(DecodeState* st, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) st->step = v; }
+inline __global__ void k_set_step(DecodeState* st, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) st->step = v; }
 // ------------------------------------------------------------------------------------------
 // Tensor parallel, one-shot peer-to-peer exchange (instead of an RCCL all-gather per activation vector: ~3 us against ~12).
 // The producing kernel has stored its slice of the vector into EVERY rank's buffer (GemvArgs::out_peer).  This one-workgroup
@@ -84,7 +84,7 @@ __global__ void k_set_step(DecodeState* st, int v) { if (threadIdx.x == 0 && blo
 // a captured graph replays correctly.  flags: [kind][rank] lines of 64 bytes.
 // ------------------------------------------------------------------------------------------
 struct XchgArgs { unsigned* local_flags; unsigned* peer_flags[8]; unsigned* epoch; int* err; int rank, world, kind; };
-__global__ void __launch_bounds__(64) k_xchg(const XchgArgs x) {
+inline __global__ void __launch_bounds__(64) k_xchg(const XchgArgs x) {
     const int r = threadIdx.x;
     const unsigned e = *x.epoch + 1;
     // release: the slices this rank's producing kernel stored into the peers' buffers (system-scope stores, completed by the kernel boundary in front of
@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(64) k_xchg(const XchgArgs x) {
 // ---- op-level test kernels: thin launchers over the same __device__ functions ----
 // square_sum both ways: out[0] the speculative wave evaluation (sq_chain_spec), out[1] the plain sequential chains (sq_chain);
 // out[2..5] the 4 strided lanes from sq_chain_spec, out[6..9] its round counts (-1: it fell back to the plain chain)
-__global__ void __launch_bounds__(256) k_op_square_sum(float* out, const float* x, int n) {
+inline __global__ void __launch_bounds__(256) k_op_square_sum(float* out, const float* x, int n) {
     extern __shared__ float sm[];
     const int n4 = n / 4, ns = n4 + 8;
     const int bs = chain_bshift(n), B = 1 << bs, LS = B + 4, CS = 64 * LS;
@@ -150,22 +150,22 @@ __global__ void __launch_bounds__(256) k_op_square_sum(float* out, const float* 
         out[2] = red[0]; out[3] = red[1]; out[4] = red[2]; out[5] = red[3];
     }
 }
-__global__ void k_op_swiglu(float* xo, const float* xr, size_t n) {
+inline __global__ void k_op_swiglu(float* xo, const float* xr, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) xo[i] = swiglu_elem(xo[i], xr[i]);
 }
 // elementary functions as the kernels evaluate them: fn 0 expf_ref(x), 1 sqrtf(x), 2 x / y, 3 rms_scale(x, n = (int)y)
-__global__ void k_op_math(int fn, float* x, const float* y, size_t n) {
+inline __global__ void k_op_math(int fn, float* x, const float* y, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float v = x[i];
         x[i] = fn == 0 ? expf_ref(v) : fn == 1 ? __builtin_sqrtf(v) : fn == 2 ? __fdiv_rn(v, y[i]) : rms_scale(v, (int)y[i]);
     }
 }
-__global__ void k_op_rope(float* o, const float* x, int n_dims, const float* c, const float* s) {
+inline __global__ void k_op_rope(float* o, const float* x, int n_dims, const float* c, const float* s) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (2 * i + 1 < n_dims) rope_pair(x[2 * i], x[2 * i + 1], c[i], s[i], o[2 * i], o[2 * i + 1]);
 }
 // softmax_sisd over n entries, one workgroup (same statements as k_attn_decode's softmax)
-__global__ void __launch_bounds__(kBlock) k_op_softmax(float* x, int n) {
+inline __global__ void __launch_bounds__(kBlock) k_op_softmax(float* x, int n) {
     __shared__ float red[16];
     float lm = -INFINITY;
     for (int i = threadIdx.x; i < n; i += kBlock) lm = fmaxf(lm, x[i]);
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(kBlock) k_op_softmax(float* x, int n) {
     for (int i = threadIdx.x; i < n; i += kBlock) x[i] = __fdiv_rn(x[i], L);
 }
 // append one token's k (with RoPE), v to the caches and rotate q: what EPI_ROPE_KV does, for flm_op_attention
-__global__ void k_op_kv_append(float* q, const float* k, const float* v, float* kc, float* vc, const float* c, const float* s,
+inline __global__ void k_op_kv_append(float* q, const float* k, const float* v, float* kc, float* vc, const float* c, const float* s,
                                int n_heads, int hs, int max_seq, int pos) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;      // pair index over heads*hs/2
     if (i >= n_heads * hs / 2) return;

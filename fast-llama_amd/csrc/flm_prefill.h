@@ -23,7 +23,7 @@ namespace flm {
 //   k_attn_prefill      causal attention: one workgroup per (head, query), the decode attention with T = pos + i + 1
 //   k_swiglu_rows       hd[b] = swiglu(gate[b], up[b])
 // ------------------------------------------------------------------------------------------
-__global__ void k_embed_rows(float* x, const void* emb, const float* emb_s, int emb_qt, int dim, const int* tokens) {
+inline __global__ void k_embed_rows(float* x, const void* emb, const float* emb_s, int emb_qt, int dim, const int* tokens) {
     const int tok = tokens[blockIdx.x];
     float* xo = x + (size_t)blockIdx.x * dim;
     for (int e = threadIdx.x; e < dim; e += blockDim.x) {
@@ -86,7 +86,7 @@ __device__ __forceinline__ void st_result_tp(float* o, const size_t idx, const f
     for (int i = 0; i < n_peer; ++i) __hip_atomic_store(peer[i] + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // the group-major copy of a weight matrix's scales (made once, when the first prompt is batched)
-__global__ void k_transpose_scales(const float* s, float* st, int rows, int sn) {
+inline __global__ void k_transpose_scales(const float* s, float* st, int rows, int sn) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < (size_t)rows * sn) { const int r = (int)(i / sn), g = (int)(i - (size_t)r * sn); st[(size_t)g * rows + r] = s[i]; }
 }
@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(256, 3) k_gemm_q16_mfma(const GemmArgs a) {
 }
 
 // qkv[b] = [q ; k ; v] (dim each) of token b at position pos0 + b: RoPE on q and k (rope_v2 pairs), q -> qout[b], k / v -> cache rows
-__global__ void k_rope_kv_rows(const float* qkv, float* qout, float* kcache, float* vcache, const float* rope_cos, const float* rope_sin,
+inline __global__ void k_rope_kv_rows(const float* qkv, float* qout, float* kcache, float* vcache, const float* rope_cos, const float* rope_sin,
                                int dim, int hs, int max_seq, int pos0) {
     const int b = blockIdx.x, pos = pos0 + b;
     const float* in = qkv + (size_t)b * 3 * dim;
@@ -433,7 +433,7 @@ __global__ void k_rope_kv_rows(const float* qkv, float* qout, float* kcache, flo
 
 // gu[b] = [gate ; up] (hidden each, this rank's slice) -> hd[b * ldo + i]; tensor parallel: hd = this rank's columns of every rank's [tokens][hidden_dim]
 struct SwigluPeers { float* p[7]; int n; };
-__global__ void k_swiglu_rows(float* hd, const float* gu, int hidden, int ldo, const SwigluPeers peers) {
+inline __global__ void k_swiglu_rows(float* hd, const float* gu, int hidden, int ldo, const SwigluPeers peers) {
     const float* g = gu + (size_t)blockIdx.x * 2 * hidden;
     for (int i = threadIdx.x; i < hidden; i += blockDim.x) st_result_tp(hd, (size_t)blockIdx.x * ldo + i, swiglu_elem(g[i], g[hidden + i]), peers.p, peers.n);   // o1.swiglu(o3) transformer.cpp:481
 }
