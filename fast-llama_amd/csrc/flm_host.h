@@ -197,7 +197,7 @@ GemvArgs args_ffn2(flm_ctx* c, int l);
 GemvArgs args_cls(flm_ctx* c);
 void set_fold(flm_ctx* c, GemvArgs& a, int l, int kind);
 // the whole decoder layer (with_qkv) / attention .. FFN2 of layer l in one launch (flm_layerlaunch.hip); FLM_ERR_UNSUPPORTED when the shape does not allow it
-int launch_layer(flm_ctx* c, hipStream_t st, int qt, int l, bool with_qkv);
+int launch_layer(flm_ctx* c, hipStream_t st, int qt, int l, bool with_qkv, int G = 1);   // G: workgroups per head (attn_parts)
 // one activation exchange between the tensor-parallel ranks (flm_token.hip)
 enum XKind { XK_ATT = 0, XK_X1 = 1, XK_HD = 2, XK_LOGITS = 3 };
 int exchange(flm_ctx* c, hipStream_t st, int kind, float* full, float* mine, int count);

@@ -67,7 +67,9 @@ __device__ __forceinline__ void poll_lines(const unsigned* flag, int n, unsigned
 // QKV = true: the whole layer -- the QKV GEMV (k_gemv<RMSNORM_QUANT, ROPE_KV> verbatim, every workgroup its rows of [Wq; Wk; Wv]) in front, as in k_qkv_attn_o: a head waits for
 // the lines of the <= 3 * ceil(hs / Rm + 1) workgroups that reduced its rows of q, k and v and reads them with coherent loads; the other workgroups go straight
 // from their last QKV row to the Wo / stash requests, so the memory pipeline has work across what used to be a kernel boundary and a launch ramp.
-template <int QT, int XR2, bool QKV = false>
+// SPLIT (long contexts): a head is spread over G = aa.G workgroups (attn_head<.., SPLIT>); n_heads counts head PARTS; a part's 32 output dimensions are half a quant group,
+// so the Wo workgroups fetch the fp32 vector and quantize it themselves (dim <= 4096: one round).
+template <int QT, int XR2, bool QKV = false, bool SPLIT = false>
 __global__ void __launch_bounds__(kGemvBlock, 4) k_attn_ffn(const GemvArgs aq, const AttnArgs aa, const GemvArgs ao, const GemvArgs a13, const GemvArgs a2, const BackArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     auto nostamp = [](int) {};
@@ -92,12 +94,13 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_attn_ffn(const GemvArgs aq, c
         }
     }
     if ((int)blockIdx.x < p.n_heads) {
+        const int G = SPLIT ? aa.G : 1, hh = blockIdx.x / G;
         if constexpr (QKV) {
             if (threadIdx.x < 256) {
                 // lane i: does workgroup i reduce a row of this head's q, k or v?  (pass p = rows [p Rm, (p + 1) Rm) of [Wq; Wk; Wv], workgroup p mod gridq)
                 bool need = false;
                 if ((int)threadIdx.x < p.gridq) {
-                    const unsigned Rm = aq.rows_per_pass, hs = aa.hs, nq = p.gridq, h = blockIdx.x;
+                    const unsigned Rm = aq.rows_per_pass, hs = aa.hs, nq = p.gridq, h = hh;
 #pragma unroll
                     for (int m = 0; m < 3; ++m) {
                         const unsigned r0 = (m == 0 ? 0u : m == 1 ? (unsigned)aq.dim : (unsigned)(aq.dim + aq.kv_dim)) + h * hs;
@@ -114,7 +117,7 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_attn_ffn(const GemvArgs aq, c
             }
             __syncthreads();
         }
-        attn_head_any<QKV, false>(aa, blockIdx.x, lds, *aa.pos_ptr + 1, aa.q, aa.out);
+        attn_head_any<QKV, SPLIT>(aa, hh, lds, *aa.pos_ptr + 1, aa.q, aa.out, blockIdx.x % G, G);
         stamp(1);
         wait_stores_done();                                                     // every wave: its part of the head's output is where the others will read it
         __syncthreads();                                                        // (and the LDS is free)
@@ -148,7 +151,10 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_attn_ffn(const GemvArgs aq, c
         __syncthreads();
         stamp(2);
         float4 xv[1], nv[1];
-        gemv_prologue<QT, PRO_NONE, 0, true>(ao, lds, xv, nv, [](int) {});   // the heads' output arrives quantized (PREQ)
+        if constexpr (SPLIT) {
+            gemv_preload<QT, PRO_QUANT, 1, true>(ao, xv, nv);
+            gemv_prologue<QT, PRO_QUANT, 1>(ao, lds, xv, nv, [](int) {});
+        } else gemv_prologue<QT, PRO_NONE, 0, true>(ao, lds, xv, nv, [](int) {});   // the heads' output arrives quantized (PREQ)
         g.run(ao, lds, nostamp);
         stamp(3);
         wait_stores_done();                                                     // every wave: its rows of x1 are where the others will read them

@@ -5,11 +5,12 @@ namespace fh {
 
 // attention + Wo + FFN13 + FFN2 of layer l in one launch (k_attn_ffn, flm_layer.h); returns FLM_ERR_UNSUPPORTED when the shape does not allow it
 template <int QT>
-int launch_attn_ffn(flm_ctx* c, hipStream_t st, int l, bool with_qkv) {
+int launch_attn_ffn(flm_ctx* c, hipStream_t st, int l, bool with_qkv, int G) {
     const auto& d = c->d;
     constexpr int esz = QTraits<QT>::kEsz;
-    const int all = c->cu_count < 256 ? c->cu_count : 256, parts = c->heads_local, wgs_o = all - parts;
-    if (c->world != 1 || c->hs % kGroup != 0 || wgs_o < 1 || parts > 256) return FLM_ERR_UNSUPPORTED;
+    const int all = c->cu_count < 256 ? c->cu_count : 256, parts = c->heads_local * G, wgs_o = all - parts;
+    if (c->world != 1 || (G == 1 && c->hs % kGroup != 0) || wgs_o < 8 || parts > 256) return FLM_ERR_UNSUPPORTED;
+    if (G > 1 && !with_qkv) return FLM_ERR_UNSUPPORTED;                     // (split heads: only the whole-layer form is instantiated)
     GemvArgs aq = args_qkv(c, l), ao = args_o(c, l), a13 = args_ffn13(c, l), a2 = args_ffn2(c, l);
     GemvPlan Pq{}, Po, P13, P2;
     int r = plan_gemv<QT, PRO_QUANT, EPI_RESIDUAL>(c, ao, wgs_o, Po); if (r) return r;
@@ -21,6 +22,7 @@ int launch_attn_ffn(flm_ctx* c, hipStream_t st, int l, bool with_qkv) {
     r = plan_gemv<QT, PRO_QUANT, EPI_RESIDUAL>(c, a2, all, P2); if (r) return r;
     const int r13 = (a13.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4), r2 = (a2.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4);
     if (r13 > 1 || r2 > 3) return FLM_ERR_UNSUPPORTED;
+    if (G > 1 && (ao.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4) > 1) return FLM_ERR_UNSUPPORTED;
     // a workgroup with a single pass needs one strip buffer: the LDS above the phases' own layouts is the stash
     auto one_pass = [&](GemvArgs& a, GemvPlan& P, bool two, int rows_per_item = 1) {
         const int rows = a.items * rows_per_item, npass = (rows + P.Rm - 1) / P.Rm;
@@ -30,13 +32,12 @@ int launch_attn_ffn(flm_ctx* c, hipStream_t st, int l, bool with_qkv) {
     size_t own = Po.lds; if (P13.lds > own) own = P13.lds; if (P2.lds > own) own = P2.lds;
     if (with_qkv) { one_pass(aq, Pq, false, 2); if (Pq.lds > kLdsMax) return FLM_ERR_UNSUPPORTED; }     // (the QKV phase is over before the first stash request: its layout may overlap the slots)
     own = (own + 255) & ~(size_t)255;
-    const size_t lds_attn = attn_lds_bytes(d.max_seq_len, c->hs, false);
+    const size_t lds_attn = attn_lds_bytes(d.max_seq_len, c->hs, G > 1);
     if (own > kLdsMax || lds_attn > kLdsMax) return FLM_ERR_UNSUPPORTED;
     const int slot = kStepBlk * 1024 + 256, fit = (int)((kLdsMax - own) / slot);
     auto slots = [&](int want) { int n = want < 0 ? fit : want; if (n > fit) n = fit; if (n > 32) n = 32; return n < 0 ? 0 : n; };
-    AttnArgs aa = args_attn(c, l, 1);
-    aa.oq = c->att_q; aa.os = c->att_qs; aa.oqt = QT;
-    ao.xq = c->att_q; ao.xs = c->att_qs;
+    AttnArgs aa = args_attn(c, l, G);
+    if (G == 1) { aa.oq = c->att_q; aa.os = c->att_qs; aa.oqt = QT; ao.xq = c->att_q; ao.xs = c->att_qs; }   // the heads hand their output over quantized
     BackArgs p{};
     p.n_heads = parts; p.grido = Po.grid; p.grid13 = P13.grid; p.grid2 = P2.grid;
     p.flag_h = c->flag_lines; p.flag_hd = c->flag_lines + 512 * 16; p.flag_x = c->flag_lines + 1024 * 16;
@@ -51,13 +52,18 @@ int launch_attn_ffn(flm_ctx* c, hipStream_t st, int l, bool with_qkv) {
         std::lock_guard<std::mutex> lk(mu);
         if (c->device >= 0 && c->device < 64 && !done[c->device]) {
             const void* fns[] = {(const void*)&k_attn_ffn<QT_INT8, 1, false>, (const void*)&k_attn_ffn<QT_INT8, 3, false>, (const void*)&k_attn_ffn<QT_INT16, 1, false>, (const void*)&k_attn_ffn<QT_INT16, 3, false>,
-                                 (const void*)&k_attn_ffn<QT_INT8, 1, true>, (const void*)&k_attn_ffn<QT_INT8, 3, true>, (const void*)&k_attn_ffn<QT_INT16, 1, true>, (const void*)&k_attn_ffn<QT_INT16, 3, true>};
+                                 (const void*)&k_attn_ffn<QT_INT8, 1, true>, (const void*)&k_attn_ffn<QT_INT8, 3, true>, (const void*)&k_attn_ffn<QT_INT16, 1, true>, (const void*)&k_attn_ffn<QT_INT16, 3, true>,
+                                 (const void*)&k_attn_ffn<QT_INT8, 1, true, true>, (const void*)&k_attn_ffn<QT_INT8, 3, true, true>, (const void*)&k_attn_ffn<QT_INT16, 1, true, true>, (const void*)&k_attn_ffn<QT_INT16, 3, true, true>};
             for (const void* f : fns) HIPC(c, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
             done[c->device] = true;
         }
     }
     const dim3 g3(grid), b3(kGemvBlock);
-    if (with_qkv) {
+    if (G > 1) {
+        if (r2 <= 1) hipLaunchKernelGGL((k_attn_ffn<QT, 1, true, true>), g3, b3, kLdsMax, st, aq, aa, ao, a13, a2, p);
+        else         hipLaunchKernelGGL((k_attn_ffn<QT, 3, true, true>), g3, b3, kLdsMax, st, aq, aa, ao, a13, a2, p);
+    }
+    else if (with_qkv) {
         if (r2 <= 1) hipLaunchKernelGGL((k_attn_ffn<QT, 1, true>), g3, b3, kLdsMax, st, aq, aa, ao, a13, a2, p);
         else         hipLaunchKernelGGL((k_attn_ffn<QT, 3, true>), g3, b3, kLdsMax, st, aq, aa, ao, a13, a2, p);
     }
@@ -67,8 +73,8 @@ int launch_attn_ffn(flm_ctx* c, hipStream_t st, int l, bool with_qkv) {
     return FLM_OK;
 }
 
-int launch_layer(flm_ctx* c, hipStream_t st, int qt, int l, bool with_qkv) {
-    return qt == FLM_QT_INT8 ? launch_attn_ffn<QT_INT8>(c, st, l, with_qkv) : launch_attn_ffn<QT_INT16>(c, st, l, with_qkv);
+int launch_layer(flm_ctx* c, hipStream_t st, int qt, int l, bool with_qkv, int G) {
+    return qt == FLM_QT_INT8 ? launch_attn_ffn<QT_INT8>(c, st, l, with_qkv, G) : launch_attn_ffn<QT_INT16>(c, st, l, with_qkv, G);
 }
 
 } // namespace fh

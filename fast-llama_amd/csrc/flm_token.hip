@@ -289,9 +289,9 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
     const bool span = fold && (c->resident || c->cu_parts > 1);
     for (int l = 0; l < L; ++l) {
         bool fused = false;
-        const bool back_ok = !tp && c->fuse_back && c->fuse_attn_o && c->fuse_ffn && G == 1 && !c->timing && (c->trace_class < 0 || c->trace_class == 102);
+        const bool back_ok = !tp && c->fuse_back && c->fuse_attn_o && c->fuse_ffn && !c->timing && (c->trace_class < 0 || c->trace_class == 102);
         if (back_ok && c->fuse_layer) {   // the whole layer in one launch
-            r = launch_layer(c, st, qt, l, true);
+            r = launch_layer(c, st, qt, l, true, G);
             if (r == FLM_OK) continue; else if (r != FLM_ERR_UNSUPPORTED) return r;
         }
         if (((!tp && c->fuse_attn_o && (c->fuse_qkv >= 2 || (c->fuse_qkv && G > 1))) || (span && c->tp_fuse_attn >= 2)) && !c->timing && c->trace_class < 0) {   // QKV + attention + ATTN_O in one launch (tensor parallel: "tp_fuse_attn" 2)
@@ -302,7 +302,7 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
             Tick t(c, st, KC_QKV);
             r = launch_gemv<PRO_RMSNORM_QUANT, EPI_ROPE_KV>(c, st, qt, folded(traced(args_qkv(c, l), KC_QKV, l), l - 1, 3), wgs, coh); if (r) return r;
         }
-        if (!fused && back_ok) {   // attention + ATTN_O + FFN13 + FFN2 in one launch
+        if (!fused && back_ok && G == 1) {   // attention + ATTN_O + FFN13 + FFN2 in one launch
             r = launch_layer(c, st, qt, l, false);
             if (r == FLM_OK) continue; else if (r != FLM_ERR_UNSUPPORTED) return r;
         }
@@ -414,8 +414,8 @@ int flm_kernel_times(flm_ctx* c, int pos, int iters, float* avg_us, int32_t* cou
                          if (!c->fuse_attn_o || !(c->fuse_qkv >= 2 || (c->fuse_qkv && G > 1))) return FLM_ERR_UNSUPPORTED;
                          return qt == FLM_QT_INT8 ? launch_qkv_attn_o<QT_INT8>(c, st, l, G) : launch_qkv_attn_o<QT_INT16>(c, st, l, G); }
         case KC_LAYER: case KC_BACK: {
-                         if (c->world > 1 || !c->fuse_back || !c->fuse_attn_o || !c->fuse_ffn || attn_parts(c, pos + 1) != 1 || (kc == KC_LAYER) != (c->fuse_layer != 0)) return FLM_ERR_UNSUPPORTED;
-                         return launch_layer(c, st, qt, l, kc == KC_LAYER); }
+                         if (c->world > 1 || !c->fuse_back || !c->fuse_attn_o || !c->fuse_ffn || (kc == KC_BACK && attn_parts(c, pos + 1) != 1) || (kc == KC_LAYER) != (c->fuse_layer != 0)) return FLM_ERR_UNSUPPORTED;
+                         return launch_layer(c, st, qt, l, kc == KC_LAYER, attn_parts(c, pos + 1)); }
         default: return FLM_OK;
         }
     };

@@ -279,7 +279,7 @@ def test_long_context_decode_with_split_heads_vs_oracle(gpu):
     cur, pos = int(np.argmax(want[0])), len(prompt)
     for _ in range(3):
         want.append(om.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(want[-1])); pos += 1
-    for opts in ({}, {"attn_split": 0}, {"attn_split": 2}, {"fuse_attn_o": 0}, {"use_graph": 0}, {"fuse_qkv": 0}, {"fuse_qkv": 2, "attn_split": 0}):
+    for opts in ({}, {"fuse_layer": 0}, {"fuse_back": 0}, {"back_nst13": 5, "back_pre13": 3}, {"attn_split": 0}, {"attn_split": 2}, {"fuse_attn_o": 0}, {"use_graph": 0}, {"fuse_qkv": 0}, {"fuse_qkv": 2, "attn_split": 0}):
         ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
         for k, v in opts.items():
             ctx.set_option(k, v)
