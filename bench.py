@@ -581,11 +581,21 @@ def open_tp_ctx(capi, cfg, rank, world, device, dist, torch):
         dist.broadcast(idt, 0)
         comm_id = bytes(idt.cpu().numpy().tobytes())
     ctx = capi.Ctx(capi.desc_from_config(cfg), device=device, rank=rank, world=world, comm_id=comm_id)
+    rehearsal = os.environ.get("FLM_BENCH_FORCE_DEVICE") is not None and world in (2, 4, 8)
+    if rehearsal:
+        # the rehearsal on ONE GPU: give every rank a CU partition of its own, so that the latency path (flag rounds folded into the consuming launches,
+        # attention + Wo as one launch across the ranks) runs between PROCESSES here as it does between GPUs there.  (Set BEFORE the blobs are exchanged:
+        # the group agrees on its launch structure at flm_p2p_import.)
+        ctx.set_option("cu_parts", world)
+    if os.environ.get("FLM_TP_TRUST_FUSED"):
+        ctx.set_option("tp_trust_fused", int(os.environ["FLM_TP_TRUST_FUSED"]))
     mine = torch.frombuffer(bytearray(ctx.p2p_export()), dtype=torch.uint8).to(dev)
     allb = [torch.zeros(128, dtype=torch.uint8, device=dev) for _ in range(world)]
     dist.all_gather(allb, mine)
     ok = 1
     try:
+        if os.environ.get("FLM_BENCH_NO_P2P"):
+            raise RuntimeError("FLM_BENCH_NO_P2P: peer mapping skipped (the RCCL all-gather branch with a world-size communicator)")
         ctx.p2p_import([bytes(b.cpu().numpy().tobytes()) for b in allb])
     except Exception as e:  # noqa: BLE001
         log(f"rank {rank}: peer-to-peer mapping failed ({e}); " + ("falling back to RCCL all-gathers" if comm_id else "no fallback"))
@@ -601,14 +611,11 @@ def open_tp_ctx(capi, cfg, rank, world, device, dist, torch):
         ctx.exchange = "rccl all-gather"
     else:
         ctx.exchange = "peer-to-peer stores over xGMI + flag round"
-        if os.environ.get("FLM_BENCH_FORCE_DEVICE") is not None and world in (2, 4, 8):
-            # the rehearsal on ONE GPU: give every rank a CU partition of its own, so that the latency path (flag rounds folded into the consuming launches,
-            # attention + Wo as one launch across the ranks) runs between PROCESSES here as it does between GPUs there
-            ctx.set_option("cu_parts", world)
+        if rehearsal:
             ctx.exchange += f" (rehearsal: {world} ranks on one GPU, 1/{world} of the CUs each)"
         # which launch structure the sharded token runs (read back, not assumed): flag rounds folded into the consuming launches or k_xchg launches; QKV + attention + Wo /
         # FFN13 + FFN2 as launches that span the ranks
-        fold, fa, fn = ctx.query("fold_active"), ctx.query("tp_fuse_attn"), ctx.query("tp_fuse_ffn")
+        fold, fa, fn = ctx.query("fold_active"), ctx.query("grp_tp_fuse_attn"), ctx.query("grp_tp_fuse_ffn")      # (what the GROUP agreed on at import)
         per_layer = 9 if not fold else (5 - (2 if fa >= 2 else 1 if fa == 1 else 0) - (1 if fn else 0))
         ctx.exchange += f"; {per_layer} launches per sharded layer (fold_active {fold}, tp_fuse_attn {fa}, tp_fuse_ffn {fn})"
     return ctx

@@ -109,6 +109,13 @@ class Ctx:
         raw = b"".join(blobs)
         _check(lib().flm_p2p_import(self._h, raw, len(blobs)), self._h)
 
+    @staticmethod
+    def regroup(ctxs):
+        """ranks of one process: exchange the blobs again (after tensor-parallel options changed: the group's launch structure is agreed at import)"""
+        blobs = [c.p2p_export() for c in ctxs]
+        for c in ctxs:
+            c.p2p_import(blobs)
+
     def upload(self, kind, layer, value):
         if isinstance(value, tuple):
             q, s = value

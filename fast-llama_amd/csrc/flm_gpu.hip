@@ -445,7 +445,14 @@ int flm_p2p_export(flm_ctx* c, void* blob128) {
     if (!c || !blob128) return FLM_ERR_INVALID;
     HIPC(c, hipSetDevice(c->device));
     P2pBlob b{}; b.magic = kP2pMagic; b.pid = (int)getpid(); b.device = c->device; b.rank = c->rank; b.world = c->world; b.bytes = c->xbuf_bytes; b.raw = c->xbuf;
-    b.caps = tp_prefill_capable(c) ? 1 : 0;
+    // caps: bit 0 batched prompt path possible, 1 one workgroup per CU resident (census), 2 heads can be split over workgroups, 3 fold_xchg, 4-5 tp_fuse_attn, 6 tp_fuse_ffn,
+    //       7 tp_trust_fused, 8-11 cu_parts, 12-15 attn_split
+    {
+        const int Gfull = c->hs / kSplitDims;
+        const bool can = c->hs % kSplitDims == 0 && Gfull >= 2 && c->hs <= 128 && c->d.max_seq_len <= kSplitMaxSeq && c->heads_local * Gfull + 8 <= c->cu_count && c->heads_local * Gfull <= 256;
+        b.caps = (tp_prefill_capable(c) ? 1 : 0) | (c->resident ? 2 : 0) | (can ? 4 : 0) | (c->fold_xchg ? 8 : 0) | ((c->tp_fuse_attn < 0 ? 0 : c->tp_fuse_attn > 2 ? 2 : c->tp_fuse_attn) << 4) | (c->tp_fuse_ffn ? 64 : 0)
+               | (c->tp_trust_fused ? 128 : 0) | ((c->cu_parts & 15) << 8) | ((c->attn_split < 0 ? 0 : c->attn_split > 15 ? 15 : c->attn_split) << 12);
+    }
     HIPC(c, hipIpcGetMemHandle(&b.h, c->xbuf));
     memcpy(blob128, &b, sizeof b);
     return FLM_OK;
@@ -461,6 +468,22 @@ int flm_p2p_import(flm_ctx* c, const void* blobs, int n) {
     c->ranks_on_device = 0;
     for (int r = 0; r < n; ++r) if (b[r].device == c->device) ++c->ranks_on_device;
     if (!tp_prefill_capable(c)) c->tp_prefill = false;
+    {   // the group's launch structure: the weakest any rank can do, computed alike on every rank from the same blobs
+        bool fold = true, span = true, can = true, multi_dev = false, trust = true; int fa = 2, ff = 1, split = (b[0].caps >> 12) & 15;
+        for (int r = 0; r < n; ++r) {
+            const int cp = (b[r].caps >> 8) & 15; int rod = 0;
+            for (int q = 0; q < n; ++q) { if (b[q].device == b[r].device) ++rod; else multi_dev = true; }
+            const bool fold_r = (b[r].caps & 8) && cp >= rod, span_r = fold_r && ((b[r].caps & 2) || cp > 1);
+            fold = fold && fold_r; span = span && span_r; can = can && (b[r].caps & 4); trust = trust && (b[r].caps & 128);
+            const int fa_r = (b[r].caps >> 4) & 3; if (fa_r < fa) fa = fa_r;
+            if (!(b[r].caps & 64)) ff = 0;
+            if (((b[r].caps >> 12) & 15) != split) split = 0;                   // (ranks that disagree: nobody splits)
+        }
+        // ranks on distinct devices: the folded exchanges and the rank-spanning launches rely on system-scope store / flag ordering over xGMI that was only ever
+        // exercised between CU partitions of ONE GPU -> the k_xchg launches (a flag round behind a kernel boundary) unless every rank says "tp_trust_fused"
+        if (multi_dev && !trust) { fold = false; span = false; }
+        c->grp_fold = fold; c->grp_span = span; c->grp_can_split = can; c->grp_tpfa = span ? fa : 0; c->grp_tpff = span ? ff : 0; c->grp_split = can ? split : 0;
+    }
     for (int r = 0; r < n; ++r) {
         if (b[r].magic != kP2pMagic || b[r].rank != r || b[r].world != c->world || b[r].bytes != c->xbuf_bytes) return fail(c, FLM_ERR_INVALID, "p2p_import: blobs are not those of this tensor-parallel group, in rank order");
         if (r == c->rank) continue;
@@ -509,6 +532,7 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (k == "fold_xchg") c->fold_xchg = value;
     else if (k == "tp_fuse_attn") c->tp_fuse_attn = value;
     else if (k == "tp_fuse_ffn") c->tp_fuse_ffn = value;
+    else if (k == "tp_trust_fused") c->tp_trust_fused = value;
     else if (k == "cu_parts") {
         // confine this context's stream to 1 / value of the device's CUs (part rank % value) and size its launches for them: how several tensor-parallel
         // ranks share ONE GPU without a waiting consumer launch taking the CUs its peers' producers need (tests; a real rank owns a device: value 1)
@@ -551,7 +575,8 @@ int flm_query(flm_ctx* c, const char* key, int* value) {
     const struct { const char* k; int v; } tab[] = {
         {"wg_per_cu", c->wg_per_cu}, {"use_graph", c->use_graph}, {"use_prefill", c->use_prefill}, {"use_mfma", c->use_mfma}, {"use_pv_mfma", c->use_pv_mfma},
         {"fuse_attn_o", c->fuse_attn_o}, {"fuse_ffn", c->fuse_ffn}, {"fuse_qkv", c->fuse_qkv}, {"fuse_back", c->fuse_back}, {"fuse_layer", c->fuse_layer}, {"back_nst13", c->back_nst13}, {"back_nst13_head", c->back_nst13_head}, {"back_nst2", c->back_nst2}, {"back_pre13", c->back_pre13}, {"use_prefill_mq", c->use_prefill_mq}, {"attn_split", c->attn_split},
-        {"use_qk_mfma", c->use_qk_mfma}, {"use_p2p", c->p2p}, {"fold_xchg", c->fold_xchg}, {"tp_fuse_attn", c->tp_fuse_attn}, {"tp_fuse_ffn", c->tp_fuse_ffn}, {"cu_parts", c->cu_parts}, {"fold_active", (c->world > 1 && c->p2p && c->fold_xchg && c->cu_parts >= c->ranks_on_device) ? 1 : 0}, {"resident", c->resident}, {"fallback", c->fell_back},
+        {"use_qk_mfma", c->use_qk_mfma}, {"use_p2p", c->p2p}, {"fold_xchg", c->fold_xchg}, {"tp_fuse_attn", c->tp_fuse_attn}, {"tp_fuse_ffn", c->tp_fuse_ffn}, {"cu_parts", c->cu_parts}, {"fold_active", (c->world > 1 && c->p2p && c->grp_fold) ? 1 : 0}, {"span_active", (c->world > 1 && c->p2p && c->grp_span) ? 1 : 0}, {"tp_trust_fused", c->tp_trust_fused},
+        {"grp_tp_fuse_attn", c->grp_tpfa}, {"grp_tp_fuse_ffn", c->grp_tpff}, {"grp_attn_split", c->grp_split}, {"resident", c->resident}, {"fallback", c->fell_back},
         {"token_path", (c->world == 1 ? ((c->fuse_attn_o ? 1 : 0) | (c->fuse_ffn ? 2 : 0) | (c->fuse_attn_o && c->fuse_qkv == 1 ? 4 : 0) | (c->fuse_attn_o && c->fuse_qkv >= 2 ? 8 : 0) | (c->fuse_back && c->fuse_attn_o && c->fuse_ffn ? (c->fuse_layer ? 128 + 256 : 128) : 0)) : 0) | (c->attn_split ? 64 : 0)},
     };
     for (const auto& t : tab) if (k == t.k) { *value = t.v; return FLM_OK; }

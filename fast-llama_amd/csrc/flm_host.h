@@ -102,6 +102,11 @@ struct flm_ctx {
     int tp_fuse_attn = 2;                              // option "tp_fuse_attn": tensor parallel with folded exchanges: 1 = attention + Wo GEMV in one launch across the ranks (k_attn_o),
                                                        // 2 (default) = with the QKV GEMV in front (k_qkv_attn_o: its rows are the rank's own heads), 0 = separate launches
     char* peer[8] = {nullptr}; bool peer_opened[8] = {false}; int p2p = 0;
+    // what the tensor-parallel GROUP runs, agreed at flm_p2p_import from every rank's blob (the ranks' hand-off protocols must match or they wait on flags nobody raises):
+    // exchanges folded into the consuming launches / launches that span the ranks / tp_fuse_attn / tp_fuse_ffn / attn_split, each the weakest any rank can do.
+    // Options set after the import take effect at the next flm_p2p_export + flm_p2p_import round of the whole group.
+    bool grp_fold = false, grp_span = false, grp_can_split = false; int grp_tpfa = 0, grp_tpff = 0, grp_split = 0;
+    int tp_trust_fused = 0;                            // option "tp_trust_fused": ranks on DISTINCT devices run the folded / rank-spanning launches too (validated only between CU partitions of one GPU)
     unsigned* xepoch = nullptr;                        // [4] exchanges done per kind (att, x1, hd, logits), device memory
     float* att_sc = nullptr;                           // [heads_local][max_seq] scores exchanged between the parts of a split head
     int attn_split = 1;                                // option "attn_split": 1 = spread a head over 4 workgroups from kSplitFrom (128) positions on, 0 = never, >= 2 = always that many

@@ -58,6 +58,10 @@ GemvArgs args_qkv(flm_ctx* c, int l) {
 int attn_parts(const flm_ctx* c, int T) {
     // every part owns kSplitDims = 32 output dimensions (its whole V slice then fits the registers / LDS of one workgroup)
     const int Gfull = c->hs / kSplitDims;
+    if (c->world > 1 && c->p2p) {   // a tensor-parallel group: what ALL ranks agreed on (flm_p2p_import): the head lines across ranks assume one G
+        if (!c->grp_can_split || c->grp_split == 0) return 1;
+        return (c->grp_split >= 2 || T >= kSplitFrom) ? Gfull : 1;
+    }
     const bool can = c->hs % kSplitDims == 0 && Gfull >= 2 && c->hs <= 128 && c->d.max_seq_len <= kSplitMaxSeq && c->heads_local * Gfull + 8 <= c->cu_count && c->heads_local * Gfull <= 256;
     if (!can || c->attn_split == 0) return 1;
     return (c->attn_split >= 2 || T >= kSplitFrom) ? Gfull : 1;
@@ -282,11 +286,12 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
     // launches of their own; what stays a k_xchg is the logits' exchange and, for a token without classifier, the last x1 exchange (the next token's
     // k_embed rewrites x1: every peer's stores into it must have landed first)
     // (ranks sharing a device need a CU partition each -- "cu_parts" -- or a consumer that fills the device while it polls keeps its peers' producers out)
-    const bool fold = tp && c->p2p && c->fold_xchg && c->world > 1 && c->cu_parts >= c->ranks_on_device;
+    const bool fold = tp && c->p2p && c->world > 1 && c->grp_fold;          // (agreed by the group at flm_p2p_import)
     auto folded = [&](GemvArgs a, int l, int kind) { if (fold && l >= 0) set_fold(c, a, l, kind); return a; };
     // launches that span the ranks wait across workgroups of one launch too: only where the census found one workgroup per CU resident (a CU partition
     // made for the tests is sized for it: launches are cut to the partition)
-    const bool span = fold && (c->resident || c->cu_parts > 1);
+    const bool span = fold && c->grp_span;
+    const int tpfa = span ? c->grp_tpfa : 0, tpff = span ? c->grp_tpff : 0;
     for (int l = 0; l < L; ++l) {
         bool fused = false;
         const bool back_ok = !tp && c->fuse_back && c->fuse_attn_o && c->fuse_ffn && !c->timing && (c->trace_class < 0 || c->trace_class == 102);
@@ -294,7 +299,7 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
             r = launch_layer(c, st, qt, l, true, G);
             if (r == FLM_OK) continue; else if (r != FLM_ERR_UNSUPPORTED) return r;
         }
-        if (((!tp && c->fuse_attn_o && (c->fuse_qkv >= 2 || (c->fuse_qkv && G > 1))) || (span && c->tp_fuse_attn >= 2)) && !c->timing && c->trace_class < 0) {   // QKV + attention + ATTN_O in one launch (tensor parallel: "tp_fuse_attn" 2)
+        if (((!tp && c->fuse_attn_o && (c->fuse_qkv >= 2 || (c->fuse_qkv && G > 1))) || (span && tpfa >= 2)) && !c->timing && c->trace_class < 0) {   // QKV + attention + ATTN_O in one launch (tensor parallel: "tp_fuse_attn" 2)
             r = qt == FLM_QT_INT8 ? launch_qkv_attn_o<QT_INT8>(c, st, l, G) : launch_qkv_attn_o<QT_INT16>(c, st, l, G);
             if (r == FLM_OK) fused = true; else if (r != FLM_ERR_UNSUPPORTED) return r;
         }
@@ -306,7 +311,7 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
             r = launch_layer(c, st, qt, l, false);
             if (r == FLM_OK) continue; else if (r != FLM_ERR_UNSUPPORTED) return r;
         }
-        if (!fused && ((!tp && c->fuse_attn_o) || (span && c->tp_fuse_attn)) && !c->timing && (c->trace_class < 0 || c->trace_class == 101)) {   // attention + ATTN_O in one launch (tensor parallel: across the ranks)
+        if (!fused && ((!tp && c->fuse_attn_o) || (span && tpfa)) && !c->timing && (c->trace_class < 0 || c->trace_class == 101)) {   // attention + ATTN_O in one launch (tensor parallel: across the ranks)
             r = qt == FLM_QT_INT8 ? launch_attn_o<QT_INT8>(c, st, l, G) : launch_attn_o<QT_INT16>(c, st, l, G);
             if (r == FLM_OK) fused = true; else if (r != FLM_ERR_UNSUPPORTED) return r;
         }
@@ -324,7 +329,7 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
             r = launch_gemv<PRO_QUANT, EPI_RESIDUAL>(c, st, qt, folded(traced(args_o(c, l), KC_ATTN_O, l), l, 0), wgs, coh); if (r) return r;
         }
         if (tp && !fold) { r = exchange(c, st, XK_X1, c->x1, c->x1 + c->drow_begin, c->drow_count); if (r) return r; }
-        if (((!tp && c->fuse_ffn) || (span && c->tp_fuse_ffn)) && !c->timing && c->trace_class < 0) {   // FFN13 + FFN2 in one launch (tensor parallel: across the ranks)
+        if (((!tp && c->fuse_ffn) || (span && tpff)) && !c->timing && c->trace_class < 0) {   // FFN13 + FFN2 in one launch (tensor parallel: across the ranks)
             r = qt == FLM_QT_INT8 ? launch_ffn<QT_INT8>(c, st, l) : launch_ffn<QT_INT16>(c, st, l);
             if (r == FLM_OK) {
                 if (tp && l == L - 1 && !with_cls) { r = exchange(c, st, XK_X1, c->x1, c->x1 + c->drow_begin, c->drow_count); if (r) return r; }   // (see below)

@@ -22,6 +22,19 @@ def _prompt(V, n):
     return np.array([1] + [int(x) for x in (np.arange(1, n) * 7919) % V], dtype=np.int32)
 
 
+def _n_devices():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:  # noqa: BLE001
+        return 1
+
+
+def _dev(r, world):
+    """rank r's device: a GPU of its own where the box has enough of them (the first run on a multi-GPU node exercises xGMI by itself), else device 0 for everybody"""
+    return r if _n_devices() >= world else 0
+
+
 def _run_ranks(ctxs, fn):
     out, err = [None] * len(ctxs), [None] * len(ctxs)
 
@@ -56,7 +69,7 @@ def test_tensor_parallel_p2p_is_bit_identical(gpu, shape, qt, layers, world):
         want.append(om.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(want[-1])); pos += 1
     ids_want = [int(np.argmax(w)) for w in want]
     desc = gpu.desc_from_config(cfg)
-    ctxs = [gpu.Ctx(desc, device=0, rank=r, world=world, comm_id=None) for r in range(world)]
+    ctxs = [gpu.Ctx(desc, device=_dev(r, world), rank=r, world=world, comm_id=None) for r in range(world)]
     for c in ctxs:
         c.upload_all(tensors)                       # the FULL tensors: each context keeps its row shard
     blobs = [c.p2p_export() for c in ctxs]
@@ -91,7 +104,7 @@ def test_tensor_parallel_long_context_split_heads(gpu):
     t = np.array([int(np.argmax(want))], np.int32)
     want2 = om.forward(t, 300)
     world = 2
-    ctxs = [gpu.Ctx(gpu.desc_from_config(cfg), device=0, rank=r, world=world, comm_id=None) for r in range(world)]
+    ctxs = [gpu.Ctx(gpu.desc_from_config(cfg), device=_dev(r, world), rank=r, world=world, comm_id=None) for r in range(world)]
     for c in ctxs:
         c.upload_all(tensors)
     blobs = [c.p2p_export() for c in ctxs]
@@ -119,7 +132,7 @@ def test_tensor_parallel_batched_prompt(gpu, shape, qt, layers, world, n):
     want = om.forward(prompt, 0)
     t = np.array([int(np.argmax(want))], np.int32)
     want2 = om.forward(t, n)
-    ctxs = [gpu.Ctx(gpu.desc_from_config(cfg), device=0, rank=r, world=world, comm_id=None) for r in range(world)]
+    ctxs = [gpu.Ctx(gpu.desc_from_config(cfg), device=_dev(r, world), rank=r, world=world, comm_id=None) for r in range(world)]
     for c in ctxs:
         c.upload_all(tensors)
     blobs = [c.p2p_export() for c in ctxs]
@@ -198,8 +211,12 @@ def test_folded_exchange_under_cu_masks(gpu, shape, qt, layers, world, fuse):
         c.p2p_import(blobs)
         assert c.query("fold_active") == 0          # ranks share the device and have no partition yet
         c.set_option("cu_parts", world)
-        assert c.query("fold_active") == 1
+        assert c.query("fold_active") == 0          # ... and what the group runs changes only when the whole group exchanges its blobs again
         c.set_option("tp_fuse_attn", fuse); c.set_option("tp_fuse_ffn", 1 if fuse else 0)
+    gpu.Ctx.regroup(ctxs)
+    for c in ctxs:
+        assert c.query("fold_active") == 1 and c.query("span_active") == 1
+        assert c.query("grp_tp_fuse_attn") == fuse and c.query("grp_tp_fuse_ffn") == (1 if fuse else 0)
 
     def rank_main(c):
         lg = [c.forward(prompt, 0)]
@@ -234,11 +251,10 @@ def test_fused_attention_across_ranks_with_split_heads(gpu, fuse):
     ctxs = [gpu.Ctx(gpu.desc_from_config(cfg), device=0, rank=r, world=world, comm_id=None) for r in range(world)]
     for c in ctxs:
         c.upload_all(tensors)
-    blobs = [c.p2p_export() for c in ctxs]
     for c in ctxs:
-        c.p2p_import(blobs)
         c.set_option("cu_parts", world)
         c.set_option("tp_fuse_attn", fuse); c.set_option("tp_fuse_ffn", 1 if fuse else 0)
+    gpu.Ctx.regroup(ctxs)                           # (the group's launch structure is agreed when the blobs are exchanged)
 
     def rank_main(c):
         lg = [c.forward(prompt, 0)]
@@ -251,3 +267,79 @@ def test_fused_attention_across_ranks_with_split_heads(gpu, fuse):
         assert ids == ids_want[2:5], f"rank {r}: greedy ids"
     for c in ctxs:
         c.close()
+
+
+def test_group_agrees_on_the_weakest_launch_structure(gpu):
+    """ranks whose options differ must not pick different hand-off protocols (they would wait on flags nobody raises): flm_p2p_import derives the group's
+    structure from all blobs -- one rank without folded exchanges, or with another attn_split, and nobody folds / splits; results stay the oracle's bits"""
+    cfg = synth.make_config("small", ff.QT_INT8)
+    tensors = synth.make_tensors(cfg, seed=77)
+    om = O.OracleModel(cfg, tensors)
+    prompt = _prompt(cfg.vocab_size, 5)
+    want = om.forward(prompt, 0)
+    world = 2
+    ctxs = [gpu.Ctx(gpu.desc_from_config(cfg), device=0, rank=r, world=world, comm_id=None) for r in range(world)]
+    for c in ctxs:
+        c.upload_all(tensors); c.set_option("cu_parts", world)
+    ctxs[1].set_option("fold_xchg", 0); ctxs[0].set_option("attn_split", 2); ctxs[1].set_option("tp_fuse_ffn", 1)
+    gpu.Ctx.regroup(ctxs)
+    for c in ctxs:
+        assert c.query("fold_active") == 0 and c.query("span_active") == 0 and c.query("grp_attn_split") == 0
+        assert c.query("grp_tp_fuse_attn") == 0 and c.query("grp_tp_fuse_ffn") == 0
+    for r, lg in enumerate(_run_ranks(ctxs, lambda c: c.forward(prompt, 0))):
+        assert bits_equal(lg, want), f"rank {r}"
+    for c in ctxs:
+        c.close()
+
+
+@pytest.mark.skipif(_n_devices() < 2, reason="needs two GPUs")
+@pytest.mark.parametrize("trust", [0, 1])
+def test_two_gpus_p2p_and_trusted_fused_launches(gpu, trust):
+    """two ranks on two GPUs: by default the group takes the k_xchg launches (a flag round behind a kernel boundary); with "tp_trust_fused" on every rank the folded
+    exchanges and the rank-spanning launches over xGMI -- oracle bits either way, graph-replayed greedy ids included"""
+    cfg = synth.make_config("7B", ff.QT_INT8); cfg.n_layers = 2
+    tensors = synth.make_tensors(cfg, seed=61)
+    om = O.OracleModel(cfg, tensors)
+    prompt = _prompt(cfg.vocab_size, 6)
+    want = [om.forward(prompt, 0)]
+    cur, pos = int(np.argmax(want[0])), len(prompt)
+    for _ in range(4):
+        want.append(om.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(want[-1])); pos += 1
+    ids_want = [int(np.argmax(w)) for w in want]
+    world = 2
+    ctxs = [gpu.Ctx(gpu.desc_from_config(cfg), device=r, rank=r, world=world, comm_id=None) for r in range(world)]
+    for c in ctxs:
+        c.upload_all(tensors); c.set_option("tp_trust_fused", trust)
+    gpu.Ctx.regroup(ctxs)
+    for c in ctxs:
+        assert c.query("fold_active") == trust and c.query("span_active") == trust
+
+    def rank_main(c):
+        lg = c.forward(prompt, 0)
+        return lg, [int(x) for x in c.decode_greedy(int(np.argmax(lg)), len(prompt), 4)]
+
+    for r, (lg, ids) in enumerate(_run_ranks(ctxs, rank_main)):
+        assert bits_equal(lg, want[0]), f"rank {r}"
+        assert ids == ids_want[1:5], f"rank {r}"
+    for c in ctxs:
+        c.close()
+
+
+@pytest.mark.skipif(_n_devices() < 2, reason="needs two GPUs")
+@pytest.mark.parametrize("mode", ["p2p", "rccl"])
+def test_two_gpus_bench_processes(gpu, mode):
+    """the driver's N = 2 command line on two real GPUs (one process per GPU over torch.distributed.run): peer to peer, and with the peer mapping refused so that
+    the RCCL all-gather branch runs with a 2-rank communicator; the line must carry the reference's ids"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    if mode == "rccl":
+        env["FLM_BENCH_NO_P2P"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--shape", "1.3B", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["parity"]["match"] in (True, None) and line["parity"]["replay_identical"]
+    if mode == "rccl":
+        assert "rccl" in line["config"]["parallelism"]

@@ -45,10 +45,10 @@ while done < n:
     except capi.FlmError as e:
         skipped += 1; continue
     for c in ctxs: c.upload_all(tensors)
-    blobs = [c.p2p_export() for c in ctxs]
     fa, fn_ = int(rng.choice([0, 1, 2])), int(rng.choice([0, 1]))
     for c in ctxs:
-        c.p2p_import(blobs); c.set_option("cu_parts", world); c.set_option("tp_fuse_attn", fa); c.set_option("tp_fuse_ffn", fn_)
+        c.set_option("cu_parts", world); c.set_option("tp_fuse_attn", fa); c.set_option("tp_fuse_ffn", fn_)
+    capi.Ctx.regroup(ctxs)
     def rank_main(c):
         lg = [c.forward(prompt, 0)]
         cur, pos = int(np.argmax(lg[0])), len(prompt)

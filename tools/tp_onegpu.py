@@ -12,9 +12,9 @@ cfg = synth.make_config("7B", ff.QT_INT8); cfg.n_layers = L
 tensors = synth.make_tensors(cfg, seed=1, share_layers=True)
 ctxs = [capi.Ctx(capi.desc_from_config(cfg), device=0, rank=r, world=world, comm_id=None) for r in range(world)]
 for c in ctxs: c.upload_all(tensors)
-blobs = [c.p2p_export() for c in ctxs]
 for c in ctxs:
-    c.p2p_import(blobs); c.set_option("cu_parts", world)
+    c.set_option("cu_parts", world)
+capi.Ctx.regroup(ctxs)
 prompt = (np.arange(1, 9, dtype=np.int64) * 7919 % cfg.vocab_size).astype(np.int32)
 
 def run(fn):
@@ -30,6 +30,7 @@ for fold, fa, fn, name in ((0, 0, 0, "k_xchg launches (9 per layer)"), (1, 0, 0,
     if only and only != f"{fold},{fa},{fn}": continue
     for c in ctxs:
         c.set_option("fold_xchg", fold); c.set_option("tp_fuse_attn", fa); c.set_option("tp_fuse_ffn", fn); c.reset_kv()
+    capi.Ctx.regroup(ctxs)              # the group's launch structure is agreed when the blobs are exchanged
     first = run(lambda c: c.forward_argmax(prompt, 0))[0]
     run(lambda c: c.decode_greedy(first, len(prompt), 8))
     best = 1e9
