@@ -89,14 +89,21 @@ def upload_synthetic(ctx, cfg, log_every=8, threads=None):
 
 
 def golden_ids(cfg, qt, prompt_len):
-    """the reference's greedy ids for this exact model and prompt (tests/golden/model_7B_int8_L32.npz, produced by
-    tests/golden/make_golden_r2.py from oracle/_ref/libflref.so), or None when there is no fixture for the configuration"""
+    """the reference's greedy ids for this exact model and prompt (fixtures under tests/golden/, produced by make_golden_r2.py / make_golden_r4.py from
+    oracle/_ref/libflref.so), or None when there is no fixture for the configuration.  prompt_len 9: bench.py's short prompt; 512: the long one."""
     from fast_llama_amd import flmfile as ff
-    path = os.path.join(ROOT, "tests", "golden", "model_7B_int8_L32.npz")
-    if not (cfg.name.endswith("7B") and cfg.n_layers == 32 and qt == ff.QT_INT8 and prompt_len == 9 and os.path.exists(path)):
+    gd = os.path.join(ROOT, "tests", "golden")
+    full7b = cfg.name.endswith("7B") and cfg.n_layers == 32
+    if full7b and qt == ff.QT_INT8 and prompt_len == 9: path, key = "model_7B_int8_L32.npz", "ids"
+    elif full7b and qt == ff.QT_INT8 and prompt_len == 512: path, key = "model_7B_int8_L32_p512.npz", "ids"
+    elif full7b and qt == ff.QT_INT16 and prompt_len == 9: path, key = "model_7B_int16_L32.npz", "p9_ids"
+    elif full7b and qt == ff.QT_INT16 and prompt_len == 512: path, key = "model_7B_int16_L32.npz", "p512_ids"
+    elif cfg.name.endswith("1.3B") and cfg.n_layers == 4 and qt == ff.QT_INT8 and prompt_len == 9: path, key = "model_1p3B_int8.npz", "ids"
+    else: return None
+    if not os.path.exists(os.path.join(gd, path)):
         return None
-    g = np.load(path)
-    return [int(x) for x in g["ids"]]
+    golden_ids.last = f"tests/golden/{path}"
+    return [int(x) for x in np.load(os.path.join(gd, path))[key]]
 
 
 def host_cores():
@@ -298,7 +305,7 @@ def time_decode(ctx, cfg, args, prompt, barrier, gold):
         n = min(len(ids), len(gold))
         mism = next((i for i in range(n) if ids[i] != gold[i]), None)
         parity.update(against="greedy ids of the reference CPU path (oracle/_ref/libflref.so, ParallelTransformer::forward) on this model and prompt: "
-                              "tests/golden/model_7B_int8_L32.npz; the same fixture's logits digests are checked bit for bit by tests/test_gpu_configs.py",
+                              f"{getattr(golden_ids, 'last', 'tests/golden')}; the same fixture's logits digests are checked bit for bit by tests/test_gpu_configs.py",
                       ids_checked=n, match=mism is None, first_mismatch=mism)
     return {"wall_s": wall, "ms_dev": ms_dev, "pos": pos, "ids": ids, "parity": parity,
             "p50_ms": float(np.median(each)), "p90_ms": float(np.percentile(each, 90)), "each_mean_ms": float(np.mean(each))}
@@ -337,6 +344,7 @@ def prefill_main(args):
     L, dim, hid = cfg.n_layers, cfg.dim, cfg.hidden_dim
     macs = (n - 1) * ((L - 1) * (4 * dim * dim + 3 * dim * hid) + 3 * dim * dim)      # the batch: every layer but the last in full, the last one's q/k/v only
     flops_qk = 2.0 * (L - 1) * cfg.n_heads * cfg.head_size * sum(range(1, n))              # causal QK^T (the fp32-MFMA kernel)
+    pgold = golden_ids(cfg, qt, n)
     line = {"metric": f"prefill tokens/s LLaMA2-{args.shape} {m.group(2)}, {n}-token prompt", "value": round(n / dt, 1), "unit": "tokens/s", "n_gpus": 1,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": m.group(2), "data": "synthetic",
@@ -344,7 +352,8 @@ def prefill_main(args):
                                    f"QK^T and softmax x V on v_mfma_f32_16x16x4_f32; last token through the decode kernels), next token {int(tok)}"},
             "parity": {"against": "next token of the token-by-token decode path over the same prompt in the same session (that path's logits are pinned to the "
                                   "reference by tests/golden/model_7B_int8_L32.npz; batched vs token-by-token cache rows and logits bit for bit: tests/test_gpu_model.py)",
-                       "match": bool(int(tok) == int(tok_ref))},
+                       "match": bool(int(tok) == int(tok_ref)),
+                       "reference_next_token": (None if pgold is None else {"fixture": golden_ids.last, "match": int(tok) == pgold[0]})},
             "linear_layers": {"int_macs": int(macs), "TMAC_per_s_over_whole_forward": round(macs / dt / 1e12, 1), "note": "lower bound: the forward's whole wall time is charged to the GEMMs"},
             "qk_flops": int(flops_qk)}
     print(json.dumps(line), flush=True)
@@ -454,10 +463,16 @@ def main():
             lf = ctx.forward_argmax(lp, 0)
             lw = ctx.decode_greedy(lf, 512, 4)
             lms = ctx.decode_timed(int(lw[-1]), 516, args.steps)
+            lids = [int(lf)] + [int(x) for x in lw] + [int(x) for x in ctx.last_tokens(args.steps)]
+            lgold = golden_ids(cfg, qt, 512)
+            lpar = None
+            if lgold is not None:
+                nchk = min(len(lids), len(lgold))
+                lpar = {"against": f"the reference's greedy ids behind the same 512-token prompt ({golden_ids.last})", "ids_checked": nchk, "match": lids[:nchk] == lgold[:nchk]}
             lb = token_bytes(cfg, 516 + args.steps // 2, esz)
             long_ctx = {"positions": f"516..{515 + args.steps}", "ms_per_step": round(lms / args.steps, 4), "tokens_per_s": round(args.steps / (lms / 1e3), 2),
                         "bytes_per_token": int(lb), "token_roofline_frac": round(lb * (args.steps / (lms / 1e3)) / 1e9 / HBM_PEAK_GBS, 4),
-                        "note": "device time of K steps between HIP events on the ctx stream; not part of `value`"}
+                        "parity": lpar, "note": "device time of K steps between HIP events on the ctx stream; not part of `value`"}
         except Exception as e:  # noqa: BLE001
             long_ctx = {"error": str(e)}
     # a third operating point, outside the timed region of `value`: BASELINE config 5's prompt path at this run's quant type -- a 512-token prompt through
@@ -466,7 +481,8 @@ def main():
     if mode == "single" and args.pos is None and rank == 0:
         try:
             lp = np.array([1] + [int(x) for x in (np.arange(1, 512) * 7919) % V], dtype=np.int32)
-            ctx.reset_kv(); ctx.forward_argmax(lp, 0)                       # warm-up (group-major scale copies, first launches)
+            ctx.reset_kv(); ptok = ctx.forward_argmax(lp, 0)               # warm-up (group-major scale copies, first launches)
+            pgold = golden_ids(cfg, qt, 512)
             pts = []
             for _ in range(3):
                 ctx.reset_kv(); ctx.sync(); torch.cuda.synchronize()
@@ -476,6 +492,10 @@ def main():
             macs = (len(lp) - 1) * ((L_ - 1) * (4 * dim_ * dim_ + 3 * dim_ * hid_) + 3 * dim_ * dim_) + L_ * (4 * dim_ * dim_ + 3 * dim_ * hid_) + V * dim_
             prefill = {"prompt_tokens": int(len(lp)), "ms": round(pdt * 1e3, 3), "prompt_tokens_per_s": round(len(lp) / pdt, 1), "linear_TMACs_per_s": round(macs / pdt / 1e12, 1),
                        "i8_mfma_peak_TMACs_per_s": 1972.0, "frac_of_i8_mfma_peak": round(macs / pdt / 1e12 / 1972.0, 4),
+                       "valu_bound_TMACs_per_s": 840.0, "frac_of_valu_bound": round(macs / pdt / 1e12 / 840.0, 4),
+                       "bound_note": "the reference's per-group fp32 chain (cvt + mul + fma per result and group: 48 VALU instructions = 192 cycles per 32 x 32 x 64 fragment against 128 "
+                                     "MFMA cycles) bounds the int8 GEMM tiles at ~0.42 of the matrix-core peak (~840 TMAC/s): DESIGN.md section 8b",
+                       "parity": (None if pgold is None else {"against": f"the reference's next token behind this prompt ({golden_ids.last})", "match": int(ptok) == pgold[0]}),
                        "note": "wall time of flm_forward_argmax (one host call, prompt ids in, next id out); MACs of the linear layers as the kernels run them (the batch skips "
                                "the last layer's attention and FFN); peak = 3944 TOPS int8 MFMA (MI355X_MICROARCH.md) / 2; not part of `value`"}
         except Exception as e:  # noqa: BLE001

@@ -100,6 +100,84 @@ def test_config3_full_32_layer_7B_int8_vs_reference_digests(gpu):
     ctx.close()
 
 
+def _dig(l):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(l).tobytes()).digest(), dtype=np.uint8)
+
+
+def _upload_portable(gpu, cfg):
+    ctx = gpu.Ctx(gpu.desc_from_config(cfg))
+    for (kind, layer), v in synth.iter_portable(cfg):
+        ctx.upload(kind, layer, v)
+    return ctx
+
+
+def test_config5_full_32_layer_7B_int16_512_token_prefill_vs_reference_digests(gpu):
+    """BASELINE config 5 as stated and at full depth: the 32-layer int16 model, the 512-token prompt through the batched path (matrix-core GEMM tiles on hi / lo byte
+    planes, QK^T and softmax x V on fp32 MFMA, last row only through the tail: transformer.cpp:92-94,140-142), then 4 greedy steps: every step's logits hash to the
+    digests of the REFERENCE's logits (tests/golden/make_golden_r4.py: oracle/_ref/libflref.so with max_batch_size = 512); the 9-token prompt's greedy ids as well"""
+    g = np.load(os.path.join(GOLD, "model_7B_int16_L32.npz"))
+    cfg = synth.make_config("7B", ff.QT_INT16)
+    ctx = _upload_portable(gpu, cfg)
+    prompt, ids = g["p512_prompt"], g["p512_ids"]
+    lg = ctx.forward(prompt, 0)
+    assert bits_equal(lg[:16], g["p512_head"][0]), (lg[:4], g["p512_head"][0][:4])
+    assert np.array_equal(_dig(lg), g["p512_sha256"][0])
+    pos = len(prompt)
+    for i in range(len(ids) - 1):
+        assert int(np.argmax(lg)) == int(ids[i])
+        lg = ctx.forward(np.array([ids[i]], np.int32), pos)
+        assert np.array_equal(_dig(lg), g["p512_sha256"][i + 1]), i
+        pos += 1
+    # the short prompt of bench.py --quant int16: prompt logits, then the graph-replayed greedy ids
+    ctx.reset_kv()
+    p9, ids9 = g["p9_prompt"], g["p9_ids"]
+    lg = ctx.forward(p9, 0)
+    assert np.array_equal(_dig(lg), g["p9_sha256"][0])
+    assert list(ctx.decode_greedy(int(ids9[0]), len(p9), len(ids9) - 1)) == [int(x) for x in ids9[1:]]
+    ctx.close()
+
+
+def test_config3_long_prompt_and_long_context_decode_vs_reference_digests(gpu):
+    """the int8 model with the 512-token prompt (bench.py's long_context / --pos 512 / prefill512-int8 modes): the batched forward's logits and 26 greedy steps at
+    positions 512.. (a head over 4 workgroups, the whole layer in one launch) hash to the reference's digests"""
+    g = np.load(os.path.join(GOLD, "model_7B_int8_L32_p512.npz"))
+    cfg = synth.make_config("7B", ff.QT_INT8)
+    ctx = _upload_portable(gpu, cfg)
+    prompt, ids = g["prompt"], g["ids"]
+    lg = ctx.forward(prompt, 0)
+    assert np.array_equal(_dig(lg), g["sha256"][0])
+    pos = len(prompt)
+    for i in range(6):
+        assert int(np.argmax(lg)) == int(ids[i])
+        lg = ctx.forward(np.array([ids[i]], np.int32), pos)
+        assert np.array_equal(_dig(lg), g["sha256"][i + 1]), i
+        pos += 1
+    ctx.reset_kv()
+    first = ctx.forward_argmax(prompt, 0)
+    assert first == int(ids[0])
+    assert list(ctx.decode_greedy(first, len(prompt), len(ids) - 1)) == [int(x) for x in ids[1:]]
+    ctx.close()
+
+
+def test_config2_1p3B_shape_int8_vs_reference_digests(gpu):
+    """BASELINE config 2's shape (4 layers, vocabulary 55296): prompt logits and 26 greedy steps against the reference's digests / ids"""
+    g = np.load(os.path.join(GOLD, "model_1p3B_int8.npz"))
+    cfg = synth.make_config("1.3B", ff.QT_INT8)
+    ctx = _upload_portable(gpu, cfg)
+    prompt, ids = g["prompt"], g["ids"]
+    lg = ctx.forward(prompt, 0)
+    assert np.array_equal(_dig(lg), g["sha256"][0])
+    pos = len(prompt)
+    for i in range(8):
+        lg = ctx.forward(np.array([ids[i]], np.int32), pos)
+        assert np.array_equal(_dig(lg), g["sha256"][i + 1]), i
+        pos += 1
+    ctx.reset_kv()
+    assert ctx.forward_argmax(prompt, 0) == int(ids[0])
+    assert list(ctx.decode_greedy(int(ids[0]), len(prompt), len(ids) - 1)) == [int(x) for x in ids[1:]]
+    ctx.close()
+
+
 def test_config5_7B_width_int16_512_token_prefill_vs_oracle(gpu):
     """7B width, int16, 2 layers, a 512-token prompt through the batched kernels: last-token logits and the next decode step"""
     cfg = synth.make_config("7B", ff.QT_INT16); cfg.n_layers = 2
