@@ -368,6 +368,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--shape", default="7B")
     ap.add_argument("--quant", default="int8", choices=["int8", "int16"])
+    ap.add_argument("--no-config5", action="store_true", help="skip the int16 512-token prefill object (a second 13.5 GB checkpoint) of the default line")
     ap.add_argument("--pos", type=int, default=None, help="start the timed steps at this position (the prompt's greedy continuation is decoded, untimed, up to it); "
                                                           "default: prompt length + warmup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -519,6 +520,28 @@ def main():
                for k, v in kt.items() if v[1] > 0}
     ctx.close()
 
+    # BASELINE config 5 as stated (LLaMA2-7B int16 + a 512-token prompt), outside the timed region of `value`: a second context with the int16 checkpoint, the prompt
+    # through the batched path, the next token checked against the reference's (tests/golden/model_7B_int16_L32.npz)
+    config5 = None
+    if mode == "single" and args.pos is None and rank == 0 and args.shape == "7B" and qt == ff.QT_INT8 and not args.no_config5:
+        try:
+            cfg16 = synth.make_config("7B", ff.QT_INT16)
+            c16 = capi.Ctx(capi.desc_from_config(cfg16), device=device)
+            upload_synthetic(c16, cfg16)
+            lp = np.array([1] + [int(x) for x in (np.arange(1, 512) * 7919) % V], dtype=np.int32)
+            c16.reset_kv(); t16 = c16.forward_argmax(lp, 0)
+            pts = []
+            for _ in range(3):
+                c16.reset_kv(); c16.sync(); torch.cuda.synchronize()
+                t0 = time.perf_counter(); c16.forward_argmax(lp, 0); pts.append(time.perf_counter() - t0)
+            g16 = golden_ids(cfg16, ff.QT_INT16, 512)
+            config5 = {"workload": "LLaMA2-7B int16, 512-token prompt through the batched path (int16 as hi / lo byte planes on the int8 matrix cores; QK^T and softmax x V on fp32 MFMA)",
+                       "ms": round(float(np.median(pts)) * 1e3, 3), "prompt_tokens_per_s": round(512 / float(np.median(pts)), 1),
+                       "parity": (None if g16 is None else {"against": f"the reference's next token behind this prompt ({golden_ids.last})", "match": int(t16) == g16[0]})}
+            c16.close()
+        except Exception as e:  # noqa: BLE001
+            config5 = {"error": str(e)}
+
     # ---- N > 1: the replicas figure beside the tensor-parallel headline (one independent sequence per GPU, no collective) ----
     replicas = None
     if mode == "tp":
@@ -534,7 +557,7 @@ def main():
             replicas = {"value": None, "note": f"failed: {e}"}
 
     qn = 2 if qt == ff.QT_INT8 else 1
-    dom_regex = {"layer": rf"k_attn_ffn<{qn}, \d+, true>", "back": rf"k_attn_ffn<{qn}, \d+, false>", "ffn": rf"k_ffn<{qn},"}.get(dom, rf"k_gemv<{qn}, 2, 2,")
+    dom_regex = {"layer": rf"k_attn_ffn<{qn}, \d+, true, false>", "back": rf"k_attn_ffn<{qn}, \d+, false, false>", "ffn": rf"k_ffn<{qn},"}.get(dom, rf"k_gemv<{qn}, 2, 2,")
     traffic, traffic_src, traffic_note = pmc_traffic(dom_regex, capi.LIB_PATH)
     dom_name = {"layer": f"k_attn_ffn<{args.quant}, QKV> (the whole decoder layer in one launch: QKV + RoPE, attention, Wo + residual, FFN13 + SwiGLU, FFN2 + residual)",
                 "back": f"k_attn_ffn<{args.quant}> (attention, Wo + residual, FFN13 + SwiGLU, FFN2 + residual in one launch)",
@@ -572,6 +595,8 @@ def main():
             line["long_context"] = long_ctx
         if prefill is not None:
             line["prefill"] = prefill
+        if config5 is not None:
+            line["config5_prefill512_int16"] = config5
         if replicas is not None:
             line["replicas"] = replicas
         if tp_note:
