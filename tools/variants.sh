@@ -7,6 +7,6 @@ cd "$(dirname "$0")/.."
 mkdir -p fast-llama_amd/lib/var
 for spec in "$@"; do
   tag="${spec%%=*}"; defs="${spec#*=}"
-  ( FLM_EXTRA_DEFS="$defs" FLM_BUILD_LIB="$PWD/fast-llama_amd/lib/var/libflm_$tag.so" FLM_LIB_ONLY=1 python -c "import __graft_entry__ as g; g.build()" > /tmp/variant_$tag.log 2>&1 && echo "built $tag ($defs)" || { echo "FAILED $tag"; tail -5 /tmp/variant_$tag.log; } ) &
+  ( FLM_ALLOW_SPILLS=1 FLM_EXTRA_DEFS="$defs" FLM_BUILD_LIB="$PWD/fast-llama_amd/lib/var/libflm_$tag.so" FLM_LIB_ONLY=1 python -c "import __graft_entry__ as g; g.build()" > /tmp/variant_$tag.log 2>&1 && echo "built $tag ($defs)" || { echo "FAILED $tag"; tail -5 /tmp/variant_$tag.log; } ) &
 done
 wait
