@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(1024) k_census(unsigned* counter, unsigned n, 
 // it picks how many workgroups a head is spread over; the graphs are keyed by it)
 int run_token(flm_ctx* c, bool with_cls, int advance, int T) {
     const int G = attn_parts(c, T);
-    if (!c->use_graph || c->timing || ((c->world > 1 || c->comm) && !c->p2p)) return enqueue_token(c, c->stream, with_cls, advance, G);   // (RCCL collectives stay eager)
+    if (!c->use_graph || c->timing || ((c->world > 1 || (c->comm && c->force_tp)) && !c->p2p)) return enqueue_token(c, c->stream, with_cls, advance, G);   // (RCCL collectives stay eager)
     const int key = (with_cls ? 4 : 0) + advance + 8 * G;
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
@@ -397,12 +397,14 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
             }
         }
         unsigned* cnt = (unsigned*)((char*)c->xwg_err + 32); int* okp = c->xwg_err + 4;
-        int one = 1;
-        HIPB(hipMemsetAsync(cnt, 0, 4, c->stream)); HIPB(hipMemcpyAsync(okp, &one, 4, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_census, dim3(c->cu_count), dim3(1024), 150 * 1024, c->stream, cnt, (unsigned)c->cu_count, okp);
-        int ok = 0;
-        if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&ok, okp, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess) c->resident = ok ? 1 : 0;
-        else { (void)hipGetLastError(); c->resident = 0; }
+        c->resident = 0;
+        for (int attempt = 0; attempt < 3 && !c->resident; ++attempt) {   // (another process busy on the device for the census' 2 ms must not switch the fused launches off for the context's whole life)
+            int one = 1, ok = 0;
+            HIPB(hipMemsetAsync(cnt, 0, 4, c->stream)); HIPB(hipMemcpyAsync(okp, &one, 4, hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(k_census, dim3(c->cu_count), dim3(1024), 150 * 1024, c->stream, cnt, (unsigned)c->cu_count, okp);
+            if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&ok, okp, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess) c->resident = ok ? 1 : 0;
+            else { (void)hipGetLastError(); break; }
+        }
         if (!c->resident) { c->fuse_attn_o = 0; c->fuse_ffn = 0; c->fuse_qkv = 0; c->fuse_back = 0; c->attn_split = 0; }
     }
 #undef HIPB
@@ -482,6 +484,7 @@ int flm_p2p_import(flm_ctx* c, const void* blobs, int n) {
         // ranks on distinct devices: the folded exchanges and the rank-spanning launches rely on system-scope store / flag ordering over xGMI that was only ever
         // exercised between CU partitions of ONE GPU -> the k_xchg launches (a flag round behind a kernel boundary) unless every rank says "tp_trust_fused"
         if (multi_dev && !trust) { fold = false; span = false; }
+        if (4 * c->d.n_layers + 2 >= (int)kEpochStride) { fold = false; span = false; }   // (the folded rounds' epoch values 4 l + kind + 1 must stay inside one token's stride)
         c->grp_fold = fold; c->grp_span = span; c->grp_can_split = can; c->grp_tpfa = span ? fa : 0; c->grp_tpff = span ? ff : 0; c->grp_split = can ? split : 0;
     }
     for (int r = 0; r < n; ++r) {
@@ -533,6 +536,7 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (k == "tp_fuse_attn") c->tp_fuse_attn = value;
     else if (k == "tp_fuse_ffn") c->tp_fuse_ffn = value;
     else if (k == "tp_trust_fused") c->tp_trust_fused = value;
+    else if (k == "force_tp") c->force_tp = value;
     else if (k == "cu_parts") {
         // confine this context's stream to 1 / value of the device's CUs (part rank % value) and size its launches for them: how several tensor-parallel
         // ranks share ONE GPU without a waiting consumer launch taking the CUs its peers' producers need (tests; a real rank owns a device: value 1)
@@ -575,7 +579,7 @@ int flm_query(flm_ctx* c, const char* key, int* value) {
     const struct { const char* k; int v; } tab[] = {
         {"wg_per_cu", c->wg_per_cu}, {"use_graph", c->use_graph}, {"use_prefill", c->use_prefill}, {"use_mfma", c->use_mfma}, {"use_pv_mfma", c->use_pv_mfma},
         {"fuse_attn_o", c->fuse_attn_o}, {"fuse_ffn", c->fuse_ffn}, {"fuse_qkv", c->fuse_qkv}, {"fuse_back", c->fuse_back}, {"fuse_layer", c->fuse_layer}, {"back_nst13", c->back_nst13}, {"back_nst13_head", c->back_nst13_head}, {"back_nst2", c->back_nst2}, {"back_pre13", c->back_pre13}, {"use_prefill_mq", c->use_prefill_mq}, {"attn_split", c->attn_split},
-        {"use_qk_mfma", c->use_qk_mfma}, {"use_p2p", c->p2p}, {"fold_xchg", c->fold_xchg}, {"tp_fuse_attn", c->tp_fuse_attn}, {"tp_fuse_ffn", c->tp_fuse_ffn}, {"cu_parts", c->cu_parts}, {"fold_active", (c->world > 1 && c->p2p && c->grp_fold) ? 1 : 0}, {"span_active", (c->world > 1 && c->p2p && c->grp_span) ? 1 : 0}, {"tp_trust_fused", c->tp_trust_fused},
+        {"use_qk_mfma", c->use_qk_mfma}, {"use_p2p", c->p2p}, {"fold_xchg", c->fold_xchg}, {"tp_fuse_attn", c->tp_fuse_attn}, {"tp_fuse_ffn", c->tp_fuse_ffn}, {"cu_parts", c->cu_parts}, {"fold_active", (c->world > 1 && c->p2p && c->grp_fold) ? 1 : 0}, {"span_active", (c->world > 1 && c->p2p && c->grp_span) ? 1 : 0}, {"tp_trust_fused", c->tp_trust_fused}, {"force_tp", c->force_tp},
         {"grp_tp_fuse_attn", c->grp_tpfa}, {"grp_tp_fuse_ffn", c->grp_tpff}, {"grp_attn_split", c->grp_split}, {"resident", c->resident}, {"fallback", c->fell_back},
         {"token_path", (c->world == 1 ? ((c->fuse_attn_o ? 1 : 0) | (c->fuse_ffn ? 2 : 0) | (c->fuse_attn_o && c->fuse_qkv == 1 ? 4 : 0) | (c->fuse_attn_o && c->fuse_qkv >= 2 ? 8 : 0) | (c->fuse_back && c->fuse_attn_o && c->fuse_ffn ? (c->fuse_layer ? 128 + 256 : 128) : 0)) : 0) | (c->attn_split ? 64 : 0)},
     };

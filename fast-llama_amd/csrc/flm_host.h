@@ -106,6 +106,7 @@ struct flm_ctx {
     // exchanges folded into the consuming launches / launches that span the ranks / tp_fuse_attn / tp_fuse_ffn / attn_split, each the weakest any rank can do.
     // Options set after the import take effect at the next flm_p2p_export + flm_p2p_import round of the whole group.
     bool grp_fold = false, grp_span = false, grp_can_split = false; int grp_tpfa = 0, grp_tpff = 0, grp_split = 0;
+    int force_tp = 0;                                  // option "force_tp": a context created with an RCCL id but world == 1 takes the sharded token path (RCCL exchanges over a 1-rank communicator: tests)
     int tp_trust_fused = 0;                            // option "tp_trust_fused": ranks on DISTINCT devices run the folded / rank-spanning launches too (validated only between CU partitions of one GPU)
     unsigned* xepoch = nullptr;                        // [4] exchanges done per kind (att, x1, hd, logits), device memory
     float* att_sc = nullptr;                           // [heads_local][max_seq] scores exchanged between the parts of a split head

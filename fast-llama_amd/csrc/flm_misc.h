@@ -12,10 +12,13 @@ namespace flm {
 // small kernels
 // ------------------------------------------------------------------------------------------
 // x1 = embedding[token] (copy or dequantize; transformer.cpp:115-122)
-inline __global__ void k_embed(float* x, const void* emb, const float* emb_s, int emb_qt, int dim, const int* tok_ptr, unsigned* bar, unsigned* eng_base = nullptr) {
+constexpr unsigned kEpochStride = 1024;      // the token's epoch base advances by this: exchanges (4 per layer + 2) per token must stay below it
+inline __global__ void k_embed(float* x, const void* emb, const float* emb_s, int emb_qt, int dim, const int* tok_ptr, unsigned* bar, unsigned* eng_base = nullptr, unsigned long long* ffn_counter = nullptr) {
     const int tok = *tok_ptr;
     // a new token: the epoch base of the tensor-parallel exchanges' flag values moves on; wrap long before a value could become 0
-    if (eng_base && blockIdx.x == 0 && threadIdx.x == 0) { const unsigned b = *eng_base; *eng_base = b >= 0xFFF00000u ? 0u : b + 1024u; }
+    if (eng_base && blockIdx.x == 0 && threadIdx.x == 0) { const unsigned b = *eng_base; *eng_base = b >= 0xFFF00000u ? 0u : b + kEpochStride; }
+    // k_ffn<TP> finds a rank's last workgroup with (count + 1) % grid: a new token starts the count at 0, whatever grid earlier launches had (or a launch that gave up left behind)
+    if (ffn_counter && blockIdx.x == 0 && threadIdx.x == 0) *ffn_counter = 0ull;
     if (bar && blockIdx.x == 0) {   // the flag lines (kFlagLines = 1536, 64 B apart) the workgroups of the token's fused launches wait on
 #pragma unroll
         for (int k = 0; k < 6; ++k) bar[(threadIdx.x + k * blockDim.x) * 16] = 0;

@@ -273,10 +273,10 @@ int exchange(flm_ctx* c, hipStream_t st, int kind, float* full, float* mine, int
 int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G) {
     const auto& d = c->d;
     const int qt = d.quant_type, hs = c->hs, L = d.n_layers;
-    const bool tp = c->world > 1 || c->comm != nullptr, coh = tp && c->p2p;
+    const bool tp = c->world > 1 || (c->comm != nullptr && c->force_tp), coh = tp && c->p2p;   // (a 1-rank communicator takes the sharded path only on request: "force_tp")
     {
         Tick t(c, st, KC_EMBED);
-        hipLaunchKernelGGL(k_embed, dim3((d.dim + 255) / 256), dim3(256), 0, st, c->x1, (const void*)c->emb, (const float*)c->emb_s, c->emb_qt, d.dim, (const int*)&c->state->tok, c->flag_lines, c->eng_base);
+        hipLaunchKernelGGL(k_embed, dim3((d.dim + 255) / 256), dim3(256), 0, st, c->x1, (const void*)c->emb, (const float*)c->emb_s, c->emb_qt, d.dim, (const int*)&c->state->tok, c->flag_lines, c->eng_base, c->ffn_counter);
         HIPC(c, hipGetLastError());
     }
     const int wgs = gemv_grid(c->cu_count, c->wg_per_cu, 0, 0);
@@ -398,7 +398,7 @@ int flm_kernel_times(flm_ctx* c, int pos, int iters, float* avg_us, int32_t* cou
     const hipEvent_t e0 = ev.e0, e1 = ev.e1;
     auto launch = [&](int kc, int l) -> int {
         switch (kc) {
-        case KC_EMBED:  hipLaunchKernelGGL(k_embed, dim3((d.dim + 255) / 256), dim3(256), 0, st, c->x1, (const void*)c->emb, (const float*)c->emb_s, c->emb_qt, d.dim, (const int*)&c->state->tok, c->flag_lines, c->eng_base); return FLM_OK;
+        case KC_EMBED:  hipLaunchKernelGGL(k_embed, dim3((d.dim + 255) / 256), dim3(256), 0, st, c->x1, (const void*)c->emb, (const float*)c->emb_s, c->emb_qt, d.dim, (const int*)&c->state->tok, c->flag_lines, c->eng_base, c->ffn_counter); return FLM_OK;
         case KC_QKV:    return launch_gemv<PRO_RMSNORM_QUANT, EPI_ROPE_KV>(c, st, qt, args_qkv(c, l), wgs);
         case KC_ATTN:   { const int G = attn_parts(c, pos + 1);
                           if (G > 1) hipLaunchKernelGGL(k_attn_decode<true>, dim3(c->heads_local * G), dim3(kAttnBlock), attn_lds_bytes(d.max_seq_len, c->hs, true), st, args_attn(c, l, G));

@@ -158,6 +158,9 @@ int  flm_debug_read(flm_ctx* ctx, int what, int layer, float* out, size_t n);
  * "use_qk_mfma" 0 = prefill attention scores on VALU chains (default 1: v_mfma_f32_16x16x4_f32, the same bits),
  * "use_pv_mfma" 0 = prefill softmax x V on VALU chains (default 1: the weighted sum on v_mfma_f32_16x16x4_f32 too; needs use_qk_mfma),
  * "use_mfma" int8 prefill GEMM tile shape on the matrix cores: 1 (default) by problem size, 2 (or 0) always 64 x 64, 3 always 128 x 128 tiles.
+ * "force_tp" 1 = a context created with an RCCL id and world == 1 takes the sharded token path anyway (RCCL exchanges over a 1-rank communicator; tests) -- by default such
+ *          a context runs the single-GPU launches,
+ * "tp_trust_fused" 1 = between DISTINCT devices too, run the folded exchanges / rank-spanning launches (default: the k_xchg launches; set on every rank before flm_p2p_export),
  * "fuse_back" 0 = attention + Wo and FFN13 + FFN2 as two launches (k_attn_o, k_ffn) instead of one (k_attn_ffn, default 1: [W1; W3] stashed in LDS under the attention),
  * "fuse_layer" 0 = the QKV GEMV as its own launch in front of k_attn_ffn (default 1: the whole decoder layer in one launch),
  * "back_nst13" / "back_nst13_head" / "back_nst2" LDS stash slots (4.25 KiB each; -1 = as many as the LDS holds) a Wo workgroup fills with [W1; W3] under the attention /

@@ -164,6 +164,7 @@ def test_rccl_exchange_branch_on_a_one_rank_communicator(gpu, qt):
     om = O.OracleModel(cfg, tensors)
     prompt = _prompt(cfg.vocab_size, 3)                    # (short: fed token by token, every token through the exchanges)
     ctx = gpu.Ctx(gpu.desc_from_config(cfg), device=0, rank=0, world=1, comm_id=gpu.comm_unique_id())
+    ctx.set_option("force_tp", 1)               # (a caller that merely passes an id keeps the single-GPU fast path)
     ctx.upload_all(tensors)
     lg = ctx.forward(prompt, 0)
     assert bits_equal(lg, om.forward(prompt, 0))
