@@ -88,7 +88,7 @@ struct flm_ctx {
     int fuse_back = 1;                                 // option "fuse_back": attention + Wo + FFN13 + FFN2 in one launch with [W1; W3] stashed in LDS under the attention (k_attn_ffn; single GPU,
                                                        // head size a multiple of 64, one workgroup per head)
     int fuse_layer = 1;                                // option "fuse_layer": ... with the QKV GEMV in front: the whole layer in one launch
-    int back_nst13 = -1, back_nst13_head = -1, back_nst2 = 0, back_pre13 = 16;   // options "back_*": k_attn_ffn's stash slots (-1: as many as the LDS holds) and early register set (flm_layer.h)
+    int back_nst13 = -1, back_nst13_head = -1, back_nst2 = 0, back_pre13 = 16, back_pre2 = 16;   // options "back_*": k_attn_ffn's stash slots (-1: as many as the LDS holds) and early register set (flm_layer.h)
     int fuse_qkv = 1;                                  // option "fuse_qkv": QKV in front of attention + Wo in the same launch (k_qkv_attn_o; single GPU): 0 never,
                                                        // 1 when a head is spread over several workgroups (long contexts: where it pays), 2 always
     unsigned* flag_lines = nullptr; int* xwg_err = nullptr;   // k_attn_o: one 64-byte flag line per head; "a cross-workgroup wait timed out"

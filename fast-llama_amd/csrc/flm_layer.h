@@ -37,6 +37,7 @@ struct BackArgs {
     int nst13;                  // stash slots of [W1; W3] a Wo workgroup fills under the attention
     int nst13_head;             // ... a head workgroup fills when its head is done
     int nst2;                   // stash slots of W2 every workgroup fills behind its rows of hd
+    int pre2;                   // the first pre2 waves request their first register set of W2 before the hd flag round
     int pre13;                  // the first pre13 waves of a workgroup request their first register set of [W1; W3] before the x1 flag round (16: all, as k_ffn does for W2)
     unsigned long long* trace;  // FLM_ABLATE builds: [grid][16] s_memrealtime stamps (100 MHz, one clock for all XCDs; tools/trace_back.py)
 };
@@ -188,7 +189,7 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_attn_ffn(const GemvArgs aq, c
     // ---- FFN2: k_gemv<QUANT, RESIDUAL> behind the hd flag round
     GemvCtx<QT, EPI_RESIDUAL, true> g2;
     g2.init(a2, blockIdx.x, p.grid2, lds, 0, p.st_base, (unsigned)p.nst2);
-    g2.issue(kAblate ? a2.ablate : 0, 1);                                       // ONE set now, the second when hd has arrived (k_ffn)
+    if ((int)g2.wave < p.pre2) g2.issue(kAblate ? a2.ablate : 0, 1);            // the first pre2 waves: ONE set now, the rest when hd has arrived (k_ffn: all 16)
     g2.stash_issue(lds);
     poll_lines(p.flag_hd, (int)gridDim.x, target, p.err);
     wait_stores_done();                                                         // every wave: the stash slots it requested have landed
@@ -196,7 +197,7 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_attn_ffn(const GemvArgs aq, c
     stamp(9);
     float4 xv2[XR2 > 0 ? XR2 : 1], nv2[XR2 > 0 ? XR2 : 1];
     gemv_preload<QT, PRO_QUANT, XR2, true>(a2, xv2, nv2);
-    gemv_prologue<QT, PRO_QUANT, XR2, true, FLM_BACK_LATE2 == 1>(a2, lds, xv2, nv2, [&](int) { if (FLM_BACK_LATE2 != 2 || (g2.wave & 1) == 0) g2.issue(kAblate ? a2.ablate : 0, 2); });
+    gemv_prologue<QT, PRO_QUANT, XR2, true, FLM_BACK_LATE2 == 1>(a2, lds, xv2, nv2, [&](int) { g2.issue_missing(kAblate ? a2.ablate : 0); });
     stamp(10);
     g2.run(a2, lds, nostamp);
     stamp(11);
