@@ -703,7 +703,9 @@ int flm_debug_read(flm_ctx* c, int what, int layer, float* out, size_t n) {
         unsigned long long t0 = ~0ull;
         for (size_t i = 0; i < nrt; ++i) if (t[i] && t[i] < t0) t0 = t[i];
         for (size_t i = 0; i < nrt; ++i) out[i] = t[i] ? (float)((double)(long long)(t[i] - t0) * 0.01) : -1.f;
-        for (size_t i = nrt; i < n; ++i) { const size_t b = i - i % 16; out[i] = i % 16 == 15 ? (float)t[i] : ((t[i] && t[b]) ? (float)(long long)(t[i] - t[b]) : -1.f); }
+        // (words [4 * 4096, 5 * 4096): 100 MHz stamps again -- FFN13's run() --, relative to the same start)
+        for (size_t i = nrt; i < n && i < 4 * 4096; ++i) { const size_t b = i - i % 16; out[i] = i % 16 == 15 ? (float)t[i] : ((t[i] && t[b]) ? (float)(long long)(t[i] - t[b]) : -1.f); }
+        for (size_t i = 4 * 4096; i < n; ++i) out[i] = t[i] ? (float)((double)(long long)(t[i] - t0) * 0.01) : -1.f;
         return FLM_OK; }
     default: return fail(c, FLM_ERR_INVALID, "debug_read: unknown buffer");
     }

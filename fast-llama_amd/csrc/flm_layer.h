@@ -148,6 +148,10 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_attn_ffn(const GemvArgs aq, c
             t.stash_issue(lds);
         }
         stamp(1);
+#ifdef FLM_TRACE_PRO_RT
+        // (tools/trace_back.py: when has everything this CU requested -- Wo's register sets and the [W1; W3] stash -- landed?  Wave 15 requested last; loads complete in order)
+        if (kAblate && p.trace && threadIdx.x == 960) { wait_stores_done(); p.trace[blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memrealtime(); }
+#endif
         poll_lines(p.flag_h, p.n_heads, target, p.err);
         __syncthreads();
         stamp(2);
@@ -176,7 +180,12 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_attn_ffn(const GemvArgs aq, c
         gemv_preload<QT, PRO_RMSNORM_QUANT, 1, true>(a13, xv, nv);
         gemv_prologue<QT, PRO_RMSNORM_QUANT, 1, true, FLM_BACK_LATE != 0>(a13, lds, xv, nv, [&](int) { g.issue_missing(kAblate ? a13.ablate : 0); });
         stamp(6);
+#ifdef FLM_TRACE_PRO_RT
+        // (tools/trace_back.py: thread 0 = the wave that runs the pass's chains: first refill requested / last step reduced, at the barrier / chains, epilogue and stores issued)
+        g.run(a13, lds, [&](int k) { if (kAblate && a13.trace && threadIdx.x == 0 && k >= 3 && k <= 5) a13.trace[3 * 4096 + blockIdx.x * 16 + k] = __builtin_amdgcn_s_memrealtime(); });
+#else
         g.run(a13, lds, nostamp);
+#endif
         stamp(7);
     } else {
         poll_lines(p.flag_x, p.grido, target, p.err);                           // (keeps the order x1 -> hd for a workgroup without rows)

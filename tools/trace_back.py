@@ -13,7 +13,7 @@ ctx = capi.Ctx(capi.desc_from_config(cfg))
 ctx.upload_all(synth.make_tensors(cfg, seed=1))
 prompt = (np.arange(1, pos + 1, dtype=np.int64) * 7919 % cfg.vocab_size).astype(np.int32)
 names = {0: "start", 1: "heads: attention done | Wo: weights + stash requested", 2: "heads: flag raised | Wo: heads' flags seen", 3: "Wo: rows done", 4: "Wo: x1 flag raised",
-         5: "x1 flags seen", 6: "FFN13 prologue done", 7: "FFN13 rows done", 8: "hd flag raised", 9: "hd flags seen", 10: "FFN2 prologue done", 11: "end", 12: "QKV prologue done", 13: "QKV rows done", 14: "QKV flag raised"}
+         5: "x1 flags seen", 6: "FFN13 prologue done", 7: "FFN13 rows done", 8: "hd flag raised", 9: "hd flags seen", 10: "FFN2 prologue done", 11: "end", 12: "QKV prologue done", 13: "QKV rows done", 14: "QKV flag raised", 15: "Wo sets + [W1; W3] stash landed (wave 15)"}
 for spec in sets:
     opts = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in spec.split(",") if kv)
     for k, v in opts.items(): ctx.set_option(k, v)
@@ -25,8 +25,8 @@ for spec in sets:
     rows = []
     for rep in range(5):
         ctx.decode_greedy(first, len(prompt) + 32 + rep, 1)
-        rows.append(ctx.debug_read("back_trace", 0, 4 * 256 * 16).reshape(4, 256, 16).copy())
-    pro = rows[-1][1:3]
+        rows.append(ctx.debug_read("back_trace", 0, 5 * 256 * 16).reshape(5, 256, 16).copy())
+    pro = rows[-1][1:3]; rn = rows[-1][4]
     ch = rows[-1][3]                  # the FFN13 chain's stages (wave 0): shader-clock ticks after the chain's start; [15] = rounds
     ok = ch[:, 14] > 0
     if ok.any():
@@ -44,7 +44,7 @@ for spec in sets:
     nh = cfg.n_heads
     print(f"--- {spec or 'defaults'}: graph decode {ms / 32 * 1000:.1f} us/token ({L} layers); stamps of layer 0, us after the first workgroup's start (median / min / max)")
     for cls, sel in (("heads", slice(0, nh)), ("others", slice(nh, 256))):
-        for k in (0, 12, 13, 14, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11):
+        for k in (0, 12, 13, 14, 1, 15, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11):
             v = t[sel, k]; v = v[v >= 0]
             if len(v): print(f"  {cls:6s} {k:2d} {names[k]:58s} {np.median(v):6.2f} {v.min():6.2f} {v.max():6.2f}")
     pn = {0: "entry", 1: "staged", 3: "stage barrier passed", 2: "chain / issue done", 4: "(same)", 5: "r known / quantized", 6: "quantize round done", 7: "final barrier passed"}
@@ -55,5 +55,7 @@ for spec in sets:
                 v = pro[which][:, w + k]; v = v[v >= 0]
                 if len(v): line.append(f"{pn[k]} {np.median(v):.2f}")
             if line: print(f"  {nm}, {wn}: " + " | ".join(line))
+    if (rn[:, 4] > 0).any():
+        print("  FFN13 run(), chain wave: " + " | ".join(f"{nm} {np.median(rn[:, k][rn[:, k] > 0]):.2f}" for k, nm in ((3, "first refill requested"), (4, "last step reduced (at the barrier)"), (5, "chains + epilogue + stores issued"))))
     ends = np.array([r[:, 11].max() for r in rows])
     print("  launch span over 5 tokens:", " ".join(f"{e:.2f}" for e in ends))
