@@ -373,6 +373,7 @@ def main():
                                                           "default: prompt length + warmup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--wg-per-cu", type=int, default=0)
+    ap.add_argument("--opt", action="append", default=[], help="k=v: flm_set_option on the decode context (launch-structure A/B runs; reported in config.options; none by default)")
     ap.add_argument("--prompt-len", type=int, default=9)
     ap.add_argument("--parallel", default="tp", choices=["replicas", "tp"],
                     help="N > 1: 'tp' (default) = ONE sequence, every matmul split by output rows over the GPUs (strong scaling, the headline value; "
@@ -448,6 +449,8 @@ def main():
         ctx = capi.Ctx(capi.desc_from_config(cfg), device=device)
         if args.wg_per_cu:
             ctx.set_option("wg_per_cu", args.wg_per_cu)
+        for kv in args.opt:
+            ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         upload_synthetic(ctx, cfg)
         m = time_decode(ctx, cfg, args, prompt_for(rank if mode == "replicas" else 0), barrier, gold if (mode == "single" or rank == 0) else None)
     tok_s, elapsed = job_throughput(m["wall_s"], args.steps, world, mode)
@@ -504,7 +507,7 @@ def main():
     # per-kernel times, live, HIP events on the ctx stream (eager launches, same kernels as the graph)
     kt = ctx.kernel_times(mid_pos, iters=3)
     # the dominant launch of the token: the fused FFN13 + FFN2 kernel where the token path runs it (single GPU), else FFN13
-    dom = next((k for k in ("layer", "back", "ffn") if kt.get(k, (0.0, 0))[1] > 0), "ffn13")
+    dom = next((k for k in ("layers", "layer", "back", "ffn") if kt.get(k, (0.0, 0))[1] > 0), "ffn13")
     dom_us, dom_cnt = kt[dom]
     dom_bytes = ctx.kernel_bytes(dom, mid_pos)
     achieved = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
@@ -512,8 +515,8 @@ def main():
         tpath = ctx.query("token_path")
         token_path = {"resident": bool(ctx.query("resident")), "fell_back_after_timeout": bool(ctx.query("fallback")),
                       "attn_wo_fused": bool(tpath & 1), "ffn_fused": bool(tpath & 2), "qkv_joins_at_long_contexts": bool(tpath & 4),
-                      "heads_split_at_long_contexts": bool(tpath & 64), "attention_to_ffn2_in_one_launch": bool(tpath & 128), "whole_layer_in_one_launch": bool(tpath & 256),
-                      "launches_per_token_short_context": (cfg.n_layers * (1 if tpath & 256 else 2 if tpath & 128 else 3) + 3)}
+                      "heads_split_at_long_contexts": bool(tpath & 64), "attention_to_ffn2_in_one_launch": bool(tpath & 128), "whole_layer_in_one_launch": bool(tpath & 256), "all_layers_in_one_launch": bool(tpath & 512) and kt.get("layers", (0.0, 0))[1] > 0,
+                      "launches_per_token_short_context": ((1 if tpath & 512 and kt.get("layers", (0.0, 0))[1] > 0 else cfg.n_layers * (1 if tpath & 256 else 2 if tpath & 128 else 3)) + 3)}
     except Exception as e:  # noqa: BLE001
         token_path = {"error": str(e)}
     kernels = {k: {"us": round(v[0], 2), "per_token": v[1], "GBps": round(ctx.kernel_bytes(k, mid_pos) / (v[0] * 1e-6) / 1e9, 1) if v[0] > 0 else 0.0}
@@ -557,9 +560,11 @@ def main():
             replicas = {"value": None, "note": f"failed: {e}"}
 
     qn = 2 if qt == ff.QT_INT8 else 1
-    dom_regex = {"layer": rf"k_attn_ffn<{qn}, \d+, true, false>", "back": rf"k_attn_ffn<{qn}, \d+, false, false>", "ffn": rf"k_ffn<{qn},"}.get(dom, rf"k_gemv<{qn}, 2, 2,")
+    dom_regex = {"layers": rf"k_layers<{qn}, \d+, false>", "layer": rf"k_attn_ffn<{qn}, \d+, true, false>", "back": rf"k_attn_ffn<{qn}, \d+, false, false>", "ffn": rf"k_ffn<{qn},"}.get(dom, rf"k_gemv<{qn}, 2, 2,")
     traffic, traffic_src, traffic_note = pmc_traffic(dom_regex, capi.LIB_PATH)
-    dom_name = {"layer": f"k_attn_ffn<{args.quant}, QKV> (the whole decoder layer in one launch: QKV + RoPE, attention, Wo + residual, FFN13 + SwiGLU, FFN2 + residual)",
+    dom_name = {"layers": f"k_layers<{args.quant}> (ALL {cfg.n_layers} decoder layers of the token in one launch: per layer QKV + RoPE, attention, Wo + residual, FFN13 + SwiGLU, FFN2 + residual; "
+                          f"the edges between phases and between layers are flag rounds)",
+                "layer": f"k_attn_ffn<{args.quant}, QKV> (the whole decoder layer in one launch: QKV + RoPE, attention, Wo + residual, FFN13 + SwiGLU, FFN2 + residual)",
                 "back": f"k_attn_ffn<{args.quant}> (attention, Wo + residual, FFN13 + SwiGLU, FFN2 + residual in one launch)",
                 "ffn": f"k_ffn<{args.quant}> (ffn13 + SwiGLU and ffn2 + residual in one launch)"}.get(dom, f"k_gemv<{args.quant},rmsnorm+quantize,swiglu> (ffn13)")
     if rank == 0:
@@ -573,7 +578,7 @@ def main():
                                    f"prompt {args.prompt_len} tokens, positions {pos}..{pos + args.steps - 1}, fp32 KV cache, max_seq 1024",
                        "parallelism": {"single": "single-gpu", "tp": f"tp{world}: ONE sequence, every matmul split by output rows over {world} GPUs, activation slices exchanged by " + (getattr(ctx, "exchange", "") if mode == "tp" else ""),
                                        "replicas": f"{world} replicas: one independent sequence per GPU, no data-path collective"}[mode],
-                       "device_ms_per_step": round(m["ms_dev"] / args.steps, 4)},
+                       "device_ms_per_step": round(m["ms_dev"] / args.steps, 4), **({"options": args.opt} if args.opt else {})},
             "p50_ms_per_step": round(m["p50_ms"], 4), "p90_ms_per_step": round(m["p90_ms"], 4),
             "parity": m["parity"],
             # per GPU: bytes each GPU streams per token it works on, at the rate it produces them
@@ -583,11 +588,12 @@ def main():
             "roofline": {"kernel": dom_name,
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
-                         "bytes_per_launch": int(dom_bytes), "avg_launch_us": round(dom_us, 2), "launches_per_token": dom_cnt},
+                         "bytes_per_launch": int(dom_bytes), "avg_launch_us": round(dom_us, 2), "launches_per_token": dom_cnt,
+                         **({"layers_per_launch": cfg.n_layers, "us_per_layer": round(dom_us / cfg.n_layers, 2)} if dom == "layers" else {})},
             "token_path": token_path,
             "kernels": kernels,
-            "kernels_note": "us per launch, back-to-back launches of one class between one pair of HIP events; on a single GPU the token runs `layer` (k_attn_ffn: the whole "
-                            "decoder layer in one launch) where it is listed: per token = embed + L * layer + cls + argmax; else attn_wo (k_attn_o) instead of attn + attn_o and ffn "
+            "kernels_note": "us per launch, back-to-back launches of one class between one pair of HIP events; on a single GPU the token runs `layers` (k_layers: all L decoder "
+                            "layers in ONE launch) where it is listed: per token = embed + layers + cls + argmax; else `layer` (k_attn_ffn: one launch per layer; timed beside it); else attn_wo (k_attn_o) instead of attn + attn_o and ffn "
                             "(k_ffn) instead of ffn13 + ffn2, and where qkv_attn_wo (k_qkv_attn_o: contexts from 128 positions on) is listed, that instead of qkv + attn_wo; the "
                             "per-phase classes (qkv .. ffn2) are timed beside them for reference",
         }

@@ -75,7 +75,11 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
     constexpr int D = SPLIT ? 4 : kAttnDepth;         // K ring depth
     constexpr int DV = SPLIT ? 1 : kAttnDepth;        // V ring depth (SPLIT: unused, the slice sits in vall)
     const int hs = a.hs, tid = threadIdx.x;
+#ifdef FLM_TRACE_PRO_RT
+    auto stamp = [&](int k) { if (kAblate && a.trace && threadIdx.x == 0) a.trace[(h * G + g) * 8 + k] = __builtin_amdgcn_s_memrealtime(); };   // (tools/trace_back.py: the 100 MHz clock of the launch's other stamps)
+#else
     auto stamp = [&](int k) { if (kAblate && a.trace && threadIdx.x == 0) a.trace[(h * G + g) * 8 + k] = __builtin_amdgcn_s_memtime(); };
+#endif
     stamp(0);
     constexpr int rs = NF * 64 + 8;
     const int f4r = hs >> 2, tile_f4 = kAttnTile * f4r;
@@ -202,6 +206,7 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
                 float* cur = (u & 1) ? tile1 : tile0;                   // D is even: slot parity
                 park(cur, prow, loff, ringK[u]);
                 __syncthreads();
+                if (s == sb) stamp(5);
                 request(rK, s + D, se, prow, goff, ringK[u]);
                 if (s < se && tid < kAttnTile * 8) score_lane(cur, s, tid >> 3, tid & 7);
             }
@@ -424,6 +429,7 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
         const int nq = hs * esz / 4;
         if (tid < nq) __hip_atomic_store(reinterpret_cast<unsigned*>(a.oq) + (size_t)h * nq + tid, reinterpret_cast<const unsigned*>(qs)[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    stamp(6);
     __syncthreads();                                                // the LDS is free for whoever runs next on it
 }
 // SPLIT is a template argument of the kernels (not a run-time branch inside one kernel): the two forms keep different things in

@@ -140,7 +140,7 @@ int xwg_check(flm_ctx* c) {
         c->attn_split = 0;
         return fail(c, FLM_ERR_COMM, "tensor parallel: a cross-workgroup wait on this rank timed out; the group's results are invalid and the context group cannot be used any more");
     }
-    c->fuse_attn_o = 0; c->fuse_ffn = 0; c->fuse_qkv = 0; c->fuse_back = 0; c->attn_split = 0; c->fell_back = 1;
+    c->fuse_attn_o = 0; c->fuse_ffn = 0; c->fuse_qkv = 0; c->fuse_back = 0; c->fuse_token = 0; c->attn_split = 0; c->fell_back = 1;
     for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
     c->graphs.clear();
     return FLM_RETRY;
@@ -169,6 +169,7 @@ __global__ void __launch_bounds__(1024) k_census(unsigned* counter, unsigned n, 
 // it picks how many workgroups a head is spread over; the graphs are keyed by it)
 int run_token(flm_ctx* c, bool with_cls, int advance, int T) {
     const int G = attn_parts(c, T);
+    { const int r = layers_prepare(c, G); if (r) return r; }                     // (k_layers' argument blocks: device memory, never built inside a capture)
     if (!c->use_graph || c->timing || ((c->world > 1 || (c->comm && c->force_tp)) && !c->p2p)) return enqueue_token(c, c->stream, with_cls, advance, G);   // (RCCL collectives stay eager)
     const int key = (with_cls ? 4 : 0) + advance + 8 * G;
     auto it = c->graphs.find(key);
@@ -423,7 +424,7 @@ void flm_ctx_destroy(flm_ctx* c) {
     for (int r = 0; r < c->world; ++r) if (c->peer_opened[r] && c->peer[r]) hipIpcCloseMemHandle(c->peer[r]);
     void* ptrs[] = {c->emb, c->emb_s, c->out_norm, c->kcache, c->vcache, c->xbuf, c->xepoch, c->qbuf,
                     c->rope_cos, c->rope_sin, c->state, c->prompt_dev, c->out_tokens_dev,
-                    c->flag_lines, c->xwg_err, c->att_q, c->att_qs, c->att_sc, c->trace, c->eng_base, c->ffn_counter,
+                    c->flag_lines, c->xwg_err, c->att_q, c->att_qs, c->att_sc, c->trace, c->eng_base, c->ffn_counter, c->la_dev[0], c->la_dev[1],
                     c->pf_in_xbuf ? nullptr : c->pf_x, c->pf_qkv, c->pf_q, c->pf_in_xbuf ? nullptr : c->pf_att, c->pf_gu, c->pf_in_xbuf ? nullptr : c->pf_hd, c->pf_xs, c->pf_xq, c->pf_scores};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->comm) ncclCommDestroy(c->comm);
@@ -526,6 +527,9 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (k == "fuse_qkv") c->fuse_qkv = value;
     else if (k == "fuse_back") c->fuse_back = value;
     else if (k == "fuse_layer") c->fuse_layer = value;
+    else if (k == "fuse_token") c->fuse_token = value;
+    else if (k == "tok_nstq") c->tok_nstq = value;
+    else if (k == "tok_preq") c->tok_preq = value;
     else if (k == "back_nst13") c->back_nst13 = value;
     else if (k == "back_nst13_head") c->back_nst13_head = value;
     else if (k == "back_nst2") c->back_nst2 = value;
@@ -570,6 +574,7 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else return fail(c, FLM_ERR_INVALID, "unknown option");
     for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
     c->graphs.clear();
+    c->la_valid[0] = c->la_valid[1] = false;
     return FLM_OK;
 }
 
@@ -579,10 +584,10 @@ int flm_query(flm_ctx* c, const char* key, int* value) {
     const std::string k(key);
     const struct { const char* k; int v; } tab[] = {
         {"wg_per_cu", c->wg_per_cu}, {"use_graph", c->use_graph}, {"use_prefill", c->use_prefill}, {"use_mfma", c->use_mfma}, {"use_pv_mfma", c->use_pv_mfma},
-        {"fuse_attn_o", c->fuse_attn_o}, {"fuse_ffn", c->fuse_ffn}, {"fuse_qkv", c->fuse_qkv}, {"fuse_back", c->fuse_back}, {"fuse_layer", c->fuse_layer}, {"back_nst13", c->back_nst13}, {"back_nst13_head", c->back_nst13_head}, {"back_nst2", c->back_nst2}, {"back_pre13", c->back_pre13}, {"back_pre2", c->back_pre2}, {"use_prefill_mq", c->use_prefill_mq}, {"attn_split", c->attn_split},
+        {"fuse_attn_o", c->fuse_attn_o}, {"fuse_ffn", c->fuse_ffn}, {"fuse_qkv", c->fuse_qkv}, {"fuse_back", c->fuse_back}, {"fuse_layer", c->fuse_layer}, {"fuse_token", c->fuse_token}, {"tok_nstq", c->tok_nstq}, {"tok_preq", c->tok_preq}, {"back_nst13", c->back_nst13}, {"back_nst13_head", c->back_nst13_head}, {"back_nst2", c->back_nst2}, {"back_pre13", c->back_pre13}, {"back_pre2", c->back_pre2}, {"use_prefill_mq", c->use_prefill_mq}, {"attn_split", c->attn_split},
         {"use_qk_mfma", c->use_qk_mfma}, {"use_p2p", c->p2p}, {"fold_xchg", c->fold_xchg}, {"tp_fuse_attn", c->tp_fuse_attn}, {"tp_fuse_ffn", c->tp_fuse_ffn}, {"cu_parts", c->cu_parts}, {"fold_active", (c->world > 1 && c->p2p && c->grp_fold) ? 1 : 0}, {"span_active", (c->world > 1 && c->p2p && c->grp_span) ? 1 : 0}, {"tp_trust_fused", c->tp_trust_fused}, {"force_tp", c->force_tp},
         {"grp_tp_fuse_attn", c->grp_tpfa}, {"grp_tp_fuse_ffn", c->grp_tpff}, {"grp_attn_split", c->grp_split}, {"resident", c->resident}, {"fallback", c->fell_back},
-        {"token_path", (c->world == 1 ? ((c->fuse_attn_o ? 1 : 0) | (c->fuse_ffn ? 2 : 0) | (c->fuse_attn_o && c->fuse_qkv == 1 ? 4 : 0) | (c->fuse_attn_o && c->fuse_qkv >= 2 ? 8 : 0) | (c->fuse_back && c->fuse_attn_o && c->fuse_ffn ? (c->fuse_layer ? 128 + 256 : 128) : 0)) : 0) | (c->attn_split ? 64 : 0)},
+        {"token_path", (c->world == 1 ? ((c->fuse_attn_o ? 1 : 0) | (c->fuse_ffn ? 2 : 0) | (c->fuse_attn_o && c->fuse_qkv == 1 ? 4 : 0) | (c->fuse_attn_o && c->fuse_qkv >= 2 ? 8 : 0) | (c->fuse_back && c->fuse_attn_o && c->fuse_ffn ? (c->fuse_layer ? 128 + 256 + (c->fuse_token ? 512 : 0) : 128) : 0)) : 0) | (c->attn_split ? 64 : 0)},
     };
     for (const auto& t : tab) if (k == t.k) { *value = t.v; return FLM_OK; }
     return fail(c, FLM_ERR_INVALID, "query: unknown key");

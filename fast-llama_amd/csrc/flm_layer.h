@@ -32,6 +32,8 @@ struct BackArgs {
     unsigned* flag_h;           // heads' lines
     unsigned* flag_x;           // Wo workgroups' lines (x1)
     unsigned* flag_hd;          // FFN13 workgroups' lines (hd)
+    unsigned* flag_x2;          // k_layers: FFN2 workgroups' lines (the residual stream x for the next layer's QKV)
+    int nstq, preq;             // k_layers: stash slots / early waves of [Wq; Wk; Wv] requested in front of the x poll
     unsigned target; int* err;
     unsigned st_base;           // LDS byte offset of the stash slots (above every phase's own layout)
     int nst13;                  // stash slots of [W1; W3] a Wo workgroup fills under the attention
@@ -70,21 +72,32 @@ __device__ __forceinline__ void poll_lines(const unsigned* flag, int n, unsigned
 // from their last QKV row to the Wo / stash requests, so the memory pipeline has work across what used to be a kernel boundary and a launch ramp.
 // SPLIT (long contexts): a head is spread over G = aa.G workgroups (attn_head<.., SPLIT>); n_heads counts head PARTS; a part's 32 output dimensions are half a quant group,
 // so the Wo workgroups fetch the fp32 vector and quantize it themselves (dim <= 4096: one round).
-template <int QT, int XR2, bool QKV = false, bool SPLIT = false>
-__global__ void __launch_bounds__(kGemvBlock, 4) k_attn_ffn(const GemvArgs aq, const AttnArgs aa, const GemvArgs ao, const GemvArgs a13, const GemvArgs a2, const BackArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
+// PERSIST (k_layers: several layers in one launch): xpoll = the layer's x comes from the previous layer's FFN2 in the SAME launch -- [Wq; Wk; Wv]'s first register sets (preq waves) and
+// nstq stash slots are requested, then the FFN2 lines are polled and x is read with coherent loads; xflag = this layer's FFN2 raises its lines for the next layer.
+template <int QT, int XR2, bool QKV, bool SPLIT, bool PERSIST>
+__device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& aa, const GemvArgs& ao, const GemvArgs& a13, const GemvArgs& a2, const BackArgs& p, char* lds,
+                                           const unsigned target, const bool xpoll, const bool xflag, const bool tracing) {
     auto nostamp = [](int) {};
-    auto stamp = [&](int k) { if (kAblate && p.trace && threadIdx.x == 0) p.trace[blockIdx.x * 16 + k] = __builtin_amdgcn_s_memrealtime(); };
+    auto stamp = [&](int k) { if (kAblate && tracing && p.trace && threadIdx.x == 0) p.trace[blockIdx.x * 16 + k] = __builtin_amdgcn_s_memrealtime(); };
     stamp(0);
-    const unsigned target = p.target;
     unsigned nst13 = 0;
     if constexpr (QKV) {
         if ((int)blockIdx.x < p.gridq) {
             float4 xq[1], nq[1];
-            gemv_preload<QT, PRO_RMSNORM_QUANT, 1>(aq, xq, nq);
-            GemvCtx<QT, EPI_ROPE_KV> gq;
-            gq.init(aq, blockIdx.x, p.gridq, lds);
-            gemv_prologue<QT, PRO_RMSNORM_QUANT, 1, false, FLM_LAYER_LATEQ != 0>(aq, lds, xq, nq, [&](int part) { gq.issue(kAblate ? aq.ablate : 0, part); });
+            if (!PERSIST || !xpoll) gemv_preload<QT, PRO_RMSNORM_QUANT, 1, PERSIST>(aq, xq, nq);    // (x is there: requested in front of the context's set-up)
+            GemvCtx<QT, EPI_ROPE_KV, PERSIST> gq;
+            gq.init(aq, blockIdx.x, p.gridq, lds, 0, p.st_base, (PERSIST && xpoll) ? (unsigned)p.nstq : 0u);
+            if constexpr (PERSIST) {
+                if (xpoll) {
+                    if ((int)gq.wave < p.preq) gq.issue(kAblate ? aq.ablate : 0, 1);
+                    gq.stash_issue(lds);
+                    poll_lines(p.flag_x2, p.grid2, target - 1u, p.err);
+                    wait_stores_done();                                         // every wave: the stash slots it requested have landed
+                    __syncthreads();
+                    gemv_preload<QT, PRO_RMSNORM_QUANT, 1, true>(aq, xq, nq);
+                }
+            }
+            gemv_prologue<QT, PRO_RMSNORM_QUANT, 1, PERSIST, FLM_LAYER_LATEQ != 0>(aq, lds, xq, nq, [&](int) { gq.issue_missing(kAblate ? aq.ablate : 0); });
             stamp(12);
             gq.run(aq, lds, nostamp);
             stamp(13);
@@ -194,7 +207,7 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_attn_ffn(const GemvArgs aq, c
     __syncthreads();                                                            // (and the LDS is free for the last phase)
     if (threadIdx.x == 0) __hip_atomic_store(p.flag_hd + blockIdx.x * kFlagStride, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     stamp(8);
-    if ((int)blockIdx.x >= p.grid2) return;
+    if ((int)blockIdx.x < p.grid2) {
     // ---- FFN2: k_gemv<QUANT, RESIDUAL> behind the hd flag round
     GemvCtx<QT, EPI_RESIDUAL, true> g2;
     g2.init(a2, blockIdx.x, p.grid2, lds, 0, p.st_base, (unsigned)p.nst2);
@@ -210,6 +223,38 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_attn_ffn(const GemvArgs aq, c
     stamp(10);
     g2.run(a2, lds, nostamp);
     stamp(11);
+    }
+    if constexpr (PERSIST) {
+        if (xflag) {
+            wait_stores_done();                                                 // every wave: its rows of x are where the next layer will read them
+            __syncthreads();                                                    // (and the LDS is free for the next layer)
+            if (threadIdx.x == 0 && (int)blockIdx.x < p.grid2) __hip_atomic_store(p.flag_x2 + blockIdx.x * kFlagStride, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+template <int QT, int XR2, bool QKV = false, bool SPLIT = false>
+__global__ void __launch_bounds__(kGemvBlock, 4) k_attn_ffn(const GemvArgs aq, const AttnArgs aa, const GemvArgs ao, const GemvArgs a13, const GemvArgs a2, const BackArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    layer_body<QT, XR2, QKV, SPLIT, false>(aq, aa, ao, a13, a2, p, lds, p.target, false, false, true);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_layers: the layers [l0, l1) of a token in ONE launch -- layer_body in a loop, the argument blocks of every layer in device memory (built once by the host: they hold
+// pointers only; position and token are read through pos_ptr).  What the loop buys is the edge between two layers: instead of a kernel boundary and a launch ramp, a flag round
+// in front of which the next layer's [Wq; Wk; Wv] starts to stream (preq waves' first register sets + nstq stash slots: the LDS is empty there).
+// ------------------------------------------------------------------------------------------
+struct LayerArgs { GemvArgs aq, ao, a13, a2; AttnArgs aa; };
+template <int QT, int XR2, bool SPLIT>
+__global__ void __launch_bounds__(kGemvBlock, 4) k_layers(const LayerArgs* __restrict__ LA, const BackArgs p, const int l0, const int l1) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    // (the argument blocks through the CONSTANT address space: uniform scalar loads at the point of use, like kernel arguments -- through a generic pointer they would sit in vector registers)
+    typedef const LayerArgs __attribute__((address_space(4))) CLayerArgs;
+    CLayerArgs* LAc = (CLayerArgs*)(unsigned long long)LA;
+    for (int l = l0; l < l1; ++l) {
+        const LayerArgs& A = *(const LayerArgs*)(LAc + l);
+        layer_body<QT, XR2, true, SPLIT, true>(A.aq, A.aa, A.ao, A.a13, A.a2, p, lds, (unsigned)(l + 1), l > l0, l + 1 < l1, l == (l1 - l0 > 1 ? l0 + 1 : l0));   // (trace builds: the stamps of the launch's second layer)
+    }
 }
 
 } // namespace flm

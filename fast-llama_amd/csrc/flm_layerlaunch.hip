@@ -4,8 +4,9 @@
 namespace fh {
 
 // attention + Wo + FFN13 + FFN2 of layer l in one launch (k_attn_ffn, flm_layer.h); returns FLM_ERR_UNSUPPORTED when the shape does not allow it
+// the argument blocks, the launch geometry and the stash sizes of layer l (the same for every layer but for the pointers): shared by k_attn_ffn's launch and k_layers' (flm_layers.hip)
 template <int QT>
-int launch_attn_ffn(flm_ctx* c, hipStream_t st, int l, bool with_qkv, int G) {
+int plan_layer(flm_ctx* c, int l, bool with_qkv, int G, LayerArgs& A, BackArgs& p, int& grid, int& r2) {
     const auto& d = c->d;
     constexpr int esz = QTraits<QT>::kEsz;
     const int all = c->cu_count < 256 ? c->cu_count : 256, parts = c->heads_local * G, wgs_o = all - parts;
@@ -20,7 +21,7 @@ int launch_attn_ffn(flm_ctx* c, hipStream_t st, int l, bool with_qkv, int G) {
     }
     r = plan_gemv<QT, PRO_RMSNORM_QUANT, EPI_SWIGLU>(c, a13, all, P13); if (r) return r;
     r = plan_gemv<QT, PRO_QUANT, EPI_RESIDUAL>(c, a2, all, P2); if (r) return r;
-    const int r13 = (a13.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4), r2 = (a2.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4);
+    const int r13 = (a13.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4); r2 = (a2.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4);
     if (r13 > 1 || r2 > 3) return FLM_ERR_UNSUPPORTED;
     if (G > 1 && (ao.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4) > 1) return FLM_ERR_UNSUPPORTED;
     // a workgroup with a single pass needs one strip buffer: the LDS above the phases' own layouts is the stash
@@ -30,7 +31,7 @@ int launch_attn_ffn(flm_ctx* c, hipStream_t st, int l, bool with_qkv, int G) {
     };
     one_pass(ao, Po, false); one_pass(a13, P13, true); one_pass(a2, P2, false);
     size_t own = Po.lds; if (P13.lds > own) own = P13.lds; if (P2.lds > own) own = P2.lds;
-    if (with_qkv) { one_pass(aq, Pq, false, 2); if (Pq.lds > kLdsMax) return FLM_ERR_UNSUPPORTED; }     // (the QKV phase is over before the first stash request: its layout may overlap the slots)
+    if (with_qkv) { one_pass(aq, Pq, false, 2); if (Pq.lds > kLdsMax) return FLM_ERR_UNSUPPORTED; if (c->fuse_token && Pq.lds > own) own = Pq.lds; }   // (k_layers stashes [Wq; Wk; Wv] too: above its layout as well)
     own = (own + 255) & ~(size_t)255;
     const size_t lds_attn = attn_lds_bytes(d.max_seq_len, c->hs, G > 1);
     if (own > kLdsMax || lds_attn > kLdsMax) return FLM_ERR_UNSUPPORTED;
@@ -38,15 +39,29 @@ int launch_attn_ffn(flm_ctx* c, hipStream_t st, int l, bool with_qkv, int G) {
     auto slots = [&](int want) { int n = want < 0 ? fit : want; if (n > fit) n = fit; if (n > 32) n = 32; return n < 0 ? 0 : n; };
     AttnArgs aa = args_attn(c, l, G);
     if (G == 1) { aa.oq = c->att_q; aa.os = c->att_qs; aa.oqt = QT; ao.xq = c->att_q; ao.xs = c->att_qs; }   // the heads hand their output over quantized
-    BackArgs p{};
+    p = BackArgs{};
     p.n_heads = parts; p.grido = Po.grid; p.grid13 = P13.grid; p.grid2 = P2.grid;
     p.flag_h = c->flag_lines; p.flag_hd = c->flag_lines + 512 * 16; p.flag_x = c->flag_lines + 1024 * 16;
     p.gridq = with_qkv ? Pq.grid : 0; p.flag_q = c->flag_lines + 768 * 16;
     p.target = (unsigned)(l + 1); p.err = c->xwg_err;
     p.st_base = (unsigned)own; p.nst13 = slots(c->back_nst13); p.nst13_head = slots(c->back_nst13_head); p.nst2 = slots(c->back_nst2); p.pre13 = c->back_pre13 < 0 ? 0 : c->back_pre13 > 16 ? 16 : c->back_pre13; p.pre2 = c->back_pre2 < 0 ? 0 : c->back_pre2 > 16 ? 16 : c->back_pre2;
     if (kAblate && c->trace_class == 102 && l == 0) { p.trace = c->trace; a13.trace = c->trace + 256 * 16; a2.trace = c->trace + 2 * 256 * 16; }   // tools/trace_back.py
-    int grid = parts + Po.grid; if (P13.grid > grid) grid = P13.grid; if (P2.grid > grid) grid = P2.grid; if (with_qkv && Pq.grid > grid) grid = Pq.grid;
+    if (kAblate && c->trace_class == 103) { p.trace = c->trace; if (l == (c->d.n_layers > 1 ? 1 : 0)) { a13.trace = c->trace + 256 * 16; a2.trace = c->trace + 2 * 256 * 16; aa.trace = c->trace + 5 * 4096; } }   // (k_layers: its second layer)
+    grid = parts + Po.grid; if (P13.grid > grid) grid = P13.grid; if (P2.grid > grid) grid = P2.grid; if (with_qkv && Pq.grid > grid) grid = Pq.grid;
     if (grid > all) return FLM_ERR_UNSUPPORTED;
+    p.flag_x2 = c->flag_lines + 1280 * 16; p.nstq = slots(c->tok_nstq); p.preq = c->tok_preq < 0 ? 0 : c->tok_preq > 16 ? 16 : c->tok_preq;
+    A.aq = aq; A.ao = ao; A.a13 = a13; A.a2 = a2; A.aa = aa;
+    return FLM_OK;
+}
+template int plan_layer<QT_INT8>(flm_ctx*, int, bool, int, LayerArgs&, BackArgs&, int&, int&);
+template int plan_layer<QT_INT16>(flm_ctx*, int, bool, int, LayerArgs&, BackArgs&, int&, int&);
+
+// attention + Wo + FFN13 + FFN2 of layer l (with_qkv: the whole layer) in one launch (k_attn_ffn, flm_layer.h); returns FLM_ERR_UNSUPPORTED when the shape does not allow it
+template <int QT>
+int launch_attn_ffn(flm_ctx* c, hipStream_t st, int l, bool with_qkv, int G) {
+    LayerArgs A; BackArgs p; int grid = 0, r2 = 0;
+    int r = plan_layer<QT>(c, l, with_qkv, G, A, p, grid, r2); if (r) return r;
+    const GemvArgs &aq = A.aq, &ao = A.ao, &a13 = A.a13, &a2 = A.a2; const AttnArgs& aa = A.aa;
     {   // the stash takes the rest of the CU's 160 KiB: raise the kernels' dynamic-LDS limit, once per device
         static std::mutex mu; static bool done[64] = {false};
         std::lock_guard<std::mutex> lk(mu);

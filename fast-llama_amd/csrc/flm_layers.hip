@@ -1,0 +1,58 @@
+// flm_layers.hip -- host side of k_layers (flm_layer.h): ALL layers of a token in one launch.  A translation unit of its own because the kernel is compiled with
+// FLM_OPAQUE_TID (flm_math.h: reads of threadIdx.x are opaque, so that nothing derived from it is hoisted out of the loop over layers and kept in registers).
+#define FLM_OPAQUE_TID 1
+#include "flm_host.h"
+
+namespace fh {
+
+template <int QT> int plan_layer(flm_ctx* c, int l, bool with_qkv, int G, LayerArgs& A, BackArgs& p, int& grid, int& r2);     // flm_layerlaunch.hip
+
+// the layers' argument blocks in device memory, per number of workgroups a head is spread over (G = 1 | hs / 32): built outside any stream capture, valid until an option changes
+int layers_prepare(flm_ctx* c, int G) {
+    const int key = G > 1 ? 1 : 0;
+    if (!c->fuse_token || c->world != 1) return FLM_OK;
+    if (c->la_valid[key]) return FLM_OK;
+    const int L = c->d.n_layers, qt = c->d.quant_type;
+    std::vector<LayerArgs> host((size_t)L);
+    c->la_ok[key] = false;
+    for (int l = 0; l < L; ++l) {
+        BackArgs p; int grid = 0, r2 = 0;
+        const int r = qt == FLM_QT_INT8 ? plan_layer<QT_INT8>(c, l, true, G, host[l], p, grid, r2) : plan_layer<QT_INT16>(c, l, true, G, host[l], p, grid, r2);
+        if (r == FLM_ERR_UNSUPPORTED) { c->la_valid[key] = true; return FLM_OK; }      // (this shape runs one launch per layer, or per phase)
+        if (r) return r;
+        c->la_p[key] = p; c->la_grid[key] = grid; c->la_r2[key] = r2;
+    }
+    if (!c->la_dev[key]) HIPC(c, hipMalloc((void**)&c->la_dev[key], sizeof(LayerArgs) * (size_t)L));
+    HIPC(c, hipMemcpyAsync(c->la_dev[key], host.data(), sizeof(LayerArgs) * (size_t)L, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));                                           // (host goes out of scope)
+    c->la_ok[key] = true; c->la_valid[key] = true;
+    return FLM_OK;
+}
+
+// layers [l0, l1) of the token in one launch; FLM_ERR_UNSUPPORTED: not prepared / not possible for this shape
+int launch_layers(flm_ctx* c, hipStream_t st, int l0, int l1, int G) {
+    const int key = G > 1 ? 1 : 0;
+    if (!c->fuse_token || !c->la_valid[key] || !c->la_ok[key] || l1 <= l0) return FLM_ERR_UNSUPPORTED;
+    {
+        static std::mutex mu; static bool done[64] = {false};
+        std::lock_guard<std::mutex> lk(mu);
+        if (c->device >= 0 && c->device < 64 && !done[c->device]) {
+            const void* fns[] = {(const void*)&k_layers<QT_INT8, 1, false>, (const void*)&k_layers<QT_INT8, 3, false>, (const void*)&k_layers<QT_INT16, 1, false>, (const void*)&k_layers<QT_INT16, 3, false>,
+                                 (const void*)&k_layers<QT_INT8, 1, true>, (const void*)&k_layers<QT_INT8, 3, true>, (const void*)&k_layers<QT_INT16, 1, true>, (const void*)&k_layers<QT_INT16, 3, true>};
+            for (const void* f : fns) HIPC(c, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
+            done[c->device] = true;
+        }
+    }
+    const dim3 g3(c->la_grid[key]), b3(kGemvBlock);
+    const LayerArgs* LA = (const LayerArgs*)c->la_dev[key];
+    const BackArgs p = c->la_p[key];
+    const bool i8 = c->d.quant_type == FLM_QT_INT8, one = c->la_r2[key] <= 1;
+#define FLM_LAUNCH_LAYERS(QT, XR2, SP) hipLaunchKernelGGL((k_layers<QT, XR2, SP>), g3, b3, kLdsMax, st, LA, p, l0, l1)
+    if (G > 1) { if (i8) { if (one) FLM_LAUNCH_LAYERS(QT_INT8, 1, true); else FLM_LAUNCH_LAYERS(QT_INT8, 3, true); } else { if (one) FLM_LAUNCH_LAYERS(QT_INT16, 1, true); else FLM_LAUNCH_LAYERS(QT_INT16, 3, true); } }
+    else       { if (i8) { if (one) FLM_LAUNCH_LAYERS(QT_INT8, 1, false); else FLM_LAUNCH_LAYERS(QT_INT8, 3, false); } else { if (one) FLM_LAUNCH_LAYERS(QT_INT16, 1, false); else FLM_LAUNCH_LAYERS(QT_INT16, 3, false); } }
+#undef FLM_LAUNCH_LAYERS
+    HIPC(c, hipGetLastError());
+    return FLM_OK;
+}
+
+} // namespace fh

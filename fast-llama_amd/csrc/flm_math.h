@@ -33,6 +33,15 @@
 //    -fhip-fp32-correctly-rounded-divide-sqrt.  HIP's __fsqrt_rn maps to the 1-ulp native sqrt: never used.
 #pragma clang fp contract(off)
 
+#ifdef FLM_OPAQUE_TID
+// k_layers (flm_layers.hip) runs layer_body in a LOOP over layers: the compiler then hoists every thread-index-derived value (lane offsets of five GemvCtx, the attention's
+// piece offsets, poll indices ...) out of the loop and keeps them in registers across all phases -- 24 to 98 spilled VGPRs, and a kernel with scratch.  Behind this macro every
+// read of threadIdx.x is an opaque value (an empty asm statement, one v_mov at most), so nothing derived from it is loop-invariant and the phases keep their own short live ranges.
+struct FlmTid3 { unsigned x, y, z; };
+__device__ __forceinline__ FlmTid3 flm_tid3() { unsigned t = __builtin_amdgcn_workitem_id_x(); asm volatile("" : "+v"(t)); return FlmTid3{t, 0u, 0u}; }
+#define threadIdx (flm_tid3())
+#endif
+
 namespace flm {
 
 constexpr int kWave = 64;

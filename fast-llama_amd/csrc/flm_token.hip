@@ -292,6 +292,10 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
     // made for the tests is sized for it: launches are cut to the partition)
     const bool span = fold && c->grp_span;
     const int tpfa = span ? c->grp_tpfa : 0, tpff = span ? c->grp_tpff : 0;
+    if (!tp && c->fuse_token && c->fuse_layer && c->fuse_back && c->fuse_attn_o && c->fuse_ffn && !c->timing && (c->trace_class < 0 || c->trace_class == 103)) {   // all layers in one launch
+        r = launch_layers(c, st, 0, L, G);
+        if (r == FLM_OK) goto layers_done; else if (r != FLM_ERR_UNSUPPORTED) return r;
+    }
     for (int l = 0; l < L; ++l) {
         bool fused = false;
         const bool back_ok = !tp && c->fuse_back && c->fuse_attn_o && c->fuse_ffn && !c->timing && (c->trace_class < 0 || c->trace_class == 102);
@@ -347,6 +351,7 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
         }
         if (tp && (!fold || (l == L - 1 && !with_cls))) { r = exchange(c, st, XK_X1, c->x1, c->x1 + c->drow_begin, c->drow_count); if (r) return r; }
     }
+layers_done:
     if (with_cls) {
         {   // final norm + CLS task (transformer.cpp:154-160, execute_cls :496-505): this rank's rows of the classifier
             Tick t(c, st, KC_CLS);
@@ -421,12 +426,18 @@ int flm_kernel_times(flm_ctx* c, int pos, int iters, float* avg_us, int32_t* cou
         case KC_LAYER: case KC_BACK: {
                          if (c->world > 1 || !c->fuse_back || !c->fuse_attn_o || !c->fuse_ffn || (kc == KC_BACK && attn_parts(c, pos + 1) != 1) || (kc == KC_LAYER) != (c->fuse_layer != 0)) return FLM_ERR_UNSUPPORTED;
                          return launch_layer(c, st, qt, l, kc == KC_LAYER, attn_parts(c, pos + 1)); }
+        case KC_LAYERS: {   // ONE launch for the L layers (enqueued for l == 0)
+                         if (c->world > 1 || !c->fuse_token || !c->fuse_layer || !c->fuse_back || !c->fuse_attn_o || !c->fuse_ffn) return FLM_ERR_UNSUPPORTED;
+                         if (l != 0) return FLM_OK;
+                         const int G = attn_parts(c, pos + 1);
+                         const int rr = layers_prepare(c, G); if (rr) return rr;
+                         return launch_layers(c, st, 0, L, G); }
         default: return FLM_OK;
         }
     };
-    const int classes[] = {KC_EMBED, KC_QKV, KC_ATTN, KC_ATTN_O, KC_FFN13, KC_FFN2, KC_CLS, KC_ARGMAX, KC_ATTN_WO, KC_FFN, KC_QKV_ATTN_WO, KC_LAYER, KC_BACK};
+    const int classes[] = {KC_EMBED, KC_QKV, KC_ATTN, KC_ATTN_O, KC_FFN13, KC_FFN2, KC_CLS, KC_ARGMAX, KC_ATTN_WO, KC_FFN, KC_QKV_ATTN_WO, KC_LAYER, KC_BACK, KC_LAYERS};
     for (int kc : classes) {
-        const bool fused = kc == KC_ATTN_WO || kc == KC_FFN || kc == KC_QKV_ATTN_WO || kc == KC_LAYER || kc == KC_BACK;
+        const bool fused = kc == KC_ATTN_WO || kc == KC_FFN || kc == KC_QKV_ATTN_WO || kc == KC_LAYER || kc == KC_BACK || kc == KC_LAYERS;
         const bool per_layer = (kc >= KC_QKV && kc <= KC_FFN2) || fused;
         const int n = per_layer ? L : 8;
         for (int it = 0; it < iters + 1 && !r; ++it) {          // first round: warm-up
@@ -437,10 +448,10 @@ int flm_kernel_times(flm_ctx* c, int pos, int iters, float* avg_us, int32_t* cou
             HIPC(c, hipEventRecord(e1, st));
             HIPC(c, hipEventSynchronize(e1));
             float ms = 0.f; HIPC(c, hipEventElapsedTime(&ms, e0, e1));
-            if (it > 0) { tot[kc] += ms * 1000.0 / n; cnt[kc] += 1; }
+            if (it > 0) { tot[kc] += ms * 1000.0 / (kc == KC_LAYERS ? 1 : n); cnt[kc] += 1; }
         }
         avg_us[kc] = cnt[kc] ? (float)(tot[kc] / cnt[kc]) : 0.f;
-        count[kc] = cnt[kc] ? (per_layer ? L : 1) : 0;
+        count[kc] = cnt[kc] ? (per_layer && kc != KC_LAYERS ? L : 1) : 0;
     }
     avg_us[KC_ALLREDUCE] = 0.f; count[KC_ALLREDUCE] = 0;
     if (r) return r;
@@ -466,6 +477,7 @@ int flm_kernel_bytes(flm_ctx* c, int kclass, int pos, double* bytes) {
     case KC_CLS:    *bytes = mat(c->cls.rows, d.dim) + d.dim * 4.0; break;
     case KC_BACK:   *bytes = 2.0 * c->heads_local * c->hs * 4.0 * (pos + 1) + mat(c->drow_count, d.dim) + 2.0 * mat(c->hidden_local, d.dim) + d.dim * 4.0 + mat(c->drow_count, d.hidden_dim); break;
     case KC_LAYER:  *bytes = mat(3.0 * c->dim_local, d.dim) + d.dim * 4.0 + 2.0 * c->heads_local * c->hs * 4.0 * (pos + 1) + mat(c->drow_count, d.dim) + 2.0 * mat(c->hidden_local, d.dim) + d.dim * 4.0 + mat(c->drow_count, d.hidden_dim); break;
+    case KC_LAYERS: *bytes = (double)d.n_layers * (mat(3.0 * c->dim_local, d.dim) + d.dim * 4.0 + 2.0 * c->heads_local * c->hs * 4.0 * (pos + 1) + mat(c->drow_count, d.dim) + 2.0 * mat(c->hidden_local, d.dim) + d.dim * 4.0 + mat(c->drow_count, d.hidden_dim)); break;
     default:        *bytes = 0; break;
     }
     return FLM_OK;

@@ -126,11 +126,13 @@ int  flm_sync(flm_ctx* ctx);
  * 11 qkv_attn_wo: QKV + attention + Wo in one launch, what the token path runs instead of (1, 9) at long contexts ("fuse_qkv").
  * 12 layer: the whole decoder layer in one launch (k_attn_ffn: QKV, attention, Wo, FFN13, FFN2 -- what the token path runs instead of (1, 9, 10) where a head is
  * one workgroup and the head size a multiple of 64; option "fuse_layer"), 13 back: the same without the QKV GEMV ("fuse_layer" 0: instead of (9, 10)).
+ * 14 layers: ALL layers of the token in one launch (k_layers: what the token path runs instead of L launches of class 12; option "fuse_token"): ONE launch per token,
+ * avg_us = the duration of that launch, flm_kernel_bytes = L layers' bytes.
  * avg_us[c] = mean duration of ONE launch of class c (single GPU: the class's launches of one token are
  * enqueued back to back between one pair of events, so the figure is launch duration + dispatch gap and
  * agrees with a rocprofv3 kernel trace), count[c] = launches of that class per token.
  * Side effect: the KV cache is cleared and the decode state is undefined afterwards. */
-#define FLM_KCLASSES 14
+#define FLM_KCLASSES 15
 int  flm_kernel_times(flm_ctx* ctx, int pos, int iters, float* avg_us, int32_t* count);
 /* weight + scale bytes one launch of class c streams (the algorithmic bytes of DESIGN.md) */
 int  flm_kernel_bytes(flm_ctx* ctx, int kclass, int pos, double* bytes);
@@ -163,6 +165,9 @@ int  flm_debug_read(flm_ctx* ctx, int what, int layer, float* out, size_t n);
  * "tp_trust_fused" 1 = between DISTINCT devices too, run the folded exchanges / rank-spanning launches (default: the k_xchg launches; set on every rank before flm_p2p_export),
  * "fuse_back" 0 = attention + Wo and FFN13 + FFN2 as two launches (k_attn_o, k_ffn) instead of one (k_attn_ffn, default 1: [W1; W3] stashed in LDS under the attention),
  * "fuse_layer" 0 = the QKV GEMV as its own launch in front of k_attn_ffn (default 1: the whole decoder layer in one launch),
+ * "fuse_token" 0 = one launch per layer (k_attn_ffn) instead of one per token (k_layers, default 1: the layers in a loop inside the launch, the edge between two layers a
+ *          flag round); "tok_preq" / "tok_nstq" how many of a workgroup's 16 waves request their first register set of the NEXT layer's [Wq; Wk; Wv] / how many LDS stash
+ *          slots it fills with it in front of that flag round (defaults 16, 4: tools/back_bench.py),
  * "back_nst13" / "back_nst13_head" / "back_nst2" LDS stash slots (4.25 KiB each; -1 = as many as the LDS holds) a Wo workgroup fills with [W1; W3] under the attention /
  *          a head workgroup fills behind its head / every workgroup fills with W2 behind its rows of hd; "back_pre13" how many of a workgroup's 16 waves request their
  *          first register set of [W1; W3] in front of the x1 flag round (defaults -1, -1, 0, 16: tools/back_bench.py),
@@ -177,7 +182,7 @@ int  flm_set_option(flm_ctx* ctx, const char* key, int value);
  *               xwg_check; the call itself was re-run and returned correct results),
  *   "token_path" bit 0 attention + Wo fused, bit 1 FFN13 + FFN2 fused, bit 2 QKV joins the attention's launch at long contexts, bit 3 the same
  *               at every context, bit 6 heads split over workgroups at long contexts, bit 7 attention .. FFN2 in one launch (k_attn_ffn), bit 8 with the QKV GEMV in front
- *               (the whole layer in one launch).
+ *               (the whole layer in one launch), bit 9 all layers of the token in one launch (k_layers).
  * Unknown key: FLM_ERR_INVALID. */
 int  flm_query(flm_ctx* ctx, const char* key, int* value);
 

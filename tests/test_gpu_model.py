@@ -91,7 +91,7 @@ def test_7b_width_layer_every_code_path_vs_oracle(gpu, qt):
     cur, pos = int(np.argmax(want[0])), len(prompt)
     for _ in range(3):
         want.append(om.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(want[-1])); pos += 1
-    for opts in ({}, {"fuse_layer": 0}, {"fuse_back": 0}, {"fuse_attn_o": 0}, {"fuse_ffn": 0}, {"fuse_attn_o": 0, "fuse_ffn": 0}, {"fuse_qkv": 2}, {"fuse_qkv": 2, "use_prefill": 0}):
+    for opts in ({}, {"fuse_token": 0}, {"fuse_layer": 0}, {"fuse_back": 0}, {"fuse_attn_o": 0}, {"fuse_ffn": 0}, {"fuse_attn_o": 0, "fuse_ffn": 0}, {"fuse_qkv": 2}, {"fuse_qkv": 2, "use_prefill": 0}):
         ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
         for k, v in opts.items():
             ctx.set_option(k, v)
@@ -105,10 +105,11 @@ def test_7b_width_layer_every_code_path_vs_oracle(gpu, qt):
         ctx.close()
 
 
-@pytest.mark.parametrize("shape,qt,layers", [("7B", ff.QT_INT8, 2), ("7B", ff.QT_INT16, 1), ("small", ff.QT_INT8, None), ("tiny128", ff.QT_INT16, None),
+@pytest.mark.parametrize("shape,qt,layers", [("7B", ff.QT_INT8, 3), ("7B", ff.QT_INT16, 2), ("small", ff.QT_INT8, None), ("tiny128", ff.QT_INT16, None),
                                              ((512, 1408, 3, 8, 320), ff.QT_INT8, None), ((1024, 2752, 2, 8, 320), ff.QT_INT16, None)])
 def test_back_half_of_a_layer_in_one_launch_vs_oracle(gpu, shape, qt, layers):
-    """k_attn_ffn: attention + Wo + FFN13 + FFN2 as one launch (head sizes that are multiples of 64; the other shapes must fall back to the two
+    """k_layers / k_attn_ffn: all layers of the token in one launch (the next layer's [Wq; Wk; Wv] requested in front of the flag round between two layers: every
+    way of sizing that request), one launch per layer, and attention + Wo + FFN13 + FFN2 as one launch (head sizes that are multiples of 64; the other shapes must fall back to the two
     launches by themselves), with every way of filling the LDS stash -- [W1; W3] under the attention, by the head workgroups behind their head, W2 behind
     a workgroup's rows of hd, the first register set in front of the x1 flag round --: logits of a prompt (token by token) and of graph-replayed greedy
     steps are the oracle's bits, whatever the stash holds."""
@@ -122,7 +123,7 @@ def test_back_half_of_a_layer_in_one_launch_vs_oracle(gpu, shape, qt, layers):
     cur, pos = int(np.argmax(want[0])), len(prompt)
     for _ in range(4):
         want.append(om.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(want[-1])); pos += 1
-    variants = ({}, {"fuse_layer": 0}, {"back_nst13": 0}, {"back_nst13": 3, "fuse_layer": 0}, {"back_nst13": 17, "back_nst13_head": 5}, {"back_nst13_head": -1, "back_nst2": -1},
+    variants = ({}, {"fuse_token": 0}, {"tok_preq": 0, "tok_nstq": 0}, {"tok_preq": 5, "tok_nstq": -1}, {"tok_preq": 16, "tok_nstq": 9, "back_nst13": 2, "use_graph": 0}, {"fuse_layer": 0}, {"back_nst13": 0}, {"back_nst13": 3, "fuse_layer": 0}, {"back_nst13": 17, "back_nst13_head": 5}, {"back_nst13_head": -1, "back_nst2": -1},
                 {"back_nst13": 0, "back_nst2": 7, "back_pre13": 1}, {"back_nst13": -1, "back_nst13_head": -1, "back_nst2": -1, "back_pre13": 1, "use_graph": 0})
     for opts in variants:
         ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
@@ -269,9 +270,9 @@ def test_fused_attention_decode_over_the_whole_context_matches_two_launches(gpu)
 
 
 def test_long_context_decode_with_split_heads_vs_oracle(gpu):
-    """7B width, one layer: a 600-token prompt, then decode steps at positions 600.. with every head spread over 4 workgroups
+    """7B width, two layers (k_layers: SPLIT heads across the edge between layers): a 600-token prompt, then decode steps at positions 600.. with every head spread over 4 workgroups
     (the default from 128 positions on) and over 1 and 2 -- logits bit-equal to the oracle's"""
-    cfg = synth.make_config("7B", ff.QT_INT8); cfg.n_layers = 1
+    cfg = synth.make_config("7B", ff.QT_INT8); cfg.n_layers = 2
     tensors = synth.make_tensors(cfg, seed=19)
     om = O.OracleModel(cfg, tensors)
     prompt = _prompt(cfg.vocab_size, 600)
@@ -279,7 +280,7 @@ def test_long_context_decode_with_split_heads_vs_oracle(gpu):
     cur, pos = int(np.argmax(want[0])), len(prompt)
     for _ in range(3):
         want.append(om.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(want[-1])); pos += 1
-    for opts in ({}, {"fuse_layer": 0}, {"fuse_back": 0}, {"back_nst13": 5, "back_pre13": 3}, {"attn_split": 0}, {"attn_split": 2}, {"fuse_attn_o": 0}, {"use_graph": 0}, {"fuse_qkv": 0}, {"fuse_qkv": 2, "attn_split": 0}):
+    for opts in ({}, {"fuse_token": 0}, {"tok_preq": 3, "tok_nstq": 7}, {"fuse_layer": 0}, {"fuse_back": 0}, {"back_nst13": 5, "back_pre13": 3}, {"attn_split": 0}, {"attn_split": 2}, {"fuse_attn_o": 0}, {"use_graph": 0}, {"fuse_qkv": 0}, {"fuse_qkv": 2, "attn_split": 0}):
         ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
         for k, v in opts.items():
             ctx.set_option(k, v)
@@ -360,8 +361,8 @@ def test_option_and_query_surface(gpu):
     ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
     assert ctx.query("resident") == 1 and ctx.query("fallback") == 0
     tp = ctx.query("token_path")
-    assert tp & 1 and tp & 2 and tp & 128 and tp & 256        # attention + Wo, FFN13 + FFN2, both in one launch, with the QKV GEMV in front
-    for key in ("fold_xchg", "cu_parts", "fuse_attn_o", "fuse_ffn", "fuse_qkv", "fuse_back", "fuse_layer", "back_nst13", "back_nst13_head", "back_nst2", "back_pre13",
+    assert tp & 1 and tp & 2 and tp & 128 and tp & 256 and tp & 512        # attention + Wo, FFN13 + FFN2, both in one launch, with the QKV GEMV in front, all layers in one launch
+    for key in ("fold_xchg", "cu_parts", "fuse_attn_o", "fuse_ffn", "fuse_qkv", "fuse_back", "fuse_layer", "fuse_token", "tok_preq", "tok_nstq", "back_nst13", "back_nst13_head", "back_nst2", "back_pre13",
                 "attn_split", "use_graph", "use_mfma", "use_prefill", "wg_per_cu"):
         ctx.query(key)
     with pytest.raises(gpu.FlmError):
@@ -380,7 +381,7 @@ def test_option_and_query_surface(gpu):
     for _ in range(2):
         want.append(om.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(want[-1])); pos += 1
     import itertools
-    keys = ("fuse_layer", "fuse_back", "fuse_attn_o", "fuse_ffn", "use_graph")
+    keys = ("fuse_token", "fuse_layer", "fuse_back", "fuse_attn_o", "fuse_ffn", "use_graph")
     for vals in itertools.product((0, 1), repeat=len(keys)):
         for fq in (0, 2):
             ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)

@@ -1,5 +1,5 @@
 """timeline of k_attn_ffn (attention + Wo + FFN13 + FFN2 in one launch; FLM_ABLATE build), all workgroups on the 100 MHz clock:
-FLM_GPU_LIB=fast-llama_amd/lib/var/libflm_abl.so python tools/trace_back.py [layers] [pos] ["k=v,k=v;k=v..." option sets]"""
+FLM_GPU_LIB=fast-llama_amd/lib/var/libflm_abl.so python tools/trace_back.py [layers] [pos] ["k=v,k=v;k=v..." option sets] [103 | 102]"""
 import sys, os
 sys.path.insert(0, os.getcwd())
 import numpy as np
@@ -8,6 +8,7 @@ from fast_llama_amd import capi, synth, flmfile as ff
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 pos = int(sys.argv[2]) if len(sys.argv) > 2 else 14
 sets = sys.argv[3].split(";") if len(sys.argv) > 3 else [""]
+tclass = int(sys.argv[4]) if len(sys.argv) > 4 else 103          # 103: k_layers (its second layer), 102: k_attn_ffn (layer 0)
 cfg = synth.make_config("7B", ff.QT_INT8); cfg.n_layers = L
 ctx = capi.Ctx(capi.desc_from_config(cfg))
 ctx.upload_all(synth.make_tensors(cfg, seed=1))
@@ -21,12 +22,13 @@ for spec in sets:
     ctx.reset_kv()
     first = ctx.forward_argmax(prompt, 0)
     ms = ctx.decode_timed(first, len(prompt), 32)
-    ctx.set_option("trace", 102); ctx.set_option("use_graph", 0)
+    ctx.set_option("trace", tclass); ctx.set_option("use_graph", 0)
     rows = []
     for rep in range(5):
         ctx.decode_greedy(first, len(prompt) + 32 + rep, 1)
-        rows.append(ctx.debug_read("back_trace", 0, 5 * 256 * 16).reshape(5, 256, 16).copy())
+        rows.append(ctx.debug_read("back_trace", 0, 6 * 256 * 16).reshape(6, 256, 16).copy())
     pro = rows[-1][1:3]; rn = rows[-1][4]
+    at = rows[-1][5].reshape(-1, 8)[:cfg.n_heads]
     ch = rows[-1][3]                  # the FFN13 chain's stages (wave 0): shader-clock ticks after the chain's start; [15] = rounds
     ok = ch[:, 14] > 0
     if ok.any():
@@ -42,7 +44,7 @@ for spec in sets:
     rows = [r[0] for r in rows]
     t = rows[-1]
     nh = cfg.n_heads
-    print(f"--- {spec or 'defaults'}: graph decode {ms / 32 * 1000:.1f} us/token ({L} layers); stamps of layer 0, us after the first workgroup's start (median / min / max)")
+    print(f"--- {spec or 'defaults'}: graph decode {ms / 32 * 1000:.1f} us/token ({L} layers); stamps of {'layer 1 inside k_layers' if tclass == 103 else 'layer 0 (k_attn_ffn)'}, us after the first workgroup's start (median / min / max)")
     for cls, sel in (("heads", slice(0, nh)), ("others", slice(nh, 256))):
         for k in (0, 12, 13, 14, 1, 15, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11):
             v = t[sel, k]; v = v[v >= 0]
@@ -57,5 +59,8 @@ for spec in sets:
             if line: print(f"  {nm}, {wn}: " + " | ".join(line))
     if (rn[:, 4] > 0).any():
         print("  FFN13 run(), chain wave: " + " | ".join(f"{nm} {np.median(rn[:, k][rn[:, k] > 0]):.2f}" for k, nm in ((3, "first refill requested"), (4, "last step reduced (at the barrier)"), (5, "chains + epilogue + stores issued"))))
+    if (at[:, 0] > 0).any():
+        an = {0: "entry (q flags seen)", 5: "first K tile parked", 1: "scores done", 2: "softmax done", 4: "weighted sum done", 6: "output quantized + stored"}
+        print("  attention (thread 0 of a head): " + " | ".join(f"{an[k]} {np.median(at[:, k][at[:, k] > 0]):.2f}" for k in (0, 5, 1, 2, 4, 6) if (at[:, k] > 0).any()))
     ends = np.array([r[:, 11].max() for r in rows])
     print("  launch span over 5 tokens:", " ".join(f"{e:.2f}" for e in ends))
