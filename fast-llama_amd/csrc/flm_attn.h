@@ -50,10 +50,10 @@ constexpr int kAttnDepth = 2;         // tiles in flight per stream (K, V), regi
 // immediate offsets; +8: the 8x8 (position, accumulator) score lanes and the PV lanes hit distinct banks
 __host__ __device__ inline int attn_row_stride(int hs) { const int nf = hs <= 64 ? 1 : hs <= 128 ? 2 : 4; return nf * 64 + 8; }
 __host__ inline size_t attn_lds_bytes(int max_seq, int hs, bool split = false) {
-    size_t tiles = (size_t)(2 * kAttnTile + 4) * attn_row_stride(hs);                       // + 4 slack rows: the PV read-ahead
+    size_t tiles = (size_t)(2 * kAttnTile + 12) * attn_row_stride(hs);                      // + 12 slack rows: the PV read-ahead
     const size_t vslice = (size_t)(1024 + 4) * 32 + 64;                                       // split heads: the part's whole V slice, transposed [32][kSplitMaxSeq + 4], lies where the K tiles were
     if (split && vslice > tiles) tiles = vslice;
-    return (size_t)(hs + 32 + ((max_seq + 3) & ~3) + 64 + tiles) * 4;
+    return (size_t)(hs + 32 + 64 + ((max_seq + 3) & ~3) + 64 + tiles) * 4;       // q, red, the exp table, scores, tiles
 }
 
 // NF = 16-byte pieces of a tile per thread = ceil(hs / 64)
@@ -69,14 +69,18 @@ __host__ inline size_t attn_lds_bytes(int max_seq, int hs, bool split = false) {
 // and the part's ENTIRE V slice (T x 32 floats <= 128 KiB) is requested when the kernel starts, waits in registers (8 x 16 bytes per
 // thread) under the scores and the softmax, and is then parked in LDS where the K tiles were: the weighted sum runs without a barrier.
 constexpr int kSplitDims = 32, kSplitMaxSeq = 1024, kSplitVRegs = kSplitMaxSeq * (kSplitDims / 4) / 1024;
-template <int NF, bool COH, bool SPLIT = false>
-__device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow, const int g = 0, const int G = 1) {
+// PRE (the whole-layer launches: q and the cache rows of THIS token come from workgroups of the same launch, behind a flag round = mid()): the rows of earlier tokens are
+// requested in FRONT of mid() and land while the lines are polled; behind it come q and the one new row of K and of V, patched into the ring registers of the
+// thread whose piece it is.  The arithmetic is untouched.
+struct AttnNoMid { __device__ __forceinline__ void operator()() const {} };
+template <int NF, bool COH, bool SPLIT = false, bool PRE = false, class Mid = AttnNoMid>
+__device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow, const int g = 0, const int G = 1, Mid&& mid = Mid()) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     constexpr int D = SPLIT ? 4 : kAttnDepth;         // K ring depth
     constexpr int DV = SPLIT ? 1 : kAttnDepth;        // V ring depth (SPLIT: unused, the slice sits in vall)
     const int hs = a.hs, tid = threadIdx.x;
 #ifdef FLM_TRACE_PRO_RT
-    auto stamp = [&](int k) { if (kAblate && a.trace && threadIdx.x == 0) a.trace[(h * G + g) * 8 + k] = __builtin_amdgcn_s_memrealtime(); };   // (tools/trace_back.py: the 100 MHz clock of the launch's other stamps)
+    auto stamp = [&](int k) { if (kAblate && a.trace && threadIdx.x == 0) a.trace[(h * G + g) * 16 + k] = __builtin_amdgcn_s_memrealtime(); };   // (tools/trace_back.py: the 100 MHz clock of the launch's other stamps)
 #else
     auto stamp = [&](int k) { if (kAblate && a.trace && threadIdx.x == 0) a.trace[(h * G + g) * 8 + k] = __builtin_amdgcn_s_memtime(); };
 #endif
@@ -85,7 +89,8 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
     const int f4r = hs >> 2, tile_f4 = kAttnTile * f4r;
     float* qs   = reinterpret_cast<float*>(lds);                 // [hs]
     float* red  = qs + hs;                                       // 32
-    float* sc   = red + 32;                                      // [T] scores -> probabilities (+ slack for the sum ring's read-ahead)
+    unsigned long long* etab = reinterpret_cast<unsigned long long*>(red + 32);   // kExp2fTab's 32 entries: the softmax's lookups stay on the CU
+    float* sc   = red + 32 + 64;                                 // [T] scores -> probabilities (+ slack for the sum ring's read-ahead)
     float* tile0 = sc + ((a.max_seq + 3) & ~3) + 64;
     float* tile1 = tile0 + kAttnTile * rs;
     const int lane = tid & 63, wave = tid >> 6;
@@ -119,13 +124,21 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
         loffv[j] = rowv * rs + c4v * 4;
     }
     const int tile_bytes = kAttnTile * hs * 4;
-    auto request = [&](const __amdgpu_buffer_rsrc_t& r, int tile, int tile_end, const int (&pr)[NF], const int (&go)[NF], v4f (&reg)[NF]) {
+    const int Told = PRE ? T - 1 : T;                               // rows below Told were written by earlier launches
+    auto request = [&](const __amdgpu_buffer_rsrc_t& r, int tile, int tile_end, const int (&pr)[NF], const int (&go)[NF], v4f (&reg)[NF], const int bound) {
         const int t0 = tile * kAttnTile;
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
-            const unsigned off = (tile < tile_end && t0 + pr[j] < T) ? (unsigned)(tile * tile_bytes + go[j]) : 0x80000000u;
+            const unsigned off = (tile < tile_end && t0 + pr[j] < bound) ? (unsigned)(tile * tile_bytes + go[j]) : 0x80000000u;
             reg[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, COH ? kAuxCoherent : 0));
         }
+    };
+    // PRE: the piece of row T - 1 (this token's) of an already requested tile, behind the flag round
+    auto patch = [&](const __amdgpu_buffer_rsrc_t& r, int tile, int tile_end, const int (&pr)[NF], const int (&go)[NF], v4f (&reg)[NF]) {
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+            if (tile < tile_end && tile * kAttnTile + pr[j] == T - 1)
+                reg[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, (int)(unsigned)(tile * tile_bytes + go[j]), 0, kAuxCoherent));
     };
     auto park = [&](float* buf, const int (&pr)[NF], const int (&lo)[NF], const v4f (&reg)[NF]) {
 #pragma unroll
@@ -133,11 +146,16 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
             if (pr[j] < kAttnTile) *reinterpret_cast<float4*>(buf + lo[j]) = make_float4(reg[j].x, reg[j].y, reg[j].z, reg[j].w);
     };
     // q first: loads return in issue order, and q requested behind the K and V tiles would arrive behind 4 tiles of data
+    // (PRE: q does not exist yet -- the earlier tokens' rows now, q behind the flag round)
+    unsigned etv = 0;
+    if (tid < 64) etv = reinterpret_cast<const unsigned*>(kExp2fTab)[tid];   // (requested first: it returns first)
     float qv[NF * 64 / kAttnBlock + 1];
+    if constexpr (!PRE) {
 #pragma unroll
-    for (int i = 0; i < NF * 64 / kAttnBlock + 1; ++i) { const int d = tid + i * kAttnBlock; qv[i] = d < hs ? (COH ? ld_agent(qrow + (size_t)h * hs + d) : qrow[(size_t)h * hs + d]) : 0.f; }
+        for (int i = 0; i < NF * 64 / kAttnBlock + 1; ++i) { const int d = tid + i * kAttnBlock; qv[i] = d < hs ? (COH ? ld_agent(qrow + (size_t)h * hs + d) : qrow[(size_t)h * hs + d]) : 0.f; }
+    }
 #pragma unroll
-    for (int u = 0; u < D; ++u) request(rK, sb + u, se, prow, goff, ringK[u]);
+    for (int u = 0; u < D; ++u) request(rK, sb + u, se, prow, goff, ringK[u], Told);
     if constexpr (SPLIT) {
         // a thread's pieces: the 16-byte column tid % 8 of the rows 4 (tid / 8) + (j % 4) + 512 (j / 4) -- four CONSECUTIVE rows per half, so
         // that the transposed parking below writes four positions of a dimension with one 16-byte store.  The first half of the slice
@@ -146,15 +164,34 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
 #pragma unroll
         for (int j = 0; j < kSplitVRegs / 2; ++j) {
             const int row = 4 * (tid >> 3) + (j & 3) + (kSplitMaxSeq / 2) * (j >> 2);
-            const unsigned off = row < T ? (unsigned)((row * hs + d0 + (tid & 7) * 4) * 4) : 0x80000000u;
+            const unsigned off = row < Told ? (unsigned)((row * hs + d0 + (tid & 7) * 4) * 4) : 0x80000000u;
             vall[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rV, (int)off, 0, COH ? kAuxCoherent : 0));
         }
     } else {
 #pragma unroll
-        for (int u = 0; u < DV; ++u) request(rV, u, nt, prowv, goffv, ringV[u]);
+        for (int u = 0; u < DV; ++u) request(rV, u, nt, prowv, goffv, ringV[u], Told);
+    }
+    if constexpr (PRE) {
+        mid();                                                      // the flag round: q and this token's cache rows are in memory
+        stamp(7);
+#pragma unroll
+        for (int i = 0; i < NF * 64 / kAttnBlock + 1; ++i) { const int d = tid + i * kAttnBlock; qv[i] = d < hs ? ld_agent(qrow + (size_t)h * hs + d) : 0.f; }
+#pragma unroll
+        for (int u = 0; u < D; ++u) patch(rK, sb + u, se, prow, goff, ringK[u]);
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int j = 0; j < kSplitVRegs / 2; ++j) {
+                const int row = 4 * (tid >> 3) + (j & 3) + (kSplitMaxSeq / 2) * (j >> 2);
+                if (row == T - 1) vall[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rV, (int)(unsigned)((row * hs + d0 + (tid & 7) * 4) * 4), 0, kAuxCoherent));
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < DV; ++u) patch(rV, u, nt, prowv, goffv, ringV[u]);
+        }
     }
 #pragma unroll
     for (int i = 0; i < NF * 64 / kAttnBlock + 1; ++i) { const int d = tid + i * kAttnBlock; if (d < hs) qs[d] = qv[i]; }
+    if (tid < 64) reinterpret_cast<unsigned*>(etab)[tid] = etv;
 
     // ---- scores: lane = (position p, strided accumulator k) -- the 8 lanes of dot_product_avx256; each lane's
     //      chain is i ascending, then the 8 partials are added 0..7 (lane k = 0 collects them with DPP row shifts).
@@ -192,7 +229,7 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
                 const int s = base + u;
                 park(tile0, prow, loff, ringK[u]); park(tile1, prow, loff, ringK[u + 1]);
                 __syncthreads();
-                request(rK, s + D, se, prow, goff, ringK[u]); request(rK, s + D + 1, se, prow, goff, ringK[u + 1]);
+                request(rK, s + D, se, prow, goff, ringK[u], T); request(rK, s + D + 1, se, prow, goff, ringK[u + 1], T);
                 const int half = tid >> 9, s2 = s + half;
                 if (s2 < se) score_lane(half ? tile1 : tile0, s2, (tid >> 3) & 63, tid & 7);
                 __syncthreads();
@@ -207,7 +244,7 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
                 park(cur, prow, loff, ringK[u]);
                 __syncthreads();
                 if (s == sb) stamp(5);
-                request(rK, s + D, se, prow, goff, ringK[u]);
+                request(rK, s + D, se, prow, goff, ringK[u], T);
                 if (s < se && tid < kAttnTile * 8) score_lane(cur, s, tid >> 3, tid & 7);
             }
         }
@@ -255,7 +292,7 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
         if (wave == 0) {
             const float sv = lane < T ? sc[lane] : -INFINITY;
             const float m = wave_max(sv);
-            const float e = lane < T ? expf_ref(__fsub_rn(sv, m)) : 0.f;
+            const float e = lane < T ? expf_ref(__fsub_rn(sv, m), etab) : 0.f;
             float pre = e;                                          // lane 0: 0 + e_0 = e_0
 #pragma unroll 4
             for (int k = 1; k < T; ++k)
@@ -273,7 +310,7 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
     float m = red[0];
 #pragma unroll
     for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
-    for (int t = tid; t < T; t += kAttnBlock) sc[t] = expf_ref(__fsub_rn(sc[t], m));
+    for (int t = tid; t < T; t += kAttnBlock) sc[t] = expf_ref(__fsub_rn(sc[t], m), etab);
     __syncthreads();
     stamp(2);
     if (tid == 0) {                                                // sum += x[i], i ascending (tf_operators.cpp:180-183)
@@ -370,41 +407,103 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
             const int i = base + u;
             float* cur = (u & 1) ? tile1 : tile0;
             park(cur, prowv, loffv, ringV[u]);
+            if (i == 0) stamp(12);
             __syncthreads();
-            request(rV, i + DV, nt, prowv, goffv, ringV[u]);
+            if (i == 0) stamp(8);
+            request(rV, i + DV, nt, prowv, goffv, ringV[u], T);
+            const float* wp = sc + i * kAttnTile;
+            const int np = (T - i * kAttnTile) < kAttnTile ? (T - i * kAttnTile) : kAttnTile;
+            unsigned long long live = 0;
+            if (i < nt) {                                           // (whole waves: the map below is a ballot over 64 lanes)
+                const float wl = lane < np ? wp[lane] : 0.f;
+                live = __ballot(wl != 0.f);
+                if (i == 0) live |= 1ull;
+            }
             if (i < nt && tid < nd) {
                 const float* vp = cur + tid;
-                const float* wp = sc + i * kAttnTile;
-                const int np = (T - i * kAttnTile) < kAttnTile ? (T - i * kAttnTile) : kAttnTile;
-                // weights are wave-uniform (one per position): lane p looks at weight p once per tile; if no row of the
-                // tile is skipped, the walk is nothing but LDS reads at immediate offsets and dependent FMAs
-                const float wl = lane < np ? wp[lane] : 1.f;
-                const bool dense = __all(wl != 0.f) != 0;
-                int p = 0;
-                if (i == 0) { o = __fmul_rn(vp[0], wp[0]); p = 1; }  // row 0 always (tf_operators.cpp:331-336)
-                if (dense) {
-                    for (; p < np && (p & 7); ++p) o = __fmaf_rn(vp[p * vrs], wp[p], o);
-                    if (p + 8 <= np) {
-                        const float* vq = vp + p * vrs; const float* wq = wp + p;
-                        float4 wa = *reinterpret_cast<const float4*>(wq), wb = *reinterpret_cast<const float4*>(wq + 4);
-                        float a0 = vq[0], a1 = vq[vrs], a2 = vq[2 * vrs], a3 = vq[3 * vrs], a4 = vq[4 * vrs], a5 = vq[5 * vrs], a6 = vq[6 * vrs], a7 = vq[7 * vrs];
-                        for (; p + 16 <= np; p += 8) {
-                            vq += 8 * vrs; wq += 8;
-                            const float4 wc = *reinterpret_cast<const float4*>(wq), wd = *reinterpret_cast<const float4*>(wq + 4);
-                            const float b0 = vq[0], b1 = vq[vrs], b2 = vq[2 * vrs], b3 = vq[3 * vrs], b4 = vq[4 * vrs], b5 = vq[5 * vrs], b6 = vq[6 * vrs], b7 = vq[7 * vrs];
-                            o = __fmaf_rn(a0, wa.x, o); o = __fmaf_rn(a1, wa.y, o); o = __fmaf_rn(a2, wa.z, o); o = __fmaf_rn(a3, wa.w, o);
-                            o = __fmaf_rn(a4, wb.x, o); o = __fmaf_rn(a5, wb.y, o); o = __fmaf_rn(a6, wb.z, o); o = __fmaf_rn(a7, wb.w, o);
-                            wa = wc; wb = wd; a0 = b0; a1 = b1; a2 = b2; a3 = b3; a4 = b4; a5 = b5; a6 = b6; a7 = b7;
-                        }
-                        o = __fmaf_rn(a0, wa.x, o); o = __fmaf_rn(a1, wa.y, o); o = __fmaf_rn(a2, wa.z, o); o = __fmaf_rn(a3, wa.w, o);
-                        o = __fmaf_rn(a4, wb.x, o); o = __fmaf_rn(a5, wb.y, o); o = __fmaf_rn(a6, wb.z, o); o = __fmaf_rn(a7, wb.w, o);
-                        p += 8;
+                // The chain is T dependent FMAs; everything else must stay out of its way.  Weights are wave-uniform (one per position): lane p looks at weight p once per
+                // tile and the ballot is the tile's map of rows that count -- a row whose weight was stored as exact 0 (the threshold of transformer.cpp:449) leaves o
+                // untouched; row 0 counts always, by multiplication (tf_operators.cpp:331-336).  Groups of four positions (four LDS reads at immediate offsets + one 16-byte read
+                // of the weights) go through a ring of three register sets: a group is read two groups (~100 cycles, the LDS latency) before its FMAs run, and the wait in
+                // front of a group asks only for that group.  A group is four FMAs (no row skipped), nothing (all skipped: a peaked softmax leaves long runs of them) or
+                // FMAs under scalar bit tests.  Straight-line code, 16 groups with early exits: around a loop's back edge the compiler's own s_waitcnt would drain the
+                // ring once per trip.  Reads run up to 11 rows / weights past the tile's last position (the slack rows of attn_lds_bytes, sc's slack); never used.
+                const int ng = (np + 3) >> 2;
+                float A0, A1, A2, A3, B0, B1, B2, B3, C0, C1, C2, C3;
+#define FLM_PVRD(G, g) { G##0 = vp[(4 * (g)) * vrs]; G##1 = vp[(4 * (g) + 1) * vrs]; G##2 = vp[(4 * (g) + 2) * vrs]; G##3 = vp[(4 * (g) + 3) * vrs]; \
+                         G##W = *reinterpret_cast<const float4*>(wp + 4 * (g)); __builtin_amdgcn_sched_barrier(0); }
+#define FLM_PVUSE(G, g) { const unsigned m = (unsigned)(live >> (4 * (g))) & 15u; \
+                          if (m == 15u) { \
+                              o = (i == 0 && (g) == 0) ? __fmul_rn(G##0, G##W.x) : __fmaf_rn(G##0, G##W.x, o); \
+                              o = __fmaf_rn(G##1, G##W.y, o); o = __fmaf_rn(G##2, G##W.z, o); o = __fmaf_rn(G##3, G##W.w, o); \
+                          } else if (m != 0u) { \
+                              if (m & 1u) o = (i == 0 && (g) == 0) ? __fmul_rn(G##0, G##W.x) : __fmaf_rn(G##0, G##W.x, o); \
+                              if (m & 2u) o = __fmaf_rn(G##1, G##W.y, o); if (m & 4u) o = __fmaf_rn(G##2, G##W.z, o); if (m & 8u) o = __fmaf_rn(G##3, G##W.w, o); \
+                          } \
+                          __builtin_amdgcn_sched_barrier(0); }
+                const unsigned long long full = np >= 64 ? ~0ull : ((1ull << np) - 1ull);
+                if ((live & full) == full) {
+                    // No row skipped -- the usual case.  A lone wave issues an instruction every ~8 cycles whatever its kind, so what counts is the NUMBER of instructions per
+                    // position: a group is a compare, a branch not taken, ONE wait, four FMAs and its successor's five reads, in a loop (12 positions per trip).  The reads
+                    // and the waits are inline assembly: the compiler's own s_waitcnt drains the ring at a loop head (and straight-line code over 16 groups spilled).
+                    // (row 0 by multiplication = a chain that starts at -0: x y + (-0) is x y, sign of zero included)
+                    if (i == 0) o = -0.f;
+                    unsigned va = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)vp;
+                    unsigned wa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)wp;
+                    v4f AW, BW, CW;
+#define FLM_PVRDA(G, g) asm volatile("ds_read_b32 %0, %5 offset:%6\n\tds_read_b32 %1, %5 offset:%7\n\tds_read_b32 %2, %5 offset:%8\n\tds_read_b32 %3, %5 offset:%9\n\tds_read_b128 %4, %10 offset:%11" \
+                                     : "=&v"(G##0), "=&v"(G##1), "=&v"(G##2), "=&v"(G##3), "=&v"(G##W) \
+                                     : "v"(va), "n"((4 * (g)) * vrs * 4), "n"((4 * (g) + 1) * vrs * 4), "n"((4 * (g) + 2) * vrs * 4), "n"((4 * (g) + 3) * vrs * 4), "v"(wa), "n"(16 * (g)));
+#define FLM_PVFMA(G) { asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(G##0), "+v"(G##1), "+v"(G##2), "+v"(G##3), "+v"(G##W)); \
+                       o = __fmaf_rn(G##0, G##W.x, o); o = __fmaf_rn(G##1, G##W.y, o); o = __fmaf_rn(G##2, G##W.z, o); o = __fmaf_rn(G##3, G##W.w, o); }
+                    const int nfull = np >> 2;
+                    FLM_PVRDA(A, 0) FLM_PVRDA(B, 1) FLM_PVRDA(C, 2)
+                    int g = 0;
+#pragma unroll 1
+                    while (true) {
+                        if (g >= nfull) break; FLM_PVFMA(A) FLM_PVRDA(A, 3) ++g;
+                        if (g >= nfull) break; FLM_PVFMA(B) FLM_PVRDA(B, 4) ++g;
+                        if (g >= nfull) break; FLM_PVFMA(C) FLM_PVRDA(C, 5) ++g;
+                        va += 12 * vrs * 4; wa += 48;
                     }
-                    for (; p < np; ++p) o = __fmaf_rn(vp[p * vrs], wp[p], o);
+                    // the tile's last, partial group sits in the ring already
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(A3), "+v"(AW), "+v"(B0), "+v"(B1), "+v"(B2), "+v"(B3), "+v"(BW), "+v"(C0), "+v"(C1), "+v"(C2), "+v"(C3), "+v"(CW));
+                    const int rem = np & 3, slot = g % 3;
+                    if (rem) {
+                        const float t0 = slot == 0 ? A0 : slot == 1 ? B0 : C0, t1 = slot == 0 ? A1 : slot == 1 ? B1 : C1, t2 = slot == 0 ? A2 : slot == 1 ? B2 : C2;
+                        const v4f tw = slot == 0 ? AW : slot == 1 ? BW : CW;
+                        o = __fmaf_rn(t0, tw.x, o);
+                        if (rem > 1) o = __fmaf_rn(t1, tw.y, o);
+                        if (rem > 2) o = __fmaf_rn(t2, tw.z, o);
+                    }
+#undef FLM_PVRDA
+#undef FLM_PVFMA
                 } else {
-                    // some row is skipped (weight stored as exact 0, threshold of transformer.cpp:449): it leaves o untouched
-                    for (; p < np; ++p) { const float w = wp[p]; o = w == 0.f ? o : __fmaf_rn(vp[p * vrs], w, o); }
+                    float4 AW, BW, CW;
+                    __builtin_amdgcn_sched_barrier(0);
+                    FLM_PVRD(A, 0) FLM_PVRD(B, 1) FLM_PVRD(C, 2)
+                    do {
+                        FLM_PVUSE(A, 0) FLM_PVRD(A, 3) if (ng <= 1) break;
+                        FLM_PVUSE(B, 1) FLM_PVRD(B, 4) if (ng <= 2) break;
+                        FLM_PVUSE(C, 2) FLM_PVRD(C, 5) if (ng <= 3) break;
+                        FLM_PVUSE(A, 3) FLM_PVRD(A, 6) if (ng <= 4) break;
+                        FLM_PVUSE(B, 4) FLM_PVRD(B, 7) if (ng <= 5) break;
+                        FLM_PVUSE(C, 5) FLM_PVRD(C, 8) if (ng <= 6) break;
+                        FLM_PVUSE(A, 6) FLM_PVRD(A, 9) if (ng <= 7) break;
+                        FLM_PVUSE(B, 7) FLM_PVRD(B, 10) if (ng <= 8) break;
+                        FLM_PVUSE(C, 8) FLM_PVRD(C, 11) if (ng <= 9) break;
+                        FLM_PVUSE(A, 9) FLM_PVRD(A, 12) if (ng <= 10) break;
+                        FLM_PVUSE(B, 10) FLM_PVRD(B, 13) if (ng <= 11) break;
+                        FLM_PVUSE(C, 11) FLM_PVRD(C, 14) if (ng <= 12) break;
+                        FLM_PVUSE(A, 12) FLM_PVRD(A, 15) if (ng <= 13) break;
+                        FLM_PVUSE(B, 13) FLM_PVRD(B, 16) if (ng <= 14) break;
+                        FLM_PVUSE(C, 14) FLM_PVRD(C, 17) if (ng <= 15) break;
+                        FLM_PVUSE(A, 15)
+                    } while (false);
                 }
+#undef FLM_PVRD
+#undef FLM_PVUSE
+                if (i == 0) stamp(9);
             }
         }
     }
@@ -434,12 +533,12 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
 }
 // SPLIT is a template argument of the kernels (not a run-time branch inside one kernel): the two forms keep different things in
 // registers, and compiled into one function they spilled a 16-byte register -- behind an s_waitcnt vmcnt(0) on the whole prefetch
-template <bool COH, bool SPLIT>
-__device__ __forceinline__ void attn_head_any(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow, const int g = 0, const int G = 1) {
+template <bool COH, bool SPLIT, bool PRE = false, class Mid = AttnNoMid>
+__device__ __forceinline__ void attn_head_any(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow, const int g = 0, const int G = 1, Mid&& mid = Mid()) {
     if constexpr (SPLIT) {      // the host picks G = hs / kSplitDims (attn_parts): every part owns 32 output dimensions; hs <= 128
-        if (a.hs <= 64) attn_head<1, COH, true>(a, h, lds, T, qrow, orow, g, G); else attn_head<2, COH, true>(a, h, lds, T, qrow, orow, g, G);
+        if (a.hs <= 64) attn_head<1, COH, true, PRE>(a, h, lds, T, qrow, orow, g, G, mid); else attn_head<2, COH, true, PRE>(a, h, lds, T, qrow, orow, g, G, mid);
     } else {
-        if (a.hs <= 64) attn_head<1, COH>(a, h, lds, T, qrow, orow); else if (a.hs <= 128) attn_head<2, COH>(a, h, lds, T, qrow, orow); else attn_head<4, COH>(a, h, lds, T, qrow, orow);
+        if (a.hs <= 64) attn_head<1, COH, false, PRE>(a, h, lds, T, qrow, orow, 0, 1, mid); else if (a.hs <= 128) attn_head<2, COH, false, PRE>(a, h, lds, T, qrow, orow, 0, 1, mid); else attn_head<4, COH, false, PRE>(a, h, lds, T, qrow, orow, 0, 1, mid);
     }
 }
 // batched prefill: workgroup (h, i) is query i of the batch, at position pos0 + i, over the cache rows 0 .. pos0 + i

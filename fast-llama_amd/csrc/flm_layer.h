@@ -109,7 +109,8 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
     }
     if ((int)blockIdx.x < p.n_heads) {
         const int G = SPLIT ? aa.G : 1, hh = blockIdx.x / G;
-        if constexpr (QKV) {
+        // the lines of the workgroups that reduced this head's rows of q, k and v: polled INSIDE the head (attn_head<.., PRE>), behind its requests for the earlier tokens' cache rows
+        auto qwait = [&]() {
             if (threadIdx.x < 256) {
                 // lane i: does workgroup i reduce a row of this head's q, k or v?  (pass p = rows [p Rm, (p + 1) Rm) of [Wq; Wk; Wv], workgroup p mod gridq)
                 bool need = false;
@@ -130,8 +131,9 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
                 }
             }
             __syncthreads();
-        }
-        attn_head_any<QKV, SPLIT>(aa, hh, lds, *aa.pos_ptr + 1, aa.q, aa.out, blockIdx.x % G, G);
+        };
+        if constexpr (QKV) attn_head_any<true, SPLIT, true>(aa, hh, lds, *aa.pos_ptr + 1, aa.q, aa.out, blockIdx.x % G, G, qwait);
+        else attn_head_any<false, SPLIT>(aa, hh, lds, *aa.pos_ptr + 1, aa.q, aa.out, blockIdx.x % G, G);
         stamp(1);
         wait_stores_done();                                                     // every wave: its part of the head's output is where the others will read it
         __syncthreads();                                                        // (and the LDS is free)

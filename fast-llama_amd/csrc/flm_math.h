@@ -113,7 +113,8 @@ __device__ const unsigned long long kExp2fTab[32] = {
     0x3feee89f995ad3adULL, 0x3feeff76f2fb5e47ULL, 0x3fef199bdd85529cULL, 0x3fef3720dcef9069ULL,
     0x3fef5818dcfba487ULL, 0x3fef7c97337b9b5fULL, 0x3fefa4afa2a490daULL, 0x3fefd0765b6e4540ULL};
 
-__device__ __forceinline__ float expf_ref(float x) {
+// tab: kExp2fTab, or a copy of it in LDS (the lookup is on a lone wave's path in the attention: a global load there is most of a microsecond)
+__device__ __forceinline__ float expf_ref(float x, const unsigned long long* tab = kExp2fTab) {
     const uint32_t ix = __float_as_uint(x);
     const uint32_t abstop = (ix >> 20) & 0x7ff;
     if (abstop >= (0x42b00000u >> 20)) {                       // |x| >= 88 or NaN/inf
@@ -131,7 +132,7 @@ __device__ __forceinline__ float expf_ref(float x) {
     const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
     kd = __dsub_rn(kd, SHIFT);
     const double r = __dsub_rn(z, kd);
-    const unsigned long long t = kExp2fTab[ki % 32] + (ki << 47);
+    const unsigned long long t = tab[ki % 32] + (ki << 47);
     const double s = __longlong_as_double((long long)t);
     z = __fma_rn(C0, r, C1);
     const double r2 = __dmul_rn(r, r);

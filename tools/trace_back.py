@@ -28,7 +28,7 @@ for spec in sets:
         ctx.decode_greedy(first, len(prompt) + 32 + rep, 1)
         rows.append(ctx.debug_read("back_trace", 0, 6 * 256 * 16).reshape(6, 256, 16).copy())
     pro = rows[-1][1:3]; rn = rows[-1][4]
-    at = rows[-1][5].reshape(-1, 8)[:cfg.n_heads]
+    at = rows[-1][5].reshape(-1, 16)[:cfg.n_heads]
     ch = rows[-1][3]                  # the FFN13 chain's stages (wave 0): shader-clock ticks after the chain's start; [15] = rounds
     ok = ch[:, 14] > 0
     if ok.any():
@@ -60,7 +60,7 @@ for spec in sets:
     if (rn[:, 4] > 0).any():
         print("  FFN13 run(), chain wave: " + " | ".join(f"{nm} {np.median(rn[:, k][rn[:, k] > 0]):.2f}" for k, nm in ((3, "first refill requested"), (4, "last step reduced (at the barrier)"), (5, "chains + epilogue + stores issued"))))
     if (at[:, 0] > 0).any():
-        an = {0: "entry (q flags seen)", 5: "first K tile parked", 1: "scores done", 2: "softmax done", 4: "weighted sum done", 6: "output quantized + stored"}
-        print("  attention (thread 0 of a head): " + " | ".join(f"{an[k]} {np.median(at[:, k][at[:, k] > 0]):.2f}" for k in (0, 5, 1, 2, 4, 6) if (at[:, k] > 0).any()))
+        an = {0: "entry (earlier rows requested)", 7: "q flags seen", 5: "first K tile parked", 1: "scores done", 2: "exp done", 3: "sum done", 12: "V tile 0 parked", 8: "barrier passed", 9: "tile 0 walked", 4: "weighted sum done", 6: "output quantized + stored"}
+        print("  attention (thread 0 of a head): " + " | ".join(f"{an[k]} {np.median(at[:, k][at[:, k] > 0]):.2f}" for k in (0, 7, 5, 1, 2, 3, 12, 8, 9, 4, 6) if (at[:, k] > 0).any()))
     ends = np.array([r[:, 11].max() for r in rows])
     print("  launch span over 5 tokens:", " ".join(f"{e:.2f}" for e in ends))
