@@ -236,17 +236,16 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
             }
         }
     } else {
-        for (int base = sb; base < se; base += D) {
-#pragma unroll
-            for (int u = 0; u < D; ++u) {
-                const int s = base + u;
-                float* cur = (u & 1) ? tile1 : tile0;                   // D is even: slot parity
-                park(cur, prow, loff, ringK[u]);
-                __syncthreads();
-                if (s == sb) stamp(5);
-                request(rK, s + D, se, prow, goff, ringK[u], T);
-                if (s < se && tid < kAttnTile * 8) score_lane(cur, s, tid >> 3, tid & 7);
-            }
+        // two tiles per step, one per half of the workgroup (contexts of 65 .. 128 positions: one step instead of two tile times)
+        static_assert(D == 2, "one step = the ring's two tiles");
+        for (int s = sb; s < se; s += 2) {
+            park(tile0, prow, loff, ringK[0]); park(tile1, prow, loff, ringK[1]);
+            __syncthreads();
+            if (s == sb) stamp(5);
+            request(rK, s + 2, se, prow, goff, ringK[0], T); request(rK, s + 3, se, prow, goff, ringK[1], T);
+            const int half = tid >> 9, s2 = s + half;
+            if (s2 < se) score_lane(half ? tile1 : tile0, s2, (tid >> 3) & 63, tid & 7);
+            __syncthreads();
         }
     }
     if constexpr (SPLIT) {

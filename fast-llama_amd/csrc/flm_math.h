@@ -61,12 +61,18 @@ template <> struct QTraits<QT_INT16> { using elem = int16_t; static constexpr in
 // kEPC = elements per 16-byte chunk; lanes per quant group = 64 / kEPC (4 for int8, 8 for int16)
 
 // ------------------------------------------------------------------------------------------
-// block reductions for ORDER-FREE quantities only (max): wave64 xor butterflies
+// block reductions for ORDER-FREE quantities only (max)
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float row16_max(float v);
+// max over the wave, in every lane: DPP only (rows, then row_bcast:15 / row_bcast:31, lane 63 read back as a scalar) -- six ds_bpermute round trips
+// (__shfl_xor) cost a lone wave ~0.3 us, and the attention calls this twice on its critical path
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
-    return v;
+    float t = row16_max(v);
+    int i = __float_as_int(t);
+    t = fmaxf(t, __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0x142 /* row_bcast:15 */, 0xA, 0xF, false)));
+    i = __float_as_int(t);
+    t = fmaxf(t, __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0x143 /* row_bcast:31 */, 0xC, 0xF, false)));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 63));
 }
 __device__ __forceinline__ float block_max(float v, float* red) {
     v = wave_max(v);
