@@ -44,18 +44,44 @@ struct BackArgs {
     unsigned long long* trace;  // FLM_ABLATE builds: [grid][16] s_memrealtime stamps (100 MHz, one clock for all XCDs; tools/trace_back.py)
 };
 
+// One wave's look at its lines until all have reached `target`.  A look is a round trip to memory (the lines are written and read across XCDs); with one look in flight a
+// raised line is noticed half a round trip late on average.  FLM_POLL_DEPTH > 1 keeps that many looks in flight, FLM_POLL_GAP apart -- measured (tools/variants.sh): depth 3
+// takes 0.2 .. 0.3 us off a short-context layer and ADDS 1.6 us to a long-context one (the split heads' loads queue behind three times the polling traffic): depth 1 stays.
+#ifndef FLM_POLL_DEPTH
+#define FLM_POLL_DEPTH 1
+#endif
+#ifndef FLM_POLL_GAP
+#define FLM_POLL_GAP 6            // s_sleep units (64 cycles) between two looks
+#endif
+__device__ __forceinline__ void poll_wave(const unsigned* line, bool mine, unsigned target, int* err) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    auto look = [&]() -> unsigned { return mine ? __hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target; };
+#if FLM_POLL_DEPTH <= 1
+    while (true) {
+        const unsigned f = look();
+        if (__all((int)(f - target) >= 0)) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    }
+#else
+    unsigned f[FLM_POLL_DEPTH];
+#pragma unroll
+    for (int i = 0; i < FLM_POLL_DEPTH; ++i) { f[i] = look(); if (i + 1 < FLM_POLL_DEPTH) __builtin_amdgcn_s_sleep(FLM_POLL_GAP); }
+    while (true) {
+        bool done = false;
+#pragma unroll
+        for (int i = 0; i < FLM_POLL_DEPTH; ++i) {
+            if (__all((int)(f[i] - target) >= 0)) { done = true; break; }
+            f[i] = look();
+            __builtin_amdgcn_s_sleep(FLM_POLL_GAP);
+        }
+        if (done) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    }
+#endif
+}
 // lane i (of the first 256 threads) polls line i of `n` lines until all have reached `target`
 __device__ __forceinline__ void poll_lines(const unsigned* flag, int n, unsigned target, int* err) {
-    if ((int)(threadIdx.x & ~63u) < n) {
-        const bool mine = (int)threadIdx.x < n;
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while (true) {
-            unsigned f = target;
-            if (mine) f = __hip_atomic_load(flag + threadIdx.x * kFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__all((int)(f - target) >= 0)) break;
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-        }
-    }
+    if ((int)(threadIdx.x & ~63u) < n) poll_wave(flag + threadIdx.x * kFlagStride, (int)threadIdx.x < n, target, err);
 }
 
 #ifndef FLM_BACK_LATE
@@ -123,12 +149,7 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
                         need |= (threadIdx.x + nq - pa % nq) % nq <= pb - pa;
                     }
                 }
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                while (true) {
-                    const unsigned f = need ? __hip_atomic_load(p.flag_q + threadIdx.x * kFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
-                    if (__all((int)(f - target) >= 0)) break;
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) { __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-                }
+                poll_wave(p.flag_q + threadIdx.x * kFlagStride, need, target, p.err);
             }
             __syncthreads();
         };
