@@ -458,6 +458,12 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
                     const int nfull = np >> 2;
                     FLM_PVRDA(A, 0) FLM_PVRDA(B, 1) FLM_PVRDA(C, 2)
                     int g = 0;
+                    // whole trips of three groups without the exit tests (4 of a group's 14 instructions), then the rest under them
+#pragma unroll 1
+                    for (int trips = nfull / 3; trips > 0; --trips) {
+                        FLM_PVFMA(A) FLM_PVRDA(A, 3) FLM_PVFMA(B) FLM_PVRDA(B, 4) FLM_PVFMA(C) FLM_PVRDA(C, 5)
+                        va += 12 * vrs * 4; wa += 48; g += 3;
+                    }
 #pragma unroll 1
                     while (true) {
                         if (g >= nfull) break; FLM_PVFMA(A) FLM_PVRDA(A, 3) ++g;
