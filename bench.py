@@ -519,6 +519,7 @@ def main():
                       "launches_per_token_short_context": ((1 if tpath & 512 and kt.get("layers", (0.0, 0))[1] > 0 else cfg.n_layers * (1 if tpath & 256 else 2 if tpath & 128 else 3)) + 3)}
     except Exception as e:  # noqa: BLE001
         token_path = {"error": str(e)}
+    ctx_tp_info = getattr(ctx, "tp_info", None) or {}
     kernels = {k: {"us": round(v[0], 2), "per_token": v[1], "GBps": round(ctx.kernel_bytes(k, mid_pos) / (v[0] * 1e-6) / 1e9, 1) if v[0] > 0 else 0.0}
                for k, v in kt.items() if v[1] > 0}
     ctx.close()
@@ -605,6 +606,13 @@ def main():
             line["config5_prefill512_int16"] = config5
         if replicas is not None:
             line["replicas"] = replicas
+        if mode == "tp" and ctx_tp_info:
+            # (c) of the review's multi-GPU item: who ran, over what, and what an exchange costs (HIP events around the exchange launches / collectives of a timed token)
+            info = dict(ctx_tp_info)
+            ar = kt.get("allreduce", (0.0, 0))
+            info["exchange_us"] = round(ar[0], 2); info["exchanges_per_token"] = ar[1]
+            info["scaling_measured"] = info["distinct_devices"] == world
+            line["tp"] = info
         if tp_note:
             line["tp_note"] = tp_note
         if world == 1 and not args.no_cpu_baseline:
@@ -660,6 +668,7 @@ def open_tp_ctx(capi, cfg, rank, world, device, dist, torch):
         if ok:
             ctx.set_option("use_p2p", 0)
         ctx.exchange = "rccl all-gather"
+        ctx.tp_info = {"transport": "rccl", "launches_per_sharded_layer": 9}
     else:
         ctx.exchange = "peer-to-peer stores over xGMI + flag round"
         if rehearsal:
@@ -669,6 +678,13 @@ def open_tp_ctx(capi, cfg, rank, world, device, dist, torch):
         fold, fa, fn = ctx.query("fold_active"), ctx.query("grp_tp_fuse_attn"), ctx.query("grp_tp_fuse_ffn")      # (what the GROUP agreed on at import)
         per_layer = 9 if not fold else (5 - (2 if fa >= 2 else 1 if fa == 1 else 0) - (1 if fn else 0))
         ctx.exchange += f"; {per_layer} launches per sharded layer (fold_active {fold}, tp_fuse_attn {fa}, tp_fuse_ffn {fn})"
+        ctx.tp_info = {"transport": "p2p", "launches_per_sharded_layer": per_layer, "fold_active": int(fold), "tp_fuse_attn": int(fa), "tp_fuse_ffn": int(fn)}
+    # every rank's device ordinal, as the ranks themselves see it (ranks_seen = how many distinct devices the group really runs on)
+    devs = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(devs, torch.tensor([int(device)], dtype=torch.int64, device=dev))
+    ctx.tp_info["rank_devices"] = [int(d.item()) for d in devs]
+    ctx.tp_info["ranks_seen"] = world
+    ctx.tp_info["distinct_devices"] = len(set(ctx.tp_info["rank_devices"]))
     return ctx
 
 
