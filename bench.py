@@ -561,8 +561,13 @@ def main():
             replicas = {"value": None, "note": f"failed: {e}"}
 
     qn = 2 if qt == ff.QT_INT8 else 1
-    dom_regex = {"layers": rf"k_layers<{qn}, \d+, false>", "layer": rf"k_attn_ffn<{qn}, \d+, true, false>", "back": rf"k_attn_ffn<{qn}, \d+, false, false>", "ffn": rf"k_ffn<{qn},"}.get(dom, rf"k_gemv<{qn}, 2, 2,")
-    traffic, traffic_src, traffic_note = pmc_traffic(dom_regex, capi.LIB_PATH)
+    split_now = bool(token_path.get("heads_split_at_long_contexts")) and mid_pos + 1 >= 128      # (the launch's SPLIT instantiation: a head spread over hs / 32 workgroups)
+    dom_regex = {"layers": rf"k_layers<{qn}, \d+, {'true' if split_now else 'false'}>", "layer": rf"k_attn_ffn<{qn}, \d+, true, false>", "back": rf"k_attn_ffn<{qn}, \d+, false, false>", "ffn": rf"k_ffn<{qn},"}.get(dom, rf"k_gemv<{qn}, 2, 2,")
+    if args.shape == "7B":
+        traffic, traffic_src, traffic_note = pmc_traffic(dom_regex, capi.LIB_PATH)
+    else:   # (the committed PMC summaries were collected on the 7B-shaped model: a launch of the same kernel on another shape moves other bytes)
+        traffic, traffic_src, traffic_note = None, None, "PMC summaries under profiles/ are of the LLaMA2-7B shape"
+
     dom_name = {"layers": f"k_layers<{args.quant}> (ALL {cfg.n_layers} decoder layers of the token in one launch: per layer QKV + RoPE, attention, Wo + residual, FFN13 + SwiGLU, FFN2 + residual; "
                           f"the edges between phases and between layers are flag rounds)",
                 "layer": f"k_attn_ffn<{args.quant}, QKV> (the whole decoder layer in one launch: QKV + RoPE, attention, Wo + residual, FFN13 + SwiGLU, FFN2 + residual)",
