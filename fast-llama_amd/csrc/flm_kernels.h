@@ -15,10 +15,12 @@
 //   * attention : q.k as 8 strided lanes + sequential lane sum; glibc-exact expf; sequential softmax
 //                 sum; weighted V sum sequential over positions
 //
-// Kernel inventory.  One decode token on a single GPU = k_embed + L x k_attn_ffn<.., QKV = true> + k_gemv(cls) + k_argmax_advance (head size a multiple of 64, contexts
-// below 128 positions); from 128 positions on (a head spread over 4 workgroups) L x {k_qkv_attn_o, k_ffn}.  What else is here runs under options, tensor parallelism or tests:
-//   k_attn_ffn<QT,XR2,QKV> THE DEFAULT DECODE LAUNCH (flm_layer.h): the whole decoder layer -- QKV GEMV, attention heads, Wo, FFN13 + SwiGLU, FFN2 -- in one launch; the
-//                         hand-offs are flag rounds, [W1; W3] is stashed in LDS by LDS-DMA under the attention ("fuse_layer" 0: without the QKV GEMV; "fuse_back" 0: off)
+// Kernel inventory.  One decode token on a single GPU = k_embed + k_layers (ALL L decoder layers) + k_gemv(cls) + k_argmax_advance (head size a multiple of 64; from 128
+// positions on the SPLIT instantiation: a head spread over hs / 32 workgroups).  What else is here runs under options, tensor parallelism or tests:
+//   k_layers<QT,XR2,SPLIT> THE DEFAULT DECODE LAUNCH (flm_layer.h, host side flm_layers.hip): layer_body -- the whole decoder layer: QKV GEMV, attention heads, Wo,
+//                         FFN13 + SwiGLU, FFN2 -- in a loop over the layers' argument blocks in device memory; every hand-off, the one between two layers included, is a flag
+//                         round; [W1; W3] is stashed in LDS by LDS-DMA under the attention, the next layer's [Wq; Wk; Wv] requested in front of the layer edge ("fuse_token" 0: off)
+//   k_attn_ffn<QT,XR2,QKV,SPLIT> the same layer_body as one launch per layer ("fuse_token" 0; "fuse_layer" 0: without the QKV GEMV; "fuse_back" 0: off)
 //   k_gemv<QT,PRO,EPI,XR> group-quantized GEMV, HBM-bound; fused prologue (rmsnorm+quantize | quantize) and epilogue (store | residual add | SwiGLU | RoPE + KV-cache
 //                         append): the classifier of every token; every phase of a tensor-parallel rank's token; the per-phase fallback behind a timed-out hand-off
 //   k_attn_decode         fp32 single-query attention over the fp32 KV cache (heads split over workgroups at long contexts): the stand-alone launch
