@@ -43,6 +43,9 @@ struct AttnArgs {
     float* out_peer[7]; int n_peer;
 };
 
+#ifndef FLM_SPLIT_V_LATE
+#define FLM_SPLIT_V_LATE 1
+#endif
 constexpr int kAttnBlock = 1024;      // 16 waves
 constexpr int kAttnTile = 64;         // positions per LDS tile
 constexpr int kAttnDepth = 2;         // tiles in flight per stream (K, V), register rings: both streams start when the kernel does
@@ -161,11 +164,14 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
         // that the transposed parking below writes four positions of a dimension with one 16-byte store.  The first half of the slice
         // (rows < 512) now, the second half when the K ring's registers are free (behind the scores; it lands under the exchange and
         // the softmax): all of it at once is 4 registers more than a 1024-thread workgroup has
+        // (PRE: behind the flag round -- V is not needed before the weighted sum, and in front of the round it is half of what the round's looks queue behind)
+        if constexpr (!(PRE && FLM_SPLIT_V_LATE)) {
 #pragma unroll
-        for (int j = 0; j < kSplitVRegs / 2; ++j) {
-            const int row = 4 * (tid >> 3) + (j & 3) + (kSplitMaxSeq / 2) * (j >> 2);
-            const unsigned off = row < Told ? (unsigned)((row * hs + d0 + (tid & 7) * 4) * 4) : 0x80000000u;
-            vall[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rV, (int)off, 0, COH ? kAuxCoherent : 0));
+            for (int j = 0; j < kSplitVRegs / 2; ++j) {
+                const int row = 4 * (tid >> 3) + (j & 3) + (kSplitMaxSeq / 2) * (j >> 2);
+                const unsigned off = row < Told ? (unsigned)((row * hs + d0 + (tid & 7) * 4) * 4) : 0x80000000u;
+                vall[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rV, (int)off, 0, COH ? kAuxCoherent : 0));
+            }
         }
     } else {
 #pragma unroll
@@ -182,7 +188,10 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
 #pragma unroll
             for (int j = 0; j < kSplitVRegs / 2; ++j) {
                 const int row = 4 * (tid >> 3) + (j & 3) + (kSplitMaxSeq / 2) * (j >> 2);
-                if (row == T - 1) vall[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rV, (int)(unsigned)((row * hs + d0 + (tid & 7) * 4) * 4), 0, kAuxCoherent));
+                if constexpr (FLM_SPLIT_V_LATE) {
+                    const unsigned off = row < T ? (unsigned)((row * hs + d0 + (tid & 7) * 4) * 4) : 0x80000000u;
+                    vall[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rV, (int)off, 0, kAuxCoherent));
+                } else if (row == T - 1) vall[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rV, (int)(unsigned)((row * hs + d0 + (tid & 7) * 4) * 4), 0, kAuxCoherent));
             }
         } else {
 #pragma unroll
