@@ -43,6 +43,9 @@ struct AttnArgs {
     float* out_peer[7]; int n_peer;
 };
 
+#ifndef FLM_V_LATE_NS
+#define FLM_V_LATE_NS 1
+#endif
 #ifndef FLM_SPLIT_V_LATE
 #define FLM_SPLIT_V_LATE 1
 #endif
@@ -174,8 +177,10 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
             }
         }
     } else {
+        if constexpr (!(PRE && FLM_V_LATE_NS)) {
 #pragma unroll
-        for (int u = 0; u < DV; ++u) request(rV, u, nt, prowv, goffv, ringV[u], Told);
+            for (int u = 0; u < DV; ++u) request(rV, u, nt, prowv, goffv, ringV[u], Told);
+        }
     }
     if constexpr (PRE) {
         mid();                                                      // the flag round: q and this token's cache rows are in memory
@@ -193,6 +198,9 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
                     vall[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rV, (int)off, 0, kAuxCoherent));
                 } else if (row == T - 1) vall[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rV, (int)(unsigned)((row * hs + d0 + (tid & 7) * 4) * 4), 0, kAuxCoherent));
             }
+        } else if constexpr (FLM_V_LATE_NS) {
+#pragma unroll
+            for (int u = 0; u < DV; ++u) request(rV, u, nt, prowv, goffv, ringV[u], T);
         } else {
 #pragma unroll
             for (int u = 0; u < DV; ++u) patch(rV, u, nt, prowv, goffv, ringV[u]);
