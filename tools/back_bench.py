@@ -9,7 +9,7 @@ L = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 pos = int(sys.argv[2]) if len(sys.argv) > 2 else 14
 qt = ff.QT_INT16 if len(sys.argv) > 3 and sys.argv[3] == "int16" else ff.QT_INT8
 cfg = synth.make_config("7B", qt); cfg.n_layers = L
-ctx = capi.Ctx(capi.desc_from_config(cfg))
+ctx = capi.Ctx(capi.desc_from_config(cfg, max_seq_len=int(os.environ.get("FLM_MAXLEN", "1024"))))   # (FLM_MAXLEN: the KV cache rows per head = the stride between two heads)
 ctx.upload_all(synth.make_tensors(cfg, seed=1))
 prompt = (np.arange(1, pos + 1, dtype=np.int64) * 7919 % cfg.vocab_size).astype(np.int32)
 specs = sys.argv[4].split(";") if len(sys.argv) > 4 else ["fuse_back=0", "fuse_back=1,back_nst13=0", "back_nst13=-1", "back_pre13=1", "back_nst13_head=-1", "back_pre13=0,back_nst13_head=0,back_nst2=8", "back_nst2=0,fuse_back=0"]
