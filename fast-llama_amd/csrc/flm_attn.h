@@ -31,6 +31,7 @@ struct AttnArgs {
     float* out;              // [heads*hs]
     const int* pos_ptr;
     int hs, max_seq;
+    int kv_rows;             // rows per head in the caches (0 = max_seq): the context pads the stride between two heads' rows -- at a power-of-two stride the heads' K / V streams share memory channels
     unsigned long long* trace;   // FLM_ABLATE builds: [head][8] s_memtime stamps
     // k_attn_o with head_size a multiple of 64: the head also leaves its output QUANTIZED (quant::quantize, quant_operators.cpp:26-47,
     // on the 64 values one wave holds) for the Wo GEMV that waits in the same launch: oq [heads*hs] int8 / int16, os [heads*hs/64]
@@ -100,8 +101,8 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
     float* tile0 = sc + ((a.max_seq + 3) & ~3) + 64;
     float* tile1 = tile0 + kAttnTile * rs;
     const int lane = tid & 63, wave = tid >> 6;
-    const float* K = a.kcache + (size_t)h * a.max_seq * hs;
-    const float* V = a.vcache + (size_t)h * a.max_seq * hs;
+    const float* K = a.kcache + (size_t)h * (a.kv_rows ? a.kv_rows : a.max_seq) * hs;
+    const float* V = a.vcache + (size_t)h * (a.kv_rows ? a.kv_rows : a.max_seq) * hs;
     // K/V rows of this token may have been written by other workgroups of the same kernel (a fused launch): coherent loads
     // (sc0|sc1) through buffer descriptors; positions past T get an out-of-range offset and read as zero
     const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(K), 0, a.max_seq * hs * 4, 0x00020000);
@@ -594,8 +595,8 @@ __device__ __forceinline__ void attn_prefill_mq(const AttnArgs& a, const int h, 
     float* tile1 = tile0 + kAttnTile * rs;
     const int Tmax = pos0 + i0 + nq;                                            // rows the last query of this workgroup sees
     const int nt = (Tmax + kAttnTile - 1) / kAttnTile;
-    const float* K = a.kcache + (size_t)h * a.max_seq * hs;
-    const float* V = a.vcache + (size_t)h * a.max_seq * hs;
+    const float* K = a.kcache + (size_t)h * (a.kv_rows ? a.kv_rows : a.max_seq) * hs;
+    const float* V = a.vcache + (size_t)h * (a.kv_rows ? a.kv_rows : a.max_seq) * hs;
     const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(K), 0, a.max_seq * hs * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V), 0, a.max_seq * hs * 4, 0x00020000);
     const float scale = (float)(1.0 / (double)__builtin_sqrtf((float)hs));      // attn_scale, transformer.cpp:418
@@ -772,7 +773,7 @@ __global__ void __launch_bounds__(256) k_qk_mfma(const AttnArgs a, int pos0, int
     const int h = blockIdx.x, q0 = blockIdx.y * kQkQ;
     const int Tmax = pos0 + (q0 + kQkQ < B ? q0 + kQkQ : B);     // positions the last query of the tile sees
     const int nt = (Tmax + 15) >> 4;                             // 16-position tiles
-    const float* K = a.kcache + (size_t)h * a.max_seq * hs;
+    const float* K = a.kcache + (size_t)h * (a.kv_rows ? a.kv_rows : a.max_seq) * hs;
     const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(K), 0, Tmax * hs * 4, 0x00020000);   // rows past the last position read as zero
     const float scale = (float)(1.0 / (double)__builtin_sqrtf((float)hs));
     const int li = lane & 15, c = lane >> 4;                      // operand lane: row / column li, k-slot c
@@ -914,7 +915,7 @@ inline __global__ void __launch_bounds__(256) k_attn_pv_mfma(const AttnArgs a, i
     // ---- weighted sum on the matrix cores
     const int li = lane & 15, c = lane >> 4, d0 = 32 * wave + 2 * li;
     if (32 * wave >= hs) return;                                  // (hs <= 96: the last waves have no dimensions)
-    const float* V = a.vcache + (size_t)h * a.max_seq * hs;
+    const float* V = a.vcache + (size_t)h * (a.kv_rows ? a.kv_rows : a.max_seq) * hs;
     const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V), 0, Tmax * hs * 4, 0x00020000);
     unsigned voff = d0 < hs ? (unsigned)((c * hs + d0) * 4) : 0x80000000u;      // position c of block 0; + 16 hs bytes per step
     const unsigned vstep = (unsigned)(4 * hs * 4);

@@ -347,7 +347,11 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
     if (alloc_qmat(c, c->cls, c->plan.vocab_count > 0 ? c->plan.vocab_count : 1, d.dim, qt)) return bail(FLM_ERR_OOM);
     c->cls.rows = c->plan.vocab_count;
     HIPB(hipMalloc((void**)&c->out_norm, d.dim * 4));
-    const size_t kvn = (size_t)L * c->heads_local * d.max_seq_len * hs;
+#ifndef FLM_KV_PAD
+#define FLM_KV_PAD 8
+#endif
+    c->kv_rows = d.max_seq_len + FLM_KV_PAD;
+    const size_t kvn = (size_t)L * c->heads_local * c->kv_rows * hs;
     HIPB(hipMalloc((void**)&c->kcache, kvn * 4)); HIPB(hipMalloc((void**)&c->vcache, kvn * 4));
     HIPB(hipMemsetAsync(c->kcache, 0, kvn * 4, c->stream)); HIPB(hipMemsetAsync(c->vcache, 0, kvn * 4, c->stream));
     HIPB(hipMalloc((void**)&c->qbuf, c->dim_local * 4));
@@ -656,7 +660,7 @@ int flm_upload_tensor(flm_ctx* c, int kind, int layer, int src_qt, const void* v
 int flm_reset_kv(flm_ctx* c) {
     if (!c) return FLM_ERR_INVALID;
     HIPC(c, hipSetDevice(c->device));
-    const size_t kvn = (size_t)c->d.n_layers * c->heads_local * c->d.max_seq_len * c->hs;
+    const size_t kvn = (size_t)c->d.n_layers * c->heads_local * c->kv_rows * c->hs;
     HIPC(c, hipMemsetAsync(c->kcache, 0, kvn * 4, c->stream)); HIPC(c, hipMemsetAsync(c->vcache, 0, kvn * 4, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     return FLM_OK;
@@ -666,15 +670,22 @@ int flm_reset_kv(flm_ctx* c) {
 int flm_debug_read(flm_ctx* c, int what, int layer, float* out, size_t n) {
     if (!c || !out) return FLM_ERR_INVALID;
     HIPC(c, hipSetDevice(c->device));
-    const size_t kvl = (size_t)c->heads_local * c->d.max_seq_len * c->hs;
+    const size_t kvl = (size_t)c->heads_local * c->d.max_seq_len * c->hs, kvs = (size_t)c->heads_local * c->kv_rows * c->hs;   // what the caller sees ([heads][max_seq][hs]) / what a layer occupies
     const float* src = nullptr; size_t cap = 0;
     switch (what) {
     case 0: src = c->x1; cap = c->d.dim; break;
     case 1: src = c->qbuf; cap = c->dim_local; break;
     case 2: src = c->att_out; cap = c->d.dim; break;
     case 3: src = c->hd; cap = c->d.hidden_dim; break;
-    case 4: src = c->kcache + (size_t)layer * kvl; cap = kvl; break;
-    case 5: src = c->vcache + (size_t)layer * kvl; cap = kvl; break;
+    case 4: case 5: {   // the cache rows of a layer, without the padding rows between two heads
+        if (n > kvl || layer < 0 || layer >= c->d.n_layers) return fail(c, FLM_ERR_INVALID, "debug_read: size/layer");
+        const float* base = (what == 4 ? c->kcache : c->vcache) + (size_t)layer * kvs;
+        const size_t row = (size_t)c->d.max_seq_len * c->hs * 4, heads = (n * 4 + row - 1) / row;
+        std::vector<float> tmp(heads * row / 4);
+        HIPC(c, hipMemcpy2DAsync(tmp.data(), row, base, (size_t)c->kv_rows * c->hs * 4, row, heads, hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
+        memcpy(out, tmp.data(), n * 4);
+        return FLM_OK; }
     case 6: src = c->logits; cap = (size_t)c->vocab_slot * c->world; break;
     case 7: {   // GEMV timeline (FLM_ABLATE builds): [grid][8] ticks relative to the earliest workgroup start; column 7 = 100 MHz ticks start -> end
         if (!c->trace || n > 4096 * 8) return fail(c, FLM_ERR_INVALID, "debug_read: no trace");

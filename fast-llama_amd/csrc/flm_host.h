@@ -60,7 +60,8 @@ struct flm_ctx {
     float* out_norm = nullptr; bool got_out_norm = false;
     QMat cls; bool got_cls = false;
 
-    float *kcache = nullptr, *vcache = nullptr;       // [L][heads_local][max_seq][hs]
+    float *kcache = nullptr, *vcache = nullptr;       // [L][heads_local][kv_rows][hs]
+    int kv_rows = 0;                                   // max_seq_len + 8: rows per head in the caches (a head's rows start 4 KiB (hs 128) off the power-of-two stride: DESIGN.md section 7c)
     float *x1 = nullptr, *qbuf = nullptr, *att_out = nullptr, *hd = nullptr;
     float *logits = nullptr;
     float *rope_cos = nullptr, *rope_sin = nullptr;

@@ -68,7 +68,7 @@ int prefill_batched(flm_ctx* c, int B, int pos) {
     const int L = d.n_layers, dim = d.dim, hid = d.hidden_dim, hs = c->hs;
     hipStream_t st = c->stream;
     int r = B <= c->pf_cap ? FLM_OK : fail(c, FLM_ERR_INVALID, "prefill: more tokens than max_seq_len"); if (r) return r;
-    const size_t kv_layer = (size_t)c->heads_local * d.max_seq_len * hs;
+    const size_t kv_layer = (size_t)c->heads_local * c->kv_rows * hs;
     if (!c->st_ready) {   // once per set of weights: the scales group-major (no allocation: the copies' memory came with the matrices)
         for (auto& w : c->layers)
             for (QMat* m : {&w.qkv, &w.o, &w.w13, &w.w2}) {
@@ -96,18 +96,18 @@ int prefill_batched(flm_ctx* c, int B, int pos) {
         if (QT == QT_INT8 && c->use_mfma && dimL % 32 == 0 && hs % 2 == 0) {
             // RoPE and the cache rows as the epilogue of the matrix-core tiles: no [tokens][3 dim] round trip, no k_rope_kv_rows
             g.qout = c->pf_q; g.kcache = c->kcache + (size_t)l * kv_layer; g.vcache = c->vcache + (size_t)l * kv_layer;
-            g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.dim = dimL; g.hs = hs; g.max_seq = d.max_seq_len; g.pos0 = pos;
+            g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.dim = dimL; g.hs = hs; g.max_seq = c->kv_rows /* (the stride between two heads' cache rows) */; g.pos0 = pos;
             r = launch_gemm<QT, EPI_ROPE_KV>(c, st, g, c->use_mfma); if (r) return r;
         } else {
             r = launch_gemm<QT, EPI_STORE>(c, st, g, c->use_mfma); if (r) return r;
             hipLaunchKernelGGL(k_rope_kv_rows, dim3(B), dim3(256), 0, st, (const float*)c->pf_qkv, c->pf_q, c->kcache + (size_t)l * kv_layer, c->vcache + (size_t)l * kv_layer,
-                               (const float*)c->rope_cos, (const float*)c->rope_sin, dimL, hs, d.max_seq_len, pos);
+                               (const float*)c->rope_cos, (const float*)c->rope_sin, dimL, hs, c->kv_rows, pos);
             HIPC(c, hipGetLastError());
         }
         if (l == L - 1) break;                            // the batch only has to fill the cache: nothing downstream of the last layer's K/V is needed
         // attention of every query over the cache rows 0 .. its own position   (execute_attn :441-449): the local heads' columns of att
         AttnArgs aa{}; aa.q = c->pf_q; aa.kcache = c->kcache + (size_t)l * kv_layer; aa.vcache = c->vcache + (size_t)l * kv_layer;
-        aa.out = c->pf_att + col_a; aa.pos_ptr = &c->state->pos; aa.hs = hs; aa.max_seq = d.max_seq_len;
+        aa.out = c->pf_att + col_a; aa.pos_ptr = &c->state->pos; aa.hs = hs; aa.max_seq = d.max_seq_len; aa.kv_rows = c->kv_rows;
         if (tp) { const size_t off = (char*)aa.out - c->xbuf; for (int r2 = 0; r2 < c->world; ++r2) if (r2 != c->rank) aa.out_peer[aa.n_peer++] = (float*)(c->peer[r2] + off); }
         // which kernels: the exps of a tile of queries (weighted sum on the matrix cores) or the scores of 8 queries (VALU) must fit the LDS;
         // one query per workgroup needs 4 bytes per position and always fits (flm_ctx_create checked max_seq_len against it)

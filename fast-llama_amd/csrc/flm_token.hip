@@ -43,13 +43,13 @@ GemvPlan gemv_plan(int n, int esz, int rows, bool two, bool pairs, bool norm, in
 // argument blocks of the five GEMVs and the attention of layer l (shared by the per-phase launches and k_token)
 GemvArgs args_qkv(flm_ctx* c, int l) {
     const auto& d = c->d; LayerW& w = c->layers[l];
-    const size_t kv_layer = (size_t)c->heads_local * d.max_seq_len * c->hs;
+    const size_t kv_layer = (size_t)c->heads_local * c->kv_rows * c->hs;
     GemvArgs a{}; a.ablate = c->ablate;
     a.W = w.qkv.q; a.sW = w.qkv.s; a.n = d.dim; a.items = w.qkv.rows / 2;
     a.x = c->x1; a.norm_w = w.att_norm;
     a.out = c->qbuf; a.kcache = c->kcache + (size_t)l * kv_layer; a.vcache = c->vcache + (size_t)l * kv_layer;
     a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.pos_ptr = &c->state->pos;
-    a.dim = c->dim_local; a.kv_dim = c->dim_local; a.max_seq = d.max_seq_len; a.hs = c->hs;
+    a.dim = c->dim_local; a.kv_dim = c->dim_local; a.max_seq = c->kv_rows /* (the epilogue's only use: the stride between two heads' cache rows) */; a.hs = c->hs;
     return a;
 }
 // Parts per head for a token whose context is T positions: long contexts spread a head's K/V stream over 4 CUs (attn_head, G > 1).
@@ -68,10 +68,10 @@ int attn_parts(const flm_ctx* c, int T) {
 }
 AttnArgs args_attn(flm_ctx* c, int l, int G) {
     const auto& d = c->d;
-    const size_t kv_layer = (size_t)c->heads_local * d.max_seq_len * c->hs;
+    const size_t kv_layer = (size_t)c->heads_local * c->kv_rows * c->hs;
     AttnArgs a{};
     a.q = c->qbuf; a.kcache = c->kcache + (size_t)l * kv_layer; a.vcache = c->vcache + (size_t)l * kv_layer;
-    a.out = c->att_out + (size_t)c->plan.head_begin * c->hs; a.pos_ptr = &c->state->pos; a.hs = c->hs; a.max_seq = d.max_seq_len;
+    a.out = c->att_out + (size_t)c->plan.head_begin * c->hs; a.pos_ptr = &c->state->pos; a.hs = c->hs; a.max_seq = d.max_seq_len; a.kv_rows = c->kv_rows;
     a.G = G; a.sc_global = c->att_sc; a.flag_sc = c->flag_lines + 256 * 16; a.epoch = (unsigned)(l + 1); a.err = c->xwg_err;
     set_peers(c, a, a.out);
     return a;
