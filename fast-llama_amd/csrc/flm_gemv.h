@@ -301,6 +301,30 @@ __device__ __forceinline__ void gemv_preload(const GemvArgs& a, float4 (&xv)[XR 
     }
 }
 
+// One quantizer round of a 16-lane row: the lane owns elements e .. e+3, 16 consecutive lanes own one 64-group (quant::quantize, quant_operators.cpp:26-47:
+// scale = max|x| / F, q = (T)(x / scale)); the packed values go to xq[e ..], the group's scale to xs[e / 64].  Every lane of the row must call it (the group
+// maximum is a DPP butterfly); `act` = the lane's elements exist.
+template <int QT>
+__device__ __forceinline__ void quant_round4(char* xq, float* xs, int e, bool act, const float4& v) {
+    using T = QTraits<QT>;
+    // group max over the 16 lanes that share this 64-element group (order-free, exact)
+    const float mx = row16_max(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    const float sc = __fdiv_rn(mx, T::kF);           // scale = max|x| / F
+    if (act) {
+        const int q0 = quant_elem(v.x, sc), q1 = quant_elem(v.y, sc), q2 = quant_elem(v.z, sc), q3 = quant_elem(v.w, sc);
+        if constexpr (QT == QT_INT8) {
+            const uint32_t pk = (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
+            *reinterpret_cast<uint32_t*>(xq + e) = pk;
+        } else {
+            uint2 pk;
+            pk.x = (uint32_t)(q0 & 0xffff) | ((uint32_t)(q1 & 0xffff) << 16);
+            pk.y = (uint32_t)(q2 & 0xffff) | ((uint32_t)(q3 & 0xffff) << 16);
+            *reinterpret_cast<uint2*>(xq + (size_t)e * 2) = pk;
+        }
+        if ((threadIdx.x & 15) == 0) xs[e / kGroup] = sc;
+    }
+}
+
 #ifdef FLM_TRACE_PRO_RT      // tools/trace_back.py: the prologue's stamps on the 100 MHz clock (one clock for all XCDs), wave 0 / wave 15
 #define FLM_PRO_STAMP(k) if (kAblate && a.trace && (threadIdx.x == 0 || threadIdx.x == 960)) a.trace[blockIdx.x * 16 + (threadIdx.x ? 8 : 0) + (k)] = __builtin_amdgcn_s_memrealtime();
 #elif defined(FLM_TRACE_PRO)
@@ -437,22 +461,7 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, char* lds, floa
                 v.z = __fmul_rn(__fmul_rn(v.z, w.z), r); v.w = __fmul_rn(__fmul_rn(v.w, w.w), r);
             }
             if (act && a.dbg_xn && blockIdx.x == 0) *reinterpret_cast<float4*>(a.dbg_xn + e) = v;
-            // group max over the 16 lanes that share this 64-element group (order-free, exact)
-            const float mx = row16_max(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-            const float sc = __fdiv_rn(mx, T::kF);           // scale = max|x| / F
-            if (act) {
-                const int q0 = quant_elem(v.x, sc), q1 = quant_elem(v.y, sc), q2 = quant_elem(v.z, sc), q3 = quant_elem(v.w, sc);
-                if constexpr (QT == QT_INT8) {
-                    const uint32_t pk = (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
-                    *reinterpret_cast<uint32_t*>(xq + e) = pk;
-                } else {
-                    uint2 pk;
-                    pk.x = (uint32_t)(q0 & 0xffff) | ((uint32_t)(q1 & 0xffff) << 16);
-                    pk.y = (uint32_t)(q2 & 0xffff) | ((uint32_t)(q3 & 0xffff) << 16);
-                    *reinterpret_cast<uint2*>(xq + (size_t)e * 2) = pk;
-                }
-                if ((tid & 15) == 0) xs[e / kGroup] = sc;
-            }
+            quant_round4<QT>(xq, xs, e, act, v);
         };
 #pragma unroll
         for (int i = 0; i < XR; ++i) { if (i < rounds) round(i, xv[i], wv[i]); }
@@ -662,10 +671,10 @@ struct GemvCtx {
 #pragma unroll
             for (int j = 0; j < H; ++j) {
                 const u32 woj = (u32)j < S.nlive ? lane_woff + wo + j * dW : kOOB;
-                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen nt lds" :: "v"(woj), "s"(rW), "s"(dst + j * 1024) : "memory");
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen nt lds" :: "v"(woj), "s"(rW), "s"(dst + j * 1024) : "memory", "m0");
             }
             const u32 svo = lane_j < S.nlive ? lane_s2off + so : kOOB;
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %0, %1, 0 offen nt lds" :: "v"(svo), "s"(rS), "s"(dst + H * 1024) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %0, %1, 0 offen nt lds" :: "v"(svo), "s"(rS), "s"(dst + H * 1024) : "memory", "m0");
         }
     }
     // whichever of the two fixed sets this wave has not requested yet
@@ -853,6 +862,112 @@ struct GemvCtx {
         if (!primedA) load_step(setA, wave, a.ablate);                         // (a wave that was busy elsewhere during the prologue)
         if (!primedB) load_step(setB, wave + kWavesPerBlock, a.ablate);
         while (do_set(setA) && do_set(setB)) {}
+    }
+
+    // ---- arrival-order activation (round 5) --------------------------------------------------------------------------------------------------------------
+    // The activation is produced by other workgroups of the SAME launch (the heads' output for Wo, FFN13's hd for FFN2), each raising its own flag line when its
+    // slice is in memory.  The classic hand-off (poll_lines + gemv_prologue + run) polls ALL lines, then the whole workgroup fetches / quantizes the whole vector
+    // between two barriers: the consumer's integer work starts when the SLOWEST producer has finished, plus a poll, the vector's read, the quantizer and the barriers.
+    // The int32 group dots are order-free and a step's column block depends on a handful of producers only.  So here every wave looks after its own steps
+    // (wave + 16 k: k = 0, 1 the two register sets, k = 2, 3 the stash slots the wave itself filled): lanes [16 k, 16 k + 16) poll the lines of the producers of
+    // step k's column block; when a block's lines are up the wave reads its elements with coherent loads, puts them -- quantized by itself (quant_round4: the same
+    // operations on the same values, whoever runs them) or copied (PRO_NONE: the heads hand their output over quantized) -- where the block lives in LDS, and reduces
+    // the step.  No workgroup barrier before the one in front of the fp32 chains; what is behind the LAST producer's flag is one look, one 1 KiB read, one wave's
+    // quantizer round, one step, the chains.  The host guarantees (BackArgs::ao_*): one pass per workgroup, every step resident (NS <= 32 + st_n), a column block
+    // of <= 256 elements (PRO_QUANT) with <= 16 producers.
+    struct AoSrc {
+        const unsigned* flags;          // the producers' flag lines (kFlagStride dwords apart)
+        u32 rows, grid;                 // element i of the vector comes from line (i / rows) % grid
+        unsigned target; int* err;
+    };
+    struct AoBlock { v4i d; float s; };
+    template <int PRO>
+    __device__ __forceinline__ AoBlock ao_fetch(const GemvArgs& a, u32 cc) const {
+        AoBlock b; b.s = 0.f;
+        const u32 CB = 1u << cbs;
+        if constexpr (PRO == PRO_NONE) {
+            // the block's CB chunks of 16 quantized bytes and its CB / LPG group scales
+            const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.xq), 0, (int)rowbytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.xs), 0, (int)(sn * 4), 0x00020000);
+            b.d = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rq, (int)(lane < CB ? ((cc << cbs) + lane) * 16 : kOOB), 0, kAuxCoherent));
+            b.s = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(lane < (CB >> LPGS) ? (((cc << cbs) >> LPGS) + lane) * 4 : kOOB), 0, kAuxCoherent));
+        } else {
+            // the block's fp32 elements: lane l owns 4 l .. 4 l + 3 of them (16 lanes = one 64-group)
+            const u32 EPB = (16u << cbs) / T::kEsz;
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)(n * 4), 0x00020000);
+            b.d = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(4 * lane < EPB ? (cc * EPB + 4 * lane) * 4 : kOOB), 0, kAuxCoherent));
+        }
+        return b;
+    }
+    template <int PRO>
+    __device__ __forceinline__ void ao_place(char* lds, u32 cc, const AoBlock& b) const {
+        char* xq = lds; float* xs = reinterpret_cast<float*>(lds + off_xs);
+        const u32 CB = 1u << cbs;
+        if constexpr (PRO == PRO_NONE) {
+            if (lane < CB) *reinterpret_cast<v4i*>(xq + ((cc << cbs) + lane) * 16) = b.d;
+            if (lane < (CB >> LPGS)) xs[((cc << cbs) >> LPGS) + lane] = b.s;
+        } else {
+            const u32 EPB = (16u << cbs) / T::kEsz, e = cc * EPB + 4 * lane;
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const v4f t = __builtin_bit_cast(v4f, b.d);
+            quant_round4<QT>(xq, xs, (int)e, 4 * lane < EPB && e < n, make_float4(t.x, t.y, t.z, t.w));
+        }
+    }
+    // mid(): called once, when the first look has come back and the loads of the blocks it found complete are out (what the caller still wants to request: the rest of the weights)
+    template <int PRO, class Mid, class Stamp>
+    __device__ __forceinline__ void run_ao(const GemvArgs& a, char* lds, const AoSrc& src, Mid&& mid, Stamp&& stamp) {
+        xa = v4i{0, 0, 0, 0}; sx2 = 0.f; cur_xo = 0xffffffffu;
+        char* strips = lds + off_scr;
+        // lane (k, j) = (lane >> 4, lane & 15): producer j of the column block of step wave + 16 k
+        const u32 EPB = (16u << cbs) / T::kEsz, inv_rows = inv_of(src.rows);
+        const u32 ks = wave + ((lane >> 4) << 4);                                // (one pass per workgroup: a step number is the remainder inside the pass)
+        const u32 kq = udiv(ks, NBCV, inv_NBCV), kc = ks - kq * NBCV;            // its row chunk, its column block
+        const u32 e0 = kc * EPB, e1 = e0 + EPB < n ? e0 + EPB : n;
+        const u32 p0 = udiv(e0, src.rows, inv_rows), p1 = udiv(e1 - 1, src.rows, inv_rows), pj = p0 + (lane & 15);
+        const bool mine = ks < NS && pj <= p1;
+        const unsigned* line = src.flags + (pj % src.grid) * 16 /* kFlagStride */;
+        u32 pending = 0;
+#pragma unroll
+        for (u32 k = 0; k < 4; ++k) if (wave + 16 * k < NS) pending |= 1u << k;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        bool first = true;
+        while (pending) {
+            const unsigned f = mine ? __hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : src.target;
+            const unsigned long long okm = __ballot((int)(f - src.target) >= 0);
+            u32 now = 0;
+#pragma unroll
+            for (u32 k = 0; k < 4; ++k) if (((okm >> (16 * k)) & 0xFFFFull) == 0xFFFFull) now |= 1u << k;
+            now &= pending;
+            if (!now && __builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) {    // 20 ms: the host re-runs the call on one kernel per phase
+                __hip_atomic_store(src.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                now = pending;
+            }
+            AoBlock b[4];
+#pragma unroll
+            for (u32 k = 0; k < 4; ++k) if (now & (1u << k)) b[k] = ao_fetch<PRO>(a, (u32)__builtin_amdgcn_readlane((int)kc, 16 * k));
+            if (first) { first = false; mid(); }
+#pragma unroll
+            for (u32 k = 0; k < 4; ++k) {
+                if (now & (1u << k)) {
+                    ao_place<PRO>(lds, (u32)__builtin_amdgcn_readlane((int)kc, 16 * k), b[k]);
+                    asm volatile("" ::: "memory");                                 // (the same wave reads the block back: LDS keeps a wave's accesses in order)
+                    cur_xo = 0xffffffffu;                                          // (the block's place in LDS has just been written: reduce_step fetches this lane's chunk)
+                    if (k == 0) reduce_step(setA, lds, strips, a.ablate);
+                    else if (k == 1) reduce_step(setB, lds, strips, a.ablate);
+                    else {
+                        wait_stores_done();                                        // this wave's own LDS-DMA into its stash slots
+                        Set S;
+                        load_step(S, wave + 16 * k, a.ablate, lds);
+                        reduce_step(S, lds, strips, a.ablate);
+                    }
+                }
+            }
+            if (pending && now == pending) stamp(3);
+            pending &= ~now;
+        }
+        stamp(4);
+        if (np_wg) finish_pass(a, wg, 0, strips, 0);
+        stamp(5);
     }
 };
 

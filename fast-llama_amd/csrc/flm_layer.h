@@ -41,6 +41,11 @@ struct BackArgs {
     int nst2;                   // stash slots of W2 every workgroup fills behind its rows of hd
     int pre2;                   // the first pre2 waves request their first register set of W2 before the hd flag round
     int pre13;                  // the first pre13 waves of a workgroup request their first register set of [W1; W3] before the x1 flag round (16: all, as k_ffn does for W2)
+    // arrival-order hand-offs (round 5; GemvCtx::run_ao): the consumer's waves poll the producers of their own steps' column blocks instead of the workgroup polling all lines
+    int ao_o;                   // Wo: a wave copies a column block of the heads' quantized output when the block's heads have raised their lines (one workgroup per head)
+    int ao_2;                   // FFN2: a wave quantizes a column block of hd when the block's FFN13 workgroups have raised theirs; 1: W2 whole (both sets + stash) in front of the first look,
+                                // 2: the first register sets in front, the rest behind the first look, 3: first sets + stash in front, the second sets behind
+    int nst2_ao;                // ... its stash slots: the steps beyond the two register sets (all of W2's share is resident)
     unsigned long long* trace;  // FLM_ABLATE builds: [grid][16] s_memrealtime stamps (100 MHz, one clock for all XCDs; tools/trace_back.py)
 };
 
@@ -57,9 +62,13 @@ __device__ __forceinline__ void poll_wave(const unsigned* line, bool mine, unsig
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     auto look = [&]() -> unsigned { return mine ? __hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target; };
 #if FLM_POLL_DEPTH <= 1
+    // (a wait of this launch has already given up: the host re-runs the call anyway; do not spend another 20 ms here -- the look at *err flies beside the first look at the lines)
+    const int gave_up = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned f = look();
+    if (gave_up) return;
     while (true) {
-        const unsigned f = look();
         if (__all((int)(f - target) >= 0)) break;
+        f = look();
         if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
     }
 #else
@@ -188,6 +197,15 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
         // (tools/trace_back.py: when has everything this CU requested -- Wo's register sets and the [W1; W3] stash -- landed?  Wave 15 requested last; loads complete in order)
         if (kAblate && p.trace && threadIdx.x == 960) { wait_stores_done(); p.trace[blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memrealtime(); }
 #endif
+        bool ao_done = false;
+        if constexpr (!SPLIT) {
+            if (p.ao_o) {                                                       // arrival order: a wave copies a column block when ITS heads' lines are up (GemvCtx::run_ao)
+                const typename GemvCtx<QT, EPI_RESIDUAL>::AoSrc src{p.flag_h, (unsigned)aa.hs, (unsigned)p.n_heads, target, p.err};
+                g.template run_ao<PRO_NONE>(ao, lds, src, []() {}, [&](int k) { if (k == 3) stamp(2); });
+                ao_done = true;
+            }
+        }
+        if (!ao_done) {
         poll_lines(p.flag_h, p.n_heads, target, p.err);
         __syncthreads();
         stamp(2);
@@ -197,6 +215,7 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
             gemv_prologue<QT, PRO_QUANT, 1>(ao, lds, xv, nv, [](int) {});
         } else gemv_prologue<QT, PRO_NONE, 0, true>(ao, lds, xv, nv, [](int) {});   // the heads' output arrives quantized (PREQ)
         g.run(ao, lds, nostamp);
+        }
         stamp(3);
         wait_stores_done();                                                     // every wave: its rows of x1 are where the others will read them
         __syncthreads();
@@ -233,6 +252,17 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
     if ((int)blockIdx.x < p.grid2) {
     // ---- FFN2: k_gemv<QUANT, RESIDUAL> behind the hd flag round
     GemvCtx<QT, EPI_RESIDUAL, true> g2;
+    if (p.ao_2) {
+        // arrival order (GemvCtx::run_ao): no workgroup-wide poll, no prologue -- a wave quantizes the column block of each of its steps when the FFN13 workgroups that
+        // produced THAT block have raised their lines.  W2's whole share is resident (two register sets per wave + nst2_ao stash slots), requested as ao_2 says.
+        g2.init(a2, blockIdx.x, p.grid2, lds, 0, p.st_base, (unsigned)p.nst2_ao);
+        g2.issue(kAblate ? a2.ablate : 0, p.ao_2 == 1 ? 0 : 1);
+        if (p.ao_2 != 2) g2.stash_issue(lds);
+        const typename GemvCtx<QT, EPI_RESIDUAL, true>::AoSrc src{p.flag_hd, (unsigned)a13.rows_per_pass, (unsigned)p.grid13, target, p.err};
+        g2.template run_ao<PRO_QUANT>(a2, lds, src, [&]() { g2.issue_missing(kAblate ? a2.ablate : 0); if (p.ao_2 == 2) g2.stash_issue(lds); },
+                                      [&](int k) { if (k == 3) stamp(9); else if (k == 4) stamp(10); });
+        stamp(11);
+    } else {
     g2.init(a2, blockIdx.x, p.grid2, lds, 0, p.st_base, (unsigned)p.nst2);
     if ((int)g2.wave < p.pre2) g2.issue(kAblate ? a2.ablate : 0, 1);            // the first pre2 waves: ONE set now, the rest when hd has arrived (k_ffn: all 16)
     g2.stash_issue(lds);
@@ -246,6 +276,7 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
     stamp(10);
     g2.run(a2, lds, nostamp);
     stamp(11);
+    }
     }
     if constexpr (PERSIST) {
         if (xflag) {

@@ -45,6 +45,16 @@ int plan_layer(flm_ctx* c, int l, bool with_qkv, int G, LayerArgs& A, BackArgs& 
     p.gridq = with_qkv ? Pq.grid : 0; p.flag_q = c->flag_lines + 768 * 16;
     p.target = (unsigned)(l + 1); p.err = c->xwg_err;
     p.st_base = (unsigned)own; p.nst13 = slots(c->back_nst13); p.nst13_head = slots(c->back_nst13_head); p.nst2 = slots(c->back_nst2); p.pre13 = c->back_pre13 < 0 ? 0 : c->back_pre13 > 16 ? 16 : c->back_pre13; p.pre2 = c->back_pre2 < 0 ? 0 : c->back_pre2 > 16 ? 16 : c->back_pre2;
+    {   // arrival-order hand-offs (GemvCtx::run_ao): one pass per workgroup, every step resident, a column block with <= 16 producers (PRO_QUANT: <= 256 elements)
+        auto steps = [&](const GemvArgs& a, const GemvPlan& P, int rows) { const int RB = 64 >> P.cb_shift, RBP = P.Rm / RB, nbc = (a.n * esz / 16) >> P.cb_shift; return (rows + P.Rm - 1) / P.Rm <= P.grid ? ((RBP + kStepBlk - 1) / kStepBlk) * nbc : 1 << 30; };
+        const int epb_o = (16 << Po.cb_shift) / esz, epb_2 = (16 << P2.cb_shift) / esz;
+        const int ns_o = steps(ao, Po, ao.items), ns_2 = steps(a2, P2, a2.items);
+        p.ao_o = (c->back_ao & 1) && G == 1 && ns_o <= 32 && ao.n < 65536 && epb_o / c->hs + 2 <= 16 ? 1 : 0;
+        const int want2 = ns_2 > 32 ? ns_2 - 32 : 0;
+        const bool ok2 = (c->back_ao & 2) && want2 <= fit && want2 <= 32 && a2.n < 65536 && epb_2 <= 256 && epb_2 / P13.Rm + 2 <= 16;
+        p.ao_2 = ok2 ? (c->back_ao2 >= 1 && c->back_ao2 <= 3 ? c->back_ao2 : 1) : 0;
+        p.nst2_ao = ok2 ? want2 : 0;
+    }
     if (kAblate && c->trace_class == 102 && l == 0) { p.trace = c->trace; a13.trace = c->trace + 256 * 16; a2.trace = c->trace + 2 * 256 * 16; }   // tools/trace_back.py
     if (kAblate && c->trace_class == 103) { p.trace = c->trace; if (l == (c->d.n_layers > 1 ? 1 : 0)) { a13.trace = c->trace + 256 * 16; a2.trace = c->trace + 2 * 256 * 16; aa.trace = c->trace + 5 * 4096; } }   // (k_layers: its second layer)
     grid = parts + Po.grid; if (P13.grid > grid) grid = P13.grid; if (P2.grid > grid) grid = P2.grid; if (with_qkv && Pq.grid > grid) grid = Pq.grid;

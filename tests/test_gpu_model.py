@@ -124,7 +124,9 @@ def test_back_half_of_a_layer_in_one_launch_vs_oracle(gpu, shape, qt, layers):
     for _ in range(4):
         want.append(om.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(want[-1])); pos += 1
     variants = ({}, {"fuse_token": 0}, {"tok_preq": 0, "tok_nstq": 0}, {"tok_preq": 5, "tok_nstq": -1}, {"tok_preq": 16, "tok_nstq": 9, "back_nst13": 2, "use_graph": 0}, {"fuse_layer": 0}, {"back_nst13": 0}, {"back_nst13": 3, "fuse_layer": 0}, {"back_nst13": 17, "back_nst13_head": 5}, {"back_nst13_head": -1, "back_nst2": -1},
-                {"back_nst13": 0, "back_nst2": 7, "back_pre13": 1}, {"back_nst13": -1, "back_nst13_head": -1, "back_nst2": -1, "back_pre13": 1, "use_graph": 0})
+                {"back_nst13": 0, "back_nst2": 7, "back_pre13": 1}, {"back_nst13": -1, "back_nst13_head": -1, "back_nst2": -1, "back_pre13": 1, "use_graph": 0},
+                # round 5: the Wo / FFN2 hand-offs consumed in arrival order (GemvCtx::run_ao) -- off, one at a time, every way of requesting W2 around the first look
+                {"back_ao": 0}, {"back_ao": 1}, {"back_ao": 2, "back_ao2": 2}, {"back_ao": 3, "back_ao2": 3}, {"back_ao": 3, "fuse_token": 0}, {"back_ao": 2, "back_ao2": 2, "fuse_layer": 0, "use_graph": 0})
     for opts in variants:
         ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
         ctx.set_option("use_prefill", 0)
@@ -362,7 +364,7 @@ def test_option_and_query_surface(gpu):
     assert ctx.query("resident") == 1 and ctx.query("fallback") == 0
     tp = ctx.query("token_path")
     assert tp & 1 and tp & 2 and tp & 128 and tp & 256 and tp & 512        # attention + Wo, FFN13 + FFN2, both in one launch, with the QKV GEMV in front, all layers in one launch
-    for key in ("fold_xchg", "cu_parts", "fuse_attn_o", "fuse_ffn", "fuse_qkv", "fuse_back", "fuse_layer", "fuse_token", "tok_preq", "tok_nstq", "back_nst13", "back_nst13_head", "back_nst2", "back_pre13",
+    for key in ("fold_xchg", "cu_parts", "fuse_attn_o", "fuse_ffn", "fuse_qkv", "fuse_back", "fuse_layer", "fuse_token", "tok_preq", "tok_nstq", "back_nst13", "back_nst13_head", "back_nst2", "back_pre13", "back_ao", "back_ao2", "ao_active",
                 "attn_split", "use_graph", "use_mfma", "use_prefill", "wg_per_cu"):
         ctx.query(key)
     with pytest.raises(gpu.FlmError):
