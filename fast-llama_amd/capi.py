@@ -23,7 +23,7 @@ SYMBOLS = (
     "flm_forward", "flm_forward_argmax", "flm_decode_greedy", "flm_decode_timed", "flm_decode_timed_each", "flm_last_tokens", "flm_reset_kv", "flm_sync",
     "flm_kernel_times", "flm_kernel_bytes", "flm_set_option", "flm_query", "flm_debug_read",
     "flm_op_quantize", "flm_op_matmul_q", "flm_op_rmsnorm", "flm_op_swiglu", "flm_op_rope", "flm_op_softmax",
-    "flm_op_attention", "flm_op_expf", "flm_op_math", "flm_op_square_sum", "flm_op_argmax", "flm_plan_shards",
+    "flm_op_attention", "flm_op_expf", "flm_op_math", "flm_op_square_sum", "flm_op_argmax", "flm_op_handoff_litmus", "flm_plan_shards",
 )
 
 
@@ -217,6 +217,13 @@ def op_argmax(logits) -> int:
     idx = C.c_int32(-1)
     _check(lib().flm_op_argmax(_p(a), int(a.size), C.byref(idx)))
     return idx.value
+
+
+def op_handoff_litmus(rounds):
+    """(wrong values read, waits timed out) after `rounds` rounds of the fused launches' publish / poll / coherent-read sequence"""
+    bad, to = C.c_int(0), C.c_int(0)
+    _check(lib().flm_op_handoff_litmus(int(rounds), C.byref(bad), C.byref(to)))
+    return bad.value, to.value
 
 
 def op_rmsnorm(x, w):

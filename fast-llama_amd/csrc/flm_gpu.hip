@@ -169,7 +169,9 @@ __global__ void __launch_bounds__(1024) k_census(unsigned* counter, unsigned n, 
 // it picks how many workgroups a head is spread over; the graphs are keyed by it)
 int run_token(flm_ctx* c, bool with_cls, int advance, int T) {
     const int G = attn_parts(c, T);
-    { const int r = layers_prepare(c, G); if (r) return r; }                     // (k_layers' argument blocks: device memory, never built inside a capture)
+    // (k_layers' argument blocks: device memory, never built inside a capture -- and both head splits at once: the copy synchronizes the stream, which must not happen
+    //  at the position where a decode loop crosses from one split to the other, inside somebody's timed region)
+    { int r = layers_prepare(c, G); if (!r) r = layers_prepare(c, attn_parts(c, 1)); if (!r) r = layers_prepare(c, attn_parts(c, c->d.max_seq_len)); if (r) return r; }
     if (!c->use_graph || c->timing || ((c->world > 1 || (c->comm && c->force_tp)) && !c->p2p)) return enqueue_token(c, c->stream, with_cls, advance, G);   // (RCCL collectives stay eager)
     const int key = (with_cls ? 4 : 0) + advance + 8 * G;
     auto it = c->graphs.find(key);
@@ -470,6 +472,13 @@ int flm_p2p_import(flm_ctx* c, const void* blobs, int n) {
     const P2pBlob* b = (const P2pBlob*)blobs;
     // the batched prompt path runs 4 exchanges per layer, token-by-token feeding 4 per layer and TOKEN: every rank must take the same one
     // (decided once, from what all ranks can do; options that would change it afterwards are refused)
+    // validate every blob before anything of the context changes: a foreign blob must not leave a half-updated group structure behind cached graphs
+    for (int r = 0; r < n; ++r)
+        if (b[r].magic != kP2pMagic || b[r].rank != r || b[r].world != c->world || b[r].bytes != c->xbuf_bytes) return fail(c, FLM_ERR_INVALID, "p2p_import: blobs are not those of this tensor-parallel group, in rank order");
+    // (from here on the group's structure may change: graphs captured under the old one must not be replayed, whatever happens below)
+    for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
+    c->graphs.clear();
+    c->la_valid[0] = c->la_valid[1] = false;
     c->tp_prefill = true;
     for (int r = 0; r < n; ++r) if (!(b[r].caps & 1)) c->tp_prefill = false;
     c->ranks_on_device = 0;
@@ -493,7 +502,6 @@ int flm_p2p_import(flm_ctx* c, const void* blobs, int n) {
         c->grp_fold = fold; c->grp_span = span; c->grp_can_split = can; c->grp_tpfa = span ? fa : 0; c->grp_tpff = span ? ff : 0; c->grp_split = can ? split : 0;
     }
     for (int r = 0; r < n; ++r) {
-        if (b[r].magic != kP2pMagic || b[r].rank != r || b[r].world != c->world || b[r].bytes != c->xbuf_bytes) return fail(c, FLM_ERR_INVALID, "p2p_import: blobs are not those of this tensor-parallel group, in rank order");
         if (r == c->rank) continue;
         if (c->peer[r]) continue;                                         // already mapped
         if (b[r].device != c->device) {                                   // (also for a peer of the same process on another GPU: one host thread per GPU)

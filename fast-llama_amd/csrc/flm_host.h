@@ -93,7 +93,7 @@ struct flm_ctx {
     void* la_dev[2] = {nullptr, nullptr}; bool la_valid[2] = {false, false}, la_ok[2] = {false, false}; flm::BackArgs la_p[2]; int la_grid[2] = {0, 0}, la_r2[2] = {0, 0};   // k_layers' argument blocks (flm_layers.hip)
     int fuse_layer = 1;                                // option "fuse_layer": ... with the QKV GEMV in front: the whole layer in one launch
     int back_nst13 = -1, back_nst13_head = -1, back_nst2 = 0, back_pre13 = 16, back_pre2 = 16;   // options "back_*": k_attn_ffn's stash slots (-1: as many as the LDS holds) and early register set (flm_layer.h)
-    int back_ao = 3, back_ao2 = 1;                     // options "back_ao" (bit 0: Wo, bit 1: FFN2 consume their activation in arrival order, GemvCtx::run_ao) / "back_ao2" (what of W2 is requested in front of the first look)
+    int back_ao = 3, back_ao2 = 2;                     // options "back_ao" (bit 0: Wo, bit 1: FFN2 consume their activation in arrival order, GemvCtx::run_ao) / "back_ao2" (what of W2 is requested in front of the first look)
     int fuse_qkv = 1;                                  // option "fuse_qkv": QKV in front of attention + Wo in the same launch (k_qkv_attn_o; single GPU): 0 never,
                                                        // 1 when a head is spread over several workgroups (long contexts: where it pays), 2 always
     unsigned* flag_lines = nullptr; int* xwg_err = nullptr;   // k_attn_o: one 64-byte flag line per head; "a cross-workgroup wait timed out"
@@ -147,7 +147,7 @@ int plan_gemv(flm_ctx* c, GemvArgs& a, int wgs, GemvPlan& P) {
     constexpr bool TWO = EPI == EPI_SWIGLU, PAIRS = EPI == EPI_ROPE_KV;
     const int rows = a.items * (PAIRS ? 2 : 1);
     if ((double)rows * a.n * QTraits<QT>::kEsz * (TWO ? 2 : 1) >= 2147483648.0) return fail(c, FLM_ERR_UNSUPPORTED, "gemv: matrix of 2 GiB or more");
-    P = gemv_plan(a.n, QTraits<QT>::kEsz, rows, TWO, PAIRS, true, wgs);
+    P = gemv_plan(a.n, QTraits<QT>::kEsz, rows, TWO, PAIRS, PRO == PRO_RMSNORM_QUANT, wgs);     // (the chain staging area only where an rmsnorm prologue runs)
     if (P.lds > kLdsMax) return fail(c, FLM_ERR_UNSUPPORTED, "gemv: activation vector does not fit LDS");
     a.rows_per_pass = P.Rm; a.cb_shift = P.cb_shift; a.nbuf = P.nbuf;
     return FLM_OK;

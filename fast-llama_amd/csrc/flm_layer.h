@@ -45,6 +45,7 @@ struct BackArgs {
     int ao_o;                   // Wo: a wave copies a column block of the heads' quantized output when the block's heads have raised their lines (one workgroup per head)
     int ao_2;                   // FFN2: a wave quantizes a column block of hd when the block's FFN13 workgroups have raised theirs; 1: W2 whole (both sets + stash) in front of the first look,
                                 // 2: the first register sets in front, the rest behind the first look, 3: first sets + stash in front, the second sets behind
+    int r5;                     // the round-5 forms the launch's instantiation carries (layer_body's R5): 3 or 0
     int nst2_ao;                // ... its stash slots: the steps beyond the two register sets (all of W2's share is resident)
     unsigned long long* trace;  // FLM_ABLATE builds: [grid][16] s_memrealtime stamps (100 MHz, one clock for all XCDs; tools/trace_back.py)
 };
@@ -109,7 +110,9 @@ __device__ __forceinline__ void poll_lines(const unsigned* flag, int n, unsigned
 // so the Wo workgroups fetch the fp32 vector and quantize it themselves (dim <= 4096: one round).
 // PERSIST (k_layers: several layers in one launch): xpoll = the layer's x comes from the previous layer's FFN2 in the SAME launch -- [Wq; Wk; Wv]'s first register sets (preq waves) and
 // nstq stash slots are requested, then the FFN2 lines are polled and x is read with coherent loads; xflag = this layer's FFN2 raises its lines for the next layer.
-template <int QT, int XR2, bool QKV, bool SPLIT, bool PERSIST>
+// R5 (round 5; compile time, so that an instantiation carries one form of every hand-off -- both forms in one kernel spill): bit 0 Wo consumes the heads' output in arrival
+// order (GemvCtx::run_ao; one workgroup per head), bit 1 FFN2 consumes hd in arrival order.  The host picks the instantiation whose forms the shape allows (plan_layer: BackArgs::r5).
+template <int QT, int XR2, bool QKV, bool SPLIT, bool PERSIST, int R5 = 0>
 __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& aa, const GemvArgs& ao, const GemvArgs& a13, const GemvArgs& a2, const BackArgs& p, char* lds,
                                            const unsigned target, const bool xpoll, const bool xflag, const bool tracing) {
     auto nostamp = [](int) {};
@@ -118,9 +121,9 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
     unsigned nst13 = 0;
     if constexpr (QKV) {
         if ((int)blockIdx.x < p.gridq) {
+            GemvCtx<QT, EPI_ROPE_KV, PERSIST> gq;
             float4 xq[1], nq[1];
             if (!PERSIST || !xpoll) gemv_preload<QT, PRO_RMSNORM_QUANT, 1, PERSIST>(aq, xq, nq);    // (x is there: requested in front of the context's set-up)
-            GemvCtx<QT, EPI_ROPE_KV, PERSIST> gq;
             gq.init(aq, blockIdx.x, p.gridq, lds, 0, p.st_base, (PERSIST && xpoll) ? (unsigned)p.nstq : 0u);
             if constexpr (PERSIST) {
                 if (xpoll) {
@@ -197,15 +200,10 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
         // (tools/trace_back.py: when has everything this CU requested -- Wo's register sets and the [W1; W3] stash -- landed?  Wave 15 requested last; loads complete in order)
         if (kAblate && p.trace && threadIdx.x == 960) { wait_stores_done(); p.trace[blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memrealtime(); }
 #endif
-        bool ao_done = false;
-        if constexpr (!SPLIT) {
-            if (p.ao_o) {                                                       // arrival order: a wave copies a column block when ITS heads' lines are up (GemvCtx::run_ao)
-                const typename GemvCtx<QT, EPI_RESIDUAL>::AoSrc src{p.flag_h, (unsigned)aa.hs, (unsigned)p.n_heads, target, p.err};
-                g.template run_ao<PRO_NONE>(ao, lds, src, []() {}, [&](int k) { if (k == 3) stamp(2); });
-                ao_done = true;
-            }
-        }
-        if (!ao_done) {
+        if constexpr (!SPLIT && (R5 & 1) != 0) {                                // arrival order: a wave copies a column block when ITS heads' lines are up (GemvCtx::run_ao)
+            const typename GemvCtx<QT, EPI_RESIDUAL>::AoSrc src{p.flag_h, (unsigned)aa.hs, (unsigned)p.n_heads, target, p.err};
+            g.template run_ao<PRO_NONE>(ao, lds, src, []() {}, [&](int k) { if (k == 3) stamp(2); });
+        } else {
         poll_lines(p.flag_h, p.n_heads, target, p.err);
         __syncthreads();
         stamp(2);
@@ -252,13 +250,13 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
     if ((int)blockIdx.x < p.grid2) {
     // ---- FFN2: k_gemv<QUANT, RESIDUAL> behind the hd flag round
     GemvCtx<QT, EPI_RESIDUAL, true> g2;
-    if (p.ao_2) {
+    if constexpr ((R5 & 2) != 0) {
         // arrival order (GemvCtx::run_ao): no workgroup-wide poll, no prologue -- a wave quantizes the column block of each of its steps when the FFN13 workgroups that
         // produced THAT block have raised their lines.  W2's whole share is resident (two register sets per wave + nst2_ao stash slots), requested as ao_2 says.
         g2.init(a2, blockIdx.x, p.grid2, lds, 0, p.st_base, (unsigned)p.nst2_ao);
+        const typename GemvCtx<QT, EPI_RESIDUAL, true>::AoSrc src{p.flag_hd, (unsigned)a13.rows_per_pass, (unsigned)p.grid13, target, p.err};
         g2.issue(kAblate ? a2.ablate : 0, p.ao_2 == 1 ? 0 : 1);
         if (p.ao_2 != 2) g2.stash_issue(lds);
-        const typename GemvCtx<QT, EPI_RESIDUAL, true>::AoSrc src{p.flag_hd, (unsigned)a13.rows_per_pass, (unsigned)p.grid13, target, p.err};
         g2.template run_ao<PRO_QUANT>(a2, lds, src, [&]() { g2.issue_missing(kAblate ? a2.ablate : 0); if (p.ao_2 == 2) g2.stash_issue(lds); },
                                       [&](int k) { if (k == 3) stamp(9); else if (k == 4) stamp(10); });
         stamp(11);
@@ -299,7 +297,7 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_attn_ffn(const GemvArgs aq, c
 // in front of which the next layer's [Wq; Wk; Wv] starts to stream (preq waves' first register sets + nstq stash slots: the LDS is empty there).
 // ------------------------------------------------------------------------------------------
 struct LayerArgs { GemvArgs aq, ao, a13, a2; AttnArgs aa; };
-template <int QT, int XR2, bool SPLIT>
+template <int QT, int XR2, bool SPLIT, int R5 = 0>
 __global__ void __launch_bounds__(kGemvBlock, 4) k_layers(const LayerArgs* __restrict__ LA, const BackArgs p, const int l0, const int l1) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     // (the argument blocks through the CONSTANT address space: uniform scalar loads at the point of use, like kernel arguments -- through a generic pointer they would sit in vector registers)
@@ -307,7 +305,7 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_layers(const LayerArgs* __res
     CLayerArgs* LAc = (CLayerArgs*)(unsigned long long)LA;
     for (int l = l0; l < l1; ++l) {
         const LayerArgs& A = *(const LayerArgs*)(LAc + l);
-        layer_body<QT, XR2, true, SPLIT, true>(A.aq, A.aa, A.ao, A.a13, A.a2, p, lds, (unsigned)(l + 1), l > l0, l + 1 < l1, l == (l1 - l0 > 1 ? l0 + 1 : l0));   // (trace builds: the stamps of the launch's second layer)
+        layer_body<QT, XR2, true, SPLIT, true, R5>(A.aq, A.aa, A.ao, A.a13, A.a2, p, lds, (unsigned)(l + 1), l > l0, l + 1 < l1, l == (l1 - l0 > 1 ? l0 + 1 : l0));   // (trace builds: the stamps of the launch's second layer)
     }
 }
 

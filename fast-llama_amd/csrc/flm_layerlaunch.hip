@@ -25,13 +25,13 @@ int plan_layer(flm_ctx* c, int l, bool with_qkv, int G, LayerArgs& A, BackArgs& 
     if (r13 > 1 || r2 > 3) return FLM_ERR_UNSUPPORTED;
     if (G > 1 && (ao.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4) > 1) return FLM_ERR_UNSUPPORTED;
     // a workgroup with a single pass needs one strip buffer: the LDS above the phases' own layouts is the stash
-    auto one_pass = [&](GemvArgs& a, GemvPlan& P, bool two, int rows_per_item = 1) {
+    auto one_pass = [&](GemvArgs& a, GemvPlan& P, bool two, bool norm, int rows_per_item = 1) {
         const int rows = a.items * rows_per_item, npass = (rows + P.Rm - 1) / P.Rm;
-        if (npass <= P.grid) { a.nbuf = 1; P.nbuf = 1; P.lds = (size_t)gemv_lds_layout(a.n, esz, true, P.Rm, 64 >> P.cb_shift, two, 1).total; }
+        if (npass <= P.grid) { a.nbuf = 1; P.nbuf = 1; P.lds = (size_t)gemv_lds_layout(a.n, esz, norm, P.Rm, 64 >> P.cb_shift, two, 1).total; }
     };
-    one_pass(ao, Po, false); one_pass(a13, P13, true); one_pass(a2, P2, false);
+    one_pass(ao, Po, false, false); one_pass(a13, P13, true, true); one_pass(a2, P2, false, false);
     size_t own = Po.lds; if (P13.lds > own) own = P13.lds; if (P2.lds > own) own = P2.lds;
-    if (with_qkv) { one_pass(aq, Pq, false, 2); if (Pq.lds > kLdsMax) return FLM_ERR_UNSUPPORTED; if (c->fuse_token && Pq.lds > own) own = Pq.lds; }   // (k_layers stashes [Wq; Wk; Wv] too: above its layout as well)
+    if (with_qkv) { one_pass(aq, Pq, false, true, 2); if (Pq.lds > kLdsMax) return FLM_ERR_UNSUPPORTED; if (c->fuse_token && Pq.lds > own) own = Pq.lds; }   // (k_layers stashes [Wq; Wk; Wv] too: above its layout as well)
     own = (own + 255) & ~(size_t)255;
     const size_t lds_attn = attn_lds_bytes(d.max_seq_len, c->hs, G > 1);
     if (own > kLdsMax || lds_attn > kLdsMax) return FLM_ERR_UNSUPPORTED;
@@ -52,8 +52,11 @@ int plan_layer(flm_ctx* c, int l, bool with_qkv, int G, LayerArgs& A, BackArgs& 
         p.ao_o = (c->back_ao & 1) && G == 1 && ns_o <= 32 && ao.n < 65536 && epb_o / c->hs + 2 <= 16 ? 1 : 0;
         const int want2 = ns_2 > 32 ? ns_2 - 32 : 0;
         const bool ok2 = (c->back_ao & 2) && want2 <= fit && want2 <= 32 && a2.n < 65536 && epb_2 <= 256 && epb_2 / P13.Rm + 2 <= 16;
-        p.ao_2 = ok2 ? (c->back_ao2 >= 1 && c->back_ao2 <= 3 ? c->back_ao2 : 1) : 0;
+        p.ao_2 = ok2 ? (c->back_ao2 >= 1 && c->back_ao2 <= 3 ? c->back_ao2 : 2) : 0;
         p.nst2_ao = ok2 ? want2 : 0;
+        // one instantiation carries both arrival-order forms (k_layers<.., R5 = 3>) or none: Wo where a head is one workgroup (with split heads Wo stays as it was), FFN2
+        p.r5 = ((G > 1 || p.ao_o) && p.ao_2 && with_qkv) ? 3 : 0;
+        if (!p.r5) { p.ao_o = 0; p.ao_2 = 0; p.nst2_ao = 0; }
     }
     if (kAblate && c->trace_class == 102 && l == 0) { p.trace = c->trace; a13.trace = c->trace + 256 * 16; a2.trace = c->trace + 2 * 256 * 16; }   // tools/trace_back.py
     if (kAblate && c->trace_class == 103) { p.trace = c->trace; if (l == (c->d.n_layers > 1 ? 1 : 0)) { a13.trace = c->trace + 256 * 16; a2.trace = c->trace + 2 * 256 * 16; aa.trace = c->trace + 5 * 4096; } }   // (k_layers: its second layer)

@@ -15,10 +15,11 @@ int layers_prepare(flm_ctx* c, int G) {
     const int L = c->d.n_layers, qt = c->d.quant_type;
     std::vector<LayerArgs> host((size_t)L);
     c->la_ok[key] = false;
+    const std::string err0 = c->err, gerr0 = g_last_error;
     for (int l = 0; l < L; ++l) {
         BackArgs p; int grid = 0, r2 = 0;
         const int r = qt == FLM_QT_INT8 ? plan_layer<QT_INT8>(c, l, true, G, host[l], p, grid, r2) : plan_layer<QT_INT16>(c, l, true, G, host[l], p, grid, r2);
-        if (r == FLM_ERR_UNSUPPORTED) { c->la_valid[key] = true; return FLM_OK; }      // (this shape runs one launch per layer, or per phase)
+        if (r == FLM_ERR_UNSUPPORTED) { c->la_valid[key] = true; c->err = err0; g_last_error = gerr0; return FLM_OK; }      // (this shape runs one launch per layer, or per phase: a probe, not a failure -- flm_last_error keeps what it said)
         if (r) return r;
         c->la_p[key] = p; c->la_grid[key] = grid; c->la_r2[key] = r2;
     }
@@ -38,7 +39,9 @@ int launch_layers(flm_ctx* c, hipStream_t st, int l0, int l1, int G) {
         std::lock_guard<std::mutex> lk(mu);
         if (c->device >= 0 && c->device < 64 && !done[c->device]) {
             const void* fns[] = {(const void*)&k_layers<QT_INT8, 1, false>, (const void*)&k_layers<QT_INT8, 3, false>, (const void*)&k_layers<QT_INT16, 1, false>, (const void*)&k_layers<QT_INT16, 3, false>,
-                                 (const void*)&k_layers<QT_INT8, 1, true>, (const void*)&k_layers<QT_INT8, 3, true>, (const void*)&k_layers<QT_INT16, 1, true>, (const void*)&k_layers<QT_INT16, 3, true>};
+                                 (const void*)&k_layers<QT_INT8, 1, true>, (const void*)&k_layers<QT_INT8, 3, true>, (const void*)&k_layers<QT_INT16, 1, true>, (const void*)&k_layers<QT_INT16, 3, true>,
+                                 (const void*)&k_layers<QT_INT8, 1, false, 3>, (const void*)&k_layers<QT_INT8, 3, false, 3>, (const void*)&k_layers<QT_INT16, 1, false, 3>, (const void*)&k_layers<QT_INT16, 3, false, 3>,
+                                 (const void*)&k_layers<QT_INT8, 1, true, 3>, (const void*)&k_layers<QT_INT8, 3, true, 3>, (const void*)&k_layers<QT_INT16, 1, true, 3>, (const void*)&k_layers<QT_INT16, 3, true, 3>};
             for (const void* f : fns) HIPC(c, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
             done[c->device] = true;
         }
@@ -47,7 +50,7 @@ int launch_layers(flm_ctx* c, hipStream_t st, int l0, int l1, int G) {
     const LayerArgs* LA = (const LayerArgs*)c->la_dev[key];
     const BackArgs p = c->la_p[key];
     const bool i8 = c->d.quant_type == FLM_QT_INT8, one = c->la_r2[key] <= 1;
-#define FLM_LAUNCH_LAYERS(QT, XR2, SP) hipLaunchKernelGGL((k_layers<QT, XR2, SP>), g3, b3, kLdsMax, st, LA, p, l0, l1)
+#define FLM_LAUNCH_LAYERS(QT, XR2, SP) do { if (p.r5) hipLaunchKernelGGL((k_layers<QT, XR2, SP, 3>), g3, b3, kLdsMax, st, LA, p, l0, l1); else hipLaunchKernelGGL((k_layers<QT, XR2, SP, 0>), g3, b3, kLdsMax, st, LA, p, l0, l1); } while (0)
     if (G > 1) { if (i8) { if (one) FLM_LAUNCH_LAYERS(QT_INT8, 1, true); else FLM_LAUNCH_LAYERS(QT_INT8, 3, true); } else { if (one) FLM_LAUNCH_LAYERS(QT_INT16, 1, true); else FLM_LAUNCH_LAYERS(QT_INT16, 3, true); } }
     else       { if (i8) { if (one) FLM_LAUNCH_LAYERS(QT_INT8, 1, false); else FLM_LAUNCH_LAYERS(QT_INT8, 3, false); } else { if (one) FLM_LAUNCH_LAYERS(QT_INT16, 1, false); else FLM_LAUNCH_LAYERS(QT_INT16, 3, false); } }
 #undef FLM_LAUNCH_LAYERS

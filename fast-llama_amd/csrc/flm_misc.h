@@ -3,6 +3,7 @@
 #pragma once
 #include "flm_math.h"
 #include "flm_gemv.h"
+#include "flm_layer.h"
 // (bit-exactness hygiene: see flm_math.h -- no implicit FMA contraction in any of these headers)
 #pragma clang fp contract(off)
 
@@ -191,6 +192,46 @@ inline __global__ void k_op_kv_append(float* q, const float* k, const float* v, 
     rope_pair(k[2 * i], k[2 * i + 1], c[d / 2], s[d / 2], o0, o1);
     float* kp = kc + ((size_t)h * max_seq + pos) * hs + d; kp[0] = o0; kp[1] = o1;
     float* vp = vc + ((size_t)h * max_seq + pos) * hs + d; vp[0] = v[2 * i]; vp[1] = v[2 * i + 1];
+}
+
+// ------------------------------------------------------------------------------------------
+// Hand-off litmus (tests/test_gpu_ops.py::test_handoff_litmus): the EXACT publish / poll / read sequence of layer_body's flag rounds, run `rounds` times by one
+// workgroup per CU, every read checked -- so that a compiler, firmware or memory-model change that reorders it fails a named test, not a token id.
+//   publish : write-through agent-scope stores of the payload (st_agent) -> wait_stores_done (s_waitcnt vmcnt(0)) -> workgroup barrier -> thread 0: relaxed
+//             agent-scope store of the round number into the workgroup's own 64-byte flag line
+//   consume : lane i of the first waves polls line i with relaxed agent-scope loads (poll_lines) -> workgroup barrier -> coherent (sc0 sc1) buffer loads
+// Payload: 64 dwords per (round parity, workgroup), values a hash of (producer, round, index): data-dependent, never repeating.  A workgroup writes round r + 2 into the
+// buffer of round r only after it has seen every line at r + 1, i.e. after every consumer has finished reading round r: two buffers suffice.
+// err[0] = wrong values read, err[1] = a wait timed out.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned litmus_value(unsigned prod, unsigned round, unsigned i) {
+    unsigned h = prod * 0x9E3779B1u ^ round * 0x85EBCA77u ^ i * 0xC2B2AE3Du;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+    return h | 1u;
+}
+inline __global__ void __launch_bounds__(256) k_handoff_litmus(float* payload, unsigned* flags, int rounds, int* err, int* timeout) {
+    const unsigned G = gridDim.x, b = blockIdx.x, tid = threadIdx.x;
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(payload, 0, (int)(2u * G * 64u * 4u), 0x00020000);
+    unsigned bad = 0;
+    for (unsigned r = 1; r <= (unsigned)rounds; ++r) {
+        float* mine = payload + ((size_t)(r & 1u) * G + b) * 64;
+        if (tid < 64) st_agent(mine + tid, __uint_as_float(litmus_value(b, r, tid)));
+        wait_stores_done();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(flags + b * kFlagStride, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        poll_lines(flags, (int)G, r, timeout);
+        __syncthreads();
+        if (__hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        // thread t reads 16 bytes of producer (b + 1 + t / 16 + 16 k) % G, k = 0 .. G / 16: every workgroup reads every producer's whole payload
+        for (unsigned k = 0; k * 16 < G; ++k) {
+            const unsigned prod = (b + 1 + tid / 16 + 16 * k) % G, i0 = (tid & 15) * 4;
+            if (tid / 16 + 16 * k >= G) continue;
+            typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+            const v4u32 v = __builtin_bit_cast(v4u32, __builtin_amdgcn_raw_buffer_load_b128(rp, (int)((((r & 1u) * G + prod) * 64 + i0) * 4), 0, kAuxCoherent));
+            bad += (v.x != litmus_value(prod, r, i0)) + (v.y != litmus_value(prod, r, i0 + 1)) + (v.z != litmus_value(prod, r, i0 + 2)) + (v.w != litmus_value(prod, r, i0 + 3));
+        }
+    }
+    if (bad) atomicAdd(err, (int)bad);
 }
 
 } // namespace flm

@@ -52,6 +52,23 @@ int flm_op_square_sum(const float* x, size_t n, float* out6) {
     return FLM_OK;
 }
 
+// the fused launches' publish / poll / coherent-read sequence, `rounds` times on one 256-thread workgroup per CU (k_handoff_litmus, flm_misc.h)
+int flm_op_handoff_litmus(int rounds, int* wrong_values, int* timed_out) {
+    if (rounds < 1 || !wrong_values || !timed_out) return FLM_ERR_INVALID;
+    int dev = 0; OPC(hipGetDevice(&dev));
+    hipDeviceProp_t pr; OPC(hipGetDeviceProperties(&pr, dev));
+    const int G = pr.multiProcessorCount < 256 ? pr.multiProcessorCount : 256;
+    DevBuf pay, fl, er;
+    if (pay.alloc((size_t)2 * G * 64 * 4) || fl.alloc((size_t)G * 64) || er.alloc(8)) return FLM_ERR_OOM;
+    OPC(hipMemset(pay.p, 0, (size_t)2 * G * 64 * 4)); OPC(hipMemset(fl.p, 0, (size_t)G * 64)); OPC(hipMemset(er.p, 0, 8));
+    hipLaunchKernelGGL(k_handoff_litmus, dim3(G), dim3(256), 0, 0, pay.as<float>(), fl.as<unsigned>(), rounds, er.as<int>(), er.as<int>() + 1);
+    OPC(hipGetLastError()); OPC(hipDeviceSynchronize());
+    int h[2] = {0, 0};
+    OPC(hipMemcpy(h, er.p, 8, hipMemcpyDeviceToHost));
+    *wrong_values = h[0]; *timed_out = h[1];
+    return FLM_OK;
+}
+
 int flm_op_rmsnorm(float* o, const float* x, const float* w, size_t n) {
     if (!o || !x || !w || n % kGroup || n > 16384 || n == 0) return FLM_ERR_INVALID;
     DevBuf dx, dw, dn, dq, ds;

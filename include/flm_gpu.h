@@ -218,6 +218,10 @@ int  flm_op_expf(float* x, size_t n);
 /* elementary fp32 functions as the kernels evaluate them, in place over x[n]:
  * fn 0 expf(x), 1 sqrtf(x), 2 x / y, 3 rmsnorm scale 1/sqrtf(x/n + 1e-5) with n = (int)y[i]. */
 int  flm_op_math(int fn, float* x, const float* y, size_t n);
+/* the hand-off protocol of the fused launches on its own (no reference counterpart: it replaces the reference's thread-pool task barrier,
+ * src/components/threadparallel.hpp, inside one GPU launch): `rounds` publish -> flag -> poll -> coherent-read rounds between one workgroup per CU,
+ * every value read checked.  *wrong_values / *timed_out must both come back 0. */
+int  flm_op_handoff_litmus(int rounds, int* wrong_values, int* timed_out);
 
 /* ---- tensor-parallel shard plan (pure host arithmetic, no GPU needed).
  * Every matmul is split by OUTPUT ROWS, as the reference splits them over its worker threads

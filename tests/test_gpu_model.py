@@ -126,7 +126,7 @@ def test_back_half_of_a_layer_in_one_launch_vs_oracle(gpu, shape, qt, layers):
     variants = ({}, {"fuse_token": 0}, {"tok_preq": 0, "tok_nstq": 0}, {"tok_preq": 5, "tok_nstq": -1}, {"tok_preq": 16, "tok_nstq": 9, "back_nst13": 2, "use_graph": 0}, {"fuse_layer": 0}, {"back_nst13": 0}, {"back_nst13": 3, "fuse_layer": 0}, {"back_nst13": 17, "back_nst13_head": 5}, {"back_nst13_head": -1, "back_nst2": -1},
                 {"back_nst13": 0, "back_nst2": 7, "back_pre13": 1}, {"back_nst13": -1, "back_nst13_head": -1, "back_nst2": -1, "back_pre13": 1, "use_graph": 0},
                 # round 5: the Wo / FFN2 hand-offs consumed in arrival order (GemvCtx::run_ao) -- off, one at a time, every way of requesting W2 around the first look
-                {"back_ao": 0}, {"back_ao": 1}, {"back_ao": 2, "back_ao2": 2}, {"back_ao": 3, "back_ao2": 3}, {"back_ao": 3, "fuse_token": 0}, {"back_ao": 2, "back_ao2": 2, "fuse_layer": 0, "use_graph": 0})
+                {"back_ao": 0}, {"back_ao": 1}, {"back_ao": 2, "back_ao2": 2}, {"back_ao2": 1}, {"back_ao": 3, "back_ao2": 3}, {"back_ao": 3, "fuse_token": 0}, {"back_ao": 2, "back_ao2": 2, "fuse_layer": 0, "use_graph": 0})
     for opts in variants:
         ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
         ctx.set_option("use_prefill", 0)

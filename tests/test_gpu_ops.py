@@ -210,3 +210,12 @@ def test_square_sum_speculative_is_bit_exact(gpu):
         fast, seq, lanes = gpu.op_square_sum(x)
         want = O.square_sum(x)
         assert np.float32(fast).view(np.uint32) == np.float32(want).view(np.uint32) == np.float32(seq).view(np.uint32), (it, n, fast, seq, want)
+
+
+def test_handoff_litmus(gpu):
+    """The fused launches hand activations from workgroup to workgroup INSIDE a launch: write-through stores -> s_waitcnt vmcnt(0) -> relaxed flag store; relaxed polls ->
+    coherent loads (flm_layer.h).  k_handoff_litmus runs exactly that sequence 10^6 times between one workgroup per CU with data-dependent payloads and checks every value
+    read -- a compiler / firmware / memory-model change that reorders it fails here, by name, not as a wrong token id three layers later."""
+    bad, timed_out = gpu.op_handoff_litmus(1_000_000)
+    assert timed_out == 0, "a flag round never completed (workgroups not co-resident?)"
+    assert bad == 0, f"{bad} payload values were read before they were visible"
