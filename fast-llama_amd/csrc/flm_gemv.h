@@ -167,9 +167,13 @@ constexpr int kChainHead = 4;          // lanes whose elements run in order befo
 #else
 #define FLM_CHAIN_STAMP(k)
 #endif
-template <int BVR>
-__device__ __forceinline__ float sq_chain_spec_t(const float* p, const int bshift, int* rounds_out, unsigned long long* tr = nullptr) {
-    const int lane = threadIdx.x & 63, B = BVR ? 4 * BVR : (1 << bshift), BV = B >> 2, LS = B + 4;
+// OP 0: l <- fma(x, x, l) (the rmsnorm sum of squares); OP 1: l <- l + x, x >= 0 (the softmax sum, tf_operators.cpp:180-183: every term is an expf, the argument above holds
+// verbatim -- inside a binade every step adds RN_u(x) whatever multiple of u it started from, exact ties aside).  PAD: floats between two lanes' runs of B elements (4: the
+// staging strips of the prologue; 0: a plain array, element k of lane L at p[L * B + k]).
+template <int OP> __device__ __forceinline__ float chain_step(float l, float x) { if constexpr (OP == 0) return __fmaf_rn(x, x, l); else return __fadd_rn(l, x); }
+template <int BVR, int OP = 0, int PAD = 4>
+__device__ __forceinline__ float chain_spec_t(const float* p, const int bshift, int* rounds_out, unsigned long long* tr = nullptr, const int Brt = 0) {
+    const int lane = threadIdx.x & 63, B = BVR ? 4 * BVR : (Brt ? Brt : (1 << bshift)), BV = B >> 2, LS = B + PAD;      // (Brt: any multiple of 4, LDS-fed form)
     const float4* pl = reinterpret_cast<const float4*>(p + lane * LS);
     float4 xr[BVR ? BVR : 1];
     if constexpr (BVR > 0) {
@@ -178,7 +182,7 @@ __device__ __forceinline__ float sq_chain_spec_t(const float* p, const int bshif
     }
     auto elem = [&](int q) -> float4 { if constexpr (BVR > 0) return xr[q]; else return pl[q]; };
     FLM_CHAIN_STAMP(0)
-#define FLM_SQ4(l, v) l = __fmaf_rn(v.x, v.x, l); l = __fmaf_rn(v.y, v.y, l); l = __fmaf_rn(v.z, v.z, l); l = __fmaf_rn(v.w, v.w, l);
+#define FLM_SQ4(l, v) l = chain_step<OP>(l, v.x); l = chain_step<OP>(l, v.y); l = chain_step<OP>(l, v.z); l = chain_step<OP>(l, v.w);
     // (A lone wave issues one instruction every ~8 shader clocks whatever its kind -- measured in situ: ~900 instructions took 3.3 us -- so what counts below is
     //  the NUMBER of instructions on this wave's path, not their latencies.)
     // 1. approximate per-lane sums; all-zero lanes (every element +-0: pass-through whatever l is)
@@ -265,8 +269,19 @@ __device__ __forceinline__ float sq_chain_spec_t(const float* p, const int bshif
 // (BVR > 0 keeps the lane's elements in registers; inside k_gemv that costs 16+ VGPRs next to the two prefetched weight sets and the
 //  kernel SPILLS -- scratch accesses then queue behind the weight loads in the memory pipeline and the chain took 10 us instead of 2.5:
 //  measured.  The prologue therefore runs the LDS-fed form; the register form is for callers with registers to spare.)
+template <int BVR>
+__device__ __forceinline__ float sq_chain_spec_t(const float* p, const int bshift, int* rounds_out, unsigned long long* tr = nullptr) { return chain_spec_t<BVR, 0, 4>(p, bshift, rounds_out, tr); }
 __device__ __forceinline__ float sq_chain_spec(const float* p, const int bshift, int* rounds_out = nullptr, unsigned long long* tr = nullptr) {
     return sq_chain_spec_t<0>(p, bshift, rounds_out, tr);
+}
+// sum of p[0 .. 64 << bshift) in index order, every element >= +0 (zeros past the data), by one wave: the softmax sum of a long context in a handful of rounds
+// instead of T dependent adds of a lone lane (2.5 us at T = 516)
+__host__ __device__ inline int sum_chain_bshift(int T) { int s = 2; while ((64 << s) < T) ++s; return s; }
+// ... from a padded strip: lane L's B elements (B any multiple of 4) at p[L * (B + 4) ..): conflict-free 16-byte reads
+__device__ __forceinline__ float add_chain_spec_strip(const float* p, const int B) { return chain_spec_t<0, 1, 4>(p, 0, nullptr, nullptr, B); }
+__device__ __forceinline__ float add_chain_spec(const float* p, const int bshift, int* rounds_out = nullptr) {
+    // (the LDS-fed form: the attention's split-head instantiations have no 16 registers to spare for the lane's elements -- the register-fed forms spilled there)
+    return chain_spec_t<0, 1, 0>(p, bshift, rounds_out);
 }
 
 // ------------------------------------------------------------------------------------------
