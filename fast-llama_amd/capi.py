@@ -27,6 +27,9 @@ SYMBOLS = (
 )
 
 
+TUNING_KEYS = ("wg_per_cu", "use_mfma", "tok_preq", "tok_nstq", "back_nst13", "back_nst13_head", "back_nst2", "back_pre13", "back_pre2", "back_ao2")   # csrc/flm_tuning.h
+
+
 class FlmError(RuntimeError):
     pass
 
@@ -169,7 +172,11 @@ class Ctx:
     def sync(self):
         _check(lib().flm_sync(self._h), self._h)
 
-    def set_option(self, key, value):
+    def set_option(self, key, value, unlock=True):
+        """flm_set_option.  The experiment dials (csrc/flm_tuning.h) are not part of the boundary: the library refuses them until option "tuning" is 1 -- the tests and
+        tools that sweep them go through here, which unlocks them first (unlock=False: the raw call, as a deployment would make it)."""
+        if unlock and key in TUNING_KEYS and not self.query("tuning"):
+            _check(lib().flm_set_option(self._h, b"tuning", 1), self._h)
         _check(lib().flm_set_option(self._h, key.encode(), int(value)), self._h)
 
     def query(self, key) -> int:

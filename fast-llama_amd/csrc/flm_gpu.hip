@@ -529,6 +529,9 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
         return fail(c, FLM_ERR_STATE, "set_option: which prompt kernels a tensor-parallel group runs is agreed at flm_p2p_import; set this option on every rank before importing (\"use_prefill\" may be switched later, on every rank alike)");
     if (!c->resident && value != 0 && (k == "fuse_attn_o" || k == "fuse_ffn" || k == "fuse_qkv" || k == "fuse_back" || k == "attn_split"))
         return fail(c, FLM_ERR_UNSUPPORTED, "set_option: this device does not keep one workgroup per CU resident (census at flm_ctx_create); the fused launches stay off");
+    for (const char* tk : kTuningKeys)
+        if (k == tk && !c->tuning) return fail(c, FLM_ERR_INVALID, "set_option: an experiment dial (csrc/flm_tuning.h), not part of the boundary: set option \"tuning\" 1 first");
+    if (k == "tuning") { c->tuning = value != 0; return FLM_OK; }
     if (k == "wg_per_cu") { c->wg_per_cu = value > 0 ? value : 1; }
     else if (k == "use_graph") c->use_graph = value;
     else if (k == "use_prefill") c->use_prefill = value;
@@ -597,7 +600,7 @@ int flm_query(flm_ctx* c, const char* key, int* value) {
     if (!c || !key || !value) return FLM_ERR_INVALID;
     const std::string k(key);
     const struct { const char* k; int v; } tab[] = {
-        {"wg_per_cu", c->wg_per_cu}, {"use_graph", c->use_graph}, {"use_prefill", c->use_prefill}, {"use_mfma", c->use_mfma}, {"use_pv_mfma", c->use_pv_mfma},
+        {"tuning", c->tuning ? 1 : 0}, {"wg_per_cu", c->wg_per_cu}, {"use_graph", c->use_graph}, {"use_prefill", c->use_prefill}, {"use_mfma", c->use_mfma}, {"use_pv_mfma", c->use_pv_mfma},
         {"fuse_attn_o", c->fuse_attn_o}, {"fuse_ffn", c->fuse_ffn}, {"fuse_qkv", c->fuse_qkv}, {"fuse_back", c->fuse_back}, {"fuse_layer", c->fuse_layer}, {"fuse_token", c->fuse_token}, {"tok_nstq", c->tok_nstq}, {"tok_preq", c->tok_preq}, {"back_nst13", c->back_nst13}, {"back_nst13_head", c->back_nst13_head}, {"back_nst2", c->back_nst2}, {"back_pre13", c->back_pre13}, {"back_pre2", c->back_pre2}, {"back_ao", c->back_ao}, {"back_ao2", c->back_ao2}, {"use_prefill_mq", c->use_prefill_mq}, {"attn_split", c->attn_split},
         {"use_qk_mfma", c->use_qk_mfma}, {"use_p2p", c->p2p}, {"fold_xchg", c->fold_xchg}, {"tp_fuse_attn", c->tp_fuse_attn}, {"tp_fuse_ffn", c->tp_fuse_ffn}, {"cu_parts", c->cu_parts}, {"fold_active", (c->world > 1 && c->p2p && c->grp_fold) ? 1 : 0}, {"span_active", (c->world > 1 && c->p2p && c->grp_span) ? 1 : 0}, {"tp_trust_fused", c->tp_trust_fused}, {"force_tp", c->force_tp},
         {"grp_tp_fuse_attn", c->grp_tpfa}, {"grp_tp_fuse_ffn", c->grp_tpff}, {"grp_attn_split", c->grp_split}, {"resident", c->resident}, {"fallback", c->fell_back},

@@ -8,6 +8,7 @@
 #pragma once
 #include "flm_gpu.h"
 #include "flm_kernels.h"
+#include "flm_tuning.h"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -69,6 +70,7 @@ struct flm_ctx {
     int prompt_cap = 0, out_cap = 0;
 
     // options
+    bool tuning = false;                               // option "tuning": the experiment dials (flm_tuning.h) may be set
     int wg_per_cu = 1; int use_graph = 1; int ablate = 0;
     int use_mfma = 1;                                  // option "use_mfma": int8 prefill GEMM tile shape on v_mfma_i32_32x32x32_i8: 1 by size, 2 (0) 64 x 64, 3 128 x 128
     int use_prefill = 1;                               // option "use_prefill": prompts of >= kPrefillMin+1 tokens go through the batched kernels

@@ -9,8 +9,10 @@
 #include <strings.h>
 
 #include <chrono>
+#include <initializer_list>
 #include <iostream>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "engine.h"
@@ -27,6 +29,7 @@ struct Args {
     float topp = 0.9f, temp = 1.0f;
     bool use_numa = false, detail = false, debug = false;
     std::vector<int> devices;
+    const char* bad_devices = nullptr;      // a --devices argument that did not parse
     Mode mode = Mode::GEN;
 };
 const char* Y = "\x1b[33m"; const char* G = "\x1b[32m"; const char* E = "\x1b[0m";
@@ -50,41 +53,61 @@ void usage(const char* bin) {
     fprintf(stderr, "   --help,-h                     print this message\n");
 }
 
-void parse(Args& a, int argc, const char** argv) {      // Arguments::parse (main.cpp:171-244)
+// The flag set is the drop-in surface (the reference's Arguments::parse, main.cpp:171-244, accepts the same spellings); here it is a table: one row per flag with what it
+// stores, so that the two builds' flags can be compared row by row and a new flag is one line.
+namespace {
+bool parse_devices(const char* v, std::vector<int>& out) {      // a comma-separated list of 1 to 8 non-negative ordinals, nothing else
+    out.clear();
+    bool ok = *v != 0;
+    while (ok && *v) {
+        char* e; const long d = strtol(v, &e, 10);
+        ok = e != v && d >= 0 && d < 1024 && (*e == 0 || (*e == ',' && e[1] != 0)) && out.size() < 8;
+        if (ok) { out.push_back((int)d); v = *e ? e + 1 : e; }
+    }
+    return ok;
+}
+template <class E> bool pick(const char* v, std::initializer_list<std::pair<const char*, E>> names, E& out) {     // case-insensitive keyword -> enum; unknown words leave `out` alone (as the reference does)
+    for (const auto& n : names) if (!strcasecmp(v, n.first)) { out = n.second; return true; }
+    return false;
+}
+struct Flag {
+    const char* short_name; const char* long_name; bool takes_value;
+    void (*apply)(Args& a, const char* v);
+};
+const Flag kFlags[] = {
+    {"-j", "--threads",        true,  [](Args& a, const char* v) { a.num_threads = atoi(v); }},
+    {"-q", "--quant",          true,  [](Args& a, const char* v) { pick<int>(v, {{"int16", 1}, {"int8", 2}, {"int4", 3}}, a.qtype); }},
+    {nullptr, "--numa",        false, [](Args& a, const char*) { a.use_numa = true; }},
+    {nullptr, "--uma",         false, [](Args& a, const char*) { a.use_numa = false; }},
+    {nullptr, "--detail",      false, [](Args& a, const char*) { a.detail = true; }},
+    {nullptr, "--debug",       false, [](Args& a, const char*) { a.debug = true; a.detail = true; }},
+    {"-c", "--checkpoint",     true,  [](Args& a, const char* v) { a.ckpt = v; }},
+    {"-z", "--tokenizer",      true,  [](Args& a, const char* v) { a.tknr = v; }},
+    {"-f", "--file-type",      true,  [](Args& a, const char* v) { pick<FileType>(v, {{"flm", FileType::FLM}, {"gguf", FileType::GGUF}, {"llama2c", FileType::LLAMA2C}}, a.ft); }},
+    {"-i", "--prompt",         true,  [](Args& a, const char* v) { a.prompt = v; }},
+    {"-e", "--encode",         true,  [](Args& a, const char* v) { a.encode_str = v; }},
+    {"-d", "--decode",         true,  [](Args& a, const char* v) { a.decode_str = v; }},
+    {"-n", "--max-new-tokens", true,  [](Args& a, const char* v) { a.max_tokens = atoi(v); }},
+    {"-p", "--topp",           true,  [](Args& a, const char* v) { a.topp = (float)atof(v); }},
+    {"-t", "--temperature",    true,  [](Args& a, const char* v) { a.temp = (float)atof(v); }},
+    {nullptr, "--seed",        true,  [](Args& a, const char* v) { a.seed = atoi(v); }},
+    {nullptr, "--rounds",      true,  [](Args& a, const char* v) { a.rounds = atoi(v); }},
+    {"-m", "--mode",           true,  [](Args& a, const char* v) { pick<Mode>(v, {{"gen", Mode::GEN}, {"generate", Mode::GEN}, {"chat", Mode::CHAT}, {"benchmark", Mode::TEST}, {"bm", Mode::TEST}}, a.mode); }},
+    {nullptr, "--device",      true,  [](Args& a, const char* v) { a.device = atoi(v); }},                                  // (this build only)
+    {nullptr, "--devices",     true,  [](Args& a, const char* v) { if (!parse_devices(v, a.devices)) a.bad_devices = v; }},   // (this build only)
+};
+}
+void parse(Args& a, int argc, const char** argv) {
     for (int i = 1; i < argc;) {
         const std::string arg = argv[i++];
-        auto val = [&]() -> const char* { if (i >= argc) { usage(argv[0]); exit(-1); } return argv[i++]; };
-        if (arg == "-j" || arg == "--threads") a.num_threads = atoi(val());
-        else if (arg == "-q" || arg == "--quant") { const char* s = val(); if (!strcasecmp(s, "int16")) a.qtype = 1; else if (!strcasecmp(s, "int8")) a.qtype = 2; else if (!strcasecmp(s, "int4")) a.qtype = 3; }
-        else if (arg == "--numa") a.use_numa = true;
-        else if (arg == "--uma") a.use_numa = false;
-        else if (arg == "--detail") a.detail = true;
-        else if (arg == "-c" || arg == "--checkpoint") a.ckpt = val();
-        else if (arg == "-z" || arg == "--tokenizer") a.tknr = val();
-        else if (arg == "-f" || arg == "--file-type") { const char* v = val(); if (!strcasecmp(v, "flm")) a.ft = FileType::FLM; else if (!strcasecmp(v, "gguf")) a.ft = FileType::GGUF; else if (!strcasecmp(v, "llama2c")) a.ft = FileType::LLAMA2C; }
-        else if (arg == "-i" || arg == "--prompt") a.prompt = val();
-        else if (arg == "-e" || arg == "--encode") a.encode_str = val();
-        else if (arg == "-d" || arg == "--decode") a.decode_str = val();
-        else if (arg == "-n" || arg == "--max-new-tokens") a.max_tokens = atoi(val());
-        else if (arg == "-p" || arg == "--topp") a.topp = (float)atof(val());
-        else if (arg == "-t" || arg == "--temperature") a.temp = (float)atof(val());
-        else if (arg == "--seed") a.seed = atoi(val());
-        else if (arg == "--rounds") a.rounds = atoi(val());
-        else if (arg == "--device") a.device = atoi(val());
-        else if (arg == "--devices") {                       // a comma-separated list of 1 to 8 non-negative ordinals, nothing else
-            const char* v = val(); a.devices.clear();
-            bool ok = *v != 0;
-            while (ok && *v) {
-                char* e; const long d = strtol(v, &e, 10);
-                ok = e != v && d >= 0 && d < 1024 && (*e == 0 || (*e == ',' && e[1] != 0)) && a.devices.size() < 8;
-                if (ok) { a.devices.push_back((int)d); v = *e ? e + 1 : e; }
-            }
-            if (!ok) { fprintf(stderr, "Invalid --devices list:\x1b[31m%s\x1b[0m (expected 1 to 8 HIP device ordinals, e.g. 0,1,2,3)\n", argv[i - 1]); usage(argv[0]); exit(-1); }
-        }
-        else if (arg == "-m" || arg == "--mode") { const char* s = val(); if (!strcasecmp(s, "gen") || !strcasecmp(s, "generate")) a.mode = Mode::GEN; else if (!strcasecmp(s, "chat")) a.mode = Mode::CHAT; else if (!strcasecmp(s, "benchmark") || !strcasecmp(s, "bm")) a.mode = Mode::TEST; }
-        else if (arg == "--debug") { a.debug = true; a.detail = true; }
-        else if (arg == "-h" || arg == "--help") { usage(argv[0]); exit(0); }
-        else { fprintf(stderr, "Unknown argument:\x1b[31m%s\x1b[0m\n", arg.c_str()); usage(argv[0]); exit(-1); }
+        if (arg == "-h" || arg == "--help") { usage(argv[0]); exit(0); }
+        const Flag* hit = nullptr;
+        for (const Flag& f : kFlags) if ((f.short_name && arg == f.short_name) || arg == f.long_name) { hit = &f; break; }
+        if (!hit) { fprintf(stderr, "Unknown argument:\x1b[31m%s\x1b[0m\n", arg.c_str()); usage(argv[0]); exit(-1); }
+        const char* v = nullptr;
+        if (hit->takes_value) { if (i >= argc) { usage(argv[0]); exit(-1); } v = argv[i++]; }
+        hit->apply(a, v);
+        if (a.bad_devices) { fprintf(stderr, "Invalid --devices list:\x1b[31m%s\x1b[0m (expected 1 to 8 HIP device ordinals, e.g. 0,1,2,3)\n", a.bad_devices); usage(argv[0]); exit(-1); }
     }
     if (a.rounds < 1) a.rounds = a.mode == Mode::TEST ? 16 : 1;
 }

@@ -142,47 +142,41 @@ int  flm_kernel_bytes(flm_ctx* ctx, int kclass, int pos, double* bytes);
  * [heads][max_seq][hs], 5 V cache of `layer`, 6 logits. */
 int  flm_debug_read(flm_ctx* ctx, int what, int layer, float* out, size_t n);
 
-/* tuning knobs: "wg_per_cu" workgroups per CU for the GEMV kernels, "use_graph" hipGraph replay on/off,
- * "fuse_attn_o" 0 = attention and the Wo GEMV as two launches (default 1: one launch, single GPU),
- * "fuse_ffn" 0 = FFN13 and FFN2 as two launches (default 1: one launch, single GPU),
- * "fuse_qkv" QKV in the same launch as attention + Wo: 0 never, 1 (default) when a head is spread over several workgroups (contexts
- *            from 128 positions on, where it pays), 2 always (single GPU),
- * "use_prefill" 0 = feed prompts token by token (default 1: batched; under tensor parallelism batched once the peers are mapped with
- * flm_p2p_import, token by token otherwise), "use_prefill_mq" 0 = batched attention with one query per
- * workgroup (default 1: eight), "attn_split" 0 = one workgroup per head at every context length (default 1: hs / 32 from 128 positions on; n >= 2: always n),
- * "use_p2p" 0 = tensor-parallel exchanges by RCCL all-gathers even though the peers are mapped (1: peer to peer again),
- * "fold_xchg" 0 = every peer-to-peer exchange's flag round as a launch of its own (k_xchg); default 1: inside the GEMV launch that consumes the vector
- *             (a sharded layer = 5 launches instead of 9; 3 with "tp_fuse_attn" 2),
- * "tp_fuse_attn" tensor parallel with folded exchanges: 1 = attention and the Wo GEMV in ONE launch across the ranks (every rank's heads raise their flag lines
- *             in every rank's array; a sharded layer = 4 launches), 2 (default) = with the QKV GEMV in front (3 launches), 0 = separate launches,
- * "tp_fuse_ffn" the same for FFN13 + FFN2 (one flag line per rank, raised by the rank's last workgroup; a sharded layer = 2 launches); default 0,
- * "cu_parts" n = confine the context's stream to 1/n of the device's CUs (part rank % n) and size its launches for them: several ranks on ONE GPU (tests),
- * "use_qk_mfma" 0 = prefill attention scores on VALU chains (default 1: v_mfma_f32_16x16x4_f32, the same bits),
- * "use_pv_mfma" 0 = prefill softmax x V on VALU chains (default 1: the weighted sum on v_mfma_f32_16x16x4_f32 too; needs use_qk_mfma),
- * "use_mfma" int8 prefill GEMM tile shape on the matrix cores: 1 (default) by problem size, 2 (or 0) always 64 x 64, 3 always 128 x 128 tiles.
- * "force_tp" 1 = a context created with an RCCL id and world == 1 takes the sharded token path anyway (RCCL exchanges over a 1-rank communicator; tests) -- by default such
- *          a context runs the single-GPU launches,
- * "tp_trust_fused" 1 = between DISTINCT devices too, run the folded exchanges / rank-spanning launches (default: the k_xchg launches; set on every rank before flm_p2p_export),
- * "fuse_back" 0 = attention + Wo and FFN13 + FFN2 as two launches (k_attn_o, k_ffn) instead of one (k_attn_ffn, default 1: [W1; W3] stashed in LDS under the attention),
- * "fuse_layer" 0 = the QKV GEMV as its own launch in front of k_attn_ffn (default 1: the whole decoder layer in one launch),
- * "fuse_token" 0 = one launch per layer (k_attn_ffn) instead of one per token (k_layers, default 1: the layers in a loop inside the launch, the edge between two layers a
- *          flag round); "tok_preq" / "tok_nstq" how many of a workgroup's 16 waves request their first register set of the NEXT layer's [Wq; Wk; Wv] / how many LDS stash
- *          slots it fills with it in front of that flag round (defaults 16, 4: tools/back_bench.py),
- * "back_nst13" / "back_nst13_head" / "back_nst2" LDS stash slots (4.25 KiB each; -1 = as many as the LDS holds) a Wo workgroup fills with [W1; W3] under the attention /
- *          a head workgroup fills behind its head / every workgroup fills with W2 behind its rows of hd; "back_pre13" how many of a workgroup's 16 waves request their
- *          first register set of [W1; W3] in front of the x1 flag round (defaults -1, -1, 0, 16: tools/back_bench.py),
- * None of them changes a result bit.  (Perf-exploration switches that DO skip work -- "ablate", "trace" -- exist only in builds
- * with -DFLM_ABLATE=1; the product library answers FLM_ERR_INVALID to them.) */
+/* Structure switches: which launches a token runs.  None of them changes a result bit; the defaults are what was measured fastest.
+ *   "use_graph"      0 = launches enqueued eagerly (default 1: a token is one hipGraph replay)
+ *   "fuse_attn_o"    0 = attention and the Wo GEMV as two launches (default 1: one launch, single GPU)
+ *   "fuse_ffn"       0 = FFN13 and FFN2 as two launches (default 1)
+ *   "fuse_qkv"       QKV in the same launch as attention + Wo: 0 never, 1 (default) where a head is spread over several workgroups, 2 always
+ *   "fuse_back"      0 = attention + Wo and FFN13 + FFN2 as two launches (k_attn_o, k_ffn) instead of one (k_attn_ffn; default 1)
+ *   "fuse_layer"     0 = the QKV GEMV as its own launch in front of k_attn_ffn (default 1: the whole decoder layer in one launch)
+ *   "fuse_token"     0 = one launch per layer instead of one per token (k_layers; default 1: the edge between two layers is a flag round)
+ *   "back_ao"        0 = inside k_layers, Wo and FFN2 wait for ALL producers of their activation (round 4); default 3: consumed in arrival order (a wave waits
+ *                    for the producers of its own steps' column blocks only)
+ *   "attn_split"     0 = one workgroup per head at every context length (default 1: hs / 32 workgroups per head from 128 positions on; n >= 2: always n)
+ *   "use_prefill"    0 = prompts token by token (default 1: batched; under tensor parallelism once the peers are mapped with flm_p2p_import)
+ *   "use_prefill_mq" 0 = batched attention with one query per workgroup (default 1: eight)
+ *   "use_qk_mfma" / "use_pv_mfma"  0 = prefill scores / softmax x V on VALU chains (default 1: v_mfma_f32_16x16x4_f32, the same bits)
+ * Tensor parallel (set on every rank alike, before flm_p2p_export where noted):
+ *   "use_p2p"        0 = exchanges by RCCL all-gathers although the peers are mapped (1: peer to peer again)
+ *   "fold_xchg"      0 = every peer-to-peer exchange's flag round as a launch of its own (k_xchg); default 1: inside the launch that consumes the vector
+ *   "tp_fuse_attn"   folded exchanges: 1 = attention + Wo in ONE launch across the ranks, 2 (default) = with the QKV GEMV in front, 0 = separate launches
+ *   "tp_fuse_ffn"    the same for FFN13 + FFN2 (default 0)
+ *   "tp_trust_fused" 1 = between DISTINCT devices too, run the folded exchanges / rank-spanning launches (default 0: the k_xchg launches; before flm_p2p_export)
+ *   "cu_parts"       n = confine the context's stream to 1/n of the device's CUs (part rank % n): several ranks on ONE GPU (tests)
+ *   "force_tp"       1 = a context created with an RCCL id and world == 1 takes the sharded token path (RCCL exchanges over a 1-rank communicator; tests)
+ * Not part of the boundary: the experiment dials whose optimum was measured and fixed (stash slots, early register sets, tile shapes: csrc/flm_tuning.h) are refused
+ * until "tuning" 1 has been set; switches that skip work ("ablate", "trace") exist only in -DFLM_ABLATE=1 builds.  Unknown key: FLM_ERR_INVALID. */
 int  flm_set_option(flm_ctx* ctx, const char* key, int value);
 /* What the context actually runs (bench.py reports it; a caller can see that a fused launch was given up).  Keys: every flm_set_option key
- * (its current value), and
+ * (its current value; the dials of csrc/flm_tuning.h too), "tuning", and
  *   "resident"  1 = the census at flm_ctx_create saw one 1024-thread workgroup per CU co-resident (the fused launches wait across workgroups;
  *               0 = they were switched off up front: a masked / partitioned device),
  *   "fallback"  1 = a cross-workgroup wait timed out during some call and the context fell back to one kernel per phase for good (flm_gpu.hip
  *               xwg_check; the call itself was re-run and returned correct results),
  *   "token_path" bit 0 attention + Wo fused, bit 1 FFN13 + FFN2 fused, bit 2 QKV joins the attention's launch at long contexts, bit 3 the same
  *               at every context, bit 6 heads split over workgroups at long contexts, bit 7 attention .. FFN2 in one launch (k_attn_ffn), bit 8 with the QKV GEMV in front
- *               (the whole layer in one launch), bit 9 all layers of the token in one launch (k_layers).
+ *               (the whole layer in one launch), bit 9 all layers of the token in one launch (k_layers),
+ *   "ao_active" which hand-offs of that launch are consumed in arrival order: bit 0 Wo, bit 1 FFN2 (-1: the launch has not been planned yet).
  * Unknown key: FLM_ERR_INVALID. */
 int  flm_query(flm_ctx* ctx, const char* key, int* value);
 

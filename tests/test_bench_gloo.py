@@ -86,3 +86,73 @@ def test_pmc_traffic_refuses_a_summary_whose_kernel_is_not_in_the_library(tmp_pa
     assert got is None and src is None and "stale" in note
     got, src, note = b.pmc_traffic(r"k_ffn<2,", str(tmp_path / "missing.so"))
     assert got is None and "cannot read" in note
+
+
+# ---- the selection of the sharded token's launch structure (bench.run_tp_structures): every structure timed and verified on every rank, the fastest VERIFIED one wins ----
+class _FakeTpCtx:
+    def __init__(self): self.opts = {"tp_trust_fused": 0, "tp_fuse_ffn": 0}; self.tp_info = {}; self.connects = 0
+    def set_option(self, k, v): self.opts[k] = v
+    def query(self, k): return 0
+
+
+def _struct_worker(rank, world, port, q, scenario):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = _FakeTpCtx()
+
+    def fake_connect(capi, c, rank_, world_, device, dist_, torch_, comm_id, first=False):
+        c.connects += 1
+        per_layer = 9 if not c.opts["tp_trust_fused"] else (2 if c.opts["tp_fuse_ffn"] else 3)
+        c.tp_info = {"transport": "p2p", "launches_per_sharded_layer": per_layer, "fold_active": int(per_layer != 9), "tp_fuse_attn": 2, "tp_fuse_ffn": c.opts["tp_fuse_ffn"]}
+
+    def fake_time(c, cfg, args, prompt, barrier, gold):
+        per_layer = c.tp_info["launches_per_sharded_layer"]
+        wall = {9: 0.9, 3: 0.5, 2: 0.4}[per_layer] + 0.01 * rank
+        match = True
+        if scenario == "ffn_structure_mismatches_on_rank1" and per_layer == 2 and rank == 1:
+            match = False
+        if scenario == "fused_raises_on_rank0" and per_layer == 3 and rank == 0:
+            raise RuntimeError("timeout in a folded exchange")
+        return {"wall_s": wall, "p50_ms": wall * 100, "parity": {"match": match, "first_mismatch": None if match else 3}}
+
+    bench.tp_connect, bench.time_decode = fake_connect, fake_time
+    args = type("A", (), {"steps": 10})()
+    m, results = bench.run_tp_structures(None, ctx, None, args, None, lambda: None, [1, 2, 3], rank, world, 0, dist, torch)
+    q.put((rank, None if m is None else m["wall_s"], [(r["name"], r.get("verified"), r.get("ms_per_step")) for r in results], dict(ctx.opts)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_structs(scenario):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_struct_worker, args=(r, 2, port, q, scenario)) for r in range(2)]
+    for p in ps: p.start()
+    res = sorted(q.get(timeout=300) for _ in ps)
+    for p in ps: p.join(timeout=60)
+    return res
+
+
+def test_tp_structure_selection_takes_the_fastest_verified_structure_world2():
+    (r0, w0, res0, o0), (r1, w1, res1, o1) = _run_structs("all_good")
+    assert res0 == res1                                                   # every rank holds the same table (max-over-ranks times, MIN-over-ranks verdicts)
+    assert [v for _, v, _ in res0] == [True, True, True]
+    assert res0[2][2] == round(1000 * 0.41 / 10, 4)                       # the slowest rank's wall time
+    assert abs(w0 - 0.40) < 1e-9 and abs(w1 - 0.41) < 1e-9                # the measurement of the winner: FFN13 + FFN2 across ranks as well
+    assert o0["tp_trust_fused"] == 1 and o0["tp_fuse_ffn"] == 1 and o0 == o1
+
+
+def test_tp_structure_that_mismatches_on_one_rank_is_reported_not_chosen_world2():
+    (r0, w0, res0, o0), (r1, w1, res1, o1) = _run_structs("ffn_structure_mismatches_on_rank1")
+    assert [v for _, v, _ in res0] == [True, True, False] and res0 == res1
+    assert abs(w0 - 0.50) < 1e-9                                          # the folded structure without the rank-spanning FFN launch
+    assert o0["tp_trust_fused"] == 1 and o0["tp_fuse_ffn"] == 0 and o0 == o1     # ... and the group was put back on it
+
+
+def test_tp_structure_that_gives_up_leaves_the_conservative_one_world2():
+    (r0, w0, res0, o0), (r1, w1, res1, o1) = _run_structs("fused_raises_on_rank0")
+    assert [v for _, v, _ in res0] == [True, False] and res0 == res1     # nothing is built on a structure that failed
+    assert abs(w0 - 0.90) < 1e-9 and o0["tp_trust_fused"] == 0 and o0 == o1

@@ -375,6 +375,14 @@ def test_option_and_query_surface(gpu):
         ctx.set_option("cu_parts", 3)                          # 1, 2, 4 or 8
     with pytest.raises(gpu.FlmError):
         ctx.set_option("engine", 1)                            # round 3's engine left the library
+    # the experiment dials (csrc/flm_tuning.h) are not part of the boundary: refused until "tuning" is set
+    assert ctx.query("tuning") == 0
+    for key in gpu.TUNING_KEYS:
+        with pytest.raises(gpu.FlmError):
+            ctx.set_option(key, 1, unlock=False)
+    ctx.set_option("tuning", 1)
+    for key in gpu.TUNING_KEYS:
+        ctx.set_option(key, ctx.query(key), unlock=False)
     ctx.close()
     om = O.OracleModel(cfg, tensors)
     prompt = _prompt(cfg.vocab_size, 4)
