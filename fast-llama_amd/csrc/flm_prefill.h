@@ -319,27 +319,34 @@ __global__ void __launch_bounds__(256, 3) k_gemm_q16_mfma(const GemmArgs a) {
     const int ntt = (a.B + TS - 1) / TS;
     const int nb = gridDim.x, per = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7;              // tiles dealt to the XCDs in contiguous runs (token tile fastest: the tiles that share 64 weight rows are neighbours in the LOGICAL order, and workgroup b runs on XCD b mod 8 with its own L2: weight rows are fetched from HBM once per XCD instead of once per token tile)
     const int tile = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
-    const int r0 = (tile / ntt) * TS, b0 = (tile % ntt) * TS;
+    // EPI_SWIGLU: W = [W1 (gate) ; W3 (up)], a.rows rows each; a tile = 32 rows of W1 (the waves 0, 1) and the SAME 32 rows of W3 (the waves 2, 3): the up halves go
+    // through LDS to the lanes that hold the gate halves, the epilogue is the SwiGLU (no [tokens][2 hidden] round trip, no k_swiglu_rows)
+    constexpr bool TWO = EPI == EPI_SWIGLU;
+    constexpr int TRW = TWO ? TS / 2 : TS;                                                     // rows of (each) matrix per tile
+    const int r0 = (tile / ntt) * TRW, b0 = (tile % ntt) * TS;
     const int sn = a.n / kGroup;
     const unsigned rowbytes = (unsigned)a.n * 2;
     constexpr unsigned kOOB = 0x80000000u;
-    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, (int)((unsigned)a.rows * rowbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, (int)((unsigned)a.rows * (TWO ? 2u : 1u) * rowbytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.Xq), 0, (int)((unsigned)a.B * rowbytes), 0x00020000);
     // loader: piece k of a thread = 16 bytes (8 elements) at (row (tid >> 3) + 32 k, chunk tid & 7) of both matrices
     const int prow = tid >> 3, pch = tid & 7;
     unsigned woff[2], xoff[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        woff[k] = (r0 + prow + 32 * k < a.rows) ? (unsigned)(r0 + prow + 32 * k) * rowbytes + pch * 16 : kOOB;
+        if constexpr (TWO) woff[k] = (r0 + prow < a.rows) ? (unsigned)(k * a.rows + r0 + prow) * rowbytes + pch * 16 : kOOB;      // piece 0: W1's row, piece 1: W3's
+        else woff[k] = (r0 + prow + 32 * k < a.rows) ? (unsigned)(r0 + prow + 32 * k) * rowbytes + pch * 16 : kOOB;
         xoff[k] = (b0 + prow + 32 * k < a.B)    ? (unsigned)(b0 + prow + 32 * k) * rowbytes + pch * 16 : kOOB;
     }
     const unsigned poff = (unsigned)(prow * LS + pch * 8);
     // scales: wave 0 = the weight rows', wave 1 = the tokens' (lane = row of the tile), from the group-major copies (see k_gemm_q8_mfma);
     // waves 2, 3 load nothing
     const bool s_x = wave == 1;
-    const int s_row = (s_x ? b0 : r0) + lane, s_rows = wave < 2 ? (s_x ? a.B : a.rows) : 0;
+    const int s_rows = wave < 2 ? (s_x ? a.B : a.rows * (TWO ? 2 : 1)) : 0;
+    int s_row = (s_x ? b0 : r0) + lane; bool s_ok = s_row < s_rows;
+    if (TWO && !s_x) { s_row = (lane >> 5) * a.rows + r0 + (lane & 31); s_ok = r0 + (lane & 31) < a.rows; }      // (lanes 0..31: W1's rows, 32..63: W3's)
     const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s_x ? a.XsT : a.sWT), 0, (int)((unsigned)s_rows * sn * 4), 0x00020000);
-    unsigned soff = s_row < s_rows ? (unsigned)s_row * 4 : kOOB;
+    unsigned soff = s_ok ? (unsigned)s_row * 4 : kOOB;
     const unsigned spoff = (unsigned)(kOffS + (tid & 127) * 4);
     v4u wr[2], xr[2]; unsigned sr;
     auto fetch = [&](int g) {                     // group g -> the register slot (groups past the end: zero scale, never consumed otherwise)
@@ -400,6 +407,32 @@ __global__ void __launch_bounds__(256, 3) k_gemm_q16_mfma(const GemmArgs a) {
         }
         park((g & 1) ^ 1); fetch(g + 2);          // unconditional: a group past the end is parked and never read with a non-zero scale
         __syncthreads();
+    }
+    if constexpr (EPI == EPI_ROPE_KV) {
+        float accw[1][16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accw[0][i] = acc[i];
+        gemm_epilogue<EPI_ROPE_KV, 1>(a, accw, r0 + wr0 + l31, b0 + wt0, lane);
+        return;
+    }
+    if constexpr (TWO) {
+        // the up halves (waves 2, 3) to the lanes that hold the gate halves of the same (row, tokens): through LDS (the loop's last barrier has passed: the stages are dead)
+        float* xch = reinterpret_cast<float*>(sm);
+        if (wave >= 2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xch[((wave & 1) * 64 + lane) * 17 + i] = acc[i];
+        }
+        __syncthreads();
+        if (wave >= 2) return;
+        const int row = r0 + l31;
+        if (row < a.rows) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int b = b0 + wt0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (b < a.B) st_result_tp(a.out, (size_t)b * a.ldo + row, swiglu_elem(acc[i], xch[((wave & 1) * 64 + lane) * 17 + i]), a.out_peer, a.n_peer);   // o1.swiglu(o3) transformer.cpp:481
+            }
+        }
+        return;
     }
     const int row = r0 + wr0 + l31;
     if (row < a.rows) {

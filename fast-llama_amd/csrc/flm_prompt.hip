@@ -56,7 +56,10 @@ int launch_gemm(flm_ctx* c, hipStream_t st, const GemmArgs& g, int use_mfma) {
         else hipLaunchKernelGGL((k_gemm_q8_mfma<EPI, 2, 2, 1>), dim3(tiles), dim3(Small::NT), Small::kLds, st, g);
         }
     }
-    else if constexpr (EPI == EPI_SWIGLU || EPI == EPI_ROPE_KV) return fail(c, FLM_ERR_INVALID, "launch_gemm: the SwiGLU / RoPE epilogues exist for the int8 matrix-core tiles only");
+    else if constexpr (EPI == EPI_SWIGLU) {   // g.rows = hidden: a tile = 32 rows of W1 and the same rows of W3
+        const int tiles2 = ((g.rows + 31) / 32) * ((g.B + 63) / 64);
+        hipLaunchKernelGGL((k_gemm_q16_mfma<EPI_SWIGLU>), dim3(tiles2), dim3(256), Gemm16Tile::kLds, st, g);
+    }
     else hipLaunchKernelGGL((k_gemm_q16_mfma<EPI>), dim3(tiles), dim3(256), Gemm16Tile::kLds, st, g);   // hi / lo byte planes on the int8 matrix cores
     HIPC(c, hipGetLastError());
     return FLM_OK;
@@ -93,7 +96,7 @@ int prefill_batched(flm_ctx* c, int B, int pos) {
         RowsArgs ra{c->pf_x, w.att_norm, c->pf_xq, c->pf_xs, dim, c->pf_xst};
         r = launch_rows<QT, PRO_RMSNORM_QUANT>(c, st, ra, B, tp); if (r) return r;
         GemmArgs g{w.qkv.q, w.qkv.s, c->pf_xq, c->pf_xs, c->pf_qkv, 3 * dimL, dim, 3 * dimL, B, c->pf_xst, w.qkv.st};
-        if (QT == QT_INT8 && c->use_mfma && dimL % 32 == 0 && hs % 2 == 0) {
+        if ((QT == QT_INT16 || c->use_mfma) && dimL % 32 == 0 && hs % 2 == 0) {      // (int16: always the matrix-core tiles -- round 5: with the same epilogues as the int8 tiles)
             // RoPE and the cache rows as the epilogue of the matrix-core tiles: no [tokens][3 dim] round trip, no k_rope_kv_rows
             g.qout = c->pf_q; g.kcache = c->kcache + (size_t)l * kv_layer; g.vcache = c->vcache + (size_t)l * kv_layer;
             g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.dim = dimL; g.hs = hs; g.max_seq = c->kv_rows /* (the stride between two heads' cache rows) */; g.pos0 = pos;
@@ -146,7 +149,7 @@ int prefill_batched(flm_ctx* c, int B, int pos) {
         // hd = swiglu(W1 qx, W3 qx) with qx = quantize(rmsnorm(x1))   (transformer.cpp:144-147, 468-483): this rank's slice of hd
         RowsArgs rf{c->pf_x, w.ffn_norm, c->pf_xq, c->pf_xs, dim, c->pf_xst};
         r = launch_rows<QT, PRO_RMSNORM_QUANT>(c, st, rf, B, tp); if (r) return r;
-        if (QT == QT_INT8 && c->use_mfma && (tp || c->use_mfma == 3 || (c->use_mfma == 1 && ((hidL + 63) / 64) * ((B + 127) / 128) >= 256))) {
+        if (QT == QT_INT16 || (c->use_mfma && (tp || c->use_mfma == 3 || (c->use_mfma == 1 && ((hidL + 63) / 64) * ((B + 127) / 128) >= 256)))) {
             // 128 x 128 tiles of 64 gate + 64 up rows: the GEMM's epilogue is the SwiGLU
             GemmArgs g13{w.w13.q, w.w13.s, c->pf_xq, c->pf_xs, c->pf_hd + col_h, hid, dim, hidL, B, c->pf_xst, w.w13.st};
             peers(g13, g13.out);

@@ -1,6 +1,9 @@
 #include "engine.h"
 
 #include <stdio.h>
+#include <string.h>
+
+#include <chrono>
 
 #include <iomanip>
 #include <iostream>
@@ -47,14 +50,65 @@ bool GpuTransformer::load(const std::string& ckpt, const std::string& tknr, File
             if (rc != FLM_OK) { _err = std::string("upload: ") + flm_last_error(_ctxs[r]); return false; }
         }
     }
-    if (world > 1) {   // connect the ranks peer to peer: every rank's exchange buffer mapped into every other (ranks of one process share pointers)
-        std::vector<unsigned char> blobs((size_t)world * FLM_P2P_BLOB_BYTES);
-        for (int r = 0; r < world; ++r)
-            if (flm_p2p_export(_ctxs[r], blobs.data() + (size_t)r * FLM_P2P_BLOB_BYTES) != FLM_OK) { _err = std::string("p2p export: ") + flm_last_error(_ctxs[r]); return false; }
-        for (int r = 0; r < world; ++r)
-            if (flm_p2p_import(_ctxs[r], blobs.data(), world) != FLM_OK) { _err = std::string("p2p import: ") + flm_last_error(_ctxs[r]); return false; }
+    if (world > 1) {
+        if (!connect_ranks()) return false;
+        if (!calibrate_structure()) return false;
     }
     return true;
+}
+
+// connect the ranks peer to peer: every rank's exchange buffer mapped into every other (ranks of one process share pointers); also the round at which the group
+// agrees on its launch structure from every rank's options
+bool GpuTransformer::connect_ranks() {
+    const int world = (int)_ctxs.size();
+    std::vector<unsigned char> blobs((size_t)world * FLM_P2P_BLOB_BYTES);
+    for (int r = 0; r < world; ++r)
+        if (flm_p2p_export(_ctxs[r], blobs.data() + (size_t)r * FLM_P2P_BLOB_BYTES) != FLM_OK) { _err = std::string("p2p export: ") + flm_last_error(_ctxs[r]); return false; }
+    for (int r = 0; r < world; ++r)
+        if (flm_p2p_import(_ctxs[r], blobs.data(), world) != FLM_OK) { _err = std::string("p2p import: ") + flm_last_error(_ctxs[r]); return false; }
+    return true;
+}
+
+bool GpuTransformer::calibrate_structure() {
+    struct Cand { const char* name; int trust, ffn; };
+    const Cand cands[] = {{"exchange launches", 0, 0}, {"folded exchanges, QKV + attention + Wo across ranks", 1, 0}, {"folded exchanges, + FFN13 + FFN2 across ranks", 1, 1}};
+    const int world = (int)_ctxs.size(), V = _cfg.vocab_size;
+    auto apply = [&](const Cand& c) {
+        for (int r = 0; r < world; ++r)
+            if (flm_set_option(_ctxs[r], "tp_trust_fused", c.trust) != FLM_OK || flm_set_option(_ctxs[r], "tp_fuse_ffn", c.ffn) != FLM_OK) { _err = std::string("set_option: ") + flm_last_error(_ctxs[r]); return false; }
+        return connect_ranks();
+    };
+    // one token (BOS at position 0) twice on a cleared cache: the first run captures the graphs, the second is timed; rank 0's logits are the verdict
+    auto probe = [&](std::vector<float>& logits, double& us) {
+        std::vector<std::vector<float>> lg(world, std::vector<float>(V));
+        const int32_t tok = 1;
+        for (int rep = 0; rep < 2; ++rep) {
+            if (on_all([&](int r) { return flm_reset_kv(_ctxs[r]); }) != FLM_OK) return false;
+            const auto t0 = std::chrono::steady_clock::now();
+            if (on_all([&](int r) { return flm_forward(_ctxs[r], &tok, 1, 0, lg[r].data()); }) != FLM_OK) return false;
+            us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        }
+        for (int r = 0; r < world; ++r) { int fb = 0; flm_query(_ctxs[r], "fallback", &fb); if (fb) { _err = "a cross-workgroup wait timed out"; return false; } }
+        logits = lg[0];
+        return true;
+    };
+    std::vector<float> want, got;
+    double best_us = 0.0, us = 0.0;
+    int best = 0;
+    if (!probe(want, best_us)) return false;                    // the conservative structure must work
+    for (int i = 1; i < 3; ++i) {
+        if (!apply(cands[i])) break;
+        if (!probe(got, us) || memcmp(got.data(), want.data(), (size_t)V * 4) != 0) {
+            if (_debug) fprintf(stderr, "tensor parallel: structure \"%s\" dropped (%s)\n", cands[i].name, _err.empty() ? "logits differ from the conservative structure's" : _err.c_str());
+            _err.clear();
+            break;                                               // (nothing is built on a structure that failed)
+        }
+        if (_debug) fprintf(stderr, "tensor parallel: structure \"%s\": %.1f us per token against %.1f\n", cands[i].name, us, best_us);
+        if (us < best_us) { best_us = us; best = i; }
+    }
+    if (!apply(cands[best])) return false;
+    _tp_structure = cands[best].name;
+    return on_all([&](int r) { return flm_reset_kv(_ctxs[r]); }) == FLM_OK;
 }
 
 std::vector<int> GpuTransformer::encode(const char* prompt) const {

@@ -32,7 +32,15 @@ public:
     bool generate(const char* prompt, const std::function<bool(const char*, int, int, bool)>& cb, int max_new_tokens, float temperature, float topp);
     int get_quant_type() const { return _cfg.quant_type; }
     const std::string& error() const { return _err; }
+    // more than one device: which launch structure of the sharded token load() settled on (calibrate_structure), for --detail
+    const std::string& tp_structure() const { return _tp_structure; }
 private:
+    // Sharded over several devices: time ONE token under the conservative launch structure (exchange flag rounds as launches of their own between distinct devices), then
+    // under each faster one ("tp_trust_fused" 1; + "tp_fuse_ffn" 1), and keep the fastest whose logits are the conservative structure's bit for bit -- nothing is trusted
+    // that was not verified on THIS machine; a structure that gives up or differs is dropped and the group put back.
+    bool connect_ranks();
+    bool calibrate_structure();
+    std::string _tp_structure;
     bool _debug;
     Config _cfg;
     Tokenizer _tok;
