@@ -319,14 +319,23 @@ __device__ __forceinline__ void gemv_preload(const GemvArgs& a, float4 (&xv)[XR 
 // One quantizer round of a 16-lane row: the lane owns elements e .. e+3, 16 consecutive lanes own one 64-group (quant::quantize, quant_operators.cpp:26-47:
 // scale = max|x| / F, q = (T)(x / scale)); the packed values go to xq[e ..], the group's scale to xs[e / 64].  Every lane of the row must call it (the group
 // maximum is a DPP butterfly); `act` = the lane's elements exist.
+#ifndef FLM_QUANT_SHARED_RCP
+#define FLM_QUANT_SHARED_RCP 1          // the four divisions of a quantizer round share the refined reciprocal of the group's scale (flm_math.h: quant_elems4); 0: four IEEE divisions
+#endif
 template <int QT>
 __device__ __forceinline__ void quant_round4(char* xq, float* xs, int e, bool act, const float4& v) {
     using T = QTraits<QT>;
     // group max over the 16 lanes that share this 64-element group (order-free, exact)
     const float mx = row16_max(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     const float sc = __fdiv_rn(mx, T::kF);           // scale = max|x| / F
+    int qq[4];
+#if FLM_QUANT_SHARED_RCP
+    quant_elems4(v, sc, qq);                          // (every lane: the range check is a ballot)
+#else
+    qq[0] = quant_elem(v.x, sc); qq[1] = quant_elem(v.y, sc); qq[2] = quant_elem(v.z, sc); qq[3] = quant_elem(v.w, sc);
+#endif
     if (act) {
-        const int q0 = quant_elem(v.x, sc), q1 = quant_elem(v.y, sc), q2 = quant_elem(v.z, sc), q3 = quant_elem(v.w, sc);
+        const int q0 = qq[0], q1 = qq[1], q2 = qq[2], q3 = qq[3];
         if constexpr (QT == QT_INT8) {
             const uint32_t pk = (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
             *reinterpret_cast<uint32_t*>(xq + e) = pk;

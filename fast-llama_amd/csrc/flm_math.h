@@ -154,6 +154,29 @@ __device__ __forceinline__ int quant_elem(float x, float r) {
     float t = __fdiv_rn(x, r);          // IEEE-correct fp32 divide, never the fast reciprocal
     return (r == 0.0f) ? 0 : (int)t;    // v_cvt_i32_f32 truncates toward zero
 }
+// The same element step for FOUR elements that share one scale, with the divisions' common part computed once.  x / r as the compiler lowers an IEEE fp32 division is
+// div_scale (x2), v_rcp_f32, two FMAs that refine the reciprocal, a multiply, four FMAs, div_fmas, div_fixup: 11 instructions, one of them quarter-rate, per element --
+// most of the quantizer round that every workgroup runs on every prologue's critical path.  When neither operand needs scaling (div_scale returns its input, div_fmas is a
+// plain FMA, div_fixup passes the result through) the sequence is  y0 = rcp(r); y = fma(fma(-r, y0, 1), y0, y0);  q0 = x y; q1 = fma(fma(-r, q0, x), y, q0);
+// q = fma(fma(-r, q1, x), y, q1)  -- and y depends on r only.  That holds for r in [2^-100, 2^100] (checked for the whole wave: otherwise everybody takes quant_elem) and
+// |x| >= r (the quotient lies in [1, 128 F]: exponents 0 .. 13 apart); |x| < r gives a quotient below 1, i.e. 0 after the truncation, whatever its bits (and NaN -> 0 as
+// v_cvt_i32_f32 does).  Precondition (the quantizer's: x belongs to the group whose maximum made r): |x| <= ~F r.  Same instructions on the same values = the same bits: tests/test_gpu_ops.py::test_quantize_shared_reciprocal_equals_ieee_division.
+__device__ __forceinline__ void quant_elems4(const float4& v, float r, int (&q)[4]) {
+    const unsigned re = __float_as_uint(r) & 0x7f800000u;
+    const bool safe = re >= (27u << 23) && re <= (227u << 23);
+    if (__ballot(!safe) != 0ull) { q[0] = quant_elem(v.x, r); q[1] = quant_elem(v.y, r); q[2] = quant_elem(v.z, r); q[3] = quant_elem(v.w, r); return; }
+    const float y0 = __builtin_amdgcn_rcpf(r);
+    const float y = __fmaf_rn(__fmaf_rn(-r, y0, 1.0f), y0, y0);
+    const float xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x = xs[i];
+        const float q0 = __fmul_rn(x, y);
+        const float q1 = __fmaf_rn(__fmaf_rn(-r, q0, x), y, q0);
+        const float t = __fmaf_rn(__fmaf_rn(-r, q1, x), y, q1);
+        q[i] = fabsf(x) >= r ? (int)t : 0;
+    }
+}
 // simd::rmsnorm scale (src/platforms/arch/x86_simd.cpp:1754-1756): r = float(1. / sqrtf(ss/n + 1e-5f))
 __device__ __forceinline__ float rms_scale(float ss, int n) {
     float v = __fadd_rn(__fdiv_rn(ss, (float)n), 1e-5f);

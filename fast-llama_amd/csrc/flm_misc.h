@@ -171,10 +171,16 @@ inline __global__ void __launch_bounds__(64) k_op_sum_chain(float* out, const fl
 inline __global__ void k_op_swiglu(float* xo, const float* xr, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) xo[i] = swiglu_elem(xo[i], xr[i]);
 }
-// elementary functions as the kernels evaluate them: fn 0 expf_ref(x), 1 sqrtf(x), 2 x / y, 3 rms_scale(x, n = (int)y)
+// elementary functions as the kernels evaluate them: fn 0 expf_ref(x), 1 sqrtf(x), 2 x / y, 3 rms_scale(x, n = (int)y), 4 / 5 the quantizer's element step (below)
 inline __global__ void k_op_math(int fn, float* x, const float* y, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float v = x[i];
+        if (fn == 4 || fn == 5) {      // the quantizer's element step, x = value, y = the group's scale: 4 through quant_elems4 (shared reciprocal), 5 through quant_elem (IEEE division)
+            int q[4]; const float4 v4 = make_float4(v, -v, v, v);
+            if (fn == 4) quant_elems4(v4, y[i], q); else { q[0] = quant_elem(v, y[i]); q[1] = quant_elem(-v, y[i]); }
+            x[i] = (float)(q[0] - 1024 * q[1]);                      // (both signs in one number: |q| <= 127 F fits)
+            continue;
+        }
         x[i] = fn == 0 ? expf_ref(v) : fn == 1 ? __builtin_sqrtf(v) : fn == 2 ? __fdiv_rn(v, y[i]) : rms_scale(v, (int)y[i]);
     }
 }

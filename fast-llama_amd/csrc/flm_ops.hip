@@ -212,7 +212,7 @@ int flm_op_attention(float* out, float* kc, float* vc, const float* q, const flo
 
 /* elementary functions exactly as the kernels evaluate them (tests pin them against the host's IEEE results) */
 int flm_op_math(int fn, float* x, const float* y, size_t n) {
-    if (!x || n == 0 || fn < 0 || fn > 3 || (fn >= 2 && !y)) return FLM_ERR_INVALID;
+    if (!x || n == 0 || fn < 0 || fn > 5 || (fn >= 2 && !y)) return FLM_ERR_INVALID;
     DevBuf d, e; if (d.alloc(n * 4) || e.alloc(n * 4)) return FLM_ERR_OOM;
     OPC(hipMemcpy(d.p, x, n * 4, hipMemcpyHostToDevice));
     if (y) OPC(hipMemcpy(e.p, y, n * 4, hipMemcpyHostToDevice));

@@ -213,7 +213,9 @@ int  flm_op_attention(float* out, float* kc, float* vc, const float* q, const fl
  * in place over n floats.  Lets the tests pin the device routine against glibc bit for bit. */
 int  flm_op_expf(float* x, size_t n);
 /* elementary fp32 functions as the kernels evaluate them, in place over x[n]:
- * fn 0 expf(x), 1 sqrtf(x), 2 x / y, 3 rmsnorm scale 1/sqrtf(x/n + 1e-5) with n = (int)y[i]. */
+ * fn 0 expf(x), 1 sqrtf(x), 2 x / y, 3 rmsnorm scale 1/sqrtf(x/n + 1e-5) with n = (int)y[i],
+ * 4 / 5 quant::quantize's element step q(x) = (T)(x / y) (quant_operators.cpp:26-47) the way the prologues evaluate it (4: the group's four divisions share one refined
+ *       reciprocal) and as a plain IEEE division (5): x[i] <- q(x) - 1024 q(-x); the two must agree on every input. */
 int  flm_op_math(int fn, float* x, const float* y, size_t n);
 /* the hand-off protocol of the fused launches on its own (no reference counterpart: it replaces the reference's thread-pool task barrier,
  * src/components/threadparallel.hpp, inside one GPU launch): `rounds` publish -> flag -> poll -> coherent-read rounds between one workgroup per CU,

@@ -241,3 +241,30 @@ def test_softmax_sum_speculative_is_bit_exact(gpu):
         fast, seq, rounds = gpu.op_sum_chain(x)
         assert np.float32(seq).view(np.uint32) == want.view(np.uint32), (name, seq, want)
         assert np.float32(fast).view(np.uint32) == want.view(np.uint32), (name, fast, want, rounds)
+
+
+def test_quantize_shared_reciprocal_equals_ieee_division(gpu):
+    """quant_elems4 (flm_math.h): the four divisions x / scale of a quantizer round share the refined reciprocal of the scale -- the instructions an IEEE fp32 division is lowered
+    to, minus the operand scaling that does nothing in the range the fast path accepts.  Against quant_elem (the plain IEEE division) on 10^8 pairs: quotients ON and one ulp
+    off every truncation boundary k = 0 .. 127 (int8) and around 5792 (int16), random quotients, scales from 2^-126 to 2^126 (beyond 2^+-100 the wave takes the plain
+    division), denormals, zeros, infinities."""
+    rng = np.random.default_rng(5)
+    n = 1 << 22
+    for rep in range(24):
+        e = rng.integers(-126, 127, n) if rep % 4 == 3 else rng.integers(-40, 40, n)
+        sc = (rng.random(n, dtype=np.float32) + np.float32(1.0)) * np.exp2(e).astype(np.float32)
+        if rep % 3 == 0:      # on and around the boundaries: x = fl(k sc) nudged by -2 .. +2 ulps
+            k = rng.integers(0, 129 if rep % 2 else 5795, n).astype(np.float32)
+            x = (k * sc).astype(np.float32)
+            x = (x.view(np.int32) + rng.integers(-2, 3, n).astype(np.int32)).view(np.float32)
+        elif rep % 3 == 1:    # random quotients in (-130, 130) / (-5800, 5800)
+            x = ((rng.random(n, dtype=np.float32) * 2 - 1) * np.float32(130 if rep % 2 else 5800) * sc).astype(np.float32)
+        else:                 # anything: tiny, huge, denormal, zero
+            x = (rng.standard_normal(n).astype(np.float32) * np.exp2(rng.integers(-149, 120, n)).astype(np.float32))
+            x = np.clip(x, -8000 * sc, 8000 * sc).astype(np.float32)      # (the quantizer's precondition: |x| <= the group's maximum = F scale)
+            x[::97] = 0.0; sc[::101] = 0.0; x[::103] = np.float32(1e-42)
+        x = np.where(np.isfinite(x), x, np.float32(1.0)).astype(np.float32)
+        fast = gpu.op_math(4, x, sc)
+        ieee = gpu.op_math(5, x, sc)
+        bad = np.nonzero(fast.view(np.uint32) != ieee.view(np.uint32))[0]
+        assert bad.size == 0, (rep, bad.size, x[bad[:4]], sc[bad[:4]], fast[bad[:4]], ieee[bad[:4]])
