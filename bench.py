@@ -520,6 +520,11 @@ def main():
                       "launches_per_token_short_context": ((1 if tpath & 512 and kt.get("layers", (0.0, 0))[1] > 0 else cfg.n_layers * (1 if tpath & 256 else 2 if tpath & 128 else 3)) + 3)}
     except Exception as e:  # noqa: BLE001
         token_path = {"error": str(e)}
+    try:
+        ao_active = ctx.query("ao_active")
+        token_path["wo_and_ffn2_consumed_in_arrival_order"] = ao_active == 3
+    except Exception:  # noqa: BLE001
+        ao_active = 0
     ctx_tp_info = getattr(ctx, "tp_info", None) or {}
     kernels = {k: {"us": round(v[0], 2), "per_token": v[1], "GBps": round(ctx.kernel_bytes(k, mid_pos) / (v[0] * 1e-6) / 1e9, 1) if v[0] > 0 else 0.0}
                for k, v in kt.items() if v[1] > 0}
@@ -563,7 +568,9 @@ def main():
 
     qn = 2 if qt == ff.QT_INT8 else 1
     split_now = bool(token_path.get("heads_split_at_long_contexts")) and mid_pos + 1 >= 128      # (the launch's SPLIT instantiation: a head spread over hs / 32 workgroups)
-    dom_regex = {"layers": rf"k_layers<{qn}, \d+, {'true' if split_now else 'false'}>", "layer": rf"k_attn_ffn<{qn}, \d+, true, false>", "back": rf"k_attn_ffn<{qn}, \d+, false, false>", "ffn": rf"k_ffn<{qn},"}.get(dom, rf"k_gemv<{qn}, 2, 2,")
+    # (round 5: k_layers<QT, XR2, SPLIT, R5>, R5 = 3 where the launch consumes Wo's / FFN2's activation in arrival order -- the instantiation this run launched, not just any in the library)
+    r5_now = 3 if (dom == "layers" and ao_active > 0) else 0
+    dom_regex = {"layers": rf"k_layers<{qn}, \d+, {'true' if split_now else 'false'}, {r5_now}>", "layer": rf"k_attn_ffn<{qn}, \d+, true, false>", "back": rf"k_attn_ffn<{qn}, \d+, false, false>", "ffn": rf"k_ffn<{qn},"}.get(dom, rf"k_gemv<{qn}, 2, 2,")
     if args.shape == "7B":
         traffic, traffic_src, traffic_note = pmc_traffic(dom_regex, capi.LIB_PATH)
     else:   # (the committed PMC summaries were collected on the 7B-shaped model: a launch of the same kernel on another shape moves other bytes)

@@ -1,11 +1,11 @@
 #!/bin/bash
 # HBM traffic per launch of the TOKEN's kernels on the full 32-layer model: two separate rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass;
-# --kernel-trace only beside them) over a short bench.py run; writes gpurun_out/pmc/pmc_fetch_write_raw.json  (k_layers = all 32 layers in one launch: its counters are a whole
+# --kernel-trace only beside them) over bench.py with the driver's --steps 20 --warmup 5; writes gpurun_out/pmc/pmc_fetch_write_raw.json  (k_layers = all 32 layers in one launch: its counters are a whole
 # token's layers)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pmc; mkdir -p gpurun_out/pmc
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/pmc/$ctr -o run -- python bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-config5 > gpurun_out/pmc/$ctr.log 2>&1
+  timeout 900 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/pmc/$ctr -o run -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-config5 > gpurun_out/pmc/$ctr.log 2>&1
 done
 python3 tools/pmc_agg.py gpurun_out/pmc/FETCH_SIZE gpurun_out/pmc/WRITE_SIZE > gpurun_out/pmc/pmc_fetch_write_raw.json
 rm -rf gpurun_out/pmc/FETCH_SIZE gpurun_out/pmc/WRITE_SIZE
