@@ -1,4 +1,4 @@
-"""hand-off stress: long greedy decodes on a 7B-width model with the fused launches (k_attn_o, k_qkv_attn_o, k_ffn, split heads) against one launch per phase;
+"""hand-off stress: long greedy decodes on a 7B-width model with the fused launches (k_layers with the arrival-order and the round-4 hand-offs, k_attn_ffn, k_attn_o, k_qkv_attn_o, k_ffn, split heads) against one launch per phase;
 any stale cross-workgroup read changes the token ids.  python tools/stress.py [layers] [tokens] [reps]"""
 import sys, os
 sys.path.insert(0, os.getcwd())
@@ -15,7 +15,7 @@ for qt, name in ((ff.QT_INT8, "int8"), (ff.QT_INT16, "int16")):
     prompt = (np.arange(1, 9, dtype=np.int64) * 7919 % cfg.vocab_size).astype(np.int32)
     ref = None
     base = {"fuse_attn_o": 0, "fuse_ffn": 0, "attn_split": 0, "fuse_back": 0}
-    for opts in (base, {}, {"use_graph": 0}, {"fuse_token": 0}, {"tok_preq": 7, "tok_nstq": 11}, {"fuse_layer": 0}, {"fuse_back": 0}, {"back_nst13_head": 0, "back_pre13": 5}, {"back_nst2": 9, "back_pre2": 3}, {"fuse_attn_o": 0}, {"attn_split": 0}, {"fuse_back": 0, "fuse_qkv": 2}):
+    for opts in (base, {}, {"use_graph": 0}, {"fuse_token": 0}, {"tok_preq": 7, "tok_nstq": 11}, {"fuse_layer": 0}, {"fuse_back": 0}, {"back_nst13_head": 0, "back_pre13": 5}, {"back_nst2": 9, "back_pre2": 3}, {"back_ao": 0}, {"back_ao2": 1}, {"back_ao2": 3, "tok_preq": 3}, {"fuse_attn_o": 0}, {"attn_split": 0}, {"fuse_back": 0, "fuse_qkv": 2}):
         ctx = capi.Ctx(capi.desc_from_config(cfg)); ctx.upload_all(tensors)
         for k, v in opts.items(): ctx.set_option(k, v)
         for r in range(reps if opts is not base else 1):
