@@ -23,7 +23,7 @@ SYMBOLS = (
     "flm_forward", "flm_forward_argmax", "flm_decode_greedy", "flm_decode_timed", "flm_decode_timed_each", "flm_last_tokens", "flm_reset_kv", "flm_sync",
     "flm_kernel_times", "flm_kernel_bytes", "flm_set_option", "flm_query", "flm_debug_read",
     "flm_op_quantize", "flm_op_matmul_q", "flm_op_rmsnorm", "flm_op_swiglu", "flm_op_rope", "flm_op_softmax",
-    "flm_op_attention", "flm_op_expf", "flm_op_math", "flm_op_square_sum", "flm_op_argmax", "flm_op_handoff_litmus", "flm_op_sum_chain", "flm_plan_shards",
+    "flm_op_attention", "flm_op_expf", "flm_op_math", "flm_op_square_sum", "flm_op_argmax", "flm_op_handoff_litmus", "flm_plan_shards",
 )
 
 
@@ -224,14 +224,6 @@ def op_argmax(logits) -> int:
     idx = C.c_int32(-1)
     _check(lib().flm_op_argmax(_p(a), int(a.size), C.byref(idx)))
     return idx.value
-
-
-def op_sum_chain(x):
-    """(speculative wave evaluation, sequential adds, rounds) of the softmax sum of x >= 0"""
-    x = np.ascontiguousarray(x, dtype=np.float32)
-    o = np.zeros(3, dtype=np.float32)
-    _check(lib().flm_op_sum_chain(_p(x), C.c_size_t(x.size), _p(o)))
-    return o[0], o[1], int(o[2])
 
 
 def op_handoff_litmus(rounds):

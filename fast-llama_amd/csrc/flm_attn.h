@@ -44,9 +44,6 @@ struct AttnArgs {
     float* out_peer[7]; int n_peer;
 };
 
-#ifndef FLM_SPEC_SUM
-#define FLM_SPEC_SUM 0        // split heads: from this many positions on the softmax sum is evaluated by one wave (add_chain_spec_strip); 0: always a lone lane's T dependent adds
-#endif
 #ifndef FLM_V_LATE_NS
 #define FLM_V_LATE_NS 1
 #endif
@@ -330,24 +327,9 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
     float m = red[0];
 #pragma unroll
     for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
-    // the sum of a long context: one wave evaluates the sequential chain exactly in a handful of rounds (add_chain_spec_strip, flm_gemv.h: all terms are >= +0) from a
-    // padded strip in the tile area (the K tiles are dead, V is parked there behind the divide): lane L owns the terms [L B, L B + B), B = 4 ceil(T / 256), zeros past T.
-    // A lone lane's T dependent adds cost ~10 clocks each, the wave ~4000 clocks whatever T: from FLM_SPEC_SUM positions on (split heads only: the strip's place).
-    const int sB = 4 * ((T + 255) >> 8);
-    const bool spec_sum = SPLIT && FLM_SPEC_SUM > 0 && T >= FLM_SPEC_SUM;
-    if (spec_sum) {
-        for (int t = tid; t < 64 * sB; t += kAttnBlock) {
-            const float e = t < T ? expf_ref(__fsub_rn(sc[t], m), etab) : 0.f;
-            if (t < T) sc[t] = e;
-            const int L = t / sB;
-            tile0[L * (sB + 4) + (t - L * sB)] = e;
-        }
-    } else { for (int t = tid; t < T; t += kAttnBlock) sc[t] = expf_ref(__fsub_rn(sc[t], m), etab); }
+    for (int t = tid; t < T; t += kAttnBlock) sc[t] = expf_ref(__fsub_rn(sc[t], m), etab);
     __syncthreads();
     stamp(2);
-    if (spec_sum) {
-        if (wave == 0) { const float l = add_chain_spec_strip(tile0, sB); if (lane == 0) red[16] = l; }
-    } else
     if (tid == 0) {                                                // sum += x[i], i ascending (tf_operators.cpp:180-183)
         // a lone lane: the loop is the T dependent adds plus one LDS read per four of them, reads 28 adds ahead
         float sum = 0.f;

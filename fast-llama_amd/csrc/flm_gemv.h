@@ -167,9 +167,8 @@ constexpr int kChainHead = 4;          // lanes whose elements run in order befo
 #else
 #define FLM_CHAIN_STAMP(k)
 #endif
-// OP 0: l <- fma(x, x, l) (the rmsnorm sum of squares); OP 1: l <- l + x, x >= 0 (the softmax sum, tf_operators.cpp:180-183: every term is an expf, the argument above holds
-// verbatim -- inside a binade every step adds RN_u(x) whatever multiple of u it started from, exact ties aside).  PAD: floats between two lanes' runs of B elements (4: the
-// staging strips of the prologue; 0: a plain array, element k of lane L at p[L * B + k]).
+// OP 0: l <- fma(x, x, l) (the rmsnorm sum of squares); OP 1: l <- l + x, x >= 0 (any chain of non-negative terms: the argument above holds verbatim; round 5 evaluated the
+// long-context softmax sum this way -- exact, and slower than the lone lane there: tools/experiments/r5_handoffs/spec_softmax_sum.*).  PAD: floats between two lanes' runs of B elements.
 template <int OP> __device__ __forceinline__ float chain_step(float l, float x) { if constexpr (OP == 0) return __fmaf_rn(x, x, l); else return __fadd_rn(l, x); }
 template <int BVR, int OP = 0, int PAD = 4>
 __device__ __forceinline__ float chain_spec_t(const float* p, const int bshift, int* rounds_out, unsigned long long* tr = nullptr, const int Brt = 0) {
@@ -273,15 +272,6 @@ template <int BVR>
 __device__ __forceinline__ float sq_chain_spec_t(const float* p, const int bshift, int* rounds_out, unsigned long long* tr = nullptr) { return chain_spec_t<BVR, 0, 4>(p, bshift, rounds_out, tr); }
 __device__ __forceinline__ float sq_chain_spec(const float* p, const int bshift, int* rounds_out = nullptr, unsigned long long* tr = nullptr) {
     return sq_chain_spec_t<0>(p, bshift, rounds_out, tr);
-}
-// sum of p[0 .. 64 << bshift) in index order, every element >= +0 (zeros past the data), by one wave: the softmax sum of a long context in a handful of rounds
-// instead of T dependent adds of a lone lane (2.5 us at T = 516)
-__host__ __device__ inline int sum_chain_bshift(int T) { int s = 2; while ((64 << s) < T) ++s; return s; }
-// ... from a padded strip: lane L's B elements (B any multiple of 4) at p[L * (B + 4) ..): conflict-free 16-byte reads
-__device__ __forceinline__ float add_chain_spec_strip(const float* p, const int B) { return chain_spec_t<0, 1, 4>(p, 0, nullptr, nullptr, B); }
-__device__ __forceinline__ float add_chain_spec(const float* p, const int bshift, int* rounds_out = nullptr) {
-    // (the LDS-fed form: the attention's split-head instantiations have no 16 registers to spare for the lane's elements -- the register-fed forms spilled there)
-    return chain_spec_t<0, 1, 0>(p, bshift, rounds_out);
 }
 
 // ------------------------------------------------------------------------------------------

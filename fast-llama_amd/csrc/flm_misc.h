@@ -154,20 +154,6 @@ inline __global__ void __launch_bounds__(256) k_op_square_sum(float* out, const 
         out[2] = red[0]; out[3] = red[1]; out[4] = red[2]; out[5] = red[3];
     }
 }
-// the softmax sum both ways: out[0] add_chain_spec (one wave, a handful of rounds), out[1] the plain sequential adds, out[2] the rounds (-1: it fell back to the plain chain)
-inline __global__ void __launch_bounds__(64) k_op_sum_chain(float* out, const float* x, int n) {
-    extern __shared__ float sm[];
-    const int bs = sum_chain_bshift(n), TS = 64 << bs;
-    for (int i = threadIdx.x; i < TS; i += 64) sm[i] = i < n ? x[i] : 0.f;
-    __syncthreads();
-    int its = 0;
-    const float l = add_chain_spec(sm, bs, &its);
-    if (threadIdx.x == 0) {
-        float s = 0.f;
-        for (int i = 0; i < n; ++i) s = __fadd_rn(s, sm[i]);
-        out[0] = l; out[1] = s; out[2] = (float)its;
-    }
-}
 inline __global__ void k_op_swiglu(float* xo, const float* xr, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) xo[i] = swiglu_elem(xo[i], xr[i]);
 }

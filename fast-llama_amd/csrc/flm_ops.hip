@@ -69,19 +69,6 @@ int flm_op_handoff_litmus(int rounds, int* wrong_values, int* timed_out) {
     return FLM_OK;
 }
 
-// softmax_sisd's sum (tf_operators.cpp:180-183) of x[n] >= +0, n <= 4096: out3 = { speculative wave evaluation (add_chain_spec), sequential adds, rounds }
-int flm_op_sum_chain(const float* x, size_t n, float* out3) {
-    if (!x || !out3 || n == 0 || n > 4096) return FLM_ERR_INVALID;
-    DevBuf dx, dout;
-    if (dx.alloc(n * 4) || dout.alloc(16)) return FLM_ERR_OOM;
-    OPC(hipMemcpy(dx.p, x, n * 4, hipMemcpyHostToDevice));
-    const size_t lds = (size_t)(64 << sum_chain_bshift((int)n)) * 4;
-    hipLaunchKernelGGL(k_op_sum_chain, dim3(1), dim3(64), lds, 0, dout.as<float>(), dx.as<float>(), (int)n);
-    OPC(hipGetLastError()); OPC(hipDeviceSynchronize());
-    OPC(hipMemcpy(out3, dout.p, 12, hipMemcpyDeviceToHost));
-    return FLM_OK;
-}
-
 int flm_op_rmsnorm(float* o, const float* x, const float* w, size_t n) {
     if (!o || !x || !w || n % kGroup || n > 16384 || n == 0) return FLM_ERR_INVALID;
     DevBuf dx, dw, dn, dq, ds;

@@ -193,9 +193,6 @@ int  flm_op_rmsnorm(float* o, const float* x, const float* w, size_t n);
 /* simd::square_sum (x86_simd.cpp:942-960), n % 16 == 0, n <= 16384: out6 = { total from the speculative wave evaluation the
  * rmsnorm prologue uses, total from the plain sequential chains, the 4 strided partial sums }; the two totals must be the same bits */
 int  flm_op_square_sum(const float* x, size_t n, float* out6);
-/* softmax_sisd's sequential sum (src/blas/tf_operators.cpp:180-183) of x[n] >= +0, n <= 4096, the way the long-context attention evaluates it:
- * out3 = { one wave's speculative evaluation, the plain sequential adds, rounds taken (-1: plain chain) } -- [0] and [1] must be the same bits */
-int  flm_op_sum_chain(const float* x, size_t n, float* out3);
 /* sample_argmax (sampler.cpp:36-47): first maximum wins */
 int  flm_op_argmax(const float* logits, int n, int32_t* idx);
 /* simd::swiglu(xo,xr,n) (x86_simd.cpp:1766-1770) */
