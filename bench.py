@@ -508,7 +508,7 @@ def main():
     # per-kernel times, live, HIP events on the ctx stream (eager launches, same kernels as the graph)
     kt = ctx.kernel_times(mid_pos, iters=3)
     # the dominant launch of the token: the fused FFN13 + FFN2 kernel where the token path runs it (single GPU), else FFN13
-    dom = next((k for k in ("layers", "layer", "back", "ffn") if kt.get(k, (0.0, 0))[1] > 0), "ffn13")
+    dom = next((k for k in ("token", "layers", "layer", "back", "ffn") if kt.get(k, (0.0, 0))[1] > 0), "ffn13")
     dom_us, dom_cnt = kt[dom]
     dom_bytes = ctx.kernel_bytes(dom, mid_pos)
     achieved = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
@@ -517,7 +517,8 @@ def main():
         token_path = {"resident": bool(ctx.query("resident")), "fell_back_after_timeout": bool(ctx.query("fallback")),
                       "attn_wo_fused": bool(tpath & 1), "ffn_fused": bool(tpath & 2), "qkv_joins_at_long_contexts": bool(tpath & 4),
                       "heads_split_at_long_contexts": bool(tpath & 64), "attention_to_ffn2_in_one_launch": bool(tpath & 128), "whole_layer_in_one_launch": bool(tpath & 256), "all_layers_in_one_launch": bool(tpath & 512) and kt.get("layers", (0.0, 0))[1] > 0,
-                      "launches_per_token_short_context": ((1 if tpath & 512 and kt.get("layers", (0.0, 0))[1] > 0 else cfg.n_layers * (1 if tpath & 256 else 2 if tpath & 128 else 3)) + 3)}
+                      "whole_greedy_token_in_one_launch": bool(tpath & 1024) and kt.get("token", (0.0, 0))[1] > 0,
+                      "launches_per_token_short_context": (1 if (tpath & 1024 and kt.get("token", (0.0, 0))[1] > 0) else (1 if tpath & 512 and kt.get("layers", (0.0, 0))[1] > 0 else cfg.n_layers * (1 if tpath & 256 else 2 if tpath & 128 else 3)) + 3)}
     except Exception as e:  # noqa: BLE001
         token_path = {"error": str(e)}
     try:
@@ -569,14 +570,16 @@ def main():
     qn = 2 if qt == ff.QT_INT8 else 1
     split_now = bool(token_path.get("heads_split_at_long_contexts")) and mid_pos + 1 >= 128      # (the launch's SPLIT instantiation: a head spread over hs / 32 workgroups)
     # (round 5: k_layers<QT, XR2, SPLIT, R5>, R5 = 3 where the launch consumes Wo's / FFN2's activation in arrival order -- the instantiation this run launched, not just any in the library)
-    r5_now = 3 if (dom == "layers" and ao_active > 0) else 0
-    dom_regex = {"layers": rf"k_layers<{qn}, \d+, {'true' if split_now else 'false'}, {r5_now}>", "layer": rf"k_attn_ffn<{qn}, \d+, true, false>", "back": rf"k_attn_ffn<{qn}, \d+, false, false>", "ffn": rf"k_ffn<{qn},"}.get(dom, rf"k_gemv<{qn}, 2, 2,")
+    r5_now = 3 if (dom in ("layers", "token") and ao_active > 0) else 0
+    dom_regex = {"token": rf"k_layers<{qn}, \d+, {'true' if split_now else 'false'}, 3, true>", "layers": rf"k_layers<{qn}, \d+, {'true' if split_now else 'false'}, {r5_now}, false>", "layer": rf"k_attn_ffn<{qn}, \d+, true, false>", "back": rf"k_attn_ffn<{qn}, \d+, false, false>", "ffn": rf"k_ffn<{qn},"}.get(dom, rf"k_gemv<{qn}, 2, 2,")
     if args.shape == "7B":
         traffic, traffic_src, traffic_note = pmc_traffic(dom_regex, capi.LIB_PATH)
     else:   # (the committed PMC summaries were collected on the 7B-shaped model: a launch of the same kernel on another shape moves other bytes)
         traffic, traffic_src, traffic_note = None, None, "PMC summaries under profiles/ are of the LLaMA2-7B shape"
 
-    dom_name = {"layers": f"k_layers<{args.quant}> (ALL {cfg.n_layers} decoder layers of the token in one launch: per layer QKV + RoPE, attention, Wo + residual, FFN13 + SwiGLU, FFN2 + residual; "
+    dom_name = {"token": f"k_layers<{args.quant}, TAIL> (the WHOLE greedy token in one launch: the embedding row read by the first layer, ALL {cfg.n_layers} decoder layers -- per layer QKV + RoPE, attention, "
+                         f"Wo + residual, FFN13 + SwiGLU, FFN2 + residual --, final norm + classifier, argmax + state advance; every edge a flag round)",
+                "layers": f"k_layers<{args.quant}> (ALL {cfg.n_layers} decoder layers of the token in one launch: per layer QKV + RoPE, attention, Wo + residual, FFN13 + SwiGLU, FFN2 + residual; "
                           f"the edges between phases and between layers are flag rounds)",
                 "layer": f"k_attn_ffn<{args.quant}, QKV> (the whole decoder layer in one launch: QKV + RoPE, attention, Wo + residual, FFN13 + SwiGLU, FFN2 + residual)",
                 "back": f"k_attn_ffn<{args.quant}> (attention, Wo + residual, FFN13 + SwiGLU, FFN2 + residual in one launch)",
@@ -604,11 +607,13 @@ def main():
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
                          "bytes_per_launch": int(dom_bytes), "avg_launch_us": round(dom_us, 2), "launches_per_token": dom_cnt,
-                         **({"layers_per_launch": cfg.n_layers, "us_per_layer": round(dom_us / cfg.n_layers, 2)} if dom == "layers" else {})},
+                         **({"layers_per_launch": cfg.n_layers, "us_per_layer": round(dom_us / cfg.n_layers, 2)} if dom == "layers" else {}),
+                         **({"layers_per_launch": cfg.n_layers, "layers_alone_us": round(kt.get("layers", (0.0, 0))[0], 2), "us_per_layer": round(kt.get("layers", (0.0, 0))[0] / cfg.n_layers, 2),
+                             "note": "the whole greedy token is this one launch: bytes = the layers' + the classifier's + the embedding row; `layers_alone_us` = the same layers as a launch of their own (k_layers<.., TAIL = false>)"} if dom == "token" else {})},
             "token_path": token_path,
             "kernels": kernels,
-            "kernels_note": "us per launch, back-to-back launches of one class between one pair of HIP events; on a single GPU the token runs `layers` (k_layers: all L decoder "
-                            "layers in ONE launch) where it is listed: per token = embed + layers + cls + argmax; else `layer` (k_attn_ffn: one launch per layer; timed beside it); else attn_wo (k_attn_o) instead of attn + attn_o and ffn "
+            "kernels_note": "us per launch, back-to-back launches of one class between one pair of HIP events; on a single GPU a greedy token runs `token` (k_layers<.., TAIL>: embedding row, all L decoder "
+                            "layers, classifier, argmax in ONE launch) where it is listed; else `layers` (k_layers: all L decoder layers in one launch): per token = embed + layers + cls + argmax; else `layer` (k_attn_ffn: one launch per layer; timed beside it); else attn_wo (k_attn_o) instead of attn + attn_o and ffn "
                             "(k_ffn) instead of ffn13 + ffn2, and where qkv_attn_wo (k_qkv_attn_o: contexts from 128 positions on) is listed, that instead of qkv + attn_wo; the "
                             "per-phase classes (qkv .. ffn2) are timed beside them for reference",
         }

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FLM_GPU_LIB") or os.path.join(_HERE, "lib", "libflm_gpu.so")   # FLM_GPU_LIB: tools/variants.sh builds
 
 QT_NONE, QT_INT16, QT_INT8 = 0, 1, 2
-KCLASSES = ("embed", "qkv", "attn", "attn_o", "ffn13", "ffn2", "cls", "argmax", "allreduce", "attn_wo", "ffn", "qkv_attn_wo", "layer", "back", "layers")   # from "attn_wo" on: the fused launches of the single-GPU token path ("layer": k_attn_ffn, the whole decoder layer in one launch; "back": the same without the QKV GEMV; "layers": k_layers, all layers of the token in one launch)
+KCLASSES = ("embed", "qkv", "attn", "attn_o", "ffn13", "ffn2", "cls", "argmax", "allreduce", "attn_wo", "ffn", "qkv_attn_wo", "layer", "back", "layers", "token")   # from "attn_wo" on: the fused launches of the single-GPU token path ("layer": k_attn_ffn, the whole decoder layer in one launch; "back": the same without the QKV GEMV; "layers": k_layers, all layers of the token in one launch; "token": k_layers<.., TAIL>, the whole greedy token in one launch)
 
 # every symbol include/flm_gpu.h declares (tests check the library exports all of them)
 SYMBOLS = (

@@ -81,7 +81,8 @@ constexpr int kSplitDims = 32, kSplitMaxSeq = 1024, kSplitVRegs = kSplitMaxSeq *
 // thread whose piece it is.  The arithmetic is untouched.
 struct AttnNoMid { __device__ __forceinline__ void operator()() const {} };
 template <int NF, bool COH, bool SPLIT = false, bool PRE = false, class Mid = AttnNoMid>
-__device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow, const int g = 0, const int G = 1, Mid&& mid = Mid()) {
+__device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow, const int g = 0, const int G = 1, Mid&& mid = Mid(), const unsigned epoch_arg = 0u) {
+    const unsigned xepoch = epoch_arg ? epoch_arg : a.epoch;      // what the parts of a split head raise / wait for in their score exchange
     typedef float v4f __attribute__((ext_vector_type(4)));
     constexpr int D = SPLIT ? 4 : kAttnDepth;         // K ring depth
     constexpr int DV = SPLIT ? 1 : kAttnDepth;        // V ring depth (SPLIT: unused, the slice sits in vall)
@@ -279,13 +280,13 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
         // exchange: my scores are in memory -> raise my line; wait for the other parts' lines; fetch their scores
         wait_stores_done();
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(a.flag_sc + (h * G + g) * 16, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(a.flag_sc + (h * G + g) * 16, xepoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid < 64) {
             const bool mine = tid < G;
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             while (true) {
-                const unsigned f = mine ? __hip_atomic_load(a.flag_sc + (h * G + tid) * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.epoch;
-                if (__all(f >= a.epoch)) break;
+                const unsigned f = mine ? __hip_atomic_load(a.flag_sc + (h * G + tid) * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : xepoch;
+                if (__all((int)(f - xepoch) >= 0)) break;
                 if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) { __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             }
         }
@@ -557,11 +558,12 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
 // SPLIT is a template argument of the kernels (not a run-time branch inside one kernel): the two forms keep different things in
 // registers, and compiled into one function they spilled a 16-byte register -- behind an s_waitcnt vmcnt(0) on the whole prefetch
 template <bool COH, bool SPLIT, bool PRE = false, class Mid = AttnNoMid>
-__device__ __forceinline__ void attn_head_any(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow, const int g = 0, const int G = 1, Mid&& mid = Mid()) {
+// epoch: the value the parts of a split head raise / wait for in their score exchange (0: a.epoch; k_layers passes the layer's flag target, which counts from the token's epoch base)
+__device__ __forceinline__ void attn_head_any(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow, const int g = 0, const int G = 1, Mid&& mid = Mid(), const unsigned epoch = 0u) {
     if constexpr (SPLIT) {      // the host picks G = hs / kSplitDims (attn_parts): every part owns 32 output dimensions; hs <= 128
-        if (a.hs <= 64) attn_head<1, COH, true, PRE>(a, h, lds, T, qrow, orow, g, G, mid); else attn_head<2, COH, true, PRE>(a, h, lds, T, qrow, orow, g, G, mid);
+        if (a.hs <= 64) attn_head<1, COH, true, PRE>(a, h, lds, T, qrow, orow, g, G, mid, epoch); else attn_head<2, COH, true, PRE>(a, h, lds, T, qrow, orow, g, G, mid, epoch);
     } else {
-        if (a.hs <= 64) attn_head<1, COH, false, PRE>(a, h, lds, T, qrow, orow, 0, 1, mid); else if (a.hs <= 128) attn_head<2, COH, false, PRE>(a, h, lds, T, qrow, orow, 0, 1, mid); else attn_head<4, COH, false, PRE>(a, h, lds, T, qrow, orow, 0, 1, mid);
+        if (a.hs <= 64) attn_head<1, COH, false, PRE>(a, h, lds, T, qrow, orow, 0, 1, mid, epoch); else if (a.hs <= 128) attn_head<2, COH, false, PRE>(a, h, lds, T, qrow, orow, 0, 1, mid, epoch); else attn_head<4, COH, false, PRE>(a, h, lds, T, qrow, orow, 0, 1, mid, epoch);
     }
 }
 // batched prefill: workgroup (h, i) is query i of the batch, at position pos0 + i, over the cache rows 0 .. pos0 + i

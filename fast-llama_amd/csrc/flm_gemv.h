@@ -286,12 +286,13 @@ __device__ __forceinline__ float sq_chain_spec(const float* p, const int bshift,
 // issued behind 32 HBM weight loads would make the whole prologue wait for them.
 // ------------------------------------------------------------------------------------------
 // COH: the activation was written by other workgroups of the SAME kernel (k_attn_o) -> coherent sc0|sc1 loads
+// xsrc: the activation comes from there instead of a.x (k_layers' first layer of a token: the embedding row, transformer.cpp:115-122)
 template <int QT, int PRO, int XR, bool COH = false>
-__device__ __forceinline__ void gemv_preload(const GemvArgs& a, float4 (&xv)[XR > 0 ? XR : 1], float4 (&wv)[XR > 0 ? XR : 1]) {
+__device__ __forceinline__ void gemv_preload(const GemvArgs& a, float4 (&xv)[XR > 0 ? XR : 1], float4 (&wv)[XR > 0 ? XR : 1], const float* xsrc = nullptr) {
     if constexpr (PRO == PRO_QUANT || PRO == PRO_RMSNORM_QUANT) {
         // branch-free: raw buffer loads, elements past n read as zero
         typedef float v4f __attribute__((ext_vector_type(4)));
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.n * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xsrc ? xsrc : a.x), 0, a.n * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(PRO == PRO_RMSNORM_QUANT ? a.norm_w : a.x), 0, a.n * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < XR; ++i) {
@@ -572,6 +573,7 @@ struct GemvCtx {
     __amdgpu_buffer_rsrc_t rW, rS;
     Set setA, setB;
     bool stored;                                                               // this wave wrote results to global memory
+    const float* resid_src;                                                    // EPI_RESIDUAL: the old value of out[row] is read from resid_src[row] instead (null: out itself)
 
     static __device__ __forceinline__ u32 inv_of(u32 d) { return d > 1 ? 0xFFFFFFFFu / d + 1u : 0u; }
     static __device__ __forceinline__ u32 udiv(u32 x, u32 d, u32 inv) { return d > 1 ? __umulhi(x, inv) : x; }
@@ -622,7 +624,7 @@ struct GemvCtx {
         const u32 NM = TWO ? 2u : 1u;
         rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, (int)(NM * TRm * rowbytes), kRsrcFlags);
         rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.sW), 0, (int)(NM * TRm * sn * 4), kRsrcFlags);
-        stored = false; primedA = primedB = false;
+        stored = false; primedA = primedB = false; resid_src = nullptr;
         // the first two steps of every wave are fixed (wave, wave + 16): they are requested before any barrier (the stash's steps are the next numbers)
         if (write_ctr && threadIdx.x == 0) *reinterpret_cast<u32*>(lds + ctr_off) = 2 * kWavesPerBlock;
     }
@@ -730,7 +732,7 @@ struct GemvCtx {
         float resid = 0.f, rc = 0.f, rs = 0.f;
         const u32 row = pass * Rm + lane;                                      // row inside its matrix
         const bool rv = chain_wave && lane < Rm && row < TRm;
-        if constexpr (EPI == EPI_RESIDUAL) { if (rv) resid = ld_agent(a.out + row); }
+        if constexpr (EPI == EPI_RESIDUAL) { if (rv) resid = ld_agent((resid_src ? resid_src : a.out) + row); }
         if constexpr (EPI == EPI_ROPE_KV) {
             if (rv && row < (u32)(a.dim + a.kv_dim)) {
                 const u32 r2 = (row < (u32)a.dim ? row : row - a.dim) & ~1u;

@@ -34,7 +34,7 @@ struct LayerW {
     unsigned got = 0;     // bitmask of uploaded kinds
 };
 
-enum KClass { KC_EMBED = 0, KC_QKV, KC_ATTN, KC_ATTN_O, KC_FFN13, KC_FFN2, KC_CLS, KC_ARGMAX, KC_ALLREDUCE, KC_ATTN_WO /* k_attn_o: attention + Wo */, KC_FFN /* k_ffn: FFN13 + FFN2 */, KC_QKV_ATTN_WO /* k_qkv_attn_o */, KC_LAYER /* k_attn_ffn with the QKV GEMV in front: the whole layer */, KC_BACK /* k_attn_ffn: attention + Wo + FFN13 + FFN2 */, KC_LAYERS /* k_layers: all layers of the token in one launch */ };
+enum KClass { KC_EMBED = 0, KC_QKV, KC_ATTN, KC_ATTN_O, KC_FFN13, KC_FFN2, KC_CLS, KC_ARGMAX, KC_ALLREDUCE, KC_ATTN_WO /* k_attn_o: attention + Wo */, KC_FFN /* k_ffn: FFN13 + FFN2 */, KC_QKV_ATTN_WO /* k_qkv_attn_o */, KC_LAYER /* k_attn_ffn with the QKV GEMV in front: the whole layer */, KC_BACK /* k_attn_ffn: attention + Wo + FFN13 + FFN2 */, KC_LAYERS /* k_layers: all layers of the token in one launch */, KC_TOKEN /* k_layers<.., TAIL>: the whole greedy token in one launch */ };
 
 struct TimedLaunch { int kclass; hipEvent_t e0, e1; };
 // owners that release on every exit path (the error macros return from the middle of a function)
@@ -93,6 +93,9 @@ struct flm_ctx {
     int fuse_token = 1;                                // option "fuse_token": ALL layers of a token in one launch (k_layers: the edge between two layers is a flag round in front of which [Wq; Wk; Wv] streams)
     int tok_nstq = 4, tok_preq = 16;                   // options "tok_nstq" / "tok_preq": its stash slots / early waves of [Wq; Wk; Wv]
     void* la_dev[2] = {nullptr, nullptr}; bool la_valid[2] = {false, false}, la_ok[2] = {false, false}; flm::BackArgs la_p[2]; int la_grid[2] = {0, 0}, la_r2[2] = {0, 0};   // k_layers' argument blocks (flm_layers.hip)
+    int fuse_tail = 1;                                 // option "fuse_tail": a greedy decode token is ONE launch (k_layers<.., TAIL>: embedding row, all layers, classifier, argmax + state advance); fp32 embedding tables
+    void* tail_dev[2] = {nullptr, nullptr}; bool tail_ok[2] = {false, false};   // its argument block per head split (flm_layers.hip)
+    unsigned* tail_mem = nullptr;                      // [0] the epoch base of the one-launch token's flag values, [16 ..) one flag line per classifier workgroup, then their argmax slots
     int fuse_layer = 1;                                // option "fuse_layer": ... with the QKV GEMV in front: the whole layer in one launch
     int back_nst13 = -1, back_nst13_head = -1, back_nst2 = 0, back_pre13 = 16, back_pre2 = 16;   // options "back_*": k_attn_ffn's stash slots (-1: as many as the LDS holds) and early register set (flm_layer.h)
     int back_ao = 3, back_ao2 = 2;                     // options "back_ao" (bit 0: Wo, bit 1: FFN2 consume their activation in arrival order, GemvCtx::run_ao) / "back_ao2" (what of W2 is requested in front of the first look)
@@ -213,7 +216,7 @@ void set_fold(flm_ctx* c, GemvArgs& a, int l, int kind);
 int launch_layer(flm_ctx* c, hipStream_t st, int qt, int l, bool with_qkv, int G = 1);
 // all layers of a token in one launch (flm_layers.hip): the argument blocks are built outside any capture
 int layers_prepare(flm_ctx* c, int G);
-int launch_layers(flm_ctx* c, hipStream_t st, int l0, int l1, int G);   // G: workgroups per head (attn_parts)
+int launch_layers(flm_ctx* c, hipStream_t st, int l0, int l1, int G, bool tail = false);   // G: workgroups per head (attn_parts); tail: the whole greedy token (FLM_ERR_UNSUPPORTED where that launch does not exist)
 // one activation exchange between the tensor-parallel ranks (flm_token.hip)
 enum XKind { XK_ATT = 0, XK_X1 = 1, XK_HD = 2, XK_LOGITS = 3 };
 int exchange(flm_ctx* c, hipStream_t st, int kind, float* full, float* mine, int count);

@@ -113,8 +113,10 @@ __device__ __forceinline__ void poll_lines(const unsigned* flag, int n, unsigned
 // R5 (round 5; compile time, so that an instantiation carries one form of every hand-off -- both forms in one kernel spill): bit 0 Wo consumes the heads' output in arrival
 // order (GemvCtx::run_ao; one workgroup per head), bit 1 FFN2 consumes hd in arrival order.  The host picks the instantiation whose forms the shape allows (plan_layer: BackArgs::r5).
 template <int QT, int XR2, bool QKV, bool SPLIT, bool PERSIST, int R5 = 0>
+// x0 (k_layers' one-launch token, first layer): the layer's input is read from there -- the embedding row -- by the QKV prologue and by Wo's residual epilogue instead of the residual
+// stream's buffer (which Wo's rows then start); null: the buffer.
 __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& aa, const GemvArgs& ao, const GemvArgs& a13, const GemvArgs& a2, const BackArgs& p, char* lds,
-                                           const unsigned target, const bool xpoll, const bool xflag, const bool tracing) {
+                                           const unsigned target, const bool xpoll, const bool xflag, const bool tracing, const float* x0 = nullptr) {
     auto nostamp = [](int) {};
     auto stamp = [&](int k) { if (kAblate && tracing && p.trace && threadIdx.x == 0) p.trace[blockIdx.x * 16 + k] = __builtin_amdgcn_s_memrealtime(); };
     stamp(0);
@@ -123,7 +125,7 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
         if ((int)blockIdx.x < p.gridq) {
             GemvCtx<QT, EPI_ROPE_KV, PERSIST> gq;
             float4 xq[1], nq[1];
-            if (!PERSIST || !xpoll) gemv_preload<QT, PRO_RMSNORM_QUANT, 1, PERSIST>(aq, xq, nq);    // (x is there: requested in front of the context's set-up)
+            if (!PERSIST || !xpoll) gemv_preload<QT, PRO_RMSNORM_QUANT, 1, PERSIST>(aq, xq, nq, x0);    // (x is there: requested in front of the context's set-up)
             gq.init(aq, blockIdx.x, p.gridq, lds, 0, p.st_base, (PERSIST && xpoll) ? (unsigned)p.nstq : 0u);
             if constexpr (PERSIST) {
                 if (xpoll) {
@@ -165,7 +167,7 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
             }
             __syncthreads();
         };
-        if constexpr (QKV) attn_head_any<true, SPLIT, true>(aa, hh, lds, *aa.pos_ptr + 1, aa.q, aa.out, blockIdx.x % G, G, qwait);
+        if constexpr (QKV) attn_head_any<true, SPLIT, true>(aa, hh, lds, *aa.pos_ptr + 1, aa.q, aa.out, blockIdx.x % G, G, qwait, target);
         else attn_head_any<false, SPLIT>(aa, hh, lds, *aa.pos_ptr + 1, aa.q, aa.out, blockIdx.x % G, G);
         stamp(1);
         wait_stores_done();                                                     // every wave: its part of the head's output is where the others will read it
@@ -188,6 +190,7 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
     } else {
         GemvCtx<QT, EPI_RESIDUAL> g;
         g.init(ao, blockIdx.x - p.n_heads, p.grido, lds);
+        g.resid_src = x0;
         g.issue(kAblate ? ao.ablate : 0);
         if (p.nst13 > 0 && (int)blockIdx.x < p.grid13) {
             nst13 = (unsigned)p.nst13;
@@ -297,15 +300,99 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_attn_ffn(const GemvArgs aq, c
 // in front of which the next layer's [Wq; Wk; Wv] starts to stream (preq waves' first register sets + nstq stash slots: the LDS is empty there).
 // ------------------------------------------------------------------------------------------
 struct LayerArgs { GemvArgs aq, ao, a13, a2; AttnArgs aa; };
-template <int QT, int XR2, bool SPLIT, int R5 = 0>
-__global__ void __launch_bounds__(kGemvBlock, 4) k_layers(const LayerArgs* __restrict__ LA, const BackArgs p, const int l0, const int l1) {
+// TAIL (round 5): the WHOLE token in this launch -- the embedding row is the first layer's input (read where it is: transformer.cpp:115-122), the classifier (final rmsnorm, quantize,
+// rows of the output matrix: transformer.cpp:154-160) is a phase behind the last layer's x flag round like the QKV phase of a layer (its first register sets and stash slots requested in
+// front of that round), and the greedy argmax (first maximum wins, sampler.cpp:36-47) + the decode state's advance close it: every classifier workgroup leaves the best of its own rows
+// in a slot and raises a line, workgroup 0 waits for all of them and picks.  Nobody clears the flag lines between tokens (k_embed did): every target of the launch counts from an epoch
+// base in device memory that the launch's last act moves on by L + 2 -- stale lines are always below.  fp32 embedding tables only (the host checks).
+struct TailArgs {
+    GemvArgs acls;              // the classifier GEMV (EPI_STORE into the logits)
+    const float* emb; const int* tok_ptr; int dim, vocab;
+    unsigned* epoch;            // the launch's flag values count from *epoch (>= 4096: above anything k_embed-era launches leave in a line)
+    unsigned* flag_cls;         // one line per classifier workgroup
+    float* slots;               // [gridc][2] { best logit, its row (as bits) } of a workgroup's rows
+    int gridc;
+    DecodeState* st; int* out_tokens; int out_cap;
+};
+template <int QT>
+__device__ __forceinline__ void tail_phase(const TailArgs& T, const BackArgs& p, char* lds, const unsigned xtarget, const unsigned ctarget, const unsigned next_epoch) {
+    auto nostamp = [](int) {};
+    if ((int)blockIdx.x < T.gridc) {
+        const GemvArgs& a = T.acls;
+        GemvCtx<QT, EPI_STORE, true> gc;
+        gc.init(a, blockIdx.x, T.gridc, lds, 0, p.st_base, (unsigned)p.nstq);
+        if ((int)gc.wave < p.preq) gc.issue(kAblate ? a.ablate : 0, 1);
+        gc.stash_issue(lds);
+        poll_lines(p.flag_x2, p.grid2, xtarget, p.err);
+        wait_stores_done();                                                     // every wave: the stash slots it requested have landed
+        __syncthreads();
+        float4 xq[1], nq[1];
+        gemv_preload<QT, PRO_RMSNORM_QUANT, 1, true>(a, xq, nq);
+        gemv_prologue<QT, PRO_RMSNORM_QUANT, 1, true, FLM_LAYER_LATEQ != 0>(a, lds, xq, nq, [&](int) { gc.issue_missing(kAblate ? a.ablate : 0); });
+        gc.run(a, lds, nostamp);
+        wait_stores_done();                                                     // every wave: its logits are in memory
+        __syncthreads();
+        // the best of this workgroup's rows (pass wg + it nwg = rows [pass Rm, pass Rm + Rm)): thread r of wave 0 walks its row of every pass in ascending order, strict '>'
+        if (threadIdx.x < 64) {
+            float best = -INFINITY; int idx = 0x7fffffff;
+            for (unsigned it = 0; it < gc.np_wg; ++it) {
+                const unsigned row = (gc.wg + it * gc.nwg) * gc.Rm + threadIdx.x;
+                if (threadIdx.x < gc.Rm && row < (unsigned)T.vocab) { const float v = ld_agent(a.out + row); if (v > best) { best = v; idx = (int)row; } }
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(best, o, kWave); const int oi = __shfl_xor(idx, o, kWave);
+                if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+            }
+            if (threadIdx.x == 0) { st_agent(T.slots + 2 * blockIdx.x, best); st_agent(T.slots + 2 * blockIdx.x + 1, __int_as_float(idx)); }
+            wait_stores_done();
+            if (threadIdx.x == 0) __hip_atomic_store(T.flag_cls + blockIdx.x * kFlagStride, ctarget, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (blockIdx.x == 0) {
+        // the token's argmax over the workgroups' candidates; lower row wins ties (sample_argmax: the first maximum)
+        poll_lines(T.flag_cls, T.gridc, ctarget, p.err);
+        __syncthreads();
+        float* bv = reinterpret_cast<float*>(lds); int* bi = reinterpret_cast<int*>(lds) + 16;
+        float best = -INFINITY; int idx = 0x7fffffff;
+        if ((int)threadIdx.x < T.gridc) { best = ld_agent(T.slots + 2 * threadIdx.x); idx = __float_as_int(ld_agent(T.slots + 2 * threadIdx.x + 1)); }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, kWave); const int oi = __shfl_xor(idx, o, kWave);
+            if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+        }
+        if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < kWavesPerBlock; ++w) if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+            if (idx == 0x7fffffff) idx = 0;                                     // all -inf / NaN: the reference returns index 0
+            DecodeState* st = T.st;
+            if (T.out_tokens && st->step >= 0 && st->step < T.out_cap) T.out_tokens[st->step] = idx;
+            st->tok = idx; st->pos += 1; st->step += 1;
+            *T.epoch = next_epoch;
+        }
+    }
+}
+template <int QT, int XR2, bool SPLIT, int R5 = 0, bool TAIL = false>
+__global__ void __launch_bounds__(kGemvBlock, 4) k_layers(const LayerArgs* __restrict__ LA, const BackArgs p, const int l0, const int l1, const TailArgs* __restrict__ TA = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     // (the argument blocks through the CONSTANT address space: uniform scalar loads at the point of use, like kernel arguments -- through a generic pointer they would sit in vector registers)
     typedef const LayerArgs __attribute__((address_space(4))) CLayerArgs;
     CLayerArgs* LAc = (CLayerArgs*)(unsigned long long)LA;
+    unsigned base = 0; const float* x0 = nullptr;
+    if constexpr (TAIL) {
+        typedef const TailArgs __attribute__((address_space(4))) CTailArgs;
+        const TailArgs& T = *(const TailArgs*)((CTailArgs*)(unsigned long long)TA);
+        base = *T.epoch;
+        x0 = T.emb + (size_t)(*T.tok_ptr) * T.dim;
+    }
     for (int l = l0; l < l1; ++l) {
         const LayerArgs& A = *(const LayerArgs*)(LAc + l);
-        layer_body<QT, XR2, true, SPLIT, true, R5>(A.aq, A.aa, A.ao, A.a13, A.a2, p, lds, (unsigned)(l + 1), l > l0, l + 1 < l1, l == (l1 - l0 > 1 ? l0 + 1 : l0));   // (trace builds: the stamps of the launch's second layer)
+        layer_body<QT, XR2, true, SPLIT, true, R5>(A.aq, A.aa, A.ao, A.a13, A.a2, p, lds, base + (unsigned)(l + 1), l > l0, TAIL || l + 1 < l1, l == (l1 - l0 > 1 ? l0 + 1 : l0),   // (trace builds: the stamps of the launch's second layer)
+                                                   (TAIL && l == l0) ? x0 : nullptr);
+    }
+    if constexpr (TAIL) {
+        typedef const TailArgs __attribute__((address_space(4))) CTailArgs;
+        const TailArgs& T = *(const TailArgs*)((CTailArgs*)(unsigned long long)TA);
+        tail_phase<QT>(T, p, lds, base + (unsigned)l1, base + (unsigned)l1 + 1u, base + (unsigned)l1 + 2u);
     }
 }
 

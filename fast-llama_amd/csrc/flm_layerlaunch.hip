@@ -6,7 +6,7 @@ namespace fh {
 // attention + Wo + FFN13 + FFN2 of layer l in one launch (k_attn_ffn, flm_layer.h); returns FLM_ERR_UNSUPPORTED when the shape does not allow it
 // the argument blocks, the launch geometry and the stash sizes of layer l (the same for every layer but for the pointers): shared by k_attn_ffn's launch and k_layers' (flm_layers.hip)
 template <int QT>
-int plan_layer(flm_ctx* c, int l, bool with_qkv, int G, LayerArgs& A, BackArgs& p, int& grid, int& r2) {
+int plan_layer(flm_ctx* c, int l, bool with_qkv, int G, LayerArgs& A, BackArgs& p, int& grid, int& r2, TailArgs* tail) {     // tail (k_layers' one-launch token): in: non-null = wanted; out: tail->gridc > 0 = possible, filled
     const auto& d = c->d;
     constexpr int esz = QTraits<QT>::kEsz;
     const int all = c->cu_count < 256 ? c->cu_count : 256, parts = c->heads_local * G, wgs_o = all - parts;
@@ -32,6 +32,17 @@ int plan_layer(flm_ctx* c, int l, bool with_qkv, int G, LayerArgs& A, BackArgs& 
     one_pass(ao, Po, false, false); one_pass(a13, P13, true, true); one_pass(a2, P2, false, false);
     size_t own = Po.lds; if (P13.lds > own) own = P13.lds; if (P2.lds > own) own = P2.lds;
     if (with_qkv) { one_pass(aq, Pq, false, true, 2); if (Pq.lds > kLdsMax) return FLM_ERR_UNSUPPORTED; if (c->fuse_token && Pq.lds > own) own = Pq.lds; }   // (k_layers stashes [Wq; Wk; Wv] too: above its layout as well)
+    // the one-launch token runs the classifier as a phase of the same launch: its layout must fit below the stash as well
+    GemvArgs acls{}; GemvPlan Pc{}; bool tail_fits = false;
+    if (tail) {
+        tail->gridc = 0;
+        if (c->fuse_tail && with_qkv && c->fuse_token && c->world == 1 && c->got_emb && c->emb_qt == 0 && c->got_cls) {
+            acls = args_cls(c);
+            if (plan_gemv<QT, PRO_RMSNORM_QUANT, EPI_STORE>(c, acls, all, Pc) == FLM_OK && (acls.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4) <= 1 && Pc.grid <= 256 && Pc.lds + 8 * (kStepBlk * 1024 + 256) <= kLdsMax) {
+                tail_fits = true; if (Pc.lds > own) own = Pc.lds;
+            }
+        }
+    }
     own = (own + 255) & ~(size_t)255;
     const size_t lds_attn = attn_lds_bytes(d.max_seq_len, c->hs, G > 1);
     if (own > kLdsMax || lds_attn > kLdsMax) return FLM_ERR_UNSUPPORTED;
@@ -64,16 +75,23 @@ int plan_layer(flm_ctx* c, int l, bool with_qkv, int G, LayerArgs& A, BackArgs& 
     if (grid > all) return FLM_ERR_UNSUPPORTED;
     p.flag_x2 = c->flag_lines + 1280 * 16; p.nstq = slots(c->tok_nstq); p.preq = c->tok_preq < 0 ? 0 : c->tok_preq > 16 ? 16 : c->tok_preq;
     A.aq = aq; A.ao = ao; A.a13 = a13; A.a2 = a2; A.aa = aa;
+    if (tail && tail_fits && p.r5 && Pc.grid <= grid) {
+        // (only beside the arrival-order instantiation: one more form of every kernel would double the translation unit for shapes nobody decodes)
+        TailArgs& T = *tail;
+        T.acls = acls; T.emb = (const float*)c->emb; T.tok_ptr = &c->state->tok; T.dim = d.dim; T.vocab = c->cls.rows;
+        T.epoch = c->tail_mem; T.flag_cls = c->tail_mem + 16; T.slots = (float*)(c->tail_mem + 16 + 256 * 16); T.gridc = Pc.grid;
+        T.st = c->state; T.out_tokens = c->out_tokens_dev; T.out_cap = c->out_cap;
+    }
     return FLM_OK;
 }
-template int plan_layer<QT_INT8>(flm_ctx*, int, bool, int, LayerArgs&, BackArgs&, int&, int&);
-template int plan_layer<QT_INT16>(flm_ctx*, int, bool, int, LayerArgs&, BackArgs&, int&, int&);
+template int plan_layer<QT_INT8>(flm_ctx*, int, bool, int, LayerArgs&, BackArgs&, int&, int&, TailArgs*);
+template int plan_layer<QT_INT16>(flm_ctx*, int, bool, int, LayerArgs&, BackArgs&, int&, int&, TailArgs*);
 
 // attention + Wo + FFN13 + FFN2 of layer l (with_qkv: the whole layer) in one launch (k_attn_ffn, flm_layer.h); returns FLM_ERR_UNSUPPORTED when the shape does not allow it
 template <int QT>
 int launch_attn_ffn(flm_ctx* c, hipStream_t st, int l, bool with_qkv, int G) {
     LayerArgs A; BackArgs p; int grid = 0, r2 = 0;
-    int r = plan_layer<QT>(c, l, with_qkv, G, A, p, grid, r2); if (r) return r;
+    int r = plan_layer<QT>(c, l, with_qkv, G, A, p, grid, r2, nullptr); if (r) return r;
     const GemvArgs &aq = A.aq, &ao = A.ao, &a13 = A.a13, &a2 = A.a2; const AttnArgs& aa = A.aa;
     {   // the stash takes the rest of the CU's 160 KiB: raise the kernels' dynamic-LDS limit, once per device
         static std::mutex mu; static bool done[64] = {false};

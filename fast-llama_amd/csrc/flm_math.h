@@ -51,6 +51,9 @@ constexpr int kGemvBlock = 1024;      // GEMV: 16 waves = ONE workgroup per CU (
 constexpr int kWavesPerBlock = kGemvBlock / kWave;
 constexpr int kGroup = 64;            // quantization group (QUANT_GROUP_SIZE, the only value the reference uses)
 
+// the device-resident decode state: a token is replayed from a hipGraph without host round trips
+struct DecodeState { int pos; int tok; int step; int pad; };
+
 enum { QT_INT16 = 1, QT_INT8 = 2 };
 enum Prologue { PRO_NONE = 0, PRO_QUANT = 1, PRO_RMSNORM_QUANT = 2 };
 enum Epilogue { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_ROPE_KV = 3 };

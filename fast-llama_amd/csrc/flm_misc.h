@@ -39,7 +39,6 @@ inline __global__ void k_embed(float* x, const void* emb, const float* emb_s, in
 
 // sample_argmax (src/transformer/sampler.cpp:36-47): first maximum wins.  One workgroup.
 // Also advances the device-resident decode state: tok <- argmax, pos <- pos+1, out[step++] <- argmax.
-struct DecodeState { int pos; int tok; int step; int pad; };
 inline __global__ void __launch_bounds__(1024) k_argmax_advance(const float* logits, int n, DecodeState* st, int* out_tokens, int advance, int out_cap) {
     __shared__ float bv[16]; __shared__ int bi[16];
     float best = -INFINITY; int idx = 0x7fffffff;

@@ -274,6 +274,11 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
     const auto& d = c->d;
     const int qt = d.quant_type, hs = c->hs, L = d.n_layers;
     const bool tp = c->world > 1 || (c->comm != nullptr && c->force_tp), coh = tp && c->p2p;   // (a 1-rank communicator takes the sharded path only on request: "force_tp")
+    if (!tp && with_cls && advance == 1 && c->fuse_tail && c->fuse_token && c->fuse_layer && c->fuse_back && c->fuse_attn_o && c->fuse_ffn && !c->timing && c->trace_class < 0) {
+        // a greedy decode token as ONE launch: embedding row, all layers, classifier, argmax + state advance (k_layers<.., TAIL>)
+        const int r = launch_layers(c, st, 0, L, G, true);
+        if (r != FLM_ERR_UNSUPPORTED) return r;
+    }
     {
         Tick t(c, st, KC_EMBED);
         hipLaunchKernelGGL(k_embed, dim3((d.dim + 255) / 256), dim3(256), 0, st, c->x1, (const void*)c->emb, (const float*)c->emb_s, c->emb_qt, d.dim, (const int*)&c->state->tok, c->flag_lines, c->eng_base, c->ffn_counter);
@@ -432,26 +437,33 @@ int flm_kernel_times(flm_ctx* c, int pos, int iters, float* avg_us, int32_t* cou
                          const int G = attn_parts(c, pos + 1);
                          const int rr = layers_prepare(c, G); if (rr) return rr;
                          return launch_layers(c, st, 0, L, G); }
+        case KC_TOKEN: {    // ONE launch for the whole greedy token: embedding row, the L layers, classifier, argmax + state advance (enqueued for l == 0; it moves the state on: put back first)
+                         if (c->world > 1 || !c->fuse_tail || !c->fuse_token || !c->fuse_layer || !c->fuse_back || !c->fuse_attn_o || !c->fuse_ffn) return FLM_ERR_UNSUPPORTED;
+                         if (l != 0) return FLM_OK;
+                         const int G = attn_parts(c, pos + 1);
+                         const int rr = layers_prepare(c, G); if (rr) return rr;
+                         return launch_layers(c, st, 0, L, G, true); }
         default: return FLM_OK;
         }
     };
-    const int classes[] = {KC_EMBED, KC_QKV, KC_ATTN, KC_ATTN_O, KC_FFN13, KC_FFN2, KC_CLS, KC_ARGMAX, KC_ATTN_WO, KC_FFN, KC_QKV_ATTN_WO, KC_LAYER, KC_BACK, KC_LAYERS};
+    const int classes[] = {KC_EMBED, KC_QKV, KC_ATTN, KC_ATTN_O, KC_FFN13, KC_FFN2, KC_CLS, KC_ARGMAX, KC_ATTN_WO, KC_FFN, KC_QKV_ATTN_WO, KC_LAYER, KC_BACK, KC_LAYERS, KC_TOKEN};
     for (int kc : classes) {
-        const bool fused = kc == KC_ATTN_WO || kc == KC_FFN || kc == KC_QKV_ATTN_WO || kc == KC_LAYER || kc == KC_BACK || kc == KC_LAYERS;
+        const bool fused = kc == KC_ATTN_WO || kc == KC_FFN || kc == KC_QKV_ATTN_WO || kc == KC_LAYER || kc == KC_BACK || kc == KC_LAYERS || kc == KC_TOKEN;
         const bool per_layer = (kc >= KC_QKV && kc <= KC_FFN2) || fused;
         const int n = per_layer ? L : 8;
         for (int it = 0; it < iters + 1 && !r; ++it) {          // first round: warm-up
-            if (kc == KC_ATTN || fused) r = launch(KC_EMBED, 0);   // (clears the flag lines the workgroups of a fused launch / the parts of a split head wait on)
+            if (kc == KC_TOKEN) r = set_state(c, pos, 1 % d.vocab_size, 0);          // (the launch moves the decode state on: put it back, outside the timed region)
+            if (kc == KC_ATTN || (fused && kc != KC_TOKEN)) r = launch(KC_EMBED, 0);   // (clears the flag lines the workgroups of a fused launch / the parts of a split head wait on)
             HIPC(c, hipEventRecord(e0, st));
             for (int i = 0; i < n && !r; ++i) r = launch(kc, per_layer ? i : 0);
             if (fused && r == FLM_ERR_UNSUPPORTED) { r = FLM_OK; cnt[kc] = 0; break; }
             HIPC(c, hipEventRecord(e1, st));
             HIPC(c, hipEventSynchronize(e1));
             float ms = 0.f; HIPC(c, hipEventElapsedTime(&ms, e0, e1));
-            if (it > 0) { tot[kc] += ms * 1000.0 / (kc == KC_LAYERS ? 1 : n); cnt[kc] += 1; }
+            if (it > 0) { tot[kc] += ms * 1000.0 / (kc == KC_LAYERS || kc == KC_TOKEN ? 1 : n); cnt[kc] += 1; }
         }
         avg_us[kc] = cnt[kc] ? (float)(tot[kc] / cnt[kc]) : 0.f;
-        count[kc] = cnt[kc] ? (per_layer && kc != KC_LAYERS ? L : 1) : 0;
+        count[kc] = cnt[kc] ? (per_layer && kc != KC_LAYERS && kc != KC_TOKEN ? L : 1) : 0;
     }
     avg_us[KC_ALLREDUCE] = 0.f; count[KC_ALLREDUCE] = 0;
     if (r) return r;
@@ -478,6 +490,7 @@ int flm_kernel_bytes(flm_ctx* c, int kclass, int pos, double* bytes) {
     case KC_BACK:   *bytes = 2.0 * c->heads_local * c->hs * 4.0 * (pos + 1) + mat(c->drow_count, d.dim) + 2.0 * mat(c->hidden_local, d.dim) + d.dim * 4.0 + mat(c->drow_count, d.hidden_dim); break;
     case KC_LAYER:  *bytes = mat(3.0 * c->dim_local, d.dim) + d.dim * 4.0 + 2.0 * c->heads_local * c->hs * 4.0 * (pos + 1) + mat(c->drow_count, d.dim) + 2.0 * mat(c->hidden_local, d.dim) + d.dim * 4.0 + mat(c->drow_count, d.hidden_dim); break;
     case KC_LAYERS: *bytes = (double)d.n_layers * (mat(3.0 * c->dim_local, d.dim) + d.dim * 4.0 + 2.0 * c->heads_local * c->hs * 4.0 * (pos + 1) + mat(c->drow_count, d.dim) + 2.0 * mat(c->hidden_local, d.dim) + d.dim * 4.0 + mat(c->drow_count, d.hidden_dim)); break;
+    case KC_TOKEN:  { double lb = 0, cb = 0; flm_kernel_bytes(c, KC_LAYERS, pos, &lb); flm_kernel_bytes(c, KC_CLS, pos, &cb); *bytes = lb + cb + d.dim * 4.0; break; }   // the layers + the classifier + the embedding row
     default:        *bytes = 0; break;
     }
     return FLM_OK;

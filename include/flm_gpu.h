@@ -128,11 +128,13 @@ int  flm_sync(flm_ctx* ctx);
  * one workgroup and the head size a multiple of 64; option "fuse_layer"), 13 back: the same without the QKV GEMV ("fuse_layer" 0: instead of (9, 10)).
  * 14 layers: ALL layers of the token in one launch (k_layers: what the token path runs instead of L launches of class 12; option "fuse_token"): ONE launch per token,
  * avg_us = the duration of that launch, flm_kernel_bytes = L layers' bytes.
+ * 15 token: a greedy decode token as ONE launch (k_layers<.., TAIL>: the embedding row read by the first layer, the L layers, the classifier, the argmax and the state's advance;
+ * option "fuse_tail"; what flm_decode_* runs instead of (0, 14, 6, 7) for fp32 embedding tables where the arrival-order launch runs); bytes = the layers' + the classifier's.
  * avg_us[c] = mean duration of ONE launch of class c (single GPU: the class's launches of one token are
  * enqueued back to back between one pair of events, so the figure is launch duration + dispatch gap and
  * agrees with a rocprofv3 kernel trace), count[c] = launches of that class per token.
  * Side effect: the KV cache is cleared and the decode state is undefined afterwards. */
-#define FLM_KCLASSES 15
+#define FLM_KCLASSES 16
 int  flm_kernel_times(flm_ctx* ctx, int pos, int iters, float* avg_us, int32_t* count);
 /* weight + scale bytes one launch of class c streams (the algorithmic bytes of DESIGN.md) */
 int  flm_kernel_bytes(flm_ctx* ctx, int kclass, int pos, double* bytes);
@@ -149,7 +151,8 @@ int  flm_debug_read(flm_ctx* ctx, int what, int layer, float* out, size_t n);
  *   "fuse_qkv"       QKV in the same launch as attention + Wo: 0 never, 1 (default) where a head is spread over several workgroups, 2 always
  *   "fuse_back"      0 = attention + Wo and FFN13 + FFN2 as two launches (k_attn_o, k_ffn) instead of one (k_attn_ffn; default 1)
  *   "fuse_layer"     0 = the QKV GEMV as its own launch in front of k_attn_ffn (default 1: the whole decoder layer in one launch)
- *   "fuse_token"     0 = one launch per layer instead of one per token (k_layers; default 1: the edge between two layers is a flag round)
+ *   "fuse_token"     0 = one launch per layer instead of one for all layers (k_layers; default 1: the edge between two layers is a flag round)
+ *   "fuse_tail"      0 = a greedy decode token as four launches (embedding row, k_layers, classifier, argmax) instead of one (default 1)
  *   "back_ao"        0 = inside k_layers, Wo and FFN2 wait for ALL producers of their activation (round 4); default 3: consumed in arrival order (a wave waits
  *                    for the producers of its own steps' column blocks only)
  *   "attn_split"     0 = one workgroup per head at every context length (default 1: hs / 32 workgroups per head from 128 positions on; n >= 2: always n)
@@ -175,7 +178,8 @@ int  flm_set_option(flm_ctx* ctx, const char* key, int value);
  *               xwg_check; the call itself was re-run and returned correct results),
  *   "token_path" bit 0 attention + Wo fused, bit 1 FFN13 + FFN2 fused, bit 2 QKV joins the attention's launch at long contexts, bit 3 the same
  *               at every context, bit 6 heads split over workgroups at long contexts, bit 7 attention .. FFN2 in one launch (k_attn_ffn), bit 8 with the QKV GEMV in front
- *               (the whole layer in one launch), bit 9 all layers of the token in one launch (k_layers),
+ *               (the whole layer in one launch), bit 9 all layers of the token in one launch (k_layers), bit 10 a greedy decode token is ONE launch (embedding row, layers,
+ *               classifier, argmax in k_layers<.., TAIL>),
  *   "ao_active" which hand-offs of that launch are consumed in arrival order: bit 0 Wo, bit 1 FFN2 (-1: the launch has not been planned yet).
  * Unknown key: FLM_ERR_INVALID. */
 int  flm_query(flm_ctx* ctx, const char* key, int* value);

@@ -355,6 +355,36 @@ def test_golden_logits_from_reference(gpu, name, shape, qt, f32):
     ctx.close()
 
 
+@pytest.mark.parametrize("pos0", [5, 130])
+def test_greedy_token_as_one_launch_vs_oracle(gpu, pos0):
+    """k_layers<.., TAIL>: a greedy decode token as ONE launch -- the embedding row read by the first layer's prologue and Wo epilogue, all layers, the classifier as a phase
+    behind the last layer's flag round, the argmax over the classifier workgroups' candidates and the decode state's advance; flag values count from a per-token epoch base
+    (nobody clears the lines).  Ids and the last token's logits are the oracle's, with the one-launch token, with the four-launch one, after switching back and forth, eager and
+    from the graph; short contexts and split heads."""
+    cfg = synth.make_config("7B", ff.QT_INT8); cfg.n_layers = 2
+    tensors = synth.make_tensors(cfg, seed=53)
+    om = O.OracleModel(cfg, tensors)
+    prompt = _prompt(cfg.vocab_size, pos0)
+    lo = om.forward(prompt, 0)
+    first = int(np.argmax(lo)); n = 6
+    want_ids, cur, pos, last = [], first, len(prompt), None
+    for _ in range(n):
+        last = om.forward(np.array([cur], np.int32), pos); cur = int(np.argmax(last)); want_ids.append(cur); pos += 1
+    ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
+    assert ctx.forward_argmax(prompt, 0) == first
+    assert ctx.query("token_path") & 1024                    # the one-launch token is what a greedy step runs
+    for opts in ({}, {"fuse_tail": 0}, {"fuse_tail": 1}, {"use_graph": 0}, {"fuse_tail": 0}, {"use_graph": 1, "fuse_tail": 1}, {"back_ao": 0}):
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        ctx.reset_kv()
+        assert ctx.forward_argmax(prompt, 0) == first
+        ids = list(ctx.decode_greedy(first, len(prompt), n))
+        assert ids == want_ids, (opts, ids, want_ids)
+        assert bits_equal(ctx.debug_read("logits", 0, cfg.vocab_size), last), opts
+        assert ctx.query("fallback") == 0
+    ctx.close()
+
+
 def test_option_and_query_surface(gpu):
     """flm_query reads back every option and the path flags; unknown keys and out-of-range values are errors, not silent no-ops; every legal on / off combination
     of the launch-structure options on a tiny model gives the oracle's bits (the options choose launches, never arithmetic)"""
@@ -364,7 +394,7 @@ def test_option_and_query_surface(gpu):
     assert ctx.query("resident") == 1 and ctx.query("fallback") == 0
     tp = ctx.query("token_path")
     assert tp & 1 and tp & 2 and tp & 128 and tp & 256 and tp & 512        # attention + Wo, FFN13 + FFN2, both in one launch, with the QKV GEMV in front, all layers in one launch
-    for key in ("fold_xchg", "cu_parts", "fuse_attn_o", "fuse_ffn", "fuse_qkv", "fuse_back", "fuse_layer", "fuse_token", "tok_preq", "tok_nstq", "back_nst13", "back_nst13_head", "back_nst2", "back_pre13", "back_ao", "back_ao2", "ao_active",
+    for key in ("fold_xchg", "cu_parts", "fuse_attn_o", "fuse_ffn", "fuse_qkv", "fuse_back", "fuse_layer", "fuse_token", "fuse_tail", "tok_preq", "tok_nstq", "back_nst13", "back_nst13_head", "back_nst2", "back_pre13", "back_ao", "back_ao2", "ao_active",
                 "attn_split", "use_graph", "use_mfma", "use_prefill", "wg_per_cu"):
         ctx.query(key)
     with pytest.raises(gpu.FlmError):
