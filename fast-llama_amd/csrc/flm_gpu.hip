@@ -167,6 +167,44 @@ __global__ void __launch_bounds__(1024) k_census(unsigned* counter, unsigned n, 
 
 // run one token, through a cached hipGraph when enabled.  T = positions the token's attention covers (known to the host:
 // it picks how many workgroups a head is spread over; the graphs are keyed by it)
+// n greedy tokens whose attention spreads a head over the same number of workgroups, as ONE cached graph of n token sequences (a chunk): between two graph launches the
+// device idles ~10 us, between two nodes of a graph ~1.5 -- with the token one launch long that gap is the largest item left outside it.  Chunks of kChunk, then single tokens.
+constexpr int kChunk = 8;
+static int run_greedy_chunk(flm_ctx* c, int T, int n) {
+    const int G = attn_parts(c, T);
+    { int r = layers_prepare(c, G); if (!r) r = layers_prepare(c, attn_parts(c, 1)); if (!r) r = layers_prepare(c, attn_parts(c, c->d.max_seq_len)); if (r) return r; }
+    const int key = 4 + 1 + 8 * G + 4096 * n;
+    auto it = c->graphs.find(key);
+    if (it == c->graphs.end()) {
+        hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+        HIPC(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        int r = FLM_OK;
+        for (int i = 0; i < n && !r; ++i) r = enqueue_token(c, c->stream, true, 1, G);
+        hipError_t e = hipStreamEndCapture(c->stream, &g);
+        if (r) { if (g) hipGraphDestroy(g); return r; }
+        HIPC(c, e);
+        HIPC(c, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        HIPC(c, hipGraphDestroy(g));
+        it = c->graphs.emplace(key, ge).first;
+    }
+    HIPC(c, hipGraphLaunch(it->second, c->stream));
+    return FLM_OK;
+}
+// greedy tokens at positions pos .. pos + n - 1 (the attention of token i covers pos + i + 1 positions)
+int run_greedy_tokens(flm_ctx* c, int pos, int n) {
+    const bool chunks = c->use_graph && !c->timing && c->world == 1 && !(c->comm && c->force_tp) && c->graph_chunks;
+    int i = 0;
+    while (i < n) {
+        const int T = pos + i + 1, G = attn_parts(c, T);
+        int m = 1;
+        if (chunks) while (m < kChunk && i + m < n && attn_parts(c, T + m) == G) ++m;
+        int r;
+        if (m == kChunk) r = run_greedy_chunk(c, T, m); else { m = 1; r = run_token(c, true, 1, T); }
+        if (r) return r;
+        i += m;
+    }
+    return FLM_OK;
+}
 int run_token(flm_ctx* c, bool with_cls, int advance, int T) {
     const int G = attn_parts(c, T);
     // (k_layers' argument blocks: device memory, never built inside a capture -- and both head splits at once: the copy synchronizes the stream, which must not happen
@@ -539,6 +577,7 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     if (k == "tuning") { c->tuning = value != 0; return FLM_OK; }
     if (k == "wg_per_cu") { c->wg_per_cu = value > 0 ? value : 1; }
     else if (k == "use_graph") c->use_graph = value;
+    else if (k == "graph_chunks") c->graph_chunks = value;
     else if (k == "use_prefill") c->use_prefill = value;
     else if (k == "use_mfma") c->use_mfma = value;
     else if (k == "use_pv_mfma") c->use_pv_mfma = value;
@@ -606,7 +645,7 @@ int flm_query(flm_ctx* c, const char* key, int* value) {
     if (!c || !key || !value) return FLM_ERR_INVALID;
     const std::string k(key);
     const struct { const char* k; int v; } tab[] = {
-        {"tuning", c->tuning ? 1 : 0}, {"wg_per_cu", c->wg_per_cu}, {"use_graph", c->use_graph}, {"use_prefill", c->use_prefill}, {"use_mfma", c->use_mfma}, {"use_pv_mfma", c->use_pv_mfma},
+        {"tuning", c->tuning ? 1 : 0}, {"wg_per_cu", c->wg_per_cu}, {"use_graph", c->use_graph}, {"graph_chunks", c->graph_chunks}, {"use_prefill", c->use_prefill}, {"use_mfma", c->use_mfma}, {"use_pv_mfma", c->use_pv_mfma},
         {"fuse_attn_o", c->fuse_attn_o}, {"fuse_ffn", c->fuse_ffn}, {"fuse_qkv", c->fuse_qkv}, {"fuse_back", c->fuse_back}, {"fuse_layer", c->fuse_layer}, {"fuse_token", c->fuse_token}, {"fuse_tail", c->fuse_tail}, {"tok_nstq", c->tok_nstq}, {"tok_preq", c->tok_preq}, {"back_nst13", c->back_nst13}, {"back_nst13_head", c->back_nst13_head}, {"back_nst2", c->back_nst2}, {"back_pre13", c->back_pre13}, {"back_pre2", c->back_pre2}, {"back_ao", c->back_ao}, {"back_ao2", c->back_ao2}, {"use_prefill_mq", c->use_prefill_mq}, {"attn_split", c->attn_split},
         {"use_qk_mfma", c->use_qk_mfma}, {"use_p2p", c->p2p}, {"fold_xchg", c->fold_xchg}, {"tp_fuse_attn", c->tp_fuse_attn}, {"tp_fuse_ffn", c->tp_fuse_ffn}, {"cu_parts", c->cu_parts}, {"fold_active", (c->world > 1 && c->p2p && c->grp_fold) ? 1 : 0}, {"span_active", (c->world > 1 && c->p2p && c->grp_span) ? 1 : 0}, {"tp_trust_fused", c->tp_trust_fused}, {"force_tp", c->force_tp},
         {"grp_tp_fuse_attn", c->grp_tpfa}, {"grp_tp_fuse_ffn", c->grp_tpff}, {"grp_attn_split", c->grp_split}, {"resident", c->resident}, {"fallback", c->fell_back},
@@ -786,7 +825,7 @@ static int decode_loop(flm_ctx* c, int32_t first_token, int pos, int n_steps, hi
     if (n_steps > c->out_cap) return fail(c, FLM_ERR_INVALID, "more steps than max_seq_len");
     r = set_state(c, pos, first_token, 0); if (r) return r;
     if (e0) HIPC(c, hipEventRecord(e0, c->stream));
-    for (int i = 0; i < n_steps; ++i) { r = run_token(c, true, 1, pos + i + 1); if (r) return r; }
+    r = run_greedy_tokens(c, pos, n_steps); if (r) return r;
     if (e1) HIPC(c, hipEventRecord(e1, c->stream));
     return FLM_OK;
 }

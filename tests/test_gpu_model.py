@@ -373,7 +373,13 @@ def test_greedy_token_as_one_launch_vs_oracle(gpu, pos0):
     ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
     assert ctx.forward_argmax(prompt, 0) == first
     assert ctx.query("token_path") & 1024                    # the one-launch token is what a greedy step runs
-    for opts in ({}, {"fuse_tail": 0}, {"fuse_tail": 1}, {"use_graph": 0}, {"fuse_tail": 0}, {"use_graph": 1, "fuse_tail": 1}, {"back_ao": 0}):
+    first_n = first, n
+    # (graphs of 8 tokens: 19 steps = two chunks + three single tokens; "graph_chunks" 0: a graph launch per token)
+    n = 19
+    want_ids, cur, pos = [], first, len(prompt)
+    for _ in range(n):
+        last = om.forward(np.array([cur], np.int32), pos); cur = int(np.argmax(last)); want_ids.append(cur); pos += 1
+    for opts in ({}, {"fuse_tail": 0}, {"fuse_tail": 1, "graph_chunks": 0}, {"use_graph": 0}, {"fuse_tail": 0, "graph_chunks": 1}, {"use_graph": 1, "fuse_tail": 1}, {"back_ao": 0}):
         for k, v in opts.items():
             ctx.set_option(k, v)
         ctx.reset_kv()
@@ -395,7 +401,7 @@ def test_option_and_query_surface(gpu):
     tp = ctx.query("token_path")
     assert tp & 1 and tp & 2 and tp & 128 and tp & 256 and tp & 512        # attention + Wo, FFN13 + FFN2, both in one launch, with the QKV GEMV in front, all layers in one launch
     for key in ("fold_xchg", "cu_parts", "fuse_attn_o", "fuse_ffn", "fuse_qkv", "fuse_back", "fuse_layer", "fuse_token", "fuse_tail", "tok_preq", "tok_nstq", "back_nst13", "back_nst13_head", "back_nst2", "back_pre13", "back_ao", "back_ao2", "ao_active",
-                "attn_split", "use_graph", "use_mfma", "use_prefill", "wg_per_cu"):
+                "attn_split", "use_graph", "graph_chunks", "use_mfma", "use_prefill", "wg_per_cu"):
         ctx.query(key)
     with pytest.raises(gpu.FlmError):
         ctx.query("no_such_key")
