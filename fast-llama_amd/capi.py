@@ -27,7 +27,7 @@ SYMBOLS = (
 )
 
 
-TUNING_KEYS = ("wg_per_cu", "use_mfma", "tok_preq", "tok_nstq", "back_nst13", "back_nst13_head", "back_nst2", "back_pre13", "back_pre2", "back_ao2")   # csrc/flm_tuning.h
+TUNING_KEYS = ("wg_per_cu", "use_mfma", "tok_preq", "tok_nstq", "back_nst13", "back_nst13_head", "back_nst2", "back_pre13", "back_pre2", "back_ao2", "inject_wait_failure")   # csrc/flm_tuning.h
 
 
 class FlmError(RuntimeError):

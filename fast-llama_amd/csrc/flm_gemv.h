@@ -947,6 +947,7 @@ struct GemvCtx {
         for (u32 k = 0; k < 4; ++k) if (wave + 16 * k < NS) pending |= 1u << k;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         bool first = true;
+        u32 spins = 0;
         while (pending) {
             const unsigned f = mine ? __hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : src.target;
             const unsigned long long okm = __ballot((int)(f - src.target) >= 0);
@@ -954,9 +955,12 @@ struct GemvCtx {
 #pragma unroll
             for (u32 k = 0; k < 4; ++k) if (((okm >> (16 * k)) & 0xFFFFull) == 0xFFFFull) now |= 1u << k;
             now &= pending;
-            if (!now && __builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) {    // 20 ms: the host re-runs the call on one kernel per phase
-                __hip_atomic_store(src.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                now = pending;
+            if (!now) {
+                // 20 ms: the host re-runs the call on one kernel per phase.  (And when ANOTHER wait of the launch has already given up, do not spend this one's 20 ms as well:
+                // a look at *err every 64 empty looks.)
+                const bool late = __builtin_amdgcn_s_memrealtime() - t0 > 2000000ull;
+                if (late) __hip_atomic_store(src.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (late || ((++spins & 63u) == 0u && __hip_atomic_load(src.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) now = pending;
             }
             AoBlock b[4];
 #pragma unroll

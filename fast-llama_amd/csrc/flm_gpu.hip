@@ -578,6 +578,10 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     if (k == "wg_per_cu") { c->wg_per_cu = value > 0 ? value : 1; }
     else if (k == "use_graph") c->use_graph = value;
     else if (k == "graph_chunks") c->graph_chunks = value;
+    else if (k == "inject_wait_failure") {   // (tuning mode only: flm_tuning.h)
+        if (value) { const int one = 1; HIPC(c, hipMemcpyAsync(c->xwg_err, &one, 4, hipMemcpyHostToDevice, c->stream)); HIPC(c, hipStreamSynchronize(c->stream)); }
+        return FLM_OK;
+    }
     else if (k == "use_prefill") c->use_prefill = value;
     else if (k == "use_mfma") c->use_mfma = value;
     else if (k == "use_pv_mfma") c->use_pv_mfma = value;

@@ -391,6 +391,33 @@ def test_greedy_token_as_one_launch_vs_oracle(gpu, pos0):
     ctx.close()
 
 
+def test_a_wait_that_gives_up_is_retried_on_one_kernel_per_phase(gpu):
+    """the error path of the in-launch hand-offs: a wait that times out (20 ms) raises a flag, the launch runs through, the host re-runs the call on one kernel per phase and returns
+    CORRECT results with FLM_OK; the context stays on the per-phase kernels ("fallback" 1).  The flag is raised by hand here ("inject_wait_failure", a tuning-mode dial): every poll of
+    the next call's launches returns at once, so what they compute is garbage -- ids, logits and cache rows must nevertheless be the oracle's after the call."""
+    cfg = synth.make_config("7B", ff.QT_INT8); cfg.n_layers = 2
+    tensors = synth.make_tensors(cfg, seed=59)
+    om = O.OracleModel(cfg, tensors)
+    prompt = _prompt(cfg.vocab_size, 5)
+    first = int(np.argmax(om.forward(prompt, 0)))
+    want_ids, cur, pos, last = [], first, len(prompt), None
+    for _ in range(10):
+        last = om.forward(np.array([cur], np.int32), pos); cur = int(np.argmax(last)); want_ids.append(cur); pos += 1
+    ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
+    assert ctx.forward_argmax(prompt, 0) == first
+    assert list(ctx.decode_greedy(first, len(prompt), 10)) == want_ids and ctx.query("fallback") == 0
+    ctx.reset_kv()
+    assert ctx.forward_argmax(prompt, 0) == first
+    ctx.set_option("inject_wait_failure", 1)
+    assert list(ctx.decode_greedy(first, len(prompt), 10)) == want_ids          # the one-launch tokens ran through on garbage, the call was repeated
+    assert ctx.query("fallback") == 1 and not (ctx.query("token_path") & 1024)
+    assert bits_equal(ctx.debug_read("logits", 0, cfg.vocab_size), last)
+    ctx.reset_kv()
+    assert ctx.forward_argmax(prompt, 0) == first
+    assert list(ctx.decode_greedy(first, len(prompt), 10)) == want_ids          # ... and the context goes on, on one kernel per phase
+    ctx.close()
+
+
 def test_option_and_query_surface(gpu):
     """flm_query reads back every option and the path flags; unknown keys and out-of-range values are errors, not silent no-ops; every legal on / off combination
     of the launch-structure options on a tiny model gives the oracle's bits (the options choose launches, never arithmetic)"""
@@ -418,7 +445,8 @@ def test_option_and_query_surface(gpu):
             ctx.set_option(key, 1, unlock=False)
     ctx.set_option("tuning", 1)
     for key in gpu.TUNING_KEYS:
-        ctx.set_option(key, ctx.query(key), unlock=False)
+        if key != "inject_wait_failure":                       # (an action, not a value)
+            ctx.set_option(key, ctx.query(key), unlock=False)
     ctx.close()
     om = O.OracleModel(cfg, tensors)
     prompt = _prompt(cfg.vocab_size, 4)
