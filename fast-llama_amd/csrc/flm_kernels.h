@@ -15,11 +15,15 @@
 //   * attention : q.k as 8 strided lanes + sequential lane sum; glibc-exact expf; sequential softmax
 //                 sum; weighted V sum sequential over positions
 //
-// Kernel inventory.  One decode token on a single GPU = k_embed + k_layers (ALL L decoder layers) + k_gemv(cls) + k_argmax_advance (head size a multiple of 64; from 128
-// positions on the SPLIT instantiation: a head spread over hs / 32 workgroups).  What else is here runs under options, tensor parallelism or tests:
-//   k_layers<QT,XR2,SPLIT> THE DEFAULT DECODE LAUNCH (flm_layer.h, host side flm_layers.hip): layer_body -- the whole decoder layer: QKV GEMV, attention heads, Wo,
+// Kernel inventory.  One GREEDY decode token on a single GPU = ONE launch, k_layers<QT, XR2, SPLIT, R5 = 3, TAIL> (fp32 embedding table, head size a multiple of 64, W2's share of a
+// workgroup resident: int8 7B; from 128 positions on the SPLIT instantiation: a head spread over hs / 32 workgroups); a token whose logits go to the host, int16 7B and other shapes run
+// k_embed + k_layers (ALL L decoder layers) + k_gemv(cls) + k_argmax_advance.  What else is here runs under options, tensor parallelism or tests:
+//   k_layers<QT,XR2,SPLIT,R5,TAIL> THE DEFAULT DECODE LAUNCH (flm_layer.h, host side flm_layers.hip): layer_body -- the whole decoder layer: QKV GEMV, attention heads, Wo,
 //                         FFN13 + SwiGLU, FFN2 -- in a loop over the layers' argument blocks in device memory; every hand-off, the one between two layers included, is a flag
-//                         round; [W1; W3] is stashed in LDS by LDS-DMA under the attention, the next layer's [Wq; Wk; Wv] requested in front of the layer edge ("fuse_token" 0: off)
+//                         round; [W1; W3] is stashed in LDS by LDS-DMA under the attention, the next layer's [Wq; Wk; Wv] requested in front of the layer edge ("fuse_token" 0: off).
+//                         R5 = 3 (round 5): Wo and FFN2 consume their activation in ARRIVAL ORDER (GemvCtx::run_ao: a wave polls the producers of its own steps' column blocks only).
+//                         TAIL (round 5): the embedding row is the first layer's input, the classifier a phase behind the last layer, the argmax + state advance the launch's last act;
+//                         flag values count from a per-token epoch base ("fuse_tail" 0: off)
 //   k_attn_ffn<QT,XR2,QKV,SPLIT> the same layer_body as one launch per layer ("fuse_token" 0; "fuse_layer" 0: without the QKV GEMV; "fuse_back" 0: off)
 //   k_gemv<QT,PRO,EPI,XR> group-quantized GEMV, HBM-bound; fused prologue (rmsnorm+quantize | quantize) and epilogue (store | residual add | SwiGLU | RoPE + KV-cache
 //                         append): the classifier of every token; every phase of a tensor-parallel rank's token; the per-phase fallback behind a timed-out hand-off
