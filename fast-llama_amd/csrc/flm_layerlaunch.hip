@@ -75,8 +75,7 @@ int plan_layer(flm_ctx* c, int l, bool with_qkv, int G, LayerArgs& A, BackArgs& 
     if (grid > all) return FLM_ERR_UNSUPPORTED;
     p.flag_x2 = c->flag_lines + 1280 * 16; p.nstq = slots(c->tok_nstq); p.preq = c->tok_preq < 0 ? 0 : c->tok_preq > 16 ? 16 : c->tok_preq;
     A.aq = aq; A.ao = ao; A.a13 = a13; A.a2 = a2; A.aa = aa;
-    if (tail && tail_fits && p.r5 && Pc.grid <= grid) {
-        // (only beside the arrival-order instantiation: one more form of every kernel would double the translation unit for shapes nobody decodes)
+    if (tail && tail_fits && Pc.grid <= grid) {
         TailArgs& T = *tail;
         T.acls = acls; T.emb = (const float*)c->emb; T.tok_ptr = &c->state->tok; T.dim = d.dim; T.vocab = c->cls.rows;
         T.epoch = c->tail_mem; T.flag_cls = c->tail_mem + 16; T.slots = (float*)(c->tail_mem + 16 + 256 * 16); T.gridc = Pc.grid;

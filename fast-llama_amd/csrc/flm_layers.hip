@@ -41,7 +41,7 @@ int layers_prepare(flm_ctx* c, int G) {
 int launch_layers(flm_ctx* c, hipStream_t st, int l0, int l1, int G, bool tail) {
     const int key = G > 1 ? 1 : 0;
     if (!c->fuse_token || !c->la_valid[key] || !c->la_ok[key] || l1 <= l0) return FLM_ERR_UNSUPPORTED;
-    if (tail && (!c->tail_ok[key] || !c->la_p[key].r5 || l0 != 0 || l1 != c->d.n_layers)) return FLM_ERR_UNSUPPORTED;
+    if (tail && (!c->tail_ok[key] || l0 != 0 || l1 != c->d.n_layers)) return FLM_ERR_UNSUPPORTED;
     {
         static std::mutex mu; static bool done[64] = {false};
         std::lock_guard<std::mutex> lk(mu);
@@ -51,7 +51,9 @@ int launch_layers(flm_ctx* c, hipStream_t st, int l0, int l1, int G, bool tail) 
                                  (const void*)&k_layers<QT_INT8, 1, false, 3>, (const void*)&k_layers<QT_INT8, 3, false, 3>, (const void*)&k_layers<QT_INT16, 1, false, 3>, (const void*)&k_layers<QT_INT16, 3, false, 3>,
                                  (const void*)&k_layers<QT_INT8, 1, true, 3>, (const void*)&k_layers<QT_INT8, 3, true, 3>, (const void*)&k_layers<QT_INT16, 1, true, 3>, (const void*)&k_layers<QT_INT16, 3, true, 3>,
                                  (const void*)&k_layers<QT_INT8, 1, false, 3, true>, (const void*)&k_layers<QT_INT8, 3, false, 3, true>, (const void*)&k_layers<QT_INT16, 1, false, 3, true>, (const void*)&k_layers<QT_INT16, 3, false, 3, true>,
-                                 (const void*)&k_layers<QT_INT8, 1, true, 3, true>, (const void*)&k_layers<QT_INT8, 3, true, 3, true>, (const void*)&k_layers<QT_INT16, 1, true, 3, true>, (const void*)&k_layers<QT_INT16, 3, true, 3, true>};
+                                 (const void*)&k_layers<QT_INT8, 1, true, 3, true>, (const void*)&k_layers<QT_INT8, 3, true, 3, true>, (const void*)&k_layers<QT_INT16, 1, true, 3, true>, (const void*)&k_layers<QT_INT16, 3, true, 3, true>,
+                                 (const void*)&k_layers<QT_INT8, 1, false, 0, true>, (const void*)&k_layers<QT_INT8, 3, false, 0, true>, (const void*)&k_layers<QT_INT16, 1, false, 0, true>, (const void*)&k_layers<QT_INT16, 3, false, 0, true>,
+                                 (const void*)&k_layers<QT_INT8, 1, true, 0, true>, (const void*)&k_layers<QT_INT8, 3, true, 0, true>, (const void*)&k_layers<QT_INT16, 1, true, 0, true>, (const void*)&k_layers<QT_INT16, 3, true, 0, true>};
             for (const void* f : fns) HIPC(c, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
             done[c->device] = true;
         }
@@ -61,7 +63,8 @@ int launch_layers(flm_ctx* c, hipStream_t st, int l0, int l1, int G, bool tail) 
     const BackArgs p = c->la_p[key];
     const bool i8 = c->d.quant_type == FLM_QT_INT8, one = c->la_r2[key] <= 1;
     const TailArgs* TA = (const TailArgs*)c->tail_dev[key];
-#define FLM_LAUNCH_LAYERS(QT, XR2, SP) do { if (tail) hipLaunchKernelGGL((k_layers<QT, XR2, SP, 3, true>), g3, b3, kLdsMax, st, LA, p, l0, l1, TA); \
+#define FLM_LAUNCH_LAYERS(QT, XR2, SP) do { if (tail && p.r5) hipLaunchKernelGGL((k_layers<QT, XR2, SP, 3, true>), g3, b3, kLdsMax, st, LA, p, l0, l1, TA); \
+                                            else if (tail) hipLaunchKernelGGL((k_layers<QT, XR2, SP, 0, true>), g3, b3, kLdsMax, st, LA, p, l0, l1, TA); \
                                             else if (p.r5) hipLaunchKernelGGL((k_layers<QT, XR2, SP, 3>), g3, b3, kLdsMax, st, LA, p, l0, l1, (const TailArgs*)nullptr); \
                                             else hipLaunchKernelGGL((k_layers<QT, XR2, SP, 0>), g3, b3, kLdsMax, st, LA, p, l0, l1, (const TailArgs*)nullptr); } while (0)
     if (G > 1) { if (i8) { if (one) FLM_LAUNCH_LAYERS(QT_INT8, 1, true); else FLM_LAUNCH_LAYERS(QT_INT8, 3, true); } else { if (one) FLM_LAUNCH_LAYERS(QT_INT16, 1, true); else FLM_LAUNCH_LAYERS(QT_INT16, 3, true); } }

@@ -355,13 +355,14 @@ def test_golden_logits_from_reference(gpu, name, shape, qt, f32):
     ctx.close()
 
 
+@pytest.mark.parametrize("qt", [ff.QT_INT8, ff.QT_INT16])
 @pytest.mark.parametrize("pos0", [5, 130])
-def test_greedy_token_as_one_launch_vs_oracle(gpu, pos0):
+def test_greedy_token_as_one_launch_vs_oracle(gpu, pos0, qt):
     """k_layers<.., TAIL>: a greedy decode token as ONE launch -- the embedding row read by the first layer's prologue and Wo epilogue, all layers, the classifier as a phase
     behind the last layer's flag round, the argmax over the classifier workgroups' candidates and the decode state's advance; flag values count from a per-token epoch base
     (nobody clears the lines).  Ids and the last token's logits are the oracle's, with the one-launch token, with the four-launch one, after switching back and forth, eager and
     from the graph; short contexts and split heads."""
-    cfg = synth.make_config("7B", ff.QT_INT8); cfg.n_layers = 2
+    cfg = synth.make_config("7B", qt); cfg.n_layers = 2             # (int16: W2's share is not resident -> the round-4 hand-offs inside the one-launch token)
     tensors = synth.make_tensors(cfg, seed=53)
     om = O.OracleModel(cfg, tensors)
     prompt = _prompt(cfg.vocab_size, pos0)
