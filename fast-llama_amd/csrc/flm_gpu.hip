@@ -661,7 +661,7 @@ int flm_query(flm_ctx* c, const char* key, int* value) {
 }
 
 int flm_upload_tensor(flm_ctx* c, int kind, int layer, int src_qt, const void* values, const float* scales, int rows, int cols) {
-    if (c) c->st_ready = false;
+    if (c) { c->st_ready = false; c->la_valid[0] = c->la_valid[1] = false; }       // (the device-resident argument blocks of k_layers hold pointers into the tensors -- the embedding table's is re-allocated below -- and depend on their types)
     if (!c || !values) return FLM_ERR_INVALID;
     HIPC(c, hipSetDevice(c->device));
     const auto& d = c->d;

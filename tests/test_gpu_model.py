@@ -392,6 +392,27 @@ def test_greedy_token_as_one_launch_vs_oracle(gpu, pos0, qt):
     ctx.close()
 
 
+def test_one_launch_token_after_the_embedding_table_is_replaced(gpu):
+    """the one-launch token reads the embedding row through a pointer in a device-resident argument block: uploading another table (a new allocation) must rebuild that block"""
+    cfg = synth.make_config("7B", ff.QT_INT8); cfg.n_layers = 1
+    tensors = dict(synth.make_tensors(cfg, seed=61))
+    ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
+    prompt = _prompt(cfg.vocab_size, 4)
+    for scale in (1.0, -0.5):
+        if scale != 1.0:
+            tensors[(ff.T_TOKEN_EMBD, 0)] = (tensors[(ff.T_TOKEN_EMBD, 0)] * np.float32(scale)).astype(np.float32)
+            ctx.upload(ff.T_TOKEN_EMBD, 0, tensors[(ff.T_TOKEN_EMBD, 0)])
+        om = O.OracleModel(cfg, tensors)
+        first = int(np.argmax(om.forward(prompt, 0)))
+        want, cur, pos = [], first, len(prompt)
+        for _ in range(5):
+            cur = int(np.argmax(om.forward(np.array([cur], np.int32), pos))); want.append(cur); pos += 1
+        ctx.reset_kv()
+        assert ctx.forward_argmax(prompt, 0) == first
+        assert list(ctx.decode_greedy(first, len(prompt), 5)) == want, scale
+    ctx.close()
+
+
 def test_a_wait_that_gives_up_is_retried_on_one_kernel_per_phase(gpu):
     """the error path of the in-launch hand-offs: a wait that times out (20 ms) raises a flag, the launch runs through, the host re-runs the call on one kernel per phase and returns
     CORRECT results with FLM_OK; the context stays on the per-phase kernels ("fallback" 1).  The flag is raised by hand here ("inject_wait_failure", a tuning-mode dial): every poll of
