@@ -778,6 +778,12 @@ def run_tp_structures(capi, ctx, cfg, args, prompt, barrier, gold, rank, world, 
             rec.update(ms_per_step=round(1000.0 * float(wall.item()) / args.steps, 4))
         if m is not None:
             rec.update(p50_ms_per_step=round(m["p50_ms"], 4))
+        if verified:     # what an exchange costs under this structure: HIP events around the exchange launches / collectives of whole timed tokens (every rank, in step)
+            try:
+                ar = ctx.kernel_times(m["pos"] + args.steps // 2, iters=2).get("allreduce", (0.0, 0))
+                rec.update(exchange_us=round(ar[0], 2), exchange_launches_per_token=ar[1])
+            except Exception as e:  # noqa: BLE001
+                rec["exchange_us_error"] = str(e)
         rec["verified"] = verified
         rec["verified_against"] = ("the reference's golden ids on every rank (all-reduce MIN)" if gold is not None else "nothing: no golden ids for this shape")
         if not verified:
