@@ -46,6 +46,14 @@ def test_random_shapes_vs_oracle(gpu, seed, long_prompt):
         t = np.array([cur], np.int32); lg = ctx.forward(t, pos); lo = om.forward(t, pos)
         assert bits_equal(lg, lo), (kw, qt, npr, i)
         cur = int(np.argmax(lo)); pos += 1
+    # ... and the device-resident greedy loop from there: the one-launch token where the shape takes it (the embedding row, the classifier and the argmax inside the launch,
+    # odd vocabulary sizes -- classifier workgroups with one, two or no rows of their own), graphs of eight tokens + single ones
+    n = 11
+    want, oc = [], cur
+    for k in range(n):
+        oc = int(np.argmax(om.forward(np.array([oc], np.int32), pos + k))); want.append(oc)
+    assert list(ctx.decode_greedy(cur, pos, n)) == want, (kw, qt, npr)
+    assert ctx.query("fallback") == 0
     ctx.close()
 
 

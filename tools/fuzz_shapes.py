@@ -30,7 +30,14 @@ for it in range(n):
     for _ in range(3):
         t = np.array([cur], np.int32); lg = ctx.forward(t, pos); lo = om.forward(t, pos)
         ok = ok and np.array_equal(lg.view(np.uint32), lo.view(np.uint32)); cur = int(np.argmax(lo)); pos += 1
-    print(f"dim {dim} hidden {hidden} heads {heads} hs {hs} vocab {vocab} {'int8' if qt == ff.QT_INT8 else 'int16'} prompt {npr}: {'ok' if ok else 'MISMATCH'}", flush=True)
+    # ... and the device-resident greedy loop from there (the one-launch token where the shape takes it: embedding row, classifier and argmax inside the launch, odd vocabulary sizes)
+    ng = min(11, cfg.max_seq_len - pos) if hasattr(cfg, "max_seq_len") else 11
+    want, oc = [], cur
+    for k in range(ng):
+        oc = int(np.argmax(om.forward(np.array([oc], np.int32), pos + k))); want.append(oc)
+    got = list(ctx.decode_greedy(cur, pos, ng)) if ng > 0 else []
+    ok = ok and got == want and ctx.query("fallback") == 0
+    print(f"dim {dim} hidden {hidden} heads {heads} hs {hs} vocab {vocab} {'int8' if qt == ff.QT_INT8 else 'int16'} prompt {npr}: {'ok' if ok else 'MISMATCH'} (one-launch token: {bool(ctx.query('token_path') & 1024)})", flush=True)
     bad += (not ok)
     ctx.close()
 print("fuzz:", "FAILED" if bad else "ok")
