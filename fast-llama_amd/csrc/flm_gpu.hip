@@ -168,8 +168,8 @@ __global__ void __launch_bounds__(1024) k_census(unsigned* counter, unsigned n, 
 // run one token, through a cached hipGraph when enabled.  T = positions the token's attention covers (known to the host:
 // it picks how many workgroups a head is spread over; the graphs are keyed by it)
 // n greedy tokens whose attention spreads a head over the same number of workgroups, as ONE cached graph of n token sequences (a chunk): between two graph launches the
-// device idles ~10 us, between two nodes of a graph ~1.5 -- with the token one launch long that gap is the largest item left outside it.  Chunks of kChunk, then single tokens.
-constexpr int kChunk = 8;
+// device idles ~10 us, between two nodes of a graph ~1.5 -- with the token one launch long that gap is the largest item left outside it.  Chunks of 16, 8, 4, 2 tokens, then single ones.
+constexpr int kChunk = 16;
 static int run_greedy_chunk(flm_ctx* c, int T, int n) {
     const int G = attn_parts(c, T);
     { int r = layers_prepare(c, G); if (!r) r = layers_prepare(c, attn_parts(c, 1)); if (!r) r = layers_prepare(c, attn_parts(c, c->d.max_seq_len)); if (r) return r; }
@@ -196,10 +196,11 @@ int run_greedy_tokens(flm_ctx* c, int pos, int n) {
     int i = 0;
     while (i < n) {
         const int T = pos + i + 1, G = attn_parts(c, T);
-        int m = 1;
-        if (chunks) while (m < kChunk && i + m < n && attn_parts(c, T + m) == G) ++m;
+        int run = 1;                                                  // tokens from here on with the same head split
+        if (chunks) while (run < kChunk && i + run < n && attn_parts(c, T + run) == G) ++run;
+        int m = 1; while (2 * m <= run) m *= 2;                       // the largest power of two of them: graphs of 16, 8, 4, 2 tokens (a handful of cached graphs), then single ones
         int r;
-        if (m == kChunk) r = run_greedy_chunk(c, T, m); else { m = 1; r = run_token(c, true, 1, T); }
+        if (m >= 2) r = run_greedy_chunk(c, T, m); else r = run_token(c, true, 1, T);
         if (r) return r;
         i += m;
     }

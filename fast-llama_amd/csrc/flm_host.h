@@ -72,7 +72,7 @@ struct flm_ctx {
     // options
     bool tuning = false;                               // option "tuning": the experiment dials (flm_tuning.h) may be set
     int wg_per_cu = 1; int use_graph = 1; int ablate = 0;
-    int graph_chunks = 1;                              // option "graph_chunks": a greedy decode loop replays graphs of 8 tokens (0: one graph launch per token)
+    int graph_chunks = 1;                              // option "graph_chunks": a greedy decode loop replays graphs of up to 16 tokens (0: one graph launch per token)
     int use_mfma = 1;                                  // option "use_mfma": int8 prefill GEMM tile shape on v_mfma_i32_32x32x32_i8: 1 by size, 2 (0) 64 x 64, 3 128 x 128
     int use_prefill = 1;                               // option "use_prefill": prompts of >= kPrefillMin+1 tokens go through the batched kernels
     int pf_cap = 0;                                    // token capacity of the batched-prefill buffers below

@@ -146,7 +146,7 @@ int  flm_debug_read(flm_ctx* ctx, int what, int layer, float* out, size_t n);
 
 /* Structure switches: which launches a token runs.  None of them changes a result bit; the defaults are what was measured fastest.
  *   "use_graph"      0 = launches enqueued eagerly (default 1: a token is one hipGraph replay)
- *   "graph_chunks"   0 = one graph launch per greedy token (default 1: flm_decode_* replay graphs of 8 tokens -- the device idles ~10 us between two graph launches, ~1.5 between two nodes)
+ *   "graph_chunks"   0 = one graph launch per greedy token (default 1: flm_decode_* replay graphs of up to 16 tokens -- the device idles ~10 us between two graph launches, ~1.5 between two nodes)
  *   "fuse_attn_o"    0 = attention and the Wo GEMV as two launches (default 1: one launch, single GPU)
  *   "fuse_ffn"       0 = FFN13 and FFN2 as two launches (default 1)
  *   "fuse_qkv"       QKV in the same launch as attention + Wo: 0 never, 1 (default) where a head is spread over several workgroups, 2 always
