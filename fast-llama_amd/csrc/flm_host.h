@@ -112,11 +112,16 @@ struct flm_ctx {
     unsigned long long* ffn_counter = nullptr;         // (its device counter)
     int tp_fuse_attn = 2;                              // option "tp_fuse_attn": tensor parallel with folded exchanges: 1 = attention + Wo GEMV in one launch across the ranks (k_attn_o),
                                                        // 2 (default) = with the QKV GEMV in front (k_qkv_attn_o: its rows are the rank's own heads), 0 = separate launches
+    int tp_fuse_layers = 1;                            // option "tp_fuse_layers" (round 6): ALL layers of a sharded token in one launch that spans the ranks (k_layers<.., TP>: the four hand-offs of a layer are
+                                                       // flag rounds between the ranks' workgroups, the next phase's weights requested in front of each, exactly as on one GPU); needs what the
+                                                       // rank-spanning launches need (grp_span) and ranks of identical geometry
+    int tp_fence = 3;                                  // tuning dial "tp_fence": bit 0 release fence in front of a cross-rank line, bit 1 acquire fence behind a cross-rank poll (k_layers<.., TP>)
+    size_t x_tlines_off = 0;                           // ... its flag region in the exchange buffer: [heads: 256 lines][x1, hd, x, cls: world x 256 lines each]
     char* peer[8] = {nullptr}; bool peer_opened[8] = {false}; int p2p = 0;
     // what the tensor-parallel GROUP runs, agreed at flm_p2p_import from every rank's blob (the ranks' hand-off protocols must match or they wait on flags nobody raises):
     // exchanges folded into the consuming launches / launches that span the ranks / tp_fuse_attn / tp_fuse_ffn / attn_split, each the weakest any rank can do.
     // Options set after the import take effect at the next flm_p2p_export + flm_p2p_import round of the whole group.
-    bool grp_fold = false, grp_span = false, grp_can_split = false; int grp_tpfa = 0, grp_tpff = 0, grp_split = 0;
+    bool grp_fold = false, grp_span = false, grp_can_split = false, grp_tpl = false; int grp_tpfa = 0, grp_tpff = 0, grp_split = 0;
     int force_tp = 0;                                  // option "force_tp": a context created with an RCCL id but world == 1 takes the sharded token path (RCCL exchanges over a 1-rank communicator: tests)
     int tp_trust_fused = 0;                            // option "tp_trust_fused": ranks on DISTINCT devices run the folded / rank-spanning launches too (validated only between CU partitions of one GPU)
     unsigned* xepoch = nullptr;                        // [4] exchanges done per kind (att, x1, hd, logits), device memory
@@ -206,6 +211,7 @@ template <class A> void set_peers(flm_ctx* c, A& a, float* p) {
 // argument blocks of the five GEMVs and the attention of layer l (flm_token.hip)
 GemvArgs args_qkv(flm_ctx* c, int l);
 constexpr int kSplitFrom = 128;
+constexpr int kTpLinesPerRank = 256;                 // k_layers<.., TP>: flag lines per rank and kind in the exchange buffer's region (one per workgroup of a launch)
 int attn_parts(const flm_ctx* c, int T);
 AttnArgs args_attn(flm_ctx* c, int l, int G = 1);
 GemvArgs args_o(flm_ctx* c, int l);

@@ -48,6 +48,21 @@ struct BackArgs {
     int r5;                     // the round-5 forms the launch's instantiation carries (layer_body's R5): 3 or 0
     int nst2_ao;                // ... its stash slots: the steps beyond the two register sets (all of W2's share is resident)
     unsigned long long* trace;  // FLM_ABLATE builds: [grid][16] s_memrealtime stamps (100 MHz, one clock for all XCDs; tools/trace_back.py)
+    // tensor parallel (layer_body<.., TP>, round 6): the launch SPANS the ranks -- every rank runs the same k_layers on its rows (heads, rows of Wo / W2, rows of [W1; W3]: the
+    // reference's row split, transformer.cpp:264-287), the four all-to-all hand-offs of a layer cross the ranks.  A producer stores its slice into every rank's buffer
+    // (GemvArgs::out_peer / AttnArgs::out_peer) and raises ITS line in every rank's array; a consumer polls the lines of ALL ranks' producers in its LOCAL array.  The ranks'
+    // geometry is identical (equal shards, equal CU counts: checked when the group forms), so rank r's workgroup w of a kind is line r * (lines per rank) + w.
+    // flag_h / flag_x / flag_hd / flag_x2 above then point into this rank's own region (peer[rank] + off_*); flag_q stays a local array (a head's q / k / v rows are its own rank's).
+    struct Tp {
+        int world, rank;
+        unsigned* peer[8];      // every rank's flag region (in its exchange buffer, mapped here); peer[rank]: this rank's own
+        unsigned off_h, off_x, off_hd, off_x2, off_cls;   // dword offsets of the kinds' line arrays inside a region
+        int head_line0;         // this rank's first head-part line (plan.head_begin * G); the heads' array has n_heads_all lines
+        int n_heads_all;        // head parts of the whole model
+        const unsigned* base;   // the token's epoch base (device memory, advanced by k_embed on every rank alike): the launch's flag values count from it, nobody clears a line
+        int abort_off;          // dword offset (signed: the line lies in front) of the group's abort line from a region's start (non-zero line: some rank gave up, nobody waits any more)
+        int fence;              // bit 0: release fence in front of a raised line, bit 1: acquire fence behind a completed poll (both on: what the flags promise across xGMI)
+    } tp;
 };
 
 // One wave's look at its lines until all have reached `target`.  A look is a round trip to memory (the lines are written and read across XCDs); with one look in flight a
@@ -93,6 +108,46 @@ __device__ __forceinline__ void poll_wave(const unsigned* line, bool mine, unsig
 __device__ __forceinline__ void poll_lines(const unsigned* flag, int n, unsigned target, int* err) {
     if ((int)(threadIdx.x & ~63u) < n) poll_wave(flag + threadIdx.x * kFlagStride, (int)threadIdx.x < n, target, err);
 }
+// ---- the same across tensor-parallel ranks (layer_body<.., TP>): the lines are written by peer GPUs (system-scope stores into this rank's region), so the looks are
+// system-scope loads; ranks start seconds apart (module loading, graph capture), so a wait is patient (20 s) -- but once ANY rank has given up (the abort line) everybody leaves.
+// *err = 2: a group error (FLM_ERR_COMM; nothing is re-run on one rank alone).
+__device__ __forceinline__ void poll_wave_tp(const unsigned* line, bool mine, unsigned target, const BackArgs& p) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned spins = 0;
+    while (true) {
+        const unsigned f = mine ? __hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : target;
+        if (__all((int)(f - target) >= 0)) break;
+        if ((++spins & 255u) == 0u) {
+            const bool aborted = __hip_atomic_load(p.tp.peer[p.tp.rank] + p.tp.abort_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 || __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            if (aborted || __builtin_amdgcn_s_memrealtime() - t0 > 2000000000ull) {
+                __hip_atomic_store(p.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                for (int r = 0; r < p.tp.world; ++r) __hip_atomic_store(p.tp.peer[r] + p.tp.abort_off, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+}
+// every thread takes the lines tid, tid + 1024, ... of `n` (<= 8 ranks x 256 workgroups); the caller's barrier follows
+template <bool TP>
+__device__ __forceinline__ void poll_lines_t(const unsigned* flag, int n, unsigned target, const BackArgs& p) {
+    if constexpr (!TP) poll_lines(flag, n, target, p.err);
+    else {
+        for (int b = 0; b < n; b += kGemvBlock) {
+            const int i = b + (int)threadIdx.x;
+            if ((i & ~63) < n) poll_wave_tp(flag + (size_t)i * kFlagStride, i < n, target, p);
+        }
+        if (p.tp.fence & 2) __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+}
+// a producer workgroup's line goes up (its stores have completed: wait_stores_done + barrier in front): one local store, or one store into every rank's array
+template <bool TP>
+__device__ __forceinline__ void raise_line(const BackArgs& p, unsigned* local, unsigned off, unsigned line, unsigned target) {
+    if constexpr (!TP) { if (threadIdx.x == 0) __hip_atomic_store(local + line * kFlagStride, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    else if (threadIdx.x == 0) {
+        if (p.tp.fence & 1) __atomic_thread_fence(__ATOMIC_RELEASE);
+        for (int r = 0; r < p.tp.world; ++r) __hip_atomic_store(p.tp.peer[r] + off + line * kFlagStride, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 
 #ifndef FLM_BACK_LATE
 #define FLM_BACK_LATE 1
@@ -112,7 +167,9 @@ __device__ __forceinline__ void poll_lines(const unsigned* flag, int n, unsigned
 // nstq stash slots are requested, then the FFN2 lines are polled and x is read with coherent loads; xflag = this layer's FFN2 raises its lines for the next layer.
 // R5 (round 5; compile time, so that an instantiation carries one form of every hand-off -- both forms in one kernel spill): bit 0 Wo consumes the heads' output in arrival
 // order (GemvCtx::run_ao; one workgroup per head), bit 1 FFN2 consumes hd in arrival order.  The host picks the instantiation whose forms the shape allows (plan_layer: BackArgs::r5).
-template <int QT, int XR2, bool QKV, bool SPLIT, bool PERSIST, int R5 = 0>
+// TP (round 6): the launch spans the tensor-parallel ranks (BackArgs::Tp).  The heads hand their output over as fp32 (every rank's Wo workgroups quantize it themselves, as
+// with split heads); R5 = 0 (the hand-offs in their all-to-all form).
+template <int QT, int XR2, bool QKV, bool SPLIT, bool PERSIST, int R5 = 0, bool TP = false>
 // x0 (k_layers' one-launch token, first layer): the layer's input is read from there -- the embedding row -- by the QKV prologue and by Wo's residual epilogue instead of the residual
 // stream's buffer (which Wo's rows then start); null: the buffer.
 __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& aa, const GemvArgs& ao, const GemvArgs& a13, const GemvArgs& a2, const BackArgs& p, char* lds,
@@ -131,7 +188,7 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
                 if (xpoll) {
                     if ((int)gq.wave < p.preq) gq.issue(kAblate ? aq.ablate : 0, 1);
                     gq.stash_issue(lds);
-                    poll_lines(p.flag_x2, p.grid2, target - 1u, p.err);
+                    poll_lines_t<TP>(p.flag_x2, (TP ? p.tp.world : 1) * p.grid2, target - 1u, p);
                     wait_stores_done();                                         // every wave: the stash slots it requested have landed
                     __syncthreads();
                     gemv_preload<QT, PRO_RMSNORM_QUANT, 1, true>(aq, xq, nq);
@@ -172,7 +229,7 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
         stamp(1);
         wait_stores_done();                                                     // every wave: its part of the head's output is where the others will read it
         __syncthreads();                                                        // (and the LDS is free)
-        if (threadIdx.x == 0) __hip_atomic_store(p.flag_h + blockIdx.x * kFlagStride, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        raise_line<TP>(p, p.flag_h, p.tp.off_h, (TP ? (unsigned)p.tp.head_line0 : 0u) + blockIdx.x, target);
         stamp(2);
         if (p.nst13_head > 0 && (int)blockIdx.x < p.grid13) {
             nst13 = (unsigned)p.nst13_head;
@@ -207,11 +264,11 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
             const typename GemvCtx<QT, EPI_RESIDUAL>::AoSrc src{p.flag_h, (unsigned)aa.hs, (unsigned)p.n_heads, target, p.err};
             g.template run_ao<PRO_NONE>(ao, lds, src, []() {}, [&](int k) { if (k == 3) stamp(2); });
         } else {
-        poll_lines(p.flag_h, p.n_heads, target, p.err);
+        poll_lines_t<TP>(p.flag_h, TP ? p.tp.n_heads_all : p.n_heads, target, p);
         __syncthreads();
         stamp(2);
         float4 xv[1], nv[1];
-        if constexpr (SPLIT) {
+        if constexpr (SPLIT || TP) {
             gemv_preload<QT, PRO_QUANT, 1, true>(ao, xv, nv);
             gemv_prologue<QT, PRO_QUANT, 1>(ao, lds, xv, nv, [](int) {});
         } else gemv_prologue<QT, PRO_NONE, 0, true>(ao, lds, xv, nv, [](int) {});   // the heads' output arrives quantized (PREQ)
@@ -220,7 +277,7 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
         stamp(3);
         wait_stores_done();                                                     // every wave: its rows of x1 are where the others will read them
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(p.flag_x + (blockIdx.x - p.n_heads) * kFlagStride, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        raise_line<TP>(p, p.flag_x, p.tp.off_x, (TP ? (unsigned)(p.tp.rank * p.grido) : 0u) + (blockIdx.x - p.n_heads), target);
         stamp(4);
     }
     // ---- FFN13: k_gemv<RMSNORM_QUANT, SWIGLU> behind the x1 flag round (x1 through coherent loads)
@@ -228,7 +285,7 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
         GemvCtx<QT, EPI_SWIGLU, true> g;
         g.init(a13, blockIdx.x, p.grid13, lds, 0, p.st_base, nst13);
         if ((int)g.wave < p.pre13) g.issue(kAblate ? a13.ablate : 0, 1);       // the first pre13 waves: their first register set in front of the x1 flag round
-        poll_lines(p.flag_x, p.grido, target, p.err);
+        poll_lines_t<TP>(p.flag_x, (TP ? p.tp.world : 1) * p.grido, target, p);
         wait_stores_done();                                                     // every wave: the stash slots it requested have landed
         __syncthreads();
         stamp(5);
@@ -244,11 +301,11 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
 #endif
         stamp(7);
     } else {
-        poll_lines(p.flag_x, p.grido, target, p.err);                           // (keeps the order x1 -> hd for a workgroup without rows)
+        poll_lines_t<TP>(p.flag_x, (TP ? p.tp.world : 1) * p.grido, target, p);       // (keeps the order x1 -> hd for a workgroup without rows)
     }
     wait_stores_done();                                                         // every wave: its rows of hd are where the others will read them
     __syncthreads();                                                            // (and the LDS is free for the last phase)
-    if (threadIdx.x == 0) __hip_atomic_store(p.flag_hd + blockIdx.x * kFlagStride, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    raise_line<TP>(p, p.flag_hd, p.tp.off_hd, (TP ? (unsigned)p.tp.rank * gridDim.x : 0u) + blockIdx.x, target);
     stamp(8);
     if ((int)blockIdx.x < p.grid2) {
     // ---- FFN2: k_gemv<QUANT, RESIDUAL> behind the hd flag round
@@ -267,7 +324,7 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
     g2.init(a2, blockIdx.x, p.grid2, lds, 0, p.st_base, (unsigned)p.nst2);
     if ((int)g2.wave < p.pre2) g2.issue(kAblate ? a2.ablate : 0, 1);            // the first pre2 waves: ONE set now, the rest when hd has arrived (k_ffn: all 16)
     g2.stash_issue(lds);
-    poll_lines(p.flag_hd, (int)gridDim.x, target, p.err);
+    poll_lines_t<TP>(p.flag_hd, (TP ? p.tp.world : 1) * (int)gridDim.x, target, p);
     wait_stores_done();                                                         // every wave: the stash slots it requested have landed
     __syncthreads();
     stamp(9);
@@ -283,7 +340,7 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
         if (xflag) {
             wait_stores_done();                                                 // every wave: its rows of x are where the next layer will read them
             __syncthreads();                                                    // (and the LDS is free for the next layer)
-            if (threadIdx.x == 0 && (int)blockIdx.x < p.grid2) __hip_atomic_store(p.flag_x2 + blockIdx.x * kFlagStride, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((int)blockIdx.x < p.grid2) raise_line<TP>(p, p.flag_x2, p.tp.off_x2, (TP ? (unsigned)(p.tp.rank * p.grid2) : 0u) + blockIdx.x, target);
         }
     }
 }
@@ -371,8 +428,11 @@ __device__ __forceinline__ void tail_phase(const TailArgs& T, const BackArgs& p,
         }
     }
 }
-template <int QT, int XR2, bool SPLIT, int R5 = 0, bool TAIL = false>
+// TP (round 6): the launch spans the tensor-parallel ranks (BackArgs::Tp; every rank launches it on its own stream, all of them must be running for any to finish): the
+// flag values count from the token's epoch base (k_embed moved it on, on every rank alike), the lines live in the ranks' exchange buffers and are never cleared.
+template <int QT, int XR2, bool SPLIT, int R5 = 0, bool TAIL = false, bool TP = false>
 __global__ void __launch_bounds__(kGemvBlock, 4) k_layers(const LayerArgs* __restrict__ LA, const BackArgs p, const int l0, const int l1, const TailArgs* __restrict__ TA = nullptr) {
+    static_assert(!TP || (R5 == 0 && !TAIL), "the rank-spanning launch carries the all-to-all hand-offs, the classifier is a launch of its own");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     // (the argument blocks through the CONSTANT address space: uniform scalar loads at the point of use, like kernel arguments -- through a generic pointer they would sit in vector registers)
     typedef const LayerArgs __attribute__((address_space(4))) CLayerArgs;
@@ -384,9 +444,10 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_layers(const LayerArgs* __res
         base = *T.epoch;
         x0 = T.emb + (size_t)(*T.tok_ptr) * T.dim;
     }
+    if constexpr (TP) base = *p.tp.base;
     for (int l = l0; l < l1; ++l) {
         const LayerArgs& A = *(const LayerArgs*)(LAc + l);
-        layer_body<QT, XR2, true, SPLIT, true, R5>(A.aq, A.aa, A.ao, A.a13, A.a2, p, lds, base + (unsigned)(l + 1), l > l0, TAIL || l + 1 < l1, l == (l1 - l0 > 1 ? l0 + 1 : l0),   // (trace builds: the stamps of the launch's second layer)
+        layer_body<QT, XR2, true, SPLIT, true, R5, TP>(A.aq, A.aa, A.ao, A.a13, A.a2, p, lds, base + (unsigned)(l + 1), l > l0, TAIL || l + 1 < l1, l == (l1 - l0 > 1 ? l0 + 1 : l0),   // (trace builds: the stamps of the launch's second layer)
                                                    (TAIL && l == l0) ? x0 : nullptr);
     }
     if constexpr (TAIL) {

@@ -10,7 +10,10 @@ int plan_layer(flm_ctx* c, int l, bool with_qkv, int G, LayerArgs& A, BackArgs& 
     const auto& d = c->d;
     constexpr int esz = QTraits<QT>::kEsz;
     const int all = c->cu_count < 256 ? c->cu_count : 256, parts = c->heads_local * G, wgs_o = all - parts;
-    if (c->world != 1 || (G == 1 && c->hs % kGroup != 0) || wgs_o < 8 || parts > 256) return FLM_ERR_UNSUPPORTED;
+    // tensor parallel (round 6): the rank-spanning form (k_layers<.., TP>) where the group agreed on it (flm_p2p_import: grp_tpl); the ranks' geometry is identical
+    const bool tpl = c->world > 1 && c->p2p && c->grp_tpl && with_qkv && c->x_tlines_off != 0;
+    if ((c->world != 1 && !tpl) || (G == 1 && !tpl && c->hs % kGroup != 0) || wgs_o < 8 || parts > 256) return FLM_ERR_UNSUPPORTED;
+    if (tpl && (d.n_heads * G > kTpLinesPerRank || all > kTpLinesPerRank)) return FLM_ERR_UNSUPPORTED;
     if (G > 1 && !with_qkv) return FLM_ERR_UNSUPPORTED;                     // (split heads: only the whole-layer form is instantiated)
     GemvArgs aq = args_qkv(c, l), ao = args_o(c, l), a13 = args_ffn13(c, l), a2 = args_ffn2(c, l);
     GemvPlan Pq{}, Po, P13, P2;
@@ -23,7 +26,7 @@ int plan_layer(flm_ctx* c, int l, bool with_qkv, int G, LayerArgs& A, BackArgs& 
     r = plan_gemv<QT, PRO_QUANT, EPI_RESIDUAL>(c, a2, all, P2); if (r) return r;
     const int r13 = (a13.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4); r2 = (a2.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4);
     if (r13 > 1 || r2 > 3) return FLM_ERR_UNSUPPORTED;
-    if (G > 1 && (ao.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4) > 1) return FLM_ERR_UNSUPPORTED;
+    if ((G > 1 || tpl) && (ao.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4) > 1) return FLM_ERR_UNSUPPORTED;     // (the Wo workgroups quantize the heads' fp32 output themselves: one round)
     // a workgroup with a single pass needs one strip buffer: the LDS above the phases' own layouts is the stash
     auto one_pass = [&](GemvArgs& a, GemvPlan& P, bool two, bool norm, int rows_per_item = 1) {
         const int rows = a.items * rows_per_item, npass = (rows + P.Rm - 1) / P.Rm;
@@ -36,7 +39,7 @@ int plan_layer(flm_ctx* c, int l, bool with_qkv, int G, LayerArgs& A, BackArgs& 
     GemvArgs acls{}; GemvPlan Pc{}; bool tail_fits = false;
     if (tail) {
         tail->gridc = 0;
-        if (c->fuse_tail && with_qkv && c->fuse_token && c->world == 1 && c->got_emb && c->emb_qt == 0 && c->got_cls) {
+        if (c->fuse_tail && with_qkv && c->fuse_token && c->world == 1 && !tpl && c->got_emb && c->emb_qt == 0 && c->got_cls) {
             acls = args_cls(c);
             if (plan_gemv<QT, PRO_RMSNORM_QUANT, EPI_STORE>(c, acls, all, Pc) == FLM_OK && (acls.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4) <= 1 && Pc.grid <= 256 && Pc.lds + 8 * (kStepBlk * 1024 + 256) <= kLdsMax) {
                 tail_fits = true; if (Pc.lds > own) own = Pc.lds;
@@ -49,7 +52,7 @@ int plan_layer(flm_ctx* c, int l, bool with_qkv, int G, LayerArgs& A, BackArgs& 
     const int slot = kStepBlk * 1024 + 256, fit = (int)((kLdsMax - own) / slot);
     auto slots = [&](int want) { int n = want < 0 ? fit : want; if (n > fit) n = fit; if (n > 32) n = 32; return n < 0 ? 0 : n; };
     AttnArgs aa = args_attn(c, l, G);
-    if (G == 1) { aa.oq = c->att_q; aa.os = c->att_qs; aa.oqt = QT; ao.xq = c->att_q; ao.xs = c->att_qs; }   // the heads hand their output over quantized
+    if (G == 1 && !tpl) { aa.oq = c->att_q; aa.os = c->att_qs; aa.oqt = QT; ao.xq = c->att_q; ao.xs = c->att_qs; }   // the heads hand their output over quantized
     p = BackArgs{};
     p.n_heads = parts; p.grido = Po.grid; p.grid13 = P13.grid; p.grid2 = P2.grid;
     p.flag_h = c->flag_lines; p.flag_hd = c->flag_lines + 512 * 16; p.flag_x = c->flag_lines + 1024 * 16;
@@ -66,7 +69,7 @@ int plan_layer(flm_ctx* c, int l, bool with_qkv, int G, LayerArgs& A, BackArgs& 
         p.ao_2 = ok2 ? (c->back_ao2 >= 1 && c->back_ao2 <= 3 ? c->back_ao2 : 2) : 0;
         p.nst2_ao = ok2 ? want2 : 0;
         // one instantiation carries both arrival-order forms (k_layers<.., R5 = 3>) or none: Wo where a head is one workgroup (with split heads Wo stays as it was), FFN2
-        p.r5 = ((G > 1 || p.ao_o) && p.ao_2 && with_qkv) ? 3 : 0;
+        p.r5 = ((G > 1 || p.ao_o) && p.ao_2 && with_qkv && !tpl) ? 3 : 0;
         if (!p.r5) { p.ao_o = 0; p.ao_2 = 0; p.nst2_ao = 0; }
     }
     if (kAblate && c->trace_class == 102 && l == 0) { p.trace = c->trace; a13.trace = c->trace + 256 * 16; a2.trace = c->trace + 2 * 256 * 16; }   // tools/trace_back.py
@@ -74,6 +77,18 @@ int plan_layer(flm_ctx* c, int l, bool with_qkv, int G, LayerArgs& A, BackArgs& 
     grid = parts + Po.grid; if (P13.grid > grid) grid = P13.grid; if (P2.grid > grid) grid = P2.grid; if (with_qkv && Pq.grid > grid) grid = Pq.grid;
     if (grid > all) return FLM_ERR_UNSUPPORTED;
     p.flag_x2 = c->flag_lines + 1280 * 16; p.nstq = slots(c->tok_nstq); p.preq = c->tok_preq < 0 ? 0 : c->tok_preq > 16 ? 16 : c->tok_preq;
+    if (tpl) {   // the cross-rank lines: regions of the ranks' exchange buffers (never cleared: epoch values); flag_q and the split heads' score lines stay local (k_embed clears them)
+        BackArgs::Tp& t = p.tp;
+        t.world = c->world; t.rank = c->rank;
+        for (int r = 0; r < c->world; ++r) t.peer[r] = (unsigned*)(c->peer[r] + c->x_tlines_off);
+        const unsigned per = (unsigned)c->world * kTpLinesPerRank * 16;
+        t.off_h = 0; t.off_x = kTpLinesPerRank * 16; t.off_hd = t.off_x + per; t.off_x2 = t.off_hd + per; t.off_cls = t.off_x2 + per;
+        t.head_line0 = c->plan.head_begin * G; t.n_heads_all = d.n_heads * G;
+        t.base = c->eng_base; t.fence = c->tp_fence;
+        t.abort_off = (int)(((long long)c->x_flags_off + (long long)kXchgAbortLine * 64 - (long long)c->x_tlines_off) / 4);      // (the group's one abort line: in the exchange flags' region, in front of this one)
+        unsigned* mine = t.peer[c->rank];
+        p.flag_h = mine + t.off_h; p.flag_x = mine + t.off_x; p.flag_hd = mine + t.off_hd; p.flag_x2 = mine + t.off_x2;
+    }
     A.aq = aq; A.ao = ao; A.a13 = a13; A.a2 = a2; A.aa = aa;
     if (tail && tail_fits && Pc.grid <= grid) {
         TailArgs& T = *tail;

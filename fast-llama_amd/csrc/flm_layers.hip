@@ -6,11 +6,12 @@
 namespace fh {
 
 template <int QT> int plan_layer(flm_ctx* c, int l, bool with_qkv, int G, LayerArgs& A, BackArgs& p, int& grid, int& r2, TailArgs* tail);     // flm_layerlaunch.hip
+int launch_layers_tp(flm_ctx* c, hipStream_t st, const LayerArgs* LA, const BackArgs& p, int grid, int r2, int l0, int l1, int G);           // flm_layers_tp.hip
 
 // the layers' argument blocks in device memory, per number of workgroups a head is spread over (G = 1 | hs / 32): built outside any stream capture, valid until an option changes
 int layers_prepare(flm_ctx* c, int G) {
     const int key = G > 1 ? 1 : 0;
-    if (!c->fuse_token || c->world != 1) return FLM_OK;
+    if (!c->fuse_token || (c->world != 1 && !(c->p2p && c->grp_tpl))) return FLM_OK;            // (tensor parallel: the rank-spanning form, where the group agreed on it)
     if (c->la_valid[key]) return FLM_OK;
     const int L = c->d.n_layers, qt = c->d.quant_type;
     std::vector<LayerArgs> host((size_t)L);
@@ -42,6 +43,10 @@ int launch_layers(flm_ctx* c, hipStream_t st, int l0, int l1, int G, bool tail) 
     const int key = G > 1 ? 1 : 0;
     if (!c->fuse_token || !c->la_valid[key] || !c->la_ok[key] || l1 <= l0) return FLM_ERR_UNSUPPORTED;
     if (tail && (!c->tail_ok[key] || l0 != 0 || l1 != c->d.n_layers)) return FLM_ERR_UNSUPPORTED;
+    if (c->world > 1) {
+        if (tail || !c->p2p || !c->grp_tpl || !c->la_p[key].tp.world) return FLM_ERR_UNSUPPORTED;
+        return launch_layers_tp(c, st, (const LayerArgs*)c->la_dev[key], c->la_p[key], c->la_grid[key], c->la_r2[key], l0, l1, G);
+    }
     {
         static std::mutex mu; static bool done[64] = {false};
         std::lock_guard<std::mutex> lk(mu);

@@ -301,6 +301,15 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
         r = launch_layers(c, st, 0, L, G);
         if (r == FLM_OK) goto layers_done; else if (r != FLM_ERR_UNSUPPORTED) return r;
     }
+    if (span && c->grp_tpl && c->fuse_token && !c->timing && c->trace_class < 0) {   // tensor parallel: all layers in one launch that spans the ranks (k_layers<.., TP>)
+        r = launch_layers(c, st, 0, L, G);
+        if (r == FLM_OK) {
+            // (a token without classifier: the next token's k_embed rewrites x1 -- every peer's stores of the last layer's rows into it must have landed first; with one, the
+            //  classifier's folded flag round below is that exchange)
+            if (!with_cls) { r = exchange(c, st, XK_X1, c->x1, c->x1 + c->drow_begin, c->drow_count); if (r) return r; }
+            goto layers_done;
+        } else if (r != FLM_ERR_UNSUPPORTED) return r;
+    }
     for (int l = 0; l < L; ++l) {
         bool fused = false;
         const bool back_ok = !tp && c->fuse_back && c->fuse_attn_o && c->fuse_ffn && !c->timing && (c->trace_class < 0 || c->trace_class == 102);

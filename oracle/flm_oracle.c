@@ -95,6 +95,41 @@ void orc_matmul_q(int qt, float* out, const void* W, const float* sW, const void
     }
 }
 
+/* NOT a reference function -- the evaluation of a DEVIATION from it (tools/ksplit_eval.py): the Megatron-style
+ * K-split of a row's chain over `parts` tensor-parallel ranks.  The n / gs quant groups are dealt to the ranks in contiguous runs
+ * (the first `rem` ranks one group more: 172 groups over 8 ranks = 22,22,22,22,21,21,21,21; a group never straddles ranks), every rank
+ * runs the reference's chain (quant_operators.cpp:252-284) over ITS groups from 0.f, and the partials are added in rank order
+ * 0..parts-1 (what a deterministic all-reduce would do).  parts == 1 is orc_matmul_q. */
+void orc_matmul_q_ksplit(int qt, float* out, const void* W, const float* sW, const void* X, const float* sX,
+                         int m, int n, int w, int gs, int parts) {
+    const int sn = (n + gs - 1) / gs;
+    if (parts < 1) parts = 1;
+    if (parts > sn) parts = sn;
+    for (int b = 0; b < w; ++b) {
+#pragma omp parallel for schedule(static)
+        for (int j = 0; j < m; ++j) {
+            float total = 0.f;
+            int g = 0;
+            for (int r = 0; r < parts; ++r) {
+                const int cnt = sn / parts + (r < sn % parts ? 1 : 0);
+                float o = 0.f;
+                for (int e = g + cnt; g < e; ++g) {
+                    int len = n - g * gs; if (len > gs) len = gs;
+                    float s = sW[(size_t)j * sn + g] * sX[(size_t)b * sn + g];
+                    int d;
+                    if (qt == ORC_QT_INT8)
+                        d = dot_i8((const int8_t*)X + (size_t)b * n + g * gs, (const int8_t*)W + (size_t)j * n + g * gs, len);
+                    else
+                        d = dot_i16((const int16_t*)X + (size_t)b * n + g * gs, (const int16_t*)W + (size_t)j * n + g * gs, len);
+                    o = fmaf(s, (float)d, o);
+                }
+                total = r == 0 ? o : total + o;
+            }
+            out[(size_t)b * m + j] = total;
+        }
+    }
+}
+
 /* simd::dot_product(float) -> dot_product_avx256 -- src/platforms/arch/x86_simd.cpp:1447-1467,1677-1699
  * 8 strided lane accumulators (mul+add contracted to FMA), then partials summed 0..7, then tail.
  * (n >= 32 takes the 8-lane path; 16 <= n < 32 the 4-lane SSE path; smaller: scalar.) */
@@ -244,6 +279,7 @@ struct orc_model {
     orc_qmat cls;
     float *kcache, *vcache;                           /* [L][KVH][max_seq][hs] */
     float* tap_x;
+    int ksplit;                                       /* > 1: Wo and W2 run orc_matmul_q_ksplit (a deviation under evaluation, never the parity path) */
 };
 
 static size_t esz(int qt) { return qt == ORC_QT_INT8 ? 1 : (qt == ORC_QT_INT16 ? 2 : 4); }
@@ -273,6 +309,7 @@ void orc_model_free(orc_model* m) {
     free(m->emb); free(m->emb_s); free(m->att_norm); free(m->ffn_norm); free(m->out_norm);
     free(m->kcache); free(m->vcache); free(m->tap_x); free(m);
 }
+void orc_model_set_ksplit(orc_model* m, int parts) { m->ksplit = parts; }
 void orc_model_reset(orc_model* m) {
     size_t kvn = (size_t)m->L * m->KVH * m->max_seq * m->hs;
     memset(m->kcache, 0, kvn * 4); memset(m->vcache, 0, kvn * 4);
@@ -368,7 +405,8 @@ int orc_model_forward(orc_model* m, const int32_t* tokens, int n, int pos, float
             for (int i = 0; i < bs; ++i) memcpy(x2 + (size_t)i * dim + (size_t)hs * h, hq_o + (size_t)i * hs, sizeof(float) * hs);
         }
         orc_quantize(qt, qx, sx, x2, (size_t)bs * dim, gs);                            /* :138 */
-        orc_matmul_q(qt, tmp, m->wo[l].q, m->wo[l].s, qx, sx, dim, dim, bs, gs);       /* :139, :457-466 */
+        if (m->ksplit > 1) orc_matmul_q_ksplit(qt, tmp, m->wo[l].q, m->wo[l].s, qx, sx, dim, dim, bs, gs, m->ksplit);
+        else orc_matmul_q(qt, tmp, m->wo[l].q, m->wo[l].s, qx, sx, dim, dim, bs, gs);       /* :139, :457-466 */
         for (size_t i = 0; i < (size_t)bs * dim; ++i) x1[i] += tmp[i];
         if (bs > 1 && l == m->L - 1) {                                                 /* :140-142 */
             memmove(x1, x1 + (size_t)(bs - 1) * dim, sizeof(float) * dim);
@@ -380,7 +418,8 @@ int orc_model_forward(orc_model* m, const int32_t* tokens, int n, int pos, float
         orc_matmul_q(qt, h3, m->w3[l].q, m->w3[l].s, qx, sx, hid, dim, bs, gs);
         orc_swiglu(hd, h3, (size_t)bs * hid);
         orc_quantize(qt, qx, sx, hd, (size_t)bs * hid, gs);                            /* :149 */
-        orc_matmul_q(qt, tmp, m->w2[l].q, m->w2[l].s, qx, sx, dim, hid, bs, gs);       /* :150, :485-494 */
+        if (m->ksplit > 1) orc_matmul_q_ksplit(qt, tmp, m->w2[l].q, m->w2[l].s, qx, sx, dim, hid, bs, gs, m->ksplit);
+        else orc_matmul_q(qt, tmp, m->w2[l].q, m->w2[l].s, qx, sx, dim, hid, bs, gs);       /* :150, :485-494 */
         for (size_t i = 0; i < (size_t)bs * dim; ++i) x1[i] += tmp[i];
     }
     float* xl = x1 + (size_t)(bs - 1) * dim;                                           /* :154 */

@@ -61,6 +61,10 @@ int        orc_model_set_tensor(orc_model* m, int kind, int layer, int src_qt, c
 /* tokens[n] at absolute position pos -> logits[vocab] of the LAST token.  0 on success. */
 int        orc_model_forward(orc_model* m, const int32_t* tokens, int n, int pos, float* logits);
 void       orc_model_reset(orc_model* m);
+/* evaluation of the K-split deviation (tools/ksplit_eval.py; NOT the reference's arithmetic): Wo and W2 as `parts` partial chains summed in rank order */
+void       orc_model_set_ksplit(orc_model* m, int parts);
+void       orc_matmul_q_ksplit(int qt, float* out, const void* W, const float* sW, const void* X, const float* sX,
+                               int m, int n, int w, int gs, int parts);
 /* debugging taps: copies of intermediate activations of the last forward (last row) */
 const float* orc_model_tap_x(orc_model* m);   /* residual stream after the last layer [dim] */
 const float* orc_model_kcache(orc_model* m, int layer);   /* [heads][max_seq][hs] */

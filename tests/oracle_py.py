@@ -150,17 +150,21 @@ class OracleModel:
                                                    cfg.vocab_size, cfg.quant_type, cfg.quant_group_size, max_seq))
         if not self.h:
             raise RuntimeError("orc_model_create failed")
-        for (kind, layer), v in tensors.items():
-            if isinstance(v, tuple):
-                q = np.ascontiguousarray(v[0]); s = np.ascontiguousarray(v[1], dtype=np.float32)
-                qt = QT_INT8 if q.dtype == np.int8 else QT_INT16
-                r = orc().orc_model_set_tensor(self.h, kind, layer, qt, _p(q), _p(s), q.shape[0], q.shape[1])
-            else:
-                a = np.ascontiguousarray(v, dtype=np.float32)
-                rows, cols = a.shape if a.ndim == 2 else (1, a.shape[0])
-                r = orc().orc_model_set_tensor(self.h, kind, layer, QT_NONE, _p(a), None, rows, cols)
-            if r != 0:
-                raise RuntimeError(f"orc_model_set_tensor({kind},{layer}) -> {r}")
+        for key, v in tensors.items():
+            self.set_tensor(key, v)
+
+    def set_tensor(self, key, v):
+        kind, layer = key
+        if isinstance(v, tuple):
+            q = np.ascontiguousarray(v[0]); s = np.ascontiguousarray(v[1], dtype=np.float32)
+            qt = QT_INT8 if q.dtype == np.int8 else QT_INT16
+            r = orc().orc_model_set_tensor(self.h, kind, layer, qt, _p(q), _p(s), q.shape[0], q.shape[1])
+        else:
+            a = np.ascontiguousarray(v, dtype=np.float32)
+            rows, cols = a.shape if a.ndim == 2 else (1, a.shape[0])
+            r = orc().orc_model_set_tensor(self.h, kind, layer, QT_NONE, _p(a), None, rows, cols)
+        if r != 0:
+            raise RuntimeError(f"orc_model_set_tensor({kind},{layer}) -> {r}")
 
     def forward(self, tokens, pos):
         t = np.ascontiguousarray(tokens, dtype=np.int32)

@@ -213,7 +213,7 @@ def test_folded_exchange_under_cu_masks(gpu, shape, qt, layers, world, fuse):
         assert c.query("fold_active") == 0          # ranks share the device and have no partition yet
         c.set_option("cu_parts", world)
         assert c.query("fold_active") == 0          # ... and what the group runs changes only when the whole group exchanges its blobs again
-        c.set_option("tp_fuse_attn", fuse); c.set_option("tp_fuse_ffn", 1 if fuse else 0)
+        c.set_option("tp_fuse_attn", fuse); c.set_option("tp_fuse_ffn", 1 if fuse else 0); c.set_option("tp_fuse_layers", 0)   # (the per-layer structures; the rank-spanning k_layers has its own test below)
     gpu.Ctx.regroup(ctxs)
     for c in ctxs:
         assert c.query("fold_active") == 1 and c.query("span_active") == 1
@@ -254,7 +254,7 @@ def test_fused_attention_across_ranks_with_split_heads(gpu, fuse):
         c.upload_all(tensors)
     for c in ctxs:
         c.set_option("cu_parts", world)
-        c.set_option("tp_fuse_attn", fuse); c.set_option("tp_fuse_ffn", 1 if fuse else 0)
+        c.set_option("tp_fuse_attn", fuse); c.set_option("tp_fuse_ffn", 1 if fuse else 0); c.set_option("tp_fuse_layers", 0)
     gpu.Ctx.regroup(ctxs)                           # (the group's launch structure is agreed when the blobs are exchanged)
 
     def rank_main(c):
@@ -266,6 +266,58 @@ def test_fused_attention_across_ranks_with_split_heads(gpu, fuse):
     for r, (lg, ids) in enumerate(_run_ranks(ctxs, rank_main)):
         assert bits_equal(lg[0], want[0]) and bits_equal(lg[1], want[1]), f"rank {r}"
         assert ids == ids_want[2:5], f"rank {r}: greedy ids"
+    for c in ctxs:
+        c.close()
+
+
+@pytest.mark.parametrize("shape,qt,layers,world,nprompt", [("small", ff.QT_INT8, None, 2, 4), ("small", ff.QT_INT16, None, 4, 4), ("7B", ff.QT_INT8, 3, 2, 4), ("7B", ff.QT_INT16, 2, 4, 4), ("7B", ff.QT_INT8, 2, 8, 4),
+                                                           ("small", ff.QT_INT8, None, 2, 200), ("7B", ff.QT_INT8, 2, 4, 150), ("7B", ff.QT_INT16, 2, 2, 140)])
+def test_rank_spanning_layers_under_cu_masks(gpu, shape, qt, layers, world, nprompt):
+    """Round 6: ALL layers of a sharded token as ONE launch per rank (k_layers<.., TP>, option "tp_fuse_layers", the default where the group can span): the single-GPU persistent
+    launch with the reference's row split (transformer.cpp:264-287) across the ranks -- the four all-to-all hand-offs of a layer (heads -> Wo, x1 -> FFN13, hd -> FFN2, x -> the next
+    layer's QKV: transformer.cpp:386-505's tasks) are flag rounds between the ranks' workgroups, every producer storing its slice into every rank's buffer and raising its line in
+    every rank's array.  CU-masked ranks on one GPU (2 x 128, 4 x 64, 8 x 32 CUs); short prompts and long ones (split heads: a head over hs / 32 workgroups of its rank);
+    logits and graph-replayed greedy ids of every rank = the oracle's bits, and the launch is what ran (tp_layers_active)."""
+    cfg = synth.make_config(shape, qt)
+    if layers:
+        cfg.n_layers = layers
+    tensors = synth.make_tensors(cfg, seed=59)
+    om = O.OracleModel(cfg, tensors)
+    prompt = _prompt(cfg.vocab_size, nprompt)
+    want = [om.forward(prompt, 0)]
+    cur, pos = int(np.argmax(want[0])), len(prompt)
+    for _ in range(6):
+        want.append(om.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(want[-1])); pos += 1
+    ids_want = [int(np.argmax(w)) for w in want]
+    ctxs = [gpu.Ctx(gpu.desc_from_config(cfg), device=0, rank=r, world=world, comm_id=None) for r in range(world)]
+    for c in ctxs:
+        c.upload_all(tensors)
+        c.set_option("cu_parts", world)
+    gpu.Ctx.regroup(ctxs)
+    for c in ctxs:
+        assert c.query("span_active") == 1 and c.query("grp_tp_fuse_layers") == 1
+
+    def rank_main(c):
+        lg = [c.forward(prompt, 0)]
+        cur, pos = int(np.argmax(lg[0])), len(prompt)
+        for _ in range(2):
+            lg.append(c.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(lg[-1])); pos += 1
+        ids = c.decode_greedy(cur, pos, 4)
+        return lg, [int(x) for x in ids], c.query("tp_layers_active")
+
+    for r, (lg, ids, act) in enumerate(_run_ranks(ctxs, rank_main)):
+        for i, l in enumerate(lg):
+            assert bits_equal(l, want[i]), f"rank {r}: logits of step {i}"
+        assert ids == ids_want[3:7], f"rank {r}: greedy ids"
+        assert act >= 1 and (nprompt < 128 or act & 2), f"rank {r}: the rank-spanning launch did not run (tp_layers_active {act})"
+    # the structure is an option like the others: off on one rank and the whole group is back on the per-layer launches, same bits
+    ctxs[-1].set_option("tp_fuse_layers", 0)
+    gpu.Ctx.regroup(ctxs)
+    for c in ctxs:
+        assert c.query("grp_tp_fuse_layers") == 0
+        c.reset_kv()
+    for r, lg in enumerate(_run_ranks(ctxs, lambda c: c.forward(prompt, 0))):
+        assert bits_equal(lg, want[0]), f"rank {r}: per-layer launches"
     for c in ctxs:
         c.close()
 
