@@ -12,6 +12,7 @@ thread_local std::string g_last_error;
 
 int fail(flm_ctx* c, int code, const char* msg) { if (c) c->err = msg; g_last_error = msg; return code; }
 
+int prepare_all(flm_ctx* c);
 int esz_of(int qt) { return qt == FLM_QT_INT8 ? 1 : qt == FLM_QT_INT16 ? 2 : 4; }
 
 // balanced contiguous split (split_rows, transformer.cpp:264-287)
@@ -140,7 +141,8 @@ int xwg_check(flm_ctx* c) {
         c->attn_split = 0;
         return fail(c, FLM_ERR_COMM, "tensor parallel: a cross-workgroup wait on this rank timed out; the group's results are invalid and the context group cannot be used any more");
     }
-    c->fuse_attn_o = 0; c->fuse_ffn = 0; c->fuse_qkv = 0; c->fuse_back = 0; c->fuse_token = 0; c->attn_split = 0; c->fell_back = 1;
+    if (!c->fb_active) { c->fb_saved[0] = c->fuse_attn_o; c->fb_saved[1] = c->fuse_ffn; c->fb_saved[2] = c->fuse_qkv; c->fb_saved[3] = c->fuse_back; c->fb_saved[4] = c->fuse_token; c->fb_saved[5] = c->attn_split; }
+    c->fuse_attn_o = 0; c->fuse_ffn = 0; c->fuse_qkv = 0; c->fuse_back = 0; c->fuse_token = 0; c->attn_split = 0; c->fell_back += 1; c->fb_active = true; c->fb_tokens = 0;
     for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
     c->graphs.clear();
     return FLM_RETRY;
@@ -165,21 +167,54 @@ __global__ void __launch_bounds__(1024) k_census(unsigned* counter, unsigned n, 
     }
 }
 
+// the census of a cu_count-wide launch on the context's stream: 1 = every workgroup resident at once (up to 3 attempts: another process busy on the device for the census' 2 ms
+// must not switch the fused launches off), 0 = not, -1 = a HIP error
+static int run_census(flm_ctx* c) {
+    unsigned* cnt = (unsigned*)((char*)c->xwg_err + 32); int* okp = c->xwg_err + 4;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        int one = 1, ok = 0;
+        if (hipMemsetAsync(cnt, 0, 4, c->stream) != hipSuccess || hipMemcpyAsync(okp, &one, 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) { (void)hipGetLastError(); return -1; }
+        hipLaunchKernelGGL(k_census, dim3(c->cu_count), dim3(1024), 150 * 1024, c->stream, cnt, (unsigned)c->cu_count, okp);
+        if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&ok, okp, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess) { if (ok) return 1; }
+        else { (void)hipGetLastError(); return -1; }
+    }
+    return 0;
+}
+// A context that fell back to one kernel per phase (xwg_check: a cross-workgroup wait gave up -- a co-tenant held CUs for 20 ms) does not stay there: after kFallbackProbation tokens
+// on the per-phase path the census runs again, and if every workgroup is resident the launch structure the context had comes back ("fallback" counts the episodes, "fallback_active"
+// says where the context is).  Called by the token entry points after a completed call.
+constexpr int kFallbackProbation = 64;
+int maybe_recover(flm_ctx* c, int tokens) {
+    if (!c->fb_active) return FLM_OK;
+    c->fb_tokens += tokens;
+    if (c->fb_tokens < kFallbackProbation) return FLM_OK;
+    c->fb_tokens = 0;
+    if (run_census(c) != 1) return FLM_OK;                               // still crowded: another probation period
+    c->fuse_attn_o = c->fb_saved[0]; c->fuse_ffn = c->fb_saved[1]; c->fuse_qkv = c->fb_saved[2]; c->fuse_back = c->fb_saved[3]; c->fuse_token = c->fb_saved[4]; c->attn_split = c->fb_saved[5];
+    c->fb_active = false;
+    for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
+    c->graphs.clear();
+    c->la_valid[0] = c->la_valid[1] = false;
+    return prepare_all(c);
+}
+
 // run one token, through a cached hipGraph when enabled.  T = positions the token's attention covers (known to the host:
 // it picks how many workgroups a head is spread over; the graphs are keyed by it)
 // n greedy tokens whose attention spreads a head over the same number of workgroups, as ONE cached graph of n token sequences (a chunk): between two graph launches the
 // device idles ~10 us, between two nodes of a graph ~1.5 -- with the token one launch long that gap is the largest item left outside it.  Chunks of 16, 8, 4, 2 tokens, then single ones.
 constexpr int kChunk = 16;
-static int run_greedy_chunk(flm_ctx* c, int T, int n) {
-    const int G = attn_parts(c, T);
-    { int r = layers_prepare(c, G); if (!r) r = layers_prepare(c, attn_parts(c, 1)); if (!r) r = layers_prepare(c, attn_parts(c, c->d.max_seq_len)); if (r) return r; }
-    const int key = 4 + 1 + 8 * G + 4096 * n;
+static bool graphs_in_use(const flm_ctx* c) { return c->use_graph && !c->timing && !((c->world > 1 || (c->comm && c->force_tp)) && !c->p2p); }   // (RCCL collectives stay eager)
+static bool chunks_in_use(const flm_ctx* c) { return c->use_graph && !c->timing && c->world == 1 && !(c->comm && c->force_tp) && c->graph_chunks; }
+// the cached graph of `n` token sequences (n >= 2: greedy tokens, a chunk; n == 1: one token by (classifier, advance)) for G workgroups per head: captured and instantiated on first use --
+// flm_prepare (and the end of the upload) asks for every graph the entry points replay, so that this happens THERE and not inside a forward
+static int token_graph(flm_ctx* c, bool with_cls, int advance, int G, int n, hipGraphExec_t* out) {
+    const int key = (with_cls ? 4 : 0) + advance + 8 * G + 4096 * (n >= 2 ? n : 0);
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
         hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
         HIPC(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         int r = FLM_OK;
-        for (int i = 0; i < n && !r; ++i) r = enqueue_token(c, c->stream, true, 1, G);
+        for (int i = 0; i < n && !r; ++i) r = enqueue_token(c, c->stream, with_cls, advance, G);
         hipError_t e = hipStreamEndCapture(c->stream, &g);
         if (r) { if (g) hipGraphDestroy(g); return r; }
         HIPC(c, e);
@@ -187,12 +222,26 @@ static int run_greedy_chunk(flm_ctx* c, int T, int n) {
         HIPC(c, hipGraphDestroy(g));
         it = c->graphs.emplace(key, ge).first;
     }
-    HIPC(c, hipGraphLaunch(it->second, c->stream));
+    *out = it->second;
+    return FLM_OK;
+}
+// k_layers' argument blocks: device memory, never built inside a capture -- and both head splits at once: the copy synchronizes the stream, which must not happen
+// at the position where a decode loop crosses from one split to the other, inside somebody's timed region
+static int prepare_layers(flm_ctx* c, int G) {
+    int r = layers_prepare(c, G); if (!r) r = layers_prepare(c, attn_parts(c, 1)); if (!r) r = layers_prepare(c, attn_parts(c, c->d.max_seq_len));
+    return r;
+}
+static int run_greedy_chunk(flm_ctx* c, int T, int n) {
+    const int G = attn_parts(c, T);
+    int r = prepare_layers(c, G); if (r) return r;
+    hipGraphExec_t ge = nullptr;
+    r = token_graph(c, true, 1, G, n, &ge); if (r) return r;
+    HIPC(c, hipGraphLaunch(ge, c->stream));
     return FLM_OK;
 }
 // greedy tokens at positions pos .. pos + n - 1 (the attention of token i covers pos + i + 1 positions)
 int run_greedy_tokens(flm_ctx* c, int pos, int n) {
-    const bool chunks = c->use_graph && !c->timing && c->world == 1 && !(c->comm && c->force_tp) && c->graph_chunks;
+    const bool chunks = chunks_in_use(c);
     int i = 0;
     while (i < n) {
         const int T = pos + i + 1, G = attn_parts(c, T);
@@ -208,24 +257,29 @@ int run_greedy_tokens(flm_ctx* c, int pos, int n) {
 }
 int run_token(flm_ctx* c, bool with_cls, int advance, int T) {
     const int G = attn_parts(c, T);
-    // (k_layers' argument blocks: device memory, never built inside a capture -- and both head splits at once: the copy synchronizes the stream, which must not happen
-    //  at the position where a decode loop crosses from one split to the other, inside somebody's timed region)
-    { int r = layers_prepare(c, G); if (!r) r = layers_prepare(c, attn_parts(c, 1)); if (!r) r = layers_prepare(c, attn_parts(c, c->d.max_seq_len)); if (r) return r; }
-    if (!c->use_graph || c->timing || ((c->world > 1 || (c->comm && c->force_tp)) && !c->p2p)) return enqueue_token(c, c->stream, with_cls, advance, G);   // (RCCL collectives stay eager)
-    const int key = (with_cls ? 4 : 0) + advance + 8 * G;
-    auto it = c->graphs.find(key);
-    if (it == c->graphs.end()) {
-        hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
-        HIPC(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        int r = enqueue_token(c, c->stream, with_cls, advance, G);
-        hipError_t e = hipStreamEndCapture(c->stream, &g);
-        if (r) { if (g) hipGraphDestroy(g); return r; }
-        HIPC(c, e);
-        HIPC(c, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-        HIPC(c, hipGraphDestroy(g));
-        it = c->graphs.emplace(key, ge).first;
+    int r = prepare_layers(c, G); if (r) return r;
+    if (!graphs_in_use(c)) return enqueue_token(c, c->stream, with_cls, advance, G);
+    hipGraphExec_t ge = nullptr;
+    r = token_graph(c, with_cls, advance, G, 1, &ge); if (r) return r;
+    HIPC(c, hipGraphLaunch(ge, c->stream));
+    return FLM_OK;
+}
+// Everything the token entry points use beyond the buffers of flm_ctx_create: k_layers' argument blocks (both head splits) and every graph flm_forward* / flm_decode_* replay --
+// single tokens by (classifier, advance) and the greedy chunks of 2 .. 16 tokens, for one workgroup per head and for split heads.  Captures and instantiates, launches nothing
+// (a tensor-parallel rank must not wait for peers here).  Called when the last tensor of a model arrives, at the end of flm_p2p_import, and by flm_prepare.
+int prepare_all(flm_ctx* c) {
+    if (!model_complete(c)) return FLM_OK;
+    if ((c->world > 1 || (c->comm && c->force_tp)) && !c->p2p && !c->comm) return FLM_OK;      // (a tensor-parallel rank that has not met its peers yet: flm_p2p_import prepares)
+    const int G1 = attn_parts(c, 1), G2 = attn_parts(c, c->d.max_seq_len);
+    int r = prepare_layers(c, G1); if (r) return r;
+    if (!graphs_in_use(c)) return FLM_OK;
+    const int Gs[2] = {G1, G2};
+    for (int i = 0; i < (G2 != G1 ? 2 : 1); ++i) {
+        const int G = Gs[i];
+        hipGraphExec_t ge = nullptr;
+        if ((r = token_graph(c, true, 0, G, 1, &ge)) || (r = token_graph(c, true, 1, G, 1, &ge)) || (r = token_graph(c, false, 2, G, 1, &ge))) return r;
+        if (chunks_in_use(c)) for (int n = 2; n <= kChunk; n *= 2) if ((r = token_graph(c, true, 1, G, n, &ge))) return r;
     }
-    HIPC(c, hipGraphLaunch(it->second, c->stream));
     return FLM_OK;
 }
 
@@ -427,6 +481,9 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
         const unsigned e0 = 4096u; HIPB(hipMemcpyAsync(c->tail_mem, &e0, 4, hipMemcpyHostToDevice, c->stream));
     }
     HIPB(hipMalloc((void**)&c->eng_base, 64)); HIPB(hipMemsetAsync(c->eng_base, 0, 64, c->stream));   // the token's epoch base
+    for (int k = 0; k < 2; ++k) {   // k_layers' argument blocks, one set per head split (filled by layers_prepare; allocated here: nothing is allocated inside a forward)
+        HIPB(hipMalloc((void**)&c->la_dev[k], sizeof(LayerArgs) * (size_t)d.n_layers)); HIPB(hipMalloc((void**)&c->tail_dev[k], sizeof(TailArgs)));
+    }
     HIPB(hipMalloc(&c->att_q, (size_t)d.dim * c->esz)); HIPB(hipMalloc((void**)&c->att_qs, (size_t)(d.dim / kGroup) * 4));
     HIPB(hipMalloc((void**)&c->att_sc, (size_t)c->heads_local * d.max_seq_len * 4));
     HIPB(hipMalloc((void**)&c->state, sizeof(DecodeState)));
@@ -448,15 +505,7 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
                 attr_done[device_id] = true;
             }
         }
-        unsigned* cnt = (unsigned*)((char*)c->xwg_err + 32); int* okp = c->xwg_err + 4;
-        c->resident = 0;
-        for (int attempt = 0; attempt < 3 && !c->resident; ++attempt) {   // (another process busy on the device for the census' 2 ms must not switch the fused launches off for the context's whole life)
-            int one = 1, ok = 0;
-            HIPB(hipMemsetAsync(cnt, 0, 4, c->stream)); HIPB(hipMemcpyAsync(okp, &one, 4, hipMemcpyHostToDevice, c->stream));
-            hipLaunchKernelGGL(k_census, dim3(c->cu_count), dim3(1024), 150 * 1024, c->stream, cnt, (unsigned)c->cu_count, okp);
-            if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&ok, okp, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess) c->resident = ok ? 1 : 0;
-            else { (void)hipGetLastError(); break; }
-        }
+        c->resident = run_census(c) == 1 ? 1 : 0;
         if (!c->resident) { c->fuse_attn_o = 0; c->fuse_ffn = 0; c->fuse_qkv = 0; c->fuse_back = 0; c->attn_split = 0; }
     }
 #undef HIPB
@@ -566,6 +615,10 @@ int flm_p2p_import(flm_ctx* c, const void* blobs, int n) {
     c->p2p = 1;
     for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
     c->graphs.clear();
+    {   // the group's structure is known now: argument blocks and token graphs (captured, not launched -- nobody waits for a peer here); an error here resurfaces at the first forward
+        const std::string err0 = c->err, gerr0 = g_last_error;
+        if (prepare_all(c) != FLM_OK) { c->err = err0; g_last_error = gerr0; (void)hipGetLastError(); }
+    }
     return FLM_OK;
 }
 
@@ -611,7 +664,7 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (k == "tp_fuse_attn") c->tp_fuse_attn = value;
     else if (k == "tp_fuse_ffn") c->tp_fuse_ffn = value;
     else if (k == "tp_fuse_layers") c->tp_fuse_layers = value;
-    else if (k == "tp_fence") c->tp_fence = value & 3;
+    else if (k == "tp_fence") c->tp_fence = value < 0 ? -1 : value & 3;
     else if (k == "tp_trust_fused") c->tp_trust_fused = value;
     else if (k == "force_tp") c->force_tp = value;
     else if (k == "cu_parts") {
@@ -658,7 +711,7 @@ int flm_query(flm_ctx* c, const char* key, int* value) {
         {"tuning", c->tuning ? 1 : 0}, {"wg_per_cu", c->wg_per_cu}, {"use_graph", c->use_graph}, {"graph_chunks", c->graph_chunks}, {"use_prefill", c->use_prefill}, {"use_mfma", c->use_mfma}, {"use_pv_mfma", c->use_pv_mfma},
         {"fuse_attn_o", c->fuse_attn_o}, {"fuse_ffn", c->fuse_ffn}, {"fuse_qkv", c->fuse_qkv}, {"fuse_back", c->fuse_back}, {"fuse_layer", c->fuse_layer}, {"fuse_token", c->fuse_token}, {"fuse_tail", c->fuse_tail}, {"tok_nstq", c->tok_nstq}, {"tok_preq", c->tok_preq}, {"back_nst13", c->back_nst13}, {"back_nst13_head", c->back_nst13_head}, {"back_nst2", c->back_nst2}, {"back_pre13", c->back_pre13}, {"back_pre2", c->back_pre2}, {"back_ao", c->back_ao}, {"back_ao2", c->back_ao2}, {"use_prefill_mq", c->use_prefill_mq}, {"attn_split", c->attn_split},
         {"use_qk_mfma", c->use_qk_mfma}, {"use_p2p", c->p2p}, {"fold_xchg", c->fold_xchg}, {"tp_fuse_attn", c->tp_fuse_attn}, {"tp_fuse_ffn", c->tp_fuse_ffn}, {"cu_parts", c->cu_parts}, {"fold_active", (c->world > 1 && c->p2p && c->grp_fold) ? 1 : 0}, {"span_active", (c->world > 1 && c->p2p && c->grp_span) ? 1 : 0}, {"tp_trust_fused", c->tp_trust_fused}, {"force_tp", c->force_tp},
-        {"tp_fuse_layers", c->tp_fuse_layers}, {"grp_tp_fuse_layers", (c->world > 1 && c->p2p && c->grp_tpl) ? 1 : 0}, {"tp_layers_active", (c->world > 1 && c->p2p && c->grp_tpl && (c->la_valid[0] || c->la_valid[1])) ? (c->la_valid[0] && c->la_ok[0] ? 1 : 0) | (c->la_valid[1] && c->la_ok[1] ? 2 : 0) : -1},   /* the rank-spanning k_layers was planned: bit 0 one workgroup per head, bit 1 split heads */ {"grp_tp_fuse_attn", c->grp_tpfa}, {"grp_tp_fuse_ffn", c->grp_tpff}, {"grp_attn_split", c->grp_split}, {"resident", c->resident}, {"fallback", c->fell_back},
+        {"tp_fuse_layers", c->tp_fuse_layers}, {"tp_fence", c->tp_fence}, {"tp_fence_active", c->tp_fence >= 0 ? c->tp_fence : (c->ranks_on_device == c->world ? 0 : 3)}, {"grp_tp_fuse_layers", (c->world > 1 && c->p2p && c->grp_tpl) ? 1 : 0}, {"tp_layers_active", (c->world > 1 && c->p2p && c->grp_tpl && (c->la_valid[0] || c->la_valid[1])) ? (c->la_valid[0] && c->la_ok[0] ? 1 : 0) | (c->la_valid[1] && c->la_ok[1] ? 2 : 0) : -1},   /* the rank-spanning k_layers was planned: bit 0 one workgroup per head, bit 1 split heads */ {"grp_tp_fuse_attn", c->grp_tpfa}, {"grp_tp_fuse_ffn", c->grp_tpff}, {"grp_attn_split", c->grp_split}, {"resident", c->resident}, {"fallback", c->fell_back}, {"fallback_active", c->fb_active ? 1 : 0},
         {"ao_active", c->la_ok[0] ? (c->la_p[0].ao_o ? 1 : 0) | (c->la_p[0].ao_2 ? 2 : 0) : -1},      // which hand-offs of the token's launch (short contexts) are consumed in arrival order; -1: that launch was not planned (yet)
         {"token_path", (c->world == 1 ? ((c->fuse_attn_o ? 1 : 0) | (c->fuse_ffn ? 2 : 0) | (c->fuse_attn_o && c->fuse_qkv == 1 ? 4 : 0) | (c->fuse_attn_o && c->fuse_qkv >= 2 ? 8 : 0) | (c->fuse_back && c->fuse_attn_o && c->fuse_ffn ? (c->fuse_layer ? 128 + 256 + (c->fuse_token ? 512 + (c->fuse_tail && c->tail_ok[0] ? 1024 : 0) : 0) : 128) : 0)) : 0) | (c->attn_split ? 64 : 0)},
     };
@@ -666,7 +719,7 @@ int flm_query(flm_ctx* c, const char* key, int* value) {
     return fail(c, FLM_ERR_INVALID, "query: unknown key");
 }
 
-int flm_upload_tensor(flm_ctx* c, int kind, int layer, int src_qt, const void* values, const float* scales, int rows, int cols) {
+static int upload_tensor_impl(flm_ctx* c, int kind, int layer, int src_qt, const void* values, const float* scales, int rows, int cols) {
     if (c) { c->st_ready = false; c->la_valid[0] = c->la_valid[1] = false; }       // (the device-resident argument blocks of k_layers hold pointers into the tensors -- the embedding table's is re-allocated below -- and depend on their types)
     if (!c || !values) return FLM_ERR_INVALID;
     HIPC(c, hipSetDevice(c->device));
@@ -724,6 +777,23 @@ int flm_upload_tensor(flm_ctx* c, int kind, int layer, int src_qt, const void* v
         return r; }
     default: return fail(c, FLM_ERR_INVALID, "unknown tensor kind");
     }
+}
+int flm_upload_tensor(flm_ctx* c, int kind, int layer, int src_qt, const void* values, const float* scales, int rows, int cols) {
+    const int r = upload_tensor_impl(c, kind, layer, src_qt, values, scales, rows, cols);
+    if (r == FLM_OK && model_complete(c)) {
+        // the model's last tensor (or a replacement) has arrived: k_layers' argument blocks and the token graphs are built NOW, not inside the first forward
+        // (transformer.cpp:110-130: no allocation during inference).  An error here is not the upload's: it resurfaces at the first forward.
+        const std::string err0 = c->err, gerr0 = g_last_error;
+        if (prepare_all(c) != FLM_OK) { c->err = err0; g_last_error = gerr0; (void)hipGetLastError(); }
+    }
+    return r;
+}
+
+int flm_prepare(flm_ctx* c) {
+    if (!c) return FLM_ERR_INVALID;
+    HIPC(c, hipSetDevice(c->device));
+    if (!model_complete(c)) return fail(c, FLM_ERR_STATE, "prepare before all tensors were uploaded");
+    return prepare_all(c);
 }
 
 int flm_reset_kv(flm_ctx* c) {
@@ -812,7 +882,7 @@ int flm_forward(flm_ctx* c, const int32_t* tokens, int n, int pos, float* logits
         r = feed(c, tokens, n, pos, 0); if (r) return r;
         HIPC(c, hipMemcpyAsync(logits_host, c->logits, (size_t)c->d.vocab_size * 4, hipMemcpyDeviceToHost, c->stream));
         HIPC(c, hipStreamSynchronize(c->stream));
-        r = xwg_check(c); if (r != FLM_RETRY) return r;
+        r = xwg_check(c); if (r != FLM_RETRY) return r ? r : maybe_recover(c, n);
     }
     return fail(c, FLM_ERR_HIP, "cross-workgroup wait timed out twice");
 }
@@ -824,7 +894,7 @@ int flm_forward_argmax(flm_ctx* c, const int32_t* tokens, int n, int pos, int32_
         r = feed(c, tokens, n, pos, 1); if (r) return r;
         HIPC(c, hipMemcpyAsync(next_token, c->out_tokens_dev, 4, hipMemcpyDeviceToHost, c->stream));
         HIPC(c, hipStreamSynchronize(c->stream));
-        r = xwg_check(c); if (r != FLM_RETRY) return r;
+        r = xwg_check(c); if (r != FLM_RETRY) return r ? r : maybe_recover(c, n);
     }
     return fail(c, FLM_ERR_HIP, "cross-workgroup wait timed out twice");
 }
@@ -846,7 +916,7 @@ int flm_decode_greedy(flm_ctx* c, int32_t first_token, int pos, int n_steps, int
         int r = decode_loop(c, first_token, pos, n_steps, nullptr, nullptr); if (r) return r;
         HIPC(c, hipMemcpyAsync(out_tokens, c->out_tokens_dev, sizeof(int) * n_steps, hipMemcpyDeviceToHost, c->stream));
         HIPC(c, hipStreamSynchronize(c->stream));
-        r = xwg_check(c); if (r != FLM_RETRY) return r;
+        r = xwg_check(c); if (r != FLM_RETRY) return r ? r : maybe_recover(c, n_steps);
     }
     return fail(c, FLM_ERR_HIP, "cross-workgroup wait timed out twice");
 }
@@ -862,6 +932,7 @@ int flm_decode_timed(flm_ctx* c, int32_t first_token, int pos, int n_steps, floa
         if (!r) r = xwg_check(c);
         if (r != FLM_RETRY) break;
     }
+    if (r == FLM_OK) return maybe_recover(c, n_steps);
     return r == FLM_RETRY ? fail(c, FLM_ERR_HIP, "cross-workgroup wait timed out twice") : r;
 }
 

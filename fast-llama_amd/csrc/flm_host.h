@@ -115,7 +115,8 @@ struct flm_ctx {
     int tp_fuse_layers = 1;                            // option "tp_fuse_layers" (round 6): ALL layers of a sharded token in one launch that spans the ranks (k_layers<.., TP>: the four hand-offs of a layer are
                                                        // flag rounds between the ranks' workgroups, the next phase's weights requested in front of each, exactly as on one GPU); needs what the
                                                        // rank-spanning launches need (grp_span) and ranks of identical geometry
-    int tp_fence = 3;                                  // tuning dial "tp_fence": bit 0 release fence in front of a cross-rank line, bit 1 acquire fence behind a cross-rank poll (k_layers<.., TP>)
+    int tp_fence = -1;                                 // option "tp_fence" (k_layers<.., TP>): bit 0 a system-scope release fence in front of a cross-rank line, bit 1 an acquire fence behind a cross-rank poll;
+                                                       // -1 (default): none where every rank of the group lives on THIS device (one memory system), both between distinct devices
     size_t x_tlines_off = 0;                           // ... its flag region in the exchange buffer: [heads: 256 lines][x1, hd, x, cls: world x 256 lines each]
     char* peer[8] = {nullptr}; bool peer_opened[8] = {false}; int p2p = 0;
     // what the tensor-parallel GROUP runs, agreed at flm_p2p_import from every rank's blob (the ranks' hand-off protocols must match or they wait on flags nobody raises):
@@ -129,7 +130,8 @@ struct flm_ctx {
     int attn_split = 1;                                // option "attn_split": 1 = spread a head over 4 workgroups from kSplitFrom (128) positions on, 0 = never, >= 2 = always that many
     unsigned* eng_base = nullptr;                      // the token's epoch base (device memory, advanced by k_embed): the tensor-parallel exchanges' flag values count from it
     int resident = 1;                                  // the census at create saw every workgroup of a cu_count-wide launch co-resident
-    int fell_back = 0;                                 // a cross-workgroup wait timed out once: fused launches off for good
+    int fell_back = 0;                                 // how many times a cross-workgroup wait timed out and the context went to one kernel per phase ("fallback")
+    bool fb_active = false; int fb_tokens = 0; int fb_saved[6] = {0, 0, 0, 0, 0, 0};   // ... it is there now / tokens since / the launch structure it had (restored when the census passes again: maybe_recover)
     int trace_class = -1; unsigned long long* trace = nullptr;   // FLM_ABLATE builds: GEMV timeline of one kernel class
     std::map<int, hipGraphExec_t> graphs;             // key = with_cls*4 + advance
     std::vector<TimedLaunch>* timing = nullptr;

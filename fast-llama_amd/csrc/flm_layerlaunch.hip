@@ -84,7 +84,7 @@ int plan_layer(flm_ctx* c, int l, bool with_qkv, int G, LayerArgs& A, BackArgs& 
         const unsigned per = (unsigned)c->world * kTpLinesPerRank * 16;
         t.off_h = 0; t.off_x = kTpLinesPerRank * 16; t.off_hd = t.off_x + per; t.off_x2 = t.off_hd + per; t.off_cls = t.off_x2 + per;
         t.head_line0 = c->plan.head_begin * G; t.n_heads_all = d.n_heads * G;
-        t.base = c->eng_base; t.fence = c->tp_fence;
+        t.base = c->eng_base; t.fence = c->tp_fence >= 0 ? c->tp_fence : (c->ranks_on_device == c->world ? 0 : 3);
         t.abort_off = (int)(((long long)c->x_flags_off + (long long)kXchgAbortLine * 64 - (long long)c->x_tlines_off) / 4);      // (the group's one abort line: in the exchange flags' region, in front of this one)
         unsigned* mine = t.peer[c->rank];
         p.flag_h = mine + t.off_h; p.flag_x = mine + t.off_x; p.flag_hd = mine + t.off_hd; p.flag_x2 = mine + t.off_x2;

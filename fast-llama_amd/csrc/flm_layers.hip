@@ -25,11 +25,9 @@ int layers_prepare(flm_ctx* c, int G) {
         if (r) return r;
         c->la_p[key] = p; c->la_grid[key] = grid; c->la_r2[key] = r2;
     }
-    if (!c->la_dev[key]) HIPC(c, hipMalloc((void**)&c->la_dev[key], sizeof(LayerArgs) * (size_t)L));
     HIPC(c, hipMemcpyAsync(c->la_dev[key], host.data(), sizeof(LayerArgs) * (size_t)L, hipMemcpyHostToDevice, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));                                           // (host goes out of scope)
     if (tail.gridc > 0) {   // the one-launch token's argument block (every layer planned with the classifier's layout below the stash: the same st_base throughout)
-        if (!c->tail_dev[key]) HIPC(c, hipMalloc((void**)&c->tail_dev[key], sizeof(TailArgs)));
         HIPC(c, hipMemcpyAsync(c->tail_dev[key], &tail, sizeof(TailArgs), hipMemcpyHostToDevice, c->stream));
         HIPC(c, hipStreamSynchronize(c->stream));
         c->tail_ok[key] = true;

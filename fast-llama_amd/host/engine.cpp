@@ -1,4 +1,5 @@
 #include "engine.h"
+#include <algorithm>
 
 #include <stdio.h>
 #include <string.h>
@@ -69,42 +70,62 @@ bool GpuTransformer::connect_ranks() {
     return true;
 }
 
+// The group's launch structure.  Default: what the LIBRARY takes by itself -- between distinct devices the conservative structure (a flag round behind a kernel boundary, release /
+// acquire fences), on one device the folded / rank-spanning launches.  The faster structures between devices rely on system-scope store / flag ordering over xGMI that the build box could
+// only rehearse between CU partitions of one GPU, and a memory-ordering race is rare: one matching token verifies nothing.  They are therefore OPT-IN (FLM_TP_CALIBRATE=1 in the
+// environment): every candidate must then reproduce the conservative structure's ids over a 96-token greedy decode AND its last logits bit for bit on every rank, is timed on the
+// device (flm_decode_timed: HIP events, median of three runs of 32 tokens) and replaces the incumbent only if at least 2 % faster.  A candidate that fails in any way other than a
+// mismatch (a time-out raises the group's abort line on every peer: the contexts cannot be used any more) is fatal -- load() fails instead of returning a poisoned group.
 bool GpuTransformer::calibrate_structure() {
-    struct Cand { const char* name; int trust, ffn; };
-    const Cand cands[] = {{"exchange launches", 0, 0}, {"folded exchanges, QKV + attention + Wo across ranks", 1, 0}, {"folded exchanges, + FFN13 + FFN2 across ranks", 1, 1}};
-    const int world = (int)_ctxs.size(), V = _cfg.vocab_size;
+    const char* env = getenv("FLM_TP_CALIBRATE");
+    if (!env || !env[0] || env[0] == '0') { _tp_structure = "library default"; return true; }
+    struct Cand { const char* name; int trust, ffn, layers, fence; };
+    const Cand cands[] = {{"exchange launches", 0, 0, 0, -1}, {"folded exchanges, QKV + attention + Wo across ranks", 1, 0, 0, -1},
+                          {"all layers in one rank-spanning launch, fenced flags", 1, 0, 1, 3}, {"all layers in one rank-spanning launch", 1, 0, 1, 0},
+                          {"folded exchanges, + FFN13 + FFN2 across ranks", 1, 1, 0, -1}};
+    const int world = (int)_ctxs.size(), V = _cfg.vocab_size, kVerify = 96 < _cfg.max_seq_len - 2 ? 96 : _cfg.max_seq_len - 2, kTime = kVerify < 32 ? kVerify : 32;
     auto apply = [&](const Cand& c) {
         for (int r = 0; r < world; ++r)
-            if (flm_set_option(_ctxs[r], "tp_trust_fused", c.trust) != FLM_OK || flm_set_option(_ctxs[r], "tp_fuse_ffn", c.ffn) != FLM_OK) { _err = std::string("set_option: ") + flm_last_error(_ctxs[r]); return false; }
+            if (flm_set_option(_ctxs[r], "tp_trust_fused", c.trust) != FLM_OK || flm_set_option(_ctxs[r], "tp_fuse_ffn", c.ffn) != FLM_OK ||
+                flm_set_option(_ctxs[r], "tp_fuse_layers", c.layers) != FLM_OK || flm_set_option(_ctxs[r], "tp_fence", c.fence) != FLM_OK) { _err = std::string("set_option: ") + flm_last_error(_ctxs[r]); return false; }
         return connect_ranks();
     };
-    // one token (BOS at position 0) twice on a cleared cache: the first run captures the graphs, the second is timed; rank 0's logits are the verdict
-    auto probe = [&](std::vector<float>& logits, double& us) {
+    // BOS at position 0, then kVerify greedy tokens: every rank's ids and its last logits are the verdict; then the device time of kTime tokens (median of three)
+    struct Probe { std::vector<int32_t> ids; std::vector<float> logits; double us = 0.0; };
+    auto probe = [&](Probe& p) -> int {     // 0 ok, 1 the ranks disagree among themselves, -1 an error (fatal for the group)
+        std::vector<std::vector<int32_t>> ids(world, std::vector<int32_t>(kVerify));
         std::vector<std::vector<float>> lg(world, std::vector<float>(V));
         const int32_t tok = 1;
-        for (int rep = 0; rep < 2; ++rep) {
-            if (on_all([&](int r) { return flm_reset_kv(_ctxs[r]); }) != FLM_OK) return false;
-            const auto t0 = std::chrono::steady_clock::now();
-            if (on_all([&](int r) { return flm_forward(_ctxs[r], &tok, 1, 0, lg[r].data()); }) != FLM_OK) return false;
-            us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (on_all([&](int r) { return flm_reset_kv(_ctxs[r]); }) != FLM_OK) return -1;
+        if (on_all([&](int r) { int rc = flm_decode_greedy(_ctxs[r], tok, 0, kVerify, ids[r].data()); if (rc == FLM_OK) rc = flm_forward(_ctxs[r], &ids[r][kVerify - 1], 1, kVerify, lg[r].data()); return rc; }) != FLM_OK) return -1;
+        for (int r = 0; r < world; ++r) { int fb = 0; flm_query(_ctxs[r], "fallback", &fb); if (fb) { _err = "a cross-workgroup wait timed out"; return -1; } }
+        for (int r = 1; r < world; ++r) if (ids[r] != ids[0] || memcmp(lg[r].data(), lg[0].data(), (size_t)V * 4) != 0) return 1;
+        std::vector<double> t;
+        for (int rep = 0; rep < 3; ++rep) {
+            std::vector<float> ms(world, 0.f);
+            if (on_all([&](int r) { return flm_decode_timed(_ctxs[r], tok, 0, kTime, &ms[r]); }) != FLM_OK) return -1;
+            double m = 0; for (float x : ms) if (x > m) m = x;
+            t.push_back(m * 1000.0 / kTime);
         }
-        for (int r = 0; r < world; ++r) { int fb = 0; flm_query(_ctxs[r], "fallback", &fb); if (fb) { _err = "a cross-workgroup wait timed out"; return false; } }
-        logits = lg[0];
-        return true;
+        std::sort(t.begin(), t.end());
+        p.ids = ids[0]; p.logits = lg[0]; p.us = t[1];
+        return 0;
     };
-    std::vector<float> want, got;
-    double best_us = 0.0, us = 0.0;
+    Probe want, got;
     int best = 0;
-    if (!probe(want, best_us)) return false;                    // the conservative structure must work
-    for (int i = 1; i < 3; ++i) {
-        if (!apply(cands[i])) break;
-        if (!probe(got, us) || memcmp(got.data(), want.data(), (size_t)V * 4) != 0) {
-            if (_debug) fprintf(stderr, "tensor parallel: structure \"%s\" dropped (%s)\n", cands[i].name, _err.empty() ? "logits differ from the conservative structure's" : _err.c_str());
-            _err.clear();
-            break;                                               // (nothing is built on a structure that failed)
+    if (!apply(cands[0])) return false;
+    if (probe(want) != 0) { if (_err.empty()) _err = "tensor parallel: the conservative structure does not give the same results on every rank"; return false; }
+    double best_us = want.us;
+    for (int i = 1; i < (int)(sizeof cands / sizeof cands[0]); ++i) {
+        if (!apply(cands[i])) return false;
+        const int rc = probe(got);
+        if (rc < 0) { if (_err.empty()) _err = std::string("tensor parallel: structure \"") + cands[i].name + "\" failed: " + flm_last_error(_ctxs[0]); return false; }   // (the group may be poisoned: no way back)
+        if (rc > 0 || got.ids != want.ids || memcmp(got.logits.data(), want.logits.data(), (size_t)V * 4) != 0) {
+            if (_debug) fprintf(stderr, "tensor parallel: structure \"%s\" dropped (its ids / logits differ from the conservative structure's)\n", cands[i].name);
+            continue;
         }
-        if (_debug) fprintf(stderr, "tensor parallel: structure \"%s\": %.1f us per token against %.1f\n", cands[i].name, us, best_us);
-        if (us < best_us) { best_us = us; best = i; }
+        if (_debug) fprintf(stderr, "tensor parallel: structure \"%s\": %.1f us per token against %.1f\n", cands[i].name, got.us, best_us);
+        if (got.us < 0.98 * best_us) { best_us = got.us; best = i; }
     }
     if (!apply(cands[best])) return false;
     _tp_structure = cands[best].name;

@@ -12,11 +12,15 @@
  * transformer.h:101-110).  Independent ctxs (replicas / tensor-parallel ranks) are independent.
  * Ownership: the caller owns every host pointer (copied during the call); the ctx owns all device
  * memory, ALL of it allocated at flm_ctx_create / flm_upload_tensor time (prompt, output-id and batched-prefill buffers are
- * sized by max_seq_len) -- nothing is allocated inside flm_forward* / flm_decode_* (the reference's zero-allocation contract,
- * transformer.cpp:110-130).
- * Robustness: the fused attention + Wo launch hands data between workgroups of one kernel; if that hand-off ever times out
- * (a workgroup not resident because another process holds CUs) the call re-runs its work on one kernel per phase and still
- * returns FLM_OK with correct results; later calls stay on that path.
+ * sized by max_seq_len; the launches' argument blocks and every token graph the entry points replay are built when the model's
+ * last tensor arrives, at flm_p2p_import, or by flm_prepare) -- nothing is allocated inside flm_forward* / flm_decode_* (the
+ * reference's zero-allocation contract, transformer.cpp:110-130; tests/test_gpu_configs.py brackets the first calls with
+ * hipMemGetInfo and a hipMalloc interposer).  Exceptions, both off the steady path: after flm_set_option the graphs are
+ * re-instantiated by the next call (or by flm_prepare), and so they are when a context returns from a fallback.
+ * Robustness: the fused launches hand data between workgroups of one kernel; if a hand-off ever times out (a workgroup not
+ * resident because another process holds CUs) the call re-runs its work on one kernel per phase and still returns FLM_OK with
+ * correct results; the context stays on that path for 64 tokens, then takes the census again and, if every workgroup is
+ * resident, returns to the launch structure it had ("fallback" counts the episodes, "fallback_active" = on that path now).
  */
 #ifndef FLM_GPU_H
 #define FLM_GPU_H
@@ -97,6 +101,10 @@ const char* flm_last_error(const flm_ctx* ctx);   /* ctx may be NULL: last creat
  * keeps its row shard. */
 int  flm_upload_tensor(flm_ctx* ctx, int kind, int layer, int src_qtype,
                        const void* values, const float* scales, int rows, int cols);
+/* Build everything the token entry points use beyond the buffers -- the launches' argument blocks and the hipGraphs of every token form (parallel_thread_init's
+ * arena carving, transformer.cpp:110-130,253-384) -- so that the calls below allocate nothing.  Done automatically when the last tensor arrives and at flm_p2p_import;
+ * call it after flm_set_option if the next forward must not pay for it.  FLM_ERR_STATE before the model is complete. */
+int  flm_prepare(flm_ctx* ctx);
 
 /* ---- the hot path: replaces ParallelTransformer::forward (transformer.h:99, transformer.cpp:105-161).
  * tokens[n] enter at absolute position pos (pos = tokens already in the KV cache);
@@ -165,6 +173,12 @@ int  flm_debug_read(flm_ctx* ctx, int what, int layer, float* out, size_t n);
  *   "fold_xchg"      0 = every peer-to-peer exchange's flag round as a launch of its own (k_xchg); default 1: inside the launch that consumes the vector
  *   "tp_fuse_attn"   folded exchanges: 1 = attention + Wo in ONE launch across the ranks, 2 (default) = with the QKV GEMV in front, 0 = separate launches
  *   "tp_fuse_ffn"    the same for FFN13 + FFN2 (default 0)
+ *   "tp_fuse_layers" 1 (default) = ALL layers of a sharded token in one launch per rank that spans the ranks (k_layers<.., TP>: the single-GPU persistent launch with the
+ *                    reference's row split across the ranks; the four hand-offs of a layer are flag rounds between the ranks' workgroups); where the group can span
+ *                    (folded exchanges, every rank's workgroups resident, identical geometry), else the per-layer launches above; before flm_p2p_export
+ *   "tp_fence"       that launch's system-scope fences: bit 0 release in front of a cross-rank flag line, bit 1 acquire behind a cross-rank poll; -1 (default) = none between
+ *                    ranks of ONE device, both between distinct devices (every cross-rank access is itself a system-scope atomic or a coherent load: the fences are belt and braces,
+ *                    and cost ~20 us per hand-off)
  *   "tp_trust_fused" 1 = between DISTINCT devices too, run the folded exchanges / rank-spanning launches (default 0: the k_xchg launches; before flm_p2p_export)
  *   "cu_parts"       n = confine the context's stream to 1/n of the device's CUs (part rank % n): several ranks on ONE GPU (tests)
  *   "force_tp"       1 = a context created with an RCCL id and world == 1 takes the sharded token path (RCCL exchanges over a 1-rank communicator; tests)
@@ -175,8 +189,9 @@ int  flm_set_option(flm_ctx* ctx, const char* key, int value);
  * (its current value; the dials of csrc/flm_tuning.h too), "tuning", and
  *   "resident"  1 = the census at flm_ctx_create saw one 1024-thread workgroup per CU co-resident (the fused launches wait across workgroups;
  *               0 = they were switched off up front: a masked / partitioned device),
- *   "fallback"  1 = a cross-workgroup wait timed out during some call and the context fell back to one kernel per phase for good (flm_gpu.hip
- *               xwg_check; the call itself was re-run and returned correct results),
+ *   "fallback"  how many times a cross-workgroup wait timed out during a call and the context fell back to one kernel per phase (flm_gpu.hip
+ *               xwg_check; the call itself was re-run and returned correct results), "fallback_active" 1 = it is on that path now (after 64 tokens the census
+ *               runs again and a context whose workgroups are all resident returns to the launch structure it had),
  *   "token_path" bit 0 attention + Wo fused, bit 1 FFN13 + FFN2 fused, bit 2 QKV joins the attention's launch at long contexts, bit 3 the same
  *               at every context, bit 6 heads split over workgroups at long contexts, bit 7 attention .. FFN2 in one launch (k_attn_ffn), bit 8 with the QKV GEMV in front
  *               (the whole layer in one launch), bit 9 all layers of the token in one launch (k_layers), bit 10 a greedy decode token is ONE launch (embedding row, layers,

@@ -415,7 +415,7 @@ def test_one_launch_token_after_the_embedding_table_is_replaced(gpu):
 
 def test_a_wait_that_gives_up_is_retried_on_one_kernel_per_phase(gpu):
     """the error path of the in-launch hand-offs: a wait that times out (20 ms) raises a flag, the launch runs through, the host re-runs the call on one kernel per phase and returns
-    CORRECT results with FLM_OK; the context stays on the per-phase kernels ("fallback" 1).  The flag is raised by hand here ("inject_wait_failure", a tuning-mode dial): every poll of
+    CORRECT results with FLM_OK; the context stays on the per-phase kernels for 64 tokens ("fallback" counts the episodes, "fallback_active" 1), then takes the census again and returns.  The flag is raised by hand here ("inject_wait_failure", a tuning-mode dial): every poll of
     the next call's launches returns at once, so what they compute is garbage -- ids, logits and cache rows must nevertheless be the oracle's after the call."""
     cfg = synth.make_config("7B", ff.QT_INT8); cfg.n_layers = 2
     tensors = synth.make_tensors(cfg, seed=59)
@@ -437,6 +437,17 @@ def test_a_wait_that_gives_up_is_retried_on_one_kernel_per_phase(gpu):
     ctx.reset_kv()
     assert ctx.forward_argmax(prompt, 0) == first
     assert list(ctx.decode_greedy(first, len(prompt), 10)) == want_ids          # ... and the context goes on, on one kernel per phase
+    assert ctx.query("fallback_active") == 1
+    # ... but not for good: after 64 tokens on that path the census runs again, and a context whose workgroups are all resident returns to the launch structure it had
+    for _ in range(6):
+        ctx.reset_kv()
+        assert ctx.forward_argmax(prompt, 0) == first
+        assert list(ctx.decode_greedy(first, len(prompt), 10)) == want_ids
+    assert ctx.query("fallback") == 1 and ctx.query("fallback_active") == 0 and (ctx.query("token_path") & 1024)     # one episode, over: the one-launch token is back
+    ctx.reset_kv()
+    assert ctx.forward_argmax(prompt, 0) == first
+    assert list(ctx.decode_greedy(first, len(prompt), 10)) == want_ids
+    assert bits_equal(ctx.debug_read("logits", 0, cfg.vocab_size), last)
     ctx.close()
 
 

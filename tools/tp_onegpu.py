@@ -12,8 +12,11 @@ cfg = synth.make_config("7B", ff.QT_INT8); cfg.n_layers = L
 tensors = synth.make_tensors(cfg, seed=1, share_layers=True)
 ctxs = [capi.Ctx(capi.desc_from_config(cfg), device=0, rank=r, world=world, comm_id=None) for r in range(world)]
 for c in ctxs: c.upload_all(tensors)
+fence = os.environ.get("FLM_TP_FENCE")    # the rank-spanning launch's fences (tuning dial "tp_fence": bit 0 release, bit 1 acquire; default 3)
 for c in ctxs:
     c.set_option("cu_parts", world)
+    if fence is not None:
+        c.set_option("tuning", 1); c.set_option("tp_fence", int(fence))
 capi.Ctx.regroup(ctxs)
 prompt = (np.arange(1, 9, dtype=np.int64) * 7919 % cfg.vocab_size).astype(np.int32)
 
