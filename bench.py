@@ -112,8 +112,10 @@ def host_cores():
         sockets = int(re.search(r"Socket\(s\):\s+(\d+)", out).group(1))
         cps = int(re.search(r"Core\(s\) per socket:\s+(\d+)", out).group(1))
         model = re.search(r"Model name:\s+(.*)", out).group(1).strip()
+        host_cores.sockets = sockets
         return sockets * cps, model
     except Exception:
+        host_cores.sockets = None
         return os.cpu_count() or 1, "unknown"
 
 
@@ -163,7 +165,11 @@ def cpu_baseline(cfg, budget_s=40.0):
     cores, model = host_cores()
     threads = max(1, min(cores, 64))
     ref_main = os.path.join(ROOT, "oracle", "_ref", "main")
-    res = {"unit": "tokens/s", "cores": threads, "host": model}
+    res = {"unit": "tokens/s", "cores": threads, "host": model, "host_sockets": getattr(host_cores, "sockets", None), "host_physical_cores_total": cores,
+           "host_logical_cpus": os.cpu_count()}
+    # what the number is: the reference's own binary, timed on a checkpoint written for TIMING -- the same tensor shapes, synthetic int8 weights, but every layer holds
+    # identical tensors (7 GB generated once instead of 32 times), so its ids are not the GPU checkpoint's; parity is pinned elsewhere (tests/golden, tests/test_gpu_configs.py)
+    kind_detail = "reference binary, timing-only checkpoint (identical layers)"
 
     def run_ref(L, n_tokens, nthreads=None, keep=False, reuse=False):
         nthreads = nthreads or threads
@@ -202,7 +208,7 @@ def cpu_baseline(cfg, budget_s=40.0):
                     res["j8"] = {"value": None, "sample": f"failed: {e}"}
                     if os.path.exists(f"/tmp/flm-bench-L{cfg.n_layers}.flm"):
                         os.remove(f"/tmp/flm-bench-L{cfg.n_layers}.flm")
-                res.update(value=1000.0 / t_tok, kind="reference",
+                res.update(value=1000.0 / t_tok, kind="reference", kind_detail=kind_detail,
                            sample=(f"reference binary (oracle/_ref/main, -O3 -march=x86-64-v3 -mfma, AVX2 kernels) -j {threads} -t 0 --mode bm --uma, the full "
                                    f"{cfg.n_layers}-layer LLaMA2-7B-shaped int8 .flm (synthetic weights, identical tensors in every layer), prompt 13 tokens + {ntok} "
                                    f"decode tokens: {t_tok:.2f} ms per output token (wall {wall:.0f}s incl. writing and loading the file)"))
@@ -213,7 +219,7 @@ def cpu_baseline(cfg, budget_s=40.0):
             t_layer = max((t4 - t2) / (Lb - La), 1e-6)
             t_cls = max(t2 - La * t_layer, 0.0)
             t_tok = t_cls + cfg.n_layers * t_layer
-            res.update(value=1000.0 / t_tok, kind="reference",
+            res.update(value=1000.0 / t_tok, kind="reference", kind_detail=kind_detail + ", 4- and 12-layer models extrapolated to 32",
                        sample=(f"reference binary (oracle/_ref/main, -O3 -march=x86-64-v3 -mfma, AVX2 kernels) -j {threads} -t 0 --mode bm, int8 .flm, "
                                f"7B-width synthetic models with {La} and {Lb} layers, {ntok} decode tokens each: {t2:.2f} / {t4:.2f} ms per token; "
                                f"t_layer={t_layer:.3f} ms, t_cls={t_cls:.3f} ms, extrapolated to 32 layers = {t_tok:.1f} ms/token "
@@ -480,6 +486,32 @@ def main():
                         "parity": lpar, "note": "device time of K steps between HIP events on the ctx stream; not part of `value`"}
         except Exception as e:  # noqa: BLE001
             long_ctx = {"error": str(e)}
+    # SURVEY.md 8d's decode protocol beside the driver's K timed steps (20 steps at positions 14..33 flatter the token by ~3 %: fewer cache rows): prompt = BOS + 8 tokens, 128 greedy
+    # steps with one event per token, the first 8 discarded, mean and p50 over the other 120 (positions 17..136), with that span's own roofline fraction.  Outside the timed region of `value`.
+    decode_128 = None
+    if mode == "single" and args.pos is None and rank == 0:
+        try:
+            p9 = prompt_for(0)
+            ctx.reset_kv(); f9 = ctx.forward_argmax(p9, 0)
+            d8 = ctx.decode_greedy(f9, len(p9), 8)                                   # the 8 discarded steps
+            p17 = len(p9) + 8
+            ctx.decode_greedy(int(d8[-1]), p17, 120)                                 # (untimed pass over the span: every chunk graph it replays has been launched once)
+            ms120 = ctx.decode_timed(int(d8[-1]), p17, 120)                          # the mean: device time of the 120 tokens between two HIP events (chunk graphs, as the headline)
+            i128 = [int(f9)] + [int(x) for x in d8] + [int(x) for x in ctx.last_tokens(120)]
+            e120 = np.asarray(ctx.decode_timed_each(int(d8[-1]), p17, 120), dtype=np.float64)    # the p50: one event per token (single-token graphs + ~3 us of event per token)
+            midp = p17 + 60
+            b128 = token_bytes(cfg, midp, esz)
+            par128 = None
+            if gold is not None:
+                nchk = min(len(i128), len(gold))
+                par128 = {"ids_checked": nchk, "match": i128[:nchk] == gold[:nchk]}
+            decode_128 = {"protocol": "SURVEY.md 8d: BOS + 8 prompt tokens, 128 greedy steps, first 8 discarded", "positions": f"{p17}..{p17 + 119}",
+                          "tokens_per_s_mean": round(120.0 / (ms120 / 1e3), 2), "tokens_per_s_p50": round(1e3 / float(np.median(e120)), 2),
+                          "ms_per_step_mean": round(ms120 / 120.0, 4), "ms_per_step_p50": round(float(np.median(e120)), 4),
+                          "bytes_per_token": int(b128), "token_roofline_frac": round(b128 * (120.0 / (ms120 / 1e3)) / 1e9 / HBM_PEAK_GBS, 4),
+                          "parity": par128, "note": "mean: device time of the 120 kept tokens between two HIP events on the ctx stream; p50: one event per token (adds a few us to each); not part of `value`"}
+        except Exception as e:  # noqa: BLE001
+            decode_128 = {"error": str(e)}
     # a third operating point, outside the timed region of `value`: BASELINE config 5's prompt path at this run's quant type -- a 512-token prompt through
     # the batched kernels (int8 GEMM tiles on the matrix cores, fp32-MFMA QK^T / PV), median of 3 forwards on a cleared cache
     prefill = None
@@ -571,7 +603,7 @@ def main():
     split_now = bool(token_path.get("heads_split_at_long_contexts")) and mid_pos + 1 >= 128      # (the launch's SPLIT instantiation: a head spread over hs / 32 workgroups)
     # (round 5: k_layers<QT, XR2, SPLIT, R5>, R5 = 3 where the launch consumes Wo's / FFN2's activation in arrival order -- the instantiation this run launched, not just any in the library)
     r5_now = 3 if (dom in ("layers", "token") and ao_active > 0) else 0
-    dom_regex = {"token": rf"k_layers<{qn}, \d+, {'true' if split_now else 'false'}, 3, true>", "layers": rf"k_layers<{qn}, \d+, {'true' if split_now else 'false'}, {r5_now}, false>", "layer": rf"k_attn_ffn<{qn}, \d+, true, false>", "back": rf"k_attn_ffn<{qn}, \d+, false, false>", "ffn": rf"k_ffn<{qn},"}.get(dom, rf"k_gemv<{qn}, 2, 2,")
+    dom_regex = {"token": rf"k_layers<{qn}, \d+, {'true' if split_now else 'false'}, {r5_now}, true>", "layers": rf"k_layers<{qn}, \d+, {'true' if split_now else 'false'}, {r5_now}, false>", "layer": rf"k_attn_ffn<{qn}, \d+, true, false>", "back": rf"k_attn_ffn<{qn}, \d+, false, false>", "ffn": rf"k_ffn<{qn},"}.get(dom, rf"k_gemv<{qn}, 2, 2,")
     if args.shape == "7B":
         traffic, traffic_src, traffic_note = pmc_traffic(dom_regex, capi.LIB_PATH)
     else:   # (the committed PMC summaries were collected on the 7B-shaped model: a launch of the same kernel on another shape moves other bytes)
@@ -617,6 +649,8 @@ def main():
                             "(k_ffn) instead of ffn13 + ffn2, and where qkv_attn_wo (k_qkv_attn_o: contexts from 128 positions on) is listed, that instead of qkv + attn_wo; the "
                             "per-phase classes (qkv .. ffn2) are timed beside them for reference",
         }
+        if decode_128 is not None:
+            line["decode_128"] = decode_128
         if long_ctx is not None:
             line["long_context"] = long_ctx
         if prefill is not None:
@@ -751,6 +785,7 @@ def run_tp_structures(capi, ctx, cfg, args, prompt, barrier, gold, rank, world, 
     results, measured, seen = [], {}, {}
     forced = os.environ.get("FLM_TP_TRUST_FUSED")
     todo = TP_STRUCTURES if forced is None else tuple(x for x in TP_STRUCTURES if x[1]["tp_trust_fused"] == int(forced))[:1] or TP_STRUCTURES[:1]
+    base_ids = None      # (no golden ids for the shape: the first -- conservative -- structure's ids)
     for name, opts in todo:
         rec = {"name": name, "options": dict(opts)}
         ok, m = 1, None
@@ -778,6 +813,8 @@ def run_tp_structures(capi, ctx, cfg, args, prompt, barrier, gold, rank, world, 
             m = time_decode(ctx, cfg, args, prompt, barrier, gold)
             if gold is not None and m["parity"]["match"] is not True:
                 ok = 0; rec["error"] = f"rank {rank}: ids differ from the reference's at generated token {m['parity'].get('first_mismatch')}"
+            elif gold is None and base_ids is not None and list(m["ids"]) != list(base_ids):      # no golden ids for this shape: the conservative structure's ids are what the others must reproduce
+                ok = 0; rec["error"] = f"rank {rank}: ids differ from the conservative structure's"
             elif ctx.query("fallback"):
                 ok = 0; rec["error"] = f"rank {rank}: a cross-workgroup wait timed out (the call was re-run on one kernel per phase)"
         except Exception as e:  # noqa: BLE001
@@ -795,8 +832,13 @@ def run_tp_structures(capi, ctx, cfg, args, prompt, barrier, gold, rank, world, 
                 rec.update(exchange_us=round(ar[0], 2), exchange_launches_per_token=ar[1])
             except Exception as e:  # noqa: BLE001
                 rec["exchange_us_error"] = str(e)
-        rec["verified"] = verified
-        rec["verified_against"] = ("the reference's golden ids on every rank (all-reduce MIN)" if gold is not None else "nothing: no golden ids for this shape")
+        if gold is None and base_ids is None:      # nothing was checked: the conservative structure is the baseline the others are compared with -- say so instead of "verified"
+            rec["verified"] = "baseline-unverified" if verified else False
+            rec["verified_against"] = "nothing: no golden ids for this shape; this structure's ids are the baseline of the others"
+            if verified and m is not None: base_ids = list(m["ids"])
+        else:
+            rec["verified"] = verified
+            rec["verified_against"] = ("the reference's golden ids on every rank (all-reduce MIN)" if gold is not None else "the conservative structure's ids on every rank (all-reduce MIN); no golden ids for this shape")
         if not verified:
             rec.setdefault("error", "another rank's ids differed, or it gave up")
         results.append(rec); seen[sig] = rec

@@ -20,7 +20,7 @@ KCLASSES = ("embed", "qkv", "attn", "attn_o", "ffn13", "ffn2", "cls", "argmax", 
 # every symbol include/flm_gpu.h declares (tests check the library exports all of them)
 SYMBOLS = (
     "flm_comm_unique_id", "flm_ctx_create", "flm_ctx_destroy", "flm_p2p_export", "flm_p2p_import", "flm_last_error", "flm_upload_tensor",
-    "flm_forward", "flm_forward_argmax", "flm_decode_greedy", "flm_decode_timed", "flm_decode_timed_each", "flm_last_tokens", "flm_reset_kv", "flm_sync",
+    "flm_forward", "flm_forward_argmax", "flm_decode_greedy", "flm_decode_timed", "flm_decode_timed_each", "flm_last_tokens", "flm_reset_kv", "flm_prepare", "flm_sync",
     "flm_kernel_times", "flm_kernel_bytes", "flm_set_option", "flm_query", "flm_debug_read",
     "flm_op_quantize", "flm_op_matmul_q", "flm_op_rmsnorm", "flm_op_swiglu", "flm_op_rope", "flm_op_softmax",
     "flm_op_attention", "flm_op_expf", "flm_op_math", "flm_op_square_sum", "flm_op_argmax", "flm_op_handoff_litmus", "flm_plan_shards",
@@ -168,6 +168,10 @@ class Ctx:
 
     def reset_kv(self):
         _check(lib().flm_reset_kv(self._h), self._h)
+
+    def prepare(self):
+        """build every argument block / token graph now (flm_prepare): nothing is left to allocate inside a forward"""
+        _check(lib().flm_prepare(self._h), self._h)
 
     def sync(self):
         _check(lib().flm_sync(self._h), self._h)

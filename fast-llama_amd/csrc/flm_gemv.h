@@ -307,6 +307,47 @@ __device__ __forceinline__ void gemv_preload(const GemvArgs& a, float4 (&xv)[XR 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Data-tagged granules (round 6; cdna_hip_programming.md G16 form R2): the residual stream crosses workgroups INSIDE k_layers' one-launch token as 8-byte {value, tag}
+// granules -- ONE aligned write-through store per element, the tag = the flag value the hand-off's line would have carried (epoch base + layer + 1: never repeats).  The
+// data is its own flag: the producer neither drains its stores nor raises a line, the consumer neither polls lines nor reads the vector behind them -- every thread re-reads
+// ITS four granules until their tags match (only the lanes whose granules are missing read again).  One round trip instead of drain + flag + look + read
+// (tools/ubench/allgather.hip).  A granule is written by one store and read by one 16-byte load of two whole granules: no ordering between stores is relied on.
+// ------------------------------------------------------------------------------------------
+typedef unsigned v4u_g __attribute__((ext_vector_type(4)));
+typedef unsigned long long granule_t;
+__device__ __forceinline__ void st_granule(granule_t* g, unsigned tag, float v) {
+    __hip_atomic_store(g, ((granule_t)tag << 32) | (granule_t)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_granule_value(const granule_t* g) { return __uint_as_float((unsigned)__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+// gemv_preload<.., PRO_RMSNORM_QUANT, 1, COH> on a granule vector (n <= 4 x 1024: one round): xv[0] = elements 4 tid .. 4 tid + 3 once their tags are `tag`; wv[0] = the norm weights.
+// A wait of ~20 ms raises *err (the host re-runs the call on one kernel per phase); a wait of this launch that has already given up is not waited for again.
+__device__ __forceinline__ void gemv_preload_granules(const GemvArgs& a, float4 (&xv)[1], float4 (&wv)[1], const granule_t* g, const unsigned tag, int* err) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<granule_t*>(g), 0, a.n * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.norm_w), 0, a.n * 4, 0x00020000);
+    const int e = threadIdx.x * 4;
+    const int gave_up = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+        const v4f u = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rn, e * 4, 0, 0));
+        wv[0] = make_float4(u.x, u.y, u.z, u.w);
+    }
+    v4u_g A = {0u, 0u, 0u, 0u}, C = {0u, 0u, 0u, 0u};
+    bool ok = e >= a.n;                                                        // (lanes past the vector: zeros, as the bounds-checked loads of gemv_preload deliver)
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (true) {
+        asm volatile("" ::: "memory");                                         // (the loads are re-issued every pass)
+        if (!ok) {
+            A = __builtin_bit_cast(v4u_g, __builtin_amdgcn_raw_buffer_load_b128(rg, e * 8, 0, kAuxCoherent));
+            C = __builtin_bit_cast(v4u_g, __builtin_amdgcn_raw_buffer_load_b128(rg, e * 8 + 16, 0, kAuxCoherent));
+            ok = A.y == tag && A.w == tag && C.y == tag && C.w == tag;
+        }
+        if (__all(ok) || gave_up) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    }
+    xv[0] = make_float4(__uint_as_float(A.x), __uint_as_float(A.z), __uint_as_float(C.x), __uint_as_float(C.z));
+}
+
 // One quantizer round of a 16-lane row: the lane owns elements e .. e+3, 16 consecutive lanes own one 64-group (quant::quantize, quant_operators.cpp:26-47:
 // scale = max|x| / F, q = (T)(x / scale)); the packed values go to xq[e ..], the group's scale to xs[e / 64].  Every lane of the row must call it (the group
 // maximum is a DPP butterfly); `act` = the lane's elements exist.
@@ -574,6 +615,9 @@ struct GemvCtx {
     Set setA, setB;
     bool stored;                                                               // this wave wrote results to global memory
     const float* resid_src;                                                    // EPI_RESIDUAL: the old value of out[row] is read from resid_src[row] instead (null: out itself)
+    // EPI_RESIDUAL inside k_layers' one-launch token (granules above): the old value comes from gsrc[row] (null: resid_src / out), the result goes to gdst[row] with tag gtag
+    // (null: out, as a plain write-through store)
+    const granule_t* gsrc; granule_t* gdst; unsigned gtag;
 
     static __device__ __forceinline__ u32 inv_of(u32 d) { return d > 1 ? 0xFFFFFFFFu / d + 1u : 0u; }
     static __device__ __forceinline__ u32 udiv(u32 x, u32 d, u32 inv) { return d > 1 ? __umulhi(x, inv) : x; }
@@ -624,7 +668,7 @@ struct GemvCtx {
         const u32 NM = TWO ? 2u : 1u;
         rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, (int)(NM * TRm * rowbytes), kRsrcFlags);
         rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.sW), 0, (int)(NM * TRm * sn * 4), kRsrcFlags);
-        stored = false; primedA = primedB = false; resid_src = nullptr;
+        stored = false; primedA = primedB = false; resid_src = nullptr; gsrc = nullptr; gdst = nullptr; gtag = 0;
         // the first two steps of every wave are fixed (wave, wave + 16): they are requested before any barrier (the stash's steps are the next numbers)
         if (write_ctr && threadIdx.x == 0) *reinterpret_cast<u32*>(lds + ctr_off) = 2 * kWavesPerBlock;
     }
@@ -732,7 +776,7 @@ struct GemvCtx {
         float resid = 0.f, rc = 0.f, rs = 0.f;
         const u32 row = pass * Rm + lane;                                      // row inside its matrix
         const bool rv = chain_wave && lane < Rm && row < TRm;
-        if constexpr (EPI == EPI_RESIDUAL) { if (rv) resid = ld_agent((resid_src ? resid_src : a.out) + row); }
+        if constexpr (EPI == EPI_RESIDUAL) { if (rv) resid = gsrc ? ld_granule_value(gsrc + row) : ld_agent((resid_src ? resid_src : a.out) + row); }
         if constexpr (EPI == EPI_ROPE_KV) {
             if (rv && row < (u32)(a.dim + a.kv_dim)) {
                 const u32 r2 = (row < (u32)a.dim ? row : row - a.dim) & ~1u;
@@ -813,6 +857,7 @@ struct GemvCtx {
         if constexpr (EPI == EPI_STORE || EPI == EPI_RESIDUAL) {
             if (rv) {
                 if constexpr (EPI == EPI_STORE) st_result(a, row, acc);
+                else if (gdst) st_granule(gdst + row, gtag, __fadd_rn(resid, acc));
                 else st_result(a, row, __fadd_rn(resid, acc));       // o.add(tmp, offset) transformer.cpp:465,493
             }
         } else if constexpr (EPI == EPI_SWIGLU) {

@@ -125,8 +125,11 @@ int xwg_check(flm_ctx* c) {
     // (on the context's own stream: a copy on the legacy stream synchronises with every blocking stream of the process -- and fails
     //  outright while another context's thread is capturing its token graph; seen once in ~10 runs of the threaded tensor-parallel tests)
     int e = 0;
-    HIPC(c, hipMemcpyAsync(&e, c->xwg_err, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    if (c->err_word_fresh) { e = c->err_word; c->err_word_fresh = false; }       // (d2h brought it along with the call's results)
+    else {
+        HIPC(c, hipMemcpyAsync(&e, c->xwg_err, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
+    }
     if (!e) return FLM_OK;
     HIPC(c, hipMemsetAsync(c->xwg_err, 0, 4, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
@@ -290,6 +293,8 @@ int alloc_run_bufs(flm_ctx* c) {
     c->prompt_cap = d.max_seq_len; c->out_cap = d.max_seq_len;
     HIPC(c, hipMalloc((void**)&c->prompt_dev, sizeof(int) * c->prompt_cap));
     HIPC(c, hipMalloc((void**)&c->out_tokens_dev, sizeof(int) * c->out_cap));
+    c->bounce_bytes = (size_t)d.vocab_size * 4; if (c->bounce_bytes < sizeof(int) * (size_t)d.max_seq_len) c->bounce_bytes = sizeof(int) * (size_t)d.max_seq_len;
+    HIPC(c, hipHostMalloc((void**)&c->bounce, c->bounce_bytes + 64, hipHostMallocDefault));          // (+ a line for the error word that rides along: d2h)
     // (tensor parallel: the full-width activations are regions of the exchange buffer, the rest is this rank's shard)
     const size_t cap = d.max_seq_len < 64 ? 64 : (size_t)d.max_seq_len, nmax = d.hidden_dim > d.dim ? d.hidden_dim : d.dim;
     if (!c->pf_in_xbuf) {
@@ -321,6 +326,7 @@ int set_state(flm_ctx* c, int pos, int tok, int step) {
 
 int check_ready(flm_ctx* c, int n, int pos) {
     if (!c) return FLM_ERR_INVALID;
+    c->err_word_fresh = false;                                                  // (an error word a previous call's read-back brought along says nothing about this call)
     if (!model_complete(c)) return fail(c, FLM_ERR_STATE, "forward before all tensors were uploaded");
     if (n < 1 || pos < 0 || pos + n > c->d.max_seq_len) return fail(c, FLM_ERR_INVALID, "tokens/pos outside [0, max_seq_len]");
     HIPC(c, hipSetDevice(c->device));
@@ -331,13 +337,51 @@ bool tp_prefill_capable(const flm_ctx* c) {
     return c->pf_in_xbuf && c->use_mfma && c->use_qk_mfma && c->use_pv_mfma && c->use_prefill_mq &&
            c->pf_scores && c->hs <= 128 && c->hs % 2 == 0 && c->dim_local % 32 == 0;
 }
+// device -> caller's buffer / caller's buffer -> device through the context's page-locked bounce buffer (flm_host.h: bounce), in pieces of its size; d2h synchronises.
+// The bytes are moved by a KERNEL on the context's stream (the bounce buffer is mapped into the device's address space), not by hipMemcpyAsync: a copy engine's queue is
+// shared by every context of the process and served in order, and a copy that waits for its stream's kernels blocks it -- under tensor parallelism (rank A's copy of token t
+// in front of rank B's copy of token t - 1, A's kernels waiting for B's next slice) that is a deadlock; the engines' queues are also created lazily (device memory taken
+// inside a forward: tools/alloc_diag.py).
+// (word_src -> word_dst: one more word from elsewhere -- the cross-workgroup error flag rides along with a call's results, so that xwg_check needs no copy of its own)
+__global__ void k_copy_words(const unsigned* __restrict__ src, unsigned* __restrict__ dst, unsigned n, const unsigned* __restrict__ word_src, unsigned* __restrict__ word_dst) {
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
+    if (word_src && blockIdx.x == 0 && threadIdx.x == 0) *word_dst = *word_src;
+}
+static int copy_words(flm_ctx* c, const void* src, void* dst, size_t bytes, bool with_err = false) {
+    const unsigned n = (unsigned)(bytes / 4);                                       // (ids, logits: whole words)
+    const unsigned blocks = n < 256 * 64 ? (n + 255) / 256 : 64;
+    hipLaunchKernelGGL(k_copy_words, dim3(blocks ? blocks : 1), dim3(256), 0, c->stream, (const unsigned*)src, (unsigned*)dst, n,
+                       with_err ? (const unsigned*)c->xwg_err : (const unsigned*)nullptr, (unsigned*)(c->bounce + c->bounce_bytes));
+    HIPC(c, hipGetLastError());
+    return FLM_OK;
+}
+int d2h(flm_ctx* c, void* dst, const void* src_dev, size_t bytes) {
+    for (size_t o = 0; o < bytes; o += c->bounce_bytes) {
+        const size_t nb = bytes - o < c->bounce_bytes ? bytes - o : c->bounce_bytes;
+        const bool last = o + nb >= bytes;
+        int r = copy_words(c, (const char*)src_dev + o, c->bounce, nb, last); if (r) return r;
+        HIPC(c, hipStreamSynchronize(c->stream));
+        memcpy((char*)dst + o, c->bounce, nb);
+        if (last) { c->err_word = *(volatile int*)(c->bounce + c->bounce_bytes); c->err_word_fresh = true; }   // (read behind the call's last kernel: what xwg_check looks at)
+    }
+    return FLM_OK;
+}
+int h2d(flm_ctx* c, void* dst_dev, const void* src, size_t bytes) {
+    for (size_t o = 0; o < bytes; o += c->bounce_bytes) {
+        const size_t nb = bytes - o < c->bounce_bytes ? bytes - o : c->bounce_bytes;
+        if (o) HIPC(c, hipStreamSynchronize(c->stream));                          // (the previous piece has left the buffer)
+        memcpy(c->bounce, (const char*)src + o, nb);
+        int r = copy_words(c, c->bounce, (char*)dst_dev + o, nb); if (r) return r;
+    }
+    return FLM_OK;
+}
 // feed tokens[0..n) sequentially (row i of the reference's batched prefill depends only on rows
 // <= i through the KV cache, so token-by-token evaluation performs the same per-row arithmetic).
 int feed(flm_ctx* c, const int32_t* tokens, int n, int pos, int final_advance) {
     int r;
     if (n > c->prompt_cap) return fail(c, FLM_ERR_INVALID, "more tokens than max_seq_len");
     for (int i = 0; i < n; ++i) if (tokens[i] < 0 || tokens[i] >= c->d.vocab_size) return fail(c, FLM_ERR_INVALID, "token id out of range");
-    HIPC(c, hipMemcpyAsync(c->prompt_dev, tokens, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));   // (the caller's buffer outlives the call: every entry point synchronises)
+    { const int rc = h2d(c, c->prompt_dev, tokens, sizeof(int) * (size_t)n); if (rc) return rc; }     // (prompt_cap <= the bounce buffer: one piece; the stream orders it in front of the kernels, nothing touches the buffer before the call's read-back)
     // batched: single GPU always; tensor parallel over the peer-to-peer exchange with the matrix-core kernels (the kernels that store their
     // column slices into the peers' buffers)
     const bool tp_ok = c->world > 1 && c->p2p && c->tp_prefill;          // agreed by all ranks at flm_p2p_import
@@ -473,6 +517,7 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
         HIPB(hipMalloc((void**)&c->xepoch, 64)); HIPB(hipMemsetAsync(c->xepoch, 0, 64, c->stream));
         HIPB(hipMalloc((void**)&c->ffn_counter, 64)); HIPB(hipMemsetAsync(c->ffn_counter, 0, 64, c->stream));
     }
+    HIPB(hipMalloc((void**)&c->xg, (size_t)2 * c->d.dim * sizeof(granule_t))); HIPB(hipMemsetAsync(c->xg, 0, (size_t)2 * c->d.dim * sizeof(granule_t), c->stream));   // (tag 0: below every epoch)
     HIPB(hipMalloc((void**)&c->flag_lines, 1536 * 64)); HIPB(hipMalloc((void**)&c->xwg_err, 64));   // lines 0..255: k_attn_o's heads, 256..511: split heads' scores, 512..767: k_ffn, 768..1023: k_qkv_attn_o's QKV rows, 1024..1279: k_attn_ffn's x1 rows (k_embed clears all 1536)
     HIPB(hipMemsetAsync(c->flag_lines, 0, 1536 * 64, c->stream)); HIPB(hipMemsetAsync(c->xwg_err, 0, 64, c->stream));
     {   // the one-launch token (k_layers<.., TAIL>): [0] its epoch base, one flag line per classifier workgroup, their argmax slots
@@ -524,9 +569,10 @@ void flm_ctx_destroy(flm_ctx* c) {
     for (int r = 0; r < c->world; ++r) if (c->peer_opened[r] && c->peer[r]) hipIpcCloseMemHandle(c->peer[r]);
     void* ptrs[] = {c->emb, c->emb_s, c->out_norm, c->kcache, c->vcache, c->xbuf, c->xepoch, c->qbuf,
                     c->rope_cos, c->rope_sin, c->state, c->prompt_dev, c->out_tokens_dev,
-                    c->flag_lines, c->xwg_err, c->att_q, c->att_qs, c->att_sc, c->trace, c->eng_base, c->ffn_counter, c->la_dev[0], c->la_dev[1], c->tail_dev[0], c->tail_dev[1], c->tail_mem,
+                    c->xg, c->flag_lines, c->xwg_err, c->att_q, c->att_qs, c->att_sc, c->trace, c->eng_base, c->ffn_counter, c->la_dev[0], c->la_dev[1], c->tail_dev[0], c->tail_dev[1], c->tail_mem,
                     c->pf_in_xbuf ? nullptr : c->pf_x, c->pf_qkv, c->pf_q, c->pf_in_xbuf ? nullptr : c->pf_att, c->pf_gu, c->pf_in_xbuf ? nullptr : c->pf_hd, c->pf_xs, c->pf_xq, c->pf_scores};
     for (void* p : ptrs) if (p) hipFree(p);
+    if (c->bounce) hipHostFree(c->bounce);
     if (c->comm) ncclCommDestroy(c->comm);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -658,6 +704,7 @@ int flm_set_option(flm_ctx* c, const char* key, int value) {
     else if (k == "back_pre2") c->back_pre2 = value;
     else if (k == "back_ao") c->back_ao = value;
     else if (k == "back_ao2") c->back_ao2 = value;
+    else if (k == "gr_edges") c->gr_edges = value;
     else if (k == "use_prefill_mq") c->use_prefill_mq = value;
     else if (k == "attn_split") c->attn_split = value;
     else if (k == "fold_xchg") c->fold_xchg = value;
@@ -709,7 +756,7 @@ int flm_query(flm_ctx* c, const char* key, int* value) {
     const std::string k(key);
     const struct { const char* k; int v; } tab[] = {
         {"tuning", c->tuning ? 1 : 0}, {"wg_per_cu", c->wg_per_cu}, {"use_graph", c->use_graph}, {"graph_chunks", c->graph_chunks}, {"use_prefill", c->use_prefill}, {"use_mfma", c->use_mfma}, {"use_pv_mfma", c->use_pv_mfma},
-        {"fuse_attn_o", c->fuse_attn_o}, {"fuse_ffn", c->fuse_ffn}, {"fuse_qkv", c->fuse_qkv}, {"fuse_back", c->fuse_back}, {"fuse_layer", c->fuse_layer}, {"fuse_token", c->fuse_token}, {"fuse_tail", c->fuse_tail}, {"tok_nstq", c->tok_nstq}, {"tok_preq", c->tok_preq}, {"back_nst13", c->back_nst13}, {"back_nst13_head", c->back_nst13_head}, {"back_nst2", c->back_nst2}, {"back_pre13", c->back_pre13}, {"back_pre2", c->back_pre2}, {"back_ao", c->back_ao}, {"back_ao2", c->back_ao2}, {"use_prefill_mq", c->use_prefill_mq}, {"attn_split", c->attn_split},
+        {"fuse_attn_o", c->fuse_attn_o}, {"fuse_ffn", c->fuse_ffn}, {"fuse_qkv", c->fuse_qkv}, {"fuse_back", c->fuse_back}, {"fuse_layer", c->fuse_layer}, {"fuse_token", c->fuse_token}, {"fuse_tail", c->fuse_tail}, {"tok_nstq", c->tok_nstq}, {"tok_preq", c->tok_preq}, {"back_nst13", c->back_nst13}, {"back_nst13_head", c->back_nst13_head}, {"back_nst2", c->back_nst2}, {"back_pre13", c->back_pre13}, {"back_pre2", c->back_pre2}, {"back_ao", c->back_ao}, {"back_ao2", c->back_ao2}, {"gr_edges", c->gr_edges}, {"gr_active", (c->world == 1 && (c->la_valid[0] || c->la_valid[1])) ? ((c->la_valid[0] && c->tail_ok[0] && c->la_p[0].gr) ? 1 : 0) | ((c->la_valid[1] && c->tail_ok[1] && c->la_p[1].gr) ? 2 : 0) : 0}, {"use_prefill_mq", c->use_prefill_mq}, {"attn_split", c->attn_split},
         {"use_qk_mfma", c->use_qk_mfma}, {"use_p2p", c->p2p}, {"fold_xchg", c->fold_xchg}, {"tp_fuse_attn", c->tp_fuse_attn}, {"tp_fuse_ffn", c->tp_fuse_ffn}, {"cu_parts", c->cu_parts}, {"fold_active", (c->world > 1 && c->p2p && c->grp_fold) ? 1 : 0}, {"span_active", (c->world > 1 && c->p2p && c->grp_span) ? 1 : 0}, {"tp_trust_fused", c->tp_trust_fused}, {"force_tp", c->force_tp},
         {"tp_fuse_layers", c->tp_fuse_layers}, {"tp_fence", c->tp_fence}, {"tp_fence_active", c->tp_fence >= 0 ? c->tp_fence : (c->ranks_on_device == c->world ? 0 : 3)}, {"grp_tp_fuse_layers", (c->world > 1 && c->p2p && c->grp_tpl) ? 1 : 0}, {"tp_layers_active", (c->world > 1 && c->p2p && c->grp_tpl && (c->la_valid[0] || c->la_valid[1])) ? (c->la_valid[0] && c->la_ok[0] ? 1 : 0) | (c->la_valid[1] && c->la_ok[1] ? 2 : 0) : -1},   /* the rank-spanning k_layers was planned: bit 0 one workgroup per head, bit 1 split heads */ {"grp_tp_fuse_attn", c->grp_tpfa}, {"grp_tp_fuse_ffn", c->grp_tpff}, {"grp_attn_split", c->grp_split}, {"resident", c->resident}, {"fallback", c->fell_back}, {"fallback_active", c->fb_active ? 1 : 0},
         {"ao_active", c->la_ok[0] ? (c->la_p[0].ao_o ? 1 : 0) | (c->la_p[0].ao_2 ? 2 : 0) : -1},      // which hand-offs of the token's launch (short contexts) are consumed in arrival order; -1: that launch was not planned (yet)
@@ -778,6 +825,22 @@ static int upload_tensor_impl(flm_ctx* c, int kind, int layer, int src_qt, const
     default: return fail(c, FLM_ERR_INVALID, "unknown tensor kind");
     }
 }
+// Once per context, when its model is complete (single GPU: a tensor-parallel rank must not wait for peers at load time): one short prompt through the batched kernels and one token
+// with logits, on dummy ids, so that whatever the HIP runtime sets up lazily at a first launch -- queue-side pools that grow with the number of launches in flight: 2 MiB of device
+// memory at the first prompt of a process (tools/alloc_diag.py) -- is set up at LOAD time and not inside the caller's first flm_forward.  The cache rows it wrote are cleared again.
+static void warm_up(flm_ctx* c) {
+    if (c->warmed || c->world != 1 || c->comm || !model_complete(c)) return;
+    c->warmed = true;
+    const std::string err0 = c->err, gerr0 = g_last_error;
+    int32_t toks[kPrefillMin + 2] = {0};
+    const int n = c->d.max_seq_len > kPrefillMin + 2 ? kPrefillMin + 2 : 1;
+    bool ok = feed(c, toks, n, 0, 0) == FLM_OK && hipStreamSynchronize(c->stream) == hipSuccess;
+    if (ok) (void)xwg_check(c);                                                // (a wait that gave up here puts the context on the per-phase kernels like any other)
+    const size_t pitch = (size_t)c->kv_rows * c->hs * 4, width = (size_t)n * c->hs * 4, height = (size_t)c->d.n_layers * c->heads_local;
+    (void)hipMemset2DAsync(c->kcache, pitch, 0, width, height, c->stream); (void)hipMemset2DAsync(c->vcache, pitch, 0, width, height, c->stream);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipGetLastError(); c->err = err0; g_last_error = gerr0;               // (an error here is not the caller's: it resurfaces at the first forward)
+}
 int flm_upload_tensor(flm_ctx* c, int kind, int layer, int src_qt, const void* values, const float* scales, int rows, int cols) {
     const int r = upload_tensor_impl(c, kind, layer, src_qt, values, scales, rows, cols);
     if (r == FLM_OK && model_complete(c)) {
@@ -785,6 +848,7 @@ int flm_upload_tensor(flm_ctx* c, int kind, int layer, int src_qt, const void* v
         // (transformer.cpp:110-130: no allocation during inference).  An error here is not the upload's: it resurfaces at the first forward.
         const std::string err0 = c->err, gerr0 = g_last_error;
         if (prepare_all(c) != FLM_OK) { c->err = err0; g_last_error = gerr0; (void)hipGetLastError(); }
+        else warm_up(c);
     }
     return r;
 }
@@ -793,7 +857,9 @@ int flm_prepare(flm_ctx* c) {
     if (!c) return FLM_ERR_INVALID;
     HIPC(c, hipSetDevice(c->device));
     if (!model_complete(c)) return fail(c, FLM_ERR_STATE, "prepare before all tensors were uploaded");
-    return prepare_all(c);
+    const int r = prepare_all(c);
+    if (r == FLM_OK) warm_up(c);
+    return r;
 }
 
 int flm_reset_kv(flm_ctx* c) {
@@ -880,8 +946,7 @@ int flm_forward(flm_ctx* c, const int32_t* tokens, int n, int pos, float* logits
     int r = check_ready(c, n, pos); if (r) return r;
     for (int attempt = 0; attempt < 2; ++attempt) {
         r = feed(c, tokens, n, pos, 0); if (r) return r;
-        HIPC(c, hipMemcpyAsync(logits_host, c->logits, (size_t)c->d.vocab_size * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPC(c, hipStreamSynchronize(c->stream));
+        r = d2h(c, logits_host, c->logits, (size_t)c->d.vocab_size * 4); if (r) return r;
         r = xwg_check(c); if (r != FLM_RETRY) return r ? r : maybe_recover(c, n);
     }
     return fail(c, FLM_ERR_HIP, "cross-workgroup wait timed out twice");
@@ -892,8 +957,7 @@ int flm_forward_argmax(flm_ctx* c, const int32_t* tokens, int n, int pos, int32_
     int r = check_ready(c, n, pos); if (r) return r;
     for (int attempt = 0; attempt < 2; ++attempt) {
         r = feed(c, tokens, n, pos, 1); if (r) return r;
-        HIPC(c, hipMemcpyAsync(next_token, c->out_tokens_dev, 4, hipMemcpyDeviceToHost, c->stream));
-        HIPC(c, hipStreamSynchronize(c->stream));
+        r = d2h(c, next_token, c->out_tokens_dev, 4); if (r) return r;
         r = xwg_check(c); if (r != FLM_RETRY) return r ? r : maybe_recover(c, n);
     }
     return fail(c, FLM_ERR_HIP, "cross-workgroup wait timed out twice");
@@ -914,8 +978,7 @@ int flm_decode_greedy(flm_ctx* c, int32_t first_token, int pos, int n_steps, int
     if (!out_tokens) return FLM_ERR_INVALID;
     for (int attempt = 0; attempt < 2; ++attempt) {
         int r = decode_loop(c, first_token, pos, n_steps, nullptr, nullptr); if (r) return r;
-        HIPC(c, hipMemcpyAsync(out_tokens, c->out_tokens_dev, sizeof(int) * n_steps, hipMemcpyDeviceToHost, c->stream));
-        HIPC(c, hipStreamSynchronize(c->stream));
+        r = d2h(c, out_tokens, c->out_tokens_dev, sizeof(int) * (size_t)n_steps); if (r) return r;
         r = xwg_check(c); if (r != FLM_RETRY) return r ? r : maybe_recover(c, n_steps);
     }
     return fail(c, FLM_ERR_HIP, "cross-workgroup wait timed out twice");
@@ -940,9 +1003,7 @@ int flm_decode_timed(flm_ctx* c, int32_t first_token, int pos, int n_steps, floa
 int flm_last_tokens(flm_ctx* c, int n, int32_t* out) {
     if (!c || !out || n < 1 || n > c->out_cap) return FLM_ERR_INVALID;
     HIPC(c, hipSetDevice(c->device));
-    HIPC(c, hipMemcpyAsync(out, c->out_tokens_dev, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
-    return FLM_OK;
+    return d2h(c, out, c->out_tokens_dev, sizeof(int) * (size_t)n);
 }
 
 // the same loop with an event after every token: ms_each[n_steps] (for a median; the events cost a few us per token, so the

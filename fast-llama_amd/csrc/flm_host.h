@@ -68,6 +68,11 @@ struct flm_ctx {
     float *rope_cos = nullptr, *rope_sin = nullptr;
     DecodeState* state = nullptr; int* prompt_dev = nullptr; int* out_tokens_dev = nullptr;
     int prompt_cap = 0, out_cap = 0;
+    // the context's own page-locked bounce buffer: logits, ids and prompt tokens cross the bus through it (allocated at create).  A caller's pageable buffer handed to
+    // hipMemcpyAsync is pinned and mapped by the runtime on every call -- ~100 us of host time per call and, the first time an address range is seen, page tables in device memory
+    // (2 MiB steps: tools/alloc_diag.py), i.e. an allocation inside flm_forward.
+    char* bounce = nullptr; size_t bounce_bytes = 0; int err_word = 0; bool err_word_fresh = false;
+    bool warmed = false;                               // flm_gpu.hip warm_up: the runtime's lazily built launch resources were set up at load time
 
     // options
     bool tuning = false;                               // option "tuning": the experiment dials (flm_tuning.h) may be set
@@ -99,6 +104,8 @@ struct flm_ctx {
     unsigned* tail_mem = nullptr;                      // [0] the epoch base of the one-launch token's flag values, [16 ..) one flag line per classifier workgroup, then their argmax slots
     int fuse_layer = 1;                                // option "fuse_layer": ... with the QKV GEMV in front: the whole layer in one launch
     int back_nst13 = -1, back_nst13_head = -1, back_nst2 = 0, back_pre13 = 16, back_pre2 = 16;   // options "back_*": k_attn_ffn's stash slots (-1: as many as the LDS holds) and early register set (flm_layer.h)
+    int gr_edges = 1;                                  // tuning dial "gr_edges" (round 6): the one-launch token's x / x1 hand-offs as data-tagged granules (flm_gemv.h: granule_t; BackArgs::gr); 0: flag rounds
+    granule_t* xg = nullptr;                           // ... their two vectors [2][dim] (x behind FFN2, x1 behind Wo)
     int back_ao = 3, back_ao2 = 2;                     // options "back_ao" (bit 0: Wo, bit 1: FFN2 consume their activation in arrival order, GemvCtx::run_ao) / "back_ao2" (what of W2 is requested in front of the first look)
     int fuse_qkv = 1;                                  // option "fuse_qkv": QKV in front of attention + Wo in the same launch (k_qkv_attn_o; single GPU): 0 never,
                                                        // 1 when a head is spread over several workgroups (long contexts: where it pays), 2 always

@@ -48,6 +48,10 @@ struct BackArgs {
     int r5;                     // the round-5 forms the launch's instantiation carries (layer_body's R5): 3 or 0
     int nst2_ao;                // ... its stash slots: the steps beyond the two register sets (all of W2's share is resident)
     unsigned long long* trace;  // FLM_ABLATE builds: [grid][16] s_memrealtime stamps (100 MHz, one clock for all XCDs; tools/trace_back.py)
+    // round 6: the residual stream as data-tagged granules inside the one-launch token (flm_gemv.h: granule_t): xg_a = x behind FFN2 (the next layer's / the classifier's input),
+    // xg_b = x1 behind Wo (FFN13's input), [dim] each.  gr = 1: the two strict all-to-all edges of a layer carry no flag round -- the consumers sweep the granules themselves.
+    // (TAIL launches only: their flag values count from an epoch and never repeat; the launch's first layer reads the embedding row, nothing else reads x.)
+    granule_t* xg_a; granule_t* xg_b; int gr;
     // tensor parallel (layer_body<.., TP>, round 6): the launch SPANS the ranks -- every rank runs the same k_layers on its rows (heads, rows of Wo / W2, rows of [W1; W3]: the
     // reference's row split, transformer.cpp:264-287), the four all-to-all hand-offs of a layer cross the ranks.  A producer stores its slice into every rank's buffer
     // (GemvArgs::out_peer / AttnArgs::out_peer) and raises ITS line in every rank's array; a consumer polls the lines of ALL ranks' producers in its LOCAL array.  The ranks'
@@ -169,7 +173,8 @@ __device__ __forceinline__ void raise_line(const BackArgs& p, unsigned* local, u
 // order (GemvCtx::run_ao; one workgroup per head), bit 1 FFN2 consumes hd in arrival order.  The host picks the instantiation whose forms the shape allows (plan_layer: BackArgs::r5).
 // TP (round 6): the launch spans the tensor-parallel ranks (BackArgs::Tp).  The heads hand their output over as fp32 (every rank's Wo workgroups quantize it themselves, as
 // with split heads); R5 = 0 (the hand-offs in their all-to-all form).
-template <int QT, int XR2, bool QKV, bool SPLIT, bool PERSIST, int R5 = 0, bool TP = false>
+template <int QT, int XR2, bool QKV, bool SPLIT, bool PERSIST, int R5 = 0, bool TP = false, bool GRC = false>
+// GRC: the instantiation may run the granule form of the x / x1 edges (k_layers<.., TAIL>); p.gr says whether this launch does.
 // x0 (k_layers' one-launch token, first layer): the layer's input is read from there -- the embedding row -- by the QKV prologue and by Wo's residual epilogue instead of the residual
 // stream's buffer (which Wo's rows then start); null: the buffer.
 __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& aa, const GemvArgs& ao, const GemvArgs& a13, const GemvArgs& a2, const BackArgs& p, char* lds,
@@ -177,6 +182,7 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
     auto nostamp = [](int) {};
     auto stamp = [&](int k) { if (kAblate && tracing && p.trace && threadIdx.x == 0) p.trace[blockIdx.x * 16 + k] = __builtin_amdgcn_s_memrealtime(); };
     stamp(0);
+    const bool gr = GRC && PERSIST && !TP && p.gr != 0;                         // (wave-uniform, from the kernel's arguments)
     unsigned nst13 = 0;
     if constexpr (QKV) {
         if ((int)blockIdx.x < p.gridq) {
@@ -188,10 +194,15 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
                 if (xpoll) {
                     if ((int)gq.wave < p.preq) gq.issue(kAblate ? aq.ablate : 0, 1);
                     gq.stash_issue(lds);
+                    if (gr) {
+                        gemv_preload_granules(aq, xq, nq, p.xg_a, target - 1u, p.err);     // (no line round: every thread waits for its own elements of x)
+                        wait_stores_done();                                     // every wave: the stash slots it requested have landed (the prologue's first barrier follows)
+                    } else {
                     poll_lines_t<TP>(p.flag_x2, (TP ? p.tp.world : 1) * p.grid2, target - 1u, p);
                     wait_stores_done();                                         // every wave: the stash slots it requested have landed
                     __syncthreads();
                     gemv_preload<QT, PRO_RMSNORM_QUANT, 1, true>(aq, xq, nq);
+                    }
                 }
             }
             gemv_prologue<QT, PRO_RMSNORM_QUANT, 1, PERSIST, FLM_LAYER_LATEQ != 0>(aq, lds, xq, nq, [&](int) { gq.issue_missing(kAblate ? aq.ablate : 0); });
@@ -248,6 +259,7 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
         GemvCtx<QT, EPI_RESIDUAL> g;
         g.init(ao, blockIdx.x - p.n_heads, p.grido, lds);
         g.resid_src = x0;
+        if (gr) { g.gsrc = xpoll ? p.xg_a : nullptr; g.gdst = p.xg_b; g.gtag = target; }   // (the launch's first layer: the old value is the embedding row's)
         g.issue(kAblate ? ao.ablate : 0);
         if (p.nst13 > 0 && (int)blockIdx.x < p.grid13) {
             nst13 = (unsigned)p.nst13;
@@ -275,9 +287,12 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
         g.run(ao, lds, nostamp);
         }
         stamp(3);
+        if (gr) __syncthreads();                                                // (the LDS is free for the next phase; x1's granules are their own flags)
+        else {
         wait_stores_done();                                                     // every wave: its rows of x1 are where the others will read them
         __syncthreads();
         raise_line<TP>(p, p.flag_x, p.tp.off_x, (TP ? (unsigned)(p.tp.rank * p.grido) : 0u) + (blockIdx.x - p.n_heads), target);
+        }
         stamp(4);
     }
     // ---- FFN13: k_gemv<RMSNORM_QUANT, SWIGLU> behind the x1 flag round (x1 through coherent loads)
@@ -285,12 +300,18 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
         GemvCtx<QT, EPI_SWIGLU, true> g;
         g.init(a13, blockIdx.x, p.grid13, lds, 0, p.st_base, nst13);
         if ((int)g.wave < p.pre13) g.issue(kAblate ? a13.ablate : 0, 1);       // the first pre13 waves: their first register set in front of the x1 flag round
+        float4 xv[1], nv[1];
+        if (gr) {
+            gemv_preload_granules(a13, xv, nv, p.xg_b, target, p.err);
+            wait_stores_done();                                                 // every wave: the stash slots it requested have landed
+            stamp(5);
+        } else {
         poll_lines_t<TP>(p.flag_x, (TP ? p.tp.world : 1) * p.grido, target, p);
         wait_stores_done();                                                     // every wave: the stash slots it requested have landed
         __syncthreads();
         stamp(5);
-        float4 xv[1], nv[1];
         gemv_preload<QT, PRO_RMSNORM_QUANT, 1, true>(a13, xv, nv);
+        }
         gemv_prologue<QT, PRO_RMSNORM_QUANT, 1, true, FLM_BACK_LATE != 0>(a13, lds, xv, nv, [&](int) { g.issue_missing(kAblate ? a13.ablate : 0); });
         stamp(6);
 #ifdef FLM_TRACE_PRO_RT
@@ -300,7 +321,7 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
         g.run(a13, lds, nostamp);
 #endif
         stamp(7);
-    } else {
+    } else if (!gr) {
         poll_lines_t<TP>(p.flag_x, (TP ? p.tp.world : 1) * p.grido, target, p);       // (keeps the order x1 -> hd for a workgroup without rows)
     }
     wait_stores_done();                                                         // every wave: its rows of hd are where the others will read them
@@ -314,6 +335,7 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
         // arrival order (GemvCtx::run_ao): no workgroup-wide poll, no prologue -- a wave quantizes the column block of each of its steps when the FFN13 workgroups that
         // produced THAT block have raised their lines.  W2's whole share is resident (two register sets per wave + nst2_ao stash slots), requested as ao_2 says.
         g2.init(a2, blockIdx.x, p.grid2, lds, 0, p.st_base, (unsigned)p.nst2_ao);
+        if (gr) { g2.gsrc = p.xg_b; g2.gdst = p.xg_a; g2.gtag = target; }
         const typename GemvCtx<QT, EPI_RESIDUAL, true>::AoSrc src{p.flag_hd, (unsigned)a13.rows_per_pass, (unsigned)p.grid13, target, p.err};
         g2.issue(kAblate ? a2.ablate : 0, p.ao_2 == 1 ? 0 : 1);
         if (p.ao_2 != 2) g2.stash_issue(lds);
@@ -322,6 +344,7 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
         stamp(11);
     } else {
     g2.init(a2, blockIdx.x, p.grid2, lds, 0, p.st_base, (unsigned)p.nst2);
+    if (gr) { g2.gsrc = p.xg_b; g2.gdst = p.xg_a; g2.gtag = target; }
     if ((int)g2.wave < p.pre2) g2.issue(kAblate ? a2.ablate : 0, 1);            // the first pre2 waves: ONE set now, the rest when hd has arrived (k_ffn: all 16)
     g2.stash_issue(lds);
     poll_lines_t<TP>(p.flag_hd, (TP ? p.tp.world : 1) * (int)gridDim.x, target, p);
@@ -338,9 +361,12 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
     }
     if constexpr (PERSIST) {
         if (xflag) {
+            if (gr) __syncthreads();                                            // (the LDS is free for the next layer; x's granules are their own flags)
+            else {
             wait_stores_done();                                                 // every wave: its rows of x are where the next layer will read them
             __syncthreads();                                                    // (and the LDS is free for the next layer)
             if ((int)blockIdx.x < p.grid2) raise_line<TP>(p, p.flag_x2, p.tp.off_x2, (TP ? (unsigned)(p.tp.rank * p.grid2) : 0u) + blockIdx.x, target);
+            }
         }
     }
 }
@@ -380,11 +406,16 @@ __device__ __forceinline__ void tail_phase(const TailArgs& T, const BackArgs& p,
         gc.init(a, blockIdx.x, T.gridc, lds, 0, p.st_base, (unsigned)p.nstq);
         if ((int)gc.wave < p.preq) gc.issue(kAblate ? a.ablate : 0, 1);
         gc.stash_issue(lds);
+        float4 xq[1], nq[1];
+        if (p.gr) {
+            gemv_preload_granules(a, xq, nq, p.xg_a, xtarget, p.err);
+            wait_stores_done();                                                 // every wave: the stash slots it requested have landed
+        } else {
         poll_lines(p.flag_x2, p.grid2, xtarget, p.err);
         wait_stores_done();                                                     // every wave: the stash slots it requested have landed
         __syncthreads();
-        float4 xq[1], nq[1];
         gemv_preload<QT, PRO_RMSNORM_QUANT, 1, true>(a, xq, nq);
+        }
         gemv_prologue<QT, PRO_RMSNORM_QUANT, 1, true, FLM_LAYER_LATEQ != 0>(a, lds, xq, nq, [&](int) { gc.issue_missing(kAblate ? a.ablate : 0); });
         gc.run(a, lds, nostamp);
         wait_stores_done();                                                     // every wave: its logits are in memory
@@ -447,7 +478,7 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_layers(const LayerArgs* __res
     if constexpr (TP) base = *p.tp.base;
     for (int l = l0; l < l1; ++l) {
         const LayerArgs& A = *(const LayerArgs*)(LAc + l);
-        layer_body<QT, XR2, true, SPLIT, true, R5, TP>(A.aq, A.aa, A.ao, A.a13, A.a2, p, lds, base + (unsigned)(l + 1), l > l0, TAIL || l + 1 < l1, l == (l1 - l0 > 1 ? l0 + 1 : l0),   // (trace builds: the stamps of the launch's second layer)
+        layer_body<QT, XR2, true, SPLIT, true, R5, TP, TAIL>(A.aq, A.aa, A.ao, A.a13, A.a2, p, lds, base + (unsigned)(l + 1), l > l0, TAIL || l + 1 < l1, l == (l1 - l0 > 1 ? l0 + 1 : l0),   // (trace builds: the stamps of the launch's second layer)
                                                    (TAIL && l == l0) ? x0 : nullptr);
     }
     if constexpr (TAIL) {

@@ -76,6 +76,8 @@ int plan_layer(flm_ctx* c, int l, bool with_qkv, int G, LayerArgs& A, BackArgs& 
     if (kAblate && c->trace_class == 103) { p.trace = c->trace; if (l == (c->d.n_layers > 1 ? 1 : 0)) { a13.trace = c->trace + 256 * 16; a2.trace = c->trace + 2 * 256 * 16; aa.trace = c->trace + 5 * 4096; } }   // (k_layers: its second layer)
     grid = parts + Po.grid; if (P13.grid > grid) grid = P13.grid; if (P2.grid > grid) grid = P2.grid; if (with_qkv && Pq.grid > grid) grid = Pq.grid;
     if (grid > all) return FLM_ERR_UNSUPPORTED;
+    p.xg_a = c->xg; p.xg_b = c->xg + d.dim;
+    p.gr = (c->gr_edges && c->xg && !tpl && c->world == 1 && with_qkv && d.dim <= 4 * kGemvBlock && d.dim % 4 == 0) ? 1 : 0;   // (one sweep round per thread; launch_layers clears it for a launch without tail)
     p.flag_x2 = c->flag_lines + 1280 * 16; p.nstq = slots(c->tok_nstq); p.preq = c->tok_preq < 0 ? 0 : c->tok_preq > 16 ? 16 : c->tok_preq;
     if (tpl) {   // the cross-rank lines: regions of the ranks' exchange buffers (never cleared: epoch values); flag_q and the split heads' score lines stay local (k_embed clears them)
         BackArgs::Tp& t = p.tp;

@@ -380,7 +380,9 @@ def test_greedy_token_as_one_launch_vs_oracle(gpu, pos0, qt):
     want_ids, cur, pos = [], first, len(prompt)
     for _ in range(n):
         last = om.forward(np.array([cur], np.int32), pos); cur = int(np.argmax(last)); want_ids.append(cur); pos += 1
-    for opts in ({}, {"fuse_tail": 0}, {"fuse_tail": 1, "graph_chunks": 0}, {"use_graph": 0}, {"fuse_tail": 0, "graph_chunks": 1}, {"use_graph": 1, "fuse_tail": 1}, {"back_ao": 0}):
+    # round 6: the one-launch token hands the residual stream over as data-tagged granules ("gr_edges", a tuning dial; default on): both forms, switching back and forth
+    for opts in ({}, {"fuse_tail": 0}, {"fuse_tail": 1, "graph_chunks": 0}, {"use_graph": 0}, {"fuse_tail": 0, "graph_chunks": 1}, {"use_graph": 1, "fuse_tail": 1}, {"back_ao": 0},
+                 {"tuning": 1, "gr_edges": 0}, {"back_ao": 3}, {"gr_edges": 1, "graph_chunks": 0}, {"graph_chunks": 1}):
         for k, v in opts.items():
             ctx.set_option(k, v)
         ctx.reset_kv()
@@ -389,6 +391,8 @@ def test_greedy_token_as_one_launch_vs_oracle(gpu, pos0, qt):
         assert ids == want_ids, (opts, ids, want_ids)
         assert bits_equal(ctx.debug_read("logits", 0, cfg.vocab_size), last), opts
         assert ctx.query("fallback") == 0
+        if ctx.query("fuse_tail"):
+            assert bool(ctx.query("gr_active")) == bool(ctx.query("gr_edges")), opts      # (the granule form is what the one-launch token ran, unless switched off)
     ctx.close()
 
 
