@@ -745,11 +745,13 @@ def tp_connect(capi, ctx, rank, world, device, dist, torch, comm_id, first=False
         tpl = ctx.query("grp_tp_fuse_layers")
         if tpl:
             per_layer = 0
-            ctx.exchange += f"; ALL layers of the sharded token in one launch per rank that spans the ranks (k_layers<TP>, tp_fence {ctx.query('tp_fence_active')})"
+            gra = 1 if (ctx.query("gr_edges") and ctx.query("grp_gr")) else 0
+            ctx.exchange += (f"; ALL layers of the sharded token in one launch per rank that spans the ranks (k_layers<TP>; " +
+                             ("every cross-rank vector as data-tagged 8-byte granules: no flag line, no fence)" if gra else f"flag rounds between the ranks' workgroups, tp_fence {ctx.query('tp_fence_active')})"))
         else:
             ctx.exchange += f"; {per_layer} launches per sharded layer (fold_active {fold}, tp_fuse_attn {fa}, tp_fuse_ffn {fn})"
         ctx.tp_info = {"transport": "p2p", "launches_per_sharded_layer": per_layer, "fold_active": int(fold), "tp_fuse_attn": int(fa), "tp_fuse_ffn": int(fn),
-                       "tp_fuse_layers": int(tpl), "tp_fence": int(ctx.query("tp_fence_active")) if tpl else None}
+                       "tp_fuse_layers": int(tpl), "tp_fence": int(ctx.query("tp_fence_active")) if tpl else None, "granules": (gra if tpl else None)}
     # every rank's device ordinal, as the ranks themselves see it (ranks_seen = how many distinct devices the group really runs on)
     devs = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(devs, torch.tensor([int(device)], dtype=torch.int64, device=dev))
@@ -764,13 +766,12 @@ def tp_connect(capi, ctx, rank, world, device, dist, torch, comm_id, first=False
 # system-scope store / flag ordering over xGMI that the build box (one GPU) can only rehearse between CU partitions: the library runs them there only when every rank says
 # "tp_trust_fused".  bench.py trusts nothing: it times the conservative structure, then each faster one, verifies EVERY one against the reference's golden ids on every rank
 # (all-reduce MIN), and reports the fastest verified one as `value`; a structure that mismatches or gives up is reported under tp.structures, not fatal.
-TP_STRUCTURES = (("xchg-launches", {"tp_trust_fused": 0, "tp_fuse_ffn": 0, "tp_fuse_layers": 0, "tp_fence": -1}),
-                 ("folded, QKV + attention + Wo across ranks", {"tp_trust_fused": 1, "tp_fuse_ffn": 0, "tp_fuse_layers": 0, "tp_fence": -1}),
-                 # round 6: ALL layers of the sharded token in one launch per rank that spans the ranks (k_layers<.., TP>), with the system-scope fences around every
-                 # cross-rank flag and without them (every cross-rank access is itself a system-scope atomic / coherent load)
-                 ("all layers in one rank-spanning launch, fenced flags", {"tp_trust_fused": 1, "tp_fuse_ffn": 0, "tp_fuse_layers": 1, "tp_fence": 3}),
-                 ("all layers in one rank-spanning launch", {"tp_trust_fused": 1, "tp_fuse_ffn": 0, "tp_fuse_layers": 1, "tp_fence": 0}),
-                 ("folded, + FFN13 + FFN2 across ranks", {"tp_trust_fused": 1, "tp_fuse_ffn": 1, "tp_fuse_layers": 0, "tp_fence": -1}))      # (last: slower than its predecessor at 2-4 ranks on one GPU)
+TP_STRUCTURES = (("xchg-launches", {"tp_trust_fused": 0, "tp_fuse_ffn": 0, "tp_fuse_layers": 0, "tp_fence": -1, "gr_edges": 0}),
+                 ("folded, QKV + attention + Wo across ranks", {"tp_trust_fused": 1, "tp_fuse_ffn": 0, "tp_fuse_layers": 0, "tp_fence": -1, "gr_edges": 0}),
+                 ("all layers in one rank-spanning launch, fenced flags", {"tp_trust_fused": 1, "tp_fuse_ffn": 0, "tp_fuse_layers": 1, "tp_fence": 3, "gr_edges": 0}),
+                 ("all layers in one rank-spanning launch, flags", {"tp_trust_fused": 1, "tp_fuse_ffn": 0, "tp_fuse_layers": 1, "tp_fence": 0, "gr_edges": 0}),
+                 ("all layers in one rank-spanning launch, data-tagged granules (no flag, no fence)", {"tp_trust_fused": 1, "tp_fuse_ffn": 0, "tp_fuse_layers": 1, "tp_fence": -1, "gr_edges": 1}),
+                 ("folded, + FFN13 + FFN2 across ranks", {"tp_trust_fused": 1, "tp_fuse_ffn": 1, "tp_fuse_layers": 0, "tp_fence": -1, "gr_edges": 0}))      # (last: slower than its predecessor at 2-4 ranks on one GPU)
 
 
 def pick_tp_structure(results):
@@ -794,9 +795,9 @@ def run_tp_structures(capi, ctx, cfg, args, prompt, barrier, gold, rank, world, 
                 ctx.set_option(k, v)
             tp_connect(capi, ctx, rank, world, device, dist, torch, getattr(ctx, "comm_id", None))
             info = dict(ctx.tp_info)
-            sig = (info.get("transport"), info.get("launches_per_sharded_layer"), info.get("fold_active"), info.get("tp_fuse_attn"), info.get("tp_fuse_ffn"), info.get("tp_fuse_layers"), info.get("tp_fence"))
+            sig = (info.get("transport"), info.get("launches_per_sharded_layer"), info.get("fold_active"), info.get("tp_fuse_attn"), info.get("tp_fuse_ffn"), info.get("tp_fuse_layers"), info.get("tp_fence"), info.get("granules"))
             rec.update(transport=info.get("transport"), launches_per_sharded_layer=info.get("launches_per_sharded_layer"),
-                       ran=(f"ONE launch for all layers of the sharded token, spanning the ranks (k_layers<TP>, tp_fence {info.get('tp_fence')}) + embedding row, classifier, logits exchange, argmax" if info.get("tp_fuse_layers") else
+                       ran=(f"ONE launch for all layers of the sharded token, spanning the ranks (k_layers<TP>, {'data-tagged granules' if info.get('granules') else 'flag rounds, tp_fence ' + str(info.get('tp_fence'))}) + embedding row, classifier, logits exchange, argmax" if info.get("tp_fuse_layers") else
                             f"{info.get('launches_per_sharded_layer')} launches per sharded layer (fold_active {info.get('fold_active')}, tp_fuse_attn {info.get('tp_fuse_attn')}, tp_fuse_ffn {info.get('tp_fuse_ffn')})")
                            + ("; every rank on ONE device: the group folds its exchanges without being asked to trust anything" if len(set(info.get("rank_devices", [0]))) == 1 and world > 1 else ""))
         except Exception as e:  # noqa: BLE001

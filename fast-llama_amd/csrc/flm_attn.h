@@ -42,6 +42,9 @@ struct AttnArgs {
     int G; float* sc_global; unsigned* flag_sc; unsigned epoch; int* err;
     // tensor parallel, peer-to-peer: the head's output also goes to the same place of every peer rank's buffer (as GemvArgs::out_peer)
     float* out_peer[7]; int n_peer;
+    // k_layers' granule hand-offs (flm_gemv.h: granule_t): non-null = the head's output leaves as {value, tag} granules (tag = the launch's flag value, attn_head's epoch_arg) into
+    // every rank's granule vector (offset like `out`) instead of plain stores -- the Wo workgroups sweep them, nobody drains stores or raises a line for them
+    unsigned long long* gout; unsigned long long* gout_peer[7];
 };
 
 #ifndef FLM_V_LATE_NS
@@ -533,8 +536,14 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
     }
     stamp(4);
     if (tid < nd) {
+        if (a.gout) {
+            const unsigned long long gv = ((unsigned long long)epoch_arg << 32) | (unsigned long long)__float_as_uint(o);
+            __hip_atomic_store(a.gout + (size_t)h * hs + d0 + tid, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < a.n_peer; ++i) __hip_atomic_store(a.gout_peer[i] + (size_t)h * hs + d0 + tid, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
         st_agent(orow + (size_t)h * hs + d0 + tid, o);
         for (int i = 0; i < a.n_peer; ++i) __hip_atomic_store(a.out_peer[i] + (size_t)h * hs + d0 + tid, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     if (a.oq && G == 1) {
         // qx.quantize(x2) (transformer.cpp:138) for this head's groups: wave w holds the 64 outputs of group h * hs/64 + w;

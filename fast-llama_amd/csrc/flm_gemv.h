@@ -34,6 +34,8 @@ struct GemvArgs {
     // xGMI; system-scope stores), so that after the launch plus one flag round every rank holds the whole vector.
     // out_peer[i] = peer i's `out` pointer (already offset like `out`); for EPI_ROPE_KV nothing is exchanged (q/k/v stay local).
     float* out_peer[7]; int n_peer;
+    // the same vector as data-tagged granules (granule_t below; k_layers' granule hand-offs: GemvCtx::gron): local / every peer's, offset like `out`; the tag is the launch's (run time)
+    unsigned long long* gout; unsigned long long* gout_peer[7];
     // ... and the flag round of that exchange folded into the CONSUMING launch (XchgFold below; world == 0: not used)
     struct XchgFold {
         unsigned* local_flags; unsigned* peer_flags[8];         // flag lines [slot][rank], 64 bytes each, in every rank's exchange buffer
@@ -320,32 +322,11 @@ __device__ __forceinline__ void st_granule(granule_t* g, unsigned tag, float v) 
     __hip_atomic_store(g, ((granule_t)tag << 32) | (granule_t)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ float ld_granule_value(const granule_t* g) { return __uint_as_float((unsigned)__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
-// gemv_preload<.., PRO_RMSNORM_QUANT, 1, COH> on a granule vector (n <= 4 x 1024: one round): xv[0] = elements 4 tid .. 4 tid + 3 once their tags are `tag`; wv[0] = the norm weights.
-// A wait of ~20 ms raises *err (the host re-runs the call on one kernel per phase); a wait of this launch that has already given up is not waited for again.
-__device__ __forceinline__ void gemv_preload_granules(const GemvArgs& a, float4 (&xv)[1], float4 (&wv)[1], const granule_t* g, const unsigned tag, int* err) {
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<granule_t*>(g), 0, a.n * 8, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.norm_w), 0, a.n * 4, 0x00020000);
-    const int e = threadIdx.x * 4;
-    const int gave_up = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    {
-        const v4f u = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rn, e * 4, 0, 0));
-        wv[0] = make_float4(u.x, u.y, u.z, u.w);
-    }
-    v4u_g A = {0u, 0u, 0u, 0u}, C = {0u, 0u, 0u, 0u};
-    bool ok = e >= a.n;                                                        // (lanes past the vector: zeros, as the bounds-checked loads of gemv_preload deliver)
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (true) {
-        asm volatile("" ::: "memory");                                         // (the loads are re-issued every pass)
-        if (!ok) {
-            A = __builtin_bit_cast(v4u_g, __builtin_amdgcn_raw_buffer_load_b128(rg, e * 8, 0, kAuxCoherent));
-            C = __builtin_bit_cast(v4u_g, __builtin_amdgcn_raw_buffer_load_b128(rg, e * 8 + 16, 0, kAuxCoherent));
-            ok = A.y == tag && A.w == tag && C.y == tag && C.w == tag;
-        }
-        if (__all(ok) || gave_up) break;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-    }
-    xv[0] = make_float4(__uint_as_float(A.x), __uint_as_float(A.z), __uint_as_float(C.x), __uint_as_float(C.z));
+// result store as granules: local (agent scope) + every peer (system scope: one 8-byte store each, over xGMI as one write)
+__device__ __forceinline__ void st_result_granule(const GemvArgs& a, unsigned row, unsigned tag, float v) {
+    st_granule(a.gout + row, tag, v);
+    const granule_t g = ((granule_t)tag << 32) | (granule_t)__float_as_uint(v);
+    for (int i = 0; i < a.n_peer; ++i) __hip_atomic_store(a.gout_peer[i] + row, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // One quantizer round of a 16-lane row: the lane owns elements e .. e+3, 16 consecutive lanes own one 64-group (quant::quantize, quant_operators.cpp:26-47:
@@ -615,9 +596,9 @@ struct GemvCtx {
     Set setA, setB;
     bool stored;                                                               // this wave wrote results to global memory
     const float* resid_src;                                                    // EPI_RESIDUAL: the old value of out[row] is read from resid_src[row] instead (null: out itself)
-    // EPI_RESIDUAL inside k_layers' one-launch token (granules above): the old value comes from gsrc[row] (null: resid_src / out), the result goes to gdst[row] with tag gtag
-    // (null: out, as a plain write-through store)
-    const granule_t* gsrc; granule_t* gdst; unsigned gtag;
+    // k_layers' granule hand-offs (granule_t above): gron = this GEMV's results leave as granules (GemvArgs::gout / gout_peer) with tag gtag instead of plain stores;
+    // EPI_RESIDUAL: the old value comes from gsrc[row] (null: resid_src / out)
+    const granule_t* gsrc; bool gron; unsigned gtag;
 
     static __device__ __forceinline__ u32 inv_of(u32 d) { return d > 1 ? 0xFFFFFFFFu / d + 1u : 0u; }
     static __device__ __forceinline__ u32 udiv(u32 x, u32 d, u32 inv) { return d > 1 ? __umulhi(x, inv) : x; }
@@ -668,7 +649,7 @@ struct GemvCtx {
         const u32 NM = TWO ? 2u : 1u;
         rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, (int)(NM * TRm * rowbytes), kRsrcFlags);
         rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.sW), 0, (int)(NM * TRm * sn * 4), kRsrcFlags);
-        stored = false; primedA = primedB = false; resid_src = nullptr; gsrc = nullptr; gdst = nullptr; gtag = 0;
+        stored = false; primedA = primedB = false; resid_src = nullptr; gsrc = nullptr; gron = false; gtag = 0;
         // the first two steps of every wave are fixed (wave, wave + 16): they are requested before any barrier (the stash's steps are the next numbers)
         if (write_ctr && threadIdx.x == 0) *reinterpret_cast<u32*>(lds + ctr_off) = 2 * kWavesPerBlock;
     }
@@ -857,11 +838,11 @@ struct GemvCtx {
         if constexpr (EPI == EPI_STORE || EPI == EPI_RESIDUAL) {
             if (rv) {
                 if constexpr (EPI == EPI_STORE) st_result(a, row, acc);
-                else if (gdst) st_granule(gdst + row, gtag, __fadd_rn(resid, acc));
+                else if (gron) st_result_granule(a, row, gtag, __fadd_rn(resid, acc));
                 else st_result(a, row, __fadd_rn(resid, acc));       // o.add(tmp, offset) transformer.cpp:465,493
             }
         } else if constexpr (EPI == EPI_SWIGLU) {
-            if (rv) st_result(a, row, swiglu_elem(acc, acc2));       // o1.swiglu(o3) transformer.cpp:481
+            if (rv) { const float hv = swiglu_elem(acc, acc2); if (gron) st_result_granule(a, row, gtag, hv); else st_result(a, row, hv); }       // o1.swiglu(o3) transformer.cpp:481
         } else {   // EPI_ROPE_KV: rows (2i, 2i+1) of [Wq;Wk;Wv]; RoPE on q and k, append k,v to the cache
             const float other = __shfl_xor(acc, 1, kWave);
             if (rv && (lane & 1) == 0) {

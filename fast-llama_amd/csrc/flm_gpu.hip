@@ -505,11 +505,12 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
         const size_t o_px = up(o_hf + (world > 1 ? (256 + 8) * 64 : 0));                             // (+ one line per rank: k_ffn's hand-off across ranks)
         const size_t o_pa = up(o_px + (world > 1 ? pcap * d.dim * 4 : 0)), o_ph = up(o_pa + (world > 1 ? pcap * d.dim * 4 : 0));
         const size_t o_tl = up(o_ph + pcap * d.hidden_dim * 4);                                      // tensor parallel: the rank-spanning k_layers' lines [heads: 256][x1 | hd | x | cls: world x 256 each]
-        const size_t total = world > 1 ? up(o_tl + (size_t)(1 + 4 * world) * kTpLinesPerRank * 64) : o_fl + (kXchgSlots * 8 + 1) * 64;      // (flags: + the abort line)
+        const size_t o_gr = up(o_tl + (size_t)(1 + 4 * world) * kTpLinesPerRank * 64);                  // tensor parallel: the rank-spanning k_layers' granule vectors [x | x1 | att | hd] (flm_layer.h BackArgs::xg_*)
+        const size_t total = world > 1 ? up(o_gr + ((size_t)3 * d.dim + d.hidden_dim) * sizeof(granule_t)) : o_fl + (kXchgSlots * 8 + 1) * 64;      // (flags: + the abort line)
         hipError_t ae = hipErrorUnknown;
         if (world > 1) { ae = hipExtMallocWithFlags((void**)&c->xbuf, total, hipDeviceMallocFinegrained); c->xbuf_fine = ae == hipSuccess; }   // written by peer GPUs
         if (ae != hipSuccess) { (void)hipGetLastError(); HIPB(hipMalloc((void**)&c->xbuf, total)); }
-        c->xbuf_bytes = total; c->x_flags_off = o_fl; c->x_hflags_off = o_hf; c->x_tlines_off = world > 1 ? o_tl : 0;
+        c->xbuf_bytes = total; c->x_flags_off = o_fl; c->x_hflags_off = o_hf; c->x_tlines_off = world > 1 ? o_tl : 0; c->x_gran_off = world > 1 ? o_gr : 0;
         HIPB(hipMemsetAsync(c->xbuf, 0, total, c->stream));
         c->att_out = (float*)(c->xbuf + o_att); c->x1 = (float*)(c->xbuf + o_x1); c->hd = (float*)(c->xbuf + o_hd); c->logits = (float*)(c->xbuf + o_lg);
         c->peer[rank] = c->xbuf;
@@ -517,7 +518,8 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
         HIPB(hipMalloc((void**)&c->xepoch, 64)); HIPB(hipMemsetAsync(c->xepoch, 0, 64, c->stream));
         HIPB(hipMalloc((void**)&c->ffn_counter, 64)); HIPB(hipMemsetAsync(c->ffn_counter, 0, 64, c->stream));
     }
-    HIPB(hipMalloc((void**)&c->xg, (size_t)2 * c->d.dim * sizeof(granule_t))); HIPB(hipMemsetAsync(c->xg, 0, (size_t)2 * c->d.dim * sizeof(granule_t), c->stream));   // (tag 0: below every epoch)
+    if (world > 1) c->xg = (granule_t*)(c->xbuf + c->x_gran_off);                 // (cleared with the exchange buffer: tag 0, below every epoch)
+    else { const size_t gb = ((size_t)3 * c->d.dim + c->d.hidden_dim) * sizeof(granule_t); HIPB(hipMalloc((void**)&c->xg, gb)); HIPB(hipMemsetAsync(c->xg, 0, gb, c->stream)); }
     HIPB(hipMalloc((void**)&c->flag_lines, 1536 * 64)); HIPB(hipMalloc((void**)&c->xwg_err, 64));   // lines 0..255: k_attn_o's heads, 256..511: split heads' scores, 512..767: k_ffn, 768..1023: k_qkv_attn_o's QKV rows, 1024..1279: k_attn_ffn's x1 rows (k_embed clears all 1536)
     HIPB(hipMemsetAsync(c->flag_lines, 0, 1536 * 64, c->stream)); HIPB(hipMemsetAsync(c->xwg_err, 0, 64, c->stream));
     {   // the one-launch token (k_layers<.., TAIL>): [0] its epoch base, one flag line per classifier workgroup, their argmax slots
@@ -569,7 +571,7 @@ void flm_ctx_destroy(flm_ctx* c) {
     for (int r = 0; r < c->world; ++r) if (c->peer_opened[r] && c->peer[r]) hipIpcCloseMemHandle(c->peer[r]);
     void* ptrs[] = {c->emb, c->emb_s, c->out_norm, c->kcache, c->vcache, c->xbuf, c->xepoch, c->qbuf,
                     c->rope_cos, c->rope_sin, c->state, c->prompt_dev, c->out_tokens_dev,
-                    c->xg, c->flag_lines, c->xwg_err, c->att_q, c->att_qs, c->att_sc, c->trace, c->eng_base, c->ffn_counter, c->la_dev[0], c->la_dev[1], c->tail_dev[0], c->tail_dev[1], c->tail_mem,
+                    c->world > 1 ? nullptr : (void*)c->xg, c->flag_lines, c->xwg_err, c->att_q, c->att_qs, c->att_sc, c->trace, c->eng_base, c->ffn_counter, c->la_dev[0], c->la_dev[1], c->tail_dev[0], c->tail_dev[1], c->tail_mem,
                     c->pf_in_xbuf ? nullptr : c->pf_x, c->pf_qkv, c->pf_q, c->pf_in_xbuf ? nullptr : c->pf_att, c->pf_gu, c->pf_in_xbuf ? nullptr : c->pf_hd, c->pf_xs, c->pf_xq, c->pf_scores};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->bounce) hipHostFree(c->bounce);
@@ -601,7 +603,7 @@ int flm_p2p_export(flm_ctx* c, void* blob128) {
         const bool can = c->hs % kSplitDims == 0 && Gfull >= 2 && c->hs <= 128 && c->d.max_seq_len <= kSplitMaxSeq && c->heads_local * Gfull + 8 <= c->cu_count && c->heads_local * Gfull <= 256;
         b.caps = (tp_prefill_capable(c) ? 1 : 0) | (c->resident ? 2 : 0) | (can ? 4 : 0) | (c->fold_xchg ? 8 : 0) | ((c->tp_fuse_attn < 0 ? 0 : c->tp_fuse_attn > 2 ? 2 : c->tp_fuse_attn) << 4) | (c->tp_fuse_ffn ? 64 : 0)
                | (c->tp_trust_fused ? 128 : 0) | ((c->cu_parts & 15) << 8) | ((c->attn_split < 0 ? 0 : c->attn_split > 15 ? 15 : c->attn_split) << 12)
-               | (c->tp_fuse_layers && c->fuse_token ? 1 << 16 : 0) | ((c->cu_count & 1023) << 17);          // 16 tp_fuse_layers, 17-26 the CUs this rank's launches are sized for
+               | (c->tp_fuse_layers && c->fuse_token ? 1 << 16 : 0) | ((c->cu_count & 1023) << 17) | (c->gr_edges ? 1 << 27 : 0);          // 16 tp_fuse_layers, 17-26 the CUs this rank's launches are sized for
     }
     HIPC(c, hipIpcGetMemHandle(&b.h, c->xbuf));
     memcpy(blob128, &b, sizeof b);
@@ -626,7 +628,7 @@ int flm_p2p_import(flm_ctx* c, const void* blobs, int n) {
     for (int r = 0; r < n; ++r) if (b[r].device == c->device) ++c->ranks_on_device;
     if (!tp_prefill_capable(c)) c->tp_prefill = false;
     {   // the group's launch structure: the weakest any rank can do, computed alike on every rank from the same blobs
-        bool fold = true, span = true, can = true, multi_dev = false, trust = true, tpl = true; int fa = 2, ff = 1, split = (b[0].caps >> 12) & 15;
+        bool fold = true, span = true, can = true, multi_dev = false, trust = true, tpl = true, ggr = true; int fa = 2, ff = 1, split = (b[0].caps >> 12) & 15;
         for (int r = 0; r < n; ++r) {
             const int cp = (b[r].caps >> 8) & 15; int rod = 0;
             for (int q = 0; q < n; ++q) { if (b[q].device == b[r].device) ++rod; else multi_dev = true; }
@@ -634,6 +636,7 @@ int flm_p2p_import(flm_ctx* c, const void* blobs, int n) {
             fold = fold && fold_r; span = span && span_r; can = can && (b[r].caps & 4); trust = trust && (b[r].caps & 128);
             const int fa_r = (b[r].caps >> 4) & 3; if (fa_r < fa) fa = fa_r;
             if (!(b[r].caps & 64)) ff = 0;
+            if (!(b[r].caps & (1 << 27))) ggr = false;
             if (((b[r].caps >> 12) & 15) != split) split = 0;                   // (ranks that disagree: nobody splits)
             if (!(b[r].caps & (1 << 16)) || ((b[r].caps >> 17) & 1023) != ((b[0].caps >> 17) & 1023)) tpl = false;   // (the rank-spanning k_layers: every rank wants it, identical launch geometry)
         }
@@ -641,7 +644,7 @@ int flm_p2p_import(flm_ctx* c, const void* blobs, int n) {
         // exercised between CU partitions of ONE GPU -> the k_xchg launches (a flag round behind a kernel boundary) unless every rank says "tp_trust_fused"
         if (multi_dev && !trust) { fold = false; span = false; }
         if (4 * c->d.n_layers + 2 >= (int)kEpochStride) { fold = false; span = false; }   // (the folded rounds' epoch values 4 l + kind + 1 must stay inside one token's stride)
-        c->grp_fold = fold; c->grp_span = span; c->grp_can_split = can; c->grp_tpfa = span ? fa : 0; c->grp_tpff = span ? ff : 0; c->grp_split = can ? split : 0; c->grp_tpl = span && tpl;
+        c->grp_fold = fold; c->grp_span = span; c->grp_can_split = can; c->grp_tpfa = span ? fa : 0; c->grp_tpff = span ? ff : 0; c->grp_split = can ? split : 0; c->grp_tpl = span && tpl; c->grp_gr = ggr;
     }
     for (int r = 0; r < n; ++r) {
         if (r == c->rank) continue;
@@ -756,9 +759,9 @@ int flm_query(flm_ctx* c, const char* key, int* value) {
     const std::string k(key);
     const struct { const char* k; int v; } tab[] = {
         {"tuning", c->tuning ? 1 : 0}, {"wg_per_cu", c->wg_per_cu}, {"use_graph", c->use_graph}, {"graph_chunks", c->graph_chunks}, {"use_prefill", c->use_prefill}, {"use_mfma", c->use_mfma}, {"use_pv_mfma", c->use_pv_mfma},
-        {"fuse_attn_o", c->fuse_attn_o}, {"fuse_ffn", c->fuse_ffn}, {"fuse_qkv", c->fuse_qkv}, {"fuse_back", c->fuse_back}, {"fuse_layer", c->fuse_layer}, {"fuse_token", c->fuse_token}, {"fuse_tail", c->fuse_tail}, {"tok_nstq", c->tok_nstq}, {"tok_preq", c->tok_preq}, {"back_nst13", c->back_nst13}, {"back_nst13_head", c->back_nst13_head}, {"back_nst2", c->back_nst2}, {"back_pre13", c->back_pre13}, {"back_pre2", c->back_pre2}, {"back_ao", c->back_ao}, {"back_ao2", c->back_ao2}, {"gr_edges", c->gr_edges}, {"gr_active", (c->world == 1 && (c->la_valid[0] || c->la_valid[1])) ? ((c->la_valid[0] && c->tail_ok[0] && c->la_p[0].gr) ? 1 : 0) | ((c->la_valid[1] && c->tail_ok[1] && c->la_p[1].gr) ? 2 : 0) : 0}, {"use_prefill_mq", c->use_prefill_mq}, {"attn_split", c->attn_split},
+        {"fuse_attn_o", c->fuse_attn_o}, {"fuse_ffn", c->fuse_ffn}, {"fuse_qkv", c->fuse_qkv}, {"fuse_back", c->fuse_back}, {"fuse_layer", c->fuse_layer}, {"fuse_token", c->fuse_token}, {"fuse_tail", c->fuse_tail}, {"tok_nstq", c->tok_nstq}, {"tok_preq", c->tok_preq}, {"back_nst13", c->back_nst13}, {"back_nst13_head", c->back_nst13_head}, {"back_nst2", c->back_nst2}, {"back_pre13", c->back_pre13}, {"back_pre2", c->back_pre2}, {"back_ao", c->back_ao}, {"back_ao2", c->back_ao2}, {"gr_edges", c->gr_edges}, {"gr_active", ((c->la_valid[0] && c->la_ok[0] && c->la_p[0].gr && (c->world > 1 ? (c->p2p && c->grp_tpl) : c->tail_ok[0])) ? 1 : 0) | ((c->la_valid[1] && c->la_ok[1] && c->la_p[1].gr && (c->world > 1 ? (c->p2p && c->grp_tpl) : c->tail_ok[1])) ? 2 : 0)},   /* the granule hand-offs are what the one-launch token / the rank-spanning launch runs: bit 0 one workgroup per head, bit 1 split heads */ {"use_prefill_mq", c->use_prefill_mq}, {"attn_split", c->attn_split},
         {"use_qk_mfma", c->use_qk_mfma}, {"use_p2p", c->p2p}, {"fold_xchg", c->fold_xchg}, {"tp_fuse_attn", c->tp_fuse_attn}, {"tp_fuse_ffn", c->tp_fuse_ffn}, {"cu_parts", c->cu_parts}, {"fold_active", (c->world > 1 && c->p2p && c->grp_fold) ? 1 : 0}, {"span_active", (c->world > 1 && c->p2p && c->grp_span) ? 1 : 0}, {"tp_trust_fused", c->tp_trust_fused}, {"force_tp", c->force_tp},
-        {"tp_fuse_layers", c->tp_fuse_layers}, {"tp_fence", c->tp_fence}, {"tp_fence_active", c->tp_fence >= 0 ? c->tp_fence : (c->ranks_on_device == c->world ? 0 : 3)}, {"grp_tp_fuse_layers", (c->world > 1 && c->p2p && c->grp_tpl) ? 1 : 0}, {"tp_layers_active", (c->world > 1 && c->p2p && c->grp_tpl && (c->la_valid[0] || c->la_valid[1])) ? (c->la_valid[0] && c->la_ok[0] ? 1 : 0) | (c->la_valid[1] && c->la_ok[1] ? 2 : 0) : -1},   /* the rank-spanning k_layers was planned: bit 0 one workgroup per head, bit 1 split heads */ {"grp_tp_fuse_attn", c->grp_tpfa}, {"grp_tp_fuse_ffn", c->grp_tpff}, {"grp_attn_split", c->grp_split}, {"resident", c->resident}, {"fallback", c->fell_back}, {"fallback_active", c->fb_active ? 1 : 0},
+        {"tp_fuse_layers", c->tp_fuse_layers}, {"tp_fence", c->tp_fence}, {"tp_fence_active", c->tp_fence >= 0 ? c->tp_fence : (c->ranks_on_device == c->world ? 0 : 3)}, {"grp_gr", (c->world > 1 && c->grp_gr) ? 1 : 0}, {"grp_tp_fuse_layers", (c->world > 1 && c->p2p && c->grp_tpl) ? 1 : 0}, {"tp_layers_active", (c->world > 1 && c->p2p && c->grp_tpl && (c->la_valid[0] || c->la_valid[1])) ? (c->la_valid[0] && c->la_ok[0] ? 1 : 0) | (c->la_valid[1] && c->la_ok[1] ? 2 : 0) : -1},   /* the rank-spanning k_layers was planned: bit 0 one workgroup per head, bit 1 split heads */ {"grp_tp_fuse_attn", c->grp_tpfa}, {"grp_tp_fuse_ffn", c->grp_tpff}, {"grp_attn_split", c->grp_split}, {"resident", c->resident}, {"fallback", c->fell_back}, {"fallback_active", c->fb_active ? 1 : 0},
         {"ao_active", c->la_ok[0] ? (c->la_p[0].ao_o ? 1 : 0) | (c->la_p[0].ao_2 ? 2 : 0) : -1},      // which hand-offs of the token's launch (short contexts) are consumed in arrival order; -1: that launch was not planned (yet)
         {"token_path", (c->world == 1 ? ((c->fuse_attn_o ? 1 : 0) | (c->fuse_ffn ? 2 : 0) | (c->fuse_attn_o && c->fuse_qkv == 1 ? 4 : 0) | (c->fuse_attn_o && c->fuse_qkv >= 2 ? 8 : 0) | (c->fuse_back && c->fuse_attn_o && c->fuse_ffn ? (c->fuse_layer ? 128 + 256 + (c->fuse_token ? 512 + (c->fuse_tail && c->tail_ok[0] ? 1024 : 0) : 0) : 128) : 0)) : 0) | (c->attn_split ? 64 : 0)},
     };

@@ -105,7 +105,7 @@ struct flm_ctx {
     int fuse_layer = 1;                                // option "fuse_layer": ... with the QKV GEMV in front: the whole layer in one launch
     int back_nst13 = -1, back_nst13_head = -1, back_nst2 = 0, back_pre13 = 16, back_pre2 = 16;   // options "back_*": k_attn_ffn's stash slots (-1: as many as the LDS holds) and early register set (flm_layer.h)
     int gr_edges = 1;                                  // tuning dial "gr_edges" (round 6): the one-launch token's x / x1 hand-offs as data-tagged granules (flm_gemv.h: granule_t; BackArgs::gr); 0: flag rounds
-    granule_t* xg = nullptr;                           // ... their two vectors [2][dim] (x behind FFN2, x1 behind Wo)
+    granule_t* xg = nullptr; size_t x_gran_off = 0;    // ... the granule vectors [x: dim][x1: dim][att: dim][hd: hidden] (tensor parallel: a region of the exchange buffer, at x_gran_off in every rank's)
     int back_ao = 3, back_ao2 = 2;                     // options "back_ao" (bit 0: Wo, bit 1: FFN2 consume their activation in arrival order, GemvCtx::run_ao) / "back_ao2" (what of W2 is requested in front of the first look)
     int fuse_qkv = 1;                                  // option "fuse_qkv": QKV in front of attention + Wo in the same launch (k_qkv_attn_o; single GPU): 0 never,
                                                        // 1 when a head is spread over several workgroups (long contexts: where it pays), 2 always
@@ -129,7 +129,7 @@ struct flm_ctx {
     // what the tensor-parallel GROUP runs, agreed at flm_p2p_import from every rank's blob (the ranks' hand-off protocols must match or they wait on flags nobody raises):
     // exchanges folded into the consuming launches / launches that span the ranks / tp_fuse_attn / tp_fuse_ffn / attn_split, each the weakest any rank can do.
     // Options set after the import take effect at the next flm_p2p_export + flm_p2p_import round of the whole group.
-    bool grp_fold = false, grp_span = false, grp_can_split = false, grp_tpl = false; int grp_tpfa = 0, grp_tpff = 0, grp_split = 0;
+    bool grp_fold = false, grp_span = false, grp_can_split = false, grp_tpl = false, grp_gr = false /* every rank has "gr_edges": the rank-spanning launch's vectors are granules */; int grp_tpfa = 0, grp_tpff = 0, grp_split = 0;
     int force_tp = 0;                                  // option "force_tp": a context created with an RCCL id but world == 1 takes the sharded token path (RCCL exchanges over a 1-rank communicator: tests)
     int tp_trust_fused = 0;                            // option "tp_trust_fused": ranks on DISTINCT devices run the folded / rank-spanning launches too (validated only between CU partitions of one GPU)
     unsigned* xepoch = nullptr;                        // [4] exchanges done per kind (att, x1, hd, logits), device memory

@@ -51,7 +51,10 @@ struct BackArgs {
     // round 6: the residual stream as data-tagged granules inside the one-launch token (flm_gemv.h: granule_t): xg_a = x behind FFN2 (the next layer's / the classifier's input),
     // xg_b = x1 behind Wo (FFN13's input), [dim] each.  gr = 1: the two strict all-to-all edges of a layer carry no flag round -- the consumers sweep the granules themselves.
     // (TAIL launches only: their flag values count from an epoch and never repeat; the launch's first layer reads the embedding row, nothing else reads x.)
-    granule_t* xg_a; granule_t* xg_b; int gr;
+    // Tensor parallel (k_layers<.., TP>): ALL four cross-rank vectors of a layer are granules in every rank's exchange buffer -- xg_att = the heads' fp32 output, xg_hd = FFN13's hd
+    // too --, so the rank-spanning launch raises no line and needs no fence: a granule is ONE 8-byte store (over xGMI: one write), and nothing is inferred from the order of stores.
+    // xg_hd also serves any launch whose FFN2 takes hd in its all-to-all form (R5 bit 1 clear: int16 7B).  gres_off: this rank's first row of the residual stream (0 on one GPU).
+    granule_t* xg_a; granule_t* xg_b; granule_t* xg_att; granule_t* xg_hd; int gr; int gres_off;
     // tensor parallel (layer_body<.., TP>, round 6): the launch SPANS the ranks -- every rank runs the same k_layers on its rows (heads, rows of Wo / W2, rows of [W1; W3]: the
     // reference's row split, transformer.cpp:264-287), the four all-to-all hand-offs of a layer cross the ranks.  A producer stores its slice into every rank's buffer
     // (GemvArgs::out_peer / AttnArgs::out_peer) and raises ITS line in every rank's array; a consumer polls the lines of ALL ranks' producers in its LOCAL array.  The ranks'
@@ -153,6 +156,57 @@ __device__ __forceinline__ void raise_line(const BackArgs& p, unsigned* local, u
     }
 }
 
+// gemv_preload on a granule vector (flm_gemv.h: granule_t): xv[i] = elements 4 tid + 4096 i .. + 3 once their tags are `tag` (every thread re-reads ITS granules until they
+// match; only the lanes whose granules are missing read again); wv[i] = the norm weights (PRO_RMSNORM_QUANT).  XR rounds cover the vector (the host checks).  A wait of ~20 ms
+// raises *err (the host re-runs the call on one kernel per phase); TP: patient (20 s: ranks start seconds apart), leaves when any rank has given up (the abort line), *err = 2.
+template <int PRO, int XR, bool TP>
+__device__ __forceinline__ void gemv_preload_granules(const GemvArgs& a, float4 (&xv)[XR], float4 (&wv)[XR], const granule_t* g, const unsigned tag, const BackArgs& p) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<granule_t*>(g), 0, a.n * 8, 0x00020000);
+    const int gave_up = __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (PRO == PRO_RMSNORM_QUANT) {
+        const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.norm_w), 0, a.n * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            const v4f u = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rn, (int)((threadIdx.x * 4 + i * kGemvBlock * 4) * 4), 0, 0));
+            wv[i] = make_float4(u.x, u.y, u.z, u.w);
+        }
+    }
+    v4u32 A[XR], C[XR]; bool ok[XR];
+#pragma unroll
+    for (int i = 0; i < XR; ++i) { A[i] = v4u32{0u, 0u, 0u, 0u}; C[i] = A[i]; ok[i] = (int)(threadIdx.x * 4 + i * kGemvBlock * 4) >= a.n; }   // (past the vector: zeros, as gemv_preload's bounds-checked loads)
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned spins = 0;
+    while (true) {
+        asm volatile("" ::: "memory");                                         // (the loads are re-issued every pass)
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            if (!ok[i]) {
+                const int off = (int)((threadIdx.x * 4 + i * kGemvBlock * 4) * 8);
+                A[i] = __builtin_bit_cast(v4u32, __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, kAuxCoherent));
+                C[i] = __builtin_bit_cast(v4u32, __builtin_amdgcn_raw_buffer_load_b128(rg, off + 16, 0, kAuxCoherent));
+            }
+        }
+        bool all = true;
+#pragma unroll
+        for (int i = 0; i < XR; ++i) { if (!ok[i]) ok[i] = A[i].y == tag && A[i].w == tag && C[i].y == tag && C[i].w == tag; all = all && ok[i]; }
+        if (__all(all) || gave_up) break;
+        if constexpr (!TP) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) { __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        } else if ((++spins & 255u) == 0u) {
+            const bool aborted = __hip_atomic_load(p.tp.peer[p.tp.rank] + p.tp.abort_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 || __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            if (aborted || __builtin_amdgcn_s_memrealtime() - t0 > 2000000000ull) {
+                __hip_atomic_store(p.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                for (int r = 0; r < p.tp.world; ++r) __hip_atomic_store(p.tp.peer[r] + p.tp.abort_off, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < XR; ++i) xv[i] = make_float4(__uint_as_float(A[i].x), __uint_as_float(A[i].z), __uint_as_float(C[i].x), __uint_as_float(C[i].z));
+}
+
 #ifndef FLM_BACK_LATE
 #define FLM_BACK_LATE 1
 #endif
@@ -173,8 +227,9 @@ __device__ __forceinline__ void raise_line(const BackArgs& p, unsigned* local, u
 // order (GemvCtx::run_ao; one workgroup per head), bit 1 FFN2 consumes hd in arrival order.  The host picks the instantiation whose forms the shape allows (plan_layer: BackArgs::r5).
 // TP (round 6): the launch spans the tensor-parallel ranks (BackArgs::Tp).  The heads hand their output over as fp32 (every rank's Wo workgroups quantize it themselves, as
 // with split heads); R5 = 0 (the hand-offs in their all-to-all form).
-template <int QT, int XR2, bool QKV, bool SPLIT, bool PERSIST, int R5 = 0, bool TP = false, bool GRC = false>
-// GRC: the instantiation may run the granule form of the x / x1 edges (k_layers<.., TAIL>); p.gr says whether this launch does.
+template <int QT, int XR2, bool QKV, bool SPLIT, bool PERSIST, int R5 = 0, bool TP = false, int GRM = 0>
+// GRM: the granule form of the hand-offs (BackArgs::gr): 0 the instantiation has none, 1 it carries both forms and p.gr says which this launch runs (k_layers<.., TAIL>), 2 granules only
+// (k_layers<.., TP, GRT>: both forms in one rank-spanning kernel spill).
 // x0 (k_layers' one-launch token, first layer): the layer's input is read from there -- the embedding row -- by the QKV prologue and by Wo's residual epilogue instead of the residual
 // stream's buffer (which Wo's rows then start); null: the buffer.
 __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& aa, const GemvArgs& ao, const GemvArgs& a13, const GemvArgs& a2, const BackArgs& p, char* lds,
@@ -182,7 +237,9 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
     auto nostamp = [](int) {};
     auto stamp = [&](int k) { if (kAblate && tracing && p.trace && threadIdx.x == 0) p.trace[blockIdx.x * 16 + k] = __builtin_amdgcn_s_memrealtime(); };
     stamp(0);
-    const bool gr = GRC && PERSIST && !TP && p.gr != 0;                         // (wave-uniform, from the kernel's arguments)
+    const bool gr = PERSIST && (GRM == 2 || (GRM == 1 && p.gr != 0));            // the x / x1 edges as granules (wave-uniform: a constant, or from the kernel's arguments)
+    const bool gr_hd = gr && (R5 & 2) == 0;                                     // ... and hd, where FFN2 takes it in its all-to-all form
+    const bool gr_att = gr && TP;                                               // ... and the heads' fp32 output (the ranks' Wo workgroups quantize it themselves)
     unsigned nst13 = 0;
     if constexpr (QKV) {
         if ((int)blockIdx.x < p.gridq) {
@@ -195,7 +252,7 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
                     if ((int)gq.wave < p.preq) gq.issue(kAblate ? aq.ablate : 0, 1);
                     gq.stash_issue(lds);
                     if (gr) {
-                        gemv_preload_granules(aq, xq, nq, p.xg_a, target - 1u, p.err);     // (no line round: every thread waits for its own elements of x)
+                        gemv_preload_granules<PRO_RMSNORM_QUANT, 1, TP>(aq, xq, nq, p.xg_a, target - 1u, p);     // (no line round: every thread waits for its own elements of x)
                         wait_stores_done();                                     // every wave: the stash slots it requested have landed (the prologue's first barrier follows)
                     } else {
                     poll_lines_t<TP>(p.flag_x2, (TP ? p.tp.world : 1) * p.grid2, target - 1u, p);
@@ -238,9 +295,12 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
         if constexpr (QKV) attn_head_any<true, SPLIT, true>(aa, hh, lds, *aa.pos_ptr + 1, aa.q, aa.out, blockIdx.x % G, G, qwait, target);
         else attn_head_any<false, SPLIT>(aa, hh, lds, *aa.pos_ptr + 1, aa.q, aa.out, blockIdx.x % G, G);
         stamp(1);
+        if (gr_att) __syncthreads();                                            // (the LDS is free; the output's granules are their own flags)
+        else {
         wait_stores_done();                                                     // every wave: its part of the head's output is where the others will read it
         __syncthreads();                                                        // (and the LDS is free)
         raise_line<TP>(p, p.flag_h, p.tp.off_h, (TP ? (unsigned)p.tp.head_line0 : 0u) + blockIdx.x, target);
+        }
         stamp(2);
         if (p.nst13_head > 0 && (int)blockIdx.x < p.grid13) {
             nst13 = (unsigned)p.nst13_head;
@@ -259,7 +319,7 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
         GemvCtx<QT, EPI_RESIDUAL> g;
         g.init(ao, blockIdx.x - p.n_heads, p.grido, lds);
         g.resid_src = x0;
-        if (gr) { g.gsrc = xpoll ? p.xg_a : nullptr; g.gdst = p.xg_b; g.gtag = target; }   // (the launch's first layer: the old value is the embedding row's)
+        if (gr) { g.gsrc = xpoll ? p.xg_a + p.gres_off : nullptr; g.gron = true; g.gtag = target; }   // (the launch's first layer: the old value is the embedding row's / the plain vector's)
         g.issue(kAblate ? ao.ablate : 0);
         if (p.nst13 > 0 && (int)blockIdx.x < p.grid13) {
             nst13 = (unsigned)p.nst13;
@@ -275,6 +335,12 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
         if constexpr (!SPLIT && (R5 & 1) != 0) {                                // arrival order: a wave copies a column block when ITS heads' lines are up (GemvCtx::run_ao)
             const typename GemvCtx<QT, EPI_RESIDUAL>::AoSrc src{p.flag_h, (unsigned)aa.hs, (unsigned)p.n_heads, target, p.err};
             g.template run_ao<PRO_NONE>(ao, lds, src, []() {}, [&](int k) { if (k == 3) stamp(2); });
+        } else if (gr_att) {
+            float4 xv[1], nv[1];
+            gemv_preload_granules<PRO_QUANT, 1, TP>(ao, xv, nv, p.xg_att, target, p);
+            stamp(2);
+            gemv_prologue<QT, PRO_QUANT, 1>(ao, lds, xv, nv, [](int) {});
+            g.run(ao, lds, nostamp);
         } else {
         poll_lines_t<TP>(p.flag_h, TP ? p.tp.n_heads_all : p.n_heads, target, p);
         __syncthreads();
@@ -299,10 +365,11 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
     if ((int)blockIdx.x < p.grid13) {
         GemvCtx<QT, EPI_SWIGLU, true> g;
         g.init(a13, blockIdx.x, p.grid13, lds, 0, p.st_base, nst13);
+        if (gr_hd) { g.gron = true; g.gtag = target; }
         if ((int)g.wave < p.pre13) g.issue(kAblate ? a13.ablate : 0, 1);       // the first pre13 waves: their first register set in front of the x1 flag round
         float4 xv[1], nv[1];
         if (gr) {
-            gemv_preload_granules(a13, xv, nv, p.xg_b, target, p.err);
+            gemv_preload_granules<PRO_RMSNORM_QUANT, 1, TP>(a13, xv, nv, p.xg_b, target, p);
             wait_stores_done();                                                 // every wave: the stash slots it requested have landed
             stamp(5);
         } else {
@@ -324,9 +391,12 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
     } else if (!gr) {
         poll_lines_t<TP>(p.flag_x, (TP ? p.tp.world : 1) * p.grido, target, p);       // (keeps the order x1 -> hd for a workgroup without rows)
     }
+    if (gr_hd) __syncthreads();                                                 // (the LDS is free for the last phase; hd's granules are their own flags)
+    else {
     wait_stores_done();                                                         // every wave: its rows of hd are where the others will read them
     __syncthreads();                                                            // (and the LDS is free for the last phase)
     raise_line<TP>(p, p.flag_hd, p.tp.off_hd, (TP ? (unsigned)p.tp.rank * gridDim.x : 0u) + blockIdx.x, target);
+    }
     stamp(8);
     if ((int)blockIdx.x < p.grid2) {
     // ---- FFN2: k_gemv<QUANT, RESIDUAL> behind the hd flag round
@@ -335,7 +405,7 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
         // arrival order (GemvCtx::run_ao): no workgroup-wide poll, no prologue -- a wave quantizes the column block of each of its steps when the FFN13 workgroups that
         // produced THAT block have raised their lines.  W2's whole share is resident (two register sets per wave + nst2_ao stash slots), requested as ao_2 says.
         g2.init(a2, blockIdx.x, p.grid2, lds, 0, p.st_base, (unsigned)p.nst2_ao);
-        if (gr) { g2.gsrc = p.xg_b; g2.gdst = p.xg_a; g2.gtag = target; }
+        if (gr) { g2.gsrc = p.xg_b + p.gres_off; g2.gron = xflag; g2.gtag = target; }   // (a launch's last layer without tail: the classifier's launch reads the plain vector)
         const typename GemvCtx<QT, EPI_RESIDUAL, true>::AoSrc src{p.flag_hd, (unsigned)a13.rows_per_pass, (unsigned)p.grid13, target, p.err};
         g2.issue(kAblate ? a2.ablate : 0, p.ao_2 == 1 ? 0 : 1);
         if (p.ao_2 != 2) g2.stash_issue(lds);
@@ -344,15 +414,21 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
         stamp(11);
     } else {
     g2.init(a2, blockIdx.x, p.grid2, lds, 0, p.st_base, (unsigned)p.nst2);
-    if (gr) { g2.gsrc = p.xg_b; g2.gdst = p.xg_a; g2.gtag = target; }
+    if (gr) { g2.gsrc = p.xg_b + p.gres_off; g2.gron = xflag; g2.gtag = target; }
     if ((int)g2.wave < p.pre2) g2.issue(kAblate ? a2.ablate : 0, 1);            // the first pre2 waves: ONE set now, the rest when hd has arrived (k_ffn: all 16)
     g2.stash_issue(lds);
+    float4 xv2[XR2 > 0 ? XR2 : 1], nv2[XR2 > 0 ? XR2 : 1];
+    if (gr_hd) {
+        gemv_preload_granules<PRO_QUANT, (XR2 > 0 ? XR2 : 1), TP>(a2, xv2, nv2, p.xg_hd, target, p);
+        wait_stores_done();                                                     // every wave: the stash slots it requested have landed
+        stamp(9);
+    } else {
     poll_lines_t<TP>(p.flag_hd, (TP ? p.tp.world : 1) * (int)gridDim.x, target, p);
     wait_stores_done();                                                         // every wave: the stash slots it requested have landed
     __syncthreads();
     stamp(9);
-    float4 xv2[XR2 > 0 ? XR2 : 1], nv2[XR2 > 0 ? XR2 : 1];
     gemv_preload<QT, PRO_QUANT, XR2, true>(a2, xv2, nv2);
+    }
     gemv_prologue<QT, PRO_QUANT, XR2, true, FLM_BACK_LATE2 == 1>(a2, lds, xv2, nv2, [&](int) { g2.issue_missing(kAblate ? a2.ablate : 0); });
     stamp(10);
     g2.run(a2, lds, nostamp);
@@ -408,7 +484,7 @@ __device__ __forceinline__ void tail_phase(const TailArgs& T, const BackArgs& p,
         gc.stash_issue(lds);
         float4 xq[1], nq[1];
         if (p.gr) {
-            gemv_preload_granules(a, xq, nq, p.xg_a, xtarget, p.err);
+            gemv_preload_granules<PRO_RMSNORM_QUANT, 1, false>(a, xq, nq, p.xg_a, xtarget, p);
             wait_stores_done();                                                 // every wave: the stash slots it requested have landed
         } else {
         poll_lines(p.flag_x2, p.grid2, xtarget, p.err);
@@ -461,7 +537,7 @@ __device__ __forceinline__ void tail_phase(const TailArgs& T, const BackArgs& p,
 }
 // TP (round 6): the launch spans the tensor-parallel ranks (BackArgs::Tp; every rank launches it on its own stream, all of them must be running for any to finish): the
 // flag values count from the token's epoch base (k_embed moved it on, on every rank alike), the lines live in the ranks' exchange buffers and are never cleared.
-template <int QT, int XR2, bool SPLIT, int R5 = 0, bool TAIL = false, bool TP = false>
+template <int QT, int XR2, bool SPLIT, int R5 = 0, bool TAIL = false, bool TP = false, bool GRT = false>     // GRT: the rank-spanning launch on granules (BackArgs::gr)
 __global__ void __launch_bounds__(kGemvBlock, 4) k_layers(const LayerArgs* __restrict__ LA, const BackArgs p, const int l0, const int l1, const TailArgs* __restrict__ TA = nullptr) {
     static_assert(!TP || (R5 == 0 && !TAIL), "the rank-spanning launch carries the all-to-all hand-offs, the classifier is a launch of its own");
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -478,7 +554,7 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_layers(const LayerArgs* __res
     if constexpr (TP) base = *p.tp.base;
     for (int l = l0; l < l1; ++l) {
         const LayerArgs& A = *(const LayerArgs*)(LAc + l);
-        layer_body<QT, XR2, true, SPLIT, true, R5, TP, TAIL>(A.aq, A.aa, A.ao, A.a13, A.a2, p, lds, base + (unsigned)(l + 1), l > l0, TAIL || l + 1 < l1, l == (l1 - l0 > 1 ? l0 + 1 : l0),   // (trace builds: the stamps of the launch's second layer)
+        layer_body<QT, XR2, true, SPLIT, true, R5, TP, (TP ? (GRT ? 2 : 0) : (TAIL ? 1 : 0))>(A.aq, A.aa, A.ao, A.a13, A.a2, p, lds, base + (unsigned)(l + 1), l > l0, TAIL || l + 1 < l1, l == (l1 - l0 > 1 ? l0 + 1 : l0),   // (trace builds: the stamps of the launch's second layer)
                                                    (TAIL && l == l0) ? x0 : nullptr);
     }
     if constexpr (TAIL) {

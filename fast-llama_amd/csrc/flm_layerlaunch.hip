@@ -76,8 +76,18 @@ int plan_layer(flm_ctx* c, int l, bool with_qkv, int G, LayerArgs& A, BackArgs& 
     if (kAblate && c->trace_class == 103) { p.trace = c->trace; if (l == (c->d.n_layers > 1 ? 1 : 0)) { a13.trace = c->trace + 256 * 16; a2.trace = c->trace + 2 * 256 * 16; aa.trace = c->trace + 5 * 4096; } }   // (k_layers: its second layer)
     grid = parts + Po.grid; if (P13.grid > grid) grid = P13.grid; if (P2.grid > grid) grid = P2.grid; if (with_qkv && Pq.grid > grid) grid = Pq.grid;
     if (grid > all) return FLM_ERR_UNSUPPORTED;
-    p.xg_a = c->xg; p.xg_b = c->xg + d.dim;
-    p.gr = (c->gr_edges && c->xg && !tpl && c->world == 1 && with_qkv && d.dim <= 4 * kGemvBlock && d.dim % 4 == 0) ? 1 : 0;   // (one sweep round per thread; launch_layers clears it for a launch without tail)
+    // the granule hand-offs (flm_layer.h BackArgs::gr): one GPU -- the one-launch token (launch_layers clears gr for a launch without tail: its flag values repeat from token to token);
+    // tensor parallel -- the rank-spanning launch, where every rank asked for them (its values count from the token's epoch base)
+    p.xg_a = c->xg; p.xg_b = c->xg + d.dim; p.xg_att = c->xg + 2 * (size_t)d.dim; p.xg_hd = c->xg + 3 * (size_t)d.dim; p.gres_off = c->drow_begin;
+    p.gr = (c->gr_edges && c->xg && with_qkv && d.dim <= 4 * kGemvBlock && d.dim % 4 == 0 && d.hidden_dim % 4 == 0 && (tpl ? c->grp_gr : c->world == 1)) ? 1 : 0;   // (one sweep round per thread for dim; r2 <= 3 rounds for hidden: checked above)
+    {
+        auto gpeers = [&](unsigned long long* (&peer)[7], size_t off) { int k = 0; for (int r = 0; r < c->world; ++r) if (r != c->rank) peer[k++] = (unsigned long long*)(c->peer[r] + c->x_gran_off) + off; };
+        ao.gout = p.xg_b + c->drow_begin; a2.gout = p.xg_a + c->drow_begin; a13.gout = p.xg_hd + c->plan.hidden_begin;
+        if (tpl && p.gr) {
+            gpeers(ao.gout_peer, (size_t)d.dim + c->drow_begin); gpeers(a2.gout_peer, (size_t)c->drow_begin); gpeers(a13.gout_peer, 3 * (size_t)d.dim + c->plan.hidden_begin);
+            aa.gout = p.xg_att + (size_t)c->plan.head_begin * c->hs; gpeers(aa.gout_peer, 2 * (size_t)d.dim + (size_t)c->plan.head_begin * c->hs);
+        }
+    }
     p.flag_x2 = c->flag_lines + 1280 * 16; p.nstq = slots(c->tok_nstq); p.preq = c->tok_preq < 0 ? 0 : c->tok_preq > 16 ? 16 : c->tok_preq;
     if (tpl) {   // the cross-rank lines: regions of the ranks' exchange buffers (never cleared: epoch values); flag_q and the split heads' score lines stay local (k_embed clears them)
         BackArgs::Tp& t = p.tp;

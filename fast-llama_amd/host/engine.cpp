@@ -79,15 +79,16 @@ bool GpuTransformer::connect_ranks() {
 bool GpuTransformer::calibrate_structure() {
     const char* env = getenv("FLM_TP_CALIBRATE");
     if (!env || !env[0] || env[0] == '0') { _tp_structure = "library default"; return true; }
-    struct Cand { const char* name; int trust, ffn, layers, fence; };
-    const Cand cands[] = {{"exchange launches", 0, 0, 0, -1}, {"folded exchanges, QKV + attention + Wo across ranks", 1, 0, 0, -1},
-                          {"all layers in one rank-spanning launch, fenced flags", 1, 0, 1, 3}, {"all layers in one rank-spanning launch", 1, 0, 1, 0},
-                          {"folded exchanges, + FFN13 + FFN2 across ranks", 1, 1, 0, -1}};
+    struct Cand { const char* name; int trust, ffn, layers, fence, gr; };
+    const Cand cands[] = {{"exchange launches", 0, 0, 0, -1, 0}, {"folded exchanges, QKV + attention + Wo across ranks", 1, 0, 0, -1, 0},
+                          {"all layers in one rank-spanning launch, fenced flags", 1, 0, 1, 3, 0}, {"all layers in one rank-spanning launch, flags", 1, 0, 1, 0, 0},
+                          {"all layers in one rank-spanning launch, data-tagged granules (no flag, no fence)", 1, 0, 1, -1, 1},
+                          {"folded exchanges, + FFN13 + FFN2 across ranks", 1, 1, 0, -1, 0}};
     const int world = (int)_ctxs.size(), V = _cfg.vocab_size, kVerify = 96 < _cfg.max_seq_len - 2 ? 96 : _cfg.max_seq_len - 2, kTime = kVerify < 32 ? kVerify : 32;
     auto apply = [&](const Cand& c) {
         for (int r = 0; r < world; ++r)
             if (flm_set_option(_ctxs[r], "tp_trust_fused", c.trust) != FLM_OK || flm_set_option(_ctxs[r], "tp_fuse_ffn", c.ffn) != FLM_OK ||
-                flm_set_option(_ctxs[r], "tp_fuse_layers", c.layers) != FLM_OK || flm_set_option(_ctxs[r], "tp_fence", c.fence) != FLM_OK) { _err = std::string("set_option: ") + flm_last_error(_ctxs[r]); return false; }
+                flm_set_option(_ctxs[r], "tp_fuse_layers", c.layers) != FLM_OK || flm_set_option(_ctxs[r], "tp_fence", c.fence) != FLM_OK || flm_set_option(_ctxs[r], "gr_edges", c.gr) != FLM_OK) { _err = std::string("set_option: ") + flm_last_error(_ctxs[r]); return false; }
         return connect_ranks();
     };
     // BOS at position 0, then kVerify greedy tokens: every rank's ids and its last logits are the verdict; then the device time of kTime tokens (median of three)

@@ -179,6 +179,11 @@ int  flm_debug_read(flm_ctx* ctx, int what, int layer, float* out, size_t n);
  *   "tp_fence"       that launch's system-scope fences: bit 0 release in front of a cross-rank flag line, bit 1 acquire behind a cross-rank poll; -1 (default) = none between
  *                    ranks of ONE device, both between distinct devices (every cross-rank access is itself a system-scope atomic or a coherent load: the fences are belt and braces,
  *                    and cost ~20 us per hand-off)
+ *   "gr_edges"       1 (default) = inside the one-launch token (one GPU) and inside the rank-spanning launch (tensor parallel, where every rank says so; before flm_p2p_export) the
+ *                    vectors that cross workgroups / ranks -- the residual stream behind Wo and behind FFN2; across ranks also the heads' output and FFN13's hd -- travel as
+ *                    8-byte {value, tag} granules: ONE aligned store per element, the tag = the hand-off's flag value.  The data is its own flag: no drained stores, no flag
+ *                    line, no fence, nothing inferred from the ORDER of stores (over xGMI a granule is one write); the consumers re-read their own granules until the tags
+ *                    match.  0 = flag rounds (rounds 4-5).  Same results bit for bit
  *   "tp_trust_fused" 1 = between DISTINCT devices too, run the folded exchanges / rank-spanning launches (default 0: the k_xchg launches; before flm_p2p_export)
  *   "cu_parts"       n = confine the context's stream to 1/n of the device's CUs (part rank % n): several ranks on ONE GPU (tests)
  *   "force_tp"       1 = a context created with an RCCL id and world == 1 takes the sharded token path (RCCL exchanges over a 1-rank communicator; tests)

@@ -107,11 +107,11 @@ def _struct_worker(rank, world, port, q, scenario):
         tpl = int(bool(c.opts["tp_trust_fused"] and c.opts.get("tp_fuse_layers")))
         per_layer = 9 if not c.opts["tp_trust_fused"] else 0 if tpl else (2 if c.opts["tp_fuse_ffn"] else 3)
         c.tp_info = {"transport": "p2p", "launches_per_sharded_layer": per_layer, "fold_active": int(per_layer != 9), "tp_fuse_attn": 2, "tp_fuse_ffn": c.opts["tp_fuse_ffn"],
-                     "tp_fuse_layers": tpl, "tp_fence": c.opts.get("tp_fence") if tpl else None}
+                     "tp_fuse_layers": tpl, "tp_fence": c.opts.get("tp_fence") if tpl else None, "granules": (int(bool(c.opts.get("gr_edges"))) if tpl else None)}
 
     def fake_time(c, cfg, args, prompt, barrier, gold):
         per_layer = c.tp_info["launches_per_sharded_layer"]
-        wall = ({9: 0.9, 3: 0.5, 2: 0.4}[per_layer] if per_layer else (0.6 if c.tp_info["tp_fence"] else 0.3)) + 0.01 * rank      # (the rank-spanning launch: slow with fences, the fastest without)
+        wall = ({9: 0.9, 3: 0.5, 2: 0.4}[per_layer] if per_layer else (0.28 if c.tp_info["granules"] else 0.6 if c.tp_info["tp_fence"] else 0.3)) + 0.01 * rank      # (the rank-spanning launch: slow with fenced flags, faster without, the fastest on granules)
         match = True
         if scenario == "ffn_structure_mismatches_on_rank1" and per_layer == 2 and rank == 1:
             match = False
@@ -141,16 +141,16 @@ def _run_structs(scenario):
 def test_tp_structure_selection_takes_the_fastest_verified_structure_world2():
     (r0, w0, res0, o0), (r1, w1, res1, o1) = _run_structs("all_good")
     assert res0 == res1                                                   # every rank holds the same table (max-over-ranks times, MIN-over-ranks verdicts)
-    assert [v for _, v, _ in res0] == [True, True, True, True, True]
-    assert res0[4][2] == round(1000 * 0.41 / 10, 4)                       # the slowest rank's wall time (FFN13 + FFN2 across ranks: the last structure tried)
-    assert abs(w0 - 0.30) < 1e-9 and abs(w1 - 0.31) < 1e-9                # the measurement of the winner: all layers in one rank-spanning launch, without fences
-    assert o0["tp_trust_fused"] == 1 and o0["tp_fuse_layers"] == 1 and o0["tp_fence"] == 0 and o0["tp_fuse_ffn"] == 0 and o0 == o1     # ... and the group was put back on it
+    assert [v for _, v, _ in res0] == [True, True, True, True, True, True]
+    assert res0[5][2] == round(1000 * 0.41 / 10, 4)                       # the slowest rank's wall time (FFN13 + FFN2 across ranks: the last structure tried)
+    assert abs(w0 - 0.28) < 1e-9 and abs(w1 - 0.29) < 1e-9                # the measurement of the winner: all layers in one rank-spanning launch, on data-tagged granules
+    assert o0["tp_trust_fused"] == 1 and o0["tp_fuse_layers"] == 1 and o0["gr_edges"] == 1 and o0["tp_fuse_ffn"] == 0 and o0 == o1     # ... and the group was put back on it
 
 
 def test_tp_structure_that_mismatches_on_one_rank_is_reported_not_chosen_world2():
     (r0, w0, res0, o0), (r1, w1, res1, o1) = _run_structs("ffn_structure_mismatches_on_rank1")
-    assert [v for _, v, _ in res0] == [True, True, True, True, False] and res0 == res1
-    assert abs(w0 - 0.30) < 1e-9                                          # the rank-spanning launch stays the winner
+    assert [v for _, v, _ in res0] == [True, True, True, True, True, False] and res0 == res1
+    assert abs(w0 - 0.28) < 1e-9                                          # the rank-spanning launch stays the winner
     assert o0["tp_trust_fused"] == 1 and o0["tp_fuse_ffn"] == 0 and o0["tp_fuse_layers"] == 1 and o0 == o1     # ... and the group was put back on it
 
 

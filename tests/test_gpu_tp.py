@@ -277,7 +277,9 @@ def test_rank_spanning_layers_under_cu_masks(gpu, shape, qt, layers, world, npro
     launch with the reference's row split (transformer.cpp:264-287) across the ranks -- the four all-to-all hand-offs of a layer (heads -> Wo, x1 -> FFN13, hd -> FFN2, x -> the next
     layer's QKV: transformer.cpp:386-505's tasks) are flag rounds between the ranks' workgroups, every producer storing its slice into every rank's buffer and raising its line in
     every rank's array.  CU-masked ranks on one GPU (2 x 128, 4 x 64, 8 x 32 CUs); short prompts and long ones (split heads: a head over hs / 32 workgroups of its rank);
-    logits and graph-replayed greedy ids of every rank = the oracle's bits, and the launch is what ran (tp_layers_active)."""
+    logits and graph-replayed greedy ids of every rank = the oracle's bits, and the launch is what ran (tp_layers_active).
+    Both forms of the hand-offs: the default -- every cross-rank vector (heads' output, x1, hd, x) as data-tagged 8-byte granules, no flag line and no fence ("gr_edges" 1,
+    gr_active) -- and the flag rounds ("gr_edges" 0 on ONE rank: the whole group is back on flags), with and without the fences around the lines."""
     cfg = synth.make_config(shape, qt)
     if layers:
         cfg.n_layers = layers
@@ -305,11 +307,25 @@ def test_rank_spanning_layers_under_cu_masks(gpu, shape, qt, layers, world, npro
         ids = c.decode_greedy(cur, pos, 4)
         return lg, [int(x) for x in ids], c.query("tp_layers_active")
 
-    for r, (lg, ids, act) in enumerate(_run_ranks(ctxs, rank_main)):
-        for i, l in enumerate(lg):
-            assert bits_equal(l, want[i]), f"rank {r}: logits of step {i}"
-        assert ids == ids_want[3:7], f"rank {r}: greedy ids"
-        assert act >= 1 and (nprompt < 128 or act & 2), f"rank {r}: the rank-spanning launch did not run (tp_layers_active {act})"
+    for form in ("granules", "flags", "fenced flags", "granules again"):
+        if form == "flags": ctxs[0].set_option("gr_edges", 0)
+        elif form == "fenced flags":
+            for c in ctxs: c.set_option("tuning", 1); c.set_option("tp_fence", 3)
+        elif form == "granules again":
+            for c in ctxs: c.set_option("tp_fence", -1)
+            ctxs[0].set_option("gr_edges", 1)
+        if form != "granules":
+            gpu.Ctx.regroup(ctxs)
+            for c in ctxs: c.reset_kv()
+        for c in ctxs:
+            assert c.query("grp_tp_fuse_layers") == 1 and c.query("grp_gr") == (1 if form.startswith("granules") else 0)
+        for r, (lg, ids, act) in enumerate(_run_ranks(ctxs, rank_main)):
+            for i, l in enumerate(lg):
+                assert bits_equal(l, want[i]), f"{form}, rank {r}: logits of step {i}"
+            assert ids == ids_want[3:7], f"{form}, rank {r}: greedy ids"
+            assert act >= 1 and (nprompt < 128 or act & 2), f"{form}, rank {r}: the rank-spanning launch did not run (tp_layers_active {act})"
+        for c in ctxs:
+            assert bool(c.query("gr_active")) == form.startswith("granules"), form
     # the structure is an option like the others: off on one rank and the whole group is back on the per-layer launches, same bits
     ctxs[-1].set_option("tp_fuse_layers", 0)
     gpu.Ctx.regroup(ctxs)

@@ -27,13 +27,14 @@ def run(fn):
     return out
 
 only = os.environ.get("FLM_TP_ONLY")      # e.g. "1,2,1": that structure alone (for a profile)
-for fold, fa, fn, name in ((1, 2, 0, "ALL layers in one rank-spanning launch (k_layers<TP>)"), (0, 0, 0, "k_xchg launches (9 per layer)"), (1, 0, 0, "folded exchanges (5 per layer)"), (1, 1, 0, "folded + attention and Wo in one launch (4 per layer)"),
+for fold, fa, fn, name in ((1, 2, 0, "ALL layers in one rank-spanning launch (k_layers<TP>), data-tagged granules"), (1, 2, 0, "ALL layers in one rank-spanning launch (k_layers<TP>), flag rounds"), (0, 0, 0, "k_xchg launches (9 per layer)"), (1, 0, 0, "folded exchanges (5 per layer)"), (1, 1, 0, "folded + attention and Wo in one launch (4 per layer)"),
                            (1, 2, 0, "folded + QKV, attention and Wo in one launch (3 per layer)"), (1, 1, 1, "folded + attention and Wo, FFN13 and FFN2 fused (3 per layer)"),
                            (1, 2, 1, "folded + QKV, attention, Wo | FFN13, FFN2 (2 per layer)")):
     tpl = 1 if name.startswith("ALL") else 0
-    if only and only != (f"{fold},{fa},{fn}" if not tpl else "tpl"): continue
+    gr = 1 if "granules" in name else 0
+    if only and only != (f"{fold},{fa},{fn}" if not tpl else ("tplg" if gr else "tpl")): continue
     for c in ctxs:
-        c.set_option("tp_fuse_layers", tpl); c.set_option("fold_xchg", fold); c.set_option("tp_fuse_attn", fa); c.set_option("tp_fuse_ffn", fn); c.reset_kv()
+        c.set_option("gr_edges", gr); c.set_option("tp_fuse_layers", tpl); c.set_option("fold_xchg", fold); c.set_option("tp_fuse_attn", fa); c.set_option("tp_fuse_ffn", fn); c.reset_kv()
     capi.Ctx.regroup(ctxs)              # the group's launch structure is agreed when the blobs are exchanged
     first = run(lambda c: c.forward_argmax(prompt, 0))[0]
     run(lambda c: c.decode_greedy(first, len(prompt), 8))
