@@ -45,6 +45,9 @@ struct AttnArgs {
     // k_layers' granule hand-offs (flm_gemv.h: granule_t): non-null = the head's output leaves as {value, tag} granules (tag = the launch's flag value, attn_head's epoch_arg) into
     // every rank's granule vector (offset like `out`) instead of plain stores -- the Wo workgroups sweep them, nobody drains stores or raises a line for them
     unsigned long long* gout; unsigned long long* gout_peer[7];
+    // ... and its INPUT: q [heads * hs] and this token's K / V cache row [heads * hs] as granules written by the QKV phase of the same launch (attn_head's gr_in: the head sweeps
+    // its own pieces instead of polling the QKV workgroups' lines and reading behind them; the cache rows themselves are written for the NEXT tokens and not waited for)
+    const unsigned long long* qg; const unsigned long long* kg; const unsigned long long* vg;
 };
 
 #ifndef FLM_V_LATE_NS
@@ -83,8 +86,8 @@ constexpr int kSplitDims = 32, kSplitMaxSeq = 1024, kSplitVRegs = kSplitMaxSeq *
 // requested in FRONT of mid() and land while the lines are polled; behind it come q and the one new row of K and of V, patched into the ring registers of the
 // thread whose piece it is.  The arithmetic is untouched.
 struct AttnNoMid { __device__ __forceinline__ void operator()() const {} };
-template <int NF, bool COH, bool SPLIT = false, bool PRE = false, class Mid = AttnNoMid>
-__device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow, const int g = 0, const int G = 1, Mid&& mid = Mid(), const unsigned epoch_arg = 0u) {
+template <int NF, bool COH, bool SPLIT = false, bool PRE = false, class Mid = AttnNoMid, bool GRIN = false>
+__device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow, const int g = 0, const int G = 1, Mid&& mid = Mid(), const unsigned epoch_arg = 0u, const bool gr_out = false) {
     const unsigned xepoch = epoch_arg ? epoch_arg : a.epoch;      // what the parts of a split head raise / wait for in their score exchange
     typedef float v4f __attribute__((ext_vector_type(4)));
     constexpr int D = SPLIT ? 4 : kAttnDepth;         // K ring depth
@@ -187,7 +190,62 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
             for (int u = 0; u < DV; ++u) request(rV, u, nt, prowv, goffv, ringV[u], Told);
         }
     }
-    if constexpr (PRE) {
+    constexpr bool swept = PRE && !SPLIT && GRIN;                  // (GRIN: k_layers' one-launch token, one workgroup per head)
+    if constexpr (swept) {
+        {
+            // q and this token's K / V row as granules (tag epoch_arg) from the QKV phase of this launch: every thread re-reads ITS pieces until their tags match -- q element
+            // tid, and at most one 16-byte piece of the K tile and of the V tile that hold row T - 1 (T <= 2 tiles: everything was requested above).  No line round, no read behind it.
+            typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+            const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(a.qg) + (size_t)h * hs, 0, hs * 8, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(a.kg) + (size_t)h * hs, 0, hs * 8, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(a.vg) + (size_t)h * hs, 0, hs * 8, 0x00020000);
+            int kcol = -1, vcol = -1;                                   // first column of the thread's piece of row T - 1 (none: -1)
+#pragma unroll
+            for (int u = 0; u < D; ++u)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    if (sb + u < se && (sb + u) * kAttnTile + prow[j] == T - 1) kcol = (goff[j] >> 2) % hs;
+                    if (u < DV && u < nt && u * kAttnTile + prowv[j] == T - 1) vcol = (goffv[j] >> 2) % hs;
+                }
+            unsigned qbits = 0; v4u32 KA = {0u, 0u, 0u, 0u}, KC = KA, VA = KA, VC = KA;
+            bool okq = tid >= hs, okk = kcol < 0, okv = vcol < 0;
+            const int gave_up = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (true) {
+                asm volatile("" ::: "memory");
+                uint2 qq = make_uint2(0u, 0u);
+                if (!okq) qq = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rq, tid * 8, 0, kAuxCoherent));
+                if (!okk) { KA = __builtin_bit_cast(v4u32, __builtin_amdgcn_raw_buffer_load_b128(rk, kcol * 8, 0, kAuxCoherent)); KC = __builtin_bit_cast(v4u32, __builtin_amdgcn_raw_buffer_load_b128(rk, kcol * 8 + 16, 0, kAuxCoherent)); }
+                if (!okv) { VA = __builtin_bit_cast(v4u32, __builtin_amdgcn_raw_buffer_load_b128(rv, vcol * 8, 0, kAuxCoherent)); VC = __builtin_bit_cast(v4u32, __builtin_amdgcn_raw_buffer_load_b128(rv, vcol * 8 + 16, 0, kAuxCoherent)); }
+                if (!okq) { okq = qq.y == epoch_arg; qbits = qq.x; }
+                if (!okk) okk = KA.y == epoch_arg && KA.w == epoch_arg && KC.y == epoch_arg && KC.w == epoch_arg;
+                if (!okv) okv = VA.y == epoch_arg && VA.w == epoch_arg && VC.y == epoch_arg && VC.w == epoch_arg;
+                if (__all(okq && okk && okv) || gave_up) break;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) { __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            }
+            stamp(7);
+            qv[0] = tid < hs ? __uint_as_float(qbits) : 0.f;
+            const v4f kp = {__uint_as_float(KA.x), __uint_as_float(KA.z), __uint_as_float(KC.x), __uint_as_float(KC.z)};
+            const v4f vp = {__uint_as_float(VA.x), __uint_as_float(VA.z), __uint_as_float(VC.x), __uint_as_float(VC.z)};
+#pragma unroll
+            for (int u = 0; u < D; ++u)
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    if (sb + u < se && (sb + u) * kAttnTile + prow[j] == T - 1) ringK[u][j] = kp;
+            // the V tiles behind the sweep (as behind the flag round before): the earlier rows from the cache, the piece of row T - 1 from its granules
+#pragma unroll
+            for (int u = 0; u < DV; ++u)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    if (u < nt && u * kAttnTile + prowv[j] == T - 1) ringV[u][j] = vp;
+                    else {
+                        const unsigned off = (u < nt && u * kAttnTile + prowv[j] < Told) ? (unsigned)(u * tile_bytes + goffv[j]) : 0x80000000u;
+                        ringV[u][j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rV, (int)off, 0, COH ? kAuxCoherent : 0));
+                    }
+                }
+        }
+    }
+    if constexpr (PRE && !swept) {
         mid();                                                      // the flag round: q and this token's cache rows are in memory
         stamp(7);
 #pragma unroll
@@ -536,7 +594,7 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
     }
     stamp(4);
     if (tid < nd) {
-        if (a.gout) {
+        if (gr_out) {                                                         // (k_layers' granule hand-offs: AttnArgs::gout)
             const unsigned long long gv = ((unsigned long long)epoch_arg << 32) | (unsigned long long)__float_as_uint(o);
             __hip_atomic_store(a.gout + (size_t)h * hs + d0 + tid, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int i = 0; i < a.n_peer; ++i) __hip_atomic_store(a.gout_peer[i] + (size_t)h * hs + d0 + tid, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -566,13 +624,13 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
 }
 // SPLIT is a template argument of the kernels (not a run-time branch inside one kernel): the two forms keep different things in
 // registers, and compiled into one function they spilled a 16-byte register -- behind an s_waitcnt vmcnt(0) on the whole prefetch
-template <bool COH, bool SPLIT, bool PRE = false, class Mid = AttnNoMid>
+template <bool COH, bool SPLIT, bool PRE = false, bool GRIN = false, class Mid = AttnNoMid>
 // epoch: the value the parts of a split head raise / wait for in their score exchange (0: a.epoch; k_layers passes the layer's flag target, which counts from the token's epoch base)
-__device__ __forceinline__ void attn_head_any(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow, const int g = 0, const int G = 1, Mid&& mid = Mid(), const unsigned epoch = 0u) {
+__device__ __forceinline__ void attn_head_any(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow, const int g = 0, const int G = 1, Mid&& mid = Mid(), const unsigned epoch = 0u, const bool gr_out = false) {
     if constexpr (SPLIT) {      // the host picks G = hs / kSplitDims (attn_parts): every part owns 32 output dimensions; hs <= 128
-        if (a.hs <= 64) attn_head<1, COH, true, PRE>(a, h, lds, T, qrow, orow, g, G, mid, epoch); else attn_head<2, COH, true, PRE>(a, h, lds, T, qrow, orow, g, G, mid, epoch);
+        if (a.hs <= 64) attn_head<1, COH, true, PRE, Mid>(a, h, lds, T, qrow, orow, g, G, static_cast<Mid&&>(mid), epoch, gr_out); else attn_head<2, COH, true, PRE, Mid>(a, h, lds, T, qrow, orow, g, G, static_cast<Mid&&>(mid), epoch, gr_out);
     } else {
-        if (a.hs <= 64) attn_head<1, COH, false, PRE>(a, h, lds, T, qrow, orow, 0, 1, mid, epoch); else if (a.hs <= 128) attn_head<2, COH, false, PRE>(a, h, lds, T, qrow, orow, 0, 1, mid, epoch); else attn_head<4, COH, false, PRE>(a, h, lds, T, qrow, orow, 0, 1, mid, epoch);
+        if (a.hs <= 64) attn_head<1, COH, false, PRE, Mid, GRIN>(a, h, lds, T, qrow, orow, 0, 1, static_cast<Mid&&>(mid), epoch, gr_out); else if (a.hs <= 128) attn_head<2, COH, false, PRE, Mid, GRIN>(a, h, lds, T, qrow, orow, 0, 1, static_cast<Mid&&>(mid), epoch, gr_out); else attn_head<4, COH, false, PRE, Mid, GRIN>(a, h, lds, T, qrow, orow, 0, 1, static_cast<Mid&&>(mid), epoch, gr_out);
     }
 }
 // batched prefill: workgroup (h, i) is query i of the batch, at position pos0 + i, over the cache rows 0 .. pos0 + i

@@ -36,6 +36,7 @@ struct GemvArgs {
     float* out_peer[7]; int n_peer;
     // the same vector as data-tagged granules (granule_t below; k_layers' granule hand-offs: GemvCtx::gron): local / every peer's, offset like `out`; the tag is the launch's (run time)
     unsigned long long* gout; unsigned long long* gout_peer[7];
+    unsigned long long* gk; unsigned long long* gv;   // EPI_ROPE_KV: this token's K / V cache row [kv_dim] as granules beside the cache rows (gout: q)
     // ... and the flag round of that exchange folded into the CONSUMING launch (XchgFold below; world == 0: not used)
     struct XchgFold {
         unsigned* local_flags; unsigned* peer_flags[8];         // flag lines [slot][rank], 64 bytes each, in every rank's exchange buffer
@@ -853,12 +854,19 @@ struct GemvCtx {
                     const u32 h = rr / hs, d = rr - h * hs;
                     float o0, o1;
                     rope_pair(x0, x1, rc, rs, o0, o1);
-                    if (row < (u32)a.dim) { st_agent(a.out + row, o0); st_agent(a.out + row + 1, o1); }
-                    else { float* kp = a.kcache + ((size_t)h * a.max_seq + pos) * hs + d; st_agent(kp, o0); st_agent(kp + 1, o1); }
+                    if (row < (u32)a.dim) {
+                        if (gron) { st_granule(a.gout + row, gtag, o0); st_granule(a.gout + row + 1, gtag, o1); }     // (the head sweeps q's granules; nothing else reads q)
+                        else { st_agent(a.out + row, o0); st_agent(a.out + row + 1, o1); }
+                    }
+                    else {
+                        float* kp = a.kcache + ((size_t)h * a.max_seq + pos) * hs + d; st_agent(kp, o0); st_agent(kp + 1, o1);
+                        if (gron) { st_granule(a.gk + rr, gtag, o0); st_granule(a.gk + rr + 1, gtag, o1); }     // (the cache row is for the NEXT tokens; this token's head reads the granules)
+                    }
                 } else {
                     const u32 rr = row - a.dim - a.kv_dim;
                     const u32 h = rr / hs, d = rr - h * hs;
                     float* vp = a.vcache + ((size_t)h * a.max_seq + pos) * hs + d; st_agent(vp, x0); st_agent(vp + 1, x1);
+                    if (gron) { st_granule(a.gv + rr, gtag, x0); st_granule(a.gv + rr + 1, gtag, x1); }
                 }
             }
         }

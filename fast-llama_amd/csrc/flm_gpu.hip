@@ -519,7 +519,7 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
         HIPB(hipMalloc((void**)&c->ffn_counter, 64)); HIPB(hipMemsetAsync(c->ffn_counter, 0, 64, c->stream));
     }
     if (world > 1) c->xg = (granule_t*)(c->xbuf + c->x_gran_off);                 // (cleared with the exchange buffer: tag 0, below every epoch)
-    else { const size_t gb = ((size_t)3 * c->d.dim + c->d.hidden_dim) * sizeof(granule_t); HIPB(hipMalloc((void**)&c->xg, gb)); HIPB(hipMemsetAsync(c->xg, 0, gb, c->stream)); }
+    else { const size_t gb = ((size_t)6 * c->d.dim + c->d.hidden_dim) * sizeof(granule_t);   /* x | x1 | att | hd | q | k | v */ HIPB(hipMalloc((void**)&c->xg, gb)); HIPB(hipMemsetAsync(c->xg, 0, gb, c->stream)); }
     HIPB(hipMalloc((void**)&c->flag_lines, 1536 * 64)); HIPB(hipMalloc((void**)&c->xwg_err, 64));   // lines 0..255: k_attn_o's heads, 256..511: split heads' scores, 512..767: k_ffn, 768..1023: k_qkv_attn_o's QKV rows, 1024..1279: k_attn_ffn's x1 rows (k_embed clears all 1536)
     HIPB(hipMemsetAsync(c->flag_lines, 0, 1536 * 64, c->stream)); HIPB(hipMemsetAsync(c->xwg_err, 0, 64, c->stream));
     {   // the one-launch token (k_layers<.., TAIL>): [0] its epoch base, one flag line per classifier workgroup, their argmax slots

@@ -97,13 +97,13 @@ struct flm_ctx {
     int fuse_back = 1;                                 // option "fuse_back": attention + Wo + FFN13 + FFN2 in one launch with [W1; W3] stashed in LDS under the attention (k_attn_ffn; single GPU,
                                                        // head size a multiple of 64, one workgroup per head)
     int fuse_token = 1;                                // option "fuse_token": ALL layers of a token in one launch (k_layers: the edge between two layers is a flag round in front of which [Wq; Wk; Wv] streams)
-    int tok_nstq = 4, tok_preq = 16;                   // options "tok_nstq" / "tok_preq": its stash slots / early waves of [Wq; Wk; Wv]
+    int tok_nstq = 4, tok_preq = 99 /* 99: by launch (plan_layer) */;                   // options "tok_nstq" / "tok_preq": its stash slots / early waves of [Wq; Wk; Wv]
     void* la_dev[2] = {nullptr, nullptr}; bool la_valid[2] = {false, false}, la_ok[2] = {false, false}; flm::BackArgs la_p[2]; int la_grid[2] = {0, 0}, la_r2[2] = {0, 0};   // k_layers' argument blocks (flm_layers.hip)
     int fuse_tail = 1;                                 // option "fuse_tail": a greedy decode token is ONE launch (k_layers<.., TAIL>: embedding row, all layers, classifier, argmax + state advance); fp32 embedding tables
     void* tail_dev[2] = {nullptr, nullptr}; bool tail_ok[2] = {false, false};   // its argument block per head split (flm_layers.hip)
     unsigned* tail_mem = nullptr;                      // [0] the epoch base of the one-launch token's flag values, [16 ..) one flag line per classifier workgroup, then their argmax slots
     int fuse_layer = 1;                                // option "fuse_layer": ... with the QKV GEMV in front: the whole layer in one launch
-    int back_nst13 = -1, back_nst13_head = -1, back_nst2 = 0, back_pre13 = 16, back_pre2 = 16;   // options "back_*": k_attn_ffn's stash slots (-1: as many as the LDS holds) and early register set (flm_layer.h)
+    int back_nst13 = -1, back_nst13_head = -1, back_nst2 = 0, back_pre13 = 99 /* 99: by launch (plan_layer) */, back_pre2 = 16;   // options "back_*": k_attn_ffn's stash slots (-1: as many as the LDS holds) and early register set (flm_layer.h)
     int gr_edges = 1;                                  // tuning dial "gr_edges" (round 6): the one-launch token's x / x1 hand-offs as data-tagged granules (flm_gemv.h: granule_t; BackArgs::gr); 0: flag rounds
     granule_t* xg = nullptr; size_t x_gran_off = 0;    // ... the granule vectors [x: dim][x1: dim][att: dim][hd: hidden] (tensor parallel: a region of the exchange buffer, at x_gran_off in every rank's)
     int back_ao = 3, back_ao2 = 2;                     // options "back_ao" (bit 0: Wo, bit 1: FFN2 consume their activation in arrival order, GemvCtx::run_ao) / "back_ao2" (what of W2 is requested in front of the first look)

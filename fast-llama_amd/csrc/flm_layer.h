@@ -228,8 +228,8 @@ __device__ __forceinline__ void gemv_preload_granules(const GemvArgs& a, float4 
 // TP (round 6): the launch spans the tensor-parallel ranks (BackArgs::Tp).  The heads hand their output over as fp32 (every rank's Wo workgroups quantize it themselves, as
 // with split heads); R5 = 0 (the hand-offs in their all-to-all form).
 template <int QT, int XR2, bool QKV, bool SPLIT, bool PERSIST, int R5 = 0, bool TP = false, int GRM = 0>
-// GRM: the granule form of the hand-offs (BackArgs::gr): 0 the instantiation has none, 1 it carries both forms and p.gr says which this launch runs (k_layers<.., TAIL>), 2 granules only
-// (k_layers<.., TP, GRT>: both forms in one rank-spanning kernel spill).
+// GRM: the granule form of the hand-offs (BackArgs::gr): 0 the instantiation runs flag rounds, 2 granules -- a compile-time choice (both forms in one kernel spill): the one-launch token
+// (k_layers<.., TAIL>) IS the granule form (a shape that cannot run it has no one-launch token: plan_layer), the rank-spanning launch has both instantiations (k_layers<.., TP, GRT>).
 // x0 (k_layers' one-launch token, first layer): the layer's input is read from there -- the embedding row -- by the QKV prologue and by Wo's residual epilogue instead of the residual
 // stream's buffer (which Wo's rows then start); null: the buffer.
 __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& aa, const GemvArgs& ao, const GemvArgs& a13, const GemvArgs& a2, const BackArgs& p, char* lds,
@@ -237,9 +237,12 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
     auto nostamp = [](int) {};
     auto stamp = [&](int k) { if (kAblate && tracing && p.trace && threadIdx.x == 0) p.trace[blockIdx.x * 16 + k] = __builtin_amdgcn_s_memrealtime(); };
     stamp(0);
-    const bool gr = PERSIST && (GRM == 2 || (GRM == 1 && p.gr != 0));            // the x / x1 edges as granules (wave-uniform: a constant, or from the kernel's arguments)
-    const bool gr_hd = gr && (R5 & 2) == 0;                                     // ... and hd, where FFN2 takes it in its all-to-all form
-    const bool gr_att = gr && TP;                                               // ... and the heads' fp32 output (the ranks' Wo workgroups quantize it themselves)
+    constexpr bool gr = PERSIST && GRM == 2;                                    // the x / x1 edges as granules
+    constexpr bool gr_hd = gr && (R5 & 2) == 0;                                     // ... and hd, where FFN2 takes it in its all-to-all form
+    // ... and q + this token's K / V row from the QKV phase to the heads, where a head is one workgroup and its <= 2 tiles are all requested at once
+    // (one GPU, one workgroup per head: the host launches this instantiation below kSplitFrom positions only -- plan_layer gives a shape whose long contexts cannot split no one-launch token)
+    constexpr bool gr_q = gr && !TP && !SPLIT && QKV;
+    constexpr bool gr_att = gr && (TP || SPLIT);                                    // ... and the heads' fp32 output, where the Wo workgroups quantize it themselves (across ranks; split heads)
     unsigned nst13 = 0;
     if constexpr (QKV) {
         if ((int)blockIdx.x < p.gridq) {
@@ -247,6 +250,7 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
             float4 xq[1], nq[1];
             if (!PERSIST || !xpoll) gemv_preload<QT, PRO_RMSNORM_QUANT, 1, PERSIST>(aq, xq, nq, x0);    // (x is there: requested in front of the context's set-up)
             gq.init(aq, blockIdx.x, p.gridq, lds, 0, p.st_base, (PERSIST && xpoll) ? (unsigned)p.nstq : 0u);
+            if (gr_q) { gq.gron = true; gq.gtag = target; }
             if constexpr (PERSIST) {
                 if (xpoll) {
                     if ((int)gq.wave < p.preq) gq.issue(kAblate ? aq.ablate : 0, 1);
@@ -266,9 +270,12 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
             stamp(12);
             gq.run(aq, lds, nostamp);
             stamp(13);
+            if (gr_q) __syncthreads();                                          // (the LDS is free for the next phase; q and the new K / V row travel as granules)
+            else {
             wait_stores_done();                                                 // every wave: its q / cache rows are where the heads will read them
             __syncthreads();                                                    // (and the LDS is free for the next phase)
             if (threadIdx.x == 0) __hip_atomic_store(p.flag_q + blockIdx.x * kFlagStride, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             stamp(14);
         }
     }
@@ -292,7 +299,7 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
             }
             __syncthreads();
         };
-        if constexpr (QKV) attn_head_any<true, SPLIT, true>(aa, hh, lds, *aa.pos_ptr + 1, aa.q, aa.out, blockIdx.x % G, G, qwait, target);
+        if constexpr (QKV) attn_head_any<true, SPLIT, true, gr_q>(aa, hh, lds, *aa.pos_ptr + 1, aa.q, aa.out, blockIdx.x % G, G, qwait, target, gr_att);
         else attn_head_any<false, SPLIT>(aa, hh, lds, *aa.pos_ptr + 1, aa.q, aa.out, blockIdx.x % G, G);
         stamp(1);
         if (gr_att) __syncthreads();                                            // (the LDS is free; the output's granules are their own flags)
@@ -366,7 +373,7 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
         GemvCtx<QT, EPI_SWIGLU, true> g;
         g.init(a13, blockIdx.x, p.grid13, lds, 0, p.st_base, nst13);
         if (gr_hd) { g.gron = true; g.gtag = target; }
-        if ((int)g.wave < p.pre13) g.issue(kAblate ? a13.ablate : 0, 1);       // the first pre13 waves: their first register set in front of the x1 flag round
+        if ((int)g.wave < p.pre13) g.issue(kAblate ? a13.ablate : 0, 1);       // the first pre13 waves: their first register set in front of the x1 hand-off
         float4 xv[1], nv[1];
         if (gr) {
             gemv_preload_granules<PRO_RMSNORM_QUANT, 1, TP>(a13, xv, nv, p.xg_b, target, p);
@@ -483,15 +490,8 @@ __device__ __forceinline__ void tail_phase(const TailArgs& T, const BackArgs& p,
         if ((int)gc.wave < p.preq) gc.issue(kAblate ? a.ablate : 0, 1);
         gc.stash_issue(lds);
         float4 xq[1], nq[1];
-        if (p.gr) {
-            gemv_preload_granules<PRO_RMSNORM_QUANT, 1, false>(a, xq, nq, p.xg_a, xtarget, p);
-            wait_stores_done();                                                 // every wave: the stash slots it requested have landed
-        } else {
-        poll_lines(p.flag_x2, p.grid2, xtarget, p.err);
+        gemv_preload_granules<PRO_RMSNORM_QUANT, 1, false>(a, xq, nq, p.xg_a, xtarget, p);     // (the one-launch token hands x over as granules: layer_body's GRM)
         wait_stores_done();                                                     // every wave: the stash slots it requested have landed
-        __syncthreads();
-        gemv_preload<QT, PRO_RMSNORM_QUANT, 1, true>(a, xq, nq);
-        }
         gemv_prologue<QT, PRO_RMSNORM_QUANT, 1, true, FLM_LAYER_LATEQ != 0>(a, lds, xq, nq, [&](int) { gc.issue_missing(kAblate ? a.ablate : 0); });
         gc.run(a, lds, nostamp);
         wait_stores_done();                                                     // every wave: its logits are in memory
@@ -554,7 +554,7 @@ __global__ void __launch_bounds__(kGemvBlock, 4) k_layers(const LayerArgs* __res
     if constexpr (TP) base = *p.tp.base;
     for (int l = l0; l < l1; ++l) {
         const LayerArgs& A = *(const LayerArgs*)(LAc + l);
-        layer_body<QT, XR2, true, SPLIT, true, R5, TP, (TP ? (GRT ? 2 : 0) : (TAIL ? 1 : 0))>(A.aq, A.aa, A.ao, A.a13, A.a2, p, lds, base + (unsigned)(l + 1), l > l0, TAIL || l + 1 < l1, l == (l1 - l0 > 1 ? l0 + 1 : l0),   // (trace builds: the stamps of the launch's second layer)
+        layer_body<QT, XR2, true, SPLIT, true, R5, TP, (TP ? (GRT ? 2 : 0) : (TAIL ? 2 : 0))>(A.aq, A.aa, A.ao, A.a13, A.a2, p, lds, base + (unsigned)(l + 1), l > l0, TAIL || l + 1 < l1, l == (l1 - l0 > 1 ? l0 + 1 : l0),   // (trace builds: the stamps of the launch's second layer)
                                                    (TAIL && l == l0) ? x0 : nullptr);
     }
     if constexpr (TAIL) {

@@ -39,7 +39,10 @@ int plan_layer(flm_ctx* c, int l, bool with_qkv, int G, LayerArgs& A, BackArgs& 
     GemvArgs acls{}; GemvPlan Pc{}; bool tail_fits = false;
     if (tail) {
         tail->gridc = 0;
-        if (c->fuse_tail && with_qkv && c->fuse_token && c->world == 1 && !tpl && c->got_emb && c->emb_qt == 0 && c->got_cls) {
+        // (round 6: the one-launch token IS the granule form of the hand-offs -- flm_layer.h GRM --: one sweep round per thread for dim, and its one-workgroup-per-head instantiation
+        //  takes q and the new K / V row as granules with the head's <= 2 tiles requested at once: long contexts must be able to split.  "gr_edges" 0: the four-launch token on flag rounds)
+        const bool gr_tail = c->gr_edges && c->xg && d.dim <= 4 * kGemvBlock && d.dim % 4 == 0 && d.hidden_dim % 4 == 0 && (d.max_seq_len <= kSplitFrom || attn_parts(c, d.max_seq_len) > 1);
+        if (gr_tail && c->fuse_tail && with_qkv && c->fuse_token && c->world == 1 && !tpl && c->got_emb && c->emb_qt == 0 && c->got_cls) {
             acls = args_cls(c);
             if (plan_gemv<QT, PRO_RMSNORM_QUANT, EPI_STORE>(c, acls, all, Pc) == FLM_OK && (acls.n + kGemvBlock * 4 - 1) / (kGemvBlock * 4) <= 1 && Pc.grid <= 256 && Pc.lds + 8 * (kStepBlk * 1024 + 256) <= kLdsMax) {
                 tail_fits = true; if (Pc.lds > own) own = Pc.lds;
@@ -58,7 +61,7 @@ int plan_layer(flm_ctx* c, int l, bool with_qkv, int G, LayerArgs& A, BackArgs& 
     p.flag_h = c->flag_lines; p.flag_hd = c->flag_lines + 512 * 16; p.flag_x = c->flag_lines + 1024 * 16;
     p.gridq = with_qkv ? Pq.grid : 0; p.flag_q = c->flag_lines + 768 * 16;
     p.target = (unsigned)(l + 1); p.err = c->xwg_err;
-    p.st_base = (unsigned)own; p.nst13 = slots(c->back_nst13); p.nst13_head = slots(c->back_nst13_head); p.nst2 = slots(c->back_nst2); p.pre13 = c->back_pre13 < 0 ? 0 : c->back_pre13 > 16 ? 16 : c->back_pre13; p.pre2 = c->back_pre2 < 0 ? 0 : c->back_pre2 > 16 ? 16 : c->back_pre2;
+    p.st_base = (unsigned)own; p.nst13 = slots(c->back_nst13); p.nst13_head = slots(c->back_nst13_head); p.nst2 = slots(c->back_nst2); p.pre13 = c->back_pre13 == 99 ? 16 : c->back_pre13 < 0 ? 0 : c->back_pre13 > 16 ? 16 : c->back_pre13; p.pre2 = c->back_pre2 < 0 ? 0 : c->back_pre2 > 16 ? 16 : c->back_pre2;
     {   // arrival-order hand-offs (GemvCtx::run_ao): one pass per workgroup, every step resident, a column block with <= 16 producers (PRO_QUANT: <= 256 elements)
         auto steps = [&](const GemvArgs& a, const GemvPlan& P, int rows) { const int RB = 64 >> P.cb_shift, RBP = P.Rm / RB, nbc = (a.n * esz / 16) >> P.cb_shift; return (rows + P.Rm - 1) / P.Rm <= P.grid ? ((RBP + kStepBlk - 1) / kStepBlk) * nbc : 1 << 30; };
         const int epb_o = (16 << Po.cb_shift) / esz, epb_2 = (16 << P2.cb_shift) / esz;
@@ -79,16 +82,26 @@ int plan_layer(flm_ctx* c, int l, bool with_qkv, int G, LayerArgs& A, BackArgs& 
     // the granule hand-offs (flm_layer.h BackArgs::gr): one GPU -- the one-launch token (launch_layers clears gr for a launch without tail: its flag values repeat from token to token);
     // tensor parallel -- the rank-spanning launch, where every rank asked for them (its values count from the token's epoch base)
     p.xg_a = c->xg; p.xg_b = c->xg + d.dim; p.xg_att = c->xg + 2 * (size_t)d.dim; p.xg_hd = c->xg + 3 * (size_t)d.dim; p.gres_off = c->drow_begin;
-    p.gr = (c->gr_edges && c->xg && with_qkv && d.dim <= 4 * kGemvBlock && d.dim % 4 == 0 && d.hidden_dim % 4 == 0 && (tpl ? c->grp_gr : c->world == 1)) ? 1 : 0;   // (one sweep round per thread for dim; r2 <= 3 rounds for hidden: checked above)
+    p.gr = (c->gr_edges && c->xg && with_qkv && d.dim <= 4 * kGemvBlock && d.dim % 4 == 0 && d.hidden_dim % 4 == 0 && (tpl ? c->grp_gr : (tail != nullptr && tail_fits))) ? 1 : 0;   // (one sweep round per thread for dim; r2 <= 3 rounds for hidden: checked above)
+    // with the edges on granules the sweep IS the phase's activation fetch, and it returns behind whatever its own wave requested in front of it: fewer early register sets
+    // at short contexts (tools/back_bench.py, 32 layers: pre13 16 / 12 / 8 / 4: 1571 / 1562 / 1561 / 1600 us per token; preq 16 / 12 / 8 with pre13 8: 1561 / 1545 / 1555); with
+    // split heads (long contexts) 16 stays (pre13 8: +0.9 %)
+    if (p.gr && !tpl && G == 1) { if (c->back_pre13 == 99) p.pre13 = 8; if (c->tok_preq == 99) p.preq = 12; }
     {
         auto gpeers = [&](unsigned long long* (&peer)[7], size_t off) { int k = 0; for (int r = 0; r < c->world; ++r) if (r != c->rank) peer[k++] = (unsigned long long*)(c->peer[r] + c->x_gran_off) + off; };
         ao.gout = p.xg_b + c->drow_begin; a2.gout = p.xg_a + c->drow_begin; a13.gout = p.xg_hd + c->plan.hidden_begin;
+        aa.gout = p.xg_att + (size_t)c->plan.head_begin * c->hs;                   // (used where the launch says so: layer_body's gr_att)
+        {   // q and this token's K / V row from the QKV phase to the heads (layer_body's gr_q): [q: dim][k: kv_dim][v: kv_dim] behind the four vectors
+            granule_t* gq = c->xg + 3 * (size_t)d.dim + d.hidden_dim;
+            aq.gout = gq; aq.gk = gq + d.dim; aq.gv = gq + d.dim + c->dim_local;
+            aa.qg = gq; aa.kg = aq.gk; aa.vg = aq.gv;
+        }
         if (tpl && p.gr) {
             gpeers(ao.gout_peer, (size_t)d.dim + c->drow_begin); gpeers(a2.gout_peer, (size_t)c->drow_begin); gpeers(a13.gout_peer, 3 * (size_t)d.dim + c->plan.hidden_begin);
-            aa.gout = p.xg_att + (size_t)c->plan.head_begin * c->hs; gpeers(aa.gout_peer, 2 * (size_t)d.dim + (size_t)c->plan.head_begin * c->hs);
+            gpeers(aa.gout_peer, 2 * (size_t)d.dim + (size_t)c->plan.head_begin * c->hs);
         }
     }
-    p.flag_x2 = c->flag_lines + 1280 * 16; p.nstq = slots(c->tok_nstq); p.preq = c->tok_preq < 0 ? 0 : c->tok_preq > 16 ? 16 : c->tok_preq;
+    p.flag_x2 = c->flag_lines + 1280 * 16; p.nstq = slots(c->tok_nstq); p.preq = c->tok_preq == 99 ? 16 : c->tok_preq < 0 ? 0 : c->tok_preq > 16 ? 16 : c->tok_preq;
     if (tpl) {   // the cross-rank lines: regions of the ranks' exchange buffers (never cleared: epoch values); flag_q and the split heads' score lines stay local (k_embed clears them)
         BackArgs::Tp& t = p.tp;
         t.world = c->world; t.rank = c->rank;

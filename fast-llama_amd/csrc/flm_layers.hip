@@ -64,7 +64,7 @@ int launch_layers(flm_ctx* c, hipStream_t st, int l0, int l1, int G, bool tail) 
     const dim3 g3(c->la_grid[key]), b3(kGemvBlock);
     const LayerArgs* LA = (const LayerArgs*)c->la_dev[key];
     BackArgs p = c->la_p[key];
-    if (!tail) p.gr = 0;                                                                // (granule tags count from the tail launch's epoch: flm_layer.h BackArgs::gr)
+    if (!tail) { p.gr = 0; if (c->back_pre13 == 99) p.pre13 = 16; if (c->tok_preq == 99) p.preq = 16; }                                                                // (granule tags count from the tail launch's epoch: flm_layer.h BackArgs::gr)
     const bool i8 = c->d.quant_type == FLM_QT_INT8, one = c->la_r2[key] <= 1;
     const TailArgs* TA = (const TailArgs*)c->tail_dev[key];
 #define FLM_LAUNCH_LAYERS(QT, XR2, SP) do { if (tail && p.r5) hipLaunchKernelGGL((k_layers<QT, XR2, SP, 3, true>), g3, b3, kLdsMax, st, LA, p, l0, l1, TA); \

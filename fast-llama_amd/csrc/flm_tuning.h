@@ -4,12 +4,12 @@
 //
 //   "wg_per_cu"        workgroups per CU for the stand-alone GEMV launches (1)
 //   "use_mfma"         int8 prefill GEMM tile shape on the matrix cores: 1 by problem size, 2 (or 0) always 64 x 64, 3 always 128 x 128 tiles (1)
-//   "tok_preq"         k_layers: how many of a workgroup's 16 waves request their first register set of the NEXT layer's [Wq; Wk; Wv] in front of the layer edge's flag round (16)
+//   "tok_preq"         k_layers: how many of a workgroup's 16 waves request their first register set of the NEXT layer's [Wq; Wk; Wv] in front of the layer edge's hand-off (by launch: 12 in the one-launch token below 128 positions, else 16)
 //   "tok_nstq"         ... and how many LDS stash slots (4.25 KiB each; -1: as many as the LDS holds) it fills with it there (4)
 //   "back_nst13"       stash slots a Wo workgroup fills with [W1; W3] under the attention (-1)
 //   "back_nst13_head"  ... a head workgroup fills behind its head (-1)
 //   "back_nst2"        ... every workgroup fills with W2 behind its rows of hd (0; the arrival-order FFN2 holds W2's whole share anyway)
-//   "back_pre13"       waves that request their first register set of [W1; W3] in front of the x1 flag round (16)
+//   "back_pre13"       waves that request their first register set of [W1; W3] in front of the x1 hand-off (by launch: 8 in the one-launch token below 128 positions, else 16)
 //   "back_pre2"        waves that request their first register set of W2 in front of the hd flag round (16; the hand-off in its round-4 form)
 //   "back_ao2"         arrival-order FFN2: what of W2 is requested in front of a wave's first look: 1 everything, 2 the first register sets (default), 3 first sets + stash
 //   "inject_wait_failure" 1 = raise the "a cross-workgroup wait gave up" flag NOW (one shot): the next call's fused launches run through without waiting, the call is re-run on

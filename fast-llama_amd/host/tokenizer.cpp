@@ -38,8 +38,6 @@ std::vector<int> Tokenizer::encode(std::string_view text, bool add_bos, bool add
         cur.clear();
     }
     // greedy merges by score
-    const int first = add_bos ? 0 : 0;
-    (void)first;
     for (;;) {
         float best_score = -1e10f; int best_id = -1, best_idx = -1;
         for (int i = 0; i + 1 < (int)out.size(); ++i) {
