@@ -378,6 +378,7 @@ def main():
     ap.add_argument("--pos", type=int, default=None, help="start the timed steps at this position (the prompt's greedy continuation is decoded, untimed, up to it); "
                                                           "default: prompt length + warmup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode128", action="store_true", help="skip the decode_128 object (rocprofv3 passes: per-kernel averages / counters then cover the driver's positions only, as roofline.avg_launch_us does)")
     ap.add_argument("--wg-per-cu", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="k=v: flm_set_option on the decode context (launch-structure A/B runs; reported in config.options; none by default)")
     ap.add_argument("--prompt-len", type=int, default=9)
@@ -489,7 +490,7 @@ def main():
     # SURVEY.md 8d's decode protocol beside the driver's K timed steps (20 steps at positions 14..33 flatter the token by ~3 %: fewer cache rows): prompt = BOS + 8 tokens, 128 greedy
     # steps with one event per token, the first 8 discarded, mean and p50 over the other 120 (positions 17..136), with that span's own roofline fraction.  Outside the timed region of `value`.
     decode_128 = None
-    if mode == "single" and args.pos is None and rank == 0:
+    if mode == "single" and args.pos is None and rank == 0 and not args.no_decode128:
         try:
             p9 = prompt_for(0)
             ctx.reset_kv(); f9 = ctx.forward_argmax(p9, 0)
@@ -603,7 +604,7 @@ def main():
     split_now = bool(token_path.get("heads_split_at_long_contexts")) and mid_pos + 1 >= 128      # (the launch's SPLIT instantiation: a head spread over hs / 32 workgroups)
     # (round 5: k_layers<QT, XR2, SPLIT, R5>, R5 = 3 where the launch consumes Wo's / FFN2's activation in arrival order -- the instantiation this run launched, not just any in the library)
     r5_now = 3 if (dom in ("layers", "token") and ao_active > 0) else 0
-    dom_regex = {"token": rf"k_layers<{qn}, \d+, {'true' if split_now else 'false'}, {r5_now}, true>", "layers": rf"k_layers<{qn}, \d+, {'true' if split_now else 'false'}, {r5_now}, false>", "layer": rf"k_attn_ffn<{qn}, \d+, true, false>", "back": rf"k_attn_ffn<{qn}, \d+, false, false>", "ffn": rf"k_ffn<{qn},"}.get(dom, rf"k_gemv<{qn}, 2, 2,")
+    dom_regex = {"token": rf"k_layers<{qn}, \d+, {'true' if split_now else 'false'}, {r5_now}, true(?:, \w+)*>", "layers": rf"k_layers<{qn}, \d+, {'true' if split_now else 'false'}, {r5_now}, false(?:, \w+)*>", "layer": rf"k_attn_ffn<{qn}, \d+, true, false>", "back": rf"k_attn_ffn<{qn}, \d+, false, false>", "ffn": rf"k_ffn<{qn},"}.get(dom, rf"k_gemv<{qn}, 2, 2,")
     if args.shape == "7B":
         traffic, traffic_src, traffic_note = pmc_traffic(dom_regex, capi.LIB_PATH)
     else:   # (the committed PMC summaries were collected on the 7B-shaped model: a launch of the same kernel on another shape moves other bytes)

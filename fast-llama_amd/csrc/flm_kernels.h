@@ -23,7 +23,11 @@
 //                         round; [W1; W3] is stashed in LDS by LDS-DMA under the attention, the next layer's [Wq; Wk; Wv] requested in front of the layer edge ("fuse_token" 0: off).
 //                         R5 = 3 (round 5): Wo and FFN2 consume their activation in ARRIVAL ORDER (GemvCtx::run_ao: a wave polls the producers of its own steps' column blocks only).
 //                         TAIL (round 5): the embedding row is the first layer's input, the classifier a phase behind the last layer, the argmax + state advance the launch's last act;
-//                         flag values count from a per-token epoch base ("fuse_tail" 0: off)
+//                         flag values count from a per-token epoch base ("fuse_tail" 0: off).  Round 6: the TAIL launch hands x, x1 (hd, the split heads' output) and q + the new
+//                         K / V row from workgroup to workgroup as data-tagged 8-byte granules {value, tag} -- no drained stores, no flag line, the consumers sweep their own
+//                         elements (flm_gemv.h granule_t, flm_layer.h gemv_preload_granules, attn_head<.., GRIN>; "gr_edges" 0: the four-launch token on flag rounds)
+//   k_layers<..,TP[,GRT]> (round 6; flm_layers_tp.hip) the same launch SPANNING the tensor-parallel ranks: every rank its rows (the reference's row split), the four hand-offs of a
+//                         layer across the ranks -- as granules in every rank's exchange buffer (GRT: no flag, no fence) or as flag rounds ("tp_fuse_layers", "gr_edges")
 //   k_attn_ffn<QT,XR2,QKV,SPLIT> the same layer_body as one launch per layer ("fuse_token" 0; "fuse_layer" 0: without the QKV GEMV; "fuse_back" 0: off)
 //   k_gemv<QT,PRO,EPI,XR> group-quantized GEMV, HBM-bound; fused prologue (rmsnorm+quantize | quantize) and epilogue (store | residual add | SwiGLU | RoPE + KV-cache
 //                         append): the classifier of every token; every phase of a tensor-parallel rank's token; the per-phase fallback behind a timed-out hand-off

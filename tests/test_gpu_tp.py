@@ -361,35 +361,58 @@ def test_group_agrees_on_the_weakest_launch_structure(gpu):
         c.close()
 
 
-@pytest.mark.skipif(_n_devices() < 2, reason="needs two GPUs")
-@pytest.mark.parametrize("trust", [0, 1])
-def test_two_gpus_p2p_and_trusted_fused_launches(gpu, trust):
-    """two ranks on two GPUs: by default the group takes the k_xchg launches (a flag round behind a kernel boundary); with "tp_trust_fused" on every rank the folded
-    exchanges and the rank-spanning launches over xGMI -- oracle bits either way, graph-replayed greedy ids included"""
-    cfg = synth.make_config("7B", ff.QT_INT8); cfg.n_layers = 2
+# every launch structure of the sharded token, as bench.py's TP_STRUCTURES / host/engine.cpp's candidates name them: (tp_trust_fused, tp_fuse_ffn, tp_fuse_layers, tp_fence, gr_edges)
+_TWO_GPU_STRUCTURES = [("xchg-launches", 0, 0, 0, -1, 0), ("folded", 1, 0, 0, -1, 0), ("rank-spanning launch, fenced flags", 1, 0, 1, 3, 0), ("rank-spanning launch, flags", 1, 0, 1, 0, 0),
+                       ("rank-spanning launch, granules", 1, 0, 1, -1, 1), ("folded + FFN pair across ranks", 1, 1, 0, -1, 0)]
+
+
+@pytest.mark.parametrize("qt,rehearsal", [(ff.QT_INT8, False), (ff.QT_INT16, False), (ff.QT_INT8, True)])
+def test_two_gpus_p2p_and_trusted_fused_launches(gpu, qt, rehearsal):
+    """two ranks on two GPUs (lights up on the first multi-GPU box): by default the group takes the k_xchg launches (a flag round behind a kernel boundary); with "tp_trust_fused" on
+    every rank the folded exchanges and the rank-spanning launches over xGMI -- fenced flags, bare flags, and the data-tagged granules that need neither (round 6) --: every
+    structure in one run, oracle bits each time (logits of a prompt + two single tokens, graph-replayed greedy ids), short prompts and one long enough for split heads.
+    rehearsal: the same test body with both ranks on ONE GPU under CU masks (what a 1-GPU box can run of it: there the group folds without being asked to trust anything)."""
+    if not rehearsal and _n_devices() < 2:
+        pytest.skip("needs two GPUs")
+    cfg = synth.make_config("7B", qt); cfg.n_layers = 2
     tensors = synth.make_tensors(cfg, seed=61)
     om = O.OracleModel(cfg, tensors)
-    prompt = _prompt(cfg.vocab_size, 6)
-    want = [om.forward(prompt, 0)]
-    cur, pos = int(np.argmax(want[0])), len(prompt)
-    for _ in range(4):
-        want.append(om.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(want[-1])); pos += 1
-    ids_want = [int(np.argmax(w)) for w in want]
     world = 2
-    ctxs = [gpu.Ctx(gpu.desc_from_config(cfg), device=r, rank=r, world=world, comm_id=None) for r in range(world)]
+    ctxs = [gpu.Ctx(gpu.desc_from_config(cfg), device=(0 if rehearsal else r), rank=r, world=world, comm_id=None) for r in range(world)]
     for c in ctxs:
-        c.upload_all(tensors); c.set_option("tp_trust_fused", trust)
-    gpu.Ctx.regroup(ctxs)
-    for c in ctxs:
-        assert c.query("fold_active") == trust and c.query("span_active") == trust
+        c.upload_all(tensors)
+        if rehearsal: c.set_option("cu_parts", world)
+    for nprompt in (6, 140):
+        prompt = _prompt(cfg.vocab_size, nprompt)
+        want = [om.forward(prompt, 0)]
+        cur, pos = int(np.argmax(want[0])), len(prompt)
+        for _ in range(6):
+            want.append(om.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(want[-1])); pos += 1
+        ids_want = [int(np.argmax(w)) for w in want]
 
-    def rank_main(c):
-        lg = c.forward(prompt, 0)
-        return lg, [int(x) for x in c.decode_greedy(int(np.argmax(lg)), len(prompt), 4)]
+        def rank_main(c):
+            lg = [c.forward(prompt, 0)]
+            cur, pos = int(np.argmax(lg[0])), len(prompt)
+            for _ in range(2):
+                lg.append(c.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(lg[-1])); pos += 1
+            return lg, [int(x) for x in c.decode_greedy(cur, pos, 4)]
 
-    for r, (lg, ids) in enumerate(_run_ranks(ctxs, rank_main)):
-        assert bits_equal(lg, want[0]), f"rank {r}"
-        assert ids == ids_want[1:5], f"rank {r}"
+        for name, trust, ffn, layers, fence, gr in _TWO_GPU_STRUCTURES:
+            for c in ctxs:
+                c.set_option("tp_trust_fused", trust); c.set_option("tp_fuse_ffn", ffn); c.set_option("tp_fuse_layers", layers); c.set_option("tp_fence", fence); c.set_option("gr_edges", gr)
+                c.reset_kv()
+            gpu.Ctx.regroup(ctxs)
+            for c in ctxs:
+                if not rehearsal:
+                    assert c.query("fold_active") == trust and c.query("span_active") == trust, name
+                assert c.query("grp_tp_fuse_layers") == (1 if (trust or rehearsal) and layers else 0) and c.query("grp_gr") == gr, name
+            for r, (lg, ids) in enumerate(_run_ranks(ctxs, rank_main)):
+                for i, l in enumerate(lg):
+                    assert bits_equal(l, want[i]), f"{name}, prompt of {nprompt}, rank {r}: logits of step {i}"
+                assert ids == ids_want[3:7], f"{name}, prompt of {nprompt}, rank {r}: greedy ids"
+            for c in ctxs:
+                if layers and (trust or rehearsal):
+                    assert c.query("tp_layers_active") >= 1 and bool(c.query("gr_active")) == bool(gr), name
     for c in ctxs:
         c.close()
 

@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pmc; mkdir -p gpurun_out/pmc
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/pmc/$ctr -o run -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-config5 > gpurun_out/pmc/$ctr.log 2>&1
+  timeout 900 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/pmc/$ctr -o run -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-config5 --no-decode128 > gpurun_out/pmc/$ctr.log 2>&1
 done
 python3 tools/pmc_agg.py gpurun_out/pmc/FETCH_SIZE gpurun_out/pmc/WRITE_SIZE > gpurun_out/pmc/pmc_fetch_write_raw.json
 rm -rf gpurun_out/pmc/FETCH_SIZE gpurun_out/pmc/WRITE_SIZE

@@ -11,7 +11,7 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 cfg = synth.make_config("7B", ff.QT_INT8)
 prompt = np.array([1] + [int(x) for x in (np.arange(1, 9) * 7919) % cfg.vocab_size], dtype=np.int32)
 ref = None
-for opts in ({"fuse_attn_o": 0, "fuse_ffn": 0, "attn_split": 0, "fuse_back": 0}, {}, {"fuse_tail": 0}, {"graph_chunks": 0}, {"back_ao": 0}):
+for opts in ({"fuse_attn_o": 0, "fuse_ffn": 0, "attn_split": 0, "fuse_back": 0}, {}, {"gr_edges": 0}, {"fuse_tail": 0}, {"graph_chunks": 0}, {"back_ao": 0}):     # ({}: the default -- the one-launch token on granules, round 6)
     ctx = capi.Ctx(capi.desc_from_config(cfg)); bench.upload_synthetic(ctx, cfg)
     for k, v in opts.items(): ctx.set_option(k, v)
     for r in range(reps if opts else 1):
