@@ -168,8 +168,14 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
 #pragma unroll
         for (int i = 0; i < NF * 64 / kAttnBlock + 1; ++i) { const int d = tid + i * kAttnBlock; qv[i] = d < hs ? (COH ? ld_agent(qrow + (size_t)h * hs + d) : qrow[(size_t)h * hs + d]) : 0.f; }
     }
+    // (SPLIT + PRE: only the first FLM_SPLIT_K_EARLY tiles of the part in front of the q flag round -- the round's looks return behind whatever the wave requested before them, and
+    //  the later tiles are not needed before the first step's scores are done: they are requested behind the round, with this token's row in them)
+#ifndef FLM_SPLIT_K_EARLY
+#define FLM_SPLIT_K_EARLY 2
+#endif
+    constexpr int KE = (SPLIT && PRE) ? (FLM_SPLIT_K_EARLY < D ? FLM_SPLIT_K_EARLY : D) : D;
 #pragma unroll
-    for (int u = 0; u < D; ++u) request(rK, sb + u, se, prow, goff, ringK[u], Told);
+    for (int u = 0; u < KE; ++u) request(rK, sb + u, se, prow, goff, ringK[u], Told);
     if constexpr (SPLIT) {
         // a thread's pieces: the 16-byte column tid % 8 of the rows 4 (tid / 8) + (j % 4) + 512 (j / 4) -- four CONSECUTIVE rows per half, so
         // that the transposed parking below writes four positions of a dimension with one 16-byte store.  The first half of the slice
@@ -251,7 +257,9 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
 #pragma unroll
         for (int i = 0; i < NF * 64 / kAttnBlock + 1; ++i) { const int d = tid + i * kAttnBlock; qv[i] = d < hs ? ld_agent(qrow + (size_t)h * hs + d) : 0.f; }
 #pragma unroll
-        for (int u = 0; u < D; ++u) patch(rK, sb + u, se, prow, goff, ringK[u]);
+        for (int u = 0; u < KE; ++u) patch(rK, sb + u, se, prow, goff, ringK[u]);
+#pragma unroll
+        for (int u = KE; u < D; ++u) request(rK, sb + u, se, prow, goff, ringK[u], T);
         if constexpr (SPLIT) {
 #pragma unroll
             for (int j = 0; j < kSplitVRegs / 2; ++j) {

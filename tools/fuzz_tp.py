@@ -15,8 +15,9 @@ def run(ctxs, fn):
         try: out[r] = fn(ctxs[r])
         except Exception as e: err[r] = e          # noqa: BLE001
     th = [threading.Thread(target=work, args=(r,)) for r in range(len(ctxs))]
-    [t.start() for t in th]; [t.join(300) for t in th]
-    assert not any(t.is_alive() for t in th), "a rank hung"
+    [t.start() for t in th]; [t.join(90) for t in th]
+    if any(t.is_alive() for t in th):          # (a hung rank's thread never returns: say which shape and leave hard, or the interpreter waits for it for ever)
+        print("A RANK HUNG:", current, flush=True); os._exit(3)
     for e in err:
         if e is not None: raise e
     return out
@@ -40,14 +41,18 @@ while done < n:
     for _ in range(4):
         want.append(om.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(want[-1])); pos += 1
     ids_want = [int(np.argmax(w)) for w in want]
+    current = f"world {world} dim {dim} hidden {hidden} heads {heads} hs {hs} vocab {vocab} {'int8' if qt == ff.QT_INT8 else 'int16'} prompt {npr}"
+    print("...", current, flush=True)
     try:
         ctxs = [capi.Ctx(capi.desc_from_config(cfg), device=0, rank=r, world=world, comm_id=None) for r in range(world)]
     except capi.FlmError as e:
         skipped += 1; continue
     for c in ctxs: c.upload_all(tensors)
     fa, fn_ = int(rng.choice([0, 1, 2])), int(rng.choice([0, 1]))
+    tpl, gr = int(rng.choice([0, 1, 1])), int(rng.choice([0, 1, 1]))          # (round 6: the rank-spanning launch, on granules or on flag rounds)
+    current += f" tp_fuse_attn {fa} tp_fuse_ffn {fn_} tp_fuse_layers {tpl} gr_edges {gr}"; print("   ", current, flush=True)
     for c in ctxs:
-        c.set_option("cu_parts", world); c.set_option("tp_fuse_attn", fa); c.set_option("tp_fuse_ffn", fn_)
+        c.set_option("cu_parts", world); c.set_option("tp_fuse_attn", fa); c.set_option("tp_fuse_ffn", fn_); c.set_option("tp_fuse_layers", tpl); c.set_option("gr_edges", gr)
     capi.Ctx.regroup(ctxs)
     def rank_main(c):
         lg = [c.forward(prompt, 0)]
@@ -55,10 +60,12 @@ while done < n:
         lg.append(c.forward(np.array([cur], np.int32), pos)); cur = int(np.argmax(lg[-1])); pos += 1
         return lg, [int(x) for x in c.decode_greedy(cur, pos, 3)]
     ok = True
-    for r, (lg, ids) in enumerate(run(ctxs, rank_main)):
+    res = run(ctxs, rank_main)
+    act, gra = ctxs[0].query("tp_layers_active"), ctxs[0].query("gr_active")
+    for r, (lg, ids) in enumerate(res):
         ok &= np.array_equal(lg[0].view(np.uint32), want[0].view(np.uint32)) and np.array_equal(lg[1].view(np.uint32), want[1].view(np.uint32)) and ids == ids_want[2:5]
     for c in ctxs: c.close()
-    print(f"world {world} dim {dim} hidden {hidden} heads {heads} hs {hs} vocab {vocab} {'int8' if qt == ff.QT_INT8 else 'int16'} prompt {npr} tp_fuse_attn {fa} tp_fuse_ffn {fn_}: {'ok' if ok else 'MISMATCH'}")
+    print(f"world {world} dim {dim} hidden {hidden} heads {heads} hs {hs} vocab {vocab} {'int8' if qt == ff.QT_INT8 else 'int16'} prompt {npr} tp_fuse_attn {fa} tp_fuse_ffn {fn_} tp_fuse_layers {tpl} gr_edges {gr} (rank-spanning launch ran: {act}, on granules: {gra}): {'ok' if ok else 'MISMATCH'}", flush=True)
     bad += 0 if ok else 1; done += 1
 print(f"fuzz_tp: {'ok' if bad == 0 else f'{bad} MISMATCHES'} ({done} shapes, {skipped} skipped)")
 sys.exit(1 if bad else 0)
