@@ -87,7 +87,7 @@ constexpr int kSplitDims = 32, kSplitMaxSeq = 1024, kSplitVRegs = kSplitMaxSeq *
 // thread whose piece it is.  The arithmetic is untouched.
 struct AttnNoMid { __device__ __forceinline__ void operator()() const {} };
 template <int NF, bool COH, bool SPLIT = false, bool PRE = false, class Mid = AttnNoMid, bool GRIN = false>
-__device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow, const int g = 0, const int G = 1, Mid&& mid = Mid(), const unsigned epoch_arg = 0u, const bool gr_out = false) {
+__device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow, const int g = 0, const int G = 1, Mid&& mid = Mid(), const unsigned epoch_arg = 0u, const bool gr_out = false, const bool gr_sc = false) {
     const unsigned xepoch = epoch_arg ? epoch_arg : a.epoch;      // what the parts of a split head raise / wait for in their score exchange
     typedef float v4f __attribute__((ext_vector_type(4)));
     constexpr int D = SPLIT ? 4 : kAttnDepth;         // K ring depth
@@ -306,7 +306,10 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
             const float sv = __fmul_rn(tot, scale);         // att.multiply(attn_scale) :443
             sc[t] = sv;
             lmax = fmaxf(lmax, sv);
-            if (G > 1) st_agent(a.sc_global + (size_t)h * a.max_seq + t, sv);
+            if (G > 1) {
+                if (gr_sc) __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.sc_global) + (size_t)h * a.max_seq + t, ((unsigned long long)xepoch << 32) | (unsigned long long)__float_as_uint(sv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else st_agent(a.sc_global + (size_t)h * a.max_seq + t, sv);
+            }
         }
     };
     if constexpr (SPLIT) {
@@ -345,6 +348,31 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
         }
     }
     stamp(1);
+    if (G > 1 && gr_sc) {
+        // exchange on granules (k_layers' granule hand-offs; sc_global holds 8 bytes per score): the parts' scores are {score, tag = this layer's flag value} stores, every thread
+        // re-reads the other parts' scores it needs until their tags match -- no drained stores, no line per part, no second round trip
+        __syncthreads();                                            // (this part's own scores are in sc[])
+        lmax = -INFINITY;
+        const unsigned long long* sg = reinterpret_cast<const unsigned long long*>(a.sc_global) + (size_t)h * a.max_seq;
+        const int gave_up = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int t0 = 0; t0 < T; t0 += kAttnBlock) {                // (T <= kSplitMaxSeq = one round; wave-uniform trip count)
+            const int t = t0 + tid, tl = t / kAttnTile;
+            const bool mine = t >= T || (tl >= sb && tl < se);
+            bool ok = mine; unsigned bits = 0;
+            const unsigned long long ts = __builtin_amdgcn_s_memrealtime();
+            while (true) {
+                asm volatile("" ::: "memory");
+                if (!ok) { const unsigned long long gv = __hip_atomic_load(sg + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = (unsigned)(gv >> 32) == xepoch; bits = (unsigned)gv; }
+                if (__all(ok) || gave_up) break;
+                if (__builtin_amdgcn_s_memrealtime() - ts > 2000000ull) { __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+            if (t < T) {
+                const float sv = mine ? sc[t] : __uint_as_float(bits);
+                sc[t] = sv;
+                lmax = fmaxf(lmax, sv);
+            }
+        }
+    } else
     if (G > 1) {
         // exchange: my scores are in memory -> raise my line; wait for the other parts' lines; fetch their scores
         wait_stores_done();
@@ -634,9 +662,9 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
 // registers, and compiled into one function they spilled a 16-byte register -- behind an s_waitcnt vmcnt(0) on the whole prefetch
 template <bool COH, bool SPLIT, bool PRE = false, bool GRIN = false, class Mid = AttnNoMid>
 // epoch: the value the parts of a split head raise / wait for in their score exchange (0: a.epoch; k_layers passes the layer's flag target, which counts from the token's epoch base)
-__device__ __forceinline__ void attn_head_any(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow, const int g = 0, const int G = 1, Mid&& mid = Mid(), const unsigned epoch = 0u, const bool gr_out = false) {
+__device__ __forceinline__ void attn_head_any(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow, const int g = 0, const int G = 1, Mid&& mid = Mid(), const unsigned epoch = 0u, const bool gr_out = false, const bool gr_sc = false) {
     if constexpr (SPLIT) {      // the host picks G = hs / kSplitDims (attn_parts): every part owns 32 output dimensions; hs <= 128
-        if (a.hs <= 64) attn_head<1, COH, true, PRE, Mid>(a, h, lds, T, qrow, orow, g, G, static_cast<Mid&&>(mid), epoch, gr_out); else attn_head<2, COH, true, PRE, Mid>(a, h, lds, T, qrow, orow, g, G, static_cast<Mid&&>(mid), epoch, gr_out);
+        if (a.hs <= 64) attn_head<1, COH, true, PRE, Mid>(a, h, lds, T, qrow, orow, g, G, static_cast<Mid&&>(mid), epoch, gr_out, gr_sc); else attn_head<2, COH, true, PRE, Mid>(a, h, lds, T, qrow, orow, g, G, static_cast<Mid&&>(mid), epoch, gr_out, gr_sc);
     } else {
         if (a.hs <= 64) attn_head<1, COH, false, PRE, Mid, GRIN>(a, h, lds, T, qrow, orow, 0, 1, static_cast<Mid&&>(mid), epoch, gr_out); else if (a.hs <= 128) attn_head<2, COH, false, PRE, Mid, GRIN>(a, h, lds, T, qrow, orow, 0, 1, static_cast<Mid&&>(mid), epoch, gr_out); else attn_head<4, COH, false, PRE, Mid, GRIN>(a, h, lds, T, qrow, orow, 0, 1, static_cast<Mid&&>(mid), epoch, gr_out);
     }

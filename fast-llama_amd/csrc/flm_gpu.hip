@@ -532,7 +532,7 @@ int flm_ctx_create(const flm_model_desc* desc, int device_id, int rank, int worl
         HIPB(hipMalloc((void**)&c->la_dev[k], sizeof(LayerArgs) * (size_t)d.n_layers)); HIPB(hipMalloc((void**)&c->tail_dev[k], sizeof(TailArgs)));
     }
     HIPB(hipMalloc(&c->att_q, (size_t)d.dim * c->esz)); HIPB(hipMalloc((void**)&c->att_qs, (size_t)(d.dim / kGroup) * 4));
-    HIPB(hipMalloc((void**)&c->att_sc, (size_t)c->heads_local * d.max_seq_len * 4));
+    HIPB(hipMalloc((void**)&c->att_sc, (size_t)c->heads_local * d.max_seq_len * 8)); HIPB(hipMemsetAsync(c->att_sc, 0, (size_t)c->heads_local * d.max_seq_len * 8, c->stream));   // (8 bytes per score: the parts of a split head exchange them as {score, tag} granules inside k_layers' granule launches, as floats elsewhere)
     HIPB(hipMalloc((void**)&c->state, sizeof(DecodeState)));
     HIPB(hipMemsetAsync(c->state, 0, sizeof(DecodeState), c->stream));
     std::vector<float> cs, sn; build_rope_table(hs, d.max_seq_len, cs, sn);

@@ -299,7 +299,7 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
             }
             __syncthreads();
         };
-        if constexpr (QKV) attn_head_any<true, SPLIT, true, gr_q>(aa, hh, lds, *aa.pos_ptr + 1, aa.q, aa.out, blockIdx.x % G, G, qwait, target, gr_att);
+        if constexpr (QKV) attn_head_any<true, SPLIT, true, gr_q>(aa, hh, lds, *aa.pos_ptr + 1, aa.q, aa.out, blockIdx.x % G, G, qwait, target, gr_att, gr);
         else attn_head_any<false, SPLIT>(aa, hh, lds, *aa.pos_ptr + 1, aa.q, aa.out, blockIdx.x % G, G);
         stamp(1);
         if (gr_att) __syncthreads();                                            // (the LDS is free; the output's granules are their own flags)

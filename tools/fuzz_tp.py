@@ -1,6 +1,6 @@
 """random small model shapes as tensor-parallel ranks (threads, CU masks) on one GPU against the CPU oracle, logits and greedy ids bit for bit:
 python tools/fuzz_tp.py [n] [seed]      (shapes a rank split cannot take -- rows not 64-aligned per rank, heads not divisible -- are skipped)"""
-import sys, os, threading
+import sys, os, threading, faulthandler
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np
 import __graft_entry__ as g; g.load_package()
@@ -43,6 +43,7 @@ while done < n:
     ids_want = [int(np.argmax(w)) for w in want]
     current = f"world {world} dim {dim} hidden {hidden} heads {heads} hs {hs} vocab {vocab} {'int8' if qt == ff.QT_INT8 else 'int16'} prompt {npr}"
     print("...", current, flush=True)
+    faulthandler.dump_traceback_later(150, exit=True)          # (a shape takes seconds: a hang anywhere -- create, upload, regroup, a rank -- leaves every thread's Python stack on stderr)
     try:
         ctxs = [capi.Ctx(capi.desc_from_config(cfg), device=0, rank=r, world=world, comm_id=None) for r in range(world)]
     except capi.FlmError as e:
