@@ -274,7 +274,7 @@ int enqueue_token(flm_ctx* c, hipStream_t st, bool with_cls, int advance, int G)
     const auto& d = c->d;
     const int qt = d.quant_type, hs = c->hs, L = d.n_layers;
     const bool tp = c->world > 1 || (c->comm != nullptr && c->force_tp), coh = tp && c->p2p;   // (a 1-rank communicator takes the sharded path only on request: "force_tp")
-    if (!tp && with_cls && advance == 1 && c->fuse_tail && c->fuse_token && c->fuse_layer && c->fuse_back && c->fuse_attn_o && c->fuse_ffn && !c->timing && c->trace_class < 0) {
+    if (!tp && with_cls && advance == 1 && c->fuse_tail && c->fuse_token && c->fuse_layer && c->fuse_back && c->fuse_attn_o && c->fuse_ffn && !c->timing && (c->trace_class < 0 || c->trace_class == 103)) {   // (trace builds, class 103: the stamps of the one-launch token's second layer)
         // a greedy decode token as ONE launch: embedding row, all layers, classifier, argmax + state advance (k_layers<.., TAIL>)
         const int r = launch_layers(c, st, 0, L, G, true);
         if (r != FLM_ERR_UNSUPPORTED) return r;

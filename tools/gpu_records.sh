@@ -12,7 +12,7 @@ for w in 2 4 8; do GPU_MAX_HW_QUEUES=16 timeout 400 python tools/tp_onegpu.py $w
 python bench.py --steps 20 --warmup 5 --quant int16 --no-cpu-baseline > $O/r06_bench_int16.json 2>/dev/null; cut -c1-120 $O/r06_bench_int16.json
 python bench.py --steps 20 --warmup 5 --shape 1.3B --no-cpu-baseline > $O/r06_bench_1p3B.json 2>/dev/null; cut -c1-120 $O/r06_bench_1p3B.json
 python bench.py --steps 20 --warmup 5 --pos 512 --no-cpu-baseline > $O/r06_bench_pos512.json 2>/dev/null; cut -c1-120 $O/r06_bench_pos512.json
-(python tools/soak32.py 1000 2; python tools/stress2.py 200; python tools/fuzz_shapes.py 30 7 0; python tools/fuzz_shapes.py 12 9 1) > $O/r06_fuzz_stress.txt 2>&1; tail -12 $O/r06_fuzz_stress.txt
+(timeout 900 python tools/soak32.py 1000 2; timeout 600 python tools/stress2.py 200; timeout 600 python tools/fuzz_shapes.py 30 7 0; timeout 600 python tools/fuzz_shapes.py 12 9 1) > $O/r06_fuzz_stress.txt 2>&1; tail -12 $O/r06_fuzz_stress.txt
 bash tools/pmc_prefill.sh > $O/pmc_prefill.txt 2>&1; tail -4 $O/pmc_prefill.txt
 python3 tools/pmc_agg.py gpurun_out/pmc/p1 gpurun_out/pmc/p2 gpurun_out/pmc/p3 > gpurun_out/pmc/prefill_counters.json 2>/dev/null
 python3 - > $O/r06_prefill_gemm_pmc.txt <<'PY'
