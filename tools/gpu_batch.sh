@@ -1,3 +1,2 @@
-mkdir -p gpurun_out/s16
-for lib in fast-llama_amd/lib/var/libflm_prev.so fast-llama_amd/lib/libflm_gpu.so; do echo "== $lib"; for pos in 300 516 900; do FLM_GPU_LIB=$lib python tools/back_bench.py 32 $pos int8 "tuning=1"; done; done > gpurun_out/s16/scx.txt 2>&1; cat gpurun_out/s16/scx.txt
-(timeout 900 python -m pytest tests -m gpu -q -x -k "long_context or split or config3 or rank_spanning or fuzz or one_launch" > gpurun_out/s16/sel.log 2>&1; echo rc=$? >> gpurun_out/s16/sel.log); tail -3 gpurun_out/s16/sel.log
+mkdir -p gpurun_out/s17
+python tools/back_bench.py 32 14 int8 "tuning=1;back_nst13=20;back_nst13=16;back_nst13=12;back_nst13=8;back_nst13=-1,back_nst13_head=16;back_nst13_head=8;back_nst13_head=-1,back_pre13=12;back_pre13=16;back_pre13=8" > gpurun_out/s17/nst.txt 2>&1; cat gpurun_out/s17/nst.txt
