@@ -600,6 +600,10 @@ struct GemvCtx {
     // k_layers' granule hand-offs (granule_t above): gron = this GEMV's results leave as granules (GemvArgs::gout / gout_peer) with tag gtag instead of plain stores;
     // EPI_RESIDUAL: the old value comes from gsrc[row] (null: resid_src / out)
     const granule_t* gsrc; bool gron; unsigned gtag;
+    // run_ao (Wo inside the whole-layer launches, round 6): only the waves [0, nw) hold steps (wave, wave + nw) and look for their producers; the waves [nw, 16) issue the workgroup's
+    // LDS-DMA for the NEXT phase instead (stash_issue's w0) -- a wave's loads return in order, so a look returns behind whatever the SAME wave requested before it, and with every wave
+    // carrying its share of the 106 KiB [W1; W3] stash the Wo workgroups saw the heads' lines ~4 us after they went up.  16: every wave holds steps (FFN2, every other user).
+    u32 nw;
 
     static __device__ __forceinline__ u32 inv_of(u32 d) { return d > 1 ? 0xFFFFFFFFu / d + 1u : 0u; }
     static __device__ __forceinline__ u32 udiv(u32 x, u32 d, u32 inv) { return d > 1 ? __umulhi(x, inv) : x; }
@@ -650,7 +654,7 @@ struct GemvCtx {
         const u32 NM = TWO ? 2u : 1u;
         rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, (int)(NM * TRm * rowbytes), kRsrcFlags);
         rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.sW), 0, (int)(NM * TRm * sn * 4), kRsrcFlags);
-        stored = false; primedA = primedB = false; resid_src = nullptr; gsrc = nullptr; gron = false; gtag = 0;
+        stored = false; primedA = primedB = false; resid_src = nullptr; gsrc = nullptr; gron = false; gtag = 0; nw = kWavesPerBlock;
         // the first two steps of every wave are fixed (wave, wave + 16): they are requested before any barrier (the stash's steps are the next numbers)
         if (write_ctr && threadIdx.x == 0) *reinterpret_cast<u32*>(lds + ctr_off) = 2 * kWavesPerBlock;
     }
@@ -698,15 +702,17 @@ struct GemvCtx {
     // (part 1 / 2: only the first / second set; a set that was never requested is drawn at the start of run())
     bool primedA, primedB;
     __device__ __forceinline__ void issue(int ablate, int part = 0) {
-        if (part != 2) { load_step(setA, wave, ablate); primedA = true; }
-        if (part != 1) { load_step(setB, wave + kWavesPerBlock, ablate); primedB = true; }
+        if (part != 2) { load_step(setA, wave < nw ? wave : NS, ablate); primedA = true; }               // (a wave without steps: past the end, no memory access)
+        if (part != 1) { load_step(setB, wave < nw ? wave + nw : NS, ablate); primedB = true; }
     }
 
     // this wave's stash slots: the step's H weight blocks and its scale dwords go straight to LDS, lane for lane what load_step puts into registers
     // (LDS address = M0 + 16 (4) x lane; blocks past the step's live ones / steps past the end get the out-of-range offset: no memory access)
-    __device__ __forceinline__ void stash_issue(const char* lds) const {
+    // w0: only the waves [w0, 16) issue (the workgroup's slots dealt among them); 0: every wave
+    __device__ __forceinline__ void stash_issue(const char* lds, const u32 w0 = 0) const {
         const u32 lds0 = (u32)(uintptr_t)(__attribute__((address_space(3))) const char*)lds;
-        for (u32 i = wave; i < st_n; i += kWavesPerBlock) {
+        if (wave < w0) return;
+        for (u32 i = wave - w0; i < st_n; i += kWavesPerBlock - w0) {
             Set S; u32 wo, so;
             decode(2 * kWavesPerBlock + i, S, wo, so);
             const u32 dst = __builtin_amdgcn_readfirstlane(lds0 + st_base + i * kSlotBytes);
@@ -721,8 +727,8 @@ struct GemvCtx {
     }
     // whichever of the two fixed sets this wave has not requested yet
     __device__ __forceinline__ void issue_missing(int ablate) {
-        if (!primedA) { load_step(setA, wave, ablate); primedA = true; }
-        if (!primedB) { load_step(setB, wave + kWavesPerBlock, ablate); primedB = true; }
+        if (!primedA) { load_step(setA, wave < nw ? wave : NS, ablate); primedA = true; }
+        if (!primedB) { load_step(setB, wave < nw ? wave + nw : NS, ablate); primedB = true; }
     }
 
     // reduce one step: the group dots of its H blocks (registers), then the leaders park them; the scale-role lanes park s = sW * sX
@@ -970,7 +976,7 @@ struct GemvCtx {
         char* strips = lds + off_scr;
         // lane (k, j) = (lane >> 4, lane & 15): producer j of the column block of step wave + 16 k
         const u32 EPB = (16u << cbs) / T::kEsz, inv_rows = inv_of(src.rows);
-        const u32 ks = wave + ((lane >> 4) << 4);                                // (one pass per workgroup: a step number is the remainder inside the pass)
+        const u32 ks = wave < nw ? wave + nw * (lane >> 4) : NS;                 // (one pass per workgroup: a step number is the remainder inside the pass)
         const u32 kq = udiv(ks, NBCV, inv_NBCV), kc = ks - kq * NBCV;            // its row chunk, its column block
         const u32 e0 = kc * EPB, e1 = e0 + EPB < n ? e0 + EPB : n;
         const u32 p0 = udiv(e0, src.rows, inv_rows), p1 = udiv(e1 - 1, src.rows, inv_rows), pj = p0 + (lane & 15);
@@ -978,7 +984,7 @@ struct GemvCtx {
         const unsigned* line = src.flags + (pj % src.grid) * 16 /* kFlagStride */;
         u32 pending = 0;
 #pragma unroll
-        for (u32 k = 0; k < 4; ++k) if (wave + 16 * k < NS) pending |= 1u << k;
+        for (u32 k = 0; k < 4; ++k) if (wave < nw && wave + nw * k < NS) pending |= 1u << k;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         bool first = true;
         u32 spins = 0;
@@ -1011,7 +1017,7 @@ struct GemvCtx {
                     else {
                         wait_stores_done();                                        // this wave's own LDS-DMA into its stash slots
                         Set S;
-                        load_step(S, wave + 16 * k, a.ablate, lds);
+                        load_step(S, wave + nw * k, a.ablate, lds);
                         reduce_step(S, lds, strips, a.ablate);
                     }
                 }

@@ -46,6 +46,7 @@ struct BackArgs {
     int ao_2;                   // FFN2: a wave quantizes a column block of hd when the block's FFN13 workgroups have raised theirs; 1: W2 whole (both sets + stash) in front of the first look,
                                 // 2: the first register sets in front, the rest behind the first look, 3: first sets + stash in front, the second sets behind
     int r5;                     // the round-5 forms the launch's instantiation carries (layer_body's R5): 3 or 0
+    int nw_o;                   // arrival-order Wo: the waves [0, nw_o) hold Wo's steps and look for their heads, the waves [nw_o, 16) issue the workgroup's [W1; W3] stash (GemvCtx::nw); 16: every wave does both
     int nst2_ao;                // ... its stash slots: the steps beyond the two register sets (all of W2's share is resident)
     unsigned long long* trace;  // FLM_ABLATE builds: [grid][16] s_memrealtime stamps (100 MHz, one clock for all XCDs; tools/trace_back.py)
     // round 6: the residual stream as data-tagged granules inside the one-launch token (flm_gemv.h: granule_t): xg_a = x behind FFN2 (the next layer's / the classifier's input),
@@ -325,6 +326,8 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
     } else {
         GemvCtx<QT, EPI_RESIDUAL> g;
         g.init(ao, blockIdx.x - p.n_heads, p.grido, lds);
+        const unsigned nwo = (!SPLIT && (R5 & 1) != 0 && p.nw_o > 0 && p.nw_o < kWavesPerBlock) ? (unsigned)p.nw_o : (unsigned)kWavesPerBlock;
+        g.nw = nwo;
         g.resid_src = x0;
         if (gr) { g.gsrc = xpoll ? p.xg_a + p.gres_off : nullptr; g.gron = true; g.gtag = target; }   // (the launch's first layer: the old value is the embedding row's / the plain vector's)
         g.issue(kAblate ? ao.ablate : 0);
@@ -332,7 +335,7 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
             nst13 = (unsigned)p.nst13;
             GemvCtx<QT, EPI_SWIGLU, true> t;
             t.init(a13, blockIdx.x, p.grid13, lds, 0, p.st_base, nst13, false);
-            t.stash_issue(lds);
+            t.stash_issue(lds, nwo < (unsigned)kWavesPerBlock ? nwo : 0u);     // (the waves that hold no Wo step: their DMA is in front of nobody's look)
         }
         stamp(1);
 #ifdef FLM_TRACE_PRO_RT

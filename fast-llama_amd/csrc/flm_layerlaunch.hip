@@ -74,6 +74,9 @@ int plan_layer(flm_ctx* c, int l, bool with_qkv, int G, LayerArgs& A, BackArgs& 
         // one instantiation carries both arrival-order forms (k_layers<.., R5 = 3>) or none: Wo where a head is one workgroup (with split heads Wo stays as it was), FFN2
         p.r5 = ((G > 1 || p.ao_o) && p.ao_2 && with_qkv && !tpl) ? 3 : 0;
         if (!p.r5) { p.ao_o = 0; p.ao_2 = 0; p.nst2_ao = 0; }
+        // arrival-order Wo: its ns_o steps on the first ceil(ns_o / 2) waves (two register sets each), the [W1; W3] stash issued by the others (flm_layer.h BackArgs::nw_o); "back_nwo" 16: as before
+        p.nw_o = kWavesPerBlock;
+        if (p.ao_o && G == 1) { const int need = (ns_o + 1) / 2, want = c->back_nwo > 0 ? c->back_nwo : (need < 4 ? 4 : need); p.nw_o = (want >= need && want <= kWavesPerBlock - 2) ? want : kWavesPerBlock; }
     }
     if (kAblate && c->trace_class == 102 && l == 0) { p.trace = c->trace; a13.trace = c->trace + 256 * 16; a2.trace = c->trace + 2 * 256 * 16; }   // tools/trace_back.py
     if (kAblate && c->trace_class == 103) { p.trace = c->trace; if (l == (c->d.n_layers > 1 ? 1 : 0)) { a13.trace = c->trace + 256 * 16; a2.trace = c->trace + 2 * 256 * 16; aa.trace = c->trace + 5 * 4096; } }   // (k_layers: its second layer)

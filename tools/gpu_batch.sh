@@ -1,2 +1,4 @@
-mkdir -p gpurun_out/s17
-python tools/back_bench.py 32 14 int8 "tuning=1;back_nst13=20;back_nst13=16;back_nst13=12;back_nst13=8;back_nst13=-1,back_nst13_head=16;back_nst13_head=8;back_nst13_head=-1,back_pre13=12;back_pre13=16;back_pre13=8" > gpurun_out/s17/nst.txt 2>&1; cat gpurun_out/s17/nst.txt
+mkdir -p gpurun_out/s18
+python tools/back_bench.py 32 14 int8 "tuning=1,back_nwo=16;back_nwo=0;back_nwo=12;back_nwo=14;back_nwo=10,back_nst13=20;back_nst13=-1,back_nwo=16;back_nwo=0" > gpurun_out/s18/nwo.txt 2>&1; cat gpurun_out/s18/nwo.txt
+python tools/back_bench.py 8 14 int16 "tuning=1,back_nwo=16;back_nwo=0" >> gpurun_out/s18/nwo.txt 2>&1; tail -2 gpurun_out/s18/nwo.txt
+(timeout 600 python -m pytest tests -m gpu -q -x -k "one_launch or config3 or fuzz or back_half or every_code_path" > gpurun_out/s18/sel.log 2>&1; echo rc=$? >> gpurun_out/s18/sel.log); tail -3 gpurun_out/s18/sel.log
