@@ -8,7 +8,7 @@ bash tools/prof_bench.sh --steps 20 --warmup 5 > $O/prof_bench.txt 2>&1; cp gpur
 bash tools/pmc_bench.sh > $O/pmc_bench.txt 2>&1; cp gpurun_out/pmc/pmc_fetch_write_raw.json $O/r06_pmc_fetch_write_raw.json; tail -6 $O/pmc_bench.txt
 for n in 2 4; do FLM_BENCH_FORCE_DEVICE=0 GPU_MAX_HW_QUEUES=16 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 2960$n bench.py --gpus $n --steps 10 --warmup 3 --no-cpu-baseline 2> $O/tp$n.err | grep '^{"metric' > $O/r06_bench_tp${n}_one_gpu.json; cut -c1-120 $O/r06_bench_tp${n}_one_gpu.json; done
 for w in 2 4 8; do GPU_MAX_HW_QUEUES=16 timeout 400 python tools/tp_onegpu.py $w 4 64 2>&1 | grep -v Warning; done > $O/r06_tp_onegpu.txt; cut -c1-170 $O/r06_tp_onegpu.txt
-(FLM_GPU_LIB=fast-llama_amd/lib/var/libflm_abl.so python tools/trace_back.py 4 14 "" 103; FLM_GPU_LIB=fast-llama_amd/lib/var/libflm_abl.so python tools/trace_back.py 4 516 "" 103) > $O/r06_layer_timelines.txt 2>&1; grep -c "" $O/r06_layer_timelines.txt
+(FLM_GPU_LIB=fast-llama_amd/lib/var/libflm_abl.so python tools/trace_back.py 4 14 "" 103; FLM_GPU_LIB=fast-llama_amd/lib/var/libflm_abl.so python tools/trace_back.py 4 14 "tuning=1,gr_edges=0" 103; FLM_GPU_LIB=fast-llama_amd/lib/var/libflm_abl.so python tools/trace_back.py 4 516 "" 103) > $O/r06_layer_timelines.txt 2>&1; grep -c "" $O/r06_layer_timelines.txt
 python bench.py --steps 20 --warmup 5 --quant int16 --no-cpu-baseline > $O/r06_bench_int16.json 2>/dev/null; cut -c1-120 $O/r06_bench_int16.json
 python bench.py --steps 20 --warmup 5 --shape 1.3B --no-cpu-baseline > $O/r06_bench_1p3B.json 2>/dev/null; cut -c1-120 $O/r06_bench_1p3B.json
 python bench.py --steps 20 --warmup 5 --pos 512 --no-cpu-baseline > $O/r06_bench_pos512.json 2>/dev/null; cut -c1-120 $O/r06_bench_pos512.json
@@ -34,3 +34,4 @@ for k, v in sorted(d.items()):
         if g("SQ_WAVE_CYCLES"): print(f"  -> of a wave's cycles: issuing {g('SQ_ACTIVE_INST_ANY') / g('SQ_WAVE_CYCLES') * 100:.0f} %, waiting on an instruction {g('SQ_WAIT_INST_ANY') / g('SQ_WAVE_CYCLES') * 100:.0f} %, waiting otherwise {g('SQ_WAIT_ANY') / g('SQ_WAVE_CYCLES') * 100:.0f} %; LDS waits {g('SQ_WAIT_INST_LDS') / g('SQ_WAVE_CYCLES') * 100:.0f} %")
 PY
 head -30 $O/r06_prefill_gemm_pmc.txt
+python __graft_entry__.py --smoke > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
