@@ -1,4 +1,4 @@
-O=gpurun_out/s19; mkdir -p $O
-(timeout 900 python tools/fuzz_shapes.py 60 21 0; timeout 900 python tools/fuzz_shapes.py 40 22 1; timeout 900 python tools/fuzz_shapes.py 40 23 1) > $O/fuzz_shapes.txt 2>&1; grep -c ": ok" $O/fuzz_shapes.txt; grep "fuzz:\|MISMATCH\|Error" $O/fuzz_shapes.txt | head
-timeout 900 python tools/stress.py 6 1000 3 > $O/stress.txt 2>&1; tail -6 $O/stress.txt | cut -c1-200
-for i in 1 2; do (timeout 900 python -m pytest tests -m gpu -q > $O/gputests_$i.log 2>&1); grep "passed\|failed" $O/gputests_$i.log | tail -1; done
+mkdir -p gpurun_out/s20
+python tools/back_bench.py 32 14 int8 "tuning=1,back_res2=0;back_res2=1;back_res2=0;back_res2=1" > gpurun_out/s20/res2.txt 2>&1; cat gpurun_out/s20/res2.txt
+python tools/back_bench.py 32 516 int8 "tuning=1,back_res2=0;back_res2=1" >> gpurun_out/s20/res2.txt 2>&1; tail -2 gpurun_out/s20/res2.txt
+(timeout 600 python -m pytest tests -m gpu -q -x -k "one_launch or config3 or fuzz or back_half or every_code_path or long_context" > gpurun_out/s20/sel.log 2>&1; echo rc=$? >> gpurun_out/s20/sel.log); tail -3 gpurun_out/s20/sel.log
