@@ -87,7 +87,7 @@ constexpr int kSplitDims = 32, kSplitMaxSeq = 1024, kSplitVRegs = kSplitMaxSeq *
 // thread whose piece it is.  The arithmetic is untouched.
 struct AttnNoMid { __device__ __forceinline__ void operator()() const {} };
 template <int NF, bool COH, bool SPLIT = false, bool PRE = false, class Mid = AttnNoMid, bool GRIN = false>
-__device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow, const int g = 0, const int G = 1, Mid&& mid = Mid(), const unsigned epoch_arg = 0u, const bool gr_out = false, const bool gr_sc = false) {
+__device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow, const int g = 0, const int G = 1, Mid&& mid = Mid(), const unsigned epoch_arg = 0u, const bool gr_out = false, const bool gr_sc = false, const float* kpre = nullptr) {
     const unsigned xepoch = epoch_arg ? epoch_arg : a.epoch;      // what the parts of a split head raise / wait for in their score exchange
     typedef float v4f __attribute__((ext_vector_type(4)));
     constexpr int D = SPLIT ? 4 : kAttnDepth;         // K ring depth
@@ -174,8 +174,12 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
 #define FLM_SPLIT_K_EARLY 2
 #endif
     constexpr int KE = (SPLIT && PRE) ? (FLM_SPLIT_K_EARLY < D ? FLM_SPLIT_K_EARLY : D) : D;
+    // kpre (SPLIT + PRE, k_layers): the part's first two K tiles were brought into LDS by LDS-DMA UNDER the layer's QKV phase (attn_kpre_issue: rows of earlier tokens depend on nothing
+    // of the layer), in the tile layout at kpre / kpre + one tile: nothing of them is requested here, the first step's scores start when q is there
+    if (!(SPLIT && PRE) || kpre == nullptr) {
 #pragma unroll
-    for (int u = 0; u < KE; ++u) request(rK, sb + u, se, prow, goff, ringK[u], Told);
+        for (int u = 0; u < KE; ++u) request(rK, sb + u, se, prow, goff, ringK[u], Told);
+    }
     if constexpr (SPLIT) {
         // a thread's pieces: the 16-byte column tid % 8 of the rows 4 (tid / 8) + (j % 4) + 512 (j / 4) -- four CONSECUTIVE rows per half, so
         // that the transposed parking below writes four positions of a dimension with one 16-byte store.  The first half of the slice
@@ -256,8 +260,20 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
         stamp(7);
 #pragma unroll
         for (int i = 0; i < NF * 64 / kAttnBlock + 1; ++i) { const int d = tid + i * kAttnBlock; qv[i] = d < hs ? ld_agent(qrow + (size_t)h * hs + d) : 0.f; }
+        if (SPLIT && kpre != nullptr) {
+            // this token's row, if it lies in one of the two pre-landed tiles: straight into its place in LDS (the first step's barrier follows)
+#pragma unroll
+            for (int u = 0; u < KE; ++u)
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    if (sb + u < se && (sb + u) * kAttnTile + prow[j] == T - 1) {
+                        const v4f t4 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rK, (int)(unsigned)((sb + u) * tile_bytes + goff[j]), 0, kAuxCoherent));
+                        *reinterpret_cast<float4*>(const_cast<float*>(kpre) + u * kAttnTile * rs + loff[j]) = make_float4(t4.x, t4.y, t4.z, t4.w);
+                    }
+        } else {
 #pragma unroll
         for (int u = 0; u < KE; ++u) patch(rK, sb + u, se, prow, goff, ringK[u]);
+        }
 #pragma unroll
         for (int u = KE; u < D; ++u) request(rK, sb + u, se, prow, goff, ringK[u], T);
         if constexpr (SPLIT) {
@@ -318,11 +334,13 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
 #pragma unroll
             for (int u = 0; u < D; u += 2) {
                 const int s = base + u;
-                park(tile0, prow, loff, ringK[u]); park(tile1, prow, loff, ringK[u + 1]);
+                const bool pre = PRE && u == 0 && base == sb && kpre != nullptr;   // (wave-uniform: the two pre-landed tiles)
+                if (!pre) { park(tile0, prow, loff, ringK[u]); park(tile1, prow, loff, ringK[u + 1]); }
                 __syncthreads();
                 request(rK, s + D, se, prow, goff, ringK[u], T); request(rK, s + D + 1, se, prow, goff, ringK[u + 1], T);
                 const int half = tid >> 9, s2 = s + half;
-                if (s2 < se) score_lane(half ? tile1 : tile0, s2, (tid >> 3) & 63, tid & 7);
+                const float* c0 = pre ? kpre : tile0; const float* c1 = pre ? kpre + kAttnTile * rs : tile1;
+                if (s2 < se) score_lane(half ? c1 : c0, s2, (tid >> 3) & 63, tid & 7);
                 __syncthreads();
             }
         }
@@ -658,13 +676,30 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
     stamp(6);
     __syncthreads();                                                // the LDS is free for whoever runs next on it
 }
+// The first two K tiles of a split head's part by LDS-DMA into the tile layout at lds + off (row stride attn_row_stride(hs) floats; one row per instruction: hs / 4 lanes x 16 bytes -- the
+// rows are padded, so a wave-wide DMA cannot span two), rows of EARLIER tokens only (t < T - 1: this token's row is patched in behind the q flag round).  Issued by every wave of the
+// part's workgroup under the layer's QKV phase (layer_body); every wave waits for its own DMA (vmcnt) at the phase's end.
+__device__ __forceinline__ void attn_kpre_issue(const AttnArgs& a, const int h, const int g, const int G, const int T, const char* lds, const unsigned off) {
+    const int hs = a.hs, rs = attn_row_stride(hs), f4r = hs >> 2, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nt = (T + kAttnTile - 1) / kAttnTile, tpp = (nt + G - 1) / G, sb = g * tpp, se = (sb + tpp < nt) ? sb + tpp : nt;
+    const float* K = a.kcache + (size_t)h * (a.kv_rows ? a.kv_rows : a.max_seq) * hs;
+    const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(K), 0, a.max_seq * hs * 4, 0x00020000);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)lds + off;
+    for (int r = wave; r < 2 * kAttnTile; r += kAttnBlock / 64) {
+        const int u = r / kAttnTile, row = r - u * kAttnTile, t = (sb + u) * kAttnTile + row;
+        if (sb + u >= se || t >= T - 1) continue;                                  // (wave-uniform)
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)((u * kAttnTile + row) * rs * 4)));
+        const unsigned src = (unsigned)(t * hs * 4 + lane * 16);
+        if (lane < f4r) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(src), "s"(rK), "s"(dst) : "memory", "m0");
+    }
+}
 // SPLIT is a template argument of the kernels (not a run-time branch inside one kernel): the two forms keep different things in
 // registers, and compiled into one function they spilled a 16-byte register -- behind an s_waitcnt vmcnt(0) on the whole prefetch
 template <bool COH, bool SPLIT, bool PRE = false, bool GRIN = false, class Mid = AttnNoMid>
 // epoch: the value the parts of a split head raise / wait for in their score exchange (0: a.epoch; k_layers passes the layer's flag target, which counts from the token's epoch base)
-__device__ __forceinline__ void attn_head_any(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow, const int g = 0, const int G = 1, Mid&& mid = Mid(), const unsigned epoch = 0u, const bool gr_out = false, const bool gr_sc = false) {
+__device__ __forceinline__ void attn_head_any(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow, const int g = 0, const int G = 1, Mid&& mid = Mid(), const unsigned epoch = 0u, const bool gr_out = false, const bool gr_sc = false, const float* kpre = nullptr) {
     if constexpr (SPLIT) {      // the host picks G = hs / kSplitDims (attn_parts): every part owns 32 output dimensions; hs <= 128
-        if (a.hs <= 64) attn_head<1, COH, true, PRE, Mid>(a, h, lds, T, qrow, orow, g, G, static_cast<Mid&&>(mid), epoch, gr_out, gr_sc); else attn_head<2, COH, true, PRE, Mid>(a, h, lds, T, qrow, orow, g, G, static_cast<Mid&&>(mid), epoch, gr_out, gr_sc);
+        if (a.hs <= 64) attn_head<1, COH, true, PRE, Mid>(a, h, lds, T, qrow, orow, g, G, static_cast<Mid&&>(mid), epoch, gr_out, gr_sc, kpre); else attn_head<2, COH, true, PRE, Mid>(a, h, lds, T, qrow, orow, g, G, static_cast<Mid&&>(mid), epoch, gr_out, gr_sc, kpre);
     } else {
         if (a.hs <= 64) attn_head<1, COH, false, PRE, Mid, GRIN>(a, h, lds, T, qrow, orow, 0, 1, static_cast<Mid&&>(mid), epoch, gr_out); else if (a.hs <= 128) attn_head<2, COH, false, PRE, Mid, GRIN>(a, h, lds, T, qrow, orow, 0, 1, static_cast<Mid&&>(mid), epoch, gr_out); else attn_head<4, COH, false, PRE, Mid, GRIN>(a, h, lds, T, qrow, orow, 0, 1, static_cast<Mid&&>(mid), epoch, gr_out);
     }

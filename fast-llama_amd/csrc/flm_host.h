@@ -104,6 +104,7 @@ struct flm_ctx {
     unsigned* tail_mem = nullptr;                      // [0] the epoch base of the one-launch token's flag values, [16 ..) one flag line per classifier workgroup, then their argmax slots
     int fuse_layer = 1;                                // option "fuse_layer": ... with the QKV GEMV in front: the whole layer in one launch
     int back_nst13 = -1, back_nst13_head = -1, back_nst2 = 0, back_pre13 = 99 /* 99: by launch (plan_layer) */, back_pre2 = 16;   // options "back_*": k_attn_ffn's stash slots (-1: as many as the LDS holds) and early register set (flm_layer.h)
+    int attn_kpre = 1;                                 // tuning dial "attn_kpre": split heads' first two K tiles by LDS-DMA under the QKV phase (BackArgs::kpre_off)
     int back_nwo = 0;                                  // tuning dial "back_nwo": waves that hold the arrival-order Wo's steps (0: ceil(steps / 2); 16: every wave, the stash issued by all)
     int gr_edges = 1;                                  // tuning dial "gr_edges" (round 6): the one-launch token's x / x1 hand-offs as data-tagged granules (flm_gemv.h: granule_t; BackArgs::gr); 0: flag rounds
     granule_t* xg = nullptr; size_t x_gran_off = 0;    // ... the granule vectors [x: dim][x1: dim][att: dim][hd: hidden] (tensor parallel: a region of the exchange buffer, at x_gran_off in every rank's)

@@ -46,6 +46,7 @@ struct BackArgs {
     int ao_2;                   // FFN2: a wave quantizes a column block of hd when the block's FFN13 workgroups have raised theirs; 1: W2 whole (both sets + stash) in front of the first look,
                                 // 2: the first register sets in front, the rest behind the first look, 3: first sets + stash in front, the second sets behind
     int r5;                     // the round-5 forms the launch's instantiation carries (layer_body's R5): 3 or 0
+    unsigned kpre_off;          // split heads: LDS byte offset of the two K tiles a part's workgroup brings in by LDS-DMA under the QKV phase (attn_kpre_issue; 0: off)
     int nw_o;                   // arrival-order Wo: the waves [0, nw_o) hold Wo's steps and look for their heads, the waves [nw_o, 16) issue the workgroup's [W1; W3] stash (GemvCtx::nw); 16: every wave does both
     int nst2_ao;                // ... its stash slots: the steps beyond the two register sets (all of W2's share is resident)
     unsigned long long* trace;  // FLM_ABLATE builds: [grid][16] s_memrealtime stamps (100 MHz, one clock for all XCDs; tools/trace_back.py)
@@ -267,6 +268,11 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
                     }
                 }
             }
+            if constexpr (SPLIT) {
+                // a split head's part: its first two K tiles (earlier tokens' rows: they depend on nothing of this layer) by LDS-DMA, now -- x is in registers, the rmsnorm chain and
+                // the quantizer follow, the memory pipeline has only the early register sets in it -- instead of behind the QKV phase, where the part's scores waited for them
+                if ((int)blockIdx.x < p.n_heads && p.kpre_off) attn_kpre_issue(aa, blockIdx.x / aa.G, blockIdx.x % aa.G, aa.G, *aa.pos_ptr + 1, lds, p.kpre_off);
+            }
             gemv_prologue<QT, PRO_RMSNORM_QUANT, 1, PERSIST, FLM_LAYER_LATEQ != 0>(aq, lds, xq, nq, [&](int) { gq.issue_missing(kAblate ? aq.ablate : 0); });
             stamp(12);
             gq.run(aq, lds, nostamp);
@@ -300,7 +306,7 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
             }
             __syncthreads();
         };
-        if constexpr (QKV) attn_head_any<true, SPLIT, true, gr_q>(aa, hh, lds, *aa.pos_ptr + 1, aa.q, aa.out, blockIdx.x % G, G, qwait, target, gr_att, gr);
+        if constexpr (QKV) attn_head_any<true, SPLIT, true, gr_q>(aa, hh, lds, *aa.pos_ptr + 1, aa.q, aa.out, blockIdx.x % G, G, qwait, target, gr_att, gr, (SPLIT && p.kpre_off) ? reinterpret_cast<const float*>(lds + p.kpre_off) : nullptr);
         else attn_head_any<false, SPLIT>(aa, hh, lds, *aa.pos_ptr + 1, aa.q, aa.out, blockIdx.x % G, G);
         stamp(1);
         if (gr_att) __syncthreads();                                            // (the LDS is free; the output's granules are their own flags)

@@ -104,7 +104,11 @@ int plan_layer(flm_ctx* c, int l, bool with_qkv, int G, LayerArgs& A, BackArgs& 
             gpeers(aa.gout_peer, 2 * (size_t)d.dim + (size_t)c->plan.head_begin * c->hs);
         }
     }
-    p.flag_x2 = c->flag_lines + 1280 * 16; p.nstq = slots(c->tok_nstq); p.preq = c->tok_preq == 99 ? 16 : c->tok_preq < 0 ? 0 : c->tok_preq > 16 ? 16 : c->tok_preq;
+    p.flag_x2 = c->flag_lines + 1280 * 16; p.nstq = slots(c->tok_nstq);
+    {   // split heads: two K tiles per part by LDS-DMA under the QKV phase, above the phase's stash and above everything the attention itself keeps in LDS before its scores are done
+        const size_t tile2 = (size_t)2 * 64 * attn_row_stride(c->hs) * 4, off = ((size_t)own + (size_t)p.nstq * slot + 255) & ~(size_t)255;
+        p.kpre_off = (G > 1 && with_qkv && c->attn_kpre && off >= attn_lds_bytes(d.max_seq_len, c->hs, false) && off + tile2 <= kLdsMax) ? (unsigned)off : 0u;
+    } p.preq = c->tok_preq == 99 ? 16 : c->tok_preq < 0 ? 0 : c->tok_preq > 16 ? 16 : c->tok_preq;
     if (tpl) {   // the cross-rank lines: regions of the ranks' exchange buffers (never cleared: epoch values); flag_q and the split heads' score lines stay local (k_embed clears them)
         BackArgs::Tp& t = p.tp;
         t.world = c->world; t.rank = c->rank;

@@ -12,6 +12,8 @@
 //   "back_pre13"       waves that request their first register set of [W1; W3] in front of the x1 hand-off (by launch: 8 in the one-launch token below 128 positions, else 16)
 //   "back_pre2"        waves that request their first register set of W2 in front of the hd flag round (16; the hand-off in its round-4 form)
 //   "back_ao2"         arrival-order FFN2: what of W2 is requested in front of a wave's first look: 1 everything, 2 the first register sets (default), 3 first sets + stash
+//   "attn_kpre"        split heads (long contexts) inside the whole-layer launches: a part's first two K tiles are brought into LDS by LDS-DMA under the layer's QKV phase (1) or requested when the
+//                      part's attention starts (0)
 //   "back_nwo"         arrival-order Wo: how many of a workgroup's 16 waves hold Wo's steps and look for their heads; the others issue the [W1; W3] stash (0 = ceil(steps / 2): 10 at 7B; 16 = every
 //                      wave does both, rounds 4-5)
 //   "inject_wait_failure" 1 = raise the "a cross-workgroup wait gave up" flag NOW (one shot): the next call's fused launches run through without waiting, the call is re-run on
@@ -19,5 +21,5 @@
 // Numbers behind the defaults: DESIGN.md section 7c / 7d, tools/back_bench.py.
 #pragma once
 namespace fh {
-constexpr const char* kTuningKeys[] = {"wg_per_cu", "use_mfma", "tok_preq", "tok_nstq", "back_nst13", "back_nst13_head", "back_nst2", "back_pre13", "back_pre2", "back_ao2", "back_nwo", "inject_wait_failure"};
+constexpr const char* kTuningKeys[] = {"wg_per_cu", "use_mfma", "tok_preq", "tok_nstq", "back_nst13", "back_nst13_head", "back_nst2", "back_pre13", "back_pre2", "back_ao2", "attn_kpre", "back_nwo", "inject_wait_failure"};
 }
