@@ -840,9 +840,15 @@ static void warm_up(flm_ctx* c) {
     int32_t toks[kPrefillMin + 2] = {0};
     const int n = c->d.max_seq_len > kPrefillMin + 2 ? kPrefillMin + 2 : 1;
     bool ok = feed(c, toks, n, 0, 0) == FLM_OK && hipStreamSynchronize(c->stream) == hipSuccess;
+    // ... and every graph a greedy loop replays, once: chunks of 16, 8, 4, 2 tokens and the single token, for one workgroup per head and (from kSplitFrom positions on) for split
+    // heads -- whatever a graph's FIRST launch costs (seen once: ~2 ms inside a timed region of 20 tokens) is paid here
+    const int kEach = 2 * kChunk - 1;
+    if (ok && c->d.max_seq_len > n + kEach) ok = set_state(c, n, 0, 0) == FLM_OK && run_greedy_tokens(c, n, kEach) == FLM_OK && hipStreamSynchronize(c->stream) == hipSuccess;
+    if (ok && c->d.max_seq_len > kSplitFrom + 8 + kEach && attn_parts(c, kSplitFrom + 8) != attn_parts(c, 1))
+        ok = set_state(c, kSplitFrom + 8, 0, 0) == FLM_OK && run_greedy_tokens(c, kSplitFrom + 8, kEach) == FLM_OK && hipStreamSynchronize(c->stream) == hipSuccess;
     if (ok) (void)xwg_check(c);                                                // (a wait that gave up here puts the context on the per-phase kernels like any other)
-    const size_t pitch = (size_t)c->kv_rows * c->hs * 4, width = (size_t)n * c->hs * 4, height = (size_t)c->d.n_layers * c->heads_local;
-    (void)hipMemset2DAsync(c->kcache, pitch, 0, width, height, c->stream); (void)hipMemset2DAsync(c->vcache, pitch, 0, width, height, c->stream);
+    const size_t kvn = (size_t)c->d.n_layers * c->heads_local * c->kv_rows * c->hs;     // the cache rows the dummy tokens wrote: cleared again
+    (void)hipMemsetAsync(c->kcache, 0, kvn * 4, c->stream); (void)hipMemsetAsync(c->vcache, 0, kvn * 4, c->stream);
     (void)hipStreamSynchronize(c->stream);
     (void)hipGetLastError(); c->err = err0; g_last_error = gerr0;               // (an error here is not the caller's: it resurfaces at the first forward)
 }
