@@ -176,9 +176,27 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
     constexpr int KE = (SPLIT && PRE) ? (FLM_SPLIT_K_EARLY < D ? FLM_SPLIT_K_EARLY : D) : D;
     // kpre (SPLIT + PRE, k_layers): the part's first two K tiles were brought into LDS by LDS-DMA UNDER the layer's QKV phase (attn_kpre_issue: rows of earlier tokens depend on nothing
     // of the layer), in the tile layout at kpre / kpre + one tile: nothing of them is requested here, the first step's scores start when q is there
+    // (FLM_KPRE_EARLY3: with the first two tiles pre-landed by DMA, the part's OTHER two tiles go into the ring's registers in front of the round, the whole share of a part up to
+    //  T = 1024 -- a part of three or four tiles (from position 513 on) otherwise waits a whole round trip for them behind the first step's scores.  us per 32-layer token at positions
+    //  300 / 516 / 600 / 900, same box: 0 tiles 1772 / 1927 / 1965 / 2133, 1 tile 1777 / 1915 / 1957 / 2127, 2 tiles 1765 / 1906 / 1947 / 2112)
+#ifndef FLM_KPRE_EARLY3
+#define FLM_KPRE_EARLY3 2
+#endif
+    constexpr int KE3 = (SPLIT && PRE) ? (KE + FLM_KPRE_EARLY3 < D ? FLM_KPRE_EARLY3 : D - KE) : 0;
+    // (SPLIT + GRIN: q and this token's K / V row come as granules, swept below -- everything of the earlier tokens' rows is requested in FRONT of the sweep, whose loads return
+    //  behind it: a tile requested behind the sweep and patched with a select would be waited for at the select)
+    constexpr bool swept_s = PRE && SPLIT && GRIN;
+    static_assert(!swept_s || KE + KE3 == D, "SPLIT + GRIN: the whole ring in front of the sweep");
+    if (swept_s && kpre == nullptr) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) request(rK, sb + u, se, prow, goff, ringK[u], Told);
+    } else
     if (!(SPLIT && PRE) || kpre == nullptr) {
 #pragma unroll
         for (int u = 0; u < KE; ++u) request(rK, sb + u, se, prow, goff, ringK[u], Told);
+    } else {
+#pragma unroll
+        for (int u = KE; u < KE + KE3; ++u) request(rK, sb + u, se, prow, goff, ringK[u], Told);
     }
     if constexpr (SPLIT) {
         // a thread's pieces: the 16-byte column tid % 8 of the rows 4 (tid / 8) + (j % 4) + 512 (j / 4) -- four CONSECUTIVE rows per half, so
@@ -255,7 +273,67 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
                 }
         }
     }
-    if constexpr (PRE && !swept) {
+    v4f vnew = {0.f, 0.f, 0.f, 0.f}, knew = vnew;                   // SPLIT + GRIN: this thread's piece of this token's V / K row (if it owns one)
+    const int tlast = (T - 1) / kAttnTile;
+    auto patch_lds = [&](float* buf, int tile) {                    // this token's K piece into tile `tile` parked at buf
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+            if (tile == tlast && tile < se && tile * kAttnTile + prow[j] == T - 1) *reinterpret_cast<float4*>(buf + loff[j]) = make_float4(knew.x, knew.y, knew.z, knew.w);
+    };
+    if constexpr (swept_s) {
+        // the split head's part: q element tid, the one 16-byte piece of this token's K row if it lies in one of the part's tiles, and the piece of this token's V row in the part's
+        // 32 dimensions (8 threads own them) -- as granules (tag epoch_arg) from the QKV phase of this launch, every thread re-reading ITS pieces until their tags match
+        static_assert(!swept_s || FLM_SPLIT_V_LATE, "the V slice is requested behind the sweep");
+        typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(a.qg) + (size_t)h * hs, 0, hs * 8, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(a.kg) + (size_t)h * hs, 0, hs * 8, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(a.vg) + (size_t)h * hs, 0, hs * 8, 0x00020000);
+        int kcol = -1;
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+            if (tlast >= sb && tlast < se && tlast * kAttnTile + prow[j] == T - 1) kcol = (goff[j] >> 2) % hs;
+        const bool vown = (((T - 1) & (kSplitMaxSeq / 2 - 1)) >> 2) == (tid >> 3);     // rows 4 (tid / 8) + (j % 4) + 512 (j / 4) of the slice are this thread's
+        const int vcol = d0 + (tid & 7) * 4;
+        unsigned qbits = 0; v4u32 KA = {0u, 0u, 0u, 0u}, KC = KA, VA = KA, VC = KA;
+        bool okq = tid >= hs, okk = kcol < 0, okv = !vown;
+        const int gave_up = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (true) {
+            asm volatile("" ::: "memory");
+            uint2 qq = make_uint2(0u, 0u);
+            if (!okq) qq = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rq, tid * 8, 0, kAuxCoherent));
+            if (!okk) { KA = __builtin_bit_cast(v4u32, __builtin_amdgcn_raw_buffer_load_b128(rk, kcol * 8, 0, kAuxCoherent)); KC = __builtin_bit_cast(v4u32, __builtin_amdgcn_raw_buffer_load_b128(rk, kcol * 8 + 16, 0, kAuxCoherent)); }
+            if (!okv) { VA = __builtin_bit_cast(v4u32, __builtin_amdgcn_raw_buffer_load_b128(rv, vcol * 8, 0, kAuxCoherent)); VC = __builtin_bit_cast(v4u32, __builtin_amdgcn_raw_buffer_load_b128(rv, vcol * 8 + 16, 0, kAuxCoherent)); }
+            if (!okq) { okq = qq.y == epoch_arg; qbits = qq.x; }
+            if (!okk) okk = KA.y == epoch_arg && KA.w == epoch_arg && KC.y == epoch_arg && KC.w == epoch_arg;
+            if (!okv) okv = VA.y == epoch_arg && VA.w == epoch_arg && VC.y == epoch_arg && VC.w == epoch_arg;
+            if (__all(okq && okk && okv) || gave_up) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) { __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        }
+        // every wave: what it requested before the sweep has landed -- the pre-landed tiles' DMA among it (the QKV phase of the granule form ends without a drain; the first
+        // step's barrier follows) -- loads return in order, so this waits for nothing a sweeping wave has not already seen
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(7);
+        qv[0] = tid < hs ? __uint_as_float(qbits) : 0.f;
+        knew = v4f{__uint_as_float(KA.x), __uint_as_float(KA.z), __uint_as_float(KC.x), __uint_as_float(KC.z)};
+        vnew = v4f{__uint_as_float(VA.x), __uint_as_float(VA.z), __uint_as_float(VC.x), __uint_as_float(VC.z)};
+        // (this token's K piece goes into its tile IN LDS: into a pre-landed tile now, into a ring tile when it is parked -- whichever tile of the part it is)
+        if (kpre != nullptr) {
+#pragma unroll
+            for (int u = 0; u < KE; ++u) patch_lds(const_cast<float*>(kpre) + u * kAttnTile * rs, sb + u);
+        }
+        // the first half of the V slice behind the sweep: the earlier tokens' rows from the cache, this token's piece from its granules
+#pragma unroll
+        for (int j = 0; j < kSplitVRegs / 2; ++j) {
+            const int row = 4 * (tid >> 3) + (j & 3) + (kSplitMaxSeq / 2) * (j >> 2);
+            if (row == T - 1) vall[j] = vnew;
+            else {
+                const unsigned off = row < Told ? (unsigned)((row * hs + d0 + (tid & 7) * 4) * 4) : 0x80000000u;
+                vall[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rV, (int)off, 0, COH ? kAuxCoherent : 0));
+            }
+        }
+    }
+    if constexpr (PRE && !swept && !swept_s) {
         mid();                                                      // the flag round: q and this token's cache rows are in memory
         stamp(7);
 #pragma unroll
@@ -275,7 +353,10 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
         for (int u = 0; u < KE; ++u) patch(rK, sb + u, se, prow, goff, ringK[u]);
         }
 #pragma unroll
-        for (int u = KE; u < D; ++u) request(rK, sb + u, se, prow, goff, ringK[u], T);
+        for (int u = KE; u < D; ++u) {
+            if (u < KE + KE3 && SPLIT && kpre != nullptr) patch(rK, sb + u, se, prow, goff, ringK[u]);
+            else request(rK, sb + u, se, prow, goff, ringK[u], T);
+        }
         if constexpr (SPLIT) {
 #pragma unroll
             for (int j = 0; j < kSplitVRegs / 2; ++j) {
@@ -335,9 +416,12 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
             for (int u = 0; u < D; u += 2) {
                 const int s = base + u;
                 const bool pre = PRE && u == 0 && base == sb && kpre != nullptr;   // (wave-uniform: the two pre-landed tiles)
-                if (!pre) { park(tile0, prow, loff, ringK[u]); park(tile1, prow, loff, ringK[u + 1]); }
+                if (!pre) {
+                    park(tile0, prow, loff, ringK[u]); park(tile1, prow, loff, ringK[u + 1]);
+                    if constexpr (swept_s) { patch_lds(tile0, s); patch_lds(tile1, s + 1); }
+                }
                 __syncthreads();
-                request(rK, s + D, se, prow, goff, ringK[u], T); request(rK, s + D + 1, se, prow, goff, ringK[u + 1], T);
+                request(rK, s + D, se, prow, goff, ringK[u], swept_s ? Told : T); request(rK, s + D + 1, se, prow, goff, ringK[u + 1], swept_s ? Told : T);
                 const int half = tid >> 9, s2 = s + half;
                 const float* c0 = pre ? kpre : tile0; const float* c1 = pre ? kpre + kAttnTile * rs : tile1;
                 if (s2 < se) score_lane(half ? c1 : c0, s2, (tid >> 3) & 63, tid & 7);
@@ -361,8 +445,11 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
 #pragma unroll
         for (int j = kSplitVRegs / 2; j < kSplitVRegs; ++j) {
             const int row = 4 * (tid >> 3) + (j & 3) + (kSplitMaxSeq / 2) * (j >> 2);
-            const unsigned off = row < T ? (unsigned)((row * hs + d0 + (tid & 7) * 4) * 4) : 0x80000000u;
+            if (swept_s && row == T - 1) vall[j] = vnew;           // (granule form: this token's row is not waited for in the cache)
+            else {
+            const unsigned off = row < (swept_s ? Told : T) ? (unsigned)((row * hs + d0 + (tid & 7) * 4) * 4) : 0x80000000u;
             vall[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rV, (int)off, 0, COH ? kAuxCoherent : 0));
+            }
         }
     }
     stamp(1);
@@ -419,6 +506,29 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
     // operations in the same order: max order-free; expf_ref; the sum t ascending as 63 dependent adds along the lanes (step k:
     // every lane adds its own term to its left neighbour's running sum, v_add with DPP wave_shr:1; after step k lanes 0..k hold
     // their exact prefix, so lane T - 1 ends with sum_{t < T} in the reference's order); divide; skip rule.
+    // (SPLIT: the part's V slice is parked -- transposed, where the K tiles were: every wave is behind the scores' last barrier -- by the 15 waves that only wait for the sum; wave 0
+    //  parks its pieces behind its chain.  The layout is described at the weighted sum below.)
+#ifndef FLM_SPLIT_PARK_EARLY
+#define FLM_SPLIT_PARK_EARLY 1
+#endif
+    auto park_v = [&]() {
+        if constexpr (SPLIT) {
+            constexpr int VS = kSplitMaxSeq + 4;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {                            // 4 rows x 4 dimensions in registers -> 4 dimensions x 4 positions: four 16-byte stores
+                const int p0 = 4 * (tid >> 3) + (kSplitMaxSeq / 2) * hh;     // (rows past T were never loaded: zeros)
+                if (p0 < T) {
+                    float* dst = tile0 + (tid & 7) * 4 * VS + p0;
+                    const v4f r0 = vall[4 * hh], r1 = vall[4 * hh + 1], r2 = vall[4 * hh + 2], r3 = vall[4 * hh + 3];
+                    *reinterpret_cast<float4*>(dst)          = make_float4(r0.x, r1.x, r2.x, r3.x);
+                    *reinterpret_cast<float4*>(dst + VS)     = make_float4(r0.y, r1.y, r2.y, r3.y);
+                    *reinterpret_cast<float4*>(dst + 2 * VS) = make_float4(r0.z, r1.z, r2.z, r3.z);
+                    *reinterpret_cast<float4*>(dst + 3 * VS) = make_float4(r0.w, r1.w, r2.w, r3.w);
+                }
+            }
+        }
+    };
+    constexpr bool park_early = SPLIT && FLM_SPLIT_PARK_EARLY;
     const bool short_ctx = !SPLIT && G == 1 && T <= 64;
     if (short_ctx) {
         __syncthreads();                                            // the scores are in sc[]
@@ -446,6 +556,7 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
     for (int t = tid; t < T; t += kAttnBlock) sc[t] = expf_ref(__fsub_rn(sc[t], m), etab);
     __syncthreads();
     stamp(2);
+    if (park_early && wave != 0) park_v();
     if (tid == 0) {                                                // sum += x[i], i ascending (tf_operators.cpp:180-183)
         // a lone lane: the loop is the T dependent adds plus one LDS read per four of them, reads 28 adds ahead
         float sum = 0.f;
@@ -468,13 +579,17 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
 #undef FLM_ADD4
         for (; t < T; ++t) sum = __fadd_rn(sum, sc[t]);
         red[16] = sum;
+        red[20] = 1.f;                                              // (park_early: "no row is skipped" until the divide loop says otherwise)
     }
+    if (park_early && wave == 0) park_v();
     __syncthreads();
     stamp(3);
     const float sum = red[16];
     // att[t] = exp / sum; rows t >= 1 with |att| <= 1e-15 are skipped by the weighted sum (transformer.cpp:449): they are
     // stored as exact zeros so that the PV chain can tell them apart with one wave-uniform test per four positions
-    for (int t = tid; t < T; t += kAttnBlock) { const float w = __fdiv_rn(sc[t], sum); sc[t] = (t > 0 && fabsf(w) <= 1e-15f) ? 0.f : w; }
+    bool zero_w = false;
+    for (int t = tid; t < T; t += kAttnBlock) { const float w = __fdiv_rn(sc[t], sum); const bool z = t > 0 && fabsf(w) <= 1e-15f; sc[t] = z ? 0.f : w; zero_w = zero_w || z; }
+    if (park_early && zero_w) red[20] = 0.f;                        // some row is skipped: the chain takes the careful path
     }
     // (the first barrier of the loop below orders these writes before the PV reads)
     // ---- o[d] = sum_t att[t] V[t][d]: one thread per output dimension (of this part), t ascending (the reference's chain) over
@@ -488,27 +603,18 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
         // weight fell under the threshold skipped); with operands streaming through a 4-slot register ring it runs at the pace
         // of the dependent FMAs (measured before this layout: 35 cycles per position, the LDS latency of scalar reads).
         constexpr int VS = kSplitMaxSeq + 4;
-        if (tid == 0) red[20] = 1.f;
-        __syncthreads();                                            // every wave is done with the K tiles (and has written its weights)
-        {
-            bool zero_w = false;
-            for (int t = tid; t < T; t += kAttnBlock) zero_w = zero_w || (t > 0 && sc[t] == 0.f);
-            if (zero_w) red[20] = 0.f;                              // some row is skipped: the chain takes the careful path
-        }
         static_assert(kSplitVRegs == 8, "two halves of four consecutive rows per thread");
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {                            // 4 rows x 4 dimensions in registers -> 4 dimensions x 4 positions: four 16-byte stores
-            const int p0 = 4 * (tid >> 3) + (kSplitMaxSeq / 2) * hh;     // (rows past T were never loaded: zeros)
-            if (p0 < T) {
-                float* dst = tile0 + (tid & 7) * 4 * VS + p0;
-                const v4f r0 = vall[4 * hh], r1 = vall[4 * hh + 1], r2 = vall[4 * hh + 2], r3 = vall[4 * hh + 3];
-                *reinterpret_cast<float4*>(dst)          = make_float4(r0.x, r1.x, r2.x, r3.x);
-                *reinterpret_cast<float4*>(dst + VS)     = make_float4(r0.y, r1.y, r2.y, r3.y);
-                *reinterpret_cast<float4*>(dst + 2 * VS) = make_float4(r0.z, r1.z, r2.z, r3.z);
-                *reinterpret_cast<float4*>(dst + 3 * VS) = make_float4(r0.w, r1.w, r2.w, r3.w);
+        if constexpr (!FLM_SPLIT_PARK_EARLY) {
+            if (tid == 0) red[20] = 1.f;
+            __syncthreads();                                        // every wave is done with the K tiles (and has written its weights)
+            {
+                bool zw = false;
+                for (int t = tid; t < T; t += kAttnBlock) zw = zw || (t > 0 && sc[t] == 0.f);
+                if (zw) red[20] = 0.f;                              // some row is skipped: the chain takes the careful path
             }
+            park_v();
         }
-        __syncthreads();
+        __syncthreads();                                            // (park_early: the slice was parked under the sum chain; the weights and the skip flag are written)
         if (tid < nd) {
             const float* vp = tile0 + tid * VS;
             const float* wp = sc;
@@ -699,7 +805,7 @@ template <bool COH, bool SPLIT, bool PRE = false, bool GRIN = false, class Mid =
 // epoch: the value the parts of a split head raise / wait for in their score exchange (0: a.epoch; k_layers passes the layer's flag target, which counts from the token's epoch base)
 __device__ __forceinline__ void attn_head_any(const AttnArgs& a, const int h, char* lds, const int T, const float* qrow, float* orow, const int g = 0, const int G = 1, Mid&& mid = Mid(), const unsigned epoch = 0u, const bool gr_out = false, const bool gr_sc = false, const float* kpre = nullptr) {
     if constexpr (SPLIT) {      // the host picks G = hs / kSplitDims (attn_parts): every part owns 32 output dimensions; hs <= 128
-        if (a.hs <= 64) attn_head<1, COH, true, PRE, Mid>(a, h, lds, T, qrow, orow, g, G, static_cast<Mid&&>(mid), epoch, gr_out, gr_sc, kpre); else attn_head<2, COH, true, PRE, Mid>(a, h, lds, T, qrow, orow, g, G, static_cast<Mid&&>(mid), epoch, gr_out, gr_sc, kpre);
+        if (a.hs <= 64) attn_head<1, COH, true, PRE, Mid, GRIN>(a, h, lds, T, qrow, orow, g, G, static_cast<Mid&&>(mid), epoch, gr_out, gr_sc, kpre); else attn_head<2, COH, true, PRE, Mid, GRIN>(a, h, lds, T, qrow, orow, g, G, static_cast<Mid&&>(mid), epoch, gr_out, gr_sc, kpre);
     } else {
         if (a.hs <= 64) attn_head<1, COH, false, PRE, Mid, GRIN>(a, h, lds, T, qrow, orow, 0, 1, static_cast<Mid&&>(mid), epoch, gr_out); else if (a.hs <= 128) attn_head<2, COH, false, PRE, Mid, GRIN>(a, h, lds, T, qrow, orow, 0, 1, static_cast<Mid&&>(mid), epoch, gr_out); else attn_head<4, COH, false, PRE, Mid, GRIN>(a, h, lds, T, qrow, orow, 0, 1, static_cast<Mid&&>(mid), epoch, gr_out);
     }

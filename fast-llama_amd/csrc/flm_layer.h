@@ -241,9 +241,12 @@ __device__ __forceinline__ void layer_body(const GemvArgs& aq, const AttnArgs& a
     stamp(0);
     constexpr bool gr = PERSIST && GRM == 2;                                    // the x / x1 edges as granules
     constexpr bool gr_hd = gr && (R5 & 2) == 0;                                     // ... and hd, where FFN2 takes it in its all-to-all form
-    // ... and q + this token's K / V row from the QKV phase to the heads, where a head is one workgroup and its <= 2 tiles are all requested at once
-    // (one GPU, one workgroup per head: the host launches this instantiation below kSplitFrom positions only -- plan_layer gives a shape whose long contexts cannot split no one-launch token)
-    constexpr bool gr_q = gr && !TP && !SPLIT && QKV;
+    // ... and q + this token's K / V row from the QKV phase to the heads (one GPU): a head of one workgroup has its <= 2 tiles all requested at once; a split head's part has its
+    // first two K tiles pre-landed by DMA and the other two in the ring's registers in front of the sweep (attn_head<.., GRIN>)
+#ifndef FLM_SPLIT_GRQ
+#define FLM_SPLIT_GRQ 1
+#endif
+    constexpr bool gr_q = gr && !TP && QKV && (FLM_SPLIT_GRQ || !SPLIT);
     constexpr bool gr_att = gr && (TP || SPLIT);                                    // ... and the heads' fp32 output, where the Wo workgroups quantize it themselves (across ranks; split heads)
     unsigned nst13 = 0;
     if constexpr (QKV) {

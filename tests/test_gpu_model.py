@@ -396,6 +396,36 @@ def test_greedy_token_as_one_launch_vs_oracle(gpu, pos0, qt):
     ctx.close()
 
 
+@pytest.mark.parametrize("shape,pos0", [("7B", 700), ("7B", 1000), ((2048, 5504, 2, 32, 32000), 700)])
+def test_one_launch_token_with_split_heads_deep_in_the_context_vs_oracle(gpu, shape, pos0):
+    """k_layers<.., SPLIT, .., TAIL> from position 512 on: q and this token's K / V row reach the parts of a split head as granules (attn_head<.., SPLIT, .., GRIN>) -- the K piece is
+    patched into a pre-landed tile (positions 700..703), into a ring tile when it is parked (704..: the part's third tile; 1000..: its fourth), into a tile requested inside the
+    steps loop (head size 64: two parts of six tiles); the V piece lands in the second half of the slice (rows >= 512).  19 greedy ids and the last logits are the oracle's, with
+    the granule form and with the flag form."""
+    cfg = synth.make_config(shape, ff.QT_INT8); cfg.n_layers = 2
+    tensors = synth.make_tensors(cfg, seed=61)
+    om = O.OracleModel(cfg, tensors)
+    prompt = _prompt(cfg.vocab_size, pos0)
+    first = int(np.argmax(om.forward(prompt, 0))); n = 19
+    want_ids, cur, pos, last = [], first, len(prompt), None
+    for _ in range(n):
+        last = om.forward(np.array([cur], np.int32), pos); cur = int(np.argmax(last)); want_ids.append(cur); pos += 1
+    ctx = gpu.Ctx(gpu.desc_from_config(cfg)); ctx.upload_all(tensors)
+    for opts in ({}, {"tuning": 1, "gr_edges": 0}, {"gr_edges": 1, "attn_kpre": 0}, {"attn_kpre": 1, "use_graph": 0}):
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        ctx.reset_kv()
+        assert ctx.forward_argmax(prompt, 0) == first
+        ids = list(ctx.decode_greedy(first, len(prompt), n))
+        assert ids == want_ids, (opts, ids, want_ids)
+        assert bits_equal(ctx.debug_read("logits", 0, cfg.vocab_size), last), opts
+        assert ctx.query("fallback") == 0
+        assert bool(ctx.query("gr_active") & 2) == bool(ctx.query("gr_edges")), opts      # (bit 1: the split heads' one-launch token ran, on granules)
+        if not ctx.query("attn_kpre"): assert ctx.query("kpre_active") == 0
+        elif shape == "7B" and ctx.query("gr_edges"): assert ctx.query("kpre_active") > 0, opts      # (the pre-landed tiles are what ran)
+    ctx.close()
+
+
 def test_one_launch_token_after_the_embedding_table_is_replaced(gpu):
     """the one-launch token reads the embedding row through a pointer in a device-resident argument block: uploading another table (a new allocation) must rebuild that block"""
     cfg = synth.make_config("7B", ff.QT_INT8); cfg.n_layers = 1
