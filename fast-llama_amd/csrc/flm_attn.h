@@ -274,6 +274,23 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
         }
     }
     v4f vnew = {0.f, 0.f, 0.f, 0.f}, knew = vnew;                   // SPLIT + GRIN: this thread's piece of this token's V / K row (if it owns one)
+#ifndef FLM_SPLIT_V_BEHIND
+#define FLM_SPLIT_V_BEHIND 0      /* measured neutral (positions 516 / 600 / 900: 1888 / 1930 / 2097 us per token either way): the slice stays behind the sweep */
+#endif
+    const bool v_behind = FLM_SPLIT_V_BEHIND && SPLIT && PRE && GRIN && (kpre == nullptr || se - sb > KE);          // (workgroup-uniform)
+    auto vfirst = [&]() {
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int j = 0; j < kSplitVRegs / 2; ++j) {
+                const int row = 4 * (tid >> 3) + (j & 3) + (kSplitMaxSeq / 2) * (j >> 2);
+                if (row == T - 1) vall[j] = vnew;
+                else {
+                    const unsigned off = row < Told ? (unsigned)((row * hs + d0 + (tid & 7) * 4) * 4) : 0x80000000u;
+                    vall[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rV, (int)off, 0, COH ? kAuxCoherent : 0));
+                }
+            }
+        }
+    };
     const int tlast = (T - 1) / kAttnTile;
     auto patch_lds = [&](float* buf, int tile) {                    // this token's K piece into tile `tile` parked at buf
 #pragma unroll
@@ -322,16 +339,10 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
 #pragma unroll
             for (int u = 0; u < KE; ++u) patch_lds(const_cast<float*>(kpre) + u * kAttnTile * rs, sb + u);
         }
-        // the first half of the V slice behind the sweep: the earlier tokens' rows from the cache, this token's piece from its granules
-#pragma unroll
-        for (int j = 0; j < kSplitVRegs / 2; ++j) {
-            const int row = 4 * (tid >> 3) + (j & 3) + (kSplitMaxSeq / 2) * (j >> 2);
-            if (row == T - 1) vall[j] = vnew;
-            else {
-                const unsigned off = row < Told ? (unsigned)((row * hs + d0 + (tid & 7) * 4) * 4) : 0x80000000u;
-                vall[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rV, (int)off, 0, COH ? kAuxCoherent : 0));
-            }
-        }
+        // the first half of the V slice behind the sweep (the earlier tokens' rows from the cache, this token's piece from its granules) -- where the part's scores come from the
+        // pre-landed tiles alone.  A part that PARKS ring tiles gets it behind its scores: the parks sit in a loop, the compiler merges the loop's entry with its back edge and waits
+        // there for (nearly) everything in flight -- a slice requested here would be waited for before the part's second step (measured: 3.9 us from the sweep to the last score)
+        if (!v_behind) vfirst();
     }
     if constexpr (PRE && !swept && !swept_s) {
         mid();                                                      // the flag round: q and this token's cache rows are in memory
@@ -420,12 +431,16 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
                     park(tile0, prow, loff, ringK[u]); park(tile1, prow, loff, ringK[u + 1]);
                     if constexpr (swept_s) { patch_lds(tile0, s); patch_lds(tile1, s + 1); }
                 }
+                if (base == sb) stamp(u == 0 ? 10 : 13);
                 __syncthreads();
+                if (base == sb) stamp(u == 0 ? 5 : 14);
                 request(rK, s + D, se, prow, goff, ringK[u], swept_s ? Told : T); request(rK, s + D + 1, se, prow, goff, ringK[u + 1], swept_s ? Told : T);
                 const int half = tid >> 9, s2 = s + half;
                 const float* c0 = pre ? kpre : tile0; const float* c1 = pre ? kpre + kAttnTile * rs : tile1;
                 if (s2 < se) score_lane(half ? c1 : c0, s2, (tid >> 3) & 63, tid & 7);
+                if (base == sb) stamp(u == 0 ? 11 : 15);
                 __syncthreads();
+                if (base == sb && u == 2) stamp(9);
             }
         }
     } else {
@@ -442,6 +457,7 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
         }
     }
     if constexpr (SPLIT) {
+        if (v_behind) vfirst();
 #pragma unroll
         for (int j = kSplitVRegs / 2; j < kSplitVRegs; ++j) {
             const int row = 4 * (tid >> 3) + (j & 3) + (kSplitMaxSeq / 2) * (j >> 2);

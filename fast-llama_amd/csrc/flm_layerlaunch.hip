@@ -89,6 +89,7 @@ int plan_layer(flm_ctx* c, int l, bool with_qkv, int G, LayerArgs& A, BackArgs& 
     // with the edges on granules the sweep IS the phase's activation fetch, and it returns behind whatever its own wave requested in front of it: fewer early register sets
     // at short contexts (tools/back_bench.py, 32 layers: pre13 16 / 12 / 8 / 4: 1571 / 1562 / 1561 / 1600 us per token; preq 16 / 12 / 8 with pre13 8: 1561 / 1545 / 1555); with
     // split heads (long contexts) 16 stays (pre13 8: +0.9 %)
+    if (p.gr && tpl && c->back_pre13 == 99) p.pre13 = 12;                        // (rank-spanning launch, one-GPU rehearsal, 4 layers: world 2 / 4 251-253 / 261-262 -> 249 / 256-257 us per token with pre13 12, preq 12)
     if (p.gr && !tpl && G == 1 && c->back_pre13 == 99) p.pre13 = 10;            // (preq: below, where it is set; with preq 12: pre13 8 / 10 / 12 = 1542 / 1537 / 1539 us per token at position 14, the same order at 40 and 100)
     {
         auto gpeers = [&](unsigned long long* (&peer)[7], size_t off) { int k = 0; for (int r = 0; r < c->world; ++r) if (r != c->rank) peer[k++] = (unsigned long long*)(c->peer[r] + c->x_gran_off) + off; };
@@ -110,7 +111,7 @@ int plan_layer(flm_ctx* c, int l, bool with_qkv, int G, LayerArgs& A, BackArgs& 
         p.kpre_off = (G > 1 && with_qkv && c->attn_kpre && off >= attn_lds_bytes(d.max_seq_len, c->hs, false) && off + tile2 <= kLdsMax) ? (unsigned)off : 0u;
     }
     // (12 early waves of [Wq; Wk; Wv] in front of the x sweep wherever the launch runs on granules, one workgroup per head or split heads: positions 516 / 900 1900 / 2106 -> 1891 / 2098 us per token)
-    p.preq = c->tok_preq == 99 ? ((p.gr && !tpl) ? 12 : 16) : c->tok_preq < 0 ? 0 : c->tok_preq > 16 ? 16 : c->tok_preq;
+    p.preq = c->tok_preq == 99 ? (p.gr ? 12 : 16) : c->tok_preq < 0 ? 0 : c->tok_preq > 16 ? 16 : c->tok_preq;
     if (tpl) {   // the cross-rank lines: regions of the ranks' exchange buffers (never cleared: epoch values); flag_q and the split heads' score lines stay local (k_embed clears them)
         BackArgs::Tp& t = p.tp;
         t.world = c->world; t.rank = c->rank;

@@ -17,6 +17,9 @@ for c in ctxs:
     c.set_option("cu_parts", world)
     if fence is not None:
         c.set_option("tuning", 1); c.set_option("tp_fence", int(fence))
+for kv in filter(None, os.environ.get("FLM_TP_OPTS", "").split(",")):      # e.g. FLM_TP_OPTS=tok_preq=12,back_pre13=8 (tuning dials, every rank)
+    for c in ctxs:
+        c.set_option("tuning", 1); c.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 capi.Ctx.regroup(ctxs)
 prompt = (np.arange(1, 9, dtype=np.int64) * 7919 % cfg.vocab_size).astype(np.int32)
 

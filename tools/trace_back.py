@@ -62,5 +62,10 @@ for spec in sets:
     if (at[:, 0] > 0).any():
         an = {0: "entry (earlier rows requested)", 7: "q flags seen", 5: "first K tile parked", 1: "scores done", 2: "exp done", 3: "sum done", 12: "V tile 0 parked", 8: "barrier passed", 9: "tile 0 walked", 4: "weighted sum done", 6: "output quantized + stored"}
         print("  attention (thread 0 of a head): " + " | ".join(f"{an[k]} {np.median(at[:, k][at[:, k] > 0]):.2f}" for k in (0, 7, 5, 1, 2, 3, 12, 8, 9, 4, 6) if (at[:, k] > 0).any()))
+        if pos >= 128 and (at[:, 10] > 0).any():          # split heads: the steps of the parts' scores, part by part (workgroup % 4)
+            sn = {0: "entry", 7: "swept", 10: "step 1 at its barrier", 5: "through", 11: "scored", 13: "step 2 parked", 14: "through", 15: "scored", 9: "last barrier", 1: "V requested", 2: "exp done", 3: "sum done", 4: "weighted sum done", 6: "stored"}
+            for gpart in range(4):
+                ap = at[gpart::4]
+                print(f"    part {gpart}: " + " | ".join(f"{sn[k]} {np.median(ap[:, k][ap[:, k] > 0]):.2f}" for k in (0, 7, 10, 5, 11, 13, 14, 15, 9, 1, 2, 3, 4, 6) if (ap[:, k] > 0).any()))
     ends = np.array([r[:, 11].max() for r in rows])
     print("  launch span over 5 tokens:", " ".join(f"{e:.2f}" for e in ends))
