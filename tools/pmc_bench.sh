@@ -7,7 +7,7 @@ rm -rf gpurun_out/pmc; mkdir -p gpurun_out/pmc
 for ctr in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/pmc/$ctr -o run -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-config5 --no-decode128 > gpurun_out/pmc/$ctr.log 2>&1
 done
-python3 tools/pmc_agg.py gpurun_out/pmc/FETCH_SIZE gpurun_out/pmc/WRITE_SIZE > gpurun_out/pmc/pmc_fetch_write_raw.json
+python3 tools/pmc_agg.py --last 25 gpurun_out/pmc/FETCH_SIZE gpurun_out/pmc/WRITE_SIZE > gpurun_out/pmc/pmc_fetch_write_raw.json      # (the last 25 dispatches of a kernel: a leg's 5 warm-up + 20 timed steps, not the load-time warm-up's replays)
 rm -rf gpurun_out/pmc/FETCH_SIZE gpurun_out/pmc/WRITE_SIZE
 python3 - <<'PY'
 import json
