@@ -761,7 +761,7 @@ int flm_query(flm_ctx* c, const char* key, int* value) {
     const std::string k(key);
     const struct { const char* k; int v; } tab[] = {
         {"tuning", c->tuning ? 1 : 0}, {"wg_per_cu", c->wg_per_cu}, {"use_graph", c->use_graph}, {"graph_chunks", c->graph_chunks}, {"use_prefill", c->use_prefill}, {"use_mfma", c->use_mfma}, {"use_pv_mfma", c->use_pv_mfma},
-        {"fuse_attn_o", c->fuse_attn_o}, {"fuse_ffn", c->fuse_ffn}, {"fuse_qkv", c->fuse_qkv}, {"fuse_back", c->fuse_back}, {"fuse_layer", c->fuse_layer}, {"fuse_token", c->fuse_token}, {"fuse_tail", c->fuse_tail}, {"tok_nstq", c->tok_nstq}, {"tok_preq", c->tok_preq}, {"back_nst13", c->back_nst13}, {"back_nst13_head", c->back_nst13_head}, {"back_nst2", c->back_nst2}, {"back_pre13", c->back_pre13}, {"back_pre2", c->back_pre2}, {"back_ao", c->back_ao}, {"back_ao2", c->back_ao2}, {"gr_edges", c->gr_edges}, {"back_nwo", c->back_nwo}, {"attn_kpre", c->attn_kpre}, {"kpre_active", c->la_valid[1] ? (int)c->la_p[1].kpre_off : -1}, {"nwo_active", c->la_valid[0] ? c->la_p[0].nw_o : -1}, {"gr_active", ((c->la_valid[0] && c->la_ok[0] && c->la_p[0].gr && (c->world > 1 ? (c->p2p && c->grp_tpl) : c->tail_ok[0])) ? 1 : 0) | ((c->la_valid[1] && c->la_ok[1] && c->la_p[1].gr && (c->world > 1 ? (c->p2p && c->grp_tpl) : c->tail_ok[1])) ? 2 : 0)},   /* the granule hand-offs are what the one-launch token / the rank-spanning launch runs: bit 0 one workgroup per head, bit 1 split heads */ {"use_prefill_mq", c->use_prefill_mq}, {"attn_split", c->attn_split},
+        {"fuse_attn_o", c->fuse_attn_o}, {"fuse_ffn", c->fuse_ffn}, {"fuse_qkv", c->fuse_qkv}, {"fuse_back", c->fuse_back}, {"fuse_layer", c->fuse_layer}, {"fuse_token", c->fuse_token}, {"fuse_tail", c->fuse_tail}, {"tok_nstq", c->tok_nstq}, {"tok_preq", c->tok_preq}, {"back_nst13", c->back_nst13}, {"back_nst13_head", c->back_nst13_head}, {"back_nst2", c->back_nst2}, {"back_pre13", c->back_pre13}, {"back_pre2", c->back_pre2}, {"back_ao", c->back_ao}, {"back_ao2", c->back_ao2}, {"gr_edges", c->gr_edges}, {"back_nwo", c->back_nwo}, {"attn_kpre", c->attn_kpre}, {"kpre_active", c->la_valid[1] ? (int)c->la_p[1].kpre_off : -1}, {"nwo_active", c->la_valid[0] ? c->la_p[0].nw_o : -1}, {"preq_active", c->la_valid[0] ? c->la_p[0].preq : -1}, {"pre13_active", c->la_valid[0] ? c->la_p[0].pre13 : -1}, {"preq_active_split", c->la_valid[1] ? c->la_p[1].preq : -1}, {"pre13_active_split", c->la_valid[1] ? c->la_p[1].pre13 : -1},   /* the early register sets the last one-launch token ran with (plan_layer's by-launch values) */ {"gr_active", ((c->la_valid[0] && c->la_ok[0] && c->la_p[0].gr && (c->world > 1 ? (c->p2p && c->grp_tpl) : c->tail_ok[0])) ? 1 : 0) | ((c->la_valid[1] && c->la_ok[1] && c->la_p[1].gr && (c->world > 1 ? (c->p2p && c->grp_tpl) : c->tail_ok[1])) ? 2 : 0)},   /* the granule hand-offs are what the one-launch token / the rank-spanning launch runs: bit 0 one workgroup per head, bit 1 split heads */ {"use_prefill_mq", c->use_prefill_mq}, {"attn_split", c->attn_split},
         {"use_qk_mfma", c->use_qk_mfma}, {"use_p2p", c->p2p}, {"fold_xchg", c->fold_xchg}, {"tp_fuse_attn", c->tp_fuse_attn}, {"tp_fuse_ffn", c->tp_fuse_ffn}, {"cu_parts", c->cu_parts}, {"fold_active", (c->world > 1 && c->p2p && c->grp_fold) ? 1 : 0}, {"span_active", (c->world > 1 && c->p2p && c->grp_span) ? 1 : 0}, {"tp_trust_fused", c->tp_trust_fused}, {"force_tp", c->force_tp},
         {"tp_fuse_layers", c->tp_fuse_layers}, {"tp_fence", c->tp_fence}, {"tp_fence_active", c->tp_fence >= 0 ? c->tp_fence : (c->ranks_on_device == c->world ? 0 : 3)}, {"grp_gr", (c->world > 1 && c->grp_gr) ? 1 : 0}, {"grp_tp_fuse_layers", (c->world > 1 && c->p2p && c->grp_tpl) ? 1 : 0}, {"tp_layers_active", (c->world > 1 && c->p2p && c->grp_tpl && (c->la_valid[0] || c->la_valid[1])) ? (c->la_valid[0] && c->la_ok[0] ? 1 : 0) | (c->la_valid[1] && c->la_ok[1] ? 2 : 0) : -1},   /* the rank-spanning k_layers was planned: bit 0 one workgroup per head, bit 1 split heads */ {"grp_tp_fuse_attn", c->grp_tpfa}, {"grp_tp_fuse_ffn", c->grp_tpff}, {"grp_attn_split", c->grp_split}, {"resident", c->resident}, {"fallback", c->fell_back}, {"fallback_active", c->fb_active ? 1 : 0},
         {"ao_active", c->la_ok[0] ? (c->la_p[0].ao_o ? 1 : 0) | (c->la_p[0].ao_2 ? 2 : 0) : -1},      // which hand-offs of the token's launch (short contexts) are consumed in arrival order; -1: that launch was not planned (yet)

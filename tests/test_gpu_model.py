@@ -393,6 +393,7 @@ def test_greedy_token_as_one_launch_vs_oracle(gpu, pos0, qt):
         assert ctx.query("fallback") == 0
         if ctx.query("fuse_tail"):
             assert bool(ctx.query("gr_active")) == bool(ctx.query("gr_edges")), opts      # (the granule form is what the one-launch token ran, unless switched off)
+            if pos0 < 128: assert (ctx.query("preq_active"), ctx.query("pre13_active")) == ((12, 10) if ctx.query("gr_edges") else (16, 16)), opts   # (plan_layer's by-launch early sets are what ran)
     ctx.close()
 
 
@@ -421,6 +422,7 @@ def test_one_launch_token_with_split_heads_deep_in_the_context_vs_oracle(gpu, sh
         assert bits_equal(ctx.debug_read("logits", 0, cfg.vocab_size), last), opts
         assert ctx.query("fallback") == 0
         assert bool(ctx.query("gr_active") & 2) == bool(ctx.query("gr_edges")), opts      # (bit 1: the split heads' one-launch token ran, on granules)
+        if shape == "7B": assert (ctx.query("preq_active_split"), ctx.query("pre13_active_split")) == ((12, 16) if ctx.query("gr_edges") else (16, 16)), opts   # (plan_layer's by-launch early sets are what ran)
         if not ctx.query("attn_kpre"): assert ctx.query("kpre_active") == 0
         elif shape == "7B" and ctx.query("gr_edges"): assert ctx.query("kpre_active") > 0, opts      # (the pre-landed tiles are what ran)
     ctx.close()
