@@ -1,2 +1,2 @@
-O=gpurun_out/s38; mkdir -p $O
-(timeout 1200 python -m pytest tests/test_gpu_model.py -m gpu -q -x -k "deep_in_the_context or one_launch or option_and_query" > $O/t.log 2>&1); tail -12 $O/t.log
+O=gpurun_out/s39; mkdir -p $O
+for pos in 40 70 100 130; do echo "== pos $pos" >> $O/split_from.log; timeout 300 python tools/back_bench.py 32 $pos int8 "tuning=1;attn_split=4;attn_split=1;attn_split=4;attn_split=1" 2>&1 | tail -5 >> $O/split_from.log; done; cat $O/split_from.log
