@@ -574,24 +574,28 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
     stamp(2);
     if (park_early && wave != 0) park_v();
     if (tid == 0) {                                                // sum += x[i], i ascending (tf_operators.cpp:180-183)
-        // a lone lane: the loop is the T dependent adds plus one LDS read per four of them, reads 28 adds ahead
+        // a lone lane: the T dependent adds, the operands through two groups of four 16-byte registers filled by INLINE-ASSEMBLY LDS reads with ONE s_waitcnt per 16 elements -- the
+        // compiler's own reads get a wait in front of every register's first use (6 instructions per 4 elements; here 21 per 16), and a lone wave issues an instruction every ~8 clocks
+        // whatever its kind (tools/ubench/sumchain.hip: T = 301 / 517 / 901 1.76 / 2.93 / 4.94 -> 1.44 / 2.34 / 3.87 us; 64 lanes with a DPP add per step: 1.93 / 3.39 / 5.57 -- the
+        // s_nop the hazard between two dependent DPP operations needs is an instruction like any other)
         float sum = 0.f;
         int t = 0;
+#define FLM_RD4(a0, a1, a2, a3, addr) asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48" : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3) : "v"(addr) : "memory");
+#define FLM_WAIT4(a0, a1, a2, a3, n) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) :: "memory");
 #define FLM_ADD4(q) sum = __fadd_rn(sum, q.x); sum = __fadd_rn(sum, q.y); sum = __fadd_rn(sum, q.z); sum = __fadd_rn(sum, q.w);
-#define FLM_ASTEP(q, off) FLM_ADD4(q) q = *reinterpret_cast<const float4*>(pp + (off)); __builtin_amdgcn_sched_barrier(0);
         if (T >= 32) {
-            const float* pp = sc;
-            float4 q0 = *reinterpret_cast<const float4*>(pp), q1 = *reinterpret_cast<const float4*>(pp + 4), q2 = *reinterpret_cast<const float4*>(pp + 8), q3 = *reinterpret_cast<const float4*>(pp + 12);
-            float4 q4 = *reinterpret_cast<const float4*>(pp + 16), q5 = *reinterpret_cast<const float4*>(pp + 20), q6 = *reinterpret_cast<const float4*>(pp + 24), q7 = *reinterpret_cast<const float4*>(pp + 28);
-            __builtin_amdgcn_sched_barrier(0);
-            for (; t + 32 <= T; t += 32, pp += 32) {
-                FLM_ASTEP(q0, 32) FLM_ASTEP(q1, 36) FLM_ASTEP(q2, 40) FLM_ASTEP(q3, 44)
-                FLM_ASTEP(q4, 48) FLM_ASTEP(q5, 52) FLM_ASTEP(q6, 56) FLM_ASTEP(q7, 60)
+            unsigned ad = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)sc;
+            v4f q0, q1, q2, q3, q4, q5, q6, q7;
+            FLM_RD4(q0, q1, q2, q3, ad) { const unsigned a2 = ad + 64; FLM_RD4(q4, q5, q6, q7, a2) }
+            for (; t + 32 <= T; t += 32) {                      // (reads run up to 63 elements past the last full block: sc's slack)
+                ad += 128;
+                FLM_WAIT4(q0, q1, q2, q3, 4) FLM_ADD4(q0) FLM_ADD4(q1) FLM_ADD4(q2) FLM_ADD4(q3) FLM_RD4(q0, q1, q2, q3, ad)
+                { const unsigned a2 = ad + 64; FLM_WAIT4(q4, q5, q6, q7, 4) FLM_ADD4(q4) FLM_ADD4(q5) FLM_ADD4(q6) FLM_ADD4(q7) FLM_RD4(q4, q5, q6, q7, a2) }
             }
+            FLM_WAIT4(q0, q1, q2, q3, 0) FLM_WAIT4(q4, q5, q6, q7, 0)
             if (t + 4 <= T) { FLM_ADD4(q0) t += 4; } if (t + 4 <= T) { FLM_ADD4(q1) t += 4; } if (t + 4 <= T) { FLM_ADD4(q2) t += 4; } if (t + 4 <= T) { FLM_ADD4(q3) t += 4; }
             if (t + 4 <= T) { FLM_ADD4(q4) t += 4; } if (t + 4 <= T) { FLM_ADD4(q5) t += 4; } if (t + 4 <= T) { FLM_ADD4(q6) t += 4; }
         }
-#undef FLM_ASTEP
 #undef FLM_ADD4
         for (; t < T; ++t) sum = __fadd_rn(sum, sc[t]);
         red[16] = sum;
@@ -638,18 +642,27 @@ __device__ __forceinline__ void attn_head(const AttnArgs& a, const int h, char* 
             int p = 1;
             if (red[20] != 0.f) {
                 for (; p < T && (p & 3); ++p) o = __fmaf_rn(vp[p], wp[p], o);
+                // (operands as in the sum chain above: two groups of 16 positions -- four 16-byte registers of V, four of weights -- by inline-assembly LDS reads, one s_waitcnt per group)
 #define FLM_PV4(vv, ww) o = __fmaf_rn(vv.x, ww.x, o); o = __fmaf_rn(vv.y, ww.y, o); o = __fmaf_rn(vv.z, ww.z, o); o = __fmaf_rn(vv.w, ww.w, o);
-#define FLM_PVSTEP(vv, ww, off) FLM_PV4(vv, ww) vv = *reinterpret_cast<const float4*>(vp + p + (off)); ww = *reinterpret_cast<const float4*>(wp + p + (off)); __builtin_amdgcn_sched_barrier(0);
-                if (p + 16 <= T) {
-                    float4 v0 = *reinterpret_cast<const float4*>(vp + p), v1 = *reinterpret_cast<const float4*>(vp + p + 4), v2 = *reinterpret_cast<const float4*>(vp + p + 8), v3 = *reinterpret_cast<const float4*>(vp + p + 12);
-                    float4 w0 = *reinterpret_cast<const float4*>(wp + p), w1 = *reinterpret_cast<const float4*>(wp + p + 4), w2 = *reinterpret_cast<const float4*>(wp + p + 8), w3 = *reinterpret_cast<const float4*>(wp + p + 12);
-                    __builtin_amdgcn_sched_barrier(0);
-                    for (; p + 32 <= T; p += 16) { FLM_PVSTEP(v0, w0, 16) FLM_PVSTEP(v1, w1, 20) FLM_PVSTEP(v2, w2, 24) FLM_PVSTEP(v3, w3, 28) }
-                    FLM_PV4(v0, w0) FLM_PV4(v1, w1) FLM_PV4(v2, w2) FLM_PV4(v3, w3)
-                    p += 16;
+#define FLM_WAIT8(a0, a1, a2, a3, b0, b1, b2, b3, n) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) :: "memory");
+                if (p + 32 <= T) {
+                    unsigned av = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)vp + (unsigned)p * 4u, aw = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)wp + (unsigned)p * 4u;
+                    v4f v0, v1, v2, v3, w0, w1, w2, w3, v4, v5, v6, v7, w4, w5, w6, w7;
+                    FLM_RD4(v0, v1, v2, v3, av) FLM_RD4(w0, w1, w2, w3, aw)
+                    { const unsigned av2 = av + 64, aw2 = aw + 64; FLM_RD4(v4, v5, v6, v7, av2) FLM_RD4(w4, w5, w6, w7, aw2) }
+                    for (; p + 32 <= T; p += 32) {                  // (reads run up to 63 positions past the last full block: the row's / sc's slack, inside the LDS)
+                        av += 128; aw += 128;
+                        FLM_WAIT8(v0, v1, v2, v3, w0, w1, w2, w3, 8) FLM_PV4(v0, w0) FLM_PV4(v1, w1) FLM_PV4(v2, w2) FLM_PV4(v3, w3) FLM_RD4(v0, v1, v2, v3, av) FLM_RD4(w0, w1, w2, w3, aw)
+                        { const unsigned av2 = av + 64, aw2 = aw + 64; FLM_WAIT8(v4, v5, v6, v7, w4, w5, w6, w7, 8) FLM_PV4(v4, w4) FLM_PV4(v5, w5) FLM_PV4(v6, w6) FLM_PV4(v7, w7) FLM_RD4(v4, v5, v6, v7, av2) FLM_RD4(w4, w5, w6, w7, aw2) }
+                    }
+                    FLM_WAIT8(v0, v1, v2, v3, w0, w1, w2, w3, 0) FLM_WAIT8(v4, v5, v6, v7, w4, w5, w6, w7, 0)
+                    if (p + 4 <= T) { FLM_PV4(v0, w0) p += 4; } if (p + 4 <= T) { FLM_PV4(v1, w1) p += 4; } if (p + 4 <= T) { FLM_PV4(v2, w2) p += 4; } if (p + 4 <= T) { FLM_PV4(v3, w3) p += 4; }
+                    if (p + 4 <= T) { FLM_PV4(v4, w4) p += 4; } if (p + 4 <= T) { FLM_PV4(v5, w5) p += 4; } if (p + 4 <= T) { FLM_PV4(v6, w6) p += 4; }
                 }
-#undef FLM_PVSTEP
+#undef FLM_WAIT8
 #undef FLM_PV4
+#undef FLM_RD4
+#undef FLM_WAIT4
                 for (; p < T; ++p) o = __fmaf_rn(vp[p], wp[p], o);
             } else {
                 for (; p < T; ++p) { const float w = wp[p]; o = w == 0.f ? o : __fmaf_rn(vp[p], w, o); }
